@@ -1,0 +1,331 @@
+/*
+ * btc_oracle.c -- CPU ORACLE (TEST INFRASTRUCTURE ONLY, never shipped, never benchmarked as
+ * the product).  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it.
+ *
+ * Plain-C restatement of the spconv-side arithmetic of BtcDet's hot path.
+ *
+ * PARITY STATUS: *** parity unpinned ***  The algorithms restated here live in the third-party
+ * dependency spconv v1.2.1 (commit fad3000249d27ca918f2655ff73c41f39b0f3127), pinned by the
+ * reference only in prose (/root/reference/README.md:42, setup.py:41).  Its source is absent from
+ * /root/reference, not installed, and the reference has no tests or golden vectors at this boundary
+ * (SURVEY.md §4, §8c).  What is restated is spconv's published algorithm as SURVEY.md App. B
+ * records it; what anchors it are (i) the reference's call sites cited per function and (ii)
+ * dense-equivalence tests against torch.nn.functional.conv3d / conv_transpose3d / max_pool3d
+ * (tests/test_oracle_dense_equiv.py).
+ *
+ * Conventions
+ *   indices        (N,4) int32 rows [b,z,y,x]                     (spconv_backbone.py:150,952)
+ *   kernel offset  k = (kz*KH + ky)*KW + kx, weight viewed as W[K][Cin][Cout]
+ *                  (weight parameter layout [kD,kH,kW,Cin,Cout])
+ *   orientation    PyTorch cross-correlation: in = out*s - p + k*d (conv), out = in*s - p + k*d (transpose)
+ *   neighbour maps nbr_out (n_out,K): input row feeding output row i at offset k, or -1
+ *                  nbr_in  (n_in ,K): output row fed by input row j at offset k, or -1
+ *   canonical order: output rows ascending in (b,z,y,x) for conv/transpose/pool, input order for SubM
+ *                  (SURVEY.md App. B.4).
+ *
+ * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off -shared -fPIC).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------------------------------ */
+/* Voxelizer: spconv.utils.VoxelGeneratorV2.generate -> points_to_voxel_3d_np */
+/* call sites: /root/reference/btcdet/datasets/processor/data_processor.py:63-73,107-117,136,   */
+/*             160-170,177.                                                                    */
+/* Sequential first-come semantics: voxel order = order of first appearance, within-voxel      */
+/* order = input order, points beyond max_points and voxels beyond max_voxels are dropped,      */
+/* padding is 0.  coords are written zyx.  Division and floor are float32.                      */
+/* scratch: coor_to_voxelidx, grid[2]*grid[1]*grid[0] int32, must be all -1 on entry and is     */
+/* restored to all -1 on exit.  Returns the number of voxels.                                  */
+/* ------------------------------------------------------------------------------------------ */
+int orc_voxelize(const float* pts, int n, int ld, int C, const float* range, const float* vsize,
+                 const int* grid /* x,y,z */, int max_pts, int max_vox, float* voxels /* max_vox*max_pts*C, pre-zeroed */,
+                 int* coords /* max_vox*3 zyx */, int* num /* max_vox, pre-zeroed */, int* scratch) {
+  int voxel_num = 0;
+  for (int i = 0; i < n; ++i) {
+    const float* p = pts + (size_t)i * ld;
+    int c[3];
+    int failed = 0;
+    for (int j = 0; j < 3; ++j) {
+      float q = (p[j] - range[j]) / vsize[j];
+      int cj = (int)floorf(q);
+      if (cj < 0 || cj >= grid[j]) { failed = 1; break; }
+      c[j] = cj;
+    }
+    if (failed) continue;
+    size_t lin = ((size_t)c[2] * grid[1] + c[1]) * grid[0] + c[0];
+    int vid = scratch[lin];
+    if (vid == -1) {
+      if (voxel_num >= max_vox) continue;
+      vid = voxel_num++;
+      scratch[lin] = vid;
+      coords[vid * 3 + 0] = c[2];
+      coords[vid * 3 + 1] = c[1];
+      coords[vid * 3 + 2] = c[0];
+    }
+    int m = num[vid];
+    if (m < max_pts) {
+      memcpy(voxels + ((size_t)vid * max_pts + m) * C, p, sizeof(float) * C);
+      num[vid] = m + 1;
+    }
+  }
+  for (int v = 0; v < voxel_num; ++v) {
+    size_t lin = ((size_t)coords[v * 3] * grid[1] + coords[v * 3 + 1]) * grid[0] + coords[v * 3 + 2];
+    scratch[lin] = -1;
+  }
+  return voxel_num;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* Rulebook: spconv ops.get_indice_pairs; call sites are every sparse    */
+/* layer of /root/reference/btcdet/models/backbones_3d/spconv_backbone.py:106-128,656-700,      */
+/* 732-767,831-847 and occ_head_3D.py:25-31.                                                   */
+/* mode 0 = SubM, 1 = regular conv / max-pool geometry, 2 = transposed conv.                   */
+/* ------------------------------------------------------------------------------------------ */
+static int cmp_i64(const void* a, const void* b) {
+  int64_t x = *(const int64_t*)a, y = *(const int64_t*)b;
+  return (x > y) - (x < y);
+}
+
+void orc_out_shape(const int* in_shape, const int* k, const int* s, const int* p, const int* d,
+                   const int* outpad, int mode, int* out_shape) {
+  for (int j = 0; j < 3; ++j) {
+    if (mode == 0) out_shape[j] = in_shape[j];
+    else if (mode == 1) out_shape[j] = (in_shape[j] + 2 * p[j] - d[j] * (k[j] - 1) - 1) / s[j] + 1;
+    else out_shape[j] = (in_shape[j] - 1) * s[j] - 2 * p[j] + k[j] + outpad[j];
+  }
+}
+
+/* returns n_out; out_indices capacity must be >= n*K rows (worst case), nbr_out >= n*K*K ints is
+ * never needed: n_out <= n*K, caller passes cap_out rows for out_indices / nbr_out. */
+int orc_rulebook(const int* indices, int n, const int* in_shape, const int* out_shape, const int* k,
+                 const int* s, const int* p, const int* d, int mode, int cap_out, int* out_indices,
+                 int* nbr_out, int* nbr_in) {
+  const int K = k[0] * k[1] * k[2];
+  const int64_t ovol = (int64_t)out_shape[0] * out_shape[1] * out_shape[2];
+  for (size_t t = 0; t < (size_t)n * K; ++t) nbr_in[t] = -1;
+
+  if (mode == 0) {
+    /* SubM: outputs = inputs in input order; pair iff indices[j] == indices[i] + (off - centre)*d */
+    if (n > cap_out) return -1;
+    int64_t* keys = (int64_t*)malloc(sizeof(int64_t) * 2 * (size_t)(n > 0 ? n : 1));
+    for (int i = 0; i < n; ++i) {
+      const int* c = indices + 4 * i;
+      keys[2 * i] = (((int64_t)c[0] * in_shape[0] + c[1]) * in_shape[1] + c[2]) * in_shape[2] + c[3];
+      keys[2 * i + 1] = i;
+      memcpy(out_indices + 4 * i, c, 4 * sizeof(int));
+    }
+    qsort(keys, n, 2 * sizeof(int64_t), cmp_i64);
+    for (size_t t = 0; t < (size_t)n * K; ++t) nbr_out[t] = -1;
+    for (int i = 0; i < n; ++i) {
+      const int* c = indices + 4 * i;
+      for (int kz = 0; kz < k[0]; ++kz)
+        for (int ky = 0; ky < k[1]; ++ky)
+          for (int kx = 0; kx < k[2]; ++kx) {
+            int kk = (kz * k[1] + ky) * k[2] + kx;
+            int z = c[1] + (kz - k[0] / 2) * d[0];
+            int y = c[2] + (ky - k[1] / 2) * d[1];
+            int x = c[3] + (kx - k[2] / 2) * d[2];
+            if (z < 0 || z >= in_shape[0] || y < 0 || y >= in_shape[1] || x < 0 || x >= in_shape[2]) continue;
+            int64_t key = (((int64_t)c[0] * in_shape[0] + z) * in_shape[1] + y) * in_shape[2] + x;
+            int lo = 0, hi = n;
+            while (lo < hi) { int mid = (lo + hi) / 2; if (keys[2 * mid] < key) lo = mid + 1; else hi = mid; }
+            if (lo < n && keys[2 * lo] == key) {
+              int j = (int)keys[2 * lo + 1];
+              nbr_out[(size_t)i * K + kk] = j;   /* output i gathers input j at offset kk   */
+              nbr_in[(size_t)j * K + kk] = i;    /* input j scatters to output i at offset kk */
+            }
+          }
+    }
+    free(keys);
+    return n;
+  }
+
+  /* regular / transposed: enumerate candidate outputs, sort-unique */
+  int64_t* cand = (int64_t*)malloc(sizeof(int64_t) * (size_t)(n > 0 ? n : 1) * K);
+  size_t nc = 0;
+  for (int i = 0; i < n; ++i) {
+    const int* c = indices + 4 * i;
+    for (int kz = 0; kz < k[0]; ++kz)
+      for (int ky = 0; ky < k[1]; ++ky)
+        for (int kx = 0; kx < k[2]; ++kx) {
+          int kv[3] = {kz, ky, kx};
+          int o[3];
+          int ok = 1;
+          for (int j = 0; j < 3; ++j) {
+            if (mode == 1) {
+              int t = c[1 + j] + p[j] - kv[j] * d[j];
+              if (t < 0 || t % s[j] != 0) { ok = 0; break; }
+              o[j] = t / s[j];
+            } else {
+              o[j] = c[1 + j] * s[j] - p[j] + kv[j] * d[j];
+            }
+            if (o[j] < 0 || o[j] >= out_shape[j]) { ok = 0; break; }
+          }
+          if (!ok) continue;
+          cand[nc++] = (int64_t)c[0] * ovol + ((int64_t)o[0] * out_shape[1] + o[1]) * out_shape[2] + o[2];
+        }
+  }
+  int64_t* uniq = (int64_t*)malloc(sizeof(int64_t) * (nc > 0 ? nc : 1));
+  memcpy(uniq, cand, sizeof(int64_t) * nc);
+  qsort(uniq, nc, sizeof(int64_t), cmp_i64);
+  int n_out = 0;
+  for (size_t t = 0; t < nc; ++t)
+    if (t == 0 || uniq[t] != uniq[t - 1]) uniq[n_out++] = uniq[t];
+  if (n_out > cap_out) { free(cand); free(uniq); return -1; }
+  for (int r = 0; r < n_out; ++r) {
+    int64_t key = uniq[r];
+    int b = (int)(key / ovol);
+    int64_t rem = key % ovol;
+    out_indices[4 * r + 0] = b;
+    out_indices[4 * r + 1] = (int)(rem / ((int64_t)out_shape[1] * out_shape[2]));
+    out_indices[4 * r + 2] = (int)((rem / out_shape[2]) % out_shape[1]);
+    out_indices[4 * r + 3] = (int)(rem % out_shape[2]);
+  }
+  for (size_t t = 0; t < (size_t)n_out * K; ++t) nbr_out[t] = -1;
+  /* second pass: fill maps */
+  for (int i = 0; i < n; ++i) {
+    const int* c = indices + 4 * i;
+    for (int kz = 0; kz < k[0]; ++kz)
+      for (int ky = 0; ky < k[1]; ++ky)
+        for (int kx = 0; kx < k[2]; ++kx) {
+          int kv[3] = {kz, ky, kx};
+          int kk = (kz * k[1] + ky) * k[2] + kx;
+          int o[3];
+          int ok = 1;
+          for (int j = 0; j < 3; ++j) {
+            if (mode == 1) {
+              int t = c[1 + j] + p[j] - kv[j] * d[j];
+              if (t < 0 || t % s[j] != 0) { ok = 0; break; }
+              o[j] = t / s[j];
+            } else {
+              o[j] = c[1 + j] * s[j] - p[j] + kv[j] * d[j];
+            }
+            if (o[j] < 0 || o[j] >= out_shape[j]) { ok = 0; break; }
+          }
+          if (!ok) continue;
+          int64_t key = (int64_t)c[0] * ovol + ((int64_t)o[0] * out_shape[1] + o[1]) * out_shape[2] + o[2];
+          int lo = 0, hi = n_out;
+          while (lo < hi) { int mid = (lo + hi) / 2; if (uniq[mid] < key) lo = mid + 1; else hi = mid; }
+          nbr_out[(size_t)lo * K + kk] = i;
+          nbr_in[(size_t)i * K + kk] = lo;
+        }
+  }
+  free(cand);
+  free(uniq);
+  return n_out;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* Sparse conv apply (spconv indice_conv / indice_subm_conv / indice_inverse_conv, SURVEY §3.4, */
+/* App. B.6).  Output-stationary restatement with a FIXED summation order: for each output row, */
+/* offsets k ascending, input channels ascending, one fused multiply-add per term starting from */
+/* 0, bias added last.  (spconv's scatter-add order is unspecified; any order is within fp32     */
+/* roundoff of this one.)                                                                      */
+/* ------------------------------------------------------------------------------------------ */
+void orc_conv_fwd(const float* feat, const float* W, const float* bias, const int* nbr_out, int n_out,
+                  int K, int Cin, int Cout, float* out) {
+  for (int i = 0; i < n_out; ++i) {
+    float* o = out + (size_t)i * Cout;
+    for (int co = 0; co < Cout; ++co) o[co] = 0.0f;
+    for (int k = 0; k < K; ++k) {
+      int j = nbr_out[(size_t)i * K + k];
+      if (j < 0) continue;
+      const float* f = feat + (size_t)j * Cin;
+      const float* w = W + (size_t)k * Cin * Cout;
+      for (int ci = 0; ci < Cin; ++ci) {
+        float a = f[ci];
+        for (int co = 0; co < Cout; ++co) o[co] = fmaf(a, w[(size_t)ci * Cout + co], o[co]);
+      }
+    }
+    if (bias) for (int co = 0; co < Cout; ++co) o[co] += bias[co];
+  }
+}
+
+/* dgrad: dIn[j] = sum_k dOut[nbr_in[j][k]] @ W[k]^T  (k ascending, co ascending, fmaf chain) */
+void orc_conv_dgrad(const float* dout, const float* W, const int* nbr_in, int n_in, int K, int Cin,
+                    int Cout, float* din) {
+  for (int j = 0; j < n_in; ++j) {
+    float* g = din + (size_t)j * Cin;
+    for (int ci = 0; ci < Cin; ++ci) g[ci] = 0.0f;
+    for (int k = 0; k < K; ++k) {
+      int i = nbr_in[(size_t)j * K + k];
+      if (i < 0) continue;
+      const float* dy = dout + (size_t)i * Cout;
+      const float* w = W + (size_t)k * Cin * Cout;
+      for (int co = 0; co < Cout; ++co) {
+        float a = dy[co];
+        for (int ci = 0; ci < Cin; ++ci) g[ci] = fmaf(a, w[(size_t)ci * Cout + co], g[ci]);
+      }
+    }
+  }
+}
+
+/* wgrad: dW[k][ci][co] = sum_i feat[nbr_out[i][k]][ci] * dOut[i][co], accumulated in double  */
+void orc_conv_wgrad(const float* feat, const float* dout, const int* nbr_out, int n_out, int K, int Cin,
+                    int Cout, float* dW) {
+  double* acc = (double*)calloc((size_t)K * Cin * Cout, sizeof(double));
+  for (int i = 0; i < n_out; ++i) {
+    const float* dy = dout + (size_t)i * Cout;
+    for (int k = 0; k < K; ++k) {
+      int j = nbr_out[(size_t)i * K + k];
+      if (j < 0) continue;
+      const float* f = feat + (size_t)j * Cin;
+      double* a = acc + (size_t)k * Cin * Cout;
+      for (int ci = 0; ci < Cin; ++ci)
+        for (int co = 0; co < Cout; ++co) a[(size_t)ci * Cout + co] += (double)f[ci] * (double)dy[co];
+    }
+  }
+  for (size_t t = 0; t < (size_t)K * Cin * Cout; ++t) dW[t] = (float)acc[t];
+  free(acc);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* Sparse max-pool (spconv indice_maxpool): out starts at 0, out = max(out,in) */
+/* over pairs; backward routes dOut to every input equal to the output.                        */
+/* call site: spconv_backbone.py:29,831-847.                                                   */
+/* ------------------------------------------------------------------------------------------ */
+void orc_maxpool_fwd(const float* feat, const int* nbr_out, int n_out, int K, int C, float* out) {
+  for (int i = 0; i < n_out; ++i)
+    for (int c = 0; c < C; ++c) {
+      float m = 0.0f;
+      for (int k = 0; k < K; ++k) {
+        int j = nbr_out[(size_t)i * K + k];
+        if (j < 0) continue;
+        float v = feat[(size_t)j * C + c];
+        if (v > m) m = v;
+      }
+      out[(size_t)i * C + c] = m;
+    }
+}
+
+void orc_maxpool_bwd(const float* feat, const float* out, const float* dout, const int* nbr_in, int n_in,
+                     int K, int C, float* din) {
+  for (int j = 0; j < n_in; ++j)
+    for (int c = 0; c < C; ++c) {
+      float g = 0.0f;
+      float v = feat[(size_t)j * C + c];
+      for (int k = 0; k < K; ++k) {
+        int i = nbr_in[(size_t)j * K + k];
+        if (i < 0) continue;
+        if (out[(size_t)i * C + c] == v) g += dout[(size_t)i * C + c];
+      }
+      din[(size_t)j * C + c] = g;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* SparseConvTensor.dense(): scatter rows into zeros[B,C,D,H,W]               */
+/* call sites: height_compression.py:21, occ_head_3D.py:46,51, spconv_backbone.py:890,930.      */
+/* ------------------------------------------------------------------------------------------ */
+void orc_dense(const float* feat, const int* indices, int n, int C, int B, const int* shape, float* out) {
+  size_t vol = (size_t)shape[0] * shape[1] * shape[2];
+  memset(out, 0, sizeof(float) * (size_t)B * C * vol);
+  for (int i = 0; i < n; ++i) {
+    const int* c = indices + 4 * i;
+    size_t sp = ((size_t)c[1] * shape[1] + c[2]) * shape[2] + c[3];
+    for (int ch = 0; ch < C; ++ch) out[((size_t)c[0] * C + ch) * vol + sp] = feat[(size_t)i * C + ch];
+  }
+}

@@ -1,0 +1,222 @@
+"""CPU ORACLE -- TEST INFRASTRUCTURE ONLY.
+
+ctypes/numpy front-end of ``oracle/btc_oracle.c`` plus numpy restatements of the reference's numpy
+pre-steps.  Nothing under ``btcdet_amd/`` may import this module; only ``tests/``,
+``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg do, and only as the checker.
+
+PARITY STATUS of the spconv-side functions (voxelizer, rulebook, sparse conv, max-pool, dense):
+**parity unpinned** -- see the header of ``btc_oracle.c``.  The numpy pre-steps and the occupancy
+generator restatement (``oracle/occ_oracle.py``) are pinned against golden vectors generated from the
+importable reference (``tests/golden/``).
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+_i32p = ctypes.POINTER(ctypes.c_int32)
+_f32p = ctypes.POINTER(ctypes.c_float)
+
+
+def build(force=False):
+    """Compile liboracle with gcc (oracle/Makefile)."""
+    so = os.path.join(_HERE, "libbtc_oracle.so")
+    src = os.path.join(_HERE, "btc_oracle.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "-B"])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        so = os.path.join(_HERE, "libbtc_oracle.so")
+        if not os.path.exists(so):
+            build()
+        _LIB = ctypes.CDLL(so)
+    return _LIB
+
+
+def _ip(a):
+    return a.ctypes.data_as(_i32p)
+
+
+def _fp(a):
+    return a.ctypes.data_as(_f32p)
+
+
+def _i3(v):
+    if np.isscalar(v):
+        v = [v, v, v]
+    a = np.ascontiguousarray(np.asarray(v, dtype=np.int32).reshape(-1))
+    assert a.size == 3
+    return a
+
+
+# ------------------------------------------------------------------ numpy pre-steps (reference, in tree)
+def mask_points_by_range(points, limit_range):
+    """/root/reference/btcdet/utils/common_utils.py:59-62 -- x,y only (z is NOT tested)."""
+    return (points[:, 0] >= limit_range[0]) & (points[:, 0] <= limit_range[3]) \
+        & (points[:, 1] >= limit_range[1]) & (points[:, 1] <= limit_range[4])
+
+
+def absxyz_2_cylinxyz_np(points):
+    """/root/reference/btcdet/utils/coords_utils.py:282-292 (rho, atan2(-y,x) in degrees, z, extras)."""
+    x, y, z = points[:, 0], points[:, 1], points[:, 2]
+    xydist = np.linalg.norm(points[:, :2], axis=1)
+    cylin_y = np.arctan2(-y, x) * 180. / np.pi
+    xyz = np.stack([xydist, cylin_y, z], axis=-1)
+    if points.shape[1] > 3:
+        return np.concatenate([xyz, points[:, 3:]], axis=-1)
+    return xyz
+
+
+def absxyz_2_spherexyz_np(points):
+    """/root/reference/btcdet/utils/coords_utils.py:268-279."""
+    x, y, z = points[:, 0], points[:, 1], points[:, 2]
+    dist = np.linalg.norm(points[:, :3], axis=1)
+    xydist = np.linalg.norm(points[:, :2], axis=1)
+    sphere = np.stack([dist, np.arctan2(-y, x) * 180. / np.pi, np.arctan2(z, xydist) * 180. / np.pi], axis=-1)
+    if points.shape[1] > 3:
+        return np.concatenate([sphere, points[:, 3:]], axis=-1)
+    return sphere
+
+
+# ------------------------------------------------------------------ voxelizer
+class VoxelGeneratorV2:
+    """Restatement of spconv.utils.VoxelGeneratorV2 as constructed at
+    /root/reference/btcdet/datasets/processor/data_processor.py:68-73,112-117,165-170."""
+
+    def __init__(self, voxel_size, point_cloud_range, max_num_points, max_voxels):
+        self.point_cloud_range = np.array(point_cloud_range, dtype=np.float32)
+        self.voxel_size = np.array(voxel_size, dtype=np.float32)
+        grid = (self.point_cloud_range[3:] - self.point_cloud_range[:3]) / self.voxel_size
+        self.grid_size = np.round(grid).astype(np.int64)
+        self.max_num_points = int(max_num_points)
+        self.max_voxels = int(max_voxels)
+        self._scratch = np.full(int(np.prod(self.grid_size)), -1, dtype=np.int32)
+
+    def generate(self, points, max_voxels=None):
+        points = np.ascontiguousarray(points, dtype=np.float32)
+        n, c = points.shape
+        mv = int(max_voxels or self.max_voxels)
+        voxels = np.zeros((mv, self.max_num_points, c), dtype=np.float32)
+        coords = np.zeros((mv, 3), dtype=np.int32)
+        num = np.zeros((mv,), dtype=np.int32)
+        grid = np.ascontiguousarray(self.grid_size.astype(np.int32))
+        m = lib().orc_voxelize(_fp(points), n, c, c, _fp(self.point_cloud_range), _fp(self.voxel_size),
+                               _ip(grid), self.max_num_points, mv, _fp(voxels), _ip(coords), _ip(num),
+                               _ip(self._scratch))
+        return {"voxels": voxels[:m], "coordinates": coords[:m], "num_points_per_voxel": num[:m],
+                "voxel_num": m}
+
+
+# ------------------------------------------------------------------ rulebook
+MODE_SUBM, MODE_CONV, MODE_TRANSPOSE = 0, 1, 2
+
+
+def out_shape(in_shape, k, s, p, d, mode, outpad=0):
+    o = np.zeros(3, dtype=np.int32)
+    lib().orc_out_shape(_ip(_i3(in_shape)), _ip(_i3(k)), _ip(_i3(s)), _ip(_i3(p)), _ip(_i3(d)),
+                        _ip(_i3(outpad)), int(mode), _ip(o))
+    return o
+
+
+def rulebook(indices, in_shape, k, s=1, p=0, d=1, mode=MODE_CONV, outpad=0):
+    """-> (out_indices (n_out,4), nbr_out (n_out,K), nbr_in (n_in,K), out_shape)."""
+    indices = np.ascontiguousarray(indices, dtype=np.int32).reshape(-1, 4)
+    n = indices.shape[0]
+    k3, s3, p3, d3 = _i3(k), _i3(s), _i3(p), _i3(d)
+    K = int(np.prod(k3))
+    osh = out_shape(in_shape, k3, s3, p3, d3, mode, outpad)
+    cap = max(n * K, 1) if mode != MODE_SUBM else max(n, 1)
+    out_idx = np.zeros((cap, 4), dtype=np.int32)
+    nbr_out = np.empty((cap, K), dtype=np.int32)
+    nbr_in = np.empty((max(n, 1), K), dtype=np.int32)
+    n_out = lib().orc_rulebook(_ip(indices), n, _ip(_i3(in_shape)), _ip(osh), _ip(k3), _ip(s3), _ip(p3),
+                               _ip(d3), int(mode), cap, _ip(out_idx), _ip(nbr_out), _ip(nbr_in))
+    assert n_out >= 0
+    return out_idx[:n_out].copy(), nbr_out[:n_out].copy(), nbr_in[:n].copy(), osh
+
+
+def canonical_pairs(nbr_out):
+    """Canonical rulebook of SURVEY.md App. B.4: per offset k the (in_row, out_row) pairs sorted by
+    out_row then in_row.  Returns (pairs list per k, pair_num (K,))."""
+    K = nbr_out.shape[1]
+    pairs, nums = [], np.zeros(K, dtype=np.int32)
+    for k in range(K):
+        o = np.nonzero(nbr_out[:, k] >= 0)[0]
+        pairs.append(np.stack([nbr_out[o, k], o.astype(np.int32)], axis=0))
+        nums[k] = o.size
+    return pairs, nums
+
+
+# ------------------------------------------------------------------ apply
+def conv_fwd(feat, W, bias, nbr_out):
+    feat = np.ascontiguousarray(feat, dtype=np.float32)
+    W = np.ascontiguousarray(W, dtype=np.float32)
+    K = nbr_out.shape[1]
+    cin, cout = W.shape[-2], W.shape[-1]
+    assert W.size == K * cin * cout
+    n_out = nbr_out.shape[0]
+    out = np.empty((n_out, cout), dtype=np.float32)
+    nbr_out = np.ascontiguousarray(nbr_out, dtype=np.int32)
+    b = None if bias is None else np.ascontiguousarray(bias, dtype=np.float32)
+    lib().orc_conv_fwd(_fp(feat), _fp(W), _fp(b) if b is not None else None, _ip(nbr_out), n_out, K, cin,
+                       cout, _fp(out))
+    return out
+
+
+def conv_dgrad(dout, W, nbr_in):
+    dout = np.ascontiguousarray(dout, dtype=np.float32)
+    W = np.ascontiguousarray(W, dtype=np.float32)
+    K = nbr_in.shape[1]
+    cin, cout = W.shape[-2], W.shape[-1]
+    n_in = nbr_in.shape[0]
+    din = np.empty((n_in, cin), dtype=np.float32)
+    nbr_in = np.ascontiguousarray(nbr_in, dtype=np.int32)
+    lib().orc_conv_dgrad(_fp(dout), _fp(W), _ip(nbr_in), n_in, K, cin, cout, _fp(din))
+    return din
+
+
+def conv_wgrad(feat, dout, nbr_out, wshape):
+    feat = np.ascontiguousarray(feat, dtype=np.float32)
+    dout = np.ascontiguousarray(dout, dtype=np.float32)
+    K = nbr_out.shape[1]
+    cin, cout = feat.shape[1], dout.shape[1]
+    dW = np.empty((K, cin, cout), dtype=np.float32)
+    nbr_out = np.ascontiguousarray(nbr_out, dtype=np.int32)
+    lib().orc_conv_wgrad(_fp(feat), _fp(dout), _ip(nbr_out), nbr_out.shape[0], K, cin, cout, _fp(dW))
+    return dW.reshape(wshape)
+
+
+def maxpool_fwd(feat, nbr_out):
+    feat = np.ascontiguousarray(feat, dtype=np.float32)
+    nbr_out = np.ascontiguousarray(nbr_out, dtype=np.int32)
+    out = np.empty((nbr_out.shape[0], feat.shape[1]), dtype=np.float32)
+    lib().orc_maxpool_fwd(_fp(feat), _ip(nbr_out), nbr_out.shape[0], nbr_out.shape[1], feat.shape[1], _fp(out))
+    return out
+
+
+def maxpool_bwd(feat, out, dout, nbr_in):
+    feat = np.ascontiguousarray(feat, dtype=np.float32)
+    out = np.ascontiguousarray(out, dtype=np.float32)
+    dout = np.ascontiguousarray(dout, dtype=np.float32)
+    nbr_in = np.ascontiguousarray(nbr_in, dtype=np.int32)
+    din = np.empty_like(feat)
+    lib().orc_maxpool_bwd(_fp(feat), _fp(out), _fp(dout), _ip(nbr_in), nbr_in.shape[0], nbr_in.shape[1],
+                          feat.shape[1], _fp(din))
+    return din
+
+
+def dense(feat, indices, batch_size, shape):
+    feat = np.ascontiguousarray(feat, dtype=np.float32)
+    indices = np.ascontiguousarray(indices, dtype=np.int32)
+    sh = _i3(shape)
+    out = np.empty((batch_size, feat.shape[1], int(sh[0]), int(sh[1]), int(sh[2])), dtype=np.float32)
+    lib().orc_dense(_fp(feat), _ip(indices), feat.shape[0], feat.shape[1], batch_size, _ip(sh), _fp(out))
+    return out
