@@ -1,0 +1,82 @@
+// Shared host/device helpers for libbtcdet_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/btcdet_hip.h"
+
+#define BTC_EMPTY_KEY (-1)            // hash key sentinel (memset 0xFF)
+#define BTC_EMPTY_IDX 0x7F7F7F7F      // point-index sentinel (memset 0x7F), larger than any row index
+
+void btc_set_error(const char* fmt, ...);
+
+#define BTC_CHECK_ARG(cond, ...)            \
+  do {                                      \
+    if (!(cond)) {                          \
+      btc_set_error(__VA_ARGS__);           \
+      return BTC_EINVAL;                    \
+    }                                       \
+  } while (0)
+
+#define BTC_HIP(call)                                                             \
+  do {                                                                            \
+    hipError_t e_ = (call);                                                       \
+    if (e_ != hipSuccess) {                                                       \
+      btc_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+      return BTC_ELAUNCH;                                                         \
+    }                                                                             \
+  } while (0)
+
+#define BTC_LAUNCH_CHECK()                                                        \
+  do {                                                                            \
+    hipError_t e_ = hipGetLastError();                                            \
+    if (e_ != hipSuccess) {                                                       \
+      btc_set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(e_), __FILE__, __LINE__); \
+      return BTC_ELAUNCH;                                                         \
+    }                                                                             \
+  } while (0)
+
+static inline int btc_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+static inline size_t btc_align(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+static inline unsigned btc_pow2_ge(unsigned long long v) {
+  unsigned long long p = 1;
+  while (p < v) p <<= 1;
+  return (unsigned)p;
+}
+
+// Workspace carving: every sub-buffer 256-byte aligned.
+struct BtcCarver {
+  char* base;
+  size_t off;
+  explicit BtcCarver(void* p) : base((char*)p), off(0) {}
+  template <typename T>
+  T* take(size_t count) {
+    T* r = (T*)(base + off);
+    off += btc_align(count * sizeof(T));
+    return r;
+  }
+};
+
+// Device-wide exclusive scan of int32 (scan.hip).  out may alias in.  n >= 0.
+// ws: btc_scan_ws_bytes(n).  out[i] = sum_{j<i} in[j]; if total != nullptr, *total = sum of all.
+size_t btc_scan_ws_bytes(long long n);
+int btc_scan_exclusive_i32(const int32_t* in, int32_t* out, long long n, int32_t* total, void* ws, hipStream_t stream);
+
+// Geometry passed by value to kernels.
+struct BtcGeom {
+  int in_shape[3];
+  int out_shape[3];
+  int k[3];
+  int s[3];
+  int p[3];
+  int d[3];
+  int K;
+  int mode;
+};
+
+__device__ __forceinline__ unsigned btc_hash32(unsigned key) {
+  key *= 2654435761u;
+  key ^= key >> 15;
+  return key;
+}

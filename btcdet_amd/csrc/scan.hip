@@ -1,0 +1,136 @@
+// Device-wide exclusive prefix sum of int32 (three launches: block reduce, scan of block sums,
+// block scan + offset).  Wave64 shuffles for the in-wave scan, LDS for the 4 waves of a block.
+#include <stdarg.h>
+
+#include "btc_common.h"
+
+static thread_local char g_err[512] = "";
+
+void btc_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" const char* btc_last_error(void) { return g_err; }
+extern "C" int btc_version(void) { return 1; }
+
+namespace {
+
+constexpr int SCAN_THREADS = 256;
+constexpr int SCAN_ITEMS = 8;
+constexpr int SCAN_TILE = SCAN_THREADS * SCAN_ITEMS;
+
+__device__ __forceinline__ int wave_incl_scan(int v) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    int t = __shfl_up(v, o, 64);
+    if (lane >= o) v += t;
+  }
+  return v;
+}
+
+// exclusive scan across the block of per-thread values; returns exclusive prefix, total in *block_total
+template <int THREADS>
+__device__ __forceinline__ int block_excl_scan(int v, int* s_wave /* THREADS/64 + 1 */, int* block_total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int incl = wave_incl_scan(v);
+  if (lane == 63) s_wave[wave] = incl;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int run = 0;
+#pragma unroll
+    for (int w = 0; w < THREADS / 64; ++w) {
+      int t = s_wave[w];
+      s_wave[w] = run;
+      run += t;
+    }
+    s_wave[THREADS / 64] = run;
+  }
+  __syncthreads();
+  int r = incl - v + s_wave[wave];
+  *block_total = s_wave[THREADS / 64];
+  __syncthreads();
+  return r;
+}
+
+__global__ __launch_bounds__(SCAN_THREADS) void scan_block_reduce(const int32_t* __restrict__ in, long long n,
+                                                                  int32_t* __restrict__ block_sums) {
+  __shared__ int s_wave[SCAN_THREADS / 64];
+  long long base = (long long)blockIdx.x * SCAN_TILE + (long long)threadIdx.x * SCAN_ITEMS;
+  int sum = 0;
+#pragma unroll
+  for (int j = 0; j < SCAN_ITEMS; ++j)
+    if (base + j < n) sum += in[base + j];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) sum += __shfl_down(sum, o, 64);
+  if ((threadIdx.x & 63) == 0) s_wave[threadIdx.x >> 6] = sum;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int t = 0;
+#pragma unroll
+    for (int w = 0; w < SCAN_THREADS / 64; ++w) t += s_wave[w];
+    block_sums[blockIdx.x] = t;
+  }
+}
+
+__global__ __launch_bounds__(1024) void scan_block_sums(int32_t* __restrict__ block_sums, int nblocks,
+                                                        int32_t* __restrict__ total) {
+  __shared__ int s_wave[1024 / 64 + 1];
+  int carry = 0;
+  for (int base = 0; base < nblocks; base += 1024) {
+    int i = base + threadIdx.x;
+    int v = i < nblocks ? block_sums[i] : 0;
+    int tot;
+    int ex = block_excl_scan<1024>(v, s_wave, &tot);
+    if (i < nblocks) block_sums[i] = ex + carry;
+    carry += tot;
+  }
+  if (threadIdx.x == 0 && total) *total = carry;
+}
+
+__global__ __launch_bounds__(SCAN_THREADS) void scan_final(const int32_t* __restrict__ in, int32_t* __restrict__ out,
+                                                           long long n, const int32_t* __restrict__ block_sums) {
+  __shared__ int s_wave[SCAN_THREADS / 64 + 1];
+  long long base = (long long)blockIdx.x * SCAN_TILE + (long long)threadIdx.x * SCAN_ITEMS;
+  int v[SCAN_ITEMS];
+  int sum = 0;
+#pragma unroll
+  for (int j = 0; j < SCAN_ITEMS; ++j) {
+    v[j] = (base + j < n) ? in[base + j] : 0;
+    sum += v[j];
+  }
+  int tot;
+  int ex = block_excl_scan<SCAN_THREADS>(sum, s_wave, &tot) + block_sums[blockIdx.x];
+#pragma unroll
+  for (int j = 0; j < SCAN_ITEMS; ++j) {
+    if (base + j < n) out[base + j] = ex;
+    ex += v[j];
+  }
+}
+
+}  // namespace
+
+size_t btc_scan_ws_bytes(long long n) {
+  long long nblocks = (n + SCAN_TILE - 1) / SCAN_TILE;
+  if (nblocks < 1) nblocks = 1;
+  return btc_align((size_t)nblocks * sizeof(int32_t));
+}
+
+int btc_scan_exclusive_i32(const int32_t* in, int32_t* out, long long n, int32_t* total, void* ws, hipStream_t stream) {
+  if (n <= 0) {
+    if (total) BTC_HIP(hipMemsetAsync(total, 0, sizeof(int32_t), stream));
+    return BTC_OK;
+  }
+  int nblocks = (int)((n + SCAN_TILE - 1) / SCAN_TILE);
+  int32_t* block_sums = (int32_t*)ws;
+  scan_block_reduce<<<nblocks, SCAN_THREADS, 0, stream>>>(in, n, block_sums);
+  BTC_LAUNCH_CHECK();
+  scan_block_sums<<<1, 1024, 0, stream>>>(block_sums, nblocks, total);
+  BTC_LAUNCH_CHECK();
+  scan_final<<<nblocks, SCAN_THREADS, 0, stream>>>(in, out, n, block_sums);
+  BTC_LAUNCH_CHECK();
+  return BTC_OK;
+}

@@ -1,0 +1,165 @@
+"""Sparse convolution layers with spconv v1.2.1's constructor signatures, parameter names and
+shapes (weight [kD,kH,kW,Cin,Cout], optional bias [Cout]) so reference checkpoints load
+(/root/reference/btcdet/models/detectors/detector3d_template.py:594-618) and the reference's
+model code constructs them unchanged (spconv_backbone.py:12-29,58-64,657,696; occ_head_3D.py:26,31)."""
+import math
+
+import numpy as np
+import torch
+from torch import nn
+from torch.nn import init
+
+from . import ops
+from .modules import SparseModule
+from .tensor import SparseConvTensor
+
+
+def _ntuple(v, n):
+    if isinstance(v, (list, tuple, np.ndarray)):
+        v = [int(x) for x in v]
+        assert len(v) == n, f"expected {n} values, got {v}"
+        return v
+    return [int(v)] * n
+
+
+class SparseConvolution(SparseModule):
+    def __init__(self, ndim, in_channels, out_channels, kernel_size=3, stride=1, padding=0, dilation=1, groups=1,
+                 bias=True, subm=False, output_padding=0, transposed=False, inverse=False, indice_key=None,
+                 fused_bn=False):
+        super(SparseConvolution, self).__init__()
+        assert groups == 1, "groups != 1 is not supported (nor used by the reference)"
+        assert ndim in (2, 3)
+        self.ndim = ndim
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size = _ntuple(kernel_size, ndim)
+        self.conv1x1 = int(np.prod(self.kernel_size)) == 1
+        self.stride = _ntuple(stride, ndim)
+        self.padding = _ntuple(padding, ndim)
+        self.dilation = _ntuple(dilation, ndim)
+        self.output_padding = _ntuple(output_padding, ndim)
+        self.transposed, self.inverse, self.subm = transposed, inverse, subm
+        self.groups = groups
+        self.indice_key = indice_key
+        self.fused_bn = fused_bn
+        self.weight = nn.Parameter(torch.Tensor(*self.kernel_size, in_channels, out_channels))
+        if bias:
+            self.bias = nn.Parameter(torch.Tensor(out_channels))
+        else:
+            self.register_parameter('bias', None)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        # same calls as spconv v1.2.1 (including its fan-in quirk on the [k..,Cin,Cout] layout)
+        init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        if self.bias is not None:
+            fan_in, _ = init._calculate_fan_in_and_fan_out(self.weight)
+            bound = 1 / math.sqrt(fan_in)
+            init.uniform_(self.bias, -bound, bound)
+
+    def forward(self, input):
+        assert isinstance(input, SparseConvTensor)
+        features, indices = input.features, input.indices
+        spatial_shape, batch_size = input.spatial_shape, input.batch_size
+        if not self.subm:
+            if self.transposed:
+                out_spatial_shape = ops.get_deconv_output_size(spatial_shape, self.kernel_size, self.stride, self.padding,
+                                                               self.dilation, self.output_padding)
+            else:
+                out_spatial_shape = ops.get_conv_output_size(spatial_shape, self.kernel_size, self.stride, self.padding,
+                                                             self.dilation)
+        else:
+            out_spatial_shape = spatial_shape
+        if self.conv1x1:
+            features = torch.mm(input.features, self.weight.view(self.in_channels, self.out_channels))
+            if self.bias is not None:
+                features = features + self.bias
+            out_tensor = SparseConvTensor(features, input.indices, input.spatial_shape, input.batch_size)
+            out_tensor.indice_dict = input.indice_dict
+            out_tensor.grid = input.grid
+            return out_tensor
+        rb = input.find_indice_pair(self.indice_key)
+        if self.inverse:
+            assert rb is not None and self.indice_key is not None, "inverse conv needs the cached rulebook of its indice_key"
+            assert rb.K == int(np.prod(self.kernel_size)), "inverse conv kernel does not match the cached rulebook"
+            out_features = ops.indice_conv(features, self.weight, self.bias, rb, inverse=True)
+            outids, out_spatial_shape = rb.in_indices, rb.in_shape[3 - self.ndim:]
+        else:
+            if rb is None:
+                idx4 = indices
+                if self.ndim == 2:
+                    idx4 = torch.cat([indices[:, :1], torch.zeros_like(indices[:, :1]), indices[:, 1:]], dim=1)
+                rb = ops.build_rulebook(idx4, batch_size, self._shape3(spatial_shape), self._k3(self.kernel_size, 1),
+                                        self._k3(self.stride, 1), self._k3(self.padding, 0), self._k3(self.dilation, 1),
+                                        self._k3(self.output_padding, 0), self.subm, self.transposed)
+                if self.indice_key is not None:
+                    input.indice_dict[self.indice_key] = rb
+            # on a cache hit the layer uses the cached rulebook without checking its own geometry (App. B.5)
+            out_features = ops.indice_conv(features, self.weight, self.bias, rb, inverse=False)
+            outids = rb.out_indices
+            if self.ndim == 2 and outids.shape[1] == 4:
+                outids = torch.cat([outids[:, :1], outids[:, 2:]], dim=1).contiguous()
+        out_tensor = SparseConvTensor(out_features, outids, out_spatial_shape, batch_size)
+        out_tensor.indice_dict = input.indice_dict
+        out_tensor.grid = input.grid
+        return out_tensor
+
+    def _k3(self, v, fill):
+        return list(v) if self.ndim == 3 else [fill] + list(v)
+
+    def _shape3(self, shape):
+        shape = [int(s) for s in shape]
+        return shape if self.ndim == 3 else [1] + shape
+
+
+class SparseConv2d(SparseConvolution):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1, bias=True,
+                 indice_key=None):
+        super(SparseConv2d, self).__init__(2, in_channels, out_channels, kernel_size, stride, padding, dilation, groups,
+                                           bias, indice_key=indice_key)
+
+
+class SparseConv3d(SparseConvolution):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1, bias=True,
+                 indice_key=None):
+        super(SparseConv3d, self).__init__(3, in_channels, out_channels, kernel_size, stride, padding, dilation, groups,
+                                           bias, indice_key=indice_key)
+
+
+class SparseConvTranspose2d(SparseConvolution):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1, bias=True,
+                 indice_key=None):
+        super(SparseConvTranspose2d, self).__init__(2, in_channels, out_channels, kernel_size, stride, padding, dilation,
+                                                    groups, bias, transposed=True, indice_key=indice_key)
+
+
+class SparseConvTranspose3d(SparseConvolution):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1, bias=True,
+                 indice_key=None):
+        super(SparseConvTranspose3d, self).__init__(3, in_channels, out_channels, kernel_size, stride, padding, dilation,
+                                                    groups, bias, transposed=True, indice_key=indice_key)
+
+
+class SparseInverseConv2d(SparseConvolution):
+    def __init__(self, in_channels, out_channels, kernel_size, indice_key, bias=True):
+        super(SparseInverseConv2d, self).__init__(2, in_channels, out_channels, kernel_size, bias=bias, inverse=True,
+                                                  indice_key=indice_key)
+
+
+class SparseInverseConv3d(SparseConvolution):
+    def __init__(self, in_channels, out_channels, kernel_size, indice_key, bias=True):
+        super(SparseInverseConv3d, self).__init__(3, in_channels, out_channels, kernel_size, bias=bias, inverse=True,
+                                                  indice_key=indice_key)
+
+
+class SubMConv2d(SparseConvolution):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1, bias=True,
+                 indice_key=None):
+        super(SubMConv2d, self).__init__(2, in_channels, out_channels, kernel_size, stride, padding, dilation, groups, bias,
+                                         True, indice_key=indice_key)
+
+
+class SubMConv3d(SparseConvolution):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1, bias=True,
+                 indice_key=None):
+        super(SubMConv3d, self).__init__(3, in_channels, out_channels, kernel_size, stride, padding, dilation, groups, bias,
+                                         True, indice_key=indice_key)

@@ -1,0 +1,76 @@
+"""SparseModule / SparseSequential (spconv v1.2.1 semantics):
+sparse modules receive the SparseConvTensor; plain nn.Modules (BatchNorm1d, ReLU) are applied to
+``.features`` in place when the input is sparse and has at least one row.
+Call sites: /root/reference/btcdet/models/backbones_3d/spconv_backbone.py:34-42,106-128,656-700."""
+from collections import OrderedDict
+
+from torch import nn
+
+from .tensor import SparseConvTensor
+
+
+class SparseModule(nn.Module):
+    """marker base class of modules that take a SparseConvTensor"""
+    pass
+
+
+def is_spconv_module(module):
+    return isinstance(module, SparseModule)
+
+
+def is_sparse_conv(module):
+    from .conv import SparseConvolution
+    return isinstance(module, SparseConvolution)
+
+
+class SparseSequential(SparseModule):
+    def __init__(self, *args, **kwargs):
+        super(SparseSequential, self).__init__()
+        if len(args) == 1 and isinstance(args[0], OrderedDict):
+            for key, module in args[0].items():
+                self.add_module(key, module)
+        else:
+            for idx, module in enumerate(args):
+                self.add_module(str(idx), module)
+        for name, module in kwargs.items():
+            if name in self._modules:
+                raise ValueError("name exists.")
+            self.add_module(name, module)
+        self._sparity_dict = {}
+
+    def __getitem__(self, idx):
+        if not (-len(self) <= idx < len(self)):
+            raise IndexError('index {} is out of range'.format(idx))
+        if idx < 0:
+            idx += len(self)
+        it = iter(self._modules.values())
+        for _ in range(idx):
+            next(it)
+        return next(it)
+
+    def __len__(self):
+        return len(self._modules)
+
+    @property
+    def sparity_dict(self):
+        return self._sparity_dict
+
+    def add(self, module, name=None):
+        if name is None:
+            name = str(len(self._modules))
+            if name in self._modules:
+                raise KeyError("name exists")
+        self.add_module(name, module)
+
+    def forward(self, input):
+        for k, module in self._modules.items():
+            if is_spconv_module(module):
+                assert isinstance(input, SparseConvTensor)
+                input = module(input)
+            else:
+                if isinstance(input, SparseConvTensor):
+                    if input.indices.shape[0] != 0:
+                        input.features = module(input.features)
+                else:
+                    input = module(input)
+        return input

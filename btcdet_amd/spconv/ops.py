@@ -1,0 +1,224 @@
+"""Operator layer: rulebook construction and the autograd functions over libbtcdet_hip.so.
+
+Mirrors ``spconv.ops`` / ``spconv.functional`` of spconv v1.2.1: the
+reference reaches these through SubMConv3d / SparseConv3d / SparseConvTranspose3d /
+SparseInverseConv3d / SparseMaxPool3d (/root/reference/btcdet/models/backbones_3d/
+spconv_backbone.py:12-29).  The rulebook is kept as two dense neighbour maps (see
+include/btcdet_hip.h); ``Rulebook.indice_pairs()`` gives spconv's (2,K,N)/(K,) view on demand.
+"""
+import numpy as np
+import torch
+
+from .. import _lib
+from .._lib import MODE_CONV, MODE_SUBM, MODE_TRANSPOSE, check, i3, i3p, lib, ptr, stream_ptr, workspace
+
+
+def get_conv_output_size(input_size, kernel_size, stride, padding, dilation):
+    """spconv.ops.get_conv_output_size: o = (i + 2p - d(k-1) - 1)//s + 1."""
+    return [int((int(i) + 2 * p - d * (k - 1) - 1) // s + 1)
+            for i, k, s, p, d in zip(input_size, kernel_size, stride, padding, dilation)]
+
+
+def get_deconv_output_size(input_size, kernel_size, stride, padding, dilation, output_padding):
+    """spconv.ops.get_deconv_output_size: o = (i-1)s - 2p + k + outpad."""
+    return [int((int(i) - 1) * s - 2 * p + k + op)
+            for i, k, s, p, op in zip(input_size, kernel_size, stride, padding, output_padding)]
+
+
+class Rulebook(object):
+    """One cached rulebook (what spconv stores in ``indice_dict[indice_key]``)."""
+
+    __slots__ = ("out_indices", "in_indices", "nbr_out", "nbr_in", "in_shape", "out_shape", "K", "mode")
+
+    def __init__(self, out_indices, in_indices, nbr_out, nbr_in, in_shape, out_shape, K, mode):
+        self.out_indices, self.in_indices = out_indices, in_indices
+        self.nbr_out, self.nbr_in = nbr_out, nbr_in
+        self.in_shape, self.out_shape = list(in_shape), list(out_shape)
+        self.K, self.mode = K, mode
+
+    @property
+    def n_in(self):
+        return self.in_indices.shape[0]
+
+    @property
+    def n_out(self):
+        return self.out_indices.shape[0]
+
+    def indice_pairs(self):
+        """spconv layout: indice_pairs (2,K,n_in) int32 padded with -1, indice_pair_num (K,) int32;
+        pairs of an offset are ordered by output row (canonical order)."""
+        dev = self.nbr_out.device
+        pairs = torch.empty((2, self.K, max(self.n_in, 1)), dtype=torch.int32, device=dev)
+        num = torch.empty((self.K,), dtype=torch.int32, device=dev)
+        check(lib().btc_pairs_from_nbr(ptr(self.nbr_out), self.n_out, self.K, self.n_in, ptr(pairs), ptr(num),
+                                       stream_ptr()), "btc_pairs_from_nbr")
+        return pairs[:, :, :self.n_in], num
+
+
+def _as_idx(indices):
+    if indices.dtype != torch.int32:
+        indices = indices.int()
+    return indices.contiguous()
+
+
+def build_rulebook(indices, batch_size, spatial_shape, ksize, stride=1, padding=0, dilation=1, out_padding=0,
+                   subm=False, transpose=False):
+    """ops.get_indice_pairs replacement.  indices (N,4) int32 [b,z,y,x] on the GPU."""
+    indices = _as_idx(indices)
+    if indices.dim() != 2 or indices.shape[1] != 4:
+        raise _lib.BtcHipError(f"indices must be (N,4) [b,z,y,x], got {tuple(indices.shape)}")
+    dev = indices.device
+    n = indices.shape[0]
+    L = lib()
+    k3, s3, p3, d3, op3 = i3(ksize), i3(stride), i3(padding), i3(dilation), i3(out_padding)
+    in_sh = i3([int(v) for v in spatial_shape])
+    K = int(np.prod(k3))
+    mode = MODE_SUBM if subm else (MODE_TRANSPOSE if transpose else MODE_CONV)
+    out_sh = np.zeros(3, dtype=np.int32)
+    check(L.btc_out_shape(i3p(in_sh), i3p(k3), i3p(s3), i3p(p3), i3p(d3), i3p(op3), mode, i3p(out_sh)), "btc_out_shape")
+    if subm:
+        nbr_out = torch.empty((n, K), dtype=torch.int32, device=dev)
+        nbr_in = torch.empty((n, K), dtype=torch.int32, device=dev)
+        ws_bytes = L.btc_rulebook_subm_ws_bytes(n)
+        ws = workspace(ws_bytes, dev)
+        check(L.btc_rulebook_subm(ptr(indices), n, int(batch_size), i3p(in_sh), i3p(k3), i3p(d3), ptr(nbr_out),
+                                  ptr(nbr_in), ptr(ws), ws_bytes, stream_ptr()), "btc_rulebook_subm")
+        return Rulebook(indices, indices, nbr_out, nbr_in, in_sh.tolist(), out_sh.tolist(), K, mode)
+    ws_bytes = L.btc_rulebook_conv_ws_bytes(int(batch_size), i3p(out_sh))
+    ws = workspace(ws_bytes, dev)
+    d_n_out = torch.empty((1,), dtype=torch.int32, device=dev)
+    check(L.btc_rulebook_conv_count(ptr(indices), n, int(batch_size), i3p(in_sh), i3p(out_sh), i3p(k3), i3p(s3),
+                                    i3p(p3), i3p(d3), mode, ptr(d_n_out), ptr(ws), ws_bytes, stream_ptr()),
+          "btc_rulebook_conv_count")
+    n_out = int(d_n_out.item())  # the one read-back of the build (spconv syncs here too)
+    out_indices = torch.empty((n_out, 4), dtype=torch.int32, device=dev)
+    nbr_out = torch.empty((n_out, K), dtype=torch.int32, device=dev)
+    nbr_in = torch.empty((n, K), dtype=torch.int32, device=dev)
+    check(L.btc_rulebook_conv_fill(ptr(indices), n, int(batch_size), i3p(in_sh), i3p(out_sh), i3p(k3), i3p(s3),
+                                   i3p(p3), i3p(d3), mode, n_out, ptr(out_indices), ptr(nbr_out), ptr(nbr_in), ptr(ws),
+                                   ws_bytes, stream_ptr()), "btc_rulebook_conv_fill")
+    return Rulebook(out_indices, indices, nbr_out, nbr_in, in_sh.tolist(), out_sh.tolist(), K, mode)
+
+
+def get_indice_pairs(indices, batch_size, spatial_shape, ksize=3, stride=1, padding=0, dilation=1, out_padding=0,
+                     subm=False, transpose=False, grid=None):
+    """spconv.ops.get_indice_pairs signature -> (outids, indice_pairs, indice_pair_num)."""
+    rb = build_rulebook(indices, batch_size, spatial_shape, ksize, stride, padding, dilation, out_padding, subm, transpose)
+    pairs, num = rb.indice_pairs()
+    return rb.out_indices, pairs, num
+
+
+def _f32c(t):
+    if t.dtype != torch.float32:
+        raise _lib.BtcHipError(f"float32 features expected, got {t.dtype}")
+    return t.contiguous()
+
+
+class SparseConvFunction(torch.autograd.Function):
+    """indice_conv / indice_subm_conv / indice_inverse_conv in one function.
+    map_fwd (n_res,K): source row gathered by result row i at offset k; map_bwd (n_src,K) its transpose."""
+
+    @staticmethod
+    def forward(ctx, features, weight, bias, map_fwd, map_bwd):
+        features = _f32c(features)
+        w = _f32c(weight)
+        cin, cout = w.shape[-2], w.shape[-1]
+        K = map_fwd.shape[1]
+        if w.numel() != K * cin * cout or features.shape[1] != cin:
+            raise _lib.BtcHipError(f"weight {tuple(w.shape)} does not match K={K}, Cin={features.shape[1]}")
+        n_res = map_fwd.shape[0]
+        out = torch.empty((n_res, cout), dtype=torch.float32, device=features.device)
+        b = _f32c(bias) if bias is not None else None
+        check(lib().btc_conv_fwd(ptr(features), ptr(w), ptr(b), ptr(map_fwd), n_res, K, cin, cout, ptr(out),
+                                 stream_ptr()), "btc_conv_fwd")
+        ctx.save_for_backward(features, w, map_fwd, map_bwd)
+        ctx.has_bias = bias is not None
+        ctx.wshape = tuple(weight.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        features, w, map_fwd, map_bwd = ctx.saved_tensors
+        grad_out = _f32c(grad_out)
+        cin, cout = w.shape[-2], w.shape[-1]
+        K = map_fwd.shape[1]
+        L = lib()
+        din = dw = db = None
+        if ctx.needs_input_grad[0]:
+            n_src = map_bwd.shape[0]
+            din = torch.empty((n_src, cin), dtype=torch.float32, device=grad_out.device)
+            check(L.btc_conv_dgrad(ptr(grad_out), ptr(w), ptr(map_bwd), n_src, K, cin, cout, ptr(din), stream_ptr()),
+                  "btc_conv_dgrad")
+        if ctx.needs_input_grad[1]:
+            n_res = map_fwd.shape[0]
+            dw = torch.empty(ctx.wshape, dtype=torch.float32, device=grad_out.device)
+            ws_bytes = L.btc_conv_wgrad_ws_bytes(n_res, K, cin, cout)
+            ws = workspace(ws_bytes, grad_out.device)
+            check(L.btc_conv_wgrad(ptr(features), ptr(grad_out), ptr(map_fwd), n_res, K, cin, cout, ptr(dw), ptr(ws),
+                                   ws_bytes, stream_ptr()), "btc_conv_wgrad")
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = grad_out.sum(0)
+        return din, dw, db, None, None
+
+
+class SparseMaxPoolFunction(torch.autograd.Function):
+    """indice_maxpool."""
+
+    @staticmethod
+    def forward(ctx, features, nbr_out, nbr_in):
+        features = _f32c(features)
+        n_out, K = nbr_out.shape
+        C = features.shape[1]
+        out = torch.empty((n_out, C), dtype=torch.float32, device=features.device)
+        check(lib().btc_maxpool_fwd(ptr(features), ptr(nbr_out), n_out, K, C, ptr(out), stream_ptr()), "btc_maxpool_fwd")
+        ctx.save_for_backward(features, out, nbr_in)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        features, out, nbr_in = ctx.saved_tensors
+        grad_out = _f32c(grad_out)
+        n_in, K = nbr_in.shape
+        C = features.shape[1]
+        din = torch.empty_like(features)
+        check(lib().btc_maxpool_bwd(ptr(features), ptr(out), ptr(grad_out), ptr(nbr_in), n_in, K, C, ptr(din),
+                                    stream_ptr()), "btc_maxpool_bwd")
+        return din, None, None
+
+
+class ToDenseFunction(torch.autograd.Function):
+    """SparseConvTensor.dense(): (N,C) rows -> zeros(B,C,D,H,W)."""
+
+    @staticmethod
+    def forward(ctx, features, indices, batch_size, spatial_shape):
+        features = _f32c(features)
+        indices = _as_idx(indices)
+        n, C = features.shape
+        sh = i3([int(v) for v in spatial_shape])
+        dense = torch.zeros((int(batch_size), C, int(sh[0]), int(sh[1]), int(sh[2])), dtype=torch.float32,
+                            device=features.device)
+        check(lib().btc_dense_fwd(ptr(features), ptr(indices), n, C, i3p(sh), ptr(dense), stream_ptr()), "btc_dense_fwd")
+        ctx.save_for_backward(indices)
+        ctx.sh = sh
+        ctx.nc = (n, C)
+        return dense
+
+    @staticmethod
+    def backward(ctx, grad_dense):
+        (indices,) = ctx.saved_tensors
+        n, C = ctx.nc
+        grad_dense = _f32c(grad_dense)
+        dfeat = torch.empty((n, C), dtype=torch.float32, device=grad_dense.device)
+        check(lib().btc_dense_bwd(ptr(grad_dense), ptr(indices), n, C, i3p(ctx.sh), ptr(dfeat), stream_ptr()),
+              "btc_dense_bwd")
+        return dfeat, None, None, None
+
+
+def indice_conv(features, weight, bias, rulebook, inverse=False):
+    if inverse:
+        return SparseConvFunction.apply(features, weight, bias, rulebook.nbr_in, rulebook.nbr_out)
+    return SparseConvFunction.apply(features, weight, bias, rulebook.nbr_out, rulebook.nbr_in)
+
+
+def indice_maxpool(features, rulebook):
+    return SparseMaxPoolFunction.apply(features, rulebook.nbr_out, rulebook.nbr_in)

@@ -1,0 +1,170 @@
+/*
+ * btcdet_hip.h -- C ABI of libbtcdet_hip.so, the MI355X (gfx950) implementation of BtcDet's
+ * data-parallel hot path: point-cloud voxelizer, sparse-3D-conv rulebook construction, sparse conv /
+ * max-pool apply (forward + backward), sparse->dense scatter and the occupancy-target kernels.
+ *
+ * This is the drop-in boundary.  The reference reaches this code through
+ * third-party `spconv` v1.2.1 (pybind11; /root/reference/README.md:42) and through chains of torch
+ * ops; each entry point below names the reference interface it replaces.  The Python host side
+ * (btcdet_amd/spconv/ and the btcdet_amd modules) binds these symbols with ctypes and mirrors the reference's
+ * operator / module API (INTEGRATION.md shows the binding a maintainer would add).
+ *
+ * Rules common to every entry point
+ *   - all pointers are DEVICE pointers unless the name starts with h_ (host); no torch types;
+ *   - `stream` is a hipStream_t passed as void*; work is enqueued, never synchronised, unless stated;
+ *   - caller allocates every output and workspace buffer (sizes given per function; the *_ws_bytes
+ *     helpers are pure host functions);
+ *   - return value: 0 on success, a negative BTC_E* code on error (never exit(), cf. the reference's
+ *     exit(-1) in btcdet/ops/iou3d_nms/src/iou3d_nms.cpp:14-38); btc_last_error() gives the text;
+ *   - indices are int32 rows [b,z,y,x]; features are row-major float32 (N,C);
+ *   - kernel offset index k = (kz*KH + ky)*KW + kx; weights are float32 [K][Cin][Cout]
+ *     (= spconv's parameter layout [kD,kH,kW,Cin,Cout]);
+ *   - neighbour maps: nbr_out (n_out,K) = input row gathered by output row i at offset k, or -1;
+ *                     nbr_in  (n_in ,K) = output row that input row j feeds at offset k, or -1.
+ *     They are the output-stationary / input-stationary forms of spconv's indice_pairs
+ *     (SURVEY.md App. B.4); btc_pairs_from_nbr converts to the (2,K,N) / (K,) layout.
+ */
+#ifndef BTCDET_HIP_H
+#define BTCDET_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BTC_OK 0
+#define BTC_EINVAL (-1)   /* bad argument */
+#define BTC_ELAUNCH (-2)  /* HIP launch / runtime error */
+#define BTC_ERANGE (-3)   /* problem too large for the 32-bit cell keys */
+
+#define BTC_MODE_SUBM 0
+#define BTC_MODE_CONV 1       /* also the geometry of SparseMaxPool3d */
+#define BTC_MODE_TRANSPOSE 2
+
+const char* btc_last_error(void);
+int btc_version(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Voxelizer.  Replaces spconv.utils.VoxelGeneratorV2.generate (points_to_voxel_3d_np), called at
+ * /root/reference/btcdet/datasets/processor/data_processor.py:85,136,177, for a whole batch at once.
+ * Semantics: c = floor((p - lo) / vs) in float32, point dropped unless
+ * 0 <= c < grid on every axis; voxels numbered by first appearance in input order (per scene);
+ * at most max_voxels voxels per scene (later-appearing voxels dropped with all their points);
+ * at most max_points points per voxel (earliest kept, input order); padding 0.
+ *
+ *   points        (n, ld) float32; xyz at columns [xyz_col, xyz_col+3); the C copied features start
+ *                 at feat_col (the reference copies the whole row: feat_col == xyz_col, C == ld).
+ *   scene_offsets (batch+1) int32, ascending, points of scene b are rows [off[b], off[b+1]).
+ *   range[6], vsize[3], grid[3] (x,y,z) host arrays (grid = round((hi-lo)/vs), computed by caller).
+ * Outputs (capacity cap_vox = batch*max_voxels rows):
+ *   voxels (cap_vox, max_points, C) f32 ; coords (cap_vox, 4) i32 [b,z,y,x] ; num (cap_vox) i32 ;
+ *   d_total (1) i32 = number of voxels M (rows [0,M) are valid; rows >= M are left untouched).
+ * ws: btc_voxelize_ws_bytes(n, batch, max_points) bytes.
+ * ---------------------------------------------------------------------------------------------- */
+size_t btc_voxelize_ws_bytes(int n, int batch, int max_points);
+int btc_voxelize(const float* points, int n, int ld, int xyz_col, int feat_col, int C,
+                 const int32_t* scene_offsets, int batch, const float* h_range, const float* h_vsize,
+                 const int32_t* h_grid, int max_points, int max_voxels, float* voxels, int32_t* coords,
+                 int32_t* num, int32_t* d_total, void* ws, size_t ws_bytes, void* stream);
+
+/* Cartesian -> cylinder / sphere coordinates of the leading xyz columns, other columns copied.
+ * Replaces coords_utils.absxyz_2_cylinxyz_np / absxyz_2_spherexyz_np
+ * (/root/reference/btcdet/utils/coords_utils.py:268-292).  mode 1 = cylinder, 2 = sphere.
+ * Optional per-row azimuth shift: out[:,1] -= rot_z_deg[scene(row)] when rot_z_deg != NULL is NOT
+ * applied here (the reference shifts voxel payloads after voxelization, data_processor.py:148-149;
+ * see btc_add_scalar_by_batch). */
+int btc_cart_to_occ_coords(const float* in, float* out, int n, int ld, int mode, void* stream);
+
+/* voxels[v, p, col] += sign * rot[b(v)] for every slot p (padded slots too).
+ * Replaces `voxels[..., 1] = voxels[..., 1] - data_dict['rot_z']` (data_processor.py:148-149). */
+int btc_voxel_shift_col(float* voxels, const int32_t* coords, int m, int max_points, int C, int col,
+                        const float* rot_by_batch, float sign, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Rulebook.  Replaces spconv ops.get_indice_pairs behind
+ * SubMConv3d / SparseConv3d / SparseConvTranspose3d / SparseMaxPool3d
+ * (/root/reference/btcdet/models/backbones_3d/spconv_backbone.py:12-29).
+ * ---------------------------------------------------------------------------------------------- */
+/* o = (i + 2p - d(k-1) - 1)/s + 1 (conv), (i-1)s - 2p + k + outpad (transpose), i (subm). host only */
+int btc_out_shape(const int32_t* h_in_shape, const int32_t* h_k, const int32_t* h_s, const int32_t* h_p,
+                  const int32_t* h_d, const int32_t* h_outpad, int mode, int32_t* h_out_shape);
+
+/* SubM: outputs are the inputs in input order.  Kernel sizes must be odd.
+ * nbr_out, nbr_in: (n, K) int32, both fully written.  ws: btc_rulebook_subm_ws_bytes(n). */
+size_t btc_rulebook_subm_ws_bytes(int n);
+int btc_rulebook_subm(const int32_t* indices, int n, int batch, const int32_t* h_shape, const int32_t* h_k,
+                      const int32_t* h_d, int32_t* nbr_out, int32_t* nbr_in, void* ws, size_t ws_bytes,
+                      void* stream);
+
+/* Regular / transposed conv and pooling geometry, two phases around one 4-byte read-back:
+ *   phase 1 (count): marks the set of reachable output cells and ranks it; *d_n_out = n_out.
+ *   phase 2 (fill) : out_indices (n_out,4) ascending in (b,z,y,x); nbr_out (n_out,K); nbr_in (n,K).
+ * The same ws (btc_rulebook_conv_ws_bytes(batch, out_shape)) must be passed to both phases,
+ * untouched in between. */
+size_t btc_rulebook_conv_ws_bytes(int batch, const int32_t* h_out_shape);
+int btc_rulebook_conv_count(const int32_t* indices, int n, int batch, const int32_t* h_in_shape,
+                            const int32_t* h_out_shape, const int32_t* h_k, const int32_t* h_s,
+                            const int32_t* h_p, const int32_t* h_d, int mode, int32_t* d_n_out, void* ws,
+                            size_t ws_bytes, void* stream);
+int btc_rulebook_conv_fill(const int32_t* indices, int n, int batch, const int32_t* h_in_shape,
+                           const int32_t* h_out_shape, const int32_t* h_k, const int32_t* h_s,
+                           const int32_t* h_p, const int32_t* h_d, int mode, int n_out, int32_t* out_indices,
+                           int32_t* nbr_out, int32_t* nbr_in, void* ws, size_t ws_bytes, void* stream);
+
+/* spconv-layout view of a rulebook: pairs (2,K,n_in) int32 padded with -1, pair_num (K) int32,
+ * pairs within an offset ordered by output row (the canonical order of SURVEY.md App. B.4). */
+int btc_pairs_from_nbr(const int32_t* nbr_out, int n_out, int K, int n_in, int32_t* pairs, int32_t* pair_num,
+                       void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Sparse convolution apply.  Replaces spconv's indice_conv / indice_subm_conv /
+ * indice_inverse_conv autograd functions: fp32 in, fp32 accumulate on
+ * the fp32 MFMA pipe, fused over all K offsets, output-stationary (no atomics, deterministic).
+ *   fwd   : out[i]  = bias + sum_k feat[nbr_out[i][k]] @ W[k]
+ *   dgrad : din[j]  = sum_k dout[nbr_in[j][k]] @ W[k]^T
+ *   wgrad : dW[k]   = sum_i feat[nbr_out[i][k]]^T dout[i]    (ws: btc_conv_wgrad_ws_bytes)
+ * An inverse conv (SparseInverseConv3d) is fwd with nbr_in of the cached rulebook as the map.
+ * ---------------------------------------------------------------------------------------------- */
+int btc_conv_fwd(const float* feat, const float* W, const float* bias /* may be NULL */, const int32_t* nbr_out,
+                 int n_out, int K, int Cin, int Cout, float* out, void* stream);
+int btc_conv_dgrad(const float* dout, const float* W, const int32_t* nbr_in, int n_in, int K, int Cin,
+                   int Cout, float* din, void* stream);
+size_t btc_conv_wgrad_ws_bytes(int n_out, int K, int Cin, int Cout);
+int btc_conv_wgrad(const float* feat, const float* dout, const int32_t* nbr_out, int n_out, int K, int Cin,
+                   int Cout, float* dW, void* ws, size_t ws_bytes, void* stream);
+
+/* Sparse max-pool (spconv indice_maxpool, App. B.6): out = max(0, max_k feat[nbr_out[i][k]]);
+ * backward routes dout to every input equal to its output. */
+int btc_maxpool_fwd(const float* feat, const int32_t* nbr_out, int n_out, int K, int C, float* out, void* stream);
+int btc_maxpool_bwd(const float* feat, const float* out, const float* dout, const int32_t* nbr_in, int n_in,
+                    int K, int C, float* din, void* stream);
+
+/* SparseConvTensor.dense() (height_compression.py:21, occ_head_3D.py:46,51):
+ * dense (B,C,D,H,W) must be zero-filled by the caller; backward gathers the active cells. */
+int btc_dense_fwd(const float* feat, const int32_t* indices, int n, int C, const int32_t* h_shape, float* dense,
+                  void* stream);
+int btc_dense_bwd(const float* ddense, const int32_t* indices, int n, int C, const int32_t* h_shape, float* dfeat,
+                  void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Sorted-unique re-voxelization.  Replaces torch.unique(coords, dim=0, sorted=True,
+ * return_inverse, return_counts) + sort + scatter-pad of PassOccVox
+ * (/root/reference/btcdet/models/occ_pnt/add_occ_template.py:248-268): points with integer cell
+ * coords [b,z,y,x] are grouped per cell, cells ascending in (b,z,y,x), points of a cell in input order.
+ *   phase 1: *d_m = number of cells, *d_pmax = max points per cell       (4+4 byte read-back)
+ *   phase 2: voxels (m,pmax,C) zero padded, vcoords (m,4) int64, vnum (m) int64
+ * ws: btc_revoxelize_ws_bytes(n, batch, shape).
+ * ---------------------------------------------------------------------------------------------- */
+size_t btc_revoxelize_ws_bytes(int n, int batch, const int32_t* h_shape);
+int btc_revoxelize_count(const int64_t* coords, int n, int batch, const int32_t* h_shape, int32_t* d_m,
+                         int32_t* d_pmax, void* ws, size_t ws_bytes, void* stream);
+int btc_revoxelize_fill(const float* points, const int64_t* coords, int n, int C, int batch,
+                        const int32_t* h_shape, int m, int pmax, float* voxels, int64_t* vcoords,
+                        int64_t* vnum, void* ws, size_t ws_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BTCDET_HIP_H */

@@ -220,3 +220,23 @@ def dense(feat, indices, batch_size, shape):
     out = np.empty((batch_size, feat.shape[1], int(sh[0]), int(sh[1]), int(sh[2])), dtype=np.float32)
     lib().orc_dense(_fp(feat), _ip(indices), feat.shape[0], feat.shape[1], batch_size, _ip(sh), _fp(out))
     return out
+
+
+# ------------------------------------------------------------------ PassOccVox re-voxelization
+def revoxelize(points, coords):
+    """Restatement of combine_gt_occ_voxel_point + voxelize_pad
+    (/root/reference/btcdet/models/occ_pnt/add_occ_template.py:248-268): unique cells sorted
+    lexicographically in (b,z,y,x), points of a cell in input order (stable), zero padded to the
+    largest cell.  Returns voxels (M,Pmax,C) f32, num (M,) i64, vcoords (M,4) i64."""
+    coords = np.asarray(coords, dtype=np.int64)
+    points = np.asarray(points, dtype=np.float32)
+    if coords.shape[0] == 0:
+        return np.zeros((0, 0, points.shape[1]), np.float32), np.zeros((0,), np.int64), np.zeros((0, 4), np.int64)
+    uniq, inv, cnt = np.unique(coords, axis=0, return_inverse=True, return_counts=True)
+    inv = inv.reshape(-1)
+    order = np.argsort(inv, kind="stable")
+    start = np.concatenate([[0], np.cumsum(cnt)[:-1]])
+    slot = np.arange(coords.shape[0]) - start[inv[order]]
+    vox = np.zeros((uniq.shape[0], int(cnt.max()), points.shape[1]), np.float32)
+    vox[inv[order], slot] = points[order]
+    return vox, cnt.astype(np.int64), uniq.astype(np.int64)

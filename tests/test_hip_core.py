@@ -1,0 +1,258 @@
+"""GPU parity tests of the HIP hot path against the CPU oracle, through the C ABI (ctypes).
+Bit-exact for voxel indices / rulebooks / fwd+dgrad features (identical fmaf chain); stated fp32
+tolerance for wgrad (split-K partial sums)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def rand_indices(rng, n, batch, shape):
+    vol = int(np.prod(shape))
+    lin = rng.choice(batch * vol, size=min(n, batch * vol), replace=False)
+    b, rem = lin // vol, lin % vol
+    z, rem = rem // (shape[1] * shape[2]), rem % (shape[1] * shape[2])
+    y, x = rem // shape[2], rem % shape[2]
+    return np.stack([b, z, y, x], axis=1).astype(np.int32)
+
+
+# ------------------------------------------------------------------ voxelizer
+def _check_voxelizer(points_list, vsize, rng_range, max_pts, max_vox):
+    from btcdet_amd.spconv import utils
+    gen = utils.VoxelGeneratorV2(vsize, rng_range, max_pts, max_vox)
+    ogen = orc.VoxelGeneratorV2(vsize, rng_range, max_pts, max_vox)
+    assert list(gen.grid_size) == list(ogen.grid_size)
+    pts = np.concatenate(points_list, axis=0).astype(np.float32)
+    offs = np.cumsum([0] + [p.shape[0] for p in points_list]).astype(np.int32)
+    v, c, n = gen.generate_batch(torch.from_numpy(pts).to(dev()), torch.from_numpy(offs).to(dev()))
+    v, c, n = v.cpu().numpy(), c.cpu().numpy(), n.cpu().numpy()
+    row = 0
+    for b, p in enumerate(points_list):
+        r = ogen.generate(p)
+        m = r["voxel_num"]
+        np.testing.assert_array_equal(c[row:row + m, 0], b)
+        np.testing.assert_array_equal(c[row:row + m, 1:], r["coordinates"])
+        np.testing.assert_array_equal(n[row:row + m], r["num_points_per_voxel"])
+        np.testing.assert_array_equal(v[row:row + m], r["voxels"])
+        row += m
+    assert row == v.shape[0]
+
+
+def test_voxelizer_known_answer_and_caps():
+    pts = np.array([[0.5, 0.5, 0.5, 10], [3.5, 2.5, 1.5, 11], [0.6, 0.4, 0.1, 12], [0.7, 0.7, 0.7, 13], [4.0, 0.0, 0.0, 14],
+                    [-0.01, 0.0, 0.0, 15], [1.5, 0.5, 0.5, 16], [2.5, 0.5, 0.5, 17], [1.2, 0.2, 0.2, 18],
+                    [2.6, 0.5, 0.5, 19]], dtype=np.float32)
+    _check_voxelizer([pts], [1.0, 1.0, 1.0], [0, 0, 0, 4, 3, 2], 2, 3)
+    _check_voxelizer([pts, pts[::-1].copy(), pts[:0]], [1.0, 1.0, 1.0], [0, 0, 0, 4, 3, 2], 2, 3)
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_voxelizer_random_dense_cells(seed):
+    rng = np.random.default_rng(seed)
+    # many points per cell (exercises the atomicMin cascade and the max_points cut) and a tight voxel cap
+    scenes = [rng.uniform(-0.5, 10.5, (n, 5)).astype(np.float32) for n in (5000, 1, 3000)]
+    _check_voxelizer(scenes, [1.0, 0.5, 2.0], [0, 0, 0, 10, 10, 10], 7, 150)
+    _check_voxelizer(scenes, [0.25, 0.25, 0.25], [0, 0, 0, 10, 10, 10], 3, 100000)
+
+
+def test_voxelizer_kitti_scene_both_grids():
+    from btcdet_amd import synth
+    b = synth.make_batch([1000, 1001])
+    scenes = [s["points"] for s in b["scenes"]]
+    _check_voxelizer(scenes, synth.KITTI_DET_VOXEL, synth.KITTI_DET_RANGE, 5, 16000)
+    cyl = [orc.absxyz_2_cylinxyz_np(s["pre_rot_points"]) for s in b["scenes"]]
+    _check_voxelizer(cyl, synth.KITTI_OCC_VOXEL, synth.KITTI_OCC_RANGE, 12, 20000)
+
+
+def test_cart_to_cylinder_and_sphere():
+    from btcdet_amd import _lib, synth
+    p = synth.make_scene(7)["points"]
+    x = torch.from_numpy(p).to(dev())
+    for mode, fn in ((1, orc.absxyz_2_cylinxyz_np), (2, orc.absxyz_2_spherexyz_np)):
+        out = torch.empty_like(x)
+        _lib.check(_lib.lib().btc_cart_to_occ_coords(_lib.ptr(x), _lib.ptr(out), x.shape[0], x.shape[1], mode,
+                                                     _lib.stream_ptr()), "cart")
+        ref = fn(p)
+        # fp32 transcendental (atan2f device vs libm): tolerance 2e-6 relative / 2e-5 deg absolute
+        np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=2e-6, atol=2e-5)
+        np.testing.assert_array_equal(out.cpu().numpy()[:, 3], p[:, 3])
+
+
+# ------------------------------------------------------------------ rulebook
+RB_CASES = [
+    ((9, 15, 13), (3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 1, 1), "conv"),
+    ((9, 15, 13), (3, 3, 3), (2, 2, 2), (1, 1, 1), (1, 1, 1), "conv"),
+    ((11, 16, 12), (3, 3, 3), (2, 2, 2), (0, 1, 1), (1, 1, 1), "conv"),
+    ((5, 10, 8), (3, 1, 1), (2, 1, 1), (0, 0, 0), (1, 1, 1), "conv"),
+    ((2, 10, 8), (2, 1, 1), (2, 1, 1), (0, 0, 0), (1, 1, 1), "conv"),
+    ((6, 12, 12), (3, 3, 3), (1, 2, 2), (1, 1, 1), (1, 1, 1), "conv"),
+    ((8, 9, 10), (3, 3, 3), (1, 1, 1), (2, 2, 2), (2, 2, 2), "conv"),
+    ((3, 8, 7), (3, 3, 3), (2, 2, 2), (1, 1, 1), (1, 1, 1), "transpose"),
+    ((4, 5, 6), (2, 2, 2), (2, 2, 2), (0, 0, 0), (1, 1, 1), "transpose"),
+    ((7, 12, 11), (3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 1, 1), "subm"),
+    ((7, 12, 11), (1, 3, 3), (1, 1, 1), (0, 1, 1), (1, 1, 1), "subm"),
+    ((7, 12, 11), (3, 3, 3), (1, 1, 1), (0, 0, 0), (1, 2, 2), "subm"),
+]
+
+
+def _rb_both(idx, B, shape, k, s, p, d, kind):
+    from btcdet_amd.spconv import ops
+    mode = {"conv": orc.MODE_CONV, "transpose": orc.MODE_TRANSPOSE, "subm": orc.MODE_SUBM}[kind]
+    o_idx, o_out, o_in, o_sh = orc.rulebook(idx, shape, k, s, p, d, mode)
+    rb = ops.build_rulebook(torch.from_numpy(idx).to(dev()), B, shape, k, s, p, d, 0, kind == "subm", kind == "transpose")
+    return (o_idx, o_out, o_in, o_sh), rb
+
+
+@pytest.mark.parametrize("shape,k,s,p,d,kind", RB_CASES)
+def test_rulebook_bit_exact(shape, k, s, p, d, kind):
+    rng = np.random.default_rng(5)
+    B = 3
+    idx = rand_indices(rng, 400, B, shape)
+    (o_idx, o_out, o_in, o_sh), rb = _rb_both(idx, B, shape, k, s, p, d, kind)
+    assert list(rb.out_shape) == list(o_sh)
+    np.testing.assert_array_equal(rb.out_indices.cpu().numpy(), o_idx)
+    np.testing.assert_array_equal(rb.nbr_out.cpu().numpy(), o_out)
+    np.testing.assert_array_equal(rb.nbr_in.cpu().numpy(), o_in)
+    # spconv-layout view == canonical pair lists
+    pairs, num = rb.indice_pairs()
+    pairs, num = pairs.cpu().numpy(), num.cpu().numpy()
+    cp, cn = orc.canonical_pairs(o_out)
+    np.testing.assert_array_equal(num, cn)
+    for kk in range(len(cp)):
+        np.testing.assert_array_equal(pairs[:, kk, :cn[kk]], cp[kk])
+        assert np.all(pairs[:, kk, cn[kk]:] == -1)
+
+
+def test_rulebook_empty_and_single():
+    from btcdet_amd.spconv import ops
+    for n in (0, 1):
+        idx = np.array([[0, 1, 2, 3]], np.int32)[:n]
+        for kind in ("subm", "conv"):
+            rb = ops.build_rulebook(torch.from_numpy(idx).to(dev()).reshape(-1, 4), 1, (4, 6, 8), 3, 2 if kind == "conv" else 1, 1, 1, 0,
+                                    kind == "subm", False)
+            o_idx, o_out, o_in, _ = orc.rulebook(idx.reshape(-1, 4), (4, 6, 8), 3, 2 if kind == "conv" else 1, 1, 1,
+                                                  orc.MODE_SUBM if kind == "subm" else orc.MODE_CONV)
+            np.testing.assert_array_equal(rb.out_indices.cpu().numpy(), o_idx)
+            np.testing.assert_array_equal(rb.nbr_out.cpu().numpy(), o_out)
+
+
+def test_rulebook_kitti_level_shapes_and_row_alignment():
+    """conv2 and the max-pool on the same geometry must emit identical output rows (sparse_cat,
+    spconv_backbone.py:869-873,972-974); both equal the oracle."""
+    from btcdet_amd import synth
+    from btcdet_amd.spconv import ops
+    b = synth.make_batch([1000, 1001])
+    og = orc.VoxelGeneratorV2(synth.KITTI_DET_VOXEL, synth.KITTI_DET_RANGE, 5, 16000)
+    idx = np.concatenate([np.pad(og.generate(s["points"])["coordinates"], ((0, 0), (1, 0)), constant_values=i)
+                          for i, s in enumerate(b["scenes"])]).astype(np.int32)
+    shape = [41, 1600, 1408]
+    t = torch.from_numpy(idx).to(dev())
+    rb1 = ops.build_rulebook(t, 2, shape, 3, 2, 1, 1, 0, False, False)
+    rb2 = ops.build_rulebook(t, 2, shape, 3, 2, 1, 1, 0, False, False)
+    assert torch.equal(rb1.out_indices, rb2.out_indices) and torch.equal(rb1.nbr_out, rb2.nbr_out)
+    o_idx, o_out, o_in, o_sh = orc.rulebook(idx, shape, 3, 2, 1, 1, orc.MODE_CONV)
+    assert list(o_sh) == [21, 800, 704]
+    np.testing.assert_array_equal(rb1.out_indices.cpu().numpy(), o_idx)
+    np.testing.assert_array_equal(rb1.nbr_out.cpu().numpy(), o_out)
+    np.testing.assert_array_equal(rb1.nbr_in.cpu().numpy(), o_in)
+    rbs = ops.build_rulebook(t, 2, shape, 3, 1, 1, 1, 0, True, False)
+    s_idx, s_out, s_in, _ = orc.rulebook(idx, shape, 3, 1, 0, 1, orc.MODE_SUBM)
+    np.testing.assert_array_equal(rbs.nbr_out.cpu().numpy(), s_out)
+    np.testing.assert_array_equal(rbs.nbr_in.cpu().numpy(), s_in)
+
+
+# ------------------------------------------------------------------ conv apply
+APPLY_CASES = [(4, 16), (6, 16), (16, 16), (16, 32), (34, 32), (32, 64), (64, 64), (64, 128), (256, 128), (128, 128), (32, 2), (32, 3), (2, 2), (20, 150)]
+
+
+@pytest.mark.parametrize("cin,cout", APPLY_CASES)
+@pytest.mark.parametrize("kind", ["subm", "conv"])
+def test_conv_fwd_bwd_vs_oracle(cin, cout, kind):
+    from btcdet_amd.spconv import ops
+    rng = np.random.default_rng(cin * 1000 + cout)
+    shape, B = (8, 20, 18), 2
+    n = 700 if cin * cout <= 64 * 64 else 300
+    idx = rand_indices(rng, n, B, shape)
+    k, s, p = (3, 3, 3), ((1, 1, 1) if kind == "subm" else (2, 2, 2)), (1, 1, 1)
+    (o_idx, o_out, o_in, o_sh), rb = _rb_both(idx, B, shape, k, s, p, (1, 1, 1), kind)
+    feat = rng.standard_normal((idx.shape[0], cin)).astype(np.float32)
+    W = (rng.standard_normal((3, 3, 3, cin, cout)) / np.sqrt(cin)).astype(np.float32)
+    bias = rng.standard_normal(cout).astype(np.float32) if cout % 2 == 0 else None
+    dout = rng.standard_normal((o_idx.shape[0], cout)).astype(np.float32)
+
+    f = torch.from_numpy(feat).to(dev()).requires_grad_(True)
+    w = torch.from_numpy(W).to(dev()).requires_grad_(True)
+    bt = None if bias is None else torch.from_numpy(bias).to(dev()).requires_grad_(True)
+    out = ops.indice_conv(f, w, bt, rb)
+    out.backward(torch.from_numpy(dout).to(dev()))
+
+    ref = orc.conv_fwd(feat, W, bias, o_out)
+    np.testing.assert_array_equal(out.detach().cpu().numpy(), ref)            # same fmaf chain: bit-exact
+    ref_din = orc.conv_dgrad(dout, W, o_in)
+    np.testing.assert_array_equal(f.grad.cpu().numpy(), ref_din)               # bit-exact
+    ref_dw = orc.conv_wgrad(feat, dout, o_out, W.shape)
+    # wgrad: fp32 partial sums over row splits vs a double-precision reference: rtol 1e-4 of the scale
+    scale = np.abs(ref_dw).max() + 1e-6
+    assert np.abs(w.grad.cpu().numpy() - ref_dw).max() <= 1e-4 * scale
+    if bias is not None:
+        np.testing.assert_allclose(bt.grad.cpu().numpy(), dout.sum(0), rtol=1e-4, atol=1e-4)
+
+
+def test_inverse_conv_matches_oracle():
+    from btcdet_amd.spconv import ops
+    rng = np.random.default_rng(9)
+    shape, B, cin, cout = (8, 12, 10), 2, 16, 8
+    idx = rand_indices(rng, 300, B, shape)
+    (o_idx, o_out, o_in, o_sh), rb = _rb_both(idx, B, shape, (3, 3, 3), (2, 2, 2), (1, 1, 1), (1, 1, 1), "conv")
+    feat = rng.standard_normal((o_idx.shape[0], cin)).astype(np.float32)   # lives on the conv's OUTPUT rows
+    W = rng.standard_normal((3, 3, 3, cin, cout)).astype(np.float32)
+    out = ops.indice_conv(torch.from_numpy(feat).to(dev()), torch.from_numpy(W).to(dev()), None, rb, inverse=True)
+    ref = orc.conv_fwd(feat, W, None, o_in)                                 # map = nbr_in (roles swapped)
+    np.testing.assert_array_equal(out.cpu().numpy(), ref)
+
+
+def test_maxpool_and_dense():
+    from btcdet_amd.spconv import ops
+    rng = np.random.default_rng(11)
+    shape, B, C = (9, 14, 12), 2, 2
+    idx = rand_indices(rng, 500, B, shape)
+    (o_idx, o_out, o_in, o_sh), rb = _rb_both(idx, B, shape, (3, 3, 3), (2, 2, 2), (1, 1, 1), (1, 1, 1), "conv")
+    feat = (rng.random((idx.shape[0], C)) - 0.2).astype(np.float32)
+    feat[rng.random(feat.shape) < 0.3] = 0.5  # ties
+    f = torch.from_numpy(feat).to(dev()).requires_grad_(True)
+    out = ops.indice_maxpool(f, rb)
+    ref = orc.maxpool_fwd(feat, o_out)
+    np.testing.assert_array_equal(out.detach().cpu().numpy(), ref)
+    dout = rng.standard_normal(ref.shape).astype(np.float32)
+    out.backward(torch.from_numpy(dout).to(dev()))
+    np.testing.assert_allclose(f.grad.cpu().numpy(), orc.maxpool_bwd(feat, ref, dout, o_in), rtol=1e-6, atol=1e-6)
+    # dense fwd / bwd
+    f2 = torch.from_numpy(feat).to(dev()).requires_grad_(True)
+    d = ops.ToDenseFunction.apply(f2, torch.from_numpy(idx).to(dev()), B, list(shape))
+    np.testing.assert_array_equal(d.detach().cpu().numpy(), orc.dense(feat, idx, B, shape))
+    g = rng.standard_normal(tuple(d.shape)).astype(np.float32)
+    d.backward(torch.from_numpy(g).to(dev()))
+    np.testing.assert_array_equal(f2.grad.cpu().numpy(), g[idx[:, 0], :, idx[:, 1], idx[:, 2], idx[:, 3]])
+
+
+def test_revoxelize_matches_oracle():
+    from btcdet_amd import _lib
+    rng = np.random.default_rng(13)
+    B, shape, C = 2, (40, 160, 140), 6
+    n = 5000
+    coords = np.stack([rng.integers(0, B, n), rng.integers(0, 4, n), rng.integers(0, 30, n), rng.integers(0, 30, n)], 1).astype(np.int64)
+    pts = rng.standard_normal((n, C)).astype(np.float32)
+    from btcdet_amd.pass_occ_vox import revoxelize
+    v, num, vc = revoxelize(torch.from_numpy(pts).to(dev()), torch.from_numpy(coords).to(dev()), B, shape)
+    rv, rnum, rvc = orc.revoxelize(pts, coords)
+    np.testing.assert_array_equal(vc.cpu().numpy(), rvc)
+    np.testing.assert_array_equal(num.cpu().numpy(), rnum)
+    np.testing.assert_array_equal(v.cpu().numpy(), rv)
+    assert vc.dtype == torch.int64 and num.dtype == torch.int64
