@@ -1,0 +1,285 @@
+"""Sparse 3-D backbones of BtcDet's two branches, built on btcdet_amd.spconv.
+
+Mirrors (same constructor protocol, attribute / parameter names, layer graph, channel / stride /
+padding / indice_key tables -- so reference checkpoints load key-for-key):
+  * ``post_act_block``      /root/reference/btcdet/models/backbones_3d/spconv_backbone.py:7-43
+  * ``VoxelBackBoneDeconv`` spconv_backbone.py:91-203   (occupancy branch)
+  * ``VoxelBackBone8xOcc``  spconv_backbone.py:630-1019 (detection branch)
+The graphs are written as layer tables; every sparse layer is one fused HIP launch (sparse_conv.hip).
+"""
+from functools import partial
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import spconv
+
+
+def post_act_block(in_channels, out_channels, kernel_size, indice_key=None, stride=1, padding=0, conv_type='subm',
+                   norm_fn=None, defaultvalue=1.0, activation=nn.ReLU):
+    """conv (+ norm + activation) as one SparseSequential; conv_type selects the sparse layer."""
+    if conv_type == 'subm':
+        conv = spconv.SubMConv3d(in_channels, out_channels, kernel_size, bias=False, indice_key=indice_key)
+    elif conv_type == 'subm2d':
+        conv = spconv.SubMConv2d(in_channels, out_channels, kernel_size, bias=False, indice_key=indice_key)
+    elif conv_type == 'spconv':
+        conv = spconv.SparseConv3d(in_channels, out_channels, kernel_size, stride=stride, padding=padding, bias=False,
+                                   indice_key=indice_key)
+    elif conv_type == 'fixspconv':
+        conv = fixSparseConv3d(in_channels, out_channels, kernel_size, stride=stride, padding=padding, bias=False,
+                               indice_key=indice_key, defaultvalue=defaultvalue)
+        conv.requires_grad_(False)
+    elif conv_type == 'spdeconv':
+        conv = spconv.SparseConvTranspose3d(in_channels, out_channels, kernel_size, stride=stride, padding=padding,
+                                            bias=False, indice_key=indice_key)
+    elif conv_type == 'inverseconv':
+        conv = spconv.SparseInverseConv3d(in_channels, out_channels, kernel_size, indice_key=indice_key, bias=False)
+    elif conv_type == 'submbias':
+        conv = spconv.SubMConv3d(in_channels, out_channels, kernel_size, bias=True, indice_key=indice_key)
+    elif conv_type == 'maxpool':
+        conv = spconv.SparseMaxPool3d(kernel_size, stride=stride, padding=padding)
+    else:
+        raise NotImplementedError(conv_type)
+    if norm_fn is not None:
+        return spconv.SparseSequential(conv, norm_fn(out_channels), activation())
+    return spconv.SparseSequential(conv)
+
+
+class fixSparseConv3d(spconv.SparseConv3d):
+    """constant-weight sparse conv (spconv_backbone.py:45-48)"""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, bias=False, indice_key=None,
+                 defaultvalue=1.0):
+        super(fixSparseConv3d, self).__init__(in_channels, out_channels, kernel_size, stride=stride, padding=padding,
+                                              bias=bias, indice_key=indice_key)
+        self.weight.data.fill_(defaultvalue)
+
+
+def _seq(specs, norm_fn):
+    """specs: list of (cin, cout, k, dict(kwargs)) -> SparseSequential of post_act_blocks"""
+    return spconv.SparseSequential(*[post_act_block(ci, co, k, norm_fn=norm_fn, **kw) for ci, co, k, kw in specs])
+
+
+class VoxelBackBoneDeconv(nn.Module):
+    """Occupancy-branch encoder/decoder: [9,157,209] -> /2 -> /4 -> x2 -> x2, 32 output channels."""
+
+    def __init__(self, model_cfg, input_channels, grid_size, **kwargs):
+        super().__init__()
+        self.model_cfg = model_cfg
+        self.y_shift = model_cfg.get("SHIFT", 0)
+        norm_fn = partial(nn.BatchNorm1d, eps=1e-3, momentum=0.01)
+        self.sparse_shape = grid_size[::-1]  # numpy view of the dataset's grid, as in the reference (App. D.10)
+        self.sparse_shape[1] += self.y_shift * 2
+        c = [16, 32, 64]
+        sp = dict(padding=1, conv_type='spconv')
+        self.conv1 = spconv.SparseSequential(post_act_block(input_channels, c[0], 3, norm_fn=norm_fn, indice_key='spconv1', **sp))
+        self.conv2 = _seq([(c[0], c[1], 3, dict(stride=2, indice_key='spconv2', **sp)),
+                           (c[1], c[1], 3, dict(padding=1, indice_key='subm2'))], norm_fn)
+        self.conv3 = _seq([(c[1], c[2], 3, dict(stride=2, indice_key='spconv3', **sp)),
+                           (c[2], c[2], 3, dict(padding=1, indice_key='subm3'))], norm_fn)
+        self.deconv4 = _seq([(c[2], c[1], 3, dict(stride=2, padding=1, indice_key='spconv4', conv_type='spdeconv')),
+                             (c[1], c[1], 3, dict(padding=1, indice_key='subm4'))], norm_fn)
+        self.deconv5 = _seq([(c[1], c[1], 3, dict(stride=2, padding=1, indice_key='spconv5', conv_type='spdeconv')),
+                             (c[1], c[1], 3, dict(padding=1, indice_key='subm5'))], norm_fn)
+        self.num_point_features = c[1]
+
+    def forward(self, batch_dict):
+        voxel_features, voxel_coords = batch_dict['voxel_features'], batch_dict['voxel_coords'].int()
+        if self.y_shift > 0:
+            voxel_features, voxel_coords = self.add_shift(voxel_features, voxel_coords)
+        x = spconv.SparseConvTensor(features=voxel_features, indices=voxel_coords, spatial_shape=self.sparse_shape,
+                                    batch_size=batch_dict['batch_size'])
+        for stage in (self.conv1, self.conv2, self.conv3, self.deconv4, self.deconv5):
+            x = stage(x)
+        if self.y_shift > 0:
+            x = self.remove_shift(x)
+        batch_dict.update({'encoded_spconv_tensor': x, 'encoded_spconv_tensor_stride': 1})
+        return batch_dict
+
+    # azimuth wrap-around padding (SHIFT, off in the configured model)
+    def add_shift(self, voxel_features, voxel_coords):
+        y_max = self.sparse_shape[1] - 2 * self.y_shift
+        left = voxel_coords[..., 2] < self.y_shift
+        right = voxel_coords[..., 2] >= (y_max - self.y_shift)
+        lc, rc = voxel_coords[left, :].clone(), voxel_coords[right, :].clone()
+        rc[..., 2] -= y_max
+        lc[..., 2] += y_max
+        feats = torch.cat([voxel_features[right, :], voxel_features, voxel_features[left, :]], dim=0)
+        coords = torch.cat([rc, voxel_coords, lc], dim=0)
+        coords[..., 2] += self.y_shift
+        return feats, coords
+
+    def remove_shift(self, x):
+        y_max = self.sparse_shape[1] - 2 * self.y_shift
+        x.indices[..., 2] -= self.y_shift
+        keep = (x.indices[..., 2] >= 0) & (x.indices[..., 2] < y_max)
+        x.features, x.indices = x.features[keep, :], x.indices[keep, :]
+        x.spatial_shape[1] -= self.y_shift * 2
+        return x
+
+
+class VoxelBackBone8xOcc(nn.Module):
+    """Detection-branch 8x backbone that also consumes the occupancy code channels."""
+
+    def __init__(self, model_cfg, input_channels, grid_size, **kwargs):
+        super().__init__()
+        self.model_cfg = model_cfg
+        norm_fn = partial(nn.BatchNorm1d, eps=1e-3, momentum=0.01)
+        self.sparse_shape = grid_size[::-1] + [1, 0, 0]
+        self.occ_conv_type = self.model_cfg.OCC_CONV_TYPE
+        self.occ_conv_exec = self.model_cfg.OCC_CONV_EXECUTE
+        self.out_feat_type = getattr(self.model_cfg, "OUT_FEAT_TYPE", ["None", "None", "None", "None", "combine"])
+        self.out_att = getattr(self.model_cfg, "OCC_ATT", [False, False, False, False])
+        c = [16, 32, 64, 64, 128]
+        self.occ_code_num = input_channels - kwargs["original_num_rawpoint_features"]
+        add = [self.occ_code_num if t else 0 for t in self.occ_conv_exec] + [0] * (4 - len(self.occ_conv_exec))
+
+        for i in range(1, len(self.occ_conv_exec)):
+            self._build_occ_net(self.occ_conv_type[i], i)
+        for i in range(len(self.occ_conv_exec)):
+            if self.out_att[i]:
+                ch = c[i] + add[i]
+                setattr(self, 'att_conv%d' % (i + 1), spconv.SparseSequential(post_act_block(
+                    ch, ch, 3, norm_fn=norm_fn, stride=1, padding=1, indice_key='subm%d' % (i + 1), activation=nn.LeakyReLU)))
+
+        self.conv1 = spconv.SparseSequential(
+            spconv.SubMConv3d(input_channels, c[0], 3, padding=1, bias=False, indice_key='subm1'), norm_fn(c[0]), nn.ReLU())
+        self.conv1_combine = _seq([(c[0] + add[0], c[0], 3, dict(padding=1, indice_key='subm1'))], norm_fn)
+        down = [None, dict(stride=2, padding=1, indice_key='spconv2', conv_type='spconv'),
+                dict(stride=2, padding=1, indice_key='spconv3', conv_type='spconv'),
+                dict(stride=2, padding=(0, 1, 1), indice_key='spconv4', conv_type='spconv')]
+        for lvl in (1, 2, 3):
+            setattr(self, 'conv%d' % (lvl + 1), _seq([(c[lvl - 1], c[lvl], 3, down[lvl])], norm_fn))
+            key = 'subm%d' % (lvl + 1)
+            setattr(self, 'conv%d_combine' % (lvl + 1),
+                    _seq([(c[lvl] + add[lvl], c[lvl], 3, dict(padding=1, indice_key=key)),
+                          (c[lvl], c[lvl], 3, dict(padding=1, indice_key=key))], norm_fn))
+        last_pad = self.model_cfg.get('last_pad', 0)
+        self.conv_out = spconv.SparseSequential(
+            spconv.SparseConv3d(c[3], c[4], (3, 1, 1), stride=(2, 1, 1), padding=last_pad, bias=False,
+                                indice_key='spconv_down2'), norm_fn(c[4]), nn.ReLU())
+        self.num_point_features = 128
+
+        for i in range(4):
+            if self.out_feat_type[i] == "2D":
+                ch = c[i] * [41, 21, 11, 5][i]
+                setattr(self, 'squeeze_z_conv%d' % (i + 1), spconv.SparseSequential(post_act_block(
+                    ch, ch // 2, 3, norm_fn=norm_fn, padding=1, indice_key='submsqueez%d' % (i + 1), conv_type='subm2d')))
+        self._build_combine_net(norm_fn, c, self.out_feat_type[4])
+
+    def _build_occ_net(self, kind, i):
+        """occupancy-code side branch at level i (1..3): maxpool / learned / fixed-mean / avg (spconv_backbone.py:793-866)"""
+        n = self.occ_code_num
+        key = 'spconv%d' % (i + 1)
+        pad = 1 if i < 3 else (1, 1, 1)
+        kw = {'maxpool': dict(k=3, conv_type='maxpool'), 'weight': dict(k=3, conv_type='spconv'),
+              'fix': dict(k=3, conv_type='fixspconv', defaultvalue=1.0 / 27),
+              'avgpool': dict(k=2, conv_type='fixspconv', defaultvalue=1)}[kind]
+        k = kw.pop('k')
+        setattr(self, 'occ_conv%d' % (i + 1), spconv.SparseSequential(
+            post_act_block(n, n, k, norm_fn=None, stride=2, padding=pad, indice_key=key, **kw)))
+
+    def _build_combine_net(self, norm_fn, c, comb_type):
+        sp = dict(stride=2, conv_type='spconv')
+        self.down2 = _seq([(c[1], c[1], 3, dict(padding=1, indice_key='spconv3', **sp)),
+                           (c[1], c[2], 3, dict(padding=(0, 1, 1), indice_key='spconv4', **sp))], norm_fn)
+        self.down3 = _seq([(c[2], c[2], 3, dict(padding=(0, 1, 1), indice_key='spconv4', **sp))], norm_fn)
+        cat = c[2] * 2 + c[3]
+        if comb_type == "big_combine":
+            self.down_combine = _seq([(cat, c[3] * 2, 3, dict(padding=1, indice_key='subm4')),
+                                      (c[3] * 2, c[3] * 2, 3, dict(padding=1, indice_key='subm4'))], norm_fn)
+        elif comb_type == "combine":
+            self.down_combine = _seq([(cat, c[3] * 2, 3, dict(padding=1, indice_key='subm4')),
+                                      (c[3] * 2, c[3] * 2, 3, dict(stride=[1, 2, 2], padding=(1, 1, 1), indice_key='spconv5',
+                                                                   conv_type='spconv')),
+                                      (c[3] * 2, c[3] * 2, 3, dict(padding=1, indice_key='subm5'))], norm_fn)
+        elif comb_type == "big_bev_combine":
+            self.squeezeBev = _seq([(c[4], c[3], (2, 1, 1), dict(stride=(2, 1, 1), padding=0, indice_key='subm_down2',
+                                                                  conv_type='spconv'))], norm_fn)
+            self.down_combine = _seq([(cat + c[3], c[3] * 2, 3, dict(padding=1, indice_key='subm4')),
+                                      (c[3] * 2, c[3] * 2, 3, dict(padding=1, indice_key='subm4'))], norm_fn)
+
+    @staticmethod
+    def sparse_cat(input_lst):
+        # rows of both tensors are aligned because both rulebooks emit outputs in (b,z,y,x) order
+        xrep, xocc = input_lst
+        xrep.features = torch.cat((xrep.features, xocc.features), dim=1)
+        return xrep
+
+    @staticmethod
+    def apply_att(x, att_conv):
+        a = att_conv(x)
+        x.features = x.features * a.features + x.features
+        return x
+
+    def suqeeze(self, feat, i, kind):
+        if kind == "None":
+            return None
+        if kind == "3D":
+            return feat
+        conv = getattr(self, "squeeze_z_conv{}".format(i), None)
+        dense = feat.dense()
+        B, C, Z, Y, X = list(dense.shape)
+        inds = torch.unique(torch.cat([feat.indices[..., 0:1], feat.indices[..., 2:]], dim=-1), dim=0).long()
+        pix = dense.reshape(B, C * Z, Y, X)[inds[..., 0], :, inds[..., 1], inds[..., 2]]
+        return conv(spconv.SparseConvTensor(features=pix, indices=inds.int(), spatial_shape=[Y, X], batch_size=B)).dense()
+
+    @staticmethod
+    def compress_height(t):
+        d = t.dense()
+        N, C, D, H, W = d.shape
+        return d.view(N, C * D, H, W)
+
+    def res_combine(self, x2, x3, x4, bev, out_feat_type="combine"):
+        if getattr(self, "down3", None) is None:
+            return None
+        x2, x3 = self.down2(x2), self.down3(x3)
+        x4.features = torch.cat((x2.features, x3.features, x4.features), dim=1)
+        if out_feat_type == "big_bev_combine":
+            bev2d = self.compress_height(self.squeezeBev(bev))
+            inds = x4.indices.long()
+            x4.features = torch.cat((x4.features, bev2d[inds[..., 0], :, inds[..., 2], inds[..., 3]]), dim=1)
+        return self.down_combine(x4)
+
+    def forward(self, batch_dict):
+        feats, coords = batch_dict['voxel_features'], batch_dict['voxel_coords'].int()
+        bs = batch_dict['batch_size']
+        x = spconv.SparseConvTensor(features=feats, indices=coords, spatial_shape=self.sparse_shape, batch_size=bs)
+        n_occ = len(self.occ_conv_exec)
+        x1 = self.conv1(x)
+        occ = None
+        if n_occ > 0:
+            occ = spconv.SparseConvTensor(features=batch_dict["occ_voxel_features"], indices=coords,
+                                          spatial_shape=self.sparse_shape, batch_size=bs)
+            if self.occ_conv_exec[0]:
+                x1 = self.sparse_cat([x1, occ])
+                if self.out_att[0]:
+                    x1 = self.apply_att(x1, self.att_conv1)
+        x1 = self.conv1_combine(x1)
+        levels = [x1]
+        cur = x1
+        for lvl in (1, 2, 3):
+            cur = getattr(self, 'conv%d' % (lvl + 1))(cur)
+            if n_occ > lvl:
+                occ = getattr(self, 'occ_conv%d' % (lvl + 1))(occ)
+                if self.occ_conv_exec[lvl]:
+                    cur = self.sparse_cat([cur, occ])
+                    if self.out_att[lvl]:
+                        cur = self.apply_att(cur, getattr(self, 'att_conv%d' % (lvl + 1)))
+            cur = getattr(self, 'conv%d_combine' % (lvl + 1))(cur)
+            levels.append(cur)
+        x1, x2, x3, x4 = levels
+        out = self.conv_out(x4)
+        batch_dict.update({'encoded_spconv_tensor': out, 'encoded_spconv_tensor_stride': 8})
+        batch_dict.update({'multi_scale_3d_features': {
+            'x_conv1': self.suqeeze(x1, 1, self.out_feat_type[0]),
+            'x_conv2': self.suqeeze(x2, 2, self.out_feat_type[1]),
+            'x_conv3': self.suqeeze(x3, 3, self.out_feat_type[2]),
+            'x_conv4': self.suqeeze(x4, 4, self.out_feat_type[3]),
+            'x_combine': self.res_combine(x2, x3, x4, out, out_feat_type=self.out_feat_type[4]),
+        }})
+        return batch_dict
+
+
+__all__ = {'VoxelBackBoneDeconv': VoxelBackBoneDeconv, 'VoxelBackBone8xOcc': VoxelBackBone8xOcc}

@@ -1,0 +1,152 @@
+"""OccHead3D: occupancy probability / residual head of the occupancy branch and its losses.
+
+Mirrors /root/reference/btcdet/models/occ_pnt/occ_dense_heads/occ_head_3D.py:10-52 and
+occ_head_template.py:8-111 (masked focal / smooth-L1 means) with the loss functions of
+/root/reference/btcdet/utils/loss_utils.py:77-169 (softmax focal, eps 1e-6 as passed at :169) and
+:174-240 (smooth L1, beta = res_beta)."""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import spconv
+
+
+class SoftmaxFocalClassificationLoss(nn.Module):
+    def __init__(self, alpha=1.0, gamma=2.0, reduction='none'):
+        super().__init__()
+        self.alpha, self.gamma, self.reduction, self.eps = alpha, gamma, reduction, 1e-6
+
+    def forward(self, input, target, weights):
+        p = F.softmax(input, dim=1) + self.eps
+        focal = -self.alpha * torch.pow(-p + 1., self.gamma) * torch.log(p)
+        loss = torch.sum(target * focal, dim=1, keepdim=True)
+        return loss if weights is None else loss * weights
+
+
+class SigmoidFocalClassificationLoss(nn.Module):
+    def __init__(self, gamma=2.0, alpha=0.25):
+        super().__init__()
+        self.alpha, self.gamma = alpha, gamma
+
+    def forward(self, input, target, weights):
+        p = torch.sigmoid(input)
+        alpha_w = target * self.alpha + (1 - target) * (1 - self.alpha)
+        pt = target * (1.0 - p) + (1.0 - target) * p
+        bce = torch.clamp(input, min=0) - input * target + torch.log1p(torch.exp(-torch.abs(input)))
+        loss = alpha_w * torch.pow(pt, self.gamma) * bce
+        if weights is None:
+            return loss
+        if weights.dim() == 2 or (weights.dim() == 1 and target.dim() == 2):
+            weights = weights.unsqueeze(-1)
+        return loss * weights
+
+
+class WeightedSmoothL1Loss(nn.Module):
+    def __init__(self, beta=1.0 / 9.0, code_weights=None):
+        super().__init__()
+        self.beta = beta
+
+    def forward(self, input, target, weights=None):
+        target = torch.where(torch.isnan(target), input, target)
+        n = torch.abs(input - target)
+        loss = n if self.beta < 1e-5 else torch.where(n < self.beta, 0.5 * n ** 2 / self.beta, n - 0.5 * self.beta)
+        if weights is not None:
+            loss = loss * weights.unsqueeze(-1)
+        return loss
+
+
+class OccHeadTemplate(nn.Module):
+    def __init__(self, model_cfg, data_cfg, num_class, grid_size):
+        super().__init__()
+        self.data_cfg, self.model_cfg = data_cfg, model_cfg
+        head = self.model_cfg.OCC_DENSE_HEAD
+        self.noloss = bool(head.get("NOLOSS", None))
+        self.num_class = num_class
+        self.forward_ret_dict = {}
+        self.nx, self.ny, self.nz = grid_size
+        lw = head.LOSS_CONFIG.LOSS_WEIGHTS
+        self.occ_fore_res_weight = lw.get("occ_fore_res_weight", 0.1)
+        self.occ_fore_cls_weight = lw.get("occ_fore_cls_weight", 1.0)
+        self.res_num_dim = data_cfg.OCC.RES_NUM_DIM
+        self.reg = model_cfg.PARAMS.get("REG", False)
+        self.build_losses(head.LOSS_CONFIG)
+
+    def prepare_loss_map(self, batch_dict):
+        return batch_dict
+
+    def build_losses(self, losses_cfg):
+        if self.noloss:
+            return
+        if self.is_softmax:
+            self.add_module('cls_loss_func', SoftmaxFocalClassificationLoss(alpha=1.0, gamma=2.0))
+        else:
+            self.add_module('cls_loss_func', SigmoidFocalClassificationLoss(alpha=losses_cfg.LOSS_WEIGHTS['cls_alpha'], gamma=2.0))
+        if self.reg:
+            self.add_module('reg_loss_func', WeightedSmoothL1Loss(beta=losses_cfg.LOSS_WEIGHTS['res_beta'],
+                                                                  code_weights=[1.0] * self.res_num_dim))
+
+    @staticmethod
+    def mean_masked_loss(pred, target, loss_func, loss_weight_float, mask=None):
+        """weighted mean of the per-cell loss over the cells of `mask` (occ_head_template.py:96-108)"""
+        inds = mask.nonzero() if mask is not None else (loss_weight_float > 1e-4).nonzero()
+        b, z, y, x = inds[:, 0], inds[:, 1], inds[:, 2], inds[:, 3]
+        w = loss_weight_float[b, :, z, y, x]
+        loss = loss_func(pred[b, :, z, y, x], target[b, :, z, y, x], weights=None) * w
+        return torch.sum(loss) / torch.clamp(torch.sum(w), min=1.0)
+
+    def get_cls_layer_loss(self, batch_dict):
+        w = batch_dict["general_cls_loss_mask_float"].unsqueeze(1)
+        logit = batch_dict['pred_occ_logit']
+        pos = batch_dict["pos_mask"].to(logit.dtype)
+        onehot = torch.stack([1.0 - pos, pos], dim=-1)
+        onehot = (onehot if self.is_softmax else onehot[..., 1:]).permute(0, 4, 1, 2, 3)
+        loss = self.mean_masked_loss(logit, onehot, self.cls_loss_func, w, mask=batch_dict['general_cls_loss_mask'])
+        loss = loss * self.occ_fore_cls_weight
+        return loss, {'occ_loss_cls': loss.item()}
+
+    def get_res_layer_loss(self, batch_dict):
+        w = batch_dict["general_reg_loss_mask_float"].unsqueeze(1)
+        loss = self.mean_masked_loss(batch_dict['pred_sem_residuals'], batch_dict['res_mtrx'], self.reg_loss_func, w,
+                                     mask=batch_dict["general_reg_loss_mask"]) * self.occ_fore_res_weight
+        return loss, {'occ_loss_res': loss.item()}
+
+    def get_loss(self, batch_dict):
+        if self.noloss:
+            return torch.tensor(0.0, device="cuda"), {}
+        occ_loss, tb_dict = self.get_cls_layer_loss(batch_dict)
+        if self.reg:
+            reg_loss, tb_res = self.get_res_layer_loss(batch_dict)
+            occ_loss = occ_loss + reg_loss
+            tb_dict.update(tb_res)
+        return occ_loss, tb_dict
+
+
+class OccHead3D(OccHeadTemplate):
+    def __init__(self, model_cfg, data_cfg, input_channels, num_class, grid_size):
+        lc = model_cfg.OCC_DENSE_HEAD.LOSS_CONFIG
+        self.is_softmax = lc.get("CLS_LOSS_TYPE", None) == "softmax"
+        super().__init__(model_cfg=model_cfg, data_cfg=data_cfg, num_class=num_class, grid_size=grid_size)
+        self.stride = int(model_cfg.BACKBONE_3D.STRIDE)
+        cls_channel = num_class + 1 if self.is_softmax else num_class
+        self.conv_cls = spconv.SparseSequential(
+            spconv.SubMConv3d(input_channels, (self.stride ** 3) * cls_channel, 3, padding=1, bias=True, indice_key='cls_ind'))
+        self.logit2prob = torch.nn.Softmax(dim=1) if self.is_softmax else torch.nn.Sigmoid()
+        if self.reg:
+            self.conv_res = spconv.SparseSequential(
+                spconv.SubMConv3d(input_channels, (self.stride ** 3) * self.num_class * self.res_num_dim, 3, padding=1,
+                                  bias=False, indice_key='res_ind'))
+
+    def forward(self, data_dict):
+        data_dict = self.prepare_loss_map(data_dict)
+        x = data_dict['encoded_spconv_tensor']
+        logit = self.conv_cls(x).dense()
+        prob = self.logit2prob(logit)[:, -1:, ...]
+        data_dict['pred_occ_logit'] = logit
+        # inactive cells densify to logit 0 => p = 0.5 (App. D.3): kept, they pass OCC_THRESH inside the loss mask
+        data_dict['batch_pred_occ_prob'] = prob[:, -1, ...] * data_dict["general_cls_loss_mask"]
+        if self.reg:
+            data_dict['pred_sem_residuals'] = self.conv_res(x).dense()
+        return data_dict
+
+
+__all__ = {'OccHeadTemplate': OccHeadTemplate, 'OccHead3D': OccHead3D}

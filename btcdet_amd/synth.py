@@ -51,7 +51,7 @@ def make_scene(seed, az_step=0.1728, n_occluders=40, n_boxes=None):
     nb = int(n_boxes if n_boxes is not None else rng.integers(2, 7))
     ids = rng.choice(n_occluders, nb, replace=False)
     boxes = np.zeros((nb, 8), dtype=np.float32)
-    boxes[:, 0] = occ_r[ids] * np.cos(occ_az[ids]) + 1.5
+    boxes[:, 0] = occ_r[ids] * np.cos(occ_az[ids])  # centred on the occluder face so that scan points fall inside
     boxes[:, 1] = occ_r[ids] * np.sin(occ_az[ids])
     boxes[:, 2] = -sensor_h + 0.78
     boxes[:, 3:6] = [3.9, 1.6, 1.56]

@@ -1,0 +1,100 @@
+"""Voxel feature encoders (per-voxel reductions over the point slots).
+
+Mirrors /root/reference/btcdet/models/backbones_3d/vfe/mean_vfe.py:6-68 (``MeanVFE``, occupancy
+branch: plain mean, ``maxprob`` False per detector3d_template.py:160-162) and occ_vfe.py:6-55
+(``OccVFE``, detection branch: mean of raw points, mean of occupancy points for occ-only voxels, max of
+the occupancy code channels)."""
+import torch
+import torch.nn as nn
+
+
+class VFETemplate(nn.Module):
+    def __init__(self, model_cfg, **kwargs):
+        super().__init__()
+        self.model_cfg = model_cfg
+
+    def get_output_feature_dim(self):
+        raise NotImplementedError
+
+
+def _slot_mask(num_points, max_num):
+    """(M,) counts -> (M,P) bool, slot p valid iff p < count"""
+    return torch.arange(max_num, dtype=torch.int, device=num_points.device).view(1, -1) < num_points.int().view(-1, 1)
+
+
+class MeanVFE(VFETemplate):
+    def __init__(self, model_cfg, num_point_features, data_cfg, **kwargs):
+        super().__init__(model_cfg=model_cfg)
+        self.maxprob = kwargs["maxprob"]
+        self.OCC_CODE = model_cfg.get("OCC_CODE", None)
+        occ = data_cfg.get("OCC", None)
+        self.xyz_dim = 6 if occ is not None and occ.USE_ABSXYZ == "both" else 3
+        self.num_point_features = num_point_features + (1 if self.OCC_CODE else 0) + self.xyz_dim - 3
+        self.num_raw_features = len(data_cfg.POINT_FEATURE_ENCODING.used_feature_list) + self.xyz_dim - 3
+
+    def get_output_feature_dim(self):
+        return self.num_point_features
+
+    def get_paddings_indicator(self, actual_num, max_num, axis=0):
+        return _slot_mask(actual_num, max_num)
+
+    def forward(self, batch_dict, **kwargs):
+        vox, num = batch_dict['voxels'], batch_dict['voxel_num_points']
+        normalizer = torch.clamp_min(num.view(-1, 1), min=1.0).type_as(vox)
+        if not self.maxprob:
+            batch_dict['voxel_features'] = (vox.sum(dim=1) / normalizer).contiguous()
+        else:
+            mask = _slot_mask(num, vox.shape[1])
+            raw_mask = (vox[:, :, -1] < 0.1) & mask
+            raw_norm = torch.clamp_min(raw_mask.sum(dim=1).view(-1, 1), min=1.0).type_as(vox)
+            xyz_mean = vox[:, :, :self.xyz_dim].sum(dim=1) / normalizer
+            inten_mean = vox[:, :, self.xyz_dim:self.num_raw_features].sum(dim=1) / raw_norm
+            occ_max = vox[:, :, self.num_raw_features:].max(dim=1)[0]
+            batch_dict['voxel_features'] = torch.cat([xyz_mean, inten_mean, occ_max], dim=-1).contiguous()
+        if self.OCC_CODE is not None:  # not configured for BtcDet-KITTI; kept for interface completeness
+            f = batch_dict['voxel_features']
+            M, F = f.shape
+            occ_bzyx = torch.nonzero((batch_dict["general_cls_loss_mask"] & (1 - batch_dict["voxelwise_mask"])) > 0)
+            N = occ_bzyx.shape[0]
+            batch_dict['voxel_coords'] = torch.cat([batch_dict['voxel_coords'], occ_bzyx], dim=0)
+            if not self.OCC_CODE:
+                batch_dict['voxel_features'] = torch.cat([f, f.new_zeros(N, F)], dim=0)
+            else:
+                batch_dict['voxel_features'] = torch.cat([torch.cat([f, f.new_ones(M, 1)], dim=-1),
+                                                          f.new_zeros(N, F + 1)], dim=0)
+        return batch_dict
+
+
+class OccVFE(VFETemplate):
+    def __init__(self, model_cfg, num_point_features, data_cfg, **kwargs):
+        super().__init__(model_cfg=model_cfg)
+        self.num_point_features = num_point_features
+        self.maxprob = kwargs["maxprob"]
+        self.num_raw_features = len(data_cfg.POINT_FEATURE_ENCODING.used_feature_list)
+
+    def get_output_feature_dim(self):
+        return self.num_point_features
+
+    def get_paddings_indicator(self, actual_num, max_num, axis=0):
+        return _slot_mask(actual_num, max_num)
+
+    def forward(self, batch_dict, **kwargs):
+        vox, num = batch_dict['voxels'], batch_dict['voxel_num_points']
+        R = self.num_raw_features
+        mask = _slot_mask(num, vox.shape[1])
+        is_occ = vox[:, :, -1] >= 0.05
+        raw_mask, occ_mask = (~is_occ) & mask, is_occ & mask
+        raw_n = raw_mask.sum(dim=1).view(-1, 1)
+        occ_n = occ_mask.sum(dim=1).view(-1, 1)
+        occ_only = (occ_n > 0.5) & (raw_n < 0.5)
+        raw_norm = torch.clamp_min(raw_n, min=1.0).type_as(vox)
+        occ_norm = torch.clamp_min(occ_n, min=1.0).type_as(vox)
+        raw_feat = (raw_mask.unsqueeze(-1) * vox[:, :, :R]).sum(dim=1) / raw_norm
+        occ_feat = (occ_mask.unsqueeze(-1) * vox[:, :, :R]).sum(dim=1) / occ_norm
+        occ_max = vox[:, :, R:].max(dim=1)[0]
+        batch_dict['voxel_features'] = torch.cat([raw_feat + occ_only * occ_feat, occ_max], dim=-1)
+        batch_dict['occ_voxel_features'] = occ_max
+        return batch_dict
+
+
+__all__ = {'VFETemplate': VFETemplate, 'MeanVFE': MeanVFE, 'OccVFE': OccVFE}
