@@ -26,6 +26,30 @@ class BtcHipError(RuntimeError):
     pass
 
 
+class BtcOccConfig(ctypes.Structure):
+    """struct BtcOccConfig of include/btcdet_hip.h"""
+    _fields_ = [("batch", ctypes.c_int32), ("grid", ctypes.c_int32 * 3), ("sphere_grid", ctypes.c_int32 * 3),
+                ("dist_kern", ctypes.c_int32 * 3), ("concede_x", ctypes.c_int32), ("empt_sur_thresh", ctypes.c_int32),
+                ("max_boxes", ctypes.c_int32), ("use_box_weight", ctypes.c_int32),
+                ("occ_range", ctypes.c_float * 6), ("occ_voxel", ctypes.c_float * 3),
+                ("sphere_range", ctypes.c_float * 6), ("sphere_voxel", ctypes.c_float * 3),
+                ("det_zmin", ctypes.c_float), ("det_zmax", ctypes.c_float),
+                ("w_fore_cls", ctypes.c_float), ("w_mirr_cls", ctypes.c_float), ("w_bm_cls", ctypes.c_float),
+                ("w_neg_cls", ctypes.c_float), ("w_fore_res", ctypes.c_float), ("w_mirr_res", ctypes.c_float),
+                ("w_bm_res", ctypes.c_float), ("box_weight", ctypes.c_float)]
+
+
+OCC_BUFFER_FIELDS = ["vcc_mask", "voxelwise_mask", "bm_voxelwise_mask", "occ_voxelwise_mask", "fore_voxelwise_mask",
+                     "pos_mask", "general_cls_loss_mask", "occ_fore_cls_mask", "occ_mirr_cls_mask", "occ_bm_cls_mask",
+                     "general_reg_loss_mask", "forebox_label", "general_cls_loss_mask_float",
+                     "general_reg_loss_mask_float", "res_mtrx", "pos_all_num"]
+
+
+class BtcOccBuffers(ctypes.Structure):
+    """struct BtcOccBuffers of include/btcdet_hip.h (all device pointers)"""
+    _fields_ = [(k, ctypes.c_void_p) for k in OCC_BUFFER_FIELDS]
+
+
 _SIGS = {
     # name: (restype, argtypes)
     "btc_last_error": (ctypes.c_char_p, []),
@@ -52,6 +76,9 @@ _SIGS = {
     "btc_revoxelize_ws_bytes": (sz, [ci, ci, c_i32p]),
     "btc_revoxelize_count": (ci, [vp, ci, ci, c_i32p, vp, vp, vp, sz, vp]),
     "btc_revoxelize_fill": (ci, [vp, vp, ci, ci, ci, c_i32p, ci, ci, vp, vp, vp, vp, sz, vp]),
+    "btc_occ_targets_ws_bytes": (sz, [ctypes.POINTER(BtcOccConfig)]),
+    "btc_occ_targets": (ci, [ctypes.POINTER(BtcOccConfig), vp, vp, vp, ci, ci, ci, vp, vp, vp, vp, ci, vp, vp,
+                             ctypes.POINTER(BtcOccBuffers), vp, sz, vp]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGS.keys())

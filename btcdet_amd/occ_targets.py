@@ -1,0 +1,139 @@
+"""OccTargets3D: occupancy / occlusion training-target generator on the GPU.
+
+Mirror of /root/reference/btcdet/models/occ_pnt/occ_training_targets/occ_targets_3d.py:8-171 and
+occ_targets_template.py:11-469 (constructor protocol of detector3d_template.py:116-130, module
+protocol ``forward(batch_dict) -> batch_dict``, batch_dict keys of SURVEY.md App. E) for the
+configured variant: COORD_TYPE cylinder, REG True, TMPLT True, DROPOUT_RATE 0.  The reference's
+chain of torch ops + python loop over the batch + ~17 host syncs is one C-ABI call here
+(btc_occ_targets, csrc/occupancy.hip)."""
+import ctypes
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib
+from ._lib import BtcOccBuffers, BtcOccConfig, OCC_BUFFER_FIELDS, check, lib, ptr, stream_ptr, workspace
+
+
+def cylinder_voxel_centers(grid_size, occ_range, voxel_size, device):
+    """all_voxel_centers (nz,ny,nx,3) and its BEV mean (ny*nx,2): Detector3DTemplate.create_subvox_loc
+    (detector3d_template.py:52-63) for COORD_TYPE cylinder, in float32 like the reference."""
+    nx, ny, nz = [int(g) for g in grid_size]
+    vs = torch.tensor([voxel_size[2], voxel_size[1], voxel_size[0]], dtype=torch.float32)
+    org = torch.tensor([occ_range[2], occ_range[1], occ_range[0]], dtype=torch.float32)
+    z, y, x = torch.meshgrid(torch.arange(nz), torch.arange(ny), torch.arange(nx), indexing="ij")
+    c = (0.5 + torch.stack([z, y, x], dim=0).to(torch.float32)) * vs.view(3, 1, 1, 1) + org.view(3, 1, 1, 1)
+    rho, th, zz = c[2], c[1], c[0]
+    ctr = torch.stack([rho * torch.cos(th * np.pi / 180.), -rho * torch.sin(th * np.pi / 180.), zz], dim=-1)
+    return {"all_voxel_centers": ctr.to(device).contiguous(),
+            "all_voxel_centers_2d": torch.mean(ctr[:, :, :, :2], dim=0).view(-1, 2).to(device)}
+
+
+class OccTargets3D(nn.Module):
+    def __init__(self, model_cfg, voxel_size, point_cloud_range, data_cfg, grid_size, num_class, voxel_centers):
+        super().__init__()
+        self.model_cfg, self.data_cfg, self.num_class = model_cfg, data_cfg, num_class
+        occ = data_cfg.OCC
+        assert occ.COORD_TYPE == "cylinder", "only the configured cylinder occupancy grid is implemented"
+        assert occ.DROPOUT_RATE <= 1e-3, "occupancy dropout is off in the configured model"
+        assert model_cfg.PARAMS.get("REVERSE_VIS", "NOTHING") == "NOTHING"
+        self.reg = model_cfg.PARAMS.get("REG", False)
+        assert self.reg and model_cfg.TARGETS.TMPLT, "configured variant: REG True, TMPLT True"
+        self.nx, self.ny, self.nz = [int(g) for g in grid_size]
+        self.point_cloud_range = point_cloud_range
+        self.all_voxel_centers = voxel_centers["all_voxel_centers"]
+        self.all_voxel_centers_2d = voxel_centers["all_voxel_centers_2d"]
+        # frozen 3x3 ones conv of the reference (occ_targets_template.py:30-32): kept so that
+        # `occ_modules.occ_targets.fix_conv_2dzy.weight` exists in checkpoints
+        self.fix_conv_2dzy = torch.nn.Conv2d(1, 1, kernel_size=3, stride=1, padding=1, bias=False)
+        self.fix_conv_2dzy.weight.data.fill_(1.0)
+        self.fix_conv_2dzy.requires_grad_(False)
+        sr = np.asarray(occ.SUPPORT_SPHERE_RANGE, dtype=np.float64)
+        if hasattr(occ, 'SUPPORT_SPHERE_VOXEL_SIZE'):
+            svs = np.array([occ.SUPPORT_SPHERE_VOXEL_SIZE[0], occ.SUPPORT_SPHERE_VOXEL_SIZE[1], sr[6]])
+        else:
+            svs = np.array([voxel_size[0], voxel_size[1], sr[6]])
+        sgrid = ((sr[3:6] - sr[:3]) / svs).astype(int)  # truncation, occ_targets_template.py:51
+        self.sphere_nx, self.sphere_ny, self.sphere_nz = [int(v) for v in sgrid]
+        lw = model_cfg.OCC_DENSE_HEAD.LOSS_CONFIG.LOSS_WEIGHTS
+        kern = occ.DIST_KERN
+        self.concede_x = occ.get("CONCEDE_X", kern[-1] // 2 if occ.get("HALF_X", False) else 0)
+        self.point_coding = occ.get("USE_ABSXYZ", "original")
+        assert self.point_coding is True or self.point_coding == "absxyz", "configured variant: USE_ABSXYZ True"
+        c = BtcOccConfig()
+        c.grid[:] = [self.nx, self.ny, self.nz]
+        c.sphere_grid[:] = [self.sphere_nx, self.sphere_ny, self.sphere_nz]
+        c.dist_kern[:] = [int(k) for k in kern]
+        c.concede_x = int(self.concede_x)
+        et = occ.EMPT_SUR_THRESH
+        c.empt_sur_thresh = int(et) if (et != "None" and et < 9) else -1
+        c.use_box_weight = int(occ.BOX_WEIGHT != 1.0)
+        c.occ_range[:] = [float(np.float32(v)) for v in point_cloud_range]
+        c.occ_voxel[:] = [float(np.float32(v)) for v in voxel_size]
+        c.sphere_range[:] = [float(np.float32(v)) for v in sr[:6]]
+        c.sphere_voxel[:] = [float(np.float32(v)) for v in svs]
+        c.det_zmin, c.det_zmax = float(data_cfg.POINT_CLOUD_RANGE[2]), float(data_cfg.POINT_CLOUD_RANGE[5])
+        c.w_fore_cls, c.w_mirr_cls = lw["occ_fore_cls_weight"], lw["occ_mirr_cls_weight"]
+        c.w_bm_cls, c.w_neg_cls = lw["occ_bm_cls_weight"], lw["occ_neg_cls_weight"]
+        c.w_fore_res, c.w_mirr_res = lw.get("occ_fore_res_weight", 0.1), lw.get("occ_mirr_res_weight", 0.1)
+        c.w_bm_res, c.box_weight = lw.get("occ_bm_res_weight", 0.1), occ.BOX_WEIGHT
+        self._cfg = c
+
+    def get_paddings_indicator(self, actual_num, max_num, axis=0):
+        return actual_num.int().unsqueeze(1) > torch.arange(max_num, dtype=torch.int, device=actual_num.device).view(1, -1)
+
+    def forward(self, batch_dict, **kwargs):
+        vox = batch_dict['voxels']
+        dev = vox.device
+        num = batch_dict['voxel_num_points'].int().contiguous()
+        coords = batch_dict['voxel_coords'].int().contiguous()
+        mask = self.get_paddings_indicator(num, vox.shape[1])
+        batch_dict["voxel_point_mask"] = mask
+        gt = batch_dict["gt_boxes"].float().contiguous()
+        bs, G = gt.shape[0], gt.shape[1]
+        gtn = batch_dict["gt_boxes_num"]
+        gtn = gtn.to(dev).int() if torch.is_tensor(gtn) else torch.tensor(list(gtn), dtype=torch.int32, device=dev)
+        mirr = batch_dict['box_mirr_flag'].float().contiguous()
+        rot_z = batch_dict["rot_z"].float().contiguous() if "rot_z" in batch_dict else torch.zeros(bs, device=dev)
+        bm = batch_dict.get("bm_points", None)
+        n_bm = 0 if bm is None else int(bm.shape[0])
+        bm = bm.float().contiguous() if n_bm > 0 else None
+        vox = vox.float().contiguous().clone() if not vox.is_contiguous() or vox.dtype != torch.float32 else vox.clone()
+        M, P, C = vox.shape
+        shape = (bs, self.nz, self.ny, self.nx)
+        out = {}
+        for k in OCC_BUFFER_FIELDS:
+            if k == "res_mtrx":
+                out[k] = torch.empty((bs, 3, self.nz, self.ny, self.nx), dtype=torch.float32, device=dev)
+            elif k == "pos_all_num":
+                out[k] = torch.empty((1,), dtype=torch.int32, device=dev)
+            elif k.endswith("_float"):
+                out[k] = torch.empty(shape, dtype=torch.float32, device=dev)
+            elif k == "forebox_label":
+                out[k] = torch.empty(shape, dtype=torch.int8, device=dev)
+            else:
+                out[k] = torch.empty(shape, dtype=torch.uint8, device=dev)
+        bufs = BtcOccBuffers(**{k: out[k].data_ptr() for k in OCC_BUFFER_FIELDS})
+        cfg = self._cfg
+        cfg.batch, cfg.max_boxes = bs, G
+        L = lib()
+        ws_bytes = L.btc_occ_targets_ws_bytes(ctypes.byref(cfg))
+        ws = workspace(ws_bytes, dev)
+        check(L.btc_occ_targets(ctypes.byref(cfg), ptr(vox), ptr(coords), ptr(num), M, P, C, ptr(gt), ptr(gtn), ptr(mirr),
+                                ptr(bm), n_bm, ptr(rot_z), ptr(self.all_voxel_centers), ctypes.byref(bufs), ptr(ws), ws_bytes,
+                                stream_ptr()), "btc_occ_targets")
+        batch_dict['voxels'] = vox  # absolute xyz payload (USE_ABSXYZ True)
+        out["occ_voxelwise_mask"] = out["occ_voxelwise_mask"].bool()
+        out["pos_all_num"] = out["pos_all_num"][0]
+        if not batch_dict.get("is_train", True):
+            out["neg_mask"] = out["general_cls_loss_mask"] & (1 - out["pos_mask"])
+        batch_dict.update(out)
+        if "point_drop_inds" in batch_dict.keys():
+            inds = batch_dict["point_drop_inds"]
+            mask[inds[:, 0], inds[:, 1]] = False
+        batch_dict["final_point_mask"] = mask
+        return batch_dict
+
+
+__all__ = {'OccTargets3D': OccTargets3D}

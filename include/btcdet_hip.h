@@ -164,6 +164,53 @@ int btc_revoxelize_fill(const float* points, const int64_t* coords, int n, int C
                         const int32_t* h_shape, int m, int pmax, float* voxels, int64_t* vcoords,
                         int64_t* vnum, void* ws, size_t ws_bytes, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Occupancy / occlusion target generator.  Replaces OccTargets3D.forward -> create_voxel_res_label
+ * (/root/reference/btcdet/models/occ_pnt/occ_training_targets/occ_targets_3d.py:18-171,
+ * occ_targets_template.py:82-255,330-447; geometry helpers coords_utils.py:180-239,
+ * point_box_utils.py:70-121,241-329) for COORD_TYPE cylinder, REG True: seven launches, no host sync.
+ *
+ * In/out:
+ *   voxels (M,P,C) f32   cylinder payload (rho, azimuth_deg - rot_z, z, ...) -> rewritten IN PLACE to
+ *                        absolute xyz (USE_ABSXYZ True, occ_targets_3d.py:45-47), padded slots included
+ *   voxel_coords (M,4) i32 [b,z,y,x]; voxel_num (M) i32
+ *   gt_boxes (B,G,8) f32 [x,y,z,dx,dy,dz,yaw,cls]; gt_num (B) i32; mirr_flag (B,G) f32
+ *   bm_points (n_bm,4) f32 [b,x,y,z] (may be NULL when n_bm == 0); rot_z (B) f32 degrees
+ *   centers (nz,ny,nx,3) f32: Cartesian centres of the cylinder cells (detector3d_template.py:52-63)
+ * Outputs (BtcOccBuffers, all [B,nz,ny,nx] unless noted; caller allocates, need not be initialised):
+ *   the eleven uint8 masks and forebox_label (int8) of occ_targets_template.py:360-400,
+ *   general_cls_loss_mask_float / general_reg_loss_mask_float (f32), res_mtrx [B,3,nz,ny,nx] f32,
+ *   pos_all_num (1) i32.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct BtcOccConfig {
+  int32_t batch;
+  int32_t grid[3];          /* cylinder grid nx, ny, nz (209,157,9) */
+  int32_t sphere_grid[3];   /* support sphere grid nx, ny, nz (214,157,49) */
+  int32_t dist_kern[3];     /* DIST_KERN z,y,x (5,9,5) */
+  int32_t concede_x;        /* CONCEDE_X or DIST_KERN[-1]//2 when HALF_X */
+  int32_t empt_sur_thresh;  /* EMPT_SUR_THRESH, < 0 or >= 9 disables the empty-ray fix */
+  int32_t max_boxes;        /* G */
+  int32_t use_box_weight;   /* BOX_WEIGHT != 1.0 */
+  float occ_range[6], occ_voxel[3];
+  float sphere_range[6], sphere_voxel[3];
+  float det_zmin, det_zmax; /* DATA_CONFIG.POINT_CLOUD_RANGE[2], [5] */
+  float w_fore_cls, w_mirr_cls, w_bm_cls, w_neg_cls, w_fore_res, w_mirr_res, w_bm_res, box_weight;
+} BtcOccConfig;
+
+typedef struct BtcOccBuffers {
+  uint8_t *vcc_mask, *voxelwise_mask, *bm_voxelwise_mask, *occ_voxelwise_mask, *fore_voxelwise_mask, *pos_mask,
+      *general_cls_loss_mask, *occ_fore_cls_mask, *occ_mirr_cls_mask, *occ_bm_cls_mask, *general_reg_loss_mask;
+  int8_t* forebox_label;
+  float *general_cls_loss_mask_float, *general_reg_loss_mask_float, *res_mtrx;
+  int32_t* pos_all_num;
+} BtcOccBuffers;
+
+size_t btc_occ_targets_ws_bytes(const BtcOccConfig* cfg);
+int btc_occ_targets(const BtcOccConfig* cfg, float* voxels, const int32_t* voxel_coords, const int32_t* voxel_num,
+                    int M, int max_points, int C, const float* gt_boxes, const int32_t* gt_num, const float* mirr_flag,
+                    const float* bm_points, int n_bm, const float* rot_z, const float* centers,
+                    const BtcOccBuffers* out, void* ws, size_t ws_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
