@@ -1,0 +1,236 @@
+#!/usr/bin/env python
+"""bench.py -- BtcDet hot path on MI355X: scenes/s forward+backward, KITTI-Car configuration, bs=2 per GPU.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One step = one pass of the hot path over one synthetic batch whose raw points already sit in HBM:
+  GPU voxelization of both grids (cylinder occupancy grid + Cartesian detection grid)
+  -> OccTargets3D -> MeanVFE -> VoxelBackBoneDeconv -> OccHead3D (+ occupancy loss) -> PassOccVox
+  -> OccVFE -> VoxelBackBone8xOcc -> HeightCompression (+ an L2 stand-in for the out-of-scope BEV heads)
+  -> backward (DDP gradient all-reduce over RCCL when N > 1) -> the two Adam steps of the reference.
+fp32 throughout.  Prints ONE JSON line on rank 0 (contract in the task statement), including
+  roofline      the dominant kernel (conv_apply = fused sparse conv fwd/dgrad) timed live with HIP events
+  cpu_baseline  the CPU oracle timed on the host cores for a bounded sample of the same workload (N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0       # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+FP32_MFMA_PEAK_TF = 157.3   # same guide: fp32-input MFMA peak
+
+
+def build_batches(n_batches, rank, device, batch_size=2):
+    from btcdet_amd import synth
+    batches = []
+    for i in range(n_batches):
+        seeds = [1000 * rank + 10 * i + j for j in range(batch_size)]
+        b = synth.make_batch(seeds)
+        batches.append({
+            "batch_size": batch_size,
+            "points5": torch.from_numpy(b["points"]).to(device),                       # [b,x,y,z,i] (collate layout)
+            "points": torch.from_numpy(np.ascontiguousarray(b["points"][:, 1:])).to(device),
+            "pre_rot_points": torch.from_numpy(b["pre_rot_points"]).to(device),
+            "scene_offsets": torch.from_numpy(b["scene_offsets"]).to(device),
+            "gt_boxes": torch.from_numpy(b["gt_boxes"]).to(device),
+            "gt_boxes_num": torch.tensor(b["gt_boxes_num"], dtype=torch.int32, device=device),
+            "box_mirr_flag": torch.from_numpy(b["box_mirr_flag"]).to(device),
+            "bm_points": torch.from_numpy(b["bm_points"]).to(device),
+            "rot_z": torch.from_numpy(b["rot_z"]).to(device),
+            "n_points": int(b["points"].shape[0]),
+        })
+    return batches
+
+
+def make_step(model, ddp, proc, opts):
+    def step(batch):
+        for o in opts:
+            o.zero_grad(set_to_none=True)
+        bd = proc.forward_batch(batch["points"], batch["pre_rot_points"], batch["scene_offsets"], batch["rot_z"])
+        bd.update({"batch_size": batch["batch_size"], "points": batch["points5"], "gt_boxes": batch["gt_boxes"],
+                   "gt_boxes_num": batch["gt_boxes_num"], "box_mirr_flag": batch["box_mirr_flag"],
+                   "bm_points": batch["bm_points"], "rot_z": batch["rot_z"], "is_train": True})
+        ret, tb, _ = ddp(bd)
+        loss = ret["loss_occ"] + 1e-3 * ret["spatial_features"].pow(2).mean()
+        loss.backward()
+        for o in opts:
+            o.step()
+        return loss
+    return step
+
+
+def cpu_baseline(seconds_budget=20.0):
+    """CPU oracle ("port") on the host, 1 thread: per scene the reference's CPU dataset/voxelize path
+    (cylinder transform + both voxelizations) and the occupancy-branch sparse convolutions fwd+dgrad+wgrad;
+    see DESIGN.md for what the sample covers."""
+    from btcdet_amd import synth
+    from oracle import oracle as orc
+    torch.set_num_threads(1)
+    occ_gen = orc.VoxelGeneratorV2(synth.KITTI_OCC_VOXEL, synth.KITTI_OCC_RANGE, 12, 20000)
+    det_gen = orc.VoxelGeneratorV2(synth.KITTI_DET_VOXEL, synth.KITTI_DET_RANGE, 5, 16000)
+    rng = np.random.default_rng(0)
+    layers = [(4, 16, 1, orc.MODE_CONV), (16, 32, 2, orc.MODE_CONV), (32, 32, 1, orc.MODE_SUBM), (32, 64, 2, orc.MODE_CONV),
+              (64, 64, 1, orc.MODE_SUBM), (64, 32, 2, orc.MODE_TRANSPOSE), (32, 32, 1, orc.MODE_SUBM),
+              (32, 32, 2, orc.MODE_TRANSPOSE), (32, 32, 1, orc.MODE_SUBM)]
+    t_start = time.perf_counter()
+    scenes, t_vox, t_conv = 0, 0.0, 0.0
+    while time.perf_counter() - t_start < seconds_budget and scenes < 8:
+        s = synth.make_scene(5000 + scenes)
+        t0 = time.perf_counter()
+        cyl = orc.absxyz_2_cylinxyz_np(s["pre_rot_points"])
+        r = occ_gen.generate(cyl)
+        r["voxels"][..., 1] -= s["rot_z"]
+        det_gen.generate(s["points"])
+        t1 = time.perf_counter()
+        idx = np.pad(r["coordinates"], ((0, 0), (1, 0))).astype(np.int32)
+        feat = (r["voxels"].sum(1) / np.maximum(r["num_points_per_voxel"], 1)[:, None]).astype(np.float32)
+        shape = [9, 157, 209]
+        for cin, cout, stride, mode in layers:
+            o_idx, nbr_out, nbr_in, osh = orc.rulebook(idx, shape, 3, stride, 1 if mode != orc.MODE_SUBM else 0, 1, mode)
+            W = (rng.standard_normal((3, 3, 3, cin, cout)) / np.sqrt(27 * cin)).astype(np.float32)
+            out = orc.conv_fwd(feat, W, None, nbr_out)
+            dout = np.ones_like(out)
+            orc.conv_dgrad(dout, W, nbr_in)
+            orc.conv_wgrad(feat, dout, nbr_out, W.shape)
+            idx, feat, shape = o_idx, np.maximum(out, 0), list(osh)
+        t2 = time.perf_counter()
+        t_vox += t1 - t0
+        t_conv += t2 - t1
+        scenes += 1
+    total = t_vox + t_conv
+    return {"value": round(scenes / total, 3), "unit": "scenes/s", "cores": 1, "kind": "port",
+            "sample": "%d synthetic KITTI scenes, CPU oracle, 1 thread: cylinder transform + 2 voxelizations (%.1f ms/scene) + "
+                      "occupancy-branch sparse convs (9 layers) fwd+dgrad+wgrad incl. rulebooks (%.0f ms/scene); the detection branch, "
+                      "occupancy targets and heads are NOT in the sample" % (scenes, 1e3 * t_vox / scenes, 1e3 * t_conv / scenes),
+            "voxelize_scenes_per_s": round(scenes / t_vox, 2), "host_cpus": os.cpu_count()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback for the hot path)"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend="nccl", device_id=device)  # "nccl" is RCCL on ROCm
+
+    from btcdet_amd.btc_path import BtcHotPath
+    from btcdet_amd.config import load_cfg
+    from btcdet_amd.spconv import ops
+
+    torch.manual_seed(666)
+    np.random.seed(666 + rank)
+    cfg = load_cfg()
+    model = BtcHotPath(cfg, device=device).to(device)
+    model.train()
+    ddp = model
+    if world > 1:
+        ddp = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], find_unused_parameters=False)
+    occ_params = [p for p in model.occ_modules.parameters() if p.requires_grad]
+    det_params = [p for p in model.det_modules.parameters() if p.requires_grad]
+    # adam_onecycle groups of the reference (optimization/__init__.py:36-40; LR is scheduled, yaml:331-372)
+    opts = [torch.optim.Adam(occ_params, lr=3e-3, weight_decay=0.001, betas=(0.9, 0.99)),
+            torch.optim.Adam(det_params, lr=3e-3, weight_decay=0.01, betas=(0.9, 0.99))]
+    bs = 2
+    batches = build_batches(4, rank, device, bs)
+    step = make_step(model, ddp, model.dataset.data_processor, opts)
+
+    def sync():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(batches[i % len(batches)])
+    sync()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(batches[i % len(batches)])
+    sync()
+    dt = time.perf_counter() - t0
+    # roofline leg: the SAME steps once more with a HIP event pair around every sparse-conv / rulebook launch
+    # (kept out of the timed region above because counting the pairs of each rulebook needs a read-back)
+    prof = None
+    prof_steps = 0
+    if not args.no_roofline and rank == 0:
+        prof = ops.LaunchProfile()
+        ops.PROFILE = prof
+        prof_steps = min(args.steps, 8)
+    if not args.no_roofline:
+        for i in range(min(args.steps, 8)):
+            step(batches[i % len(batches)])
+        sync()
+    ops.PROFILE = None
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    result = None
+    if rank == 0:
+        scenes = bs * world * args.steps
+        result = {
+            "metric": "scenes/s fwd+bwd KITTI-Car bs=2/GPU (BtcDet hot path)", "value": round(scenes / dt, 3), "unit": "scenes/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "btcdet_kitti_car hot path, bs=2/GPU, ~28.6k pts/scene: HIP voxelize (occ+det grids) -> OccTargets3D -> "
+                                   "MeanVFE -> VoxelBackBoneDeconv -> OccHead3D+loss -> PassOccVox -> OccVFE -> VoxelBackBone8xOcc -> "
+                                   "HeightCompression (+L2 stand-in for the out-of-scope BEV heads), fwd+bwd+2xAdam, fp32",
+                       "global_batch": bs * world, "parallelism": "dp%d" % world,
+                       "points_per_batch": [b["n_points"] for b in batches]},
+        }
+        if prof is not None:
+            summ = prof.summary()
+            k = summ.get("conv_apply")
+            if k:
+                gbs = k["bytes"] / (k["ms"] * 1e-3) / 1e9
+                result["roofline"] = {"kernel": "conv_apply (fused sparse conv fwd + dgrad, output-stationary MFMA f32)", "bound": "hbm",
+                                      "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5),
+                                      "traffic": None, "launches_per_step": k["launches"] / prof_steps,
+                                      "avg_launch_us": round(1e3 * k["ms"] / k["launches"], 2),
+                                      "alg_bytes_per_step": k["bytes"] // prof_steps,
+                                      "tflops": round(k["flops"] / (k["ms"] * 1e-3) / 1e12, 3), "mfma_f32_peak_tflops": FP32_MFMA_PEAK_TF,
+                                      "kernel_ms_per_step": round(k["ms"] / prof_steps, 3)}
+            for name in ("conv_wgrad", "rulebook"):
+                k = summ.get(name)
+                if k:
+                    result.setdefault("other_kernels", {})[name] = {
+                        "GB/s": round(k["bytes"] / (k["ms"] * 1e-3) / 1e9, 2), "ms_per_step": round(k["ms"] / prof_steps, 3),
+                        "launches_per_step": k["launches"] / prof_steps, "alg_bytes_per_step": k["bytes"] // prof_steps}
+            rb = summ.get("rulebook")
+            if rb:
+                result["rulebook_hbm_GBps"] = round(rb["bytes"] / (rb["ms"] * 1e-3) / 1e9, 2)
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(result))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,93 @@
+"""The hot path assembled as the reference assembles it: BtcNet's occupancy branch and the sparse part of its
+detection branch, with the module lists, registry names and ``occ_modules`` / ``det_modules`` containers of
+/root/reference/btcdet/models/detectors/detector3d_template.py:28-113 and btcnet.py:32-56, so that
+``state_dict`` keys line up with reference checkpoints (occ_modules.backbone_3d.conv1.0.0.weight, ...).
+
+Out of scope: BaseBEVBackbone, AnchorHeadSingle, ConvHead.  The detection branch therefore ends
+at HeightCompression; bench.py drives its backward with a stand-in L2 loss on ``spatial_features``.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import backbones_3d, height_compression, occ_head, occ_targets, pass_occ_vox, vfe
+from .processor import DataProcessor
+
+
+class HotPathDataset(object):
+    """the attributes Detector3DTemplate reads from its dataset (dataset.py:27-41)"""
+
+    def __init__(self, cfg, training=True):
+        d = cfg.DATA_CONFIG
+        self.dataset_cfg = d
+        self.class_names = cfg.CLASS_NAMES
+        self.training = training
+        self.mode = 'train' if training else 'test'
+        self.point_cloud_range = np.array(d.POINT_CLOUD_RANGE, dtype=np.float32)
+        self.occ_point_cloud_range = np.array(d.OCC.POINT_CLOUD_RANGE, dtype=np.float32)
+        self.num_point_features = len(d.POINT_FEATURE_ENCODING.used_feature_list)
+        self.data_processor = DataProcessor(d.DATA_PROCESSOR, point_cloud_range=self.occ_point_cloud_range, training=training,
+                                            occ_config=d.OCC, det_point_cloud_range=self.point_cloud_range)
+        self.occ_grid_size, self.occ_voxel_size = self.data_processor.occ_grid_size, self.data_processor.occ_voxel_size
+        self.det_grid_size, self.det_voxel_size = self.data_processor.det_grid_size, self.data_processor.det_voxel_size
+        self.occ_dim = self.data_processor.occ_dim
+
+
+class BtcHotPath(nn.Module):
+    def __init__(self, cfg, dataset=None, device="cuda"):
+        super().__init__()
+        self.cfg = cfg
+        self.dataset = dataset if dataset is not None else HotPathDataset(cfg)
+        ds, m, d = self.dataset, cfg.MODEL, cfg.DATA_CONFIG
+        self.register_buffer('global_step', torch.LongTensor(1).zero_())
+        self.voxel_centers = occ_targets.cylinder_voxel_centers(ds.occ_grid_size, d.OCC.POINT_CLOUD_RANGE, d.OCC.VOXEL_SIZE, device)
+        nraw = ds.num_point_features
+        self.occ_modules, self.det_modules = nn.Module(), nn.Module()
+        occ_num_class = 1 if m.OCC.PARAMS.CLASS_AGNOSTIC else len(cfg.CLASS_NAMES)
+        # ---- occupancy branch (occ_module_topology, detector3d_template.py:32-34)
+        tgt = occ_targets.__all__[m.OCC.TARGETS.NAME](model_cfg=m.OCC, point_cloud_range=ds.occ_point_cloud_range,
+                                                       voxel_size=ds.occ_voxel_size, data_cfg=d, grid_size=ds.occ_grid_size,
+                                                       num_class=occ_num_class, voxel_centers=self.voxel_centers)
+        ovfe = vfe.__all__[m.OCC.VFE.NAME](model_cfg=m.OCC.VFE, num_point_features=nraw, point_cloud_range=ds.point_cloud_range,
+                                           voxel_size=ds.occ_voxel_size, data_cfg=d, grid_size=ds.occ_grid_size,
+                                           num_class=occ_num_class, maxprob=False)
+        obb = backbones_3d.__all__[m.OCC.BACKBONE_3D.NAME](model_cfg=m.OCC.BACKBONE_3D, input_channels=ovfe.get_output_feature_dim(),
+                                                           grid_size=ds.occ_grid_size, voxel_size=ds.occ_voxel_size,
+                                                           point_cloud_range=ds.point_cloud_range,
+                                                           original_num_rawpoint_features=nraw)
+        head = occ_head.__all__[m.OCC.OCC_DENSE_HEAD.NAME](model_cfg=m.OCC, data_cfg=d, input_channels=obb.num_point_features,
+                                                           num_class=occ_num_class, grid_size=ds.occ_grid_size)
+        upd = pass_occ_vox.__all__[m.OCC.OCC_PNT_UPDATE.NAME](model_cfg=m.OCC, data_cfg=d, point_cloud_range=ds.point_cloud_range,
+                                                              occ_voxel_size=ds.occ_voxel_size, occ_grid_size=ds.occ_grid_size,
+                                                              det_voxel_size=ds.det_voxel_size, det_grid_size=ds.det_grid_size,
+                                                              mode=ds.mode, voxel_centers=self.voxel_centers)
+        for name, mod in [("occ_targets", tgt), ("vfe", ovfe), ("backbone_3d", obb), ("occ_dense_head", head), ("occ_pnt_update", upd)]:
+            self.occ_modules.add_module(name, mod)
+        self.occ_module_list = [tgt, ovfe, obb, head, upd]
+        # ---- detection branch up to the BEV map (module_topology, detector3d_template.py:28-30)
+        nvox = nraw + upd.code_num_dim
+        dvfe = vfe.__all__[m.VFE.NAME](model_cfg=m.VFE, num_point_features=nvox, point_cloud_range=ds.point_cloud_range,
+                                       voxel_size=ds.det_voxel_size, data_cfg=d, grid_size=ds.det_grid_size,
+                                       num_class=len(cfg.CLASS_NAMES), maxprob=d.OCC.get("MAX_VFE", False))
+        dbb = backbones_3d.__all__[m.BACKBONE_3D.NAME](model_cfg=m.BACKBONE_3D, input_channels=dvfe.get_output_feature_dim(),
+                                                       grid_size=ds.det_grid_size, voxel_size=ds.det_voxel_size,
+                                                       point_cloud_range=ds.point_cloud_range, original_num_rawpoint_features=nraw)
+        bev = height_compression.__all__[m.MAP_TO_BEV.NAME](model_cfg=m.MAP_TO_BEV, grid_size=ds.det_grid_size, occ_dim=ds.occ_dim)
+        for name, mod in [("vfe", dvfe), ("backbone_3d", dbb), ("map_to_bev_module", bev)]:
+            self.det_modules.add_module(name, mod)
+        self.det_module_list = [dvfe, dbb, bev]
+        self.percentage = d.OCC.get("USEOCC_PERCENTAGE", 1.0)
+
+    def forward(self, batch_dict):
+        """BtcNet.forward up to the BEV map (btcnet.py:32-56) + the occupancy loss (btcnet.py:91-101)"""
+        use_occ_prob = [True] * batch_dict["batch_size"]
+        prob = np.random.uniform(size=batch_dict["batch_size"], high=0.9999)  # the reference consumes this stream too
+        if batch_dict["is_train"]:
+            use_occ_prob = prob <= self.percentage
+        batch_dict["use_occ_prob"] = use_occ_prob
+        for mod in self.occ_module_list:
+            batch_dict = mod(batch_dict)
+        for mod in self.det_module_list:
+            batch_dict = mod(batch_dict)
+        occ_loss, tb_dict = self.occ_modules.occ_dense_head.get_loss(batch_dict)
+        return {"loss_occ": occ_loss, "spatial_features": batch_dict["spatial_features"]}, tb_dict, batch_dict

@@ -36,3 +36,140 @@ def revoxelize(points, coords, batch_size, grid_zyx):
     check(L.btc_revoxelize_fill(ptr(points), ptr(coords), n, C, int(batch_size), i3p(sh), m, pmax, ptr(voxels),
                                 ptr(vcoords), ptr(vnum), ptr(ws), ws_bytes, stream_ptr()), "btc_revoxelize_fill")
     return voxels, vnum, vcoords
+
+
+class PassOccVox(torch.nn.Module):
+    """Module protocol of the reference (constructor kwargs of detector3d_template.py:133-154)."""
+
+    def __init__(self, model_cfg, data_cfg, point_cloud_range, occ_voxel_size, occ_grid_size, det_voxel_size, det_grid_size,
+                 mode, voxel_centers, **kwargs):
+        super().__init__()
+        self.model_cfg, self.data_cfg = model_cfg, data_cfg
+        p = model_cfg.PARAMS
+        self.occ_thresh, self.eval_occ_thresh = p.OCC_THRESH, p.EVAL_OCC_THRESH
+        self.max_add_occpnts_num, self.eval_max_add_occpnts_num = p.MAX_NUM_OCC_PNTS, p.EVAL_MAX_NUM_OCC_PNTS
+        self.pass_gradient = model_cfg.OCC_PNT_UPDATE.PASS_GRAD
+        self.res_num_dim = data_cfg.OCC.RES_NUM_DIM
+        self.point_cloud_range = [float(v) for v in point_cloud_range]
+        self.occ_voxel_size = occ_voxel_size
+        self.nvx, self.nvy, self.nvz = [float(v) for v in occ_voxel_size]
+        self.occ_grid_size, self.det_grid_size = occ_grid_size, det_grid_size
+        self.det_voxel_size = [float(v) for v in det_voxel_size]
+        self.occ_point_cloud_range = data_cfg.OCC.POINT_CLOUD_RANGE
+        self.occ_x_origin, self.occ_y_origin, self.occ_z_origin = [float(v) for v in self.occ_point_cloud_range[:3]]
+        self.all_voxel_centers = voxel_centers["all_voxel_centers"]
+        self.config_realdrop = data_cfg.OCC.get('REAL_DROP', None) is None or data_cfg.OCC.REAL_DROP
+        self.config_rawadd = data_cfg.OCC.get('RAW_ADD', False)
+        self.code_num_dim = data_cfg.OCC.get('CODE_NUM_DIM', 2)
+        self.reg = p.get("REG", False)
+        self.db_proj = model_cfg.OCC_PNT_UPDATE.get('DB_PROJ', False)
+        self.remain_percentage = p.get('REMAIN_PERCENTAGE', None)
+        assert not self.db_proj and self.remain_percentage is None, "DB_PROJ / REMAIN_PERCENTAGE are off in the configured model"
+        assert data_cfg.OCC.COORD_TYPE == "cylinder"
+
+    def visualize(self, batch_dict, binds):  # visualisation is out of scope (SURVEY.md §2.1 #5)
+        return {}, {}
+
+    def filter_occ_points(self, batch_size, occ_probs, batch_dict):
+        """cells with p > OCC_THRESH, at most MAX_NUM_OCC_PNTS per scene (highest p); add_occ_template.py:94-128.
+        (The reference compares against self.occ_thresh in both modes, App. D.2.)  The selected cells of a scene are
+        kept in ascending cell order -- topk(sorted=False) leaves the order unspecified in the reference."""
+        max_add = self.max_add_occpnts_num if batch_dict["is_train"] else self.eval_max_add_occpnts_num
+        res_lst, probs_lst, coords_lst = [], [], []
+        for i in range(batch_size):
+            if not batch_dict["use_occ_prob"][i]:
+                continue
+            flat = occ_probs[i].reshape(-1)
+            sel = torch.nonzero(flat > self.occ_thresh)[:, 0]
+            if sel.numel() == 0:
+                continue
+            if sel.numel() > max_add:
+                top = torch.topk(flat[sel], max_add, largest=True, sorted=False)[1]
+                sel = sel[torch.sort(top)[0]]
+            NZ, NY, NX = occ_probs.shape[1:]
+            z, r = torch.div(sel, NY * NX, rounding_mode='floor'), sel % (NY * NX)
+            coords_lst.append(torch.stack([torch.full_like(sel, i), z, torch.div(r, NX, rounding_mode='floor'), r % NX], dim=-1))
+            probs_lst.append(flat[sel])
+            if self.reg:
+                res_lst.append(batch_dict["pred_sem_residuals"][i].reshape(self.res_num_dim, -1)[:, sel].permute(1, 0))
+        return res_lst, probs_lst, coords_lst
+
+    def occ_coords2absxyz(self, occ_coords, type, rot_z=None):
+        """cell centre of the cylinder grid -> Cartesian (add_occ_template.py:131-146)"""
+        cx = self.occ_x_origin + (occ_coords[..., 3] + 0.5) * self.nvx
+        cy = self.occ_y_origin + (occ_coords[..., 2] + 0.5) * self.nvy
+        cz = self.occ_z_origin + (occ_coords[..., 1] + 0.5) * self.nvz
+        if rot_z is not None:
+            cy = cy - rot_z[occ_coords[..., 0]]
+        return torch.stack([cx * torch.cos(cy * np.pi / 180.), -cx * torch.sin(cy * np.pi / 180.), cz], dim=-1)
+
+    def trans_voxel_grid(self, occ_xyz, b_inds):
+        """xyz -> detection-grid cell [b,z,y,x], floor + clamp (add_occ_template.py:78-88)"""
+        rng = torch.tensor(self.point_cloud_range[0:3], device=occ_xyz.device, dtype=torch.float32)
+        vs = torch.tensor(self.det_voxel_size, device=occ_xyz.device, dtype=torch.float32)
+        c = torch.floor(torch.div(occ_xyz - rng.unsqueeze(0), vs.unsqueeze(0)))
+        nx, ny, nz = [int(g) for g in self.det_grid_size]
+        cx = torch.clamp(c[..., 0], min=0, max=nx - 1).to(torch.int64)
+        cy = torch.clamp(c[..., 1], min=0, max=ny - 1).to(torch.int64)
+        cz = torch.clamp(c[..., 2], min=0, max=nz - 1).to(torch.int64)
+        return torch.stack([b_inds, cz, cy, cx], dim=-1)
+
+    def forward(self, batch_dict, **kwargs):
+        pnt_feat_dim = batch_dict['voxels'].shape[2]
+        batch_size, probs = batch_dict['batch_size'], batch_dict['batch_pred_occ_prob']
+        res_lst, probs_lst, coords_lst = self.filter_occ_points(batch_size, probs, batch_dict)
+        batch_dict["gt_points_xyz"] = batch_dict["points"][..., 1:4]
+        batch_dict["gt_b_ind"] = batch_dict["points"][..., 0]
+        if 'det_voxel_coords' in batch_dict:
+            batch_dict['voxels'], batch_dict['voxel_num_points'], batch_dict['voxel_coords'] = \
+                batch_dict['det_voxels'], batch_dict['det_voxel_num_points'], batch_dict['det_voxel_coords']
+        dev = batch_dict['voxels'].device
+        if len(probs_lst) > 0:
+            occ_probs, occ_coords = torch.cat(probs_lst, dim=0), torch.cat(coords_lst, dim=0)
+            xyz = self.occ_coords2absxyz(occ_coords, self.data_cfg.OCC.COORD_TYPE, rot_z=batch_dict.get("rot_z", None))
+            if self.reg:
+                xyz = xyz + torch.cat(res_lst, dim=0)
+            batch_dict["added_occ_xyz"] = xyz
+            batch_dict["occ_pnts"] = torch.cat([xyz, occ_probs.unsqueeze(-1)], dim=-1)
+            batch_dict["added_occ_b_ind"] = occ_coords[..., 0]
+            occ_cells = self.trans_voxel_grid(xyz, occ_coords[..., 0])
+            # [x, y, z, intensity = OCC.INTEN, prob, 1] (assemble_occ_points, add_occ_template.py:149-165)
+            inten = self.data_cfg.OCC.INTEN if self.data_cfg.OCC.get("INTEN", None) is not None else 0.0
+            cols = [xyz]
+            if self.res_num_dim < pnt_feat_dim:
+                cols.append(torch.full_like(occ_probs, inten).unsqueeze(-1))
+                if pnt_feat_dim > 4:
+                    cols.append(torch.zeros_like(occ_probs).unsqueeze(-1))
+            cols.append(occ_probs.unsqueeze(-1))
+            if self.code_num_dim > 1:
+                cols.append(torch.ones_like(occ_probs).unsqueeze(-1))
+            occ_points = torch.cat(cols, dim=-1)
+            # valid points of the detection voxels + zero code channels (assemble_gt_vox_points, :168-190)
+            gv, gn, gc = batch_dict['voxels'], batch_dict['voxel_num_points'], batch_dict['voxel_coords']
+            fpm = batch_dict.get("final_point_mask", None)
+            if self.config_realdrop and fpm is not None and gv.shape[1] == fpm.shape[1]:
+                mask = fpm
+            else:
+                mask = gn.view(-1, 1) > torch.arange(gv.shape[1], dtype=torch.int, device=dev).view(1, -1)
+            inds = mask.nonzero()
+            gt_points = torch.cat([gv[inds[:, 0], inds[:, 1], :],
+                                   torch.zeros((inds.shape[0], self.code_num_dim), dtype=gv.dtype, device=dev)], dim=-1)
+            gt_cells = gc[inds[:, 0], :].to(torch.int64)
+            points = torch.cat((gt_points, occ_points), dim=0)
+            cells = torch.cat((gt_cells, occ_cells), dim=0)
+            nx, ny, nz = [int(g) for g in self.det_grid_size]
+            voxels, num, vcoords = revoxelize(points.float(), cells, batch_size, [nz, ny, nx])
+            batch_dict['voxels'], batch_dict['voxel_num_points'], batch_dict['voxel_coords'] = voxels, num, vcoords
+        else:
+            zeros = torch.zeros_like(batch_dict['voxels'][..., 0:self.code_num_dim])
+            batch_dict["added_occ_b_ind"] = torch.zeros([1], dtype=torch.int64, device=dev)
+            batch_dict["added_occ_xyz"] = torch.zeros([1, 3], dtype=torch.float32, device=dev)
+            batch_dict["occ_pnts"] = torch.zeros([1, 4], dtype=torch.float32, device=dev)
+            batch_dict['voxels'] = torch.cat((batch_dict['voxels'], zeros), dim=-1)
+        if not self.pass_gradient:
+            for k in ('occ_pnts', 'added_occ_xyz', 'added_occ_b_ind', 'voxels'):
+                batch_dict[k] = batch_dict[k].detach()
+        return batch_dict
+
+
+__all__ = {'PassOccVox': PassOccVox}

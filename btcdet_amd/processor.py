@@ -1,0 +1,157 @@
+"""DataProcessor: the reference's NAME-dispatched pre-processing queue with the voxelizers on the GPU.
+
+Mirrors /root/reference/btcdet/datasets/processor/data_processor.py:7-258 (constructor
+``DataProcessor(processor_configs, point_cloud_range, training, occ_config=, det_point_cloud_range=)``,
+attributes ``occ_grid_size / occ_voxel_size / det_grid_size / det_voxel_size / occ_dim``, one method per
+``NAME``).  Two entry points:
+  * ``forward(data_dict)``      -- the reference protocol (one scene, numpy in / numpy out), for drop-in use
+                                   inside a DataLoader-style caller;
+  * ``forward_batch(batch)``    -- the resident path: a collated batch already in HBM is range-masked,
+                                   transformed and voxelized for both grids with no host round trip
+                                   (what bench.py times; the reference does this on CPU workers).
+"""
+from functools import partial
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check, lib, ptr, stream_ptr
+from .spconv.utils import VoxelGeneratorV2
+
+
+def mask_points_by_range(points, limit_range):
+    """x,y only (z is not tested): /root/reference/btcdet/utils/common_utils.py:59-62"""
+    return (points[:, 0] >= limit_range[0]) & (points[:, 0] <= limit_range[3]) \
+        & (points[:, 1] >= limit_range[1]) & (points[:, 1] <= limit_range[4])
+
+
+def boxes_to_corners_3d(boxes3d):
+    """(N,7) [x,y,z,dx,dy,dz,heading] -> (N,8,3); box_utils.boxes_to_corners_3d of OpenPCDet"""
+    template = np.array([[1, 1, -1], [1, -1, -1], [-1, -1, -1], [-1, 1, -1], [1, 1, 1], [1, -1, 1], [-1, -1, 1], [-1, 1, 1]]) / 2
+    corners = boxes3d[:, None, 3:6] * template[None, :, :]
+    c, s = np.cos(boxes3d[:, 6]), np.sin(boxes3d[:, 6])
+    rot = np.stack([np.stack([c, s, np.zeros_like(c)], -1), np.stack([-s, c, np.zeros_like(c)], -1),
+                    np.stack([np.zeros_like(c), np.zeros_like(c), np.ones_like(c)], -1)], axis=1)
+    return np.einsum("nkj,nji->nki", corners, rot) + boxes3d[:, None, 0:3]
+
+
+def mask_boxes_outside_range_numpy(boxes, limit_range, min_num_corners=1):
+    if boxes.shape[1] > 7:
+        boxes = boxes[:, 0:7]
+    corners = boxes_to_corners_3d(boxes)
+    mask = ((corners >= limit_range[0:3]) & (corners <= limit_range[3:6])).all(axis=2)
+    return mask.sum(axis=1) >= min_num_corners
+
+
+def cart_to_occ_coords(points, coord_type):
+    """GPU absxyz_2_cylinxyz_np / absxyz_2_spherexyz_np (coords_utils.py:268-292)"""
+    points = points.contiguous()
+    out = torch.empty_like(points)
+    mode = {"cylinder": 1, "sphere": 2}[coord_type]
+    check(lib().btc_cart_to_occ_coords(ptr(points), ptr(out), points.shape[0], points.shape[1], mode, stream_ptr()),
+          "btc_cart_to_occ_coords")
+    return out
+
+
+class DataProcessor(object):
+    def __init__(self, processor_configs, point_cloud_range, training, **kwargs):
+        self.point_cloud_range = point_cloud_range
+        self.training = training
+        self.mode = 'train' if training else 'test'
+        self.grid_size = self.voxel_size = None
+        self.occ_config = kwargs["occ_config"]
+        self.det_point_cloud_range = kwargs["det_point_cloud_range"]
+        self.data_processor_queue = []
+        self.occ_dim = None
+        self._occ_gen = self._det_gen = None
+        for cur_cfg in processor_configs:
+            self.data_processor_queue.append(getattr(self, cur_cfg.NAME)(config=cur_cfg))
+
+    # ------------------------------------------------------------------ reference protocol (per scene, numpy)
+    def mask_points_and_boxes_outside_range(self, data_dict=None, config=None):
+        if data_dict is None:
+            return partial(self.mask_points_and_boxes_outside_range, config=config)
+        mask = mask_points_by_range(data_dict['points'], self.det_point_cloud_range)
+        data_dict['points'] = data_dict['points'][mask]
+        if 'pre_rot_points' in data_dict:
+            data_dict['pre_rot_points'] = data_dict['pre_rot_points'][mask]
+        if data_dict.get('gt_boxes', None) is not None and config.REMOVE_OUTSIDE_BOXES and self.training:
+            keep = mask_boxes_outside_range_numpy(data_dict['gt_boxes'], self.det_point_cloud_range,
+                                                  min_num_corners=config.get('min_num_corners', 1))
+            data_dict['gt_boxes'] = data_dict['gt_boxes'][keep]
+        return data_dict
+
+    def shuffle_points(self, data_dict=None, config=None):
+        if data_dict is None:
+            return partial(self.shuffle_points, config=config)
+        if config.SHUFFLE_ENABLED[self.mode]:
+            data_dict['points'] = data_dict['points'][np.random.permutation(data_dict['points'].shape[0])]
+        return data_dict
+
+    def _make_gen(self, config, rng):
+        gen = VoxelGeneratorV2(voxel_size=config.VOXEL_SIZE, point_cloud_range=rng, max_num_points=config.MAX_POINTS_PER_VOXEL,
+                               max_voxels=config.MAX_NUMBER_OF_VOXELS[self.mode])
+        grid = (np.asarray(rng[3:6]) - np.asarray(rng[0:3])) / np.array(config.VOXEL_SIZE)
+        return gen, np.round(grid).astype(np.int64)
+
+    def transform_points_to_sphere_voxels(self, data_dict=None, config=None, voxel_generator=None):
+        if data_dict is None:
+            voxel_generator, self.occ_grid_size = self._make_gen(config, self.point_cloud_range)
+            self.occ_voxel_size = config.VOXEL_SIZE
+            self.max_points_per_voxel = config.MAX_POINTS_PER_VOXEL
+            self._occ_gen = voxel_generator
+            return partial(self.transform_points_to_sphere_voxels, voxel_generator=voxel_generator)
+        points = data_dict['pre_rot_points'] if 'pre_rot_points' in data_dict else data_dict['points']
+        pts = torch.from_numpy(np.ascontiguousarray(points, dtype=np.float32)).cuda()
+        out = voxel_generator.generate(cart_to_occ_coords(pts, self.occ_config.COORD_TYPE))
+        voxels, coords, num = out['voxels'].cpu().numpy(), out['coordinates'].cpu().numpy(), out['num_points_per_voxel'].cpu().numpy()
+        if not data_dict['use_lead_xyz']:
+            voxels = voxels[..., 3:]
+        if 'pre_rot_points' in data_dict:
+            voxels[..., 1] = voxels[..., 1] - np.float32(data_dict['rot_z'])
+            data_dict.pop('pre_rot_points')
+        data_dict['voxels'], data_dict['voxel_coords'], data_dict['voxel_num_points'] = voxels, coords, num
+        return data_dict
+
+    def det_transform_points_to_voxels(self, data_dict=None, config=None, det_voxel_generator=None):
+        if data_dict is None:
+            det_voxel_generator, self.det_grid_size = self._make_gen(config, self.det_point_cloud_range)
+            self.det_voxel_size = config.VOXEL_SIZE
+            self._det_gen = det_voxel_generator
+            return partial(self.det_transform_points_to_voxels, det_voxel_generator=det_voxel_generator)
+        out = det_voxel_generator.generate(np.ascontiguousarray(data_dict['points'], dtype=np.float32))
+        voxels = out['voxels'] if data_dict['use_lead_xyz'] else out['voxels'][..., 3:]
+        data_dict['det_voxels'], data_dict['det_voxel_coords'], data_dict['det_voxel_num_points'] = \
+            voxels, out['coordinates'], out['num_points_per_voxel']
+        return data_dict
+
+    def transform_points_to_voxels(self, data_dict=None, config=None, voxel_generator=None):
+        if data_dict is None:
+            voxel_generator, grid = self._make_gen(config, self.point_cloud_range)
+            self.occ_grid_size = self.det_grid_size = grid
+            self.occ_voxel_size = self.det_voxel_size = config.VOXEL_SIZE
+            return partial(self.transform_points_to_voxels, voxel_generator=voxel_generator)
+        out = voxel_generator.generate(np.ascontiguousarray(data_dict['points'], dtype=np.float32))
+        voxels = out['voxels'] if data_dict['use_lead_xyz'] else out['voxels'][..., 3:]
+        data_dict['voxels'], data_dict['voxel_coords'], data_dict['voxel_num_points'] = \
+            voxels, out['coordinates'], out['num_points_per_voxel']
+        return data_dict
+
+    def forward(self, data_dict):
+        for cur_processor in self.data_processor_queue:
+            data_dict = cur_processor(data_dict=data_dict)
+        return data_dict
+
+    # ------------------------------------------------------------------ resident path (whole batch in HBM)
+    def forward_batch(self, points, pre_rot_points, scene_offsets, rot_z):
+        """points / pre_rot_points (sum N, 4) f32 on the GPU (already range-masked and shuffled, scenes contiguous),
+        scene_offsets (B+1) i32, rot_z (B) f32 -> the voxel keys of collate_batch (dataset.py:185-192), on the GPU."""
+        cyl = cart_to_occ_coords(pre_rot_points, self.occ_config.COORD_TYPE)
+        vox, coords, num = self._occ_gen.generate_batch(cyl, scene_offsets)
+        if vox.shape[0] > 0:
+            check(lib().btc_voxel_shift_col(ptr(vox), ptr(coords), vox.shape[0], vox.shape[1], vox.shape[2], 1, ptr(rot_z), -1.0,
+                                            stream_ptr()), "btc_voxel_shift_col")
+        dvox, dcoords, dnum = self._det_gen.generate_batch(points, scene_offsets)
+        return {"voxels": vox, "voxel_coords": coords, "voxel_num_points": num, "det_voxels": dvox,
+                "det_voxel_coords": dcoords, "det_voxel_num_points": dnum}

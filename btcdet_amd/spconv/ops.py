@@ -13,6 +13,73 @@ from .. import _lib
 from .._lib import MODE_CONV, MODE_SUBM, MODE_TRANSPOSE, check, i3, i3p, lib, ptr, stream_ptr, workspace
 
 
+class LaunchProfile(object):
+    """Optional per-launch instrumentation (bench.py's `roofline` leg): HIP events recorded on the stream the
+    kernels are launched on, plus the ALGORITHMIC bytes / flops of each launch (SURVEY.md §8d formulas)."""
+
+    def __init__(self):
+        self.records = []  # (name, start_event, end_event, bytes, flops)
+
+    def span(self, name, nbytes, flops, info=None):
+        return _Span(self, name, nbytes, flops, info)
+
+    def details(self):
+        """per-launch rows: (name, ms, bytes, flops, info)"""
+        return [(r[0], r[1].elapsed_time(r[2]), r[3], r[4], r[5] if len(r) > 5 else None) for r in self.records]
+
+    def summary(self):
+        out = {}
+        for name, e0, e1, nbytes, flops in [r[:5] for r in self.records]:
+            d = out.setdefault(name, {"launches": 0, "ms": 0.0, "bytes": 0, "flops": 0})
+            d["launches"] += 1
+            d["ms"] += e0.elapsed_time(e1)
+            d["bytes"] += nbytes
+            d["flops"] += flops
+        return out
+
+
+class _Span(object):
+    def __init__(self, prof, name, nbytes, flops, info=None):
+        self.prof, self.name, self.nbytes, self.flops, self.info = prof, name, nbytes, flops, info
+
+    def __enter__(self):
+        self.e0 = torch.cuda.Event(enable_timing=True)
+        self.e1 = torch.cuda.Event(enable_timing=True)
+        self.e0.record()
+
+    def __exit__(self, *a):
+        self.e1.record()
+        self.prof.records.append((self.name, self.e0, self.e1, self.nbytes, self.flops, self.info))
+
+
+class _NoSpan(object):
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *a):
+        return False
+
+
+PROFILE = None  # set to a LaunchProfile() to instrument
+_NOSPAN = _NoSpan()
+
+
+def _span(name, nbytes_fn):
+    if PROFILE is None:
+        return _NOSPAN
+    r = nbytes_fn()
+    return PROFILE.span(name, r[0], r[1], r[2] if len(r) > 2 else None)
+
+
+def _num_pairs(nbr):
+    """number of (in,out) pairs of a neighbour map = sum_k P_k (profile mode only; one sync per distinct map)"""
+    n = getattr(nbr, "_btc_pairs", None)
+    if n is None:
+        n = int((nbr >= 0).sum().item())
+        nbr._btc_pairs = n
+    return n
+
+
 def get_conv_output_size(input_size, kernel_size, stride, padding, dilation):
     """spconv.ops.get_conv_output_size: o = (i + 2p - d(k-1) - 1)//s + 1 (SURVEY.md App. B.3)."""
     return [int((int(i) + 2 * p - d * (k - 1) - 1) // s + 1)
@@ -76,6 +143,33 @@ def build_rulebook(indices, batch_size, spatial_shape, ksize, stride=1, padding=
     mode = MODE_SUBM if subm else (MODE_TRANSPOSE if transpose else MODE_CONV)
     out_sh = np.zeros(3, dtype=np.int32)
     check(L.btc_out_shape(i3p(in_sh), i3p(k3), i3p(s3), i3p(p3), i3p(d3), i3p(op3), mode, i3p(out_sh)), "btc_out_shape")
+    if PROFILE is not None:
+        return _build_rulebook_profiled(indices, batch_size, spatial_shape, ksize, stride, padding, dilation, out_padding,
+                                        subm, transpose)
+    return _build_rulebook(indices, batch_size, in_sh, out_sh, k3, s3, p3, d3, K, mode, subm)
+
+
+def _build_rulebook_profiled(indices, batch_size, spatial_shape, ksize, stride, padding, dilation, out_padding, subm, transpose):
+    global PROFILE
+    prof, PROFILE = PROFILE, None
+    try:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rb = build_rulebook(indices, batch_size, spatial_shape, ksize, stride, padding, dilation, out_padding, subm, transpose)
+        e1.record()
+        # SURVEY.md §8d, rulebook: 16 N_in + 16 N_out + 8 sum_k P_k bytes
+        prof.records.append(("rulebook", e0, e1, 16 * rb.n_in + 16 * rb.n_out + 8 * _num_pairs(rb.nbr_out), 0,
+                             dict(rows=rb.n_out, n_in=rb.n_in, K=rb.K, pairs=_num_pairs(rb.nbr_out), mode=rb.mode,
+                                  out_shape=list(rb.out_shape))))
+    finally:
+        PROFILE = prof
+    return rb
+
+
+def _build_rulebook(indices, batch_size, in_sh, out_sh, k3, s3, p3, d3, K, mode, subm):
+    dev = indices.device
+    n = indices.shape[0]
+    L = lib()
     if subm:
         nbr_out = torch.empty((n, K), dtype=torch.int32, device=dev)
         nbr_in = torch.empty((n, K), dtype=torch.int32, device=dev)
@@ -114,6 +208,18 @@ def _f32c(t):
     return t.contiguous()
 
 
+def _conv_cost(nbr, n_res, K, cred, cres):
+    """SURVEY.md §8d, sparse conv fwd (dgrad is the same launch with the channel roles swapped):
+    bytes = 4 (sum_k P_k (Cin + Cout) + K Cin Cout + N_out Cout), flops = 2 sum_k P_k Cin Cout"""
+    P = _num_pairs(nbr)
+    return 4 * (P * (cred + cres) + K * cred * cres + n_res * cres), 2 * P * cred * cres, dict(rows=n_res, K=K, cred=cred, cres=cres, pairs=P)
+
+
+def _wgrad_cost(nbr, n_res, K, cin, cout):
+    P = _num_pairs(nbr)
+    return 4 * (P * (cin + cout) + K * cin * cout), 2 * P * cin * cout, dict(rows=n_res, K=K, cred=cin, cres=cout, pairs=P)
+
+
 class SparseConvFunction(torch.autograd.Function):
     """indice_conv / indice_subm_conv / indice_inverse_conv in one function.
     map_fwd (n_res,K): source row gathered by result row i at offset k; map_bwd (n_src,K) its transpose."""
@@ -129,8 +235,9 @@ class SparseConvFunction(torch.autograd.Function):
         n_res = map_fwd.shape[0]
         out = torch.empty((n_res, cout), dtype=torch.float32, device=features.device)
         b = _f32c(bias) if bias is not None else None
-        check(lib().btc_conv_fwd(ptr(features), ptr(w), ptr(b), ptr(map_fwd), n_res, K, cin, cout, ptr(out),
-                                 stream_ptr()), "btc_conv_fwd")
+        with _span("conv_apply", lambda: _conv_cost(map_fwd, n_res, K, cin, cout)):
+            check(lib().btc_conv_fwd(ptr(features), ptr(w), ptr(b), ptr(map_fwd), n_res, K, cin, cout, ptr(out),
+                                     stream_ptr()), "btc_conv_fwd")
         ctx.save_for_backward(features, w, map_fwd, map_bwd)
         ctx.has_bias = bias is not None
         ctx.wshape = tuple(weight.shape)
@@ -147,15 +254,17 @@ class SparseConvFunction(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             n_src = map_bwd.shape[0]
             din = torch.empty((n_src, cin), dtype=torch.float32, device=grad_out.device)
-            check(L.btc_conv_dgrad(ptr(grad_out), ptr(w), ptr(map_bwd), n_src, K, cin, cout, ptr(din), stream_ptr()),
-                  "btc_conv_dgrad")
+            with _span("conv_apply", lambda: _conv_cost(map_bwd, n_src, K, cout, cin)):
+                check(L.btc_conv_dgrad(ptr(grad_out), ptr(w), ptr(map_bwd), n_src, K, cin, cout, ptr(din), stream_ptr()),
+                      "btc_conv_dgrad")
         if ctx.needs_input_grad[1]:
             n_res = map_fwd.shape[0]
             dw = torch.empty(ctx.wshape, dtype=torch.float32, device=grad_out.device)
             ws_bytes = L.btc_conv_wgrad_ws_bytes(n_res, K, cin, cout)
             ws = workspace(ws_bytes, grad_out.device)
-            check(L.btc_conv_wgrad(ptr(features), ptr(grad_out), ptr(map_fwd), n_res, K, cin, cout, ptr(dw), ptr(ws),
-                                   ws_bytes, stream_ptr()), "btc_conv_wgrad")
+            with _span("conv_wgrad", lambda: _wgrad_cost(map_fwd, n_res, K, cin, cout)):
+                check(L.btc_conv_wgrad(ptr(features), ptr(grad_out), ptr(map_fwd), n_res, K, cin, cout, ptr(dw), ptr(ws),
+                                       ws_bytes, stream_ptr()), "btc_conv_wgrad")
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = grad_out.sum(0)
         return din, dw, db, None, None
