@@ -29,11 +29,25 @@ HBM_PEAK_GBS = 8000.0       # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 
 FP32_MFMA_PEAK_TF = 157.3   # same guide: fp32-input MFMA peak
 
 
+def rank_seeds(rank, i, batch_size=2):
+    """scene seeds of batch i on a rank: ranks draw disjoint scenes (the DistributedSampler shard)"""
+    return [1000 * rank + 10 * i + j for j in range(batch_size)]
+
+
+def max_over_ranks(dt, dist, device):
+    """wall time of the slowest rank (the step ends at the gradient all-reduce barrier)"""
+    if dist is None:
+        return dt
+    t = torch.tensor([dt], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
 def build_batches(n_batches, rank, device, batch_size=2):
     from btcdet_amd import synth
     batches = []
     for i in range(n_batches):
-        seeds = [1000 * rank + 10 * i + j for j in range(batch_size)]
+        seeds = rank_seeds(rank, i, batch_size)
         b = synth.make_batch(seeds)
         batches.append({
             "batch_size": batch_size,
@@ -60,7 +74,8 @@ def make_step(model, ddp, proc, opts):
                    "gt_boxes_num": batch["gt_boxes_num"], "box_mirr_flag": batch["box_mirr_flag"],
                    "bm_points": batch["bm_points"], "rot_z": batch["rot_z"], "is_train": True})
         ret, tb, _ = ddp(bd)
-        loss = ret["loss_occ"] + 1e-3 * ret["spatial_features"].pow(2).mean()
+        # occupancy loss (real) + L2 stand-ins for the out-of-scope consumers of the detection branch
+        loss = ret["loss_occ"] + 1e-3 * ret["spatial_features"].pow(2).mean() + 1e-3 * ret["x_combine"].pow(2).mean()
         loss.backward()
         for o in opts:
             o.step()
@@ -185,10 +200,7 @@ def main():
             step(batches[i % len(batches)])
         sync()
     ops.PROFILE = None
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = max_over_ranks(dt, dist, device)
 
     result = None
     if rank == 0:

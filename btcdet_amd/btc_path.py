@@ -4,7 +4,8 @@ detection branch, with the module lists, registry names and ``occ_modules`` / ``
 ``state_dict`` keys line up with reference checkpoints (occ_modules.backbone_3d.conv1.0.0.weight, ...).
 
 Out of scope: BaseBEVBackbone, AnchorHeadSingle, ConvHead.  The detection branch therefore ends
-at HeightCompression; bench.py drives its backward with a stand-in L2 loss on ``spatial_features``.
+at HeightCompression; bench.py drives its backward with a stand-in L2 loss on the two tensors those heads
+consume (``spatial_features`` and ``multi_scale_3d_features['x_combine']``).
 """
 import numpy as np
 import torch
@@ -90,4 +91,6 @@ class BtcHotPath(nn.Module):
         for mod in self.det_module_list:
             batch_dict = mod(batch_dict)
         occ_loss, tb_dict = self.occ_modules.occ_dense_head.get_loss(batch_dict)
-        return {"loss_occ": occ_loss, "spatial_features": batch_dict["spatial_features"]}, tb_dict, batch_dict
+        # the two tensors the out-of-scope heads consume: the BEV map (BaseBEVBackbone) and x_combine (ConvHead)
+        return {"loss_occ": occ_loss, "spatial_features": batch_dict["spatial_features"],
+                "x_combine": batch_dict["multi_scale_3d_features"]["x_combine"].features}, tb_dict, batch_dict

@@ -1,0 +1,47 @@
+"""world_size-2 gloo run of the data-parallel scaffolding bench.py uses (one process per device, DDP gradient
+all-reduce, barrier-bracketed timing with max over ranks, disjoint scene shards).  The HIP kernels cannot run on CPU,
+so the model here is a small torch module; what is covered is the N > 1 control path."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    import bench
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(666)
+    model = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.BatchNorm1d(16), torch.nn.ReLU(), torch.nn.Linear(16, 1))
+    ddp = torch.nn.parallel.DistributedDataParallel(model, find_unused_parameters=False)
+    seeds = bench.rank_seeds(rank, 0)
+    x = torch.from_numpy(np.random.default_rng(seeds[0]).standard_normal((32, 8)).astype(np.float32))
+    dist.barrier()
+    loss = ddp(x).pow(2).mean()
+    loss.backward()
+    dist.barrier()
+    dt = bench.max_over_ranks(0.1 * (rank + 1), dist, torch.device("cpu"))
+    g = torch.cat([p.grad.reshape(-1) for p in model.parameters()])
+    local = torch.autograd.grad(model(x).pow(2).mean(), list(model.parameters()))
+    out[rank] = (g.numpy(), torch.cat([t.reshape(-1) for t in local]).numpy(), dt, seeds)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ddp_gloo_world2():
+    world, port = 2, 29731
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
+    g0, l0, dt0, s0 = out[0]
+    g1, l1, dt1, s1 = out[1]
+    np.testing.assert_allclose(g0, g1, rtol=0, atol=0)                      # all ranks hold the same reduced gradient
+    np.testing.assert_allclose(g0, 0.5 * (l0 + l1), rtol=1e-5, atol=1e-6)  # = mean of the per-rank gradients
+    assert dt0 == dt1 == 0.2                                                # max over ranks
+    assert not set(s0) & set(s1)                                            # disjoint scene shards

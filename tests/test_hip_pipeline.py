@@ -1,0 +1,171 @@
+"""GPU tests of the module layer (DataProcessor, VFEs, backbones, OccHead3D losses, PassOccVox, the assembled
+hot path) against the golden vectors of the real reference and the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+import common
+from golden_batch import golden_batch
+from oracle import occ_oracle, oracle as orc
+from test_oracle_golden import canon_slots
+
+from btcdet_amd import synth
+from btcdet_amd.config import load_cfg
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def G():
+    g, scenes, bd = golden_batch()
+    cfg = load_cfg()
+    from btcdet_amd.btc_path import BtcHotPath
+    torch.manual_seed(0)
+    model = BtcHotPath(cfg, device=DEV).to(DEV)
+    return g, scenes, bd, cfg, model
+
+
+def voxel_dict(coords, num, voxels):
+    return {tuple(c): (int(n), v[:int(n)]) for c, n, v in zip(coords.tolist(), num.tolist(), voxels)}
+
+
+def test_processor_forward_batch_vs_golden(G):
+    g, scenes, bd, cfg, model = G
+    proc = model.dataset.data_processor
+    pts = np.concatenate([s["points"] for s in scenes])
+    pre = np.concatenate([s["pre_rot_points"] for s in scenes])
+    offs = np.cumsum([0] + [s["points"].shape[0] for s in scenes]).astype(np.int32)
+    rot = np.array([s["rot_z"] for s in scenes], np.float32)
+    out = proc.forward_batch(torch.from_numpy(pts).to(DEV), torch.from_numpy(pre).to(DEV), torch.from_numpy(offs).to(DEV),
+                             torch.from_numpy(rot).to(DEV))
+    # detection grid: no transcendental involved -> bit-exact with the reference's DataProcessor output
+    np.testing.assert_array_equal(out["det_voxel_coords"].cpu().numpy(), bd["det_voxel_coords"].numpy().astype(np.int32))
+    np.testing.assert_array_equal(out["det_voxel_num_points"].cpu().numpy(), bd["det_voxel_num_points"].numpy().astype(np.int32))
+    np.testing.assert_array_equal(out["det_voxels"].cpu().numpy(), bd["det_voxels"].numpy())
+    # cylinder grid: device atan2f vs numpy's -> a point on a cell boundary may move; <= 0.2% of the voxels may differ,
+    # matched voxels hold the same points within 2e-5 (deg / m)
+    a = voxel_dict(out["voxel_coords"].cpu().numpy(), out["voxel_num_points"].cpu().numpy(), out["voxels"].cpu().numpy())
+    b = voxel_dict(bd["voxel_coords"].numpy().astype(np.int32), bd["voxel_num_points"].numpy().astype(np.int32), bd["voxels"].numpy())
+    bad = len(set(a) ^ set(b))
+    for k in set(a) & set(b):
+        if a[k][0] != b[k][0] or not np.allclose(a[k][1], b[k][1], rtol=0, atol=2e-5):
+            bad += 1
+    assert bad <= 0.002 * len(b) + 2, (bad, len(b))
+
+
+def test_vfe_modules(G):
+    g, scenes, bd, cfg, model = G
+    d = {"voxels": torch.from_numpy(g["tgt_voxels_absxyz"]).to(DEV), "voxel_num_points": bd["voxel_num_points"].to(DEV)}
+    out = model.occ_modules.vfe(d)["voxel_features"]
+    np.testing.assert_allclose(out.cpu().numpy(), g["meanvfe_voxel_features"], rtol=1e-6, atol=1e-6)
+    d = {"voxels": torch.from_numpy(g["pov_voxels"]).to(DEV), "voxel_num_points": torch.from_numpy(g["pov_voxel_num_points"]).to(DEV),
+         "voxel_coords": torch.from_numpy(g["pov_voxel_coords"]).to(DEV)}
+    d = model.det_modules.vfe(d)
+    np.testing.assert_allclose(d["voxel_features"].cpu().numpy(), g["occvfe_voxel_features"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_array_equal(d["occ_voxel_features"].cpu().numpy(), g["occvfe_occ_voxel_features"])
+
+
+def reference_side_dict(g, bd, cfg, device):
+    """batch_dict as the reference has it right after OccTargets3D + the synthetic head outputs (oracle = pinned)"""
+    O = occ_oracle.OccOracle(cfg)
+    t = O.targets(bd)
+    d = {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in bd.items()}
+    d.update({k: v.to(device) for k, v in t.items() if not k.startswith("_") and torch.is_tensor(v)})
+    logit, res = common.synthetic_head_outputs(2, O.nz, O.ny, O.nx)
+    d["pred_occ_logit"] = torch.from_numpy(logit).to(device)
+    d["batch_pred_occ_prob"] = torch.softmax(d["pred_occ_logit"], dim=1)[:, 1] * d["general_cls_loss_mask"]
+    d["pred_sem_residuals"] = torch.from_numpy(res).to(device)
+    return d
+
+
+def test_occ_loss_vs_golden(G):
+    g, scenes, bd, cfg, model = G
+    d = reference_side_dict(g, bd, cfg, DEV)
+    loss, tb = model.occ_modules.occ_dense_head.get_loss(d)
+    np.testing.assert_allclose([float(loss), tb["occ_loss_cls"], tb["occ_loss_res"]], g["head_loss"], rtol=2e-5)
+
+
+def test_pass_occ_vox_vs_golden(G):
+    g, scenes, bd, cfg, model = G
+    d = reference_side_dict(g, bd, cfg, DEV)
+    d = model.occ_modules.occ_pnt_update(d)
+    vc, vn, vv = d["voxel_coords"].cpu().numpy(), d["voxel_num_points"].cpu().numpy(), d["voxels"].cpu().numpy()
+    assert d["voxel_coords"].dtype == torch.int64 and d["voxel_num_points"].dtype == torch.int64
+    # added occupancy points: same set of (scene, prob) and xyz within 1e-4 m (device cos/sin); order is unspecified in the
+    # reference (topk sorted=False), so compare after sorting by (scene, prob, x)
+    def srt(p, b):
+        k = np.lexsort((p[:, 0], np.round(p[:, 3], 5), b))
+        return p[k], b[k]
+    pa, ba = srt(d["occ_pnts"].cpu().numpy(), d["added_occ_b_ind"].cpu().numpy())
+    pb, bb = srt(g["pov_occ_pnts"], g["pov_added_occ_b_ind"])
+    np.testing.assert_array_equal(ba, bb)
+    np.testing.assert_allclose(pa[:, 3], pb[:, 3], rtol=0, atol=3e-7)   # softmax evaluated on the device
+    np.testing.assert_allclose(pa[:, :3], pb[:, :3], rtol=0, atol=1e-4)
+    # merged detection voxels: identical cells / counts unless an added point sits within 1e-4 m of a 5 cm cell face
+    a = voxel_dict(vc, vn, canon_slots(vv, vn))
+    b = voxel_dict(g["pov_voxel_coords"], g["pov_voxel_num_points"], canon_slots(g["pov_voxels"], g["pov_voxel_num_points"]))
+    bad = len(set(a) ^ set(b))
+    for k in set(a) & set(b):
+        if a[k][0] != b[k][0] or not np.allclose(a[k][1], b[k][1], rtol=0, atol=1e-4):
+            bad += 1
+    assert bad <= 0.002 * len(b) + 2, (bad, len(b))
+    # lexicographic order of the cells (torch.unique(dim=0, sorted=True) in the reference)
+    lin = ((vc[:, 0] * 40 + vc[:, 1]) * 1600 + vc[:, 2]) * 1408 + vc[:, 3]
+    assert np.all(np.diff(lin) > 0)
+
+
+def test_occ_backbone_vs_oracle_chain(G):
+    """VoxelBackBoneDeconv (eval-mode BN) against the oracle's rulebooks + conv chain, layer table of
+    spconv_backbone.py:106-128; checks rulebook construction, the transposed convs and indice_key handling end to end."""
+    g, scenes, bd, cfg, model = G
+    bb = model.occ_modules.backbone_3d.eval()
+    feat = g["meanvfe_voxel_features"]
+    idx = bd["voxel_coords"].numpy().astype(np.int32)
+    d = {"voxel_features": torch.from_numpy(feat).to(DEV), "voxel_coords": torch.from_numpy(idx).to(DEV), "batch_size": 2}
+    with torch.no_grad():
+        out = bb(d)["encoded_spconv_tensor"]
+    layers = [("conv1.0.0", 1, orc.MODE_CONV), ("conv2.0.0", 2, orc.MODE_CONV), ("conv2.1.0", 1, orc.MODE_SUBM),
+              ("conv3.0.0", 2, orc.MODE_CONV), ("conv3.1.0", 1, orc.MODE_SUBM), ("deconv4.0.0", 2, orc.MODE_TRANSPOSE),
+              ("deconv4.1.0", 1, orc.MODE_SUBM), ("deconv5.0.0", 2, orc.MODE_TRANSPOSE), ("deconv5.1.0", 1, orc.MODE_SUBM)]
+    sd = {k: v.cpu().numpy() for k, v in bb.state_dict().items()}
+    shape, f = [9, 157, 209], feat
+    bn = np.float32(1.0) / np.sqrt(np.float32(1.0) + np.float32(1e-3))
+    for name, stride, mode in layers:
+        o_idx, nbr_out, nbr_in, osh = orc.rulebook(idx, shape, 3, stride, 0 if mode == orc.MODE_SUBM else 1, 1, mode)
+        f = np.maximum(orc.conv_fwd(f, sd[name + ".weight"], None, nbr_out) * bn, 0).astype(np.float32)
+        idx, shape = o_idx, list(osh)
+    assert list(out.spatial_shape) == [9, 157, 209] == shape
+    np.testing.assert_array_equal(out.indices.cpu().numpy(), idx)
+    np.testing.assert_allclose(out.features.cpu().numpy(), f, rtol=1e-4, atol=1e-5)
+    bb.train()
+
+
+def test_full_step_runs_and_is_finite(G):
+    import bench
+    g, scenes, bd, cfg, model = G
+    model.train()
+    opts = [torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=1e-4)]
+    batch = bench.build_batches(1, 0, torch.device(DEV))[0]
+    step = bench.make_step(model, model, model.dataset.data_processor, opts)
+    losses = [float(step(batch)) for _ in range(3)]
+    assert all(np.isfinite(losses)), losses
+    missing = [n for n, p in model.named_parameters() if p.requires_grad and p.grad is None]
+    assert not missing, missing
+    assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
+
+
+def test_spconv_drop_in_import():
+    """`import spconv` resolves to this implementation after install_as_spconv() (spconv_backbone.py:3)"""
+    import btcdet_amd
+    sp = btcdet_amd.install_as_spconv()
+    import spconv
+    from spconv.utils import VoxelGeneratorV2
+    assert spconv is sp and VoxelGeneratorV2 is sp.utils.VoxelGeneratorV2
+    x = spconv.SparseConvTensor(torch.randn(5, 4, device=DEV), torch.tensor([[0, 1, 2, 3], [0, 1, 2, 4], [0, 2, 2, 3], [0, 0, 0, 0], [0, 3, 5, 7]],
+                                dtype=torch.int32, device=DEV), [4, 6, 8], 1)
+    net = spconv.SparseSequential(spconv.SubMConv3d(4, 8, 3, padding=1, bias=False, indice_key="a"), torch.nn.BatchNorm1d(8), torch.nn.ReLU(),
+                                  spconv.SparseConv3d(8, 8, 3, stride=2, padding=1, indice_key="b"),
+                                  spconv.SparseInverseConv3d(8, 4, 3, indice_key="b")).to(DEV)
+    y = net(x)
+    assert y.features.shape == (5, 4) and torch.equal(y.indices, x.indices) and list(y.dense().shape) == [1, 4, 4, 6, 8]
