@@ -67,8 +67,8 @@ _SIGS = {
     "btc_pairs_from_nbr": (ci, [vp, ci, ci, ci, vp, vp, vp]),
     "btc_conv_fwd": (ci, [vp, vp, vp, vp, ci, ci, ci, ci, vp, vp]),
     "btc_conv_dgrad": (ci, [vp, vp, vp, ci, ci, ci, ci, vp, vp]),
-    "btc_conv_wgrad_ws_bytes": (sz, [ci, ci, ci, ci]),
-    "btc_conv_wgrad": (ci, [vp, vp, vp, ci, ci, ci, ci, vp, vp, sz, vp]),
+    "btc_conv_wgrad_ws_bytes": (sz, [ci, ci, ci, ci, ci]),
+    "btc_conv_wgrad": (ci, [vp, vp, vp, ci, vp, ci, ci, ci, ci, vp, vp, sz, vp]),
     "btc_maxpool_fwd": (ci, [vp, vp, ci, ci, ci, vp, vp]),
     "btc_maxpool_bwd": (ci, [vp, vp, vp, vp, ci, ci, ci, vp, vp]),
     "btc_dense_fwd": (ci, [vp, vp, ci, ci, c_i32p, vp, vp]),

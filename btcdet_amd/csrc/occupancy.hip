@@ -272,19 +272,29 @@ __global__ __launch_bounds__(256) void occ_bm_pass(const float* __restrict__ bm,
 }
 
 // colmin[b][x] = min over (z,y) of (occupied ? centre_z : 100 + centre_z)  (occ_targets_template.py:251-252)
-__global__ __launch_bounds__(256) void occ_colmin(const uint8_t* __restrict__ voxelwise, OccParams P, float* __restrict__ colmin) {
-  int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= P.B * P.nx) return;
-  int b = t / P.nx, x = t % P.nx;
+// block = 64 x-columns x 16 slices of the (z,y) plane, LDS min-reduce over the slices
+__global__ __launch_bounds__(1024) void occ_colmin(const uint8_t* __restrict__ voxelwise, OccParams P, float* __restrict__ colmin) {
+  __shared__ float s_min[16][64];
+  const int lx = threadIdx.x & 63, part = threadIdx.x >> 6;
+  const int xblocks = (P.nx + 63) / 64;
+  const int b = blockIdx.x / xblocks, x = (blockIdx.x % xblocks) * 64 + lx;
   float m = 3.0e38f;
-  for (int z = 0; z < P.nz; ++z) {
-    float cz = __fadd_rn(__fmul_rn(__fadd_rn(0.5f, (float)z), P.vs[2]), P.origin[2]);
-    for (int y = 0; y < P.ny; ++y) {
-      float v = voxelwise[cell_index(P, b, z, y, x)] ? cz : __fadd_rn(100.0f, cz);
+  if (x < P.nx) {
+    const int zy = P.nz * P.ny;
+    for (int q = part; q < zy; q += 16) {
+      int z = q / P.ny;
+      float cz = __fadd_rn(__fmul_rn(__fadd_rn(0.5f, (float)z), P.vs[2]), P.origin[2]);
+      float v = voxelwise[((size_t)b * zy + q) * P.nx + x] ? cz : __fadd_rn(100.0f, cz);
       m = fminf(m, v);
     }
   }
-  colmin[t] = m;
+  s_min[part][lx] = m;
+  __syncthreads();
+  if (part == 0 && x < P.nx) {
+#pragma unroll
+    for (int q = 1; q < 16; ++q) m = fminf(m, s_min[q][lx]);
+    colmin[b * P.nx + x] = m;
+  }
 }
 
 struct OccOut {
@@ -488,7 +498,7 @@ extern "C" int btc_occ_targets(const BtcOccConfig* cfg, float* voxels, const int
     occ_bm_pass<<<btc_cdiv(n_bm, T), T, 0, stream>>>(bm_points, n_bm, gt_boxes, gt_num, rot_z, P, out->bm_voxelwise_mask, bm_sum, bm_cnt);
     BTC_LAUNCH_CHECK();
   }
-  occ_colmin<<<btc_cdiv(P.B * P.nx, T), T, 0, stream>>>(out->voxelwise_mask, P, colmin);
+  occ_colmin<<<P.B * ((P.nx + 63) / 64), 1024, 0, stream>>>(out->voxelwise_mask, P, colmin);
   BTC_LAUNCH_CHECK();
   OccOut O;
   O.vcc = out->vcc_mask; O.voxelwise = out->voxelwise_mask; O.bm_mask = out->bm_voxelwise_mask; O.occ = out->occ_voxelwise_mask;

@@ -25,86 +25,156 @@ __host__ __device__ constexpr int ldb_of(int nt) { return nt * 16 + (((nt * 16) 
 // out[i] = bias + sum_k feat[nbr[i][k]] @ Wk     (TRANS_W = false: Wk = W[k]      (Cin x Cout), fwd)
 // din[j] =        sum_k dout[nbr[j][k]] @ Wk     (TRANS_W = true : Wk = W[k]^T    (Cout x Cin), dgrad)
 // Cred = reduction channels, Cres = result channels; W is always stored [K][Cin][Cout].
-template <int NT, bool TRANS_W>
-__global__ __launch_bounds__(256) void conv_apply(const float* __restrict__ feat, const float* __restrict__ W,
+//
+// Work items = (active offset k, 32-channel chunk).  Register-staged software pipeline: the global loads of item
+// i+1 (gathered rows + weight panel) are issued before the MFMAs of item i and land in registers while the matrix
+// pipe runs; all loads of an item are issued back to back (one memory latency per item, not one per element).
+template <int NT, bool TRANS_W, bool VEC, int KB, int THREADS>
+__global__ __launch_bounds__(THREADS) void conv_apply(const float* __restrict__ feat, const float* __restrict__ W,
                                                   const float* __restrict__ bias, const int32_t* __restrict__ nbr,
                                                   int n_rows, int K, int Cred, int Cres, float* __restrict__ out) {
+  // KB > 1 (narrow layers, Cred <= 32: one chunk per offset): KB active offsets are staged per phase, which divides the
+  // number of barrier-separated phases by KB and multiplies the loads in flight per workgroup by KB.
+  // THREADS = 256 / 128 / 64 -> 64 / 32 / 16 output rows per workgroup (one 16-row MFMA slab per wave): small and
+  // mid-size layers do not have enough 64-row tiles to hide memory latency by occupancy, so they get smaller workgroups.
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int TM = THREADS / 4;                   // rows per workgroup (shadows the file-level TM)
   constexpr int LDB = ldb_of(NT);
-  float* As = (float*)smem;                    // [TM][LDA]
-  float* Bs = As + TM * LDA;                   // [KC][LDB]
-  int32_t* s_nbr = (int32_t*)(Bs + KC * LDB);  // [TM][K]
-  int32_t* s_kact = s_nbr + TM * K;            // [K]
+  constexpr int NB = NT * 512 / THREADS;            // weight-panel floats per thread and offset (KC * NT*16 / THREADS)
+  float* As = (float*)smem;                         // [KB][TM][LDA]
+  float* Bs = As + KB * TM * LDA;                   // [KB][KC][LDB]
+  int32_t* s_nbr = (int32_t*)(Bs + KB * KC * LDB);  // [TM][K]
+  int32_t* s_kact = s_nbr + TM * K;                 // [K] flags, then the compact list of active offsets
+  int32_t* s_nact = s_kact + K;                     // [1]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int row0 = blockIdx.x * TM;
   const int n0 = blockIdx.y * (NT * 16);
 
-  for (int e = tid; e < K; e += 256) s_kact[e] = 0;
+  for (int e = tid; e < K; e += THREADS) s_kact[e] = 0;
   __syncthreads();
   {
     const long long gbase = (long long)row0 * K;
     const long long gend = (long long)n_rows * K;
-    for (int e = tid; e < TM * K; e += 256) {
+    for (int e = tid; e < TM * K; e += THREADS) {
       int v = (gbase + e < gend) ? nbr[gbase + e] : -1;
       s_nbr[e] = v;
       if (v >= 0) s_kact[e % K] = 1;
     }
   }
   __syncthreads();
+  if (tid == 0) {
+    int n = 0;
+    for (int k = 0; k < K; ++k)
+      if (s_kact[k]) s_kact[n++] = k;  // in-place compaction (n <= k)
+    *s_nact = n;
+  }
+  __syncthreads();
+  const int n_act = *s_nact;
+  const int n_chunks = (KB > 1) ? 1 : (Cred + KC - 1) / KC;
+  const int n_items = (KB > 1) ? (n_act + KB - 1) / KB : n_act * n_chunks;
 
   f32x4 acc[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
   const int arow = wave * 16 + (lane & 15);
   const int kq = lane >> 4;
-  const bool vec4 = (Cred & 3) == 0;
 
-  for (int k = 0; k < K; ++k) {
-    if (!s_kact[k]) continue;  // block-uniform
-    const float* Wk = W + (size_t)k * Cred * Cres;  // same element count either orientation
-    for (int cc = 0; cc < Cred; cc += KC) {
+  float4 av[KB][2];   // VEC : 2 float4 of each A tile
+  float as_[KB][8];   // !VEC: 8 scalars
+  float bv[KB][NB];
+
+  auto prefetch = [&](int item) {
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+      const int ai = (KB > 1) ? item * KB + kb : item / n_chunks;
+      const bool live = ai < n_act;
+      const int k = live ? s_kact[ai] : 0;
+      const int cc = (KB > 1) ? 0 : (item % n_chunks) * KC;
       const int kc = min(KC, Cred - cc);
-      // ---- gather A tile: TM rows x KC channels (zeros for missing rows / channels)
-      if (vec4) {
-        for (int e = tid; e < TM * (KC / 4); e += 256) {
-          int r = e / (KC / 4), c = (e % (KC / 4)) * 4;
-          int j = s_nbr[r * K + k];
-          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (j >= 0 && c < kc) v = *reinterpret_cast<const float4*>(feat + (size_t)j * Cred + cc + c);
-          float* d = As + r * LDA + c;
-          d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+      const float* Wk = W + (size_t)k * Cred * Cres;
+      if (VEC) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          int e = i * THREADS + tid, r = e / (KC / 4), c = (e % (KC / 4)) * 4;
+          int j = live ? s_nbr[r * K + k] : -1;
+          av[kb][i] = (j >= 0 && c < kc) ? *reinterpret_cast<const float4*>(feat + (size_t)j * Cred + cc + c) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
       } else {
-        for (int e = tid; e < TM * KC; e += 256) {
-          int r = e / KC, c = e % KC;
-          int j = s_nbr[r * K + k];
-          As[r * LDA + c] = (j >= 0 && c < kc) ? feat[(size_t)j * Cred + cc + c] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          int e = i * THREADS + tid, r = e / KC, c = e % KC;
+          int j = live ? s_nbr[r * K + k] : -1;
+          as_[kb][i] = (j >= 0 && c < kc) ? feat[(size_t)j * Cred + cc + c] : 0.f;
         }
       }
-      // ---- stage B tile: KC reduction channels x NT*16 result channels of W[k]
-      if (!TRANS_W) {
-        for (int e = tid; e < KC * (NT * 16); e += 256) {
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        int e = i * THREADS + tid;
+        if (!TRANS_W) {
           int r = e / (NT * 16), c = e % (NT * 16);
-          Bs[r * LDB + c] = (r < kc && n0 + c < Cres) ? Wk[(size_t)(cc + r) * Cres + n0 + c] : 0.f;
-        }
-      } else {
-        // Wk^T[r = co][c = ci] = W[k][ci][co]; read along co (contiguous), write transposed
-        for (int e = tid; e < KC * (NT * 16); e += 256) {
+          bv[kb][i] = (live && r < kc && n0 + c < Cres) ? Wk[(size_t)(cc + r) * Cres + n0 + c] : 0.f;
+        } else {  // Wk^T[r = co][c = ci] = W[k][ci][co]; consecutive threads read along co (contiguous)
           int c = e / KC, r = e % KC;
-          Bs[r * LDB + c] = (r < kc && n0 + c < Cres) ? Wk[(size_t)(n0 + c) * Cred + cc + r] : 0.f;
+          bv[kb][i] = (live && r < kc && n0 + c < Cres) ? Wk[(size_t)(n0 + c) * Cred + cc + r] : 0.f;
         }
       }
-      __syncthreads();
-      const int steps = (kc + 3) >> 2;
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+      float* A = As + kb * TM * LDA;
+      float* B = Bs + kb * KC * LDB;
+      if (VEC) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          int e = i * THREADS + tid, r = e / (KC / 4), c = (e % (KC / 4)) * 4;
+          float* d = A + r * LDA + c;
+          d[0] = av[kb][i].x; d[1] = av[kb][i].y; d[2] = av[kb][i].z; d[3] = av[kb][i].w;
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          int e = i * THREADS + tid, r = e / KC, c = e % KC;
+          A[r * LDA + c] = as_[kb][i];
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        int e = i * THREADS + tid;
+        if (!TRANS_W) {
+          int r = e / (NT * 16), c = e % (NT * 16);
+          B[r * LDB + c] = bv[kb][i];
+        } else {
+          int c = e / KC, r = e % KC;
+          B[r * LDB + c] = bv[kb][i];
+        }
+      }
+    }
+  };
+
+  if (n_items > 0) prefetch(0);
+  for (int item = 0; item < n_items; ++item) {
+    const int cc = (KB > 1) ? 0 : (item % n_chunks) * KC;
+    const int kc = min(KC, Cred - cc);
+    __syncthreads();  // the previous item's fragment reads are done
+    commit();
+    __syncthreads();
+    if (item + 1 < n_items) prefetch(item + 1);  // in flight during the MFMAs below
+    const int steps = (kc + 3) >> 2;
+    const int cnt = (KB > 1) ? min(KB, n_act - item * KB) : 1;
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+      if (kb >= cnt) break;  // block-uniform; padded offsets hold zeros anyway
+      const float* A = As + kb * TM * LDA;
+      const float* B = Bs + kb * KC * LDB;
       for (int q = 0; q < steps; ++q) {
-        float a = As[arow * LDA + q * 4 + kq];
-        const float* bp = Bs + (q * 4 + kq) * LDB + (lane & 15);
+        float a = A[arow * LDA + q * 4 + kq];
+        const float* bp = B + (q * 4 + kq) * LDB + (lane & 15);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bp[nt * 16], acc[nt], 0, 0, 0);
       }
-      __syncthreads();
     }
   }
 
@@ -113,12 +183,140 @@ __global__ __launch_bounds__(256) void conv_apply(const float* __restrict__ feat
   for (int nt = 0; nt < NT; ++nt) {
     const int col = n0 + nt * 16 + (lane & 15);
     if (col >= Cres) continue;
-    const float bv = bias ? bias[col] : 0.f;
+    const float bv0 = bias ? bias[col] : 0.f;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       int row = row0 + wave * 16 + kq * 4 + r;
-      if (row < n_rows) out[(size_t)row * Cres + col] = bias ? (acc[nt][r] + bv) : acc[nt][r];
+      if (row < n_rows) out[(size_t)row * Cres + col] = bias ? (acc[nt][r] + bv0) : acc[nt][r];
     }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Weight-stationary variant for narrow layers (Cred, Cres <= 32: K*Cred*Cres*4 <= 110 KB).  The profile of
+// conv_apply on these layers is dominated by L2->LDS re-reads of the K weight panels by every 64-row workgroup and
+// by the serial chain of K barrier-separated gather->MFMA phases per tile.  Here one persistent 16-wave workgroup
+// per CU keeps ALL K panels resident in LDS (160 KB per CU on gfx950); every wave walks its own 16-row tiles with
+// no workgroup barrier after the weight load; the A fragments are gathered STRAIGHT INTO REGISTERS in MFMA layout
+// (lane (row, kq) loads channels q*4+kq), WS_KB offsets at a time, one group ahead of the MFMAs.
+// Same summation order as conv_apply (offset ascending, channel ascending) -> same bits.
+// ------------------------------------------------------------------------------------------------------------
+constexpr int WS_WAVES = 16;
+constexpr int WS_KB = 4;
+
+__host__ __device__ inline size_t ws_lds_bytes(int K, int Cred, int nt) {
+  int crp = (Cred + 3) & ~3;
+  return (size_t)K * crp * (nt * 16) * sizeof(float) + (size_t)WS_WAVES * 16 * K * sizeof(int32_t);
+}
+
+template <int NT, bool TRANS_W>
+__global__ __launch_bounds__(WS_WAVES * 64) void conv_apply_ws(const float* __restrict__ feat, const float* __restrict__ W,
+                                                              const float* __restrict__ bias, const int32_t* __restrict__ nbr,
+                                                              int n_rows, int K, int Cred, int Cres, float* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int LDW = NT * 16;
+  constexpr int QMAX = KC / 4;  // k-steps of a full 32-channel row
+  const int crp = (Cred + 3) & ~3;
+  float* Ws = (float*)smem;                                     // [K][crp][LDW], column XOR-swizzled by (row & 1) << 4 when NT == 2
+  int32_t* nb_all = (int32_t*)(Ws + (size_t)K * crp * LDW);     // [WS_WAVES][16][K]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kq = lane >> 4, lrow = lane & 15;
+  int32_t* nb = nb_all + wave * 16 * K;
+
+  // ---- resident weights: Ws[k][r][c] = Wk[r][c]  (Wk = W[k] or W[k]^T), zero padded; loads batched 8 deep
+  {
+    const int total = K * crp * LDW;
+    for (int base = 0; base < total; base += WS_WAVES * 64 * 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        int e = base + u * WS_WAVES * 64 + tid;
+        int c = e % LDW, r = (e / LDW) % crp, k = e / (LDW * crp);
+        v[u] = 0.f;
+        if (e < total && r < Cred && c < Cres) v[u] = TRANS_W ? W[((size_t)k * Cres + c) * Cred + r] : W[((size_t)k * Cred + r) * Cres + c];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        int e = base + u * WS_WAVES * 64 + tid;
+        if (e < total) {
+          int c = e % LDW, r = (e / LDW) % crp, k = e / (LDW * crp);
+          int cs = (NT == 2) ? (c ^ ((r & 1) << 4)) : c;
+          Ws[((size_t)k * crp + r) * LDW + cs] = v[u];
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  const int n_tiles = (n_rows + 15) >> 4;
+  const int steps = crp >> 2;
+  for (int tile = blockIdx.x * WS_WAVES + wave; tile < n_tiles; tile += gridDim.x * WS_WAVES) {
+    const int row0 = tile << 4;
+    // neighbour rows of the tile (16 x K ints, contiguous) and the set of offsets that occur in it
+    unsigned long long kmask = 0;
+    {
+      const long long gbase = (long long)row0 * K, gend = (long long)n_rows * K;
+      for (int e = lane; e < 16 * K; e += 64) {
+        int v = (gbase + e < gend) ? nbr[gbase + e] : -1;
+        nb[e] = v;
+        if (v >= 0) kmask |= 1ull << (e % K);
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) kmask |= __shfl_xor(kmask, o, 64);
+    }
+    __builtin_amdgcn_wave_barrier();
+    f32x4 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    float va[WS_KB][QMAX], vb[WS_KB][QMAX];  // current / next group of A fragments
+    int ka[WS_KB], kb_[WS_KB];
+    unsigned long long rem = kmask;
+    // take the next WS_KB active offsets off the mask and issue their gathers into `v`
+#define WS_FETCH(v, kk)                                                                             \
+  _Pragma("unroll") for (int g = 0; g < WS_KB; ++g) {                                               \
+    kk[g] = rem ? (__ffsll((long long)rem) - 1) : -1;                                               \
+    rem &= rem - 1;                                                                                 \
+    const int j = (kk[g] >= 0) ? nb[lrow * K + kk[g]] : -1;                                         \
+    const float* src = feat + (size_t)(j >= 0 ? j : 0) * Cred + kq;                                 \
+    _Pragma("unroll") for (int q = 0; q < QMAX; ++q)                                                \
+        v[g][q] = (j >= 0 && q * 4 + kq < Cred && q < steps) ? src[q * 4] : 0.f;                    \
+  }
+#define WS_MATH(v, kk)                                                                              \
+  _Pragma("unroll") for (int g = 0; g < WS_KB; ++g) {                                               \
+    if (kk[g] < 0) break;                                                                           \
+    const float* Wk = Ws + (size_t)kk[g] * crp * LDW;                                               \
+    _Pragma("unroll") for (int q = 0; q < QMAX; ++q) {                                              \
+      if (q >= steps) break;                                                                        \
+      const int r = q * 4 + kq;                                                                     \
+      _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) {                                           \
+        int c = nt * 16 + lrow;                                                                     \
+        if (NT == 2) c ^= (r & 1) << 4;                                                             \
+        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[g][q], Wk[r * LDW + c], acc[nt], 0, 0, 0); \
+      }                                                                                             \
+    }                                                                                               \
+  }
+    WS_FETCH(va, ka)
+    while (ka[0] >= 0) {
+      WS_FETCH(vb, kb_)   // next group in flight during this group's MFMAs
+      WS_MATH(va, ka)
+      if (kb_[0] < 0) break;
+      WS_FETCH(va, ka)
+      WS_MATH(vb, kb_)
+    }
+#undef WS_FETCH
+#undef WS_MATH
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int col = nt * 16 + lrow;
+      if (col >= Cres) continue;
+      const float bv0 = bias ? bias[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int row = row0 + kq * 4 + r;
+        if (row < n_rows) out[(size_t)row * Cres + col] = bias ? (acc[nt][r] + bv0) : acc[nt][r];
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -155,14 +353,56 @@ __global__ __launch_bounds__(256) void conv_wgrad_partial(const float* __restric
     if (tid < TM && row0 + tid < n_out) j = nbr[(size_t)(row0 + tid) * K + k];
     if (tid < TM) s_j[tid] = j;
     if (!__syncthreads_or(j >= 0)) continue;
-    for (int e = tid; e < TM * 64; e += 256) {
-      int r = e >> 6, c = e & 63;
-      int jj = s_j[r];
-      As[r * WG_LDA + c] = (jj >= 0 && m0 + c < Cin) ? feat[(size_t)jj * Cin + m0 + c] : 0.f;
-    }
-    for (int e = tid; e < TM * (NT * 16); e += 256) {
-      int r = e / (NT * 16), c = e % (NT * 16);
-      Ds[r * LDB + c] = (s_j[r] >= 0 && n0 + c < Cout) ? dout[(size_t)(row0 + r) * Cout + n0 + c] : 0.f;
+    // all loads of a thread are issued before the first LDS store (one memory latency per tile)
+    if (((Cin | Cout) & 3) == 0) {
+      float4 va[4], vd[NT];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        int e = i * 256 + tid, r = e >> 4, c = (e & 15) * 4;
+        int jj = s_j[r];
+        va[i] = (jj >= 0 && m0 + c < Cin) ? *reinterpret_cast<const float4*>(feat + (size_t)jj * Cin + m0 + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int i = 0; i < NT; ++i) {
+        int e = i * 256 + tid, r = e / (NT * 4), c = (e % (NT * 4)) * 4;
+        vd[i] = (s_j[r] >= 0 && n0 + c < Cout) ? *reinterpret_cast<const float4*>(dout + (size_t)(row0 + r) * Cout + n0 + c)
+                                               : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        int e = i * 256 + tid, r = e >> 4, c = (e & 15) * 4;
+        float* d = As + r * WG_LDA + c;
+        d[0] = va[i].x; d[1] = va[i].y; d[2] = va[i].z; d[3] = va[i].w;
+      }
+#pragma unroll
+      for (int i = 0; i < NT; ++i) {
+        int e = i * 256 + tid, r = e / (NT * 4), c = (e % (NT * 4)) * 4;
+        float* d = Ds + r * LDB + c;
+        d[0] = vd[i].x; d[1] = vd[i].y; d[2] = vd[i].z; d[3] = vd[i].w;
+      }
+    } else {
+      float va[16], vd[NT * 4];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        int e = i * 256 + tid, r = e >> 6, c = e & 63;
+        int jj = s_j[r];
+        va[i] = (jj >= 0 && m0 + c < Cin) ? feat[(size_t)jj * Cin + m0 + c] : 0.f;
+      }
+#pragma unroll
+      for (int i = 0; i < NT * 4; ++i) {
+        int e = i * 256 + tid, r = e / (NT * 16), c = e % (NT * 16);
+        vd[i] = (s_j[r] >= 0 && n0 + c < Cout) ? dout[(size_t)(row0 + r) * Cout + n0 + c] : 0.f;
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        int e = i * 256 + tid, r = e >> 6, c = e & 63;
+        As[r * WG_LDA + c] = va[i];
+      }
+#pragma unroll
+      for (int i = 0; i < NT * 4; ++i) {
+        int e = i * 256 + tid, r = e / (NT * 16), c = e % (NT * 16);
+        Ds[r * LDB + c] = vd[i];
+      }
     }
     __syncthreads();
     if (wave_live) {
@@ -189,12 +429,169 @@ __global__ __launch_bounds__(256) void conv_wgrad_partial(const float* __restric
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Row-stationary weight gradient for the large-N / small-C layers (the occupancy branch: up to 210 K rows at 32
+// channels).  A persistent workgroup walks row tiles; per tile the dOut rows and the neighbour-map rows are loaded
+// ONCE (coalesced, row-major) and the K offsets are processed in phases of KB gathered input tiles; the whole
+// dW slab of the workgroup's offset group (PH*KB offsets x Cin x Cout) lives in MFMA accumulators for the entire
+// walk and is written out once.  (The offset-major kernel below re-reads dOut K times and reads the map column-wise.)
+//   MT, NT : 16-wide tiles of Cin / Cout;  KB : offsets per LDS phase;  PH : phases per offset group
+// ------------------------------------------------------------------------------------------------------------
+template <int MT, int NT, int KB, int PH>
+__global__ __launch_bounds__(256) void conv_wgrad_rows(const float* __restrict__ feat, const float* __restrict__ dout,
+                                                       const int32_t* __restrict__ nbr, int n_out, int K, int Cin, int Cout,
+                                                       float* __restrict__ part, int swap) {
+  // Naming follows the un-swapped case: `feat` = gathered operand (Cin channels, via the map), `dout` = contiguous
+  // operand (Cout channels), one tile per 64 map rows.  swap = 1: the walk is over the INPUT rows instead (map =
+  // nbr_in, gathered = dOut, contiguous = features) -- used when the layer has far fewer input than output rows
+  // (transposed / dilating convs) -- and the slab is written transposed so that dW keeps the [K][Cin][Cout] layout.
+  constexpr int TPP = KB * MT * NT / 4;  // accumulator tiles per wave per phase
+  static_assert(KB * MT * NT % 4 == 0, "phase tiles must split evenly over the 4 waves");
+  constexpr int LDA = ldb_of(MT), LDB = ldb_of(NT);
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* As = (float*)smem;                       // [KB][TM][LDA]
+  float* Ds = As + KB * TM * LDA;                 // [TM][LDB]
+  int32_t* s_nbr = (int32_t*)(Ds + TM * LDB);     // [TM][K]
+  int32_t* s_kact = s_nbr + TM * K;               // [K]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kq = lane >> 4;
+  const int kg0 = blockIdx.y * (PH * KB);         // first offset of this workgroup's group
+  const int n_tiles = (n_out + TM - 1) / TM;
+
+  f32x4 acc[PH * TPP];
+#pragma unroll
+  for (int t = 0; t < PH * TPP; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int row0 = tile * TM;
+    for (int e = tid; e < K; e += 256) s_kact[e] = 0;
+    __syncthreads();
+    {
+      const long long gbase = (long long)row0 * K, gend = (long long)n_out * K;
+      for (int e = tid; e < TM * K; e += 256) {
+        int v = (gbase + e < gend) ? nbr[gbase + e] : -1;
+        s_nbr[e] = v;
+        if (v >= 0) s_kact[e % K] = 1;
+      }
+    }
+    // dOut tile: all loads of a thread are issued before the first LDS store (one latency, not one per element)
+    if ((Cout & 3) == 0) {
+      float4 v[NT];
+#pragma unroll
+      for (int i = 0; i < NT; ++i) {
+        int e = i * 256 + tid, r = e / (NT * 4), c = (e % (NT * 4)) * 4;
+        v[i] = (row0 + r < n_out && c < Cout) ? *reinterpret_cast<const float4*>(dout + (size_t)(row0 + r) * Cout + c)
+                                              : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int i = 0; i < NT; ++i) {
+        int e = i * 256 + tid, r = e / (NT * 4), c = (e % (NT * 4)) * 4;
+        float* d = Ds + r * LDB + c;
+        d[0] = v[i].x; d[1] = v[i].y; d[2] = v[i].z; d[3] = v[i].w;
+      }
+    } else {
+      float v[NT * 4];
+#pragma unroll
+      for (int i = 0; i < NT * 4; ++i) {
+        int e = i * 256 + tid, r = e / (NT * 16), c = e % (NT * 16);
+        v[i] = (row0 + r < n_out && c < Cout) ? dout[(size_t)(row0 + r) * Cout + c] : 0.f;
+      }
+#pragma unroll
+      for (int i = 0; i < NT * 4; ++i) {
+        int e = i * 256 + tid, r = e / (NT * 16), c = e % (NT * 16);
+        Ds[r * LDB + c] = v[i];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < PH; ++p) {
+      const int k0 = kg0 + p * KB;
+      int any = 0;
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) any |= (k0 + kb < K) ? s_kact[k0 + kb] : 0;
+      if (!any) continue;  // block-uniform
+      // gather KB input tiles; loads batched in registers as above
+      if ((Cin & 3) == 0) {
+        float4 v[KB * MT];
+#pragma unroll
+        for (int i = 0; i < KB * MT; ++i) {
+          int e = i * 256 + tid, c = (e % (MT * 4)) * 4, r = (e / (MT * 4)) % TM, kb = e / (MT * 4 * TM);
+          int j = (k0 + kb < K) ? s_nbr[r * K + k0 + kb] : -1;
+          v[i] = (j >= 0 && c < Cin) ? *reinterpret_cast<const float4*>(feat + (size_t)j * Cin + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < KB * MT; ++i) {
+          int e = i * 256 + tid, c = (e % (MT * 4)) * 4, r = (e / (MT * 4)) % TM, kb = e / (MT * 4 * TM);
+          float* d = As + (kb * TM + r) * LDA + c;
+          d[0] = v[i].x; d[1] = v[i].y; d[2] = v[i].z; d[3] = v[i].w;
+        }
+      } else {
+        float v[KB * MT * 4];
+#pragma unroll
+        for (int i = 0; i < KB * MT * 4; ++i) {
+          int e = i * 256 + tid, c = e % (MT * 16), r = (e / (MT * 16)) % TM, kb = e / (MT * 16 * TM);
+          int j = (k0 + kb < K) ? s_nbr[r * K + k0 + kb] : -1;
+          v[i] = (j >= 0 && c < Cin) ? feat[(size_t)j * Cin + c] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < KB * MT * 4; ++i) {
+          int e = i * 256 + tid, c = e % (MT * 16), r = (e / (MT * 16)) % TM, kb = e / (MT * 16 * TM);
+          As[(kb * TM + r) * LDA + c] = v[i];
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < TPP; ++q) {
+        const int l = q * 4 + wave;  // phase-local tile: (kb, mt, nt)
+        const int nt = l % NT, mt = (l / NT) % MT, kb = l / (NT * MT);
+        const float* ap = As + (size_t)kb * TM * LDA + mt * 16 + (lane & 15);
+        const float* bp = Ds + nt * 16 + (lane & 15);
+        f32x4 a4 = acc[p * TPP + q];
+#pragma unroll 4
+        for (int s = 0; s < TM / 4; ++s)
+          a4 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[(s * 4 + kq) * LDA], bp[(s * 4 + kq) * LDB], a4, 0, 0, 0);
+        acc[p * TPP + q] = a4;
+      }
+      __syncthreads();
+    }
+  }
+  // write this workgroup's slab: part[blockIdx.x][k][ci][co]
+  float* P = part + (size_t)blockIdx.x * K * Cin * Cout;
+#pragma unroll
+  for (int p = 0; p < PH; ++p)
+#pragma unroll
+    for (int q = 0; q < TPP; ++q) {
+      const int l = q * 4 + wave;
+      const int nt = l % NT, mt = (l / NT) % MT, kb = l / (NT * MT);
+      const int k = kg0 + p * KB + kb;
+      const int co = nt * 16 + (lane & 15);
+      if (k >= K || co >= Cout) continue;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int ci = mt * 16 + kq * 4 + r;
+        if (ci < Cin) {
+          if (!swap) P[((size_t)k * Cin + ci) * Cout + co] = acc[p * TPP + q][r];
+          else P[((size_t)k * Cout + co) * Cin + ci] = acc[p * TPP + q][r];  // here ci indexes dOut channels, co feature channels
+        }
+      }
+    }
+}
+
+// dW[e] = sum_s part[s][e] in slab order (deterministic); 8 loads in flight per thread
 __global__ __launch_bounds__(256) void wgrad_reduce(const float* __restrict__ part, int S, long long count,
                                                     float* __restrict__ dW) {
   long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= count) return;
   float s = 0.f;
-  for (int q = 0; q < S; ++q) s += part[(size_t)q * count + e];
+  int q = 0;
+  for (; q + 8 <= S; q += 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = part[(size_t)(q + u) * count + e];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u];
+  }
+  for (; q < S; ++q) s += part[(size_t)q * count + e];
   dW[e] = s;
 }
 
@@ -247,29 +644,103 @@ __global__ __launch_bounds__(256) void dense_bwd_k(const float* __restrict__ dde
   dfeat[(size_t)i * C + c] = ddense[((size_t)q.x * C + c) * vol + ((size_t)q.y * H + q.z) * Wd + q.w];
 }
 
+template <int NT, bool TRANS_W, int THREADS>
+void launch_apply_t(dim3 grid, size_t lds, hipStream_t stream, bool vec, const float* feat, const float* W, const float* bias,
+                    const int32_t* nbr, int n_rows, int K, int Cred, int Cres, float* out) {
+  if (vec) conv_apply<NT, TRANS_W, true, 1, THREADS><<<grid, THREADS, lds, stream>>>(feat, W, bias, nbr, n_rows, K, Cred, Cres, out);
+  else conv_apply<NT, TRANS_W, false, 1, THREADS><<<grid, THREADS, lds, stream>>>(feat, W, bias, nbr, n_rows, K, Cred, Cres, out);
+}
+
 template <bool TRANS_W>
 int launch_apply(const float* feat, const float* W, const float* bias, const int32_t* nbr, int n_rows, int K, int Cred,
                  int Cres, float* out, hipStream_t stream) {
   if (n_rows <= 0) return BTC_OK;
   int nt = Cres <= 16 ? 1 : (Cres <= 32 ? 2 : (Cres <= 64 ? 4 : 8));
-  dim3 grid(btc_cdiv(n_rows, TM), btc_cdiv(Cres, nt * 16));
-  size_t lds = (size_t)(TM * LDA + KC * ldb_of(nt)) * sizeof(float) + (size_t)(TM * K + K) * sizeof(int32_t);
-  switch (nt) {
-    case 1: conv_apply<1, TRANS_W><<<grid, 256, lds, stream>>>(feat, W, bias, nbr, n_rows, K, Cred, Cres, out); break;
-    case 2: conv_apply<2, TRANS_W><<<grid, 256, lds, stream>>>(feat, W, bias, nbr, n_rows, K, Cred, Cres, out); break;
-    case 4: conv_apply<4, TRANS_W><<<grid, 256, lds, stream>>>(feat, W, bias, nbr, n_rows, K, Cred, Cres, out); break;
-    default: conv_apply<8, TRANS_W><<<grid, 256, lds, stream>>>(feat, W, bias, nbr, n_rows, K, Cred, Cres, out); break;
+  // weight-stationary persistent kernel (one 16-wave workgroup per CU).  Measured on MI355X: its dword-granular register
+  // gather wins 2.5x for Cred <= 8 (the dgrad of the 2/3-channel occupancy heads, the 4/6-channel input layers) and loses
+  // 2x at Cred = 32 (load-issue bound), so wider layers stay on the LDS-staged float4 kernel below.
+  if (Cred <= 8 && Cres <= 32 && K <= 64 && n_rows >= 2048 && ws_lds_bytes(K, Cred, nt) <= 160 * 1024) {
+    const int n_tiles16 = btc_cdiv(n_rows, 16);
+    int wgs = btc_cdiv(n_tiles16, WS_WAVES);
+    if (wgs > 256) wgs = 256;
+    size_t lds = ws_lds_bytes(K, Cred, nt);
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute((const void*)conv_apply_ws<1, TRANS_W>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute((const void*)conv_apply_ws<2, TRANS_W>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attr_set = true;
+    }
+    if (nt == 1) conv_apply_ws<1, TRANS_W><<<wgs, WS_WAVES * 64, lds, stream>>>(feat, W, bias, nbr, n_rows, K, Cred, Cres, out);
+    else conv_apply_ws<2, TRANS_W><<<wgs, WS_WAVES * 64, lds, stream>>>(feat, W, bias, nbr, n_rows, K, Cred, Cres, out);
+    BTC_LAUNCH_CHECK();
+    return BTC_OK;
   }
+  // rows per workgroup: 64 when there are >= 4 tiles per CU, else 32, else 16 (latency hiding by occupancy)
+  // (measured: 32- and 16-row workgroups are ~2x SLOWER on every BtcDet layer -- each workgroup re-reads all K weight
+  //  panels, so L2->LDS weight traffic scales with the number of workgroups; the 128/64-thread variants stay available)
+  int threads = 256;
+  const int tm = threads / 4;
+  const int n_tiles = btc_cdiv(n_rows, tm);
+  // still too few workgroups (deep, narrow levels): also split the result channels
+  while (nt > 2 && (long long)n_tiles * btc_cdiv(Cres, nt * 16) < 512) nt >>= 1;
+  dim3 grid(n_tiles, btc_cdiv(Cres, nt * 16));
+  size_t lds = (size_t)(tm * LDA + KC * ldb_of(nt)) * sizeof(float) + (size_t)(tm * K + K + 1) * sizeof(int32_t);
+  const bool vec = (Cred & 3) == 0;
+#define BTC_APPLY(NT_)                                                                                                          \
+  do {                                                                                                                          \
+    if (threads == 256) launch_apply_t<NT_, TRANS_W, 256>(grid, lds, stream, vec, feat, W, bias, nbr, n_rows, K, Cred, Cres, out);      \
+    else if (threads == 128) launch_apply_t<NT_, TRANS_W, 128>(grid, lds, stream, vec, feat, W, bias, nbr, n_rows, K, Cred, Cres, out); \
+    else launch_apply_t<NT_, TRANS_W, 64>(grid, lds, stream, vec, feat, W, bias, nbr, n_rows, K, Cred, Cres, out);                      \
+  } while (0)
+  switch (nt) {
+    case 1: BTC_APPLY(1); break;
+    case 2: BTC_APPLY(2); break;
+    case 4: BTC_APPLY(4); break;
+    default: BTC_APPLY(8); break;
+  }
+#undef BTC_APPLY
   BTC_LAUNCH_CHECK();
   return BTC_OK;
 }
 
 struct WgradPlan {
   int nt, n_cblk, n_mblk, S, tiles_per_split;
+  int rows_kernel;  // 1 = conv_wgrad_rows (row-stationary), 0 = offset-major conv_wgrad_partial
+  int mt, kb, ph, groups, swap, rows;
 };
 
-WgradPlan wgrad_plan(int n_out, int K, int Cin, int Cout) {
+WgradPlan wgrad_plan(int n_out, int K, int Cin, int Cout, int n_in = -1) {
   WgradPlan p;
+  p.rows_kernel = 0;
+  p.swap = 0;
+  p.rows = n_out;
+  {
+    // row-stationary kernel: supported (MT,NT) tile shapes and enough rows to amortise the persistent walk
+    const bool swap = n_in > 0 && 2 * n_in < n_out;  // walk the smaller side of the rulebook
+    const int rows = swap ? n_in : n_out;
+    int mt = btc_cdiv(swap ? Cout : Cin, 16), ntt = btc_cdiv(swap ? Cin : Cout, 16), kb = 0, ph = 7;
+    if (mt == 1 && ntt == 1) { kb = 8; ph = 4; }
+    else if (mt * ntt == 2) kb = 4;
+    else if (mt == 2 && ntt == 2) kb = 4;
+    else if (mt == 3 && ntt == 2) kb = 2;
+    else if (mt * ntt == 8 && (mt == 2 || mt == 4)) kb = 2;
+    else if (mt == 4 && ntt == 4) kb = 1;
+    if (kb && rows >= 4096 && K <= 64) {
+      p.rows_kernel = 1;
+      p.swap = swap; p.rows = rows;
+      p.mt = mt; p.nt = ntt; p.kb = kb; p.ph = ph;
+      p.groups = btc_cdiv(K, kb * ph);
+      int n_tiles = btc_cdiv(rows, TM);
+      int S = 256 / p.groups;
+      if (S > n_tiles / 2) S = n_tiles / 2;  // at least two row tiles per persistent workgroup
+      if (S > n_tiles) S = n_tiles;
+      if (S < 1) S = 1;
+      p.S = S;
+      p.n_cblk = p.n_mblk = 1;
+      p.tiles_per_split = 0;
+      return p;
+    }
+  }
   p.nt = Cout <= 16 ? 1 : (Cout <= 32 ? 2 : (Cout <= 64 ? 4 : 8));
   p.n_cblk = btc_cdiv(Cout, p.nt * 16);
   p.n_mblk = btc_cdiv(Cin, 64);
@@ -299,25 +770,50 @@ extern "C" int btc_conv_dgrad(const float* dout, const float* W, const int32_t* 
   return launch_apply<true>(dout, W, nullptr, nbr_in, n_in, K, /*Cred=*/Cout, /*Cres=*/Cin, din, (hipStream_t)stream);
 }
 
-extern "C" size_t btc_conv_wgrad_ws_bytes(int n_out, int K, int Cin, int Cout) {
-  WgradPlan p = wgrad_plan(n_out, K, Cin, Cout);
+extern "C" size_t btc_conv_wgrad_ws_bytes(int n_out, int K, int Cin, int Cout, int n_in) {
+  WgradPlan p = wgrad_plan(n_out, K, Cin, Cout, n_in);
   return btc_align((size_t)p.S * K * Cin * Cout * sizeof(float));
 }
 
-extern "C" int btc_conv_wgrad(const float* feat, const float* dout, const int32_t* nbr_out, int n_out, int K, int Cin,
-                              int Cout, float* dW, void* ws, size_t ws_bytes, void* stream_) {
+extern "C" int btc_conv_wgrad(const float* feat, const float* dout, const int32_t* nbr_out, int n_out, const int32_t* nbr_in,
+                              int n_in, int K, int Cin, int Cout, float* dW, void* ws, size_t ws_bytes, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   BTC_CHECK_ARG(K >= 1 && Cin >= 1 && Cout >= 1 && n_out >= 0, "btc_conv_wgrad: bad sizes");
-  BTC_CHECK_ARG(ws_bytes >= btc_conv_wgrad_ws_bytes(n_out, K, Cin, Cout), "btc_conv_wgrad: workspace too small");
+  if (!nbr_in) n_in = -1;
+  BTC_CHECK_ARG(ws_bytes >= btc_conv_wgrad_ws_bytes(n_out, K, Cin, Cout, n_in), "btc_conv_wgrad: workspace too small");
   long long count = (long long)K * Cin * Cout;
   if (n_out <= 0) {
     BTC_HIP(hipMemsetAsync(dW, 0, (size_t)count * sizeof(float), stream));
     return BTC_OK;
   }
-  WgradPlan p = wgrad_plan(n_out, K, Cin, Cout);
+  WgradPlan p = wgrad_plan(n_out, K, Cin, Cout, n_in);
+  float* part = (float*)ws;
+  if (p.rows_kernel) {
+    // operands of the walk: gathered rows (via the map) and contiguous rows, see conv_wgrad_rows
+    const float* g_ = p.swap ? dout : feat;
+    const float* c_ = p.swap ? feat : dout;
+    const int32_t* map_ = p.swap ? nbr_in : nbr_out;
+    const int Cg = p.swap ? Cout : Cin, Cc = p.swap ? Cin : Cout;
+    dim3 grid(p.S, p.groups);
+    size_t lds = (size_t)(p.kb * TM * ldb_of(p.mt) + TM * ldb_of(p.nt)) * sizeof(float) + (size_t)(TM * K + K) * sizeof(int32_t);
+#define BTC_WG_ROWS(MT_, NT_, KB_, PH_) \
+  conv_wgrad_rows<MT_, NT_, KB_, PH_><<<grid, 256, lds, stream>>>(g_, c_, map_, p.rows, K, Cg, Cc, part, p.swap)
+    if (p.mt == 1 && p.nt == 1) BTC_WG_ROWS(1, 1, 8, 4);
+    else if (p.mt == 2 && p.nt == 1) BTC_WG_ROWS(2, 1, 4, 7);
+    else if (p.mt == 1 && p.nt == 2) BTC_WG_ROWS(1, 2, 4, 7);
+    else if (p.mt == 2 && p.nt == 2) BTC_WG_ROWS(2, 2, 4, 7);
+    else if (p.mt == 3 && p.nt == 2) BTC_WG_ROWS(3, 2, 2, 7);
+    else if (p.mt == 2 && p.nt == 4) BTC_WG_ROWS(2, 4, 2, 7);
+    else if (p.mt == 4 && p.nt == 2) BTC_WG_ROWS(4, 2, 2, 7);
+    else BTC_WG_ROWS(4, 4, 1, 7);
+#undef BTC_WG_ROWS
+    BTC_LAUNCH_CHECK();
+    wgrad_reduce<<<btc_cdiv(count, 256), 256, 0, stream>>>(part, p.S, count, dW);
+    BTC_LAUNCH_CHECK();
+    return BTC_OK;
+  }
   dim3 grid(K, p.S, p.n_mblk * p.n_cblk);
   size_t lds = (size_t)(TM * WG_LDA + TM * ldb_of(p.nt)) * sizeof(float) + TM * sizeof(int32_t);
-  float* part = (float*)ws;
   switch (p.nt) {
     case 1: conv_wgrad_partial<1><<<grid, 256, lds, stream>>>(feat, dout, nbr_out, n_out, K, Cin, Cout, p.tiles_per_split, p.n_cblk, part); break;
     case 2: conv_wgrad_partial<2><<<grid, 256, lds, stream>>>(feat, dout, nbr_out, n_out, K, Cin, Cout, p.tiles_per_split, p.n_cblk, part); break;

@@ -260,11 +260,12 @@ class SparseConvFunction(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             n_res = map_fwd.shape[0]
             dw = torch.empty(ctx.wshape, dtype=torch.float32, device=grad_out.device)
-            ws_bytes = L.btc_conv_wgrad_ws_bytes(n_res, K, cin, cout)
+            n_src = map_bwd.shape[0]
+            ws_bytes = L.btc_conv_wgrad_ws_bytes(n_res, K, cin, cout, n_src)
             ws = workspace(ws_bytes, grad_out.device)
             with _span("conv_wgrad", lambda: _wgrad_cost(map_fwd, n_res, K, cin, cout)):
-                check(L.btc_conv_wgrad(ptr(features), ptr(grad_out), ptr(map_fwd), n_res, K, cin, cout, ptr(dw), ptr(ws),
-                                       ws_bytes, stream_ptr()), "btc_conv_wgrad")
+                check(L.btc_conv_wgrad(ptr(features), ptr(grad_out), ptr(map_fwd), n_res, ptr(map_bwd), n_src, K, cin, cout,
+                                       ptr(dw), ptr(ws), ws_bytes, stream_ptr()), "btc_conv_wgrad")
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = grad_out.sum(0)
         return din, dw, db, None, None

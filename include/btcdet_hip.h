@@ -124,16 +124,17 @@ int btc_pairs_from_nbr(const int32_t* nbr_out, int n_out, int K, int n_in, int32
  * the fp32 MFMA pipe, fused over all K offsets, output-stationary (no atomics, deterministic).
  *   fwd   : out[i]  = bias + sum_k feat[nbr_out[i][k]] @ W[k]
  *   dgrad : din[j]  = sum_k dout[nbr_in[j][k]] @ W[k]^T
- *   wgrad : dW[k]   = sum_i feat[nbr_out[i][k]]^T dout[i]    (ws: btc_conv_wgrad_ws_bytes)
+ *   wgrad : dW[k]   = sum_i feat[nbr_out[i][k]]^T dout[i]    (ws: btc_conv_wgrad_ws_bytes; nbr_in / n_in are optional
+ *           (NULL / -1): when given, the kernel may walk the smaller side of the rulebook)
  * An inverse conv (SparseInverseConv3d) is fwd with nbr_in of the cached rulebook as the map.
  * ---------------------------------------------------------------------------------------------- */
 int btc_conv_fwd(const float* feat, const float* W, const float* bias /* may be NULL */, const int32_t* nbr_out,
                  int n_out, int K, int Cin, int Cout, float* out, void* stream);
 int btc_conv_dgrad(const float* dout, const float* W, const int32_t* nbr_in, int n_in, int K, int Cin,
                    int Cout, float* din, void* stream);
-size_t btc_conv_wgrad_ws_bytes(int n_out, int K, int Cin, int Cout);
-int btc_conv_wgrad(const float* feat, const float* dout, const int32_t* nbr_out, int n_out, int K, int Cin,
-                   int Cout, float* dW, void* ws, size_t ws_bytes, void* stream);
+size_t btc_conv_wgrad_ws_bytes(int n_out, int K, int Cin, int Cout, int n_in);
+int btc_conv_wgrad(const float* feat, const float* dout, const int32_t* nbr_out, int n_out, const int32_t* nbr_in,
+                   int n_in, int K, int Cin, int Cout, float* dW, void* ws, size_t ws_bytes, void* stream);
 
 /* Sparse max-pool (spconv indice_maxpool, App. B.6): out = max(0, max_k feat[nbr_out[i][k]]);
  * backward routes dout to every input equal to its output. */

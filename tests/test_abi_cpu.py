@@ -44,7 +44,7 @@ def test_host_only_entry_points():
     # workspace helpers are monotone and non-trivial
     assert L.btc_voxelize_ws_bytes(60000, 2, 12) > L.btc_voxelize_ws_bytes(1000, 2, 12) > 0
     assert L.btc_rulebook_subm_ws_bytes(40000) >= 2 * 4 * 65536
-    assert L.btc_conv_wgrad_ws_bytes(15000, 27, 256, 128) >= 27 * 256 * 128 * 4
+    assert L.btc_conv_wgrad_ws_bytes(15000, 27, 256, 128, -1) >= 27 * 256 * 128 * 4
     cfg = _lib.BtcOccConfig()
     cfg.batch, cfg.grid[:], cfg.sphere_grid[:] = 2, [209, 157, 9], [214, 157, 49]
     assert L.btc_occ_targets_ws_bytes(ctypes.byref(cfg)) > 2 * 209 * 157 * 9 * (9 * 4 + 3 * 4)

@@ -205,6 +205,53 @@ def test_conv_fwd_bwd_vs_oracle(cin, cout, kind):
         np.testing.assert_allclose(bt.grad.cpu().numpy(), dout.sum(0), rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("cin,cout", [(4, 16), (6, 16), (16, 16), (32, 2), (32, 3), (16, 32), (32, 16), (32, 32), (34, 32), (32, 64), (64, 32), (64, 64), (2, 2)])
+@pytest.mark.parametrize("kind", ["subm", "conv"])
+def test_wgrad_row_stationary_kernel(cin, cout, kind):
+    """>= 4096 output rows selects conv_wgrad_rows (persistent, row-stationary); fp32 tolerance as above"""
+    from btcdet_amd.spconv import ops
+    rng = np.random.default_rng(cin * 100 + cout)
+    shape, B = (12, 48, 44), 2
+    idx = rand_indices(rng, 9000, B, shape)
+    s = (1, 1, 1) if kind == "subm" else (2, 2, 2)
+    (o_idx, o_out, o_in, o_sh), rb = _rb_both(idx, B, shape, (3, 3, 3), s, (1, 1, 1), (1, 1, 1), kind)
+    assert o_idx.shape[0] >= 4096
+    feat = rng.standard_normal((idx.shape[0], cin)).astype(np.float32)
+    W = (rng.standard_normal((3, 3, 3, cin, cout)) / np.sqrt(cin)).astype(np.float32)
+    dout = rng.standard_normal((o_idx.shape[0], cout)).astype(np.float32)
+    f = torch.from_numpy(feat).to(dev()).requires_grad_(True)
+    w = torch.from_numpy(W).to(dev()).requires_grad_(True)
+    out = ops.indice_conv(f, w, None, rb)
+    out.backward(torch.from_numpy(dout).to(dev()))
+    # large-N narrow layers take the weight-stationary conv_apply_ws kernel: same fmaf order -> still bit-exact
+    np.testing.assert_array_equal(out.detach().cpu().numpy(), orc.conv_fwd(feat, W, None, o_out))
+    np.testing.assert_array_equal(f.grad.cpu().numpy(), orc.conv_dgrad(dout, W, o_in))
+    ref = orc.conv_wgrad(feat, dout, o_out, W.shape)
+    assert np.abs(w.grad.cpu().numpy() - ref).max() <= 1e-4 * (np.abs(ref).max() + 1e-6)
+
+
+@pytest.mark.parametrize("cin,cout", [(32, 32), (64, 32), (16, 32), (32, 3)])
+def test_wgrad_walks_smaller_side_for_transposed_conv(cin, cout):
+    """transposed conv with n_out > 2 n_in: btc_conv_wgrad walks nbr_in (swap path of conv_wgrad_rows)"""
+    from btcdet_amd.spconv import ops
+    rng = np.random.default_rng(cin + cout)
+    shape, B = (6, 30, 28), 2
+    idx = rand_indices(rng, 5000, B, shape)
+    (o_idx, o_out, o_in, o_sh), rb = _rb_both(idx, B, shape, (3, 3, 3), (2, 2, 2), (1, 1, 1), (1, 1, 1), "transpose")
+    assert o_idx.shape[0] > 2 * idx.shape[0] >= 8192
+    feat = rng.standard_normal((idx.shape[0], cin)).astype(np.float32)
+    W = (rng.standard_normal((3, 3, 3, cin, cout)) / np.sqrt(cin)).astype(np.float32)
+    dout = rng.standard_normal((o_idx.shape[0], cout)).astype(np.float32)
+    f = torch.from_numpy(feat).to(dev()).requires_grad_(True)
+    w = torch.from_numpy(W).to(dev()).requires_grad_(True)
+    out = ops.indice_conv(f, w, None, rb)
+    out.backward(torch.from_numpy(dout).to(dev()))
+    np.testing.assert_array_equal(out.detach().cpu().numpy(), orc.conv_fwd(feat, W, None, o_out))
+    np.testing.assert_array_equal(f.grad.cpu().numpy(), orc.conv_dgrad(dout, W, o_in))
+    ref = orc.conv_wgrad(feat, dout, o_out, W.shape)
+    assert np.abs(w.grad.cpu().numpy() - ref).max() <= 1e-4 * (np.abs(ref).max() + 1e-6)
+
+
 def test_inverse_conv_matches_oracle():
     from btcdet_amd.spconv import ops
     rng = np.random.default_rng(9)
