@@ -144,13 +144,20 @@ def main():
     if args.gpus > 1 and world == 1:
         raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback for the hot path)"
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # BTC_BENCH_BACKEND=gloo lets N ranks share one GPU (functional check of the N > 1 path on a 1-GPU box); the default
+    # is one rank per GPU over RCCL ("nccl" on ROCm)
+    backend = os.environ.get("BTC_BENCH_BACKEND", "nccl")
+    dev_index = local_rank % torch.cuda.device_count() if backend != "nccl" else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", device_id=device)  # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=device)
+        else:
+            dist.init_process_group(backend=backend)
 
     from btcdet_amd.btc_path import BtcHotPath
     from btcdet_amd.config import load_cfg
@@ -163,7 +170,7 @@ def main():
     model.train()
     ddp = model
     if world > 1:
-        ddp = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], find_unused_parameters=False)
+        ddp = torch.nn.parallel.DistributedDataParallel(model, device_ids=[dev_index], find_unused_parameters=False)
     occ_params = [p for p in model.occ_modules.parameters() if p.requires_grad]
     det_params = [p for p in model.det_modules.parameters() if p.requires_grad]
     # adam_onecycle groups of the reference (optimization/__init__.py:36-40; LR is scheduled, yaml:331-372)

@@ -76,6 +76,9 @@ _SIGS = {
     "btc_revoxelize_ws_bytes": (sz, [ci, ci, c_i32p]),
     "btc_revoxelize_count": (ci, [vp, ci, ci, c_i32p, vp, vp, vp, sz, vp]),
     "btc_revoxelize_fill": (ci, [vp, vp, ci, ci, ci, c_i32p, ci, ci, vp, vp, vp, vp, sz, vp]),
+    "btc_bn_ws_bytes": (sz, [ci]),
+    "btc_bn_relu_fwd": (ci, [vp, ci, ci, vp, vp, vp, vp, vp, ctypes.c_float, ctypes.c_float, ci, ci, vp, vp, vp, vp, sz, vp]),
+    "btc_bn_relu_bwd": (ci, [vp, vp, vp, ci, ci, vp, vp, vp, ci, ci, vp, vp, vp, vp, sz, vp]),
     "btc_occ_targets_ws_bytes": (sz, [ctypes.POINTER(BtcOccConfig)]),
     "btc_occ_targets": (ci, [ctypes.POINTER(BtcOccConfig), vp, vp, vp, ci, ci, ci, vp, vp, vp, vp, ci, vp, vp,
                              ctypes.POINTER(BtcOccBuffers), vp, sz, vp]),
@@ -108,7 +111,8 @@ def check(rc, what):
 
 
 def stream_ptr():
-    return vp(torch.cuda.current_stream().cuda_stream)
+    """the current HIP stream of the current device as a void* (raw query: ~10x cheaper than torch.cuda.current_stream())"""
+    return vp(torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()))
 
 
 def ptr(t):
@@ -122,17 +126,35 @@ def ptr(t):
     return vp(t.data_ptr())
 
 
+_I3_CACHE = {}
+
+
 def i3(v):
-    """int / list / tuple / ndarray -> ctypes int32[3] (accepts the reference's int|list|tuple kernel args)."""
+    """int / list / tuple / ndarray -> int32[3] array (accepts the reference's int|list|tuple kernel args); small-value
+    triples are interned so that their ctypes pointers are built once"""
     if isinstance(v, (int, np.integer)):
-        v = [int(v)] * 3
-    a = np.ascontiguousarray(np.asarray(v).reshape(-1).astype(np.int32))
-    if a.size != 3:
-        raise BtcHipError(f"expected 3 values, got {v!r}")
+        key = (int(v),) * 3
+    else:
+        key = tuple(int(x) for x in np.asarray(v).reshape(-1))
+        if len(key) != 3:
+            raise BtcHipError(f"expected 3 values, got {v!r}")
+    a = _I3_CACHE.get(key)
+    if a is None:
+        a = np.ascontiguousarray(np.array(key, dtype=np.int32))
+        a.setflags(write=False)
+        a_ptr = a.ctypes.data_as(c_i32p)
+        _I3_CACHE[key] = a
+        _I3P_CACHE[id(a)] = (a, a_ptr)
     return a
 
 
+_I3P_CACHE = {}
+
+
 def i3p(a):
+    hit = _I3P_CACHE.get(id(a))
+    if hit is not None and hit[0] is a:
+        return hit[1]
     return a.ctypes.data_as(c_i32p)
 
 

@@ -1,0 +1,318 @@
+// Fused BatchNorm1d (+ReLU) over sparse-tensor features (N rows x C channels, fp32) for gfx950.
+//
+// The reference applies nn.BatchNorm1d(eps=1e-3, momentum=0.01) and nn.ReLU to `.features` after every sparse conv
+// (spconv.SparseSequential, /root/reference/btcdet/models/backbones_3d/spconv_backbone.py:33-43,96,634): on ROCm that is
+// ~10 small launches per layer (statistics, running-stat updates, transform, clamp, and their backward twins), all
+// latency bound at BtcDet's sizes.  Here: 2 launches forward, 2 backward.
+//   bn_stats / bn_bwd_stats : per-workgroup partial channel sums (fp64 accumulation), and the LAST workgroup to
+//                             arrive (agent-scope release / acquire around one atomic ticket, cdna guide G16) reduces
+//                             the partials in index order (deterministic), updates the running statistics and
+//                             num_batches_tracked, and publishes mean / rstd (or dgamma / dbeta)
+//   bn_apply / bn_bwd_apply : elementwise, float4
+#include "btc_common.h"
+
+namespace {
+
+constexpr int BN_T = 256;
+
+struct BnShape {
+  int N, C, cpow, rpi;  // cpow = pow2 >= min(C,256); rpi = rows per iteration of a workgroup
+};
+
+// last-arriver election (placement independent: release -> ticket -> acquire)
+__device__ __forceinline__ bool last_block(int32_t* counter) {
+  __shared__ int s_last;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    int t = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = (t == (int)gridDim.x - 1);
+  }
+  __syncthreads();
+  if (!s_last) return false;
+  if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  __syncthreads();
+  return true;
+}
+
+// partial[blk][0][c] = sum_x, partial[blk][1][c] = sum_x^2 over the block's rows
+__global__ __launch_bounds__(BN_T) void bn_stats(const float* __restrict__ x, BnShape S, double* __restrict__ partial,
+                                                 int32_t* __restrict__ counter, float momentum, float eps, int training,
+                                                 const float* __restrict__ running_mean_in, float* __restrict__ running_mean,
+                                                 float* __restrict__ running_var, long long* __restrict__ num_batches,
+                                                 float* __restrict__ mean_out, float* __restrict__ rstd_out) {
+  __shared__ double s_a[BN_T], s_b[BN_T];
+  const int tid = threadIdx.x;
+  for (int c0 = 0; c0 < S.C; c0 += S.cpow) {
+    const int c = c0 + (tid % S.cpow), rr = tid / S.cpow;
+    double a = 0.0, b = 0.0;
+    if (c < S.C) {
+      const long long stride = (long long)gridDim.x * S.rpi;
+      long long r = (long long)blockIdx.x * S.rpi + rr;
+      for (; r + 3 * stride < S.N; r += 4 * stride) {  // 4 independent loads in flight
+        float v0 = x[r * S.C + c], v1 = x[(r + stride) * S.C + c], v2 = x[(r + 2 * stride) * S.C + c], v3 = x[(r + 3 * stride) * S.C + c];
+        a += (double)v0 + (double)v1 + (double)v2 + (double)v3;
+        b += (double)v0 * v0 + (double)v1 * v1 + (double)v2 * v2 + (double)v3 * v3;
+      }
+      for (; r < S.N; r += stride) {
+        float v = x[r * S.C + c];
+        a += v;
+        b += (double)v * v;
+      }
+    }
+    s_a[tid] = a;
+    s_b[tid] = b;
+    __syncthreads();
+    if (rr == 0 && c < S.C) {
+      for (int q = 1; q < S.rpi; ++q) {
+        a += s_a[tid + q * S.cpow];
+        b += s_b[tid + q * S.cpow];
+      }
+      partial[((size_t)blockIdx.x * 2 + 0) * S.C + c] = a;
+      partial[((size_t)blockIdx.x * 2 + 1) * S.C + c] = b;
+    }
+    __syncthreads();
+  }
+  if (!last_block(counter)) return;
+  // partials reduced in a fixed order: thread-row rr takes workgroups rr, rr + rpi, ...; rows combined 0..rpi-1
+  for (int c0 = 0; c0 < S.C; c0 += S.cpow) {
+    const int c = c0 + (tid % S.cpow), rr = tid / S.cpow;
+    double a = 0.0, b = 0.0;
+    if (c < S.C)
+      for (int g = rr; g < (int)gridDim.x; g += S.rpi) {
+        a += partial[((size_t)g * 2 + 0) * S.C + c];
+        b += partial[((size_t)g * 2 + 1) * S.C + c];
+      }
+    s_a[tid] = a;
+    s_b[tid] = b;
+    __syncthreads();
+    if (rr == 0 && c < S.C) {
+      for (int q = 1; q < S.rpi; ++q) {
+        a += s_a[tid + q * S.cpow];
+        b += s_b[tid + q * S.cpow];
+      }
+      double mean = a / S.N;
+      double var = b / S.N - mean * mean;  // biased, as F.batch_norm normalises with
+      if (var < 0.0) var = 0.0;
+      mean_out[c] = (float)mean;
+      rstd_out[c] = (float)(1.0 / sqrt(var + (double)eps));
+      if (running_mean) {
+        double unb = S.N > 1 ? var * ((double)S.N / (double)(S.N - 1)) : var;
+        running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mean);
+        running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unb);
+      }
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    if (num_batches) *num_batches += 1;
+    __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next call on this stream
+  }
+}
+
+__global__ __launch_bounds__(BN_T) void bn_eval_stats(const float* __restrict__ running_mean, const float* __restrict__ running_var,
+                                                      int C, float eps, float* __restrict__ mean_out, float* __restrict__ rstd_out) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  mean_out[c] = running_mean[c];
+  rstd_out[c] = 1.0f / sqrtf(running_var[c] + eps);
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(BN_T) void bn_apply(const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                 const float* __restrict__ gamma, const float* __restrict__ beta, long long total, int C,
+                                                 int relu, float* __restrict__ y) {
+  long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * (VEC ? 4 : 1);
+  if (i >= total) return;
+  if (VEC) {
+    int c = (int)(i % C);
+    float4 v = *reinterpret_cast<const float4*>(x + i);
+    float o[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float g = gamma ? gamma[c + j] : 1.f, b = beta ? beta[c + j] : 0.f;
+      float t = (o[j] - mean[c + j]) * rstd[c + j] * g + b;
+      o[j] = relu ? fmaxf(t, 0.f) : t;
+    }
+    *reinterpret_cast<float4*>(y + i) = make_float4(o[0], o[1], o[2], o[3]);
+  } else {
+    int c = (int)(i % C);
+    float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    float t = (x[i] - mean[c]) * rstd[c] * g + b;
+    y[i] = relu ? fmaxf(t, 0.f) : t;
+  }
+}
+
+// partial sums of g = dy * (y > 0) and g * xhat; the last block turns them into dbeta / dgamma
+__global__ __launch_bounds__(BN_T) void bn_bwd_stats(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ dy,
+                                                     const float* __restrict__ mean, const float* __restrict__ rstd, BnShape S, int relu,
+                                                     double* __restrict__ partial, int32_t* __restrict__ counter,
+                                                     float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  __shared__ double s_a[BN_T], s_b[BN_T];
+  const int tid = threadIdx.x;
+  for (int c0 = 0; c0 < S.C; c0 += S.cpow) {
+    const int c = c0 + (tid % S.cpow), rr = tid / S.cpow;
+    double a = 0.0, b = 0.0;
+    if (c < S.C) {
+      const float m = mean[c], rs = rstd[c];
+      const long long stride = (long long)gridDim.x * S.rpi;
+      long long r = (long long)blockIdx.x * S.rpi + rr;
+      for (; r + stride < S.N; r += 2 * stride) {  // 6 independent loads in flight
+        const long long i0 = r * S.C + c, i1 = (r + stride) * S.C + c;
+        float g0 = dy[i0], g1 = dy[i1], y0 = y[i0], y1 = y[i1], x0 = x[i0], x1 = x[i1];
+        if (relu && !(y0 > 0.f)) g0 = 0.f;
+        if (relu && !(y1 > 0.f)) g1 = 0.f;
+        a += (double)g0 + (double)g1;
+        b += (double)g0 * ((x0 - m) * rs) + (double)g1 * ((x1 - m) * rs);
+      }
+      for (; r < S.N; r += stride) {
+        float g = dy[r * S.C + c];
+        if (relu && !(y[r * S.C + c] > 0.f)) g = 0.f;
+        a += g;
+        b += (double)g * ((x[r * S.C + c] - m) * rs);
+      }
+    }
+    s_a[tid] = a;
+    s_b[tid] = b;
+    __syncthreads();
+    if (rr == 0 && c < S.C) {
+      for (int q = 1; q < S.rpi; ++q) {
+        a += s_a[tid + q * S.cpow];
+        b += s_b[tid + q * S.cpow];
+      }
+      partial[((size_t)blockIdx.x * 2 + 0) * S.C + c] = a;
+      partial[((size_t)blockIdx.x * 2 + 1) * S.C + c] = b;
+    }
+    __syncthreads();
+  }
+  if (!last_block(counter)) return;
+  for (int c0 = 0; c0 < S.C; c0 += S.cpow) {
+    const int c = c0 + (tid % S.cpow), rr = tid / S.cpow;
+    double a = 0.0, b = 0.0;
+    if (c < S.C)
+      for (int g = rr; g < (int)gridDim.x; g += S.rpi) {
+        a += partial[((size_t)g * 2 + 0) * S.C + c];
+        b += partial[((size_t)g * 2 + 1) * S.C + c];
+      }
+    s_a[tid] = a;
+    s_b[tid] = b;
+    __syncthreads();
+    if (rr == 0 && c < S.C) {
+      for (int q = 1; q < S.rpi; ++q) {
+        a += s_a[tid + q * S.cpow];
+        b += s_b[tid + q * S.cpow];
+      }
+      dbeta[c] = (float)a;
+      dgamma[c] = (float)b;
+    }
+    __syncthreads();
+  }
+  if (tid == 0) __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(BN_T) void bn_bwd_apply(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ dy,
+                                                     const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                     const float* __restrict__ gamma, const float* __restrict__ dgamma,
+                                                     const float* __restrict__ dbeta, long long total, int C, int N, int relu, int training,
+                                                     float* __restrict__ dx) {
+  long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * (VEC ? 4 : 1);
+  if (i >= total) return;
+  const float invn = 1.0f / (float)N;
+  constexpr int W = VEC ? 4 : 1;
+  float xv[W], yv[W], gv[W];
+  if (VEC) {
+    float4 a = *reinterpret_cast<const float4*>(x + i), b = *reinterpret_cast<const float4*>(y + i), c4 = *reinterpret_cast<const float4*>(dy + i);
+    xv[0] = a.x; xv[W > 1 ? 1 : 0] = a.y; xv[W > 2 ? 2 : 0] = a.z; xv[W > 3 ? 3 : 0] = a.w;
+    yv[0] = b.x; yv[W > 1 ? 1 : 0] = b.y; yv[W > 2 ? 2 : 0] = b.z; yv[W > 3 ? 3 : 0] = b.w;
+    gv[0] = c4.x; gv[W > 1 ? 1 : 0] = c4.y; gv[W > 2 ? 2 : 0] = c4.z; gv[W > 3 ? 3 : 0] = c4.w;
+  } else {
+    xv[0] = x[i]; yv[0] = y[i]; gv[0] = dy[i];
+  }
+  const int c = (int)(i % C);
+  float o[W];
+#pragma unroll
+  for (int j = 0; j < W; ++j) {
+    float g = gv[j];
+    if (relu && !(yv[j] > 0.f)) g = 0.f;
+    const float gm = gamma ? gamma[c + j] : 1.f, rs = rstd[c + j];
+    if (training) {
+      float xh = (xv[j] - mean[c + j]) * rs;
+      o[j] = gm * rs * (g - dbeta[c + j] * invn - xh * dgamma[c + j] * invn);
+    } else {
+      o[j] = gm * rs * g;
+    }
+  }
+  if (VEC) *reinterpret_cast<float4*>(dx + i) = make_float4(o[0], o[W > 1 ? 1 : 0], o[W > 2 ? 2 : 0], o[W > 3 ? 3 : 0]);
+  else dx[i] = o[0];
+}
+
+BnShape bn_shape(int N, int C) {
+  BnShape S;
+  S.N = N;
+  S.C = C;
+  int cp = 1;
+  while (cp < C && cp < BN_T) cp <<= 1;
+  S.cpow = cp;
+  S.rpi = BN_T / cp;
+  return S;
+}
+
+int bn_grid(int N, const BnShape& S) {
+  int g = btc_cdiv(N, S.rpi * 16);  // >= 16 rows per thread-row before adding another workgroup
+  if (g > 256) g = 256;
+  if (g < 1) g = 1;
+  return g;
+}
+
+}  // namespace
+
+extern "C" size_t btc_bn_ws_bytes(int C) { return 256 + btc_align((size_t)512 * 2 * C * sizeof(double)); }
+
+extern "C" int btc_bn_relu_fwd(const float* x, int N, int C, const float* gamma, const float* beta, float* running_mean,
+                               float* running_var, long long* num_batches_tracked, float momentum, float eps, int training, int relu,
+                               float* y, float* save_mean, float* save_rstd, void* ws, size_t ws_bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  BTC_CHECK_ARG(N >= 1 && C >= 1, "btc_bn_relu_fwd: empty input");
+  BTC_CHECK_ARG(ws_bytes >= btc_bn_ws_bytes(C), "btc_bn_relu_fwd: workspace too small");
+  BTC_CHECK_ARG(training || (running_mean && running_var), "btc_bn_relu_fwd: eval mode needs running statistics");
+  int32_t* counter = (int32_t*)ws;  // first 256 bytes: arrival counter, zero on entry, zero on exit
+  double* partial = (double*)((char*)ws + 256);
+  BnShape S = bn_shape(N, C);
+  if (training) {
+    bn_stats<<<bn_grid(N, S), BN_T, 0, stream>>>(x, S, partial, counter, momentum, eps, training, running_mean, running_mean, running_var,
+                                                num_batches_tracked, save_mean, save_rstd);
+  } else {
+    bn_eval_stats<<<btc_cdiv(C, BN_T), BN_T, 0, stream>>>(running_mean, running_var, C, eps, save_mean, save_rstd);
+  }
+  BTC_LAUNCH_CHECK();
+  long long total = (long long)N * C;
+  if ((C & 3) == 0) bn_apply<true><<<btc_cdiv(total / 4, BN_T), BN_T, 0, stream>>>(x, save_mean, save_rstd, gamma, beta, total, C, relu, y);
+  else bn_apply<false><<<btc_cdiv(total, BN_T), BN_T, 0, stream>>>(x, save_mean, save_rstd, gamma, beta, total, C, relu, y);
+  BTC_LAUNCH_CHECK();
+  return BTC_OK;
+}
+
+extern "C" int btc_bn_relu_bwd(const float* x, const float* y, const float* dy, int N, int C, const float* gamma, const float* save_mean,
+                               const float* save_rstd, int training, int relu, float* dx, float* dgamma, float* dbeta, void* ws,
+                               size_t ws_bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  BTC_CHECK_ARG(N >= 1 && C >= 1, "btc_bn_relu_bwd: empty input");
+  BTC_CHECK_ARG(ws_bytes >= btc_bn_ws_bytes(C), "btc_bn_relu_bwd: workspace too small");
+  int32_t* counter = (int32_t*)ws;
+  double* partial = (double*)((char*)ws + 256);
+  BnShape S = bn_shape(N, C);
+  bn_bwd_stats<<<bn_grid(N, S), BN_T, 0, stream>>>(x, y, dy, save_mean, save_rstd, S, relu, partial, counter, dgamma, dbeta);
+  BTC_LAUNCH_CHECK();
+  long long total = (long long)N * C;
+  if ((C & 3) == 0)
+    bn_bwd_apply<true><<<btc_cdiv(total / 4, BN_T), BN_T, 0, stream>>>(x, y, dy, save_mean, save_rstd, gamma, dgamma, dbeta, total, C, N, relu,
+                                                                      training, dx);
+  else
+    bn_bwd_apply<false><<<btc_cdiv(total, BN_T), BN_T, 0, stream>>>(x, y, dy, save_mean, save_rstd, gamma, dgamma, dbeta, total, C, N, relu,
+                                                                   training, dx);
+  BTC_LAUNCH_CHECK();
+  return BTC_OK;
+}

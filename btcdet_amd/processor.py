@@ -148,10 +148,14 @@ class DataProcessor(object):
         """points / pre_rot_points (sum N, 4) f32 on the GPU (already range-masked and shuffled, scenes contiguous),
         scene_offsets (B+1) i32, rot_z (B) f32 -> the voxel keys of collate_batch (dataset.py:185-192), on the GPU."""
         cyl = cart_to_occ_coords(pre_rot_points, self.occ_config.COORD_TYPE)
-        vox, coords, num = self._occ_gen.generate_batch(cyl, scene_offsets)
-        if vox.shape[0] > 0:
-            check(lib().btc_voxel_shift_col(ptr(vox), ptr(coords), vox.shape[0], vox.shape[1], vox.shape[2], 1, ptr(rot_z), -1.0,
+        # both voxelizations are enqueued back to back; ONE read-back returns the two voxel counts
+        vox, coords, num, m_occ = self._occ_gen.generate_batch(cyl, scene_offsets, sync=False)
+        dvox, dcoords, dnum, m_det = self._det_gen.generate_batch(points, scene_offsets, sync=False)
+        m_occ, m_det = torch.cat([m_occ, m_det]).tolist()
+        vox, coords, num = vox[:m_occ], coords[:m_occ], num[:m_occ]
+        dvox, dcoords, dnum = dvox[:m_det], dcoords[:m_det], dnum[:m_det]
+        if m_occ > 0:
+            check(lib().btc_voxel_shift_col(ptr(vox), ptr(coords), m_occ, vox.shape[1], vox.shape[2], 1, ptr(rot_z), -1.0,
                                             stream_ptr()), "btc_voxel_shift_col")
-        dvox, dcoords, dnum = self._det_gen.generate_batch(points, scene_offsets)
         return {"voxels": vox, "voxel_coords": coords, "voxel_num_points": num, "det_voxels": dvox,
                 "det_voxel_coords": dcoords, "det_voxel_num_points": dnum}

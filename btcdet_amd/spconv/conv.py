@@ -85,12 +85,26 @@ class SparseConvolution(SparseModule):
             outids, out_spatial_shape = rb.in_indices, rb.in_shape[3 - self.ndim:]
         else:
             if rb is None:
-                idx4 = indices
-                if self.ndim == 2:
-                    idx4 = torch.cat([indices[:, :1], torch.zeros_like(indices[:, :1]), indices[:, 1:]], dim=1)
-                rb = ops.build_rulebook(idx4, batch_size, self._shape3(spatial_shape), self._k3(self.kernel_size, 1),
-                                        self._k3(self.stride, 1), self._k3(self.padding, 0), self._k3(self.dilation, 1),
-                                        self._k3(self.output_padding, 0), self.subm, self.transposed)
+                # A rulebook is a pure function of (indices, geometry): layers that ask for the same geometry on the same
+                # index tensor under different indice_keys (OccHead3D's 'cls_ind' / 'res_ind' after 'subm5',
+                # occ_head_3D.py:26,31) share one build.  The cache lives in the shared indice_dict and keeps the index
+                # tensor alive, so a recycled data_ptr can never alias.
+                geom = input.indice_dict.setdefault("__geometry_cache__", {})
+                gkey = (indices.data_ptr(), tuple(indices.shape), tuple(int(v) for v in spatial_shape), tuple(self.kernel_size),
+                        tuple(self.dilation), self.subm, self.transposed)
+                if not self.subm:  # stride / padding do not enter a submanifold rulebook
+                    gkey = gkey + (tuple(self.stride), tuple(self.padding), tuple(self.output_padding))
+                hit = geom.get(gkey, None)
+                if hit is not None:
+                    rb = hit[0]
+                else:
+                    idx4 = indices
+                    if self.ndim == 2:
+                        idx4 = torch.cat([indices[:, :1], torch.zeros_like(indices[:, :1]), indices[:, 1:]], dim=1)
+                    rb = ops.build_rulebook(idx4, batch_size, self._shape3(spatial_shape), self._k3(self.kernel_size, 1),
+                                            self._k3(self.stride, 1), self._k3(self.padding, 0), self._k3(self.dilation, 1),
+                                            self._k3(self.output_padding, 0), self.subm, self.transposed)
+                    geom[gkey] = (rb, indices)
                 if self.indice_key is not None:
                     input.indice_dict[self.indice_key] = rb
             # on a cache hit the layer uses the cached rulebook without checking its own geometry (App. B.5)

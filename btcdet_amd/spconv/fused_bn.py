@@ -1,0 +1,66 @@
+"""Fused BatchNorm1d(+ReLU) over `.features` -- used by SparseSequential when it meets the reference's
+``norm_fn(out_channels), nn.ReLU()`` pair (spconv_backbone.py:33-43).  The modules, their parameters, buffers and
+state_dict keys stay the plain torch ones; only the arithmetic goes through btc_bn_relu_fwd / btc_bn_relu_bwd."""
+import torch
+
+from .._lib import check, lib, ptr, stream_ptr
+
+_WS = {}
+
+
+def _ws(device, C):
+    """persistent per-device workspace; its head (arrival counter) starts zeroed and every call leaves it zeroed"""
+    need = lib().btc_bn_ws_bytes(int(C))
+    key = (device.type, device.index)
+    buf = _WS.get(key)
+    if buf is None or buf.numel() < need:
+        buf = torch.zeros(int(lib().btc_bn_ws_bytes(max(int(C), 1024))), dtype=torch.uint8, device=device)
+        _WS[key] = buf
+    return buf, need
+
+
+class BatchNormReLUFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, num_batches_tracked, training, momentum, eps, relu):
+        x = x.contiguous()
+        N, C = x.shape
+        y = torch.empty_like(x)
+        mean = torch.empty((C,), dtype=torch.float32, device=x.device)
+        rstd = torch.empty((C,), dtype=torch.float32, device=x.device)
+        ws, need = _ws(x.device, C)
+        use_batch = bool(training or running_mean is None)
+        check(lib().btc_bn_relu_fwd(ptr(x), N, C, ptr(weight), ptr(bias), ptr(running_mean) if training else ptr(running_mean),
+                                    ptr(running_var), ptr(num_batches_tracked) if training else None, float(momentum), float(eps),
+                                    int(use_batch), int(relu), ptr(y), ptr(mean), ptr(rstd), ptr(ws), need, stream_ptr()),
+              "btc_bn_relu_fwd")
+        ctx.save_for_backward(x, y, weight, mean, rstd)
+        ctx.flags = (use_batch, bool(relu))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, weight, mean, rstd = ctx.saved_tensors
+        use_batch, relu = ctx.flags
+        dy = dy.contiguous()
+        N, C = x.shape
+        dx = torch.empty_like(x)
+        dgamma = torch.empty((C,), dtype=torch.float32, device=x.device)
+        dbeta = torch.empty((C,), dtype=torch.float32, device=x.device)
+        ws, need = _ws(x.device, C)
+        check(lib().btc_bn_relu_bwd(ptr(x), ptr(y), ptr(dy), N, C, ptr(weight), ptr(mean), ptr(rstd), int(use_batch), int(relu),
+                                    ptr(dx), ptr(dgamma), ptr(dbeta), ptr(ws), need, stream_ptr()), "btc_bn_relu_bwd")
+        return dx, (dgamma if weight is not None else None), (dbeta if weight is not None else None), None, None, None, None, None, None, None
+
+
+def fusable(bn):
+    return isinstance(bn, torch.nn.BatchNorm1d) and bn.affine == (bn.weight is not None) and \
+        (bn.momentum is not None) and (bn.track_running_stats or bn.training)
+
+
+def batch_norm_relu(bn, x, relu):
+    """same semantics as bn(x) followed by ReLU for a (N,C) float32 GPU tensor with N >= 1"""
+    training = bn.training or not bn.track_running_stats
+    nbt = bn.num_batches_tracked if (bn.training and bn.track_running_stats) else None
+    rm = bn.running_mean if bn.track_running_stats else None
+    rv = bn.running_var if bn.track_running_stats else None
+    return BatchNormReLUFunction.apply(x, bn.weight, bn.bias, rm, rv, nbt, training, bn.momentum, bn.eps, relu)

@@ -9,6 +9,12 @@ from torch import nn
 from .tensor import SparseConvTensor
 
 
+import torch as _torch
+
+nn_float32 = _torch.float32
+FUSE_BN_RELU = True  # set False to run BatchNorm1d / ReLU through torch (used by the parity test)
+
+
 class SparseModule(nn.Module):
     """marker base class of modules that take a SparseConvTensor"""
     pass
@@ -63,14 +69,26 @@ class SparseSequential(SparseModule):
         self.add_module(name, module)
 
     def forward(self, input):
-        for k, module in self._modules.items():
+        from . import fused_bn
+        mods = list(self._modules.values())
+        i = 0
+        while i < len(mods):
+            module = mods[i]
+            i += 1
             if is_spconv_module(module):
                 assert isinstance(input, SparseConvTensor)
                 input = module(input)
             else:
                 if isinstance(input, SparseConvTensor):
                     if input.indices.shape[0] != 0:
-                        input.features = module(input.features)
+                        f = input.features
+                        if FUSE_BN_RELU and fused_bn.fusable(module) and f.is_cuda and f.dtype == nn_float32 and f.dim() == 2:
+                            # BatchNorm1d (+ the ReLU that follows it): one fused HIP call, same parameters / buffers
+                            relu = i < len(mods) and type(mods[i]) is nn.ReLU
+                            input.features = fused_bn.batch_norm_relu(module, f, relu)
+                            i += int(relu)
+                        else:
+                            input.features = module(f)
                 else:
                     input = module(input)
         return input

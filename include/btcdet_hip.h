@@ -212,6 +212,22 @@ int btc_occ_targets(const BtcOccConfig* cfg, float* voxels, const int32_t* voxel
                     const float* bm_points, int n_bm, const float* rot_z, const float* centers,
                     const BtcOccBuffers* out, void* ws, size_t ws_bytes, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Fused BatchNorm1d (+ReLU) over sparse-tensor features (N,C).  Replaces the nn.BatchNorm1d(eps=1e-3,
+ * momentum=0.01) + nn.ReLU pair that spconv.SparseSequential applies to `.features` after every sparse conv
+ * (/root/reference/btcdet/models/backbones_3d/spconv_backbone.py:33-43,96,634).  Training mode normalises with
+ * the batch statistics (biased variance) and updates running_mean / running_var (unbiased) / num_batches_tracked
+ * exactly like torch; eval mode uses the running statistics.  ws: btc_bn_ws_bytes(C) bytes whose FIRST 256 bytes
+ * must be zero before the first call and are left zero by every call (arrival counter).
+ * ---------------------------------------------------------------------------------------------- */
+size_t btc_bn_ws_bytes(int C);
+int btc_bn_relu_fwd(const float* x, int N, int C, const float* gamma, const float* beta, float* running_mean,
+                    float* running_var, long long* num_batches_tracked, float momentum, float eps, int training,
+                    int relu, float* y, float* save_mean, float* save_rstd, void* ws, size_t ws_bytes, void* stream);
+int btc_bn_relu_bwd(const float* x, const float* y, const float* dy, int N, int C, const float* gamma,
+                    const float* save_mean, const float* save_rstd, int training, int relu, float* dx, float* dgamma,
+                    float* dbeta, void* ws, size_t ws_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

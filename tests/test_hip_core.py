@@ -303,3 +303,40 @@ def test_revoxelize_matches_oracle():
     np.testing.assert_array_equal(num.cpu().numpy(), rnum)
     np.testing.assert_array_equal(v.cpu().numpy(), rv)
     assert vc.dtype == torch.int64 and num.dtype == torch.int64
+
+
+@pytest.mark.parametrize("n,c,relu", [(5000, 32, True), (130, 16, True), (70000, 64, False), (3, 128, True), (20000, 34, True)])
+@pytest.mark.parametrize("training", [True, False])
+def test_fused_batchnorm_relu_matches_torch(n, c, relu, training):
+    """btc_bn_relu_fwd / bwd against torch's BatchNorm1d(+ReLU) in fp64: outputs, input / affine gradients, running
+    statistics and num_batches_tracked (fp32 tolerance 2e-5: different reduction order)"""
+    from btcdet_amd.spconv import fused_bn
+    torch.manual_seed(n + c)
+    x = (torch.randn(n, c, device=dev()) * 2 + 0.5)
+    bn = torch.nn.BatchNorm1d(c, eps=1e-3, momentum=0.01).to(dev())
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.uniform_(-0.5, 0.5)
+        bn.running_mean.uniform_(-0.1, 0.1)
+        bn.running_var.uniform_(0.5, 1.5)
+    ref = torch.nn.BatchNorm1d(c, eps=1e-3, momentum=0.01).to(dev()).double()
+    ref.load_state_dict({k: (v.double() if v.is_floating_point() else v.clone()) for k, v in bn.state_dict().items()})
+    bn.train(training)
+    ref.train(training)
+    g = torch.randn(n, c, device=dev())
+    xa = x.clone().requires_grad_(True)
+    ya = fused_bn.batch_norm_relu(bn, xa, relu)
+    ya.backward(g)
+    xb = x.double().clone().requires_grad_(True)
+    yb = ref(xb)
+    if relu:
+        yb = torch.relu(yb)
+    yb.backward(g.double())
+    tol = dict(rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(ya.detach().cpu().numpy(), yb.detach().cpu().numpy(), **tol)
+    np.testing.assert_allclose(xa.grad.cpu().numpy(), xb.grad.cpu().numpy(), rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(bn.weight.grad.cpu().numpy(), ref.weight.grad.cpu().numpy(), rtol=2e-4, atol=2e-3)
+    np.testing.assert_allclose(bn.bias.grad.cpu().numpy(), ref.bias.grad.cpu().numpy(), rtol=2e-4, atol=2e-3)
+    np.testing.assert_allclose(bn.running_mean.cpu().numpy(), ref.running_mean.cpu().numpy(), **tol)
+    np.testing.assert_allclose(bn.running_var.cpu().numpy(), ref.running_var.cpu().numpy(), **tol)
+    assert int(bn.num_batches_tracked) == int(ref.num_batches_tracked)
