@@ -29,6 +29,17 @@ HBM_PEAK_GBS = 8000.0       # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 
 FP32_MFMA_PEAK_TF = 157.3   # same guide: fp32-input MFMA peak
 
 
+def pmc_traffic_per_launch():
+    """HBM bytes per conv_apply launch from the committed PMC passes (profiles/r01e_pmc_conv.json: rocprofv3 --pmc FETCH_SIZE and
+    --pmc WRITE_SIZE in separate runs, FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md); PMC counters cannot be read
+    inside the timed process, so this is null when the file is absent"""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01e_pmc_conv.json")) as f:
+            return json.load(f)["conv_apply"]["hbm_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def rank_seeds(rank, i, batch_size=2):
     """scene seeds of batch i on a rank: ranks draw disjoint scenes (the DistributedSampler shard)"""
     return [1000 * rank + 10 * i + j for j in range(batch_size)]
@@ -83,49 +94,69 @@ def make_step(model, ddp, proc, opts):
     return step
 
 
-def cpu_baseline(seconds_budget=20.0):
-    """CPU oracle ("port") on the host, 1 thread: per scene the reference's CPU dataset/voxelize path
-    (cylinder transform + both voxelizations) and the occupancy-branch sparse convolutions fwd+dgrad+wgrad;
-    see DESIGN.md for what the sample covers."""
+def cpu_baseline(seconds_budget=25.0, max_scenes=2):
+    """CPU oracle ("port") on ONE host core: per scene the reference's CPU dataset/voxelize path (cylinder transform +
+    both voxelizations, data_processor.py:105-190) and every sparse-conv layer of both backbones + the occupancy head
+    (rulebooks, forward, dgrad, wgrad) with the C oracle.  Not in the sample: occupancy targets, VFEs, losses,
+    PassOccVox merging, BatchNorm, dense scatter, optimizer (all small next to the convolutions on a CPU)."""
     from btcdet_amd import synth
     from oracle import oracle as orc
-    torch.set_num_threads(1)
     occ_gen = orc.VoxelGeneratorV2(synth.KITTI_OCC_VOXEL, synth.KITTI_OCC_RANGE, 12, 20000)
     det_gen = orc.VoxelGeneratorV2(synth.KITTI_DET_VOXEL, synth.KITTI_DET_RANGE, 5, 16000)
     rng = np.random.default_rng(0)
-    layers = [(4, 16, 1, orc.MODE_CONV), (16, 32, 2, orc.MODE_CONV), (32, 32, 1, orc.MODE_SUBM), (32, 64, 2, orc.MODE_CONV),
-              (64, 64, 1, orc.MODE_SUBM), (64, 32, 2, orc.MODE_TRANSPOSE), (32, 32, 1, orc.MODE_SUBM),
-              (32, 32, 2, orc.MODE_TRANSPOSE), (32, 32, 1, orc.MODE_SUBM)]
+    C, S, T = orc.MODE_CONV, orc.MODE_SUBM, orc.MODE_TRANSPOSE
+    # (cin, cout, kernel, stride, padding, mode, source tensor, result tensor); layer tables of spconv_backbone.py:106-128,656-767
+    occ_layers = [(4, 16, 3, 1, 1, C, "in", "a"), (16, 32, 3, 2, 1, C, "a", "b"), (32, 32, 3, 1, 0, S, "b", "b"),
+                  (32, 64, 3, 2, 1, C, "b", "c"), (64, 64, 3, 1, 0, S, "c", "c"), (64, 32, 3, 2, 1, T, "c", "d"),
+                  (32, 32, 3, 1, 0, S, "d", "d"), (32, 32, 3, 2, 1, T, "d", "e"), (32, 32, 3, 1, 0, S, "e", "e"),
+                  (32, 2, 3, 1, 0, S, "e", "cls"), (32, 3, 3, 1, 0, S, "e", "res")]
+    det_layers = [(6, 16, 3, 1, 0, S, "in", "x1"), (16, 16, 3, 1, 0, S, "x1", "x1"), (16, 32, 3, 2, 1, C, "x1", "x2"),
+                  (32, 32, 3, 1, 0, S, "x2", "x2"), (32, 32, 3, 1, 0, S, "x2", "x2"), (32, 64, 3, 2, 1, C, "x2", "x3"),
+                  (64, 64, 3, 1, 0, S, "x3", "x3"), (64, 64, 3, 1, 0, S, "x3", "x3"), (64, 64, 3, 2, (0, 1, 1), C, "x3", "x4"),
+                  (64, 64, 3, 1, 0, S, "x4", "x4"), (64, 64, 3, 1, 0, S, "x4", "x4"), (64, 128, (3, 1, 1), (2, 1, 1), 0, C, "x4", "out"),
+                  (32, 32, 3, 2, 1, C, "x2", "d2"), (32, 64, 3, 2, (0, 1, 1), C, "d2", "d2b"), (64, 64, 3, 2, (0, 1, 1), C, "x3", "d3"),
+                  (128, 64, (2, 1, 1), (2, 1, 1), 0, C, "out", "bev"), (256, 128, 3, 1, 0, S, "x4", "x4c"), (128, 128, 3, 1, 0, S, "x4c", "x4c")]
+
+    def run_chain(layers, idx0, shape0, c0):
+        tensors = {"in": (idx0, list(shape0), (rng.standard_normal((idx0.shape[0], c0))).astype(np.float32))}
+        cache = {}
+        for cin, cout, k, st, pd, mode, src, dst in layers:
+            idx, shape, feat = tensors[src]
+            if feat.shape[1] != cin:
+                feat = np.ascontiguousarray(np.resize(feat, (feat.shape[0], cin)))
+            key = (src, str(k), str(st), str(pd), mode)
+            if key not in cache:
+                cache[key] = orc.rulebook(idx, shape, k, st, pd, 1, mode)
+            o_idx, nbr_out, nbr_in, osh = cache[key]
+            W = (rng.standard_normal((27, cin, cout)) / np.sqrt(27 * cin)).astype(np.float32)[:nbr_out.shape[1]]
+            out = orc.conv_fwd(feat, W, None, nbr_out)
+            dout = np.ones_like(out)
+            orc.conv_dgrad(dout, W, nbr_in)
+            orc.conv_wgrad(feat, dout, nbr_out, W.shape)
+            tensors[dst] = (o_idx, list(osh), np.maximum(out, 0))
+
     t_start = time.perf_counter()
     scenes, t_vox, t_conv = 0, 0.0, 0.0
-    while time.perf_counter() - t_start < seconds_budget and scenes < 8:
+    while scenes < max_scenes and (scenes == 0 or time.perf_counter() - t_start < seconds_budget / 2):
         s = synth.make_scene(5000 + scenes)
         t0 = time.perf_counter()
         cyl = orc.absxyz_2_cylinxyz_np(s["pre_rot_points"])
         r = occ_gen.generate(cyl)
         r["voxels"][..., 1] -= s["rot_z"]
-        det_gen.generate(s["points"])
+        rd = det_gen.generate(s["points"])
         t1 = time.perf_counter()
-        idx = np.pad(r["coordinates"], ((0, 0), (1, 0))).astype(np.int32)
-        feat = (r["voxels"].sum(1) / np.maximum(r["num_points_per_voxel"], 1)[:, None]).astype(np.float32)
-        shape = [9, 157, 209]
-        for cin, cout, stride, mode in layers:
-            o_idx, nbr_out, nbr_in, osh = orc.rulebook(idx, shape, 3, stride, 1 if mode != orc.MODE_SUBM else 0, 1, mode)
-            W = (rng.standard_normal((3, 3, 3, cin, cout)) / np.sqrt(27 * cin)).astype(np.float32)
-            out = orc.conv_fwd(feat, W, None, nbr_out)
-            dout = np.ones_like(out)
-            orc.conv_dgrad(dout, W, nbr_in)
-            orc.conv_wgrad(feat, dout, nbr_out, W.shape)
-            idx, feat, shape = o_idx, np.maximum(out, 0), list(osh)
+        run_chain(occ_layers, np.pad(r["coordinates"], ((0, 0), (1, 0))).astype(np.int32), [9, 157, 209], 4)
+        run_chain(det_layers, np.pad(rd["coordinates"], ((0, 0), (1, 0))).astype(np.int32), [41, 1600, 1408], 6)
         t2 = time.perf_counter()
         t_vox += t1 - t0
         t_conv += t2 - t1
         scenes += 1
     total = t_vox + t_conv
     return {"value": round(scenes / total, 3), "unit": "scenes/s", "cores": 1, "kind": "port",
-            "sample": "%d synthetic KITTI scenes, CPU oracle, 1 thread: cylinder transform + 2 voxelizations (%.1f ms/scene) + "
-                      "occupancy-branch sparse convs (9 layers) fwd+dgrad+wgrad incl. rulebooks (%.0f ms/scene); the detection branch, "
-                      "occupancy targets and heads are NOT in the sample" % (scenes, 1e3 * t_vox / scenes, 1e3 * t_conv / scenes),
+            "sample": "%d synthetic KITTI scene(s), C oracle, 1 thread: cylinder transform + 2 voxelizations (%.1f ms/scene) + all %d sparse-conv "
+                      "layers of both backbones and the occupancy head: rulebooks + fwd + dgrad + wgrad (%.0f ms/scene); occupancy targets, "
+                      "VFEs, BatchNorm, PassOccVox merge, losses and optimizer are NOT in the sample"
+                      % (scenes, 1e3 * t_vox / scenes, len(occ_layers) + len(det_layers), 1e3 * t_conv / scenes),
             "voxelize_scenes_per_s": round(scenes / t_vox, 2), "host_cpus": os.cpu_count()}
 
 
@@ -229,7 +260,7 @@ def main():
                 gbs = k["bytes"] / (k["ms"] * 1e-3) / 1e9
                 result["roofline"] = {"kernel": "conv_apply (fused sparse conv fwd + dgrad, output-stationary MFMA f32)", "bound": "hbm",
                                       "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5),
-                                      "traffic": None, "launches_per_step": k["launches"] / prof_steps,
+                                      "traffic": pmc_traffic_per_launch(), "launches_per_step": k["launches"] / prof_steps,
                                       "avg_launch_us": round(1e3 * k["ms"] / k["launches"], 2),
                                       "alg_bytes_per_step": k["bytes"] // prof_steps,
                                       "tflops": round(k["flops"] / (k["ms"] * 1e-3) / 1e12, 3), "mfma_f32_peak_tflops": FP32_MFMA_PEAK_TF,

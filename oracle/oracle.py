@@ -24,17 +24,27 @@ _f32p = ctypes.POINTER(ctypes.c_float)
 
 def build(force=False):
     """Compile liboracle with gcc (oracle/Makefile)."""
-    so = os.path.join(_HERE, "libbtc_oracle.so")
+    so = os.path.join(_HERE, "libbtc_oracle_fast.so")
     src = os.path.join(_HERE, "btc_oracle.c")
     if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
         subprocess.check_call(["make", "-s", "-C", _HERE, "-B"])
     return so
 
 
+def _cpu_has_fma():
+    try:
+        flags = open("/proc/cpuinfo").read()
+        return " avx2" in flags and " fma" in flags
+    except OSError:
+        return False
+
+
 def lib():
+    """liboracle; the -mfma build when the host CPU has FMA (bit-identical results, explicit fmaf() either way)"""
     global _LIB
     if _LIB is None:
-        so = os.path.join(_HERE, "libbtc_oracle.so")
+        name = "libbtc_oracle_fast.so" if _cpu_has_fma() and os.environ.get("BTC_ORACLE_PLAIN", "0") != "1" else "libbtc_oracle.so"
+        so = os.path.join(_HERE, name)
         if not os.path.exists(so):
             build()
         _LIB = ctypes.CDLL(so)
