@@ -50,6 +50,13 @@ class BtcOccBuffers(ctypes.Structure):
     _fields_ = [(k, ctypes.c_void_p) for k in OCC_BUFFER_FIELDS]
 
 
+class BtcPovConfig(ctypes.Structure):
+    """struct BtcPovConfig of include/btcdet_hip.h"""
+    _fields_ = [("batch", ctypes.c_int32), ("max_k", ctypes.c_int32), ("occ_grid", ctypes.c_int32 * 3), ("det_grid", ctypes.c_int32 * 3),
+                ("occ_origin", ctypes.c_float * 3), ("occ_voxel", ctypes.c_float * 3), ("det_origin", ctypes.c_float * 3),
+                ("det_voxel", ctypes.c_float * 3), ("occ_thresh", ctypes.c_float), ("inten", ctypes.c_float), ("code_dim", ctypes.c_int32)]
+
+
 _SIGS = {
     # name: (restype, argtypes)
     "btc_last_error": (ctypes.c_char_p, []),
@@ -76,6 +83,9 @@ _SIGS = {
     "btc_revoxelize_ws_bytes": (sz, [ci, ci, c_i32p]),
     "btc_revoxelize_count": (ci, [vp, ci, ci, c_i32p, vp, vp, vp, sz, vp]),
     "btc_revoxelize_fill": (ci, [vp, vp, ci, ci, ci, c_i32p, ci, ci, vp, vp, vp, vp, sz, vp]),
+    "btc_pass_occ_vox_ws_bytes": (sz, [ctypes.POINTER(BtcPovConfig), ci, ci]),
+    "btc_pass_occ_vox_count": (ci, [ctypes.POINTER(BtcPovConfig), vp, vp, vp, vp, vp, vp, ci, ci, ci, vp, vp, sz, vp]),
+    "btc_pass_occ_vox_fill": (ci, [ctypes.POINTER(BtcPovConfig), vp, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, sz, vp]),
     "btc_bn_ws_bytes": (sz, [ci]),
     "btc_bn_relu_fwd": (ci, [vp, ci, ci, vp, vp, vp, vp, vp, ctypes.c_float, ctypes.c_float, ci, ci, vp, vp, vp, vp, sz, vp]),
     "btc_bn_relu_bwd": (ci, [vp, vp, vp, ci, ci, vp, vp, vp, ci, ci, vp, vp, vp, vp, sz, vp]),

@@ -12,6 +12,9 @@ from . import _lib
 from ._lib import check, i3, i3p, lib, ptr, stream_ptr, workspace
 
 
+FUSED = True  # PassOccVox.forward through btc_pass_occ_vox_* (False: the torch op chain + btc_revoxelize_*)
+
+
 def revoxelize(points, coords, batch_size, grid_zyx):
     """combine_gt_occ_voxel_point (add_occ_template.py:262-268) on the GPU.
     points (n,C) f32, coords (n,4) int64 [b,z,y,x] -> voxels (M,Pmax,C) f32, num (M,) i64, vcoords (M,4) i64
@@ -114,7 +117,70 @@ class PassOccVox(torch.nn.Module):
         cz = torch.clamp(c[..., 2], min=0, max=nz - 1).to(torch.int64)
         return torch.stack([b_inds, cz, cy, cx], dim=-1)
 
+    def _fused_ok(self, batch_dict):
+        fpm = batch_dict.get("final_point_mask", None)
+        dv = batch_dict.get('det_voxels', None)
+        realdrop = self.config_realdrop and fpm is not None and dv is not None and dv.shape[1] == fpm.shape[1]
+        return FUSED and 'det_voxel_coords' in batch_dict and dv is not None and dv.is_cuda and not realdrop \
+            and self.res_num_dim == 3 and dv.shape[2] >= 4
+
+    def forward_fused(self, batch_dict):
+        """the whole module as two C-ABI calls around one read-back (csrc/pass_occ.hip)"""
+        import ctypes
+        from ._lib import BtcPovConfig
+        bs, probs = batch_dict['batch_size'], batch_dict['batch_pred_occ_prob'].contiguous()
+        dv = batch_dict['det_voxels'].float().contiguous()
+        dn = batch_dict['det_voxel_num_points'].int().contiguous()
+        dc = batch_dict['det_voxel_coords'].int().contiguous()
+        dev = dv.device
+        M, P, C = dv.shape
+        res = batch_dict["pred_sem_residuals"].detach().contiguous() if self.reg else None
+        is_train = batch_dict["is_train"]
+        c = BtcPovConfig()
+        c.batch = bs
+        c.max_k = int(self.max_add_occpnts_num if is_train else self.eval_max_add_occpnts_num)
+        c.occ_grid[:] = [int(g) for g in self.occ_grid_size]
+        c.det_grid[:] = [int(g) for g in self.det_grid_size]
+        c.occ_origin[:] = [self.occ_x_origin, self.occ_y_origin, self.occ_z_origin]
+        c.occ_voxel[:] = [self.nvx, self.nvy, self.nvz]
+        c.det_origin[:] = self.point_cloud_range[0:3]
+        c.det_voxel[:] = self.det_voxel_size
+        c.occ_thresh = float(self.occ_thresh)
+        c.inten = float(self.data_cfg.OCC.INTEN if self.data_cfg.OCC.get("INTEN", None) is not None else 0.0)
+        c.code_dim = int(self.code_num_dim)
+        use = torch.as_tensor(np.asarray(batch_dict["use_occ_prob"], dtype=np.uint8)).to(dev)
+        rot = batch_dict["rot_z"].float().contiguous() if "rot_z" in batch_dict else None
+        L = lib()
+        ws_bytes = L.btc_pass_occ_vox_ws_bytes(ctypes.byref(c), M, P)
+        ws = workspace(ws_bytes, dev)
+        d_info = torch.empty((2 + bs,), dtype=torch.int32, device=dev)
+        check(L.btc_pass_occ_vox_count(ctypes.byref(c), ptr(probs.detach()), ptr(res), ptr(use), ptr(rot), ptr(dc), ptr(dn), M, P, C,
+                                       ptr(d_info), ptr(ws), ws_bytes, stream_ptr()), "btc_pass_occ_vox_count")
+        info = d_info.tolist()  # the one read-back of the module
+        m, pmax, k_total = info[0], info[1], sum(info[2:])
+        batch_dict["gt_points_xyz"] = batch_dict["points"][..., 1:4]
+        batch_dict["gt_b_ind"] = batch_dict["points"][..., 0]
+        if k_total == 0:  # nothing passed the threshold: detection voxels + zero code channels (pass_occ_vox.py:48-53)
+            batch_dict['voxel_num_points'], batch_dict['voxel_coords'] = batch_dict['det_voxel_num_points'], batch_dict['det_voxel_coords']
+            batch_dict["added_occ_b_ind"] = torch.zeros([1], dtype=torch.int64, device=dev)
+            batch_dict["added_occ_xyz"] = torch.zeros([1, 3], dtype=torch.float32, device=dev)
+            batch_dict["occ_pnts"] = torch.zeros([1, 4], dtype=torch.float32, device=dev)
+            batch_dict['voxels'] = torch.cat((dv, torch.zeros_like(dv[..., 0:self.code_num_dim])), dim=-1)
+            return batch_dict
+        voxels = torch.empty((m, pmax, C + self.code_num_dim), dtype=torch.float32, device=dev)
+        vcoords = torch.empty((m, 4), dtype=torch.int64, device=dev)
+        vnum = torch.empty((m,), dtype=torch.int64, device=dev)
+        occ_pnts = torch.empty((k_total, 4), dtype=torch.float32, device=dev)
+        occ_b = torch.empty((k_total,), dtype=torch.int64, device=dev)
+        check(L.btc_pass_occ_vox_fill(ctypes.byref(c), ptr(dv), M, P, C, m, pmax, k_total, ptr(voxels), ptr(vcoords), ptr(vnum),
+                                      ptr(occ_pnts), ptr(occ_b), ptr(ws), ws_bytes, stream_ptr()), "btc_pass_occ_vox_fill")
+        batch_dict['voxels'], batch_dict['voxel_num_points'], batch_dict['voxel_coords'] = voxels, vnum, vcoords
+        batch_dict["occ_pnts"], batch_dict["added_occ_xyz"], batch_dict["added_occ_b_ind"] = occ_pnts, occ_pnts[:, :3], occ_b
+        return batch_dict
+
     def forward(self, batch_dict, **kwargs):
+        if self._fused_ok(batch_dict) and not self.pass_gradient:
+            return self.forward_fused(batch_dict)
         pnt_feat_dim = batch_dict['voxels'].shape[2]
         batch_size, probs = batch_dict['batch_size'], batch_dict['batch_pred_occ_prob']
         res_lst, probs_lst, coords_lst = self.filter_occ_points(batch_size, probs, batch_dict)

@@ -61,6 +61,17 @@ class _NoSpan(object):
 
 
 PROFILE = None  # set to a LaunchProfile() to instrument
+OVERLAP_WGRAD = True  # run wgrad on a side stream concurrently with dgrad (backward of every sparse conv)
+_SIDE = {}
+
+
+def _side_stream(device):
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    st = _SIDE.get(key)
+    if st is None:
+        st = torch.cuda.Stream(device=device)
+        _SIDE[key] = st
+    return st
 _NOSPAN = _NoSpan()
 
 
@@ -251,23 +262,40 @@ class SparseConvFunction(torch.autograd.Function):
         K = map_fwd.shape[1]
         L = lib()
         din = dw = db = None
-        if ctx.needs_input_grad[0]:
+        need_din, need_dw = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        # dgrad and wgrad are independent and each is latency bound on its own at BtcDet's sizes: wgrad goes to a side
+        # HIP stream (fork / join with events, no host sync) so the two kernels share the GPU
+        side = _side_stream(grad_out.device) if (need_din and need_dw and OVERLAP_WGRAD and PROFILE is None) else None
+        if need_dw:
+            n_res, n_src = map_fwd.shape[0], map_bwd.shape[0]
+            ws_bytes = L.btc_conv_wgrad_ws_bytes(n_res, K, cin, cout, n_src)
+            if side is not None:
+                main = torch.cuda.current_stream()
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    dw = torch.empty(ctx.wshape, dtype=torch.float32, device=grad_out.device)
+                    ws = workspace(ws_bytes, grad_out.device)
+                    check(L.btc_conv_wgrad(ptr(features), ptr(grad_out), ptr(map_fwd), n_res, ptr(map_bwd), n_src, K, cin, cout,
+                                           ptr(dw), ptr(ws), ws_bytes, stream_ptr()), "btc_conv_wgrad")
+                for t in (features, grad_out, map_fwd, map_bwd):
+                    t.record_stream(side)
+            else:
+                dw = torch.empty(ctx.wshape, dtype=torch.float32, device=grad_out.device)
+                ws = workspace(ws_bytes, grad_out.device)
+                with _span("conv_wgrad", lambda: _wgrad_cost(map_fwd, n_res, K, cin, cout)):
+                    check(L.btc_conv_wgrad(ptr(features), ptr(grad_out), ptr(map_fwd), n_res, ptr(map_bwd), n_src, K, cin, cout,
+                                           ptr(dw), ptr(ws), ws_bytes, stream_ptr()), "btc_conv_wgrad")
+        if need_din:
             n_src = map_bwd.shape[0]
             din = torch.empty((n_src, cin), dtype=torch.float32, device=grad_out.device)
             with _span("conv_apply", lambda: _conv_cost(map_bwd, n_src, K, cout, cin)):
                 check(L.btc_conv_dgrad(ptr(grad_out), ptr(w), ptr(map_bwd), n_src, K, cin, cout, ptr(din), stream_ptr()),
                       "btc_conv_dgrad")
-        if ctx.needs_input_grad[1]:
-            n_res = map_fwd.shape[0]
-            dw = torch.empty(ctx.wshape, dtype=torch.float32, device=grad_out.device)
-            n_src = map_bwd.shape[0]
-            ws_bytes = L.btc_conv_wgrad_ws_bytes(n_res, K, cin, cout, n_src)
-            ws = workspace(ws_bytes, grad_out.device)
-            with _span("conv_wgrad", lambda: _wgrad_cost(map_fwd, n_res, K, cin, cout)):
-                check(L.btc_conv_wgrad(ptr(features), ptr(grad_out), ptr(map_fwd), n_res, ptr(map_bwd), n_src, K, cin, cout,
-                                       ptr(dw), ptr(ws), ws_bytes, stream_ptr()), "btc_conv_wgrad")
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = grad_out.sum(0)
+        if side is not None:
+            torch.cuda.current_stream().wait_stream(side)  # join: dW is consumed on the main stream from here on
+            dw.record_stream(torch.cuda.current_stream())
         return din, dw, db, None, None
 
 

@@ -228,6 +228,34 @@ int btc_bn_relu_bwd(const float* x, const float* y, const float* dy, int N, int 
                     const float* save_mean, const float* save_rstd, int training, int relu, float* dx, float* dgamma,
                     float* dbeta, void* ws, size_t ws_bytes, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * PassOccVox, fused.  Replaces /root/reference/btcdet/models/occ_pnt/pass_occ_vox.py:10-59 with
+ * add_occ_template.py:78-190,248-268: per scene the cells with p > OCC_THRESH (exact top-MAX_NUM_OCC_PNTS by
+ * probability when there are more), cell centre (+ predicted residual) -> Cartesian -> detection-grid cell, merged
+ * with the valid points of the detection voxels into lexicographically sorted voxels (M'',Pmax,C+code_dim).
+ *   count: enqueues everything up to the member lists; d_info (2+B) i32 = [M'', Pmax, added points per scene]
+ *   fill : voxels (M'',Pmax,C+code) f32, vcoords (M'',4) i64 [b,z,y,x], vnum (M'') i64,
+ *          occ_pnts (K,4) f32 [x,y,z,prob], occ_b (K) i64, K = sum of the per-scene counts
+ * Selected cells are processed in ascending cell order (the reference's topk(sorted=False) order is unspecified).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct BtcPovConfig {
+  int32_t batch, max_k;
+  int32_t occ_grid[3];      /* nx, ny, nz of the occupancy (cylinder) grid */
+  int32_t det_grid[3];      /* nx, ny, nz of the detection grid */
+  float occ_origin[3], occ_voxel[3];
+  float det_origin[3], det_voxel[3];
+  float occ_thresh, inten;
+  int32_t code_dim;         /* CODE_NUM_DIM: appended [prob, flag] channels */
+} BtcPovConfig;
+
+size_t btc_pass_occ_vox_ws_bytes(const BtcPovConfig* cfg, int M, int P);
+int btc_pass_occ_vox_count(const BtcPovConfig* cfg, const float* probs /* B,nz,ny,nx */, const float* residuals /* B,3,nz,ny,nx or NULL */,
+                           const uint8_t* use_occ /* B or NULL */, const float* rot_z /* B or NULL */, const int32_t* det_coords,
+                           const int32_t* det_num, int M, int P, int C, int32_t* d_info, void* ws, size_t ws_bytes, void* stream);
+int btc_pass_occ_vox_fill(const BtcPovConfig* cfg, const float* det_voxels, int M, int P, int C, int m, int pmax, int k_total,
+                          float* voxels, int64_t* vcoords, int64_t* vnum, float* occ_pnts, int64_t* occ_b, void* ws,
+                          size_t ws_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -86,10 +86,18 @@ def test_occ_loss_vs_golden(G):
     np.testing.assert_allclose([float(loss), tb["occ_loss_cls"], tb["occ_loss_res"]], g["head_loss"], rtol=2e-5)
 
 
-def test_pass_occ_vox_vs_golden(G):
+@pytest.mark.parametrize("fused", [True, False])
+def test_pass_occ_vox_vs_golden(G, fused):
+    """fused = the btc_pass_occ_vox_* path (radix-select top-k + virtual-point re-voxelization);
+    not fused = the torch op chain + btc_revoxelize_*; both against the reference's golden output"""
+    from btcdet_amd import pass_occ_vox as pov
     g, scenes, bd, cfg, model = G
     d = reference_side_dict(g, bd, cfg, DEV)
-    d = model.occ_modules.occ_pnt_update(d)
+    pov.FUSED = fused
+    try:
+        d = model.occ_modules.occ_pnt_update(d)
+    finally:
+        pov.FUSED = True
     vc, vn, vv = d["voxel_coords"].cpu().numpy(), d["voxel_num_points"].cpu().numpy(), d["voxels"].cpu().numpy()
     assert d["voxel_coords"].dtype == torch.int64 and d["voxel_num_points"].dtype == torch.int64
     # added occupancy points: same set of (scene, prob) and xyz within 1e-4 m (device cos/sin); order is unspecified in the
