@@ -86,6 +86,10 @@ _SIGS = {
     "btc_pass_occ_vox_ws_bytes": (sz, [ctypes.POINTER(BtcPovConfig), ci, ci]),
     "btc_pass_occ_vox_count": (ci, [ctypes.POINTER(BtcPovConfig), vp, vp, vp, vp, vp, vp, ci, ci, ci, vp, vp, sz, vp]),
     "btc_pass_occ_vox_fill": (ci, [ctypes.POINTER(BtcPovConfig), vp, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, sz, vp]),
+    "btc_occ_loss_ws_bytes": (sz, []),
+    "btc_occ_loss_fwd": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, ci, ctypes.c_longlong, ctypes.c_float, ctypes.c_float, ctypes.c_float, vp, vp, vp,
+                              sz, vp]),
+    "btc_occ_loss_bwd": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, ci, ctypes.c_longlong, ctypes.c_float, vp, vp, vp, vp, vp]),
     "btc_bn_ws_bytes": (sz, [ci]),
     "btc_bn_relu_fwd": (ci, [vp, ci, ci, vp, vp, vp, vp, vp, ctypes.c_float, ctypes.c_float, ci, ci, vp, vp, vp, vp, sz, vp]),
     "btc_bn_relu_bwd": (ci, [vp, vp, vp, ci, ci, vp, vp, vp, ci, ci, vp, vp, vp, vp, sz, vp]),

@@ -120,7 +120,7 @@ __global__ __launch_bounds__(1024) void pov_select(const float* __restrict__ pro
   int32_t* out = sel + (size_t)b * G.max_k;
   for (int start = 0; start < G.ncell; start += 1024 * 4) {
     const int i0 = start + tid * 4;
-    int f[4], e[4], nf = 0, ne = 0;
+    int f[4], e[4], ne = 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int i = i0 + j;
@@ -128,7 +128,6 @@ __global__ __launch_bounds__(1024) void pov_select(const float* __restrict__ pro
       unsigned k = cand ? pk[i] : 0u;
       f[j] = cand && (all || k > T);
       e[j] = cand && !all && k == T;
-      nf += f[j];
       ne += e[j];
     }
     int tot_e, tot_f;

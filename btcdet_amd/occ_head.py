@@ -55,6 +55,55 @@ class WeightedSmoothL1Loss(nn.Module):
         return loss
 
 
+_LOSS_WS = {}
+
+
+class OccLossFunction(torch.autograd.Function):
+    """(cls_loss, reg_loss) of the occupancy head in one launch each way (csrc/occ_loss.hip)"""
+
+    @staticmethod
+    def forward(ctx, logit, res, res_target, pos_mask, cls_mask, cls_w, reg_mask, reg_w, beta, w_cls, w_res):
+        from ._lib import check, lib, ptr, stream_ptr
+        dev = logit.device
+        key = (dev.type, dev.index)
+        if key not in _LOSS_WS:
+            _LOSS_WS[key] = torch.zeros(int(lib().btc_occ_loss_ws_bytes()), dtype=torch.uint8, device=dev)
+        ws = _LOSS_WS[key]
+        B = logit.shape[0]
+        ncell = logit[0, 0].numel()
+        logit = logit.contiguous()
+        res_c = res.contiguous() if res is not None else None
+        tgt = res_target.contiguous() if res_target is not None else None
+        u8 = lambda t: (t if t.dtype == torch.uint8 else t.to(torch.uint8)).contiguous()
+        pos_mask, cls_mask = u8(pos_mask), u8(cls_mask)
+        reg_mask = u8(reg_mask) if reg_mask is not None else None
+        cls_w = cls_w.contiguous()
+        reg_w = reg_w.contiguous() if reg_w is not None else None
+        out = torch.empty((2,), dtype=torch.float32, device=dev)
+        norms = torch.empty((2,), dtype=torch.float32, device=dev)
+        check(lib().btc_occ_loss_fwd(ptr(logit), ptr(res_c), ptr(tgt), ptr(pos_mask), ptr(cls_mask), ptr(cls_w), ptr(reg_mask), ptr(reg_w), B,
+                                     ncell, float(beta), float(w_cls), float(w_res), ptr(out), ptr(norms), ptr(ws), ws.numel(), stream_ptr()),
+              "btc_occ_loss_fwd")
+        ctx.save_for_backward(logit, res_c, tgt, pos_mask, cls_mask, cls_w, reg_mask, reg_w, norms)
+        ctx.meta = (B, ncell, float(beta))
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        from ._lib import check, lib, ptr, stream_ptr
+        logit, res_c, tgt, pos_mask, cls_mask, cls_w, reg_mask, reg_w, norms = ctx.saved_tensors
+        B, ncell, beta = ctx.meta
+        d_logit = torch.zeros_like(logit)
+        d_res = torch.zeros_like(res_c) if res_c is not None else None
+        check(lib().btc_occ_loss_bwd(ptr(logit), ptr(res_c), ptr(tgt), ptr(pos_mask), ptr(cls_mask), ptr(cls_w), ptr(reg_mask), ptr(reg_w), B,
+                                     ncell, beta, ptr(norms), ptr(grad_out.contiguous()), ptr(d_logit), ptr(d_res), stream_ptr()),
+              "btc_occ_loss_bwd")
+        return d_logit, d_res, None, None, None, None, None, None, None, None, None
+
+
+FUSED_LOSS = True  # OccHeadTemplate.get_loss through btc_occ_loss_* (False: the torch op chain of the reference)
+
+
 class OccHeadTemplate(nn.Module):
     def __init__(self, model_cfg, data_cfg, num_class, grid_size):
         super().__init__()
@@ -113,6 +162,21 @@ class OccHeadTemplate(nn.Module):
     def get_loss(self, batch_dict):
         if self.noloss:
             return torch.tensor(0.0, device="cuda"), {}
+        logit = batch_dict['pred_occ_logit']
+        if FUSED_LOSS and self.is_softmax and logit.is_cuda and logit.shape[1] == 2 and (not self.reg or self.res_num_dim == 3):
+            lw = self.model_cfg.OCC_DENSE_HEAD.LOSS_CONFIG.LOSS_WEIGHTS
+            reg = self.reg
+            out = OccLossFunction.apply(
+                logit, batch_dict['pred_sem_residuals'] if reg else None, batch_dict['res_mtrx'] if reg else None,
+                batch_dict["pos_mask"], batch_dict['general_cls_loss_mask'], batch_dict["general_cls_loss_mask_float"],
+                batch_dict["general_reg_loss_mask"] if reg else None, batch_dict["general_reg_loss_mask_float"] if reg else None,
+                lw['res_beta'], self.occ_fore_cls_weight, self.occ_fore_res_weight)
+            vals = out.detach().tolist()  # the scalars the reference logs with .item() (one read-back for both)
+            tb_dict = {'occ_loss_cls': vals[0]}
+            if reg:
+                tb_dict['occ_loss_res'] = vals[1]
+                return out[0] + out[1], tb_dict
+            return out[0], tb_dict
         occ_loss, tb_dict = self.get_cls_layer_loss(batch_dict)
         if self.reg:
             reg_loss, tb_res = self.get_res_layer_loss(batch_dict)

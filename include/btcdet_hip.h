@@ -256,6 +256,24 @@ int btc_pass_occ_vox_fill(const BtcPovConfig* cfg, const float* det_voxels, int 
                           float* voxels, int64_t* vcoords, int64_t* vnum, float* occ_pnts, int64_t* occ_b, void* ws,
                           size_t ws_bytes, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Occupancy head losses, fused.  Replaces OccHeadTemplate.get_loss (occ_head_template.py:52-111) with
+ * SoftmaxFocalClassificationLoss (alpha 1, gamma 2, eps 1e-6; loss_utils.py:140-152) and WeightedSmoothL1Loss
+ * (beta; loss_utils.py:199-233) over the dense head outputs:
+ *   out2[0] = w_cls * sum_{cls_mask} cls_w * FL / max(sum cls_w, 1);  out2[1] = w_res * sum_{reg_mask} reg_w * SL1 / max(sum reg_w, 1)
+ * logit (B,2,ncell) f32, res / res_target (B,3,ncell) f32 (res may be NULL: no regression), masks (B,ncell) u8, weights f32.
+ * norms2 (2) f32 is saved for the backward, which writes d_logit / d_res (dense, zero-filled by the caller).
+ * ws: btc_occ_loss_ws_bytes() bytes, first 256 zero before the first call (kept zero).
+ * ---------------------------------------------------------------------------------------------- */
+size_t btc_occ_loss_ws_bytes(void);
+int btc_occ_loss_fwd(const float* logit, const float* res, const float* res_target, const uint8_t* pos_mask,
+                     const uint8_t* cls_mask, const float* cls_w, const uint8_t* reg_mask, const float* reg_w, int B,
+                     long long ncell, float beta, float w_cls, float w_res, float* out2, float* norms2, void* ws, size_t ws_bytes,
+                     void* stream);
+int btc_occ_loss_bwd(const float* logit, const float* res, const float* res_target, const uint8_t* pos_mask,
+                     const uint8_t* cls_mask, const float* cls_w, const uint8_t* reg_mask, const float* reg_w, int B,
+                     long long ncell, float beta, const float* norms2, const float* grad2, float* d_logit, float* d_res, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -79,11 +79,29 @@ def reference_side_dict(g, bd, cfg, device):
     return d
 
 
-def test_occ_loss_vs_golden(G):
+@pytest.mark.parametrize("fused", [True, False])
+def test_occ_loss_vs_golden(G, fused):
+    """loss values against the reference's golden numbers; gradients of the fused kernels against autograd through
+    the reference's op chain (fp64)"""
+    from btcdet_amd import occ_head
     g, scenes, bd, cfg, model = G
     d = reference_side_dict(g, bd, cfg, DEV)
-    loss, tb = model.occ_modules.occ_dense_head.get_loss(d)
+    d["pred_occ_logit"].requires_grad_(True)
+    d["pred_sem_residuals"].requires_grad_(True)
+    occ_head.FUSED_LOSS = fused
+    try:
+        loss, tb = model.occ_modules.occ_dense_head.get_loss(d)
+    finally:
+        occ_head.FUSED_LOSS = True
     np.testing.assert_allclose([float(loss), tb["occ_loss_cls"], tb["occ_loss_res"]], g["head_loss"], rtol=2e-5)
+    loss.backward()
+    d64 = {k: (v.detach().cpu().double() if torch.is_tensor(v) and v.is_floating_point() else (v.cpu() if torch.is_tensor(v) else v)) for k, v in d.items()}
+    d64["pred_occ_logit"].requires_grad_(True)
+    d64["pred_sem_residuals"].requires_grad_(True)
+    ref, _, _ = occ_oracle.occ_losses(d64, cfg.MODEL.OCC.OCC_DENSE_HEAD.LOSS_CONFIG.LOSS_WEIGHTS)
+    ref.backward()
+    np.testing.assert_allclose(d["pred_occ_logit"].grad.cpu().numpy(), d64["pred_occ_logit"].grad.numpy(), rtol=1e-4, atol=1e-9)
+    np.testing.assert_allclose(d["pred_sem_residuals"].grad.cpu().numpy(), d64["pred_sem_residuals"].grad.numpy(), rtol=1e-4, atol=1e-9)
 
 
 @pytest.mark.parametrize("fused", [True, False])
