@@ -206,8 +206,10 @@ def main():
     det_params = [p for p in model.det_modules.parameters() if p.requires_grad]
     # adam_onecycle groups of the reference (optimization/__init__.py:36-40; LR is scheduled, yaml:331-372)
     # fused=True: one multi-tensor launch per optimizer instead of ~10 foreach launches with 60 us host gaps between them
-    opts = [torch.optim.Adam(occ_params, lr=3e-3, weight_decay=0.001, betas=(0.9, 0.99), fused=True),
-            torch.optim.Adam(det_params, lr=3e-3, weight_decay=0.01, betas=(0.9, 0.99), fused=True)]
+    # the reference's two optimizers (occ / det) as the two parameter groups of one fused Adam: same update rule per
+    # group, half the host overhead per step
+    opts = [torch.optim.Adam([{"params": occ_params, "lr": 3e-3, "weight_decay": 0.001},
+                              {"params": det_params, "lr": 3e-3, "weight_decay": 0.01}], betas=(0.9, 0.99), fused=True)]
     bs = 2
     batches = build_batches(4, rank, device, bs)
     step = make_step(model, ddp, model.dataset.data_processor, opts)

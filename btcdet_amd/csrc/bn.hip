@@ -81,10 +81,21 @@ __global__ __launch_bounds__(BN_T) void bn_stats(const float* __restrict__ x, Bn
     const int c = c0 + (tid % S.cpow), rr = tid / S.cpow;
     double a = 0.0, b = 0.0;
     if (c < S.C)
-      for (int g = rr; g < (int)gridDim.x; g += S.rpi) {
+    {
+      int g = rr;
+      for (; g + 3 * S.rpi < (int)gridDim.x; g += 4 * S.rpi) {  // 8 loads in flight, fixed order
+        double a0 = partial[((size_t)g * 2 + 0) * S.C + c], b0 = partial[((size_t)g * 2 + 1) * S.C + c];
+        double a1 = partial[((size_t)(g + S.rpi) * 2 + 0) * S.C + c], b1 = partial[((size_t)(g + S.rpi) * 2 + 1) * S.C + c];
+        double a2 = partial[((size_t)(g + 2 * S.rpi) * 2 + 0) * S.C + c], b2 = partial[((size_t)(g + 2 * S.rpi) * 2 + 1) * S.C + c];
+        double a3 = partial[((size_t)(g + 3 * S.rpi) * 2 + 0) * S.C + c], b3 = partial[((size_t)(g + 3 * S.rpi) * 2 + 1) * S.C + c];
+        a += ((a0 + a1) + (a2 + a3));
+        b += ((b0 + b1) + (b2 + b3));
+      }
+      for (; g < (int)gridDim.x; g += S.rpi) {
         a += partial[((size_t)g * 2 + 0) * S.C + c];
         b += partial[((size_t)g * 2 + 1) * S.C + c];
       }
+    }
     s_a[tid] = a;
     s_b[tid] = b;
     __syncthreads();
@@ -192,10 +203,21 @@ __global__ __launch_bounds__(BN_T) void bn_bwd_stats(const float* __restrict__ x
     const int c = c0 + (tid % S.cpow), rr = tid / S.cpow;
     double a = 0.0, b = 0.0;
     if (c < S.C)
-      for (int g = rr; g < (int)gridDim.x; g += S.rpi) {
+    {
+      int g = rr;
+      for (; g + 3 * S.rpi < (int)gridDim.x; g += 4 * S.rpi) {  // 8 loads in flight, fixed order
+        double a0 = partial[((size_t)g * 2 + 0) * S.C + c], b0 = partial[((size_t)g * 2 + 1) * S.C + c];
+        double a1 = partial[((size_t)(g + S.rpi) * 2 + 0) * S.C + c], b1 = partial[((size_t)(g + S.rpi) * 2 + 1) * S.C + c];
+        double a2 = partial[((size_t)(g + 2 * S.rpi) * 2 + 0) * S.C + c], b2 = partial[((size_t)(g + 2 * S.rpi) * 2 + 1) * S.C + c];
+        double a3 = partial[((size_t)(g + 3 * S.rpi) * 2 + 0) * S.C + c], b3 = partial[((size_t)(g + 3 * S.rpi) * 2 + 1) * S.C + c];
+        a += ((a0 + a1) + (a2 + a3));
+        b += ((b0 + b1) + (b2 + b3));
+      }
+      for (; g < (int)gridDim.x; g += S.rpi) {
         a += partial[((size_t)g * 2 + 0) * S.C + c];
         b += partial[((size_t)g * 2 + 1) * S.C + c];
       }
+    }
     s_a[tid] = a;
     s_b[tid] = b;
     __syncthreads();
@@ -261,8 +283,8 @@ BnShape bn_shape(int N, int C) {
 }
 
 int bn_grid(int N, const BnShape& S) {
-  int g = btc_cdiv(N, S.rpi * 16);  // >= 16 rows per thread-row before adding another workgroup
-  if (g > 256) g = 256;
+  int g = btc_cdiv(N, S.rpi * 64);  // >= 64 rows per thread-row before adding another workgroup: the last-arriver
+  if (g > 256) g = 256;            // reduction walks all partials, so few, fat workgroups win at BtcDet's sizes
   if (g < 1) g = 1;
   return g;
 }

@@ -101,6 +101,7 @@ class OccLossFunction(torch.autograd.Function):
         return d_logit, d_res, None, None, None, None, None, None, None, None, None
 
 
+MERGE_HEADS = True  # OccHead3D: conv_cls + conv_res as one launch per direction
 FUSED_LOSS = True  # OccHeadTemplate.get_loss through btc_occ_loss_* (False: the torch op chain of the reference)
 
 
@@ -200,9 +201,44 @@ class OccHead3D(OccHeadTemplate):
                 spconv.SubMConv3d(input_channels, (self.stride ** 3) * self.num_class * self.res_num_dim, 3, padding=1,
                                   bias=False, indice_key='res_ind'))
 
+    def _merged_heads(self, x):
+        """conv_cls and conv_res see the same tensor with the same geometry: run them as ONE sparse conv with the two
+        weight tensors concatenated along Cout (parameters / state_dict untouched; autograd splits the gradient back)"""
+        cls, res = self.conv_cls[0], self.conv_res[0]
+        w = torch.cat([cls.weight, res.weight], dim=-1)
+        bias = torch.cat([cls.bias if cls.bias is not None else cls.weight.new_zeros(cls.out_channels),
+                          res.bias if res.bias is not None else res.weight.new_zeros(res.out_channels)])
+        from .spconv import ops
+        from .spconv.conv import _ntuple
+        geom = x.indice_dict.setdefault("__geometry_cache__", {})
+        gkey = (x.indices.data_ptr(), tuple(x.indices.shape), tuple(int(v) for v in x.spatial_shape), tuple(cls.kernel_size),
+                tuple(cls.dilation), True, False)
+        hit = geom.get(gkey, None)
+        if hit is None:
+            rb = ops.build_rulebook(x.indices, x.batch_size, x.spatial_shape, cls.kernel_size, 1, 0, cls.dilation, 0, True, False)
+            geom[gkey] = (rb, x.indices)
+        else:
+            rb = hit[0]
+        for m in (cls, res):
+            if m.indice_key is not None:
+                x.indice_dict[m.indice_key] = rb
+        out = ops.indice_conv(x.features, w, bias, rb)
+        nc = cls.out_channels
+        mk = lambda f: spconv.SparseConvTensor(f, x.indices, x.spatial_shape, x.batch_size)
+        return mk(out[:, :nc].contiguous()), mk(out[:, nc:].contiguous())
+
     def forward(self, data_dict):
         data_dict = self.prepare_loss_map(data_dict)
         x = data_dict['encoded_spconv_tensor']
+        if MERGE_HEADS and self.reg and x.features.is_cuda and len(self.conv_cls) == 1 and len(self.conv_res) == 1 \
+                and self.conv_cls[0].kernel_size == self.conv_res[0].kernel_size and self.conv_cls[0].dilation == self.conv_res[0].dilation:
+            t_cls, t_res = self._merged_heads(x)
+            logit = t_cls.dense()
+            prob = self.logit2prob(logit)[:, -1:, ...]
+            data_dict['pred_occ_logit'] = logit
+            data_dict['batch_pred_occ_prob'] = prob[:, -1, ...] * data_dict["general_cls_loss_mask"]
+            data_dict['pred_sem_residuals'] = t_res.dense()
+            return data_dict
         logit = self.conv_cls(x).dense()
         prob = self.logit2prob(logit)[:, -1:, ...]
         data_dict['pred_occ_logit'] = logit

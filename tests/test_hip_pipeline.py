@@ -195,3 +195,30 @@ def test_spconv_drop_in_import():
                                   spconv.SparseInverseConv3d(8, 4, 3, indice_key="b")).to(DEV)
     y = net(x)
     assert y.features.shape == (5, 4) and torch.equal(y.indices, x.indices) and list(y.dense().shape) == [1, 4, 4, 6, 8]
+
+
+def test_merged_occ_heads_equal_separate_heads(G):
+    """OccHead3D with conv_cls / conv_res run as one sparse conv == the two separate convs (forward bit-exact: each output
+    column is the same fmaf chain; parameter gradients within fp32 tolerance)"""
+    from btcdet_amd import occ_head, spconv
+    g, scenes, bd, cfg, model = G
+    head = model.occ_modules.occ_dense_head
+    torch.manual_seed(3)
+    idx = torch.unique(torch.stack([torch.randint(0, 2, (6000,)), torch.randint(0, 9, (6000,)), torch.randint(0, 157, (6000,)),
+                                    torch.randint(0, 209, (6000,))], 1), dim=0).int().to(DEV)
+    feat = torch.randn(idx.shape[0], 32, device=DEV)
+    mask = torch.ones(2, 9, 157, 209, dtype=torch.uint8, device=DEV)
+    outs = {}
+    for merged in (True, False):
+        occ_head.MERGE_HEADS = merged
+        head.zero_grad()
+        x = spconv.SparseConvTensor(feat.clone().requires_grad_(True), idx, [9, 157, 209], 2)
+        d = head({"encoded_spconv_tensor": x, "general_cls_loss_mask": mask})
+        (d["pred_occ_logit"].pow(2).sum() + d["pred_sem_residuals"].pow(2).sum()).backward()
+        outs[merged] = (d["pred_occ_logit"].detach(), d["pred_sem_residuals"].detach(), x.features.grad.clone(),
+                        head.conv_cls[0].weight.grad.clone(), head.conv_res[0].weight.grad.clone(), head.conv_cls[0].bias.grad.clone())
+    occ_head.MERGE_HEADS = True
+    a, b = outs[True], outs[False]
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    for i in (2, 3, 4, 5):
+        np.testing.assert_allclose(a[i].cpu().numpy(), b[i].cpu().numpy(), rtol=2e-4, atol=2e-4)
