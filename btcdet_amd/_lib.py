@@ -61,6 +61,7 @@ _SIGS = {
     # name: (restype, argtypes)
     "btc_last_error": (ctypes.c_char_p, []),
     "btc_version": (ci, []),
+    "btc_tune_set": (ci, [ci, ci]),
     "btc_voxelize_ws_bytes": (sz, [ci, ci, ci]),
     "btc_voxelize": (ci, [vp, ci, ci, ci, ci, ci, vp, ci, c_f32p, c_f32p, c_i32p, ci, ci, vp, vp, vp, vp, vp, sz, vp]),
     "btc_cart_to_occ_coords": (ci, [vp, vp, ci, ci, ci, vp]),

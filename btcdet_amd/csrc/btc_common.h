@@ -37,6 +37,16 @@ void btc_set_error(const char* fmt, ...);
     }                                                                             \
   } while (0)
 
+// tuning overrides (btc_tune_set): 0 = built-in policy
+#define BTC_TUNE_KEYS 8
+int btc_tune_get(int key);
+
+// conv_apply_glds.hip: LDS-DMA pipelined sparse-conv apply (same results as conv_apply)
+bool btc_apply_glds_supported(int K, int Cred, int Cres);
+bool btc_apply_glds_has_shape(int shape);
+int btc_launch_apply_glds(bool trans_w, int shape, int kc, int xcd, const float* feat, const float* W, const float* bias,
+                          const int32_t* nbr, int n_rows, int K, int Cred, int Cres, float* out, hipStream_t stream);
+
 static inline int btc_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 static inline size_t btc_align(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 static inline unsigned btc_pow2_ge(unsigned long long v) {

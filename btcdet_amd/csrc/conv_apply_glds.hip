@@ -1,0 +1,277 @@
+// Sparse convolution apply, LDS-DMA pipelined variant (gfx950 `global_load_lds_dwordx4`).
+//
+// Same contract, same summation order (offset ascending, channel ascending, exact fp32 MFMA fmaf chain) and therefore the
+// same bits as conv_apply in sparse_conv.hip.  What changes is how the operands reach LDS: conv_apply stages every
+// (offset, 32-channel chunk) item through registers with two workgroup barriers per item, so a workgroup alternates
+// between a store phase and an MFMA phase; here the gathered rows and the weight panel are written into a 3-deep LDS
+// ring by the LDS-DMA path (no staging VGPRs, no ds_write pass), two items stay in flight across ONE raw s_barrier per
+// item (counted `s_waitcnt vmcnt(N)`, never a drain), and a wave skips the MFMAs of an offset none of its 16 rows has.
+//
+// LDS images (the DMA destination is wave-uniform base + lane * 16 B, so swizzles are applied to the per-lane SOURCE):
+//   A (per wave, 16 rows x KC):  slot p of row r holds channel unit  p ^ (r & (KC/4 - 1))
+//   B fwd   [k][TN]           :  16-column group g of row k holds columns of group  g ^ (k & 1)       (conflict-free reads)
+//   B dgrad [c][KC] (= W^T)   :  slot p of column c holds reduction unit  p ^ (c & (KC/4 - 1))
+// Rows without a neighbour at the offset read a zeroed device row (the DMA has no per-lane predicated zero fill).
+#include "btc_common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+__device__ float g_zero_row[64];  // zero-initialised; the source of gathers for absent neighbours
+
+constexpr int G_STAGES = 3;
+
+__device__ __forceinline__ void glds16(const float* g, float* l) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16,
+                                   0, 0);
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// Workgroup = WR x WC waves: WR 16-row groups (TM = 16 WR output rows) x WC column groups of NTW 16-column tiles
+// (TN = 16 NTW WC result channels).  KC: reduction channels per pipeline item (16, 32 or 64).
+// Small layers get small TM (more workgroups than CUs), wide layers split the columns over waves (more waves per SIMD
+// to cover each other's LDS round trips); the price of a smaller TM is that every workgroup streams all K weight panels.
+template <int WR, int WC, int NTW, bool TRANS_W, int KC>
+__global__ __launch_bounds__(64 * WR * WC) void conv_apply_g(const float* __restrict__ feat, const float* __restrict__ W,
+                                                             const float* __restrict__ bias, const int32_t* __restrict__ nbr,
+                                                             int n_rows, int K, int Cred, int Cres, float* __restrict__ out,
+                                                             int xcd_swizzle, int dbg) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NW = WR * WC, THREADS = 64 * NW;
+  constexpr int TM = 16 * WR, TN = 16 * NTW * WC, NG = NTW * WC;  // NG: 16-column groups of the B image
+  constexpr int UPR = KC / 4;                      // 16-byte units per A row / per B^T column
+  constexpr int NAI_TOTAL = WR * KC / 16;          // A DMA instructions per item (64 units each), whole workgroup
+  constexpr int NAI = (NAI_TOTAL + NW - 1) / NW;   // ... per wave (duplicates when not divisible: same data, same place)
+  constexpr int NBI_TOTAL = KC * TN / 256;         // B DMA instructions per item, whole workgroup
+  constexpr int NBI = (NBI_TOTAL + NW - 1) / NW;
+  constexpr int NPI = NAI + NBI;                   // DMA instructions per wave and item
+  constexpr int STAGE = TM * KC + KC * TN;         // floats
+  float* ring = (float*)smem;                      // [G_STAGES][ A: TM x KC | B: KC x TN ]
+  int32_t* s_nbr = (int32_t*)(ring + G_STAGES * STAGE);  // [TM][K]
+  int32_t* s_kact = s_nbr + TM * K;                // [K] flags, then the compact list of active offsets
+  int32_t* s_nact = s_kact + K;                    // [1]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave / WC, wc = wave % WC;
+  int bx = blockIdx.x;
+  if (xcd_swizzle) {  // workgroups are dealt round-robin to the 8 XCDs: give XCD x the contiguous tile range x
+    const int nb = gridDim.x, per = nb >> 3, main = per << 3;
+    if (bx < main) bx = (bx & 7) * per + (bx >> 3);
+  }
+  const int row0 = bx * TM;
+  const int n0 = blockIdx.y * TN;
+
+  for (int e = tid; e < K; e += THREADS) s_kact[e] = 0;
+  __syncthreads();
+  {
+    const long long gbase = (long long)row0 * K;
+    const long long gend = (long long)n_rows * K;
+    for (int e = tid; e < TM * K; e += THREADS) {
+      int v = (gbase + e < gend) ? nbr[gbase + e] : -1;
+      s_nbr[e] = v;
+      if (v >= 0) s_kact[e % K] = 1;
+    }
+  }
+  __syncthreads();
+  // offsets this wave's 16-row group touches: lane k scans its column of the map (K <= 64)
+  unsigned long long wave_act;
+  {
+    bool any = false;
+    if (lane < K)
+      for (int r = 0; r < 16; ++r) any |= s_nbr[(wr * 16 + r) * K + lane] >= 0;
+    wave_act = __ballot(any);
+  }
+  const int kflag = (lane < K) ? s_kact[lane] : 0;
+  __syncthreads();
+  if (wave == 0) {  // compact list of the workgroup's active offsets, ascending
+    const unsigned long long m = __ballot(kflag != 0);
+    if (kflag) s_kact[__popcll(m & ((1ull << lane) - 1ull))] = lane;
+    if (lane == 0) *s_nact = __popcll(m);
+  }
+  __syncthreads();
+  const int n_act = *s_nact;
+  const int n_chunks = Cred / KC;
+  const int n_items = n_act * n_chunks;
+
+  f32x4 acc[NTW];
+#pragma unroll
+  for (int nt = 0; nt < NTW; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  auto issue = [&](int item, int st) {
+    const int k = s_kact[item / n_chunks];
+    const int cc = (item % n_chunks) * KC;
+    float* As = ring + st * STAGE;
+    float* Bs = As + TM * KC;
+#pragma unroll
+    for (int t = 0; t < NAI; ++t) {
+      const int ai = (wave + NW * t) % NAI_TOTAL;  // instruction ai covers 64 / UPR rows of the A image
+      const int rloc = ai * (64 / UPR) + lane / UPR;
+      const int u = (lane % UPR) ^ (rloc & (UPR - 1));
+      const int nb = s_nbr[rloc * K + k];
+      const float* src = nb >= 0 ? feat + (size_t)nb * Cred + cc + u * 4 : g_zero_row;
+      glds16(src, As + ai * 256);
+    }
+    const float* Wk = W + (size_t)k * Cred * Cres;
+#pragma unroll
+    for (int t = 0; t < NBI; ++t) {
+      const int ii = (wave + NW * t) % NBI_TOTAL;
+      const int U = ii * 64 + lane;
+      const float* src;
+      if (!TRANS_W) {
+        const int kr = U / (TN / 4), pu = U % (TN / 4);
+        const int g = (NG >= 2) ? ((pu >> 2) ^ (kr & 1)) : (pu >> 2);
+        src = Wk + (size_t)(cc + kr) * Cres + n0 + g * 16 + (pu & 3) * 4;
+      } else {  // B^T[c][r] = W[k][ci = n0 + c][co = cc + r]: contiguous along r
+        const int c = U / UPR, pu = U % UPR;
+        const int ru = pu ^ (c & (UPR - 1));
+        src = Wk + (size_t)(n0 + c) * Cred + cc + ru * 4;
+      }
+      glds16(src, Bs + ii * 256);
+    }
+  };
+
+  const int arow = lane & 15, kq = lane >> 4;
+  if (n_items > 0) issue(0, 0);
+  if (n_items > 1) issue(1, 1);
+  int st = 0;
+  for (int item = 0; item < n_items; ++item) {
+    if (item + 1 < n_items) wait_vm<NPI>();  // this item has landed; the next one stays in flight
+    else wait_vm<0>();
+    __builtin_amdgcn_s_barrier();  // everyone's share of this item is in LDS, and everyone is done reading item - 1
+    asm volatile("" ::: "memory");
+    if (item + 2 < n_items && !(dbg & 2)) issue(item + 2, st == 0 ? 2 : st - 1);  // into the stage item - 1 occupied
+    const int k = s_kact[item / n_chunks];
+    if (((wave_act >> k) & 1ull) && !(dbg & 1)) {
+      // fragment reads are software-pipelined by hand in groups of G reduction steps: the reads of group g + 1 are issued
+      // before the MFMAs of group g and pinned there (sched_barrier) -- left alone, hipcc sinks every ds_read next to its
+      // MFMA and drains lgkmcnt(0) there, one exposed LDS round trip per step
+      const float* A = ring + st * STAGE + (wr * 16 + arow) * KC + kq;
+      const float* B = ring + st * STAGE + TM * KC;
+      constexpr int Q = KC / 4;
+      constexpr int G = (16 / NTW) < 1 ? 1 : ((16 / NTW) > Q ? Q : (16 / NTW));
+      constexpr int NGRP = Q / G;
+      float a[2][G], b[2][G][NTW];
+      auto load_group = [&](int g, int buf) {
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+          const int q = g * G + i;
+          a[buf][i] = A[(q ^ (arow & (UPR - 1))) * 4];
+          if (!TRANS_W) {
+            const float* bp = B + (q * 4 + kq) * TN + arow;
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) {
+              const int cg = wc * NTW + nt;
+              b[buf][i][nt] = bp[((NG >= 2) ? (cg ^ (kq & 1)) : cg) * 16];
+            }
+          } else {
+            const float* bp = B + (wc * NTW * 16 + arow) * KC + (q ^ (arow & (UPR - 1))) * 4 + kq;
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) b[buf][i][nt] = bp[nt * 16 * KC];
+          }
+        }
+      };
+      load_group(0, 0);
+#pragma unroll
+      for (int g = 0; g < NGRP; ++g) {
+        if (g + 1 < NGRP) load_group(g + 1, (g + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < G; ++i)
+#pragma unroll
+          for (int nt = 0; nt < NTW; ++nt)
+            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[g & 1][i], b[g & 1][i][nt], acc[nt], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    st = (st == G_STAGES - 1) ? 0 : st + 1;
+  }
+
+  // ---- epilogue: C/D layout of 16x16: col = lane&15, row = (lane>>4)*4 + reg
+#pragma unroll
+  for (int nt = 0; nt < NTW; ++nt) {
+    const int col = n0 + (wc * NTW + nt) * 16 + (lane & 15);
+    const float bv0 = bias ? bias[col] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      int row = row0 + wr * 16 + kq * 4 + r;
+      if (row < n_rows) out[(size_t)row * Cres + col] = bias ? (acc[nt][r] + bv0) : acc[nt][r];
+    }
+  }
+}
+
+template <int WR, int WC, int NTW, bool TRANS_W, int KC>
+int launch_g(const float* feat, const float* W, const float* bias, const int32_t* nbr, int n_rows, int K, int Cred, int Cres, float* out,
+             int xcd, hipStream_t stream) {
+  constexpr int TM = 16 * WR, TN = 16 * NTW * WC;
+  const size_t lds = (size_t)G_STAGES * (TM * KC + KC * TN) * sizeof(float) + (size_t)(TM * K + K + 1) * sizeof(int32_t);
+  BTC_CHECK_ARG(lds <= 160 * 1024, "conv_apply_g: tile does not fit the LDS");
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)conv_apply_g<WR, WC, NTW, TRANS_W, KC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  dim3 grid(btc_cdiv(n_rows, TM), Cres / TN);
+  conv_apply_g<WR, WC, NTW, TRANS_W, KC><<<grid, 64 * WR * WC, lds, stream>>>(feat, W, bias, nbr, n_rows, K, Cred, Cres, out, xcd,
+                                                                            btc_tune_get(BTC_TUNE_APPLY_DEBUG));
+  BTC_LAUNCH_CHECK();
+  return BTC_OK;
+}
+
+#define G_ARGS feat, W, bias, nbr, n_rows, K, Cred, Cres, out, xcd, stream
+#define G_PARAMS                                                                                                              \
+  const float *feat, const float *W, const float *bias, const int32_t *nbr, int n_rows, int K, int Cred, int Cres, float *out, int xcd, \
+      hipStream_t stream
+
+template <int WR, int WC, int NTW, bool TRANS_W>
+int launch_g_kc(int kc, G_PARAMS) {
+  switch (kc) {
+    case 16: return launch_g<WR, WC, NTW, TRANS_W, 16>(G_ARGS);
+    case 32: return launch_g<WR, WC, NTW, TRANS_W, 32>(G_ARGS);
+    default: return launch_g<WR, WC, NTW, TRANS_W, 64>(G_ARGS);
+  }
+}
+
+template <bool TRANS_W>
+int launch_g_shape(int wr, int wc, int ntw, int kc, G_PARAMS) {
+  const int code = wr * 100 + wc * 10 + ntw;
+  switch (code) {
+#define G_CASE(WR_, WC_, NTW_) \
+  case WR_ * 100 + WC_ * 10 + NTW_: return launch_g_kc<WR_, WC_, NTW_, TRANS_W>(kc, G_ARGS)
+    G_CASE(4, 1, 1); G_CASE(4, 1, 2); G_CASE(4, 1, 4); G_CASE(4, 1, 8);
+    G_CASE(4, 2, 1); G_CASE(4, 2, 2); G_CASE(4, 2, 4);
+    G_CASE(2, 2, 1); G_CASE(2, 2, 2); G_CASE(2, 2, 4);
+    G_CASE(2, 4, 1); G_CASE(2, 4, 2);
+    G_CASE(1, 4, 1); G_CASE(1, 4, 2);
+#undef G_CASE
+    default: break;
+  }
+  btc_set_error("conv_apply_g: no instance for WR=%d WC=%d NTW=%d", wr, wc, ntw);
+  return BTC_EINVAL;
+}
+
+}  // namespace
+
+bool btc_apply_glds_has_shape(int shape) {
+  static const int shapes[] = {411, 412, 414, 418, 421, 422, 424, 221, 222, 224, 241, 242, 141, 142};
+  for (int v : shapes)
+    if (v == shape) return true;
+  return false;
+}
+
+bool btc_apply_glds_supported(int K, int Cred, int Cres) { return K <= 64 && Cred % 16 == 0 && Cres % 16 == 0 && Cred >= 16; }
+
+// shape = WR*100 + WC*10 + NTW (waves: WR row groups x WC column groups of NTW 16-column tiles), kc = reduction chunk
+int btc_launch_apply_glds(bool trans_w, int shape, int kc, int xcd, const float* feat, const float* W, const float* bias,
+                          const int32_t* nbr, int n_rows, int K, int Cred, int Cres, float* out, hipStream_t stream) {
+  if (n_rows <= 0) return BTC_OK;
+  const int wr = shape / 100, wc = (shape / 10) % 10, ntw = shape % 10;
+  BTC_CHECK_ARG(btc_apply_glds_supported(K, Cred, Cres) && wc * ntw > 0 && Cres % (16 * wc * ntw) == 0 && Cred % kc == 0 &&
+                    (kc == 16 || kc == 32 || kc == 64),
+                "conv_apply_g: unsupported K=%d Cred=%d Cres=%d shape=%d kc=%d", K, Cred, Cres, shape, kc);
+  return trans_w ? launch_g_shape<true>(wr, wc, ntw, kc, G_ARGS) : launch_g_shape<false>(wr, wc, ntw, kc, G_ARGS);
+}

@@ -656,10 +656,35 @@ int launch_apply(const float* feat, const float* W, const float* bias, const int
                  int Cres, float* out, hipStream_t stream) {
   if (n_rows <= 0) return BTC_OK;
   int nt = Cres <= 16 ? 1 : (Cres <= 32 ? 2 : (Cres <= 64 ? 4 : 8));
+  const int t_kernel = btc_tune_get(BTC_TUNE_APPLY_KERNEL), t_nt = btc_tune_get(BTC_TUNE_APPLY_NT),
+            t_xcd = btc_tune_get(BTC_TUNE_APPLY_XCD);
+  // LDS-DMA pipelined kernel (conv_apply_glds.hip) for every layer whose channel counts are multiples of 16, except the
+  // 200 K-row occupancy-branch layers where the register-staged kernel below measures 5-10 % faster.  Wave shapes from
+  // tools/conv_bench.py on MI355X (us per launch, register-staged -> LDS-DMA): 14 K rows 64->64: 80 -> 53, 128->128: 225 -> 158,
+  // 256->128: 456 -> 309; 3 K rows 64->64: 65 -> 40; 30 K rows 64->64: 119 -> 99.
+  if (t_kernel != 1 && btc_apply_glds_supported(K, Cred, Cres) && (t_kernel == 2 || n_rows < 100000)) {
+    int shape, kc = (Cred % 64 == 0) ? 64 : ((Cred % 32 == 0) ? 32 : 16);
+    if (Cres % 128 == 0) shape = 424;                       // 64 rows x 128 columns, 8 waves
+    else if (Cres % 64 == 0) shape = n_rows < 8192 ? 141 : 422;  // few rows: 16-row workgroups, 4 waves across the columns
+    else if (Cres % 32 == 0) shape = 221;
+    else shape = 411;
+    if (t_nt > 8) {  // tuning run: BTC_TUNE_APPLY_NT carries the wave shape WR*100 + WC*10 + NTW
+      int wc = (t_nt / 10) % 10, ntw = t_nt % 10;
+      while (ntw > 1 && Cres % (16 * wc * ntw)) ntw >>= 1;
+      while (wc > 1 && Cres % (16 * wc * ntw)) wc >>= 1;
+      const int cand = (t_nt / 100) * 100 + wc * 10 + ntw;
+      if (btc_apply_glds_has_shape(cand)) shape = cand;
+    }
+    const int t_kc = btc_tune_get(BTC_TUNE_APPLY_KC);
+    if (t_kc && Cred % t_kc == 0) kc = t_kc;
+    const int tm = 16 * (shape / 100), tn = 16 * ((shape / 10) % 10) * (shape % 10);
+    while (kc > 16 && (size_t)(3 * (tm * kc + kc * tn) + tm * K + K + 1) * 4 > 160 * 1024) kc >>= 1;  // 3-stage ring + map tile
+    return btc_launch_apply_glds(TRANS_W, shape, kc, t_xcd == 2, feat, W, bias, nbr, n_rows, K, Cred, Cres, out, stream);
+  }
   // weight-stationary persistent kernel (one 16-wave workgroup per CU).  Measured on MI355X: its dword-granular register
   // gather wins 2.5x for Cred <= 8 (the dgrad of the 2/3-channel occupancy heads, the 4/6-channel input layers) and loses
   // 2x at Cred = 32 (load-issue bound), so wider layers stay on the LDS-staged float4 kernel below.
-  if (Cred <= 8 && Cres <= 32 && K <= 64 && n_rows >= 2048 && ws_lds_bytes(K, Cred, nt) <= 160 * 1024) {
+  if (t_kernel != 1 && Cred <= 8 && Cres <= 32 && K <= 64 && n_rows >= 2048 && ws_lds_bytes(K, Cred, nt) <= 160 * 1024) {
     const int n_tiles16 = btc_cdiv(n_rows, 16);
     int wgs = btc_cdiv(n_tiles16, WS_WAVES);
     if (wgs > 256) wgs = 256;
@@ -683,6 +708,7 @@ int launch_apply(const float* feat, const float* W, const float* bias, const int
   const int n_tiles = btc_cdiv(n_rows, tm);
   // still too few workgroups (deep, narrow levels): also split the result channels
   while (nt > 2 && (long long)n_tiles * btc_cdiv(Cres, nt * 16) < 512) nt >>= 1;
+  if (t_nt && t_nt <= 8) nt = t_nt;
   dim3 grid(n_tiles, btc_cdiv(Cres, nt * 16));
   size_t lds = (size_t)(tm * LDA + KC * ldb_of(nt)) * sizeof(float) + (size_t)(tm * K + K + 1) * sizeof(int32_t);
   const bool vec = (Cred & 3) == 0;

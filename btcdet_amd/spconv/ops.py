@@ -61,6 +61,7 @@ class _NoSpan(object):
 
 
 PROFILE = None  # set to a LaunchProfile() to instrument
+CAPTURE = None  # set to a list to record (features, weight, bias, map_fwd, map_bwd) of every sparse conv (tools/conv_bench.py)
 OVERLAP_WGRAD = True  # run wgrad on a side stream concurrently with dgrad (backward of every sparse conv)
 _SIDE = {}
 
@@ -249,6 +250,8 @@ class SparseConvFunction(torch.autograd.Function):
         with _span("conv_apply", lambda: _conv_cost(map_fwd, n_res, K, cin, cout)):
             check(lib().btc_conv_fwd(ptr(features), ptr(w), ptr(b), ptr(map_fwd), n_res, K, cin, cout, ptr(out),
                                      stream_ptr()), "btc_conv_fwd")
+        if CAPTURE is not None:
+            CAPTURE.append((features, w, b, map_fwd, map_bwd))
         ctx.save_for_backward(features, w, map_fwd, map_bwd)
         ctx.has_bias = bias is not None
         ctx.wshape = tuple(weight.shape)

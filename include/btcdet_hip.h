@@ -46,6 +46,19 @@ extern "C" {
 const char* btc_last_error(void);
 int btc_version(void);
 
+/* Kernel-selection override for tuning / A-B measurements (tools/conv_bench.py); value 0 restores the built-in policy.
+ * Results never depend on keys 0-2 (every variant produces the same bits).  Keys:
+ *   BTC_TUNE_APPLY_KERNEL  1 = register-staged conv_apply, 2 = LDS-DMA pipelined conv_apply_g (where supported)
+ *   BTC_TUNE_APPLY_NT      16-column tiles per workgroup (1, 2, 4, 8); for kernel 2 the wave shape WR*100 + WC*10 + NTW
+ *   BTC_TUNE_APPLY_KC      kernel 2: reduction channels per pipeline item (16, 32, 64)
+ *   BTC_TUNE_APPLY_XCD     1 = XCD-contiguous row-tile mapping off, 2 = on */
+#define BTC_TUNE_APPLY_KERNEL 0
+#define BTC_TUNE_APPLY_NT 1
+#define BTC_TUNE_APPLY_XCD 2
+#define BTC_TUNE_APPLY_KC 4
+#define BTC_TUNE_APPLY_DEBUG 3 /* timing experiments only (WRONG results): 1 = no MFMA phase, 2 = no loads in the main loop */
+int btc_tune_set(int key, int value);
+
 /* ------------------------------------------------------------------------------------------------
  * Voxelizer.  Replaces spconv.utils.VoxelGeneratorV2.generate (points_to_voxel_3d_np), called at
  * /root/reference/btcdet/datasets/processor/data_processor.py:85,136,177, for a whole batch at once.

@@ -205,6 +205,44 @@ def test_conv_fwd_bwd_vs_oracle(cin, cout, kind):
         np.testing.assert_allclose(bt.grad.cpu().numpy(), dout.sum(0), rtol=1e-4, atol=1e-4)
 
 
+GLDS_SHAPES = [411, 412, 414, 418, 421, 422, 424, 221, 222, 224, 241, 242, 141, 142]
+
+
+@pytest.mark.parametrize("shape_code", GLDS_SHAPES)
+@pytest.mark.parametrize("kc", [16, 32, 64])
+def test_conv_apply_lds_dma_instances_bit_exact(shape_code, kc):
+    """every wave shape x reduction chunk of conv_apply_g (conv_apply_glds.hip), forward and dgrad, against the oracle's
+    fmaf chain; the kernel is forced with btc_tune_set (kernel-selection override, results never depend on it)"""
+    from btcdet_amd import _lib
+    from btcdet_amd.spconv import ops
+    L = _lib.lib()
+    wc, ntw = (shape_code // 10) % 10, shape_code % 10
+    cout = 16 * wc * ntw * (2 if wc * ntw <= 2 else 1)      # one or two column blocks
+    cin = 64 if kc == 64 else (96 if kc == 32 else 48)       # 1, 3 and 3 chunks
+    rng = np.random.default_rng(shape_code * 100 + kc)
+    shape, B = (8, 20, 18), 2
+    idx = rand_indices(rng, 500, B, shape)
+    (o_idx, o_out, o_in, o_sh), rb = _rb_both(idx, B, shape, (3, 3, 3), (2, 2, 2), (1, 1, 1), (1, 1, 1), "conv")
+    feat = rng.standard_normal((idx.shape[0], cin)).astype(np.float32)
+    W = (rng.standard_normal((3, 3, 3, cin, cout)) / np.sqrt(cin)).astype(np.float32)
+    bias = rng.standard_normal(cout).astype(np.float32)
+    dout = rng.standard_normal((o_idx.shape[0], cout)).astype(np.float32)
+    f = torch.from_numpy(feat).to(dev()).requires_grad_(True)
+    w = torch.from_numpy(W).to(dev())
+    bt = torch.from_numpy(bias).to(dev())
+    try:
+        for key, val in ((0, 2), (1, shape_code), (4, kc)):
+            assert L.btc_tune_set(key, val) == 0
+        out = ops.indice_conv(f, w, bt, rb)
+        out.backward(torch.from_numpy(dout).to(dev()))
+        torch.cuda.synchronize()
+    finally:
+        for key in (0, 1, 4):
+            L.btc_tune_set(key, 0)
+    np.testing.assert_array_equal(out.detach().cpu().numpy(), orc.conv_fwd(feat, W, bias, o_out))
+    np.testing.assert_array_equal(f.grad.cpu().numpy(), orc.conv_dgrad(dout, W, o_in))
+
+
 @pytest.mark.parametrize("cin,cout", [(4, 16), (6, 16), (16, 16), (32, 2), (32, 3), (16, 32), (32, 16), (32, 32), (34, 32), (32, 64), (64, 32), (64, 64), (2, 2)])
 @pytest.mark.parametrize("kind", ["subm", "conv"])
 def test_wgrad_row_stationary_kernel(cin, cout, kind):

@@ -1,0 +1,91 @@
+"""A/B timing of the sparse-conv apply kernel variants on the real layers of one hot-path step (tuning helper).
+
+usage: python tools/conv_bench.py [variant ...]   variant = kernel:nt:xcd (btc_tune_set values; 0 = built-in policy)
+Every variant's output is compared bit-for-bit with the first one."""
+import os, sys
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench
+from btcdet_amd import _lib
+from btcdet_amd._lib import ptr, stream_ptr, check
+from btcdet_amd.btc_path import BtcHotPath
+from btcdet_amd.config import load_cfg
+from btcdet_amd.spconv import ops
+
+variants = [tuple(int(x) for x in v.split(":")) for v in sys.argv[1:]] or [(0, 0, 0), (2, 0, 0)]
+dev = torch.device("cuda:0")
+torch.manual_seed(0)
+model = BtcHotPath(load_cfg(), device=dev).to(dev).train()
+opts = [torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=1e-3)]
+batches = bench.build_batches(2, 0, dev)
+step = bench.make_step(model, model, model.dataset.data_processor, opts)
+step(batches[0])
+ops.CAPTURE = []
+step(batches[0])
+cap, ops.CAPTURE = ops.CAPTURE, None
+torch.cuda.synchronize()
+L = _lib.lib()
+
+
+def tune(v):
+    v = tuple(v) + (0,) * (5 - len(v))
+    for key, val in enumerate(v):
+        check(L.btc_tune_set(key, val), "btc_tune_set")
+
+
+def timed(fn, reps=10):
+    for _ in range(2):
+        fn()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    ev[0].record()
+    for _ in range(reps):
+        fn()
+    ev[1].record()
+    torch.cuda.synchronize()
+    return ev[0].elapsed_time(ev[1]) / reps * 1e3
+
+
+seen = set()
+print("%-5s %7s %7s %2s %4s %4s %8s | " % ("dir", "n_res", "n_src", "K", "cred", "cres", "pairs") +
+      " ".join("%12s" % (":".join(map(str, v))) for v in variants))
+tot = np.zeros(len(variants))
+ONLY = os.environ.get("CB_ONLY")  # e.g. "256,128" = only layers with these (cin, cout)
+for feats, w, b, mf, mb in cap:
+    K = mf.shape[1]
+    if ONLY and (w.shape[-2], w.shape[-1]) not in [tuple(int(x) for x in o.split(",")) for o in ONLY.split(";")]:
+        continue
+    cin, cout = w.shape[-2], w.shape[-1]
+    pairs = int((mf >= 0).sum())
+    key = (mf.shape[0], mb.shape[0], K, cin, cout, pairs)
+    mult = sum(1 for c in cap if (c[3].shape[0], c[4].shape[0], c[3].shape[1], c[1].shape[-2], c[1].shape[-1]) == key[:5])
+    if key in seen:
+        continue
+    seen.add(key)
+    n_res, n_src = mf.shape[0], mb.shape[0]
+    out = torch.empty((n_res, cout), device=dev)
+    dout = torch.randn((n_res, cout), device=dev)
+    din = torch.empty((n_src, cin), device=dev)
+    for direction in ("fwd", "dgrad"):
+        us, ref = [], None
+        for v in variants:
+            tune(v)
+            if direction == "fwd":
+                fn = lambda: check(L.btc_conv_fwd(ptr(feats), ptr(w), ptr(b), ptr(mf), n_res, K, cin, cout, ptr(out), stream_ptr()), "fwd")
+                res = out
+            else:
+                fn = lambda: check(L.btc_conv_dgrad(ptr(dout), ptr(w), ptr(mb), n_src, K, cin, cout, ptr(din), stream_ptr()), "dgrad")
+                res = din
+            res.zero_()
+            t = timed(fn)
+            cur = res.clone()
+            if ref is None:
+                ref = cur
+            ok = torch.equal(ref.view(torch.int32), cur.view(torch.int32)) or (len(v) > 3 and v[3])
+            us.append((t, ok))
+        tot += np.array([u[0] for u in us]) * mult
+        cred, cres = (cin, cout) if direction == "fwd" else (cout, cin)
+        print("%-5s %7d %7d %2d %4d %4d %8d | " % (direction, n_res, n_src, K, cred, cres, pairs) +
+              " ".join("%9.1f%s" % (t, "   " if ok else " !!") for t, ok in us) + "  x%d" % mult)
+tune((0, 0, 0, 0, 0))
+print("sum over the step's layers (us): " + " ".join("%12.0f" % t for t in tot))
