@@ -54,12 +54,12 @@ def max_over_ranks(dt, dist, device):
     return float(t.item())
 
 
-def build_batches(n_batches, rank, device, batch_size=2):
+def build_batches(n_batches, rank, device, batch_size=2, profile="kitti"):
     from btcdet_amd import synth
     batches = []
     for i in range(n_batches):
         seeds = rank_seeds(rank, i, batch_size)
-        b = synth.make_batch(seeds)
+        b = synth.make_batch(seeds, profile=profile)
         batches.append({
             "batch_size": batch_size,
             "points5": torch.from_numpy(b["points"]).to(device),                       # [b,x,y,z,i] (collate layout)
@@ -167,6 +167,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--workload", choices=["kitti", "waymo"], default="kitti",
+                    help="kitti: the configuration BASELINE.json's metric is quoted on (default); waymo: the Waymo-shaped synthetic "
+                         "scenes of configs[4] (~166 k points/scene, 1504 x 1504 x 40 grid) -- same path, 6x the work per scene")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -196,7 +199,8 @@ def main():
 
     torch.manual_seed(666)
     np.random.seed(666 + rank)
-    cfg = load_cfg()
+    waymo = args.workload == "waymo"
+    cfg = load_cfg(os.path.join(ROOT, "btcdet_amd", "cfgs", "btcdet_waymo_synth.yaml") if waymo else None)
     model = BtcHotPath(cfg, device=device).to(device)
     model.train()
     ddp = model
@@ -211,7 +215,7 @@ def main():
     opts = [torch.optim.Adam([{"params": occ_params, "lr": 3e-3, "weight_decay": 0.001},
                               {"params": det_params, "lr": 3e-3, "weight_decay": 0.01}], betas=(0.9, 0.99), fused=True)]
     bs = 2
-    batches = build_batches(4, rank, device, bs)
+    batches = build_batches(4, rank, device, bs, args.workload)
     step = make_step(model, ddp, model.dataset.data_processor, opts)
 
     def sync():
@@ -247,12 +251,13 @@ def main():
     if rank == 0:
         scenes = bs * world * args.steps
         result = {
-            "metric": "scenes/s fwd+bwd KITTI-Car bs=2/GPU (BtcDet hot path)", "value": round(scenes / dt, 3), "unit": "scenes/s",
+            "metric": "scenes/s fwd+bwd %s bs=2/GPU (BtcDet hot path)" % ("Waymo-shaped synthetic" if waymo else "KITTI-Car"), "value": round(scenes / dt, 3), "unit": "scenes/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "btcdet_kitti_car hot path, bs=2/GPU, ~28.6k pts/scene: HIP voxelize (occ+det grids) -> OccTargets3D -> "
+            "config": {"workload": ("btcdet_waymo_synth (configs[4] shape) hot path, bs=2/GPU, ~166k pts/scene: HIP voxelize" if waymo else
+                                    "btcdet_kitti_car hot path, bs=2/GPU, ~28.6k pts/scene: HIP voxelize") + " (occ+det grids) -> OccTargets3D -> "
                                    "MeanVFE -> VoxelBackBoneDeconv -> OccHead3D+loss -> PassOccVox -> OccVFE -> VoxelBackBone8xOcc -> "
-                                   "HeightCompression (+L2 stand-in for the out-of-scope BEV heads), fwd+bwd+2xAdam, fp32",
+                                   "HeightCompression (+L2 stand-in for the out-of-scope BEV heads), fwd+bwd+Adam (occ / det parameter groups), fp32",
                        "global_batch": bs * world, "parallelism": "dp%d" % world,
                        "points_per_batch": [b["n_points"] for b in batches]},
         }
@@ -263,7 +268,7 @@ def main():
                 gbs = k["bytes"] / (k["ms"] * 1e-3) / 1e9
                 result["roofline"] = {"kernel": "conv_apply (fused sparse conv fwd + dgrad, output-stationary MFMA f32)", "bound": "hbm",
                                       "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5),
-                                      "traffic": pmc_traffic_per_launch(), "launches_per_step": k["launches"] / prof_steps,
+                                      "traffic": None if waymo else pmc_traffic_per_launch(), "launches_per_step": k["launches"] / prof_steps,
                                       "avg_launch_us": round(1e3 * k["ms"] / k["launches"], 2),
                                       "alg_bytes_per_step": k["bytes"] // prof_steps,
                                       "tflops": round(k["flops"] / (k["ms"] * 1e-3) / 1e12, 3), "mfma_f32_peak_tflops": FP32_MFMA_PEAK_TF,
@@ -277,7 +282,7 @@ def main():
             rb = summ.get("rulebook")
             if rb:
                 result["rulebook_hbm_GBps"] = round(rb["bytes"] / (rb["ms"] * 1e-3) / 1e9, 2)
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not waymo:
             result["cpu_baseline"] = cpu_baseline()
         print(json.dumps(result))
     if dist is not None:

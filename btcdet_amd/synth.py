@@ -24,37 +24,54 @@ def _rotz(points_xyz, deg):
     return (points_xyz.astype(np.float64) @ R).astype(np.float32)
 
 
-def make_scene(seed, az_step=0.1728, n_occluders=40, n_boxes=None):
+# Waymo-shaped synthetic workload (BASELINE.json configs[4]; the reference ships no Waymo yaml, so the constants are this
+# repository's): 360 deg 64-beam scan, ~170 k points, detection grid 1504 x 1504 x 40.
+WAYMO_DET_RANGE = np.array([-75.2, -75.2, -2, 75.2, 75.2, 4], dtype=np.float32)
+WAYMO_DET_VOXEL = [0.1, 0.1, 0.15]
+
+PROFILES = {
+    "kitti": dict(el=(-24.9, 2.0), az=(-40.5, 40.5), az_step=0.1728, sensor_h=1.73, n_occluders=40, occ_r=(8, 70), occ_az=(-0.7, 0.7),
+                  occ_top=0.3, crop=(0, -40, 70.4, 40), boxes=(2, 7), box_lwh=(3.9, 1.6, 1.56), rot=45.0),
+    "waymo": dict(el=(-17.6, 2.4), az=(-180.0, 180.0), az_step=0.135, sensor_h=1.8, n_occluders=160, occ_r=(6, 74), occ_az=(-np.pi, np.pi),
+                  occ_top=1.2, crop=(-75.2, -75.2, 75.2, 75.2), boxes=(12, 33), box_lwh=(4.7, 2.1, 1.7), rot=45.0),
+}
+
+
+def make_scene(seed, az_step=None, n_occluders=None, n_boxes=None, profile="kitti"):
+    pf = PROFILES[profile]
+    az_step = pf["az_step"] if az_step is None else az_step
+    n_occluders = pf["n_occluders"] if n_occluders is None else n_occluders
     rng = np.random.default_rng(seed)
-    el = np.deg2rad(np.linspace(-24.9, 2.0, 64))
-    az = np.deg2rad(np.arange(-40.5, 40.5, az_step))
+    el = np.deg2rad(np.linspace(pf["el"][0], pf["el"][1], 64))
+    az = np.deg2rad(np.arange(pf["az"][0], pf["az"][1], az_step))
     EL, AZ = np.meshgrid(el, az, indexing="ij")
     dx, dy, dz = np.cos(EL) * np.cos(AZ), np.cos(EL) * np.sin(AZ), np.sin(EL)
-    sensor_h = 1.73
+    sensor_h = pf["sensor_h"]
     with np.errstate(divide="ignore"):
         r_ground = np.where(dz < 0, -sensor_h / dz, np.inf)
     r = np.minimum(r_ground, 120.0)
-    occ_r = rng.uniform(8, 70, n_occluders)
-    occ_az = rng.uniform(-0.7, 0.7, n_occluders)
+    occ_r = rng.uniform(pf["occ_r"][0], pf["occ_r"][1], n_occluders)
+    occ_az = rng.uniform(pf["occ_az"][0], pf["occ_az"][1], n_occluders)
     occ_hw = rng.uniform(0.02, 0.08, n_occluders)
     for k in range(n_occluders):
         hit = np.abs(AZ - occ_az[k]) < occ_hw[k]
         rk = occ_r[k] / np.maximum(np.cos(EL), 1e-3)
         zk = rk * dz
-        hit &= (zk > -sensor_h) & (zk < 0.3) & (rk < r)
+        hit &= (zk > -sensor_h) & (zk < pf["occ_top"]) & (rk < r)
         r = np.where(hit, rk, r)
     valid = np.isfinite(r) & (r < 119.0)
     r = r + rng.normal(0, 0.02, r.shape)
     pts = np.stack([r * dx, r * dy, r * dz, rng.uniform(0, 1, r.shape)], axis=-1)[valid].astype(np.float32)
-    m = (pts[:, 0] >= 0) & (pts[:, 0] <= 70.4) & (pts[:, 1] >= -40) & (pts[:, 1] <= 40)
+    c = pf["crop"]
+    m = (pts[:, 0] >= c[0]) & (pts[:, 0] <= c[2]) & (pts[:, 1] >= c[1]) & (pts[:, 1] <= c[3])
     pts = pts[m]
-    nb = int(n_boxes if n_boxes is not None else rng.integers(2, 7))
+    nb = int(n_boxes if n_boxes is not None else rng.integers(pf["boxes"][0], pf["boxes"][1]))
     ids = rng.choice(n_occluders, nb, replace=False)
     boxes = np.zeros((nb, 8), dtype=np.float32)
     boxes[:, 0] = occ_r[ids] * np.cos(occ_az[ids])  # centred on the occluder face so that scan points fall inside
     boxes[:, 1] = occ_r[ids] * np.sin(occ_az[ids])
-    boxes[:, 2] = -sensor_h + 0.78
-    boxes[:, 3:6] = [3.9, 1.6, 1.56]
+    boxes[:, 3:6] = pf["box_lwh"]
+    boxes[:, 2] = -sensor_h + 0.5 * pf["box_lwh"][2]
     boxes[:, 6] = rng.uniform(-np.pi, np.pi, nb)
     boxes[:, 7] = 1
     bm = []
@@ -64,7 +81,7 @@ def make_scene(seed, az_step=0.1728, n_occluders=40, n_boxes=None):
         R = np.array([[c, -s, 0], [s, c, 0], [0, 0, 1]])
         bm.append((loc @ R.T + b[:3]).astype(np.float32))
     bm = np.concatenate(bm, axis=0) if bm else np.zeros((0, 3), np.float32)
-    rot_z = float(rng.uniform(-45, 45))
+    rot_z = float(rng.uniform(-pf["rot"], pf["rot"]))
     perm = rng.permutation(pts.shape[0])  # shuffle_points (data_processor.py:41-51)
     pts = pts[perm]
     pre_rot = pts.copy()
