@@ -752,12 +752,24 @@ WgradPlan wgrad_plan(int n_out, int K, int Cin, int Cout, int n_in = -1) {
     else if (mt * ntt == 8 && (mt == 2 || mt == 4)) kb = 2;
     else if (mt == 4 && ntt == 4) kb = 1;
     if (kb && rows >= 4096 && K <= 64) {
+      // Work split (tools/conv_bench.py, MI355X): two workgroups per CU (512 in all) = row splits x offset groups.  More
+      // phases per group = fewer groups re-reading the dOut tile but a larger accumulator slab per workgroup (PH = 7 no
+      // longer fits two workgroups per CU) and more slab traffic; the largest PH <= 4 that still leaves >= 3 row tiles
+      // per workgroup measured best from 12 K to 210 K rows (e.g. 32->32 at 210 K rows 307 -> 219 us, at 12 K rows 63 -> 30 us).
+      const int t_ph = btc_tune_get(BTC_TUNE_WGRAD_PH), t_wgs = btc_tune_get(BTC_TUNE_WGRAD_WGS);
+      const int wgs = t_wgs ? t_wgs : 512;
+      const int n_tiles = btc_cdiv(rows, TM);
+      if (!(mt == 1 && ntt == 1)) {
+        ph = 1;
+        for (int cand = 4; cand > 1; cand >>= 1)
+          if ((long long)n_tiles * btc_cdiv(K, kb * cand) >= 3LL * wgs) { ph = cand; break; }
+        if (t_ph) ph = t_ph;
+      }
       p.rows_kernel = 1;
       p.swap = swap; p.rows = rows;
       p.mt = mt; p.nt = ntt; p.kb = kb; p.ph = ph;
       p.groups = btc_cdiv(K, kb * ph);
-      int n_tiles = btc_cdiv(rows, TM);
-      int S = 256 / p.groups;
+      int S = wgs / p.groups;
       if (S > n_tiles / 2) S = n_tiles / 2;  // at least two row tiles per persistent workgroup
       if (S > n_tiles) S = n_tiles;
       if (S < 1) S = 1;
@@ -824,14 +836,22 @@ extern "C" int btc_conv_wgrad(const float* feat, const float* dout, const int32_
     size_t lds = (size_t)(p.kb * TM * ldb_of(p.mt) + TM * ldb_of(p.nt)) * sizeof(float) + (size_t)(TM * K + K) * sizeof(int32_t);
 #define BTC_WG_ROWS(MT_, NT_, KB_, PH_) \
   conv_wgrad_rows<MT_, NT_, KB_, PH_><<<grid, 256, lds, stream>>>(g_, c_, map_, p.rows, K, Cg, Cc, part, p.swap)
+#define BTC_WG_ROWS_PH(MT_, NT_, KB_)               \
+  do {                                              \
+    if (p.ph == 1) BTC_WG_ROWS(MT_, NT_, KB_, 1);   \
+    else if (p.ph == 2) BTC_WG_ROWS(MT_, NT_, KB_, 2); \
+    else if (p.ph == 4) BTC_WG_ROWS(MT_, NT_, KB_, 4); \
+    else BTC_WG_ROWS(MT_, NT_, KB_, 7);             \
+  } while (0)
     if (p.mt == 1 && p.nt == 1) BTC_WG_ROWS(1, 1, 8, 4);
-    else if (p.mt == 2 && p.nt == 1) BTC_WG_ROWS(2, 1, 4, 7);
-    else if (p.mt == 1 && p.nt == 2) BTC_WG_ROWS(1, 2, 4, 7);
-    else if (p.mt == 2 && p.nt == 2) BTC_WG_ROWS(2, 2, 4, 7);
-    else if (p.mt == 3 && p.nt == 2) BTC_WG_ROWS(3, 2, 2, 7);
-    else if (p.mt == 2 && p.nt == 4) BTC_WG_ROWS(2, 4, 2, 7);
-    else if (p.mt == 4 && p.nt == 2) BTC_WG_ROWS(4, 2, 2, 7);
-    else BTC_WG_ROWS(4, 4, 1, 7);
+    else if (p.mt == 2 && p.nt == 1) BTC_WG_ROWS_PH(2, 1, 4);
+    else if (p.mt == 1 && p.nt == 2) BTC_WG_ROWS_PH(1, 2, 4);
+    else if (p.mt == 2 && p.nt == 2) BTC_WG_ROWS_PH(2, 2, 4);
+    else if (p.mt == 3 && p.nt == 2) BTC_WG_ROWS_PH(3, 2, 2);
+    else if (p.mt == 2 && p.nt == 4) BTC_WG_ROWS_PH(2, 4, 2);
+    else if (p.mt == 4 && p.nt == 2) BTC_WG_ROWS_PH(4, 2, 2);
+    else BTC_WG_ROWS_PH(4, 4, 1);
+#undef BTC_WG_ROWS_PH
 #undef BTC_WG_ROWS
     BTC_LAUNCH_CHECK();
     wgrad_reduce<<<btc_cdiv(count, 256), 256, 0, stream>>>(part, p.S, count, dW);

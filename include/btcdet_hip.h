@@ -56,6 +56,8 @@ int btc_version(void);
 #define BTC_TUNE_APPLY_NT 1
 #define BTC_TUNE_APPLY_XCD 2
 #define BTC_TUNE_APPLY_KC 4
+#define BTC_TUNE_WGRAD_PH 5   /* conv_wgrad_rows: phases (of KB offsets) per offset group: 1, 2, 4, 7 */
+#define BTC_TUNE_WGRAD_WGS 6  /* conv_wgrad_rows: target number of workgroups (row splits x offset groups) */
 #define BTC_TUNE_APPLY_DEBUG 3 /* timing experiments only (WRONG results): 1 = no MFMA phase, 2 = no loads in the main loop */
 int btc_tune_set(int key, int value);
 

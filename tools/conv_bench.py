@@ -29,7 +29,7 @@ L = _lib.lib()
 
 
 def tune(v):
-    v = tuple(v) + (0,) * (5 - len(v))
+    v = tuple(v) + (0,) * (7 - len(v))
     for key, val in enumerate(v):
         check(L.btc_tune_set(key, val), "btc_tune_set")
 
@@ -66,13 +66,21 @@ for feats, w, b, mf, mb in cap:
     out = torch.empty((n_res, cout), device=dev)
     dout = torch.randn((n_res, cout), device=dev)
     din = torch.empty((n_src, cin), device=dev)
-    for direction in ("fwd", "dgrad"):
+    dw = torch.empty_like(w)
+    ws_cache = {}
+    for direction in os.environ.get("CB_DIRS", "fwd,dgrad").split(","):
         us, ref = [], None
         for v in variants:
             tune(v)
             if direction == "fwd":
                 fn = lambda: check(L.btc_conv_fwd(ptr(feats), ptr(w), ptr(b), ptr(mf), n_res, K, cin, cout, ptr(out), stream_ptr()), "fwd")
                 res = out
+            elif direction == "wgrad":
+                nb = L.btc_conv_wgrad_ws_bytes(n_res, K, cin, cout, n_src)
+                ws = torch.empty(max(nb, 256), dtype=torch.uint8, device=dev)
+                fn = lambda: check(L.btc_conv_wgrad(ptr(feats), ptr(dout), ptr(mf), n_res, ptr(mb), n_src, K, cin, cout, ptr(dw), ptr(ws), nb,
+                                                    stream_ptr()), "wgrad")
+                res = dw
             else:
                 fn = lambda: check(L.btc_conv_dgrad(ptr(dout), ptr(w), ptr(mb), n_src, K, cin, cout, ptr(din), stream_ptr()), "dgrad")
                 res = din
@@ -81,11 +89,14 @@ for feats, w, b, mf, mb in cap:
             cur = res.clone()
             if ref is None:
                 ref = cur
-            ok = torch.equal(ref.view(torch.int32), cur.view(torch.int32)) or (len(v) > 3 and v[3])
+            if direction == "wgrad":
+                ok = bool((ref - cur).abs().max() <= 1e-4 * ref.abs().max())
+            else:
+                ok = torch.equal(ref.view(torch.int32), cur.view(torch.int32)) or (len(v) > 3 and v[3])
             us.append((t, ok))
         tot += np.array([u[0] for u in us]) * mult
         cred, cres = (cin, cout) if direction == "fwd" else (cout, cin)
         print("%-5s %7d %7d %2d %4d %4d %8d | " % (direction, n_res, n_src, K, cred, cres, pairs) +
               " ".join("%9.1f%s" % (t, "   " if ok else " !!") for t, ok in us) + "  x%d" % mult)
-tune((0, 0, 0, 0, 0))
+tune(())
 print("sum over the step's layers (us): " + " ".join("%12.0f" % t for t in tot))
