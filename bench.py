@@ -30,11 +30,11 @@ FP32_MFMA_PEAK_TF = 157.3   # same guide: fp32-input MFMA peak
 
 
 def pmc_traffic_per_launch():
-    """HBM bytes per conv_apply launch from the committed PMC passes (profiles/r01e_pmc_conv.json: rocprofv3 --pmc FETCH_SIZE and
+    """HBM bytes per conv_apply launch from the committed PMC passes (profiles/r01i_pmc_conv.json: rocprofv3 --pmc FETCH_SIZE and
     --pmc WRITE_SIZE in separate runs, FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md); PMC counters cannot be read
     inside the timed process, so this is null when the file is absent"""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01e_pmc_conv.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r01i_pmc_conv.json")) as f:
             return json.load(f)["conv_apply"]["hbm_bytes_per_launch"]
     except (OSError, KeyError, ValueError):
         return None
