@@ -77,6 +77,9 @@ _SIGS = {
     "btc_conv_dgrad": (ci, [vp, vp, vp, ci, ci, ci, ci, vp, vp]),
     "btc_conv_wgrad_ws_bytes": (sz, [ci, ci, ci, ci, ci]),
     "btc_conv_wgrad": (ci, [vp, vp, vp, ci, vp, ci, ci, ci, ci, vp, vp, sz, vp]),
+    "btc_conv_fwd_bf16": (ci, [vp, vp, vp, vp, ci, ci, ci, ci, vp, vp]),
+    "btc_conv_dgrad_bf16": (ci, [vp, vp, vp, ci, ci, ci, ci, vp, vp]),
+    "btc_conv_wgrad_bf16": (ci, [vp, vp, vp, ci, vp, ci, ci, ci, ci, vp, vp, sz, vp]),
     "btc_maxpool_fwd": (ci, [vp, vp, ci, ci, ci, vp, vp]),
     "btc_maxpool_bwd": (ci, [vp, vp, vp, vp, ci, ci, ci, vp, vp]),
     "btc_dense_fwd": (ci, [vp, vp, ci, ci, c_i32p, vp, vp]),
@@ -94,6 +97,8 @@ _SIGS = {
     "btc_bn_ws_bytes": (sz, [ci]),
     "btc_bn_relu_fwd": (ci, [vp, ci, ci, vp, vp, vp, vp, vp, ctypes.c_float, ctypes.c_float, ci, ci, vp, vp, vp, vp, sz, vp]),
     "btc_bn_relu_bwd": (ci, [vp, vp, vp, ci, ci, vp, vp, vp, ci, ci, vp, vp, vp, vp, sz, vp]),
+    "btc_bn_relu_fwd_bf16": (ci, [vp, ci, ci, vp, vp, vp, vp, vp, ctypes.c_float, ctypes.c_float, ci, ci, vp, vp, vp, vp, sz, vp]),
+    "btc_bn_relu_bwd_bf16": (ci, [vp, vp, vp, ci, ci, vp, vp, vp, ci, ci, vp, vp, vp, vp, sz, vp]),
     "btc_occ_targets_ws_bytes": (sz, [ctypes.POINTER(BtcOccConfig)]),
     "btc_occ_targets": (ci, [ctypes.POINTER(BtcOccConfig), vp, vp, vp, ci, ci, ci, vp, vp, vp, vp, ci, vp, vp,
                              ctypes.POINTER(BtcOccBuffers), vp, sz, vp]),

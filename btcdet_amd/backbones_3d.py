@@ -46,6 +46,17 @@ def post_act_block(in_channels, out_channels, kernel_size, indice_key=None, stri
     return spconv.SparseSequential(conv)
 
 
+def _feature_dtype(model_cfg):
+    """FEATURE_DTYPE: bf16 -> the sparse tensors between layers are bfloat16 (BASELINE.json configs[2] "bf16 features");
+    weights, accumulation, BatchNorm statistics and every dense map stay fp32.  Not a key of the reference's yaml."""
+    v = str(model_cfg.get("FEATURE_DTYPE", "fp32")).lower()
+    if v in ("bf16", "bfloat16"):
+        return torch.bfloat16
+    if v in ("fp32", "float32"):
+        return None
+    raise ValueError("FEATURE_DTYPE must be fp32 or bf16, got %r" % v)
+
+
 class fixSparseConv3d(spconv.SparseConv3d):
     """constant-weight sparse conv (spconv_backbone.py:45-48)"""
 
@@ -68,6 +79,7 @@ class VoxelBackBoneDeconv(nn.Module):
         super().__init__()
         self.model_cfg = model_cfg
         self.y_shift = model_cfg.get("SHIFT", 0)
+        self.feature_dtype = _feature_dtype(model_cfg)
         norm_fn = partial(nn.BatchNorm1d, eps=1e-3, momentum=0.01)
         self.sparse_shape = grid_size[::-1]  # numpy view of the dataset's grid, as in the reference (App. D.10)
         self.sparse_shape[1] += self.y_shift * 2
@@ -86,6 +98,8 @@ class VoxelBackBoneDeconv(nn.Module):
 
     def forward(self, batch_dict):
         voxel_features, voxel_coords = batch_dict['voxel_features'], batch_dict['voxel_coords'].int()
+        if self.feature_dtype is not None:
+            voxel_features = voxel_features.to(self.feature_dtype)
         if self.y_shift > 0:
             voxel_features, voxel_coords = self.add_shift(voxel_features, voxel_coords)
         x = spconv.SparseConvTensor(features=voxel_features, indices=voxel_coords, spatial_shape=self.sparse_shape,
@@ -156,6 +170,7 @@ class VoxelBackBone8xOcc(nn.Module):
                     _seq([(c[lvl] + add[lvl], c[lvl], 3, dict(padding=1, indice_key=key)),
                           (c[lvl], c[lvl], 3, dict(padding=1, indice_key=key))], norm_fn))
         last_pad = self.model_cfg.get('last_pad', 0)
+        self.feature_dtype = _feature_dtype(model_cfg)
         self.conv_out = spconv.SparseSequential(
             spconv.SparseConv3d(c[3], c[4], (3, 1, 1), stride=(2, 1, 1), padding=last_pad, bias=False,
                                 indice_key='spconv_down2'), norm_fn(c[4]), nn.ReLU())
@@ -204,7 +219,7 @@ class VoxelBackBone8xOcc(nn.Module):
     def sparse_cat(input_lst):
         # rows of both tensors are aligned because both rulebooks emit outputs in (b,z,y,x) order
         xrep, xocc = input_lst
-        xrep.features = torch.cat((xrep.features, xocc.features), dim=1)
+        xrep.features = torch.cat((xrep.features, xocc.features.to(xrep.features.dtype)), dim=1)
         return xrep
 
     @staticmethod
@@ -239,11 +254,13 @@ class VoxelBackBone8xOcc(nn.Module):
         if out_feat_type == "big_bev_combine":
             bev2d = self.compress_height(self.squeezeBev(bev))
             inds = x4.indices.long()
-            x4.features = torch.cat((x4.features, bev2d[inds[..., 0], :, inds[..., 2], inds[..., 3]]), dim=1)
+            x4.features = torch.cat((x4.features, bev2d[inds[..., 0], :, inds[..., 2], inds[..., 3]].to(x4.features.dtype)), dim=1)
         return self.down_combine(x4)
 
     def forward(self, batch_dict):
         feats, coords = batch_dict['voxel_features'], batch_dict['voxel_coords'].int()
+        if self.feature_dtype is not None:
+            feats = feats.to(self.feature_dtype)
         bs = batch_dict['batch_size']
         x = spconv.SparseConvTensor(features=feats, indices=coords, spatial_shape=self.sparse_shape, batch_size=bs)
         n_occ = len(self.occ_conv_exec)

@@ -38,6 +38,7 @@ __device__ __forceinline__ bool last_block(int32_t* counter) {
 }
 
 // partial[blk][0][c] = sum_x, partial[blk][1][c] = sum_x^2 over the block's rows
+template <bool BF>
 __global__ __launch_bounds__(BN_T) void bn_stats(const float* __restrict__ x, BnShape S, double* __restrict__ partial,
                                                  int32_t* __restrict__ counter, float momentum, float eps, int training,
                                                  const float* __restrict__ running_mean_in, float* __restrict__ running_mean,
@@ -52,12 +53,13 @@ __global__ __launch_bounds__(BN_T) void bn_stats(const float* __restrict__ x, Bn
       const long long stride = (long long)gridDim.x * S.rpi;
       long long r = (long long)blockIdx.x * S.rpi + rr;
       for (; r + 3 * stride < S.N; r += 4 * stride) {  // 4 independent loads in flight
-        float v0 = x[r * S.C + c], v1 = x[(r + stride) * S.C + c], v2 = x[(r + 2 * stride) * S.C + c], v3 = x[(r + 3 * stride) * S.C + c];
+        float v0 = btc_ld1<BF>(x, r * S.C + c), v1 = btc_ld1<BF>(x, (r + stride) * S.C + c), v2 = btc_ld1<BF>(x, (r + 2 * stride) * S.C + c),
+              v3 = btc_ld1<BF>(x, (r + 3 * stride) * S.C + c);
         a += (double)v0 + (double)v1 + (double)v2 + (double)v3;
         b += (double)v0 * v0 + (double)v1 * v1 + (double)v2 * v2 + (double)v3 * v3;
       }
       for (; r < S.N; r += stride) {
-        float v = x[r * S.C + c];
+        float v = btc_ld1<BF>(x, r * S.C + c);
         a += v;
         b += (double)v * v;
       }
@@ -131,7 +133,7 @@ __global__ __launch_bounds__(BN_T) void bn_eval_stats(const float* __restrict__ 
   rstd_out[c] = 1.0f / sqrtf(running_var[c] + eps);
 }
 
-template <bool VEC>
+template <bool VEC, bool BF>
 __global__ __launch_bounds__(BN_T) void bn_apply(const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
                                                  const float* __restrict__ gamma, const float* __restrict__ beta, long long total, int C,
                                                  int relu, float* __restrict__ y) {
@@ -139,7 +141,7 @@ __global__ __launch_bounds__(BN_T) void bn_apply(const float* __restrict__ x, co
   if (i >= total) return;
   if (VEC) {
     int c = (int)(i % C);
-    float4 v = *reinterpret_cast<const float4*>(x + i);
+    float4 v = btc_ld4<BF>(x, i);
     float o[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -147,16 +149,17 @@ __global__ __launch_bounds__(BN_T) void bn_apply(const float* __restrict__ x, co
       float t = (o[j] - mean[c + j]) * rstd[c + j] * g + b;
       o[j] = relu ? fmaxf(t, 0.f) : t;
     }
-    *reinterpret_cast<float4*>(y + i) = make_float4(o[0], o[1], o[2], o[3]);
+    btc_st4<BF>(y, i, o[0], o[1], o[2], o[3]);
   } else {
     int c = (int)(i % C);
     float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
-    float t = (x[i] - mean[c]) * rstd[c] * g + b;
-    y[i] = relu ? fmaxf(t, 0.f) : t;
+    float t = (btc_ld1<BF>(x, i) - mean[c]) * rstd[c] * g + b;
+    btc_st1<BF>(y, i, relu ? fmaxf(t, 0.f) : t);
   }
 }
 
 // partial sums of g = dy * (y > 0) and g * xhat; the last block turns them into dbeta / dgamma
+template <bool BF>
 __global__ __launch_bounds__(BN_T) void bn_bwd_stats(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ dy,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd, BnShape S, int relu,
                                                      double* __restrict__ partial, int32_t* __restrict__ counter,
@@ -172,17 +175,18 @@ __global__ __launch_bounds__(BN_T) void bn_bwd_stats(const float* __restrict__ x
       long long r = (long long)blockIdx.x * S.rpi + rr;
       for (; r + stride < S.N; r += 2 * stride) {  // 6 independent loads in flight
         const long long i0 = r * S.C + c, i1 = (r + stride) * S.C + c;
-        float g0 = dy[i0], g1 = dy[i1], y0 = y[i0], y1 = y[i1], x0 = x[i0], x1 = x[i1];
+        float g0 = btc_ld1<BF>(dy, i0), g1 = btc_ld1<BF>(dy, i1), y0 = btc_ld1<BF>(y, i0), y1 = btc_ld1<BF>(y, i1), x0 = btc_ld1<BF>(x, i0),
+              x1 = btc_ld1<BF>(x, i1);
         if (relu && !(y0 > 0.f)) g0 = 0.f;
         if (relu && !(y1 > 0.f)) g1 = 0.f;
         a += (double)g0 + (double)g1;
         b += (double)g0 * ((x0 - m) * rs) + (double)g1 * ((x1 - m) * rs);
       }
       for (; r < S.N; r += stride) {
-        float g = dy[r * S.C + c];
-        if (relu && !(y[r * S.C + c] > 0.f)) g = 0.f;
+        float g = btc_ld1<BF>(dy, r * S.C + c);
+        if (relu && !(btc_ld1<BF>(y, r * S.C + c) > 0.f)) g = 0.f;
         a += g;
-        b += (double)g * ((x[r * S.C + c] - m) * rs);
+        b += (double)g * ((btc_ld1<BF>(x, r * S.C + c) - m) * rs);
       }
     }
     s_a[tid] = a;
@@ -234,7 +238,7 @@ __global__ __launch_bounds__(BN_T) void bn_bwd_stats(const float* __restrict__ x
   if (tid == 0) __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-template <bool VEC>
+template <bool VEC, bool BF>
 __global__ __launch_bounds__(BN_T) void bn_bwd_apply(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ dy,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ gamma, const float* __restrict__ dgamma,
@@ -246,12 +250,12 @@ __global__ __launch_bounds__(BN_T) void bn_bwd_apply(const float* __restrict__ x
   constexpr int W = VEC ? 4 : 1;
   float xv[W], yv[W], gv[W];
   if (VEC) {
-    float4 a = *reinterpret_cast<const float4*>(x + i), b = *reinterpret_cast<const float4*>(y + i), c4 = *reinterpret_cast<const float4*>(dy + i);
+    float4 a = btc_ld4<BF>(x, i), b = btc_ld4<BF>(y, i), c4 = btc_ld4<BF>(dy, i);
     xv[0] = a.x; xv[W > 1 ? 1 : 0] = a.y; xv[W > 2 ? 2 : 0] = a.z; xv[W > 3 ? 3 : 0] = a.w;
     yv[0] = b.x; yv[W > 1 ? 1 : 0] = b.y; yv[W > 2 ? 2 : 0] = b.z; yv[W > 3 ? 3 : 0] = b.w;
     gv[0] = c4.x; gv[W > 1 ? 1 : 0] = c4.y; gv[W > 2 ? 2 : 0] = c4.z; gv[W > 3 ? 3 : 0] = c4.w;
   } else {
-    xv[0] = x[i]; yv[0] = y[i]; gv[0] = dy[i];
+    xv[0] = btc_ld1<BF>(x, i); yv[0] = btc_ld1<BF>(y, i); gv[0] = btc_ld1<BF>(dy, i);
   }
   const int c = (int)(i % C);
   float o[W];
@@ -267,8 +271,8 @@ __global__ __launch_bounds__(BN_T) void bn_bwd_apply(const float* __restrict__ x
       o[j] = gm * rs * g;
     }
   }
-  if (VEC) *reinterpret_cast<float4*>(dx + i) = make_float4(o[0], o[W > 1 ? 1 : 0], o[W > 2 ? 2 : 0], o[W > 3 ? 3 : 0]);
-  else dx[i] = o[0];
+  if (VEC) btc_st4<BF>(dx, i, o[0], o[W > 1 ? 1 : 0], o[W > 2 ? 2 : 0], o[W > 3 ? 3 : 0]);
+  else btc_st1<BF>(dx, i, o[0]);
 }
 
 BnShape bn_shape(int N, int C) {
@@ -293,7 +297,8 @@ int bn_grid(int N, const BnShape& S) {
 
 extern "C" size_t btc_bn_ws_bytes(int C) { return 256 + btc_align((size_t)512 * 2 * C * sizeof(double)); }
 
-extern "C" int btc_bn_relu_fwd(const float* x, int N, int C, const float* gamma, const float* beta, float* running_mean,
+template <bool BF>
+static int bn_fwd_impl(const float* x, int N, int C, const float* gamma, const float* beta, float* running_mean,
                                float* running_var, long long* num_batches_tracked, float momentum, float eps, int training, int relu,
                                float* y, float* save_mean, float* save_rstd, void* ws, size_t ws_bytes, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
@@ -304,20 +309,21 @@ extern "C" int btc_bn_relu_fwd(const float* x, int N, int C, const float* gamma,
   double* partial = (double*)((char*)ws + 256);
   BnShape S = bn_shape(N, C);
   if (training) {
-    bn_stats<<<bn_grid(N, S), BN_T, 0, stream>>>(x, S, partial, counter, momentum, eps, training, running_mean, running_mean, running_var,
+    bn_stats<BF><<<bn_grid(N, S), BN_T, 0, stream>>>(x, S, partial, counter, momentum, eps, training, running_mean, running_mean, running_var,
                                                 num_batches_tracked, save_mean, save_rstd);
   } else {
     bn_eval_stats<<<btc_cdiv(C, BN_T), BN_T, 0, stream>>>(running_mean, running_var, C, eps, save_mean, save_rstd);
   }
   BTC_LAUNCH_CHECK();
   long long total = (long long)N * C;
-  if ((C & 3) == 0) bn_apply<true><<<btc_cdiv(total / 4, BN_T), BN_T, 0, stream>>>(x, save_mean, save_rstd, gamma, beta, total, C, relu, y);
-  else bn_apply<false><<<btc_cdiv(total, BN_T), BN_T, 0, stream>>>(x, save_mean, save_rstd, gamma, beta, total, C, relu, y);
+  if ((C & 3) == 0) bn_apply<true, BF><<<btc_cdiv(total / 4, BN_T), BN_T, 0, stream>>>(x, save_mean, save_rstd, gamma, beta, total, C, relu, y);
+  else bn_apply<false, BF><<<btc_cdiv(total, BN_T), BN_T, 0, stream>>>(x, save_mean, save_rstd, gamma, beta, total, C, relu, y);
   BTC_LAUNCH_CHECK();
   return BTC_OK;
 }
 
-extern "C" int btc_bn_relu_bwd(const float* x, const float* y, const float* dy, int N, int C, const float* gamma, const float* save_mean,
+template <bool BF>
+static int bn_bwd_impl(const float* x, const float* y, const float* dy, int N, int C, const float* gamma, const float* save_mean,
                                const float* save_rstd, int training, int relu, float* dx, float* dgamma, float* dbeta, void* ws,
                                size_t ws_bytes, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
@@ -326,15 +332,43 @@ extern "C" int btc_bn_relu_bwd(const float* x, const float* y, const float* dy, 
   int32_t* counter = (int32_t*)ws;
   double* partial = (double*)((char*)ws + 256);
   BnShape S = bn_shape(N, C);
-  bn_bwd_stats<<<bn_grid(N, S), BN_T, 0, stream>>>(x, y, dy, save_mean, save_rstd, S, relu, partial, counter, dgamma, dbeta);
+  bn_bwd_stats<BF><<<bn_grid(N, S), BN_T, 0, stream>>>(x, y, dy, save_mean, save_rstd, S, relu, partial, counter, dgamma, dbeta);
   BTC_LAUNCH_CHECK();
   long long total = (long long)N * C;
   if ((C & 3) == 0)
-    bn_bwd_apply<true><<<btc_cdiv(total / 4, BN_T), BN_T, 0, stream>>>(x, y, dy, save_mean, save_rstd, gamma, dgamma, dbeta, total, C, N, relu,
+    bn_bwd_apply<true, BF><<<btc_cdiv(total / 4, BN_T), BN_T, 0, stream>>>(x, y, dy, save_mean, save_rstd, gamma, dgamma, dbeta, total, C, N, relu,
                                                                       training, dx);
   else
-    bn_bwd_apply<false><<<btc_cdiv(total, BN_T), BN_T, 0, stream>>>(x, y, dy, save_mean, save_rstd, gamma, dgamma, dbeta, total, C, N, relu,
+    bn_bwd_apply<false, BF><<<btc_cdiv(total, BN_T), BN_T, 0, stream>>>(x, y, dy, save_mean, save_rstd, gamma, dgamma, dbeta, total, C, N, relu,
                                                                    training, dx);
   BTC_LAUNCH_CHECK();
   return BTC_OK;
+}
+
+extern "C" int btc_bn_relu_fwd(const float* x, int N, int C, const float* gamma, const float* beta, float* running_mean,
+                               float* running_var, long long* num_batches_tracked, float momentum, float eps, int training, int relu,
+                               float* y, float* save_mean, float* save_rstd, void* ws, size_t ws_bytes, void* stream) {
+  return bn_fwd_impl<false>(x, N, C, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, training, relu, y, save_mean,
+                            save_rstd, ws, ws_bytes, stream);
+}
+
+extern "C" int btc_bn_relu_bwd(const float* x, const float* y, const float* dy, int N, int C, const float* gamma, const float* save_mean,
+                               const float* save_rstd, int training, int relu, float* dx, float* dgamma, float* dbeta, void* ws,
+                               size_t ws_bytes, void* stream) {
+  return bn_bwd_impl<false>(x, y, dy, N, C, gamma, save_mean, save_rstd, training, relu, dx, dgamma, dbeta, ws, ws_bytes, stream);
+}
+
+// bfloat16 activations (x, y, dy, dx); parameters, statistics and their gradients stay fp32
+extern "C" int btc_bn_relu_fwd_bf16(const void* x, int N, int C, const float* gamma, const float* beta, float* running_mean,
+                                    float* running_var, long long* num_batches_tracked, float momentum, float eps, int training, int relu,
+                                    void* y, float* save_mean, float* save_rstd, void* ws, size_t ws_bytes, void* stream) {
+  return bn_fwd_impl<true>((const float*)x, N, C, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, training, relu,
+                           (float*)y, save_mean, save_rstd, ws, ws_bytes, stream);
+}
+
+extern "C" int btc_bn_relu_bwd_bf16(const void* x, const void* y, const void* dy, int N, int C, const float* gamma, const float* save_mean,
+                                    const float* save_rstd, int training, int relu, void* dx, float* dgamma, float* dbeta, void* ws,
+                                    size_t ws_bytes, void* stream) {
+  return bn_bwd_impl<true>((const float*)x, (const float*)y, (const float*)dy, N, C, gamma, save_mean, save_rstd, training, relu, (float*)dx,
+                           dgamma, dbeta, ws, ws_bytes, stream);
 }

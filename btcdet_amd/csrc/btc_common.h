@@ -43,9 +43,55 @@ int btc_tune_get(int key);
 
 // conv_apply_glds.hip: LDS-DMA pipelined sparse-conv apply (same results as conv_apply)
 bool btc_apply_glds_supported(int K, int Cred, int Cres);
-bool btc_apply_glds_has_shape(int shape);
-int btc_launch_apply_glds(bool trans_w, int shape, int kc, int xcd, const float* feat, const float* W, const float* bias,
-                          const int32_t* nbr, int n_rows, int K, int Cred, int Cres, float* out, hipStream_t stream);
+bool btc_apply_glds_has_shape(int shape, bool bf = false);
+size_t btc_apply_glds_lds_bytes(int shape, int kc, int K, bool bf);
+int btc_launch_apply_glds(bool trans_w, int shape, int kc, int xcd, bool bf, const void* feat, const float* W, const float* bias,
+                          const int32_t* nbr, int n_rows, int K, int Cred, int Cres, void* out, hipStream_t stream);
+
+// bfloat16 <-> fp32 (round to nearest even; NaN stays NaN)
+__host__ __device__ __forceinline__ unsigned short btc_f32_to_bf16(float f) {
+  union { float f; unsigned u; } c;
+  c.f = f;
+  unsigned u = c.u;
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+__host__ __device__ __forceinline__ float btc_bf16_to_f32(unsigned short h) {
+  union { float f; unsigned u; } c;
+  c.u = (unsigned)h << 16;
+  return c.f;
+}
+
+// activation loads / stores: fp32, or bfloat16 widened to / rounded from fp32 (BF); `i` is an element index
+template <bool BF>
+__device__ __forceinline__ float4 btc_ld4(const float* base, size_t i) {
+  if (!BF) return *reinterpret_cast<const float4*>(base + i);
+  const uint2 v = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(base) + i);
+  return make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16),
+                     __uint_as_float(v.y & 0xffff0000u));
+}
+template <bool BF>
+__device__ __forceinline__ float btc_ld1(const float* base, size_t i) {
+  if (!BF) return base[i];
+  return __uint_as_float((unsigned)reinterpret_cast<const unsigned short*>(base)[i] << 16);
+}
+template <bool BF>
+__device__ __forceinline__ void btc_st4(float* base, size_t i, float a, float b, float c, float d) {
+  if (!BF) {
+    *reinterpret_cast<float4*>(base + i) = make_float4(a, b, c, d);
+  } else {
+    uint2 v;
+    v.x = (unsigned)btc_f32_to_bf16(a) | ((unsigned)btc_f32_to_bf16(b) << 16);
+    v.y = (unsigned)btc_f32_to_bf16(c) | ((unsigned)btc_f32_to_bf16(d) << 16);
+    *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(base) + i) = v;
+  }
+}
+template <bool BF>
+__device__ __forceinline__ void btc_st1(float* base, size_t i, float a) {
+  if (!BF) base[i] = a;
+  else reinterpret_cast<unsigned short*>(base)[i] = btc_f32_to_bf16(a);
+}
 
 static inline int btc_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 static inline size_t btc_align(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }

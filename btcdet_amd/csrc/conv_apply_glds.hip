@@ -36,25 +36,34 @@ __device__ __forceinline__ void wait_vm() {
 // (TN = 16 NTW WC result channels).  KC: reduction channels per pipeline item (16, 32 or 64).
 // Small layers get small TM (more workgroups than CUs), wide layers split the columns over waves (more waves per SIMD
 // to cover each other's LDS round trips); the price of a smaller TM is that every workgroup streams all K weight panels.
-template <int WR, int WC, int NTW, bool TRANS_W, int KC>
-__global__ __launch_bounds__(64 * WR * WC) void conv_apply_g(const float* __restrict__ feat, const float* __restrict__ W,
+// BF: activations (the gathered operand and the result) are bfloat16 in HBM / LDS -- "bf16 features" of BASELINE.json
+// configs[2]; weights, bias and the accumulation stay fp32, so a result is the bf16 rounding (RNE) of exactly the fp32
+// fmaf chain the fp32 kernel computes on the same (bf16-representable) inputs.
+template <int WR, int WC, int NTW, bool TRANS_W, int KC, bool BF>
+__global__ __launch_bounds__(64 * WR * WC) void conv_apply_g(const void* __restrict__ feat_, const float* __restrict__ W,
                                                              const float* __restrict__ bias, const int32_t* __restrict__ nbr,
-                                                             int n_rows, int K, int Cred, int Cres, float* __restrict__ out,
+                                                             int n_rows, int K, int Cred, int Cres, void* __restrict__ out_,
                                                              int xcd_swizzle, int dbg) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NW = WR * WC, THREADS = 64 * NW;
   constexpr int TM = 16 * WR, TN = 16 * NTW * WC, NG = NTW * WC;  // NG: 16-column groups of the B image
-  constexpr int UPR = KC / 4;                      // 16-byte units per A row / per B^T column
-  constexpr int NAI_TOTAL = WR * KC / 16;          // A DMA instructions per item (64 units each), whole workgroup
+  constexpr int ES = BF ? 2 : 4;                   // bytes per activation element
+  constexpr int UPR = KC * ES / 16;                // 16-byte units per A row
+  constexpr int UPB = KC / 4;                      // 16-byte units per B^T column (weights are fp32)
+  constexpr int RPB = (128 / (KC * ES)) < 1 ? 1 : (128 / (KC * ES));  // A rows per 128-byte bank row
+  constexpr int A_UNITS = TM * UPR;
+  constexpr int NAI_TOTAL = (A_UNITS + 63) / 64;   // A DMA instructions per item (64 units each), whole workgroup
   constexpr int NAI = (NAI_TOTAL + NW - 1) / NW;   // ... per wave (duplicates when not divisible: same data, same place)
   constexpr int NBI_TOTAL = KC * TN / 256;         // B DMA instructions per item, whole workgroup
   constexpr int NBI = (NBI_TOTAL + NW - 1) / NW;
   constexpr int NPI = NAI + NBI;                   // DMA instructions per wave and item
-  constexpr int STAGE = TM * KC + KC * TN;         // floats
-  float* ring = (float*)smem;                      // [G_STAGES][ A: TM x KC | B: KC x TN ]
+  constexpr int A_BYTES = (TM * KC * ES + 1023) / 1024 * 1024;
+  constexpr int STAGE = A_BYTES + KC * TN * 4;     // bytes
+  char* ring = smem;                               // [G_STAGES][ A: TM x KC activations | B: KC x TN fp32 ]
   int32_t* s_nbr = (int32_t*)(ring + G_STAGES * STAGE);  // [TM][K]
   int32_t* s_kact = s_nbr + TM * K;                // [K] flags, then the compact list of active offsets
   int32_t* s_nact = s_kact + K;                    // [1]
+  const char* feat = (const char*)feat_;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave / WC, wc = wave % WC;
@@ -105,16 +114,19 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_apply_g(const float* __rest
   auto issue = [&](int item, int st) {
     const int k = s_kact[item / n_chunks];
     const int cc = (item % n_chunks) * KC;
-    float* As = ring + st * STAGE;
-    float* Bs = As + TM * KC;
+    char* As = ring + st * STAGE;
+    float* Bs = (float*)(As + A_BYTES);
 #pragma unroll
     for (int t = 0; t < NAI; ++t) {
-      const int ai = (wave + NW * t) % NAI_TOTAL;  // instruction ai covers 64 / UPR rows of the A image
-      const int rloc = ai * (64 / UPR) + lane / UPR;
-      const int u = (lane % UPR) ^ (rloc & (UPR - 1));
-      const int nb = s_nbr[rloc * K + k];
-      const float* src = nb >= 0 ? feat + (size_t)nb * Cred + cc + u * 4 : g_zero_row;
-      glds16(src, As + ai * 256);
+      const int ai = (wave + NW * t) % NAI_TOTAL;  // instruction ai covers units [64 ai, 64 ai + 64) of the A image
+      const int U = ai * 64 + lane;
+      if (A_UNITS % 64 == 0 || U < A_UNITS) {      // a partial last instruction is exec-masked (inactive lanes write nothing)
+        const int rloc = U / UPR;
+        const int u = (U % UPR) ^ ((rloc / RPB) & (UPR - 1));
+        const int nb = s_nbr[rloc * K + k];
+        const char* src = nb >= 0 ? feat + ((size_t)nb * Cred + cc) * ES + u * 16 : (const char*)g_zero_row;
+        glds16((const float*)src, (float*)(As + ai * 1024));
+      }
     }
     const float* Wk = W + (size_t)k * Cred * Cres;
 #pragma unroll
@@ -127,8 +139,8 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_apply_g(const float* __rest
         const int g = (NG >= 2) ? ((pu >> 2) ^ (kr & 1)) : (pu >> 2);
         src = Wk + (size_t)(cc + kr) * Cres + n0 + g * 16 + (pu & 3) * 4;
       } else {  // B^T[c][r] = W[k][ci = n0 + c][co = cc + r]: contiguous along r
-        const int c = U / UPR, pu = U % UPR;
-        const int ru = pu ^ (c & (UPR - 1));
+        const int c = U / UPB, pu = U % UPB;
+        const int ru = pu ^ (c & (UPB - 1));
         src = Wk + (size_t)(n0 + c) * Cred + cc + ru * 4;
       }
       glds16(src, Bs + ii * 256);
@@ -150,8 +162,9 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_apply_g(const float* __rest
       // fragment reads are software-pipelined by hand in groups of G reduction steps: the reads of group g + 1 are issued
       // before the MFMAs of group g and pinned there (sched_barrier) -- left alone, hipcc sinks every ds_read next to its
       // MFMA and drains lgkmcnt(0) there, one exposed LDS round trip per step
-      const float* A = ring + st * STAGE + (wr * 16 + arow) * KC + kq;
-      const float* B = ring + st * STAGE + TM * KC;
+      const char* A = ring + st * STAGE + (wr * 16 + arow) * (KC * ES);
+      const float* B = (const float*)(ring + st * STAGE + A_BYTES);
+      const int aswz = ((wr * 16 + arow) / RPB) & (UPR - 1);
       constexpr int Q = KC / 4;
       constexpr int G = (16 / NTW) < 1 ? 1 : ((16 / NTW) > Q ? Q : (16 / NTW));
       constexpr int NGRP = Q / G;
@@ -160,7 +173,12 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_apply_g(const float* __rest
 #pragma unroll
         for (int i = 0; i < G; ++i) {
           const int q = g * G + i;
-          a[buf][i] = A[(q ^ (arow & (UPR - 1))) * 4];
+          if (!BF) {  // channel q*4 + kq: unit q, element kq
+            a[buf][i] = *(const float*)(A + ((q ^ aswz) * 16) + kq * 4);
+          } else {    // unit q/2, element (q&1)*4 + kq; bf16 -> fp32 is a 16-bit shift
+            const unsigned short h = *(const unsigned short*)(A + (((q >> 1) ^ aswz) * 16) + (((q & 1) * 4 + kq) * 2));
+            a[buf][i] = __uint_as_float((unsigned)h << 16);
+          }
           if (!TRANS_W) {
             const float* bp = B + (q * 4 + kq) * TN + arow;
 #pragma unroll
@@ -169,7 +187,7 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_apply_g(const float* __rest
               b[buf][i][nt] = bp[((NG >= 2) ? (cg ^ (kq & 1)) : cg) * 16];
             }
           } else {
-            const float* bp = B + (wc * NTW * 16 + arow) * KC + (q ^ (arow & (UPR - 1))) * 4 + kq;
+            const float* bp = B + (wc * NTW * 16 + arow) * KC + (q ^ (arow & (UPB - 1))) * 4 + kq;
 #pragma unroll
             for (int nt = 0; nt < NTW; ++nt) b[buf][i][nt] = bp[nt * 16 * KC];
           }
@@ -199,79 +217,104 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_apply_g(const float* __rest
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       int row = row0 + wr * 16 + kq * 4 + r;
-      if (row < n_rows) out[(size_t)row * Cres + col] = bias ? (acc[nt][r] + bv0) : acc[nt][r];
+      if (row < n_rows) {
+        const float v = bias ? (acc[nt][r] + bv0) : acc[nt][r];
+        if (!BF) ((float*)out_)[(size_t)row * Cres + col] = v;
+        else ((unsigned short*)out_)[(size_t)row * Cres + col] = btc_f32_to_bf16(v);
+      }
     }
   }
 }
 
-template <int WR, int WC, int NTW, bool TRANS_W, int KC>
-int launch_g(const float* feat, const float* W, const float* bias, const int32_t* nbr, int n_rows, int K, int Cred, int Cres, float* out,
+template <int WR, int WC, int NTW, bool TRANS_W, int KC, bool BF>
+int launch_g(const void* feat, const float* W, const float* bias, const int32_t* nbr, int n_rows, int K, int Cred, int Cres, void* out,
              int xcd, hipStream_t stream) {
   constexpr int TM = 16 * WR, TN = 16 * NTW * WC;
-  const size_t lds = (size_t)G_STAGES * (TM * KC + KC * TN) * sizeof(float) + (size_t)(TM * K + K + 1) * sizeof(int32_t);
+  const size_t lds = btc_apply_glds_lds_bytes(WR * 100 + WC * 10 + NTW, KC, K, BF);
   BTC_CHECK_ARG(lds <= 160 * 1024, "conv_apply_g: tile does not fit the LDS");
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)conv_apply_g<WR, WC, NTW, TRANS_W, KC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_apply_g<WR, WC, NTW, TRANS_W, KC, BF>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              160 * 1024);
     attr_set = true;
   }
   dim3 grid(btc_cdiv(n_rows, TM), Cres / TN);
-  conv_apply_g<WR, WC, NTW, TRANS_W, KC><<<grid, 64 * WR * WC, lds, stream>>>(feat, W, bias, nbr, n_rows, K, Cred, Cres, out, xcd,
-                                                                            btc_tune_get(BTC_TUNE_APPLY_DEBUG));
+  conv_apply_g<WR, WC, NTW, TRANS_W, KC, BF><<<grid, 64 * WR * WC, lds, stream>>>(feat, W, bias, nbr, n_rows, K, Cred, Cres, out, xcd,
+                                                                                btc_tune_get(BTC_TUNE_APPLY_DEBUG));
   BTC_LAUNCH_CHECK();
   return BTC_OK;
 }
 
 #define G_ARGS feat, W, bias, nbr, n_rows, K, Cred, Cres, out, xcd, stream
-#define G_PARAMS                                                                                                              \
-  const float *feat, const float *W, const float *bias, const int32_t *nbr, int n_rows, int K, int Cred, int Cres, float *out, int xcd, \
+#define G_PARAMS                                                                                                             \
+  const void *feat, const float *W, const float *bias, const int32_t *nbr, int n_rows, int K, int Cred, int Cres, void *out, int xcd, \
       hipStream_t stream
 
-template <int WR, int WC, int NTW, bool TRANS_W>
+template <int WR, int WC, int NTW, bool TRANS_W, bool BF>
 int launch_g_kc(int kc, G_PARAMS) {
   switch (kc) {
-    case 16: return launch_g<WR, WC, NTW, TRANS_W, 16>(G_ARGS);
-    case 32: return launch_g<WR, WC, NTW, TRANS_W, 32>(G_ARGS);
-    default: return launch_g<WR, WC, NTW, TRANS_W, 64>(G_ARGS);
+    case 16: return launch_g<WR, WC, NTW, TRANS_W, 16, BF>(G_ARGS);
+    case 32: return launch_g<WR, WC, NTW, TRANS_W, 32, BF>(G_ARGS);
+    default: return launch_g<WR, WC, NTW, TRANS_W, 64, BF>(G_ARGS);
   }
 }
 
 template <bool TRANS_W>
-int launch_g_shape(int wr, int wc, int ntw, int kc, G_PARAMS) {
+int launch_g_shape(int wr, int wc, int ntw, int kc, bool bf, G_PARAMS) {
   const int code = wr * 100 + wc * 10 + ntw;
   switch (code) {
-#define G_CASE(WR_, WC_, NTW_) \
-  case WR_ * 100 + WC_ * 10 + NTW_: return launch_g_kc<WR_, WC_, NTW_, TRANS_W>(kc, G_ARGS)
-    G_CASE(4, 1, 1); G_CASE(4, 1, 2); G_CASE(4, 1, 4); G_CASE(4, 1, 8);
-    G_CASE(4, 2, 1); G_CASE(4, 2, 2); G_CASE(4, 2, 4);
-    G_CASE(2, 2, 1); G_CASE(2, 2, 2); G_CASE(2, 2, 4);
+    // the shapes the built-in policy picks exist for both activation types, the rest (tuning runs) for fp32 only
+#define G_CASE2(WR_, WC_, NTW_)                                                      \
+  case WR_ * 100 + WC_ * 10 + NTW_:                                                  \
+    return bf ? launch_g_kc<WR_, WC_, NTW_, TRANS_W, true>(kc, G_ARGS) : launch_g_kc<WR_, WC_, NTW_, TRANS_W, false>(kc, G_ARGS)
+#define G_CASE(WR_, WC_, NTW_)      \
+  case WR_ * 100 + WC_ * 10 + NTW_: \
+    if (bf) break;                  \
+    return launch_g_kc<WR_, WC_, NTW_, TRANS_W, false>(kc, G_ARGS)
+    G_CASE2(4, 1, 1); G_CASE(4, 1, 2); G_CASE(4, 1, 4); G_CASE(4, 1, 8);
+    G_CASE(4, 2, 1); G_CASE2(4, 2, 2); G_CASE2(4, 2, 4);
+    G_CASE2(2, 2, 1); G_CASE(2, 2, 2); G_CASE(2, 2, 4);
     G_CASE(2, 4, 1); G_CASE(2, 4, 2);
-    G_CASE(1, 4, 1); G_CASE(1, 4, 2);
+    G_CASE2(1, 4, 1); G_CASE(1, 4, 2);
 #undef G_CASE
+#undef G_CASE2
     default: break;
   }
-  btc_set_error("conv_apply_g: no instance for WR=%d WC=%d NTW=%d", wr, wc, ntw);
+  btc_set_error("conv_apply_g: no instance for WR=%d WC=%d NTW=%d bf16=%d", wr, wc, ntw, (int)bf);
   return BTC_EINVAL;
 }
 
 }  // namespace
 
-bool btc_apply_glds_has_shape(int shape) {
+bool btc_apply_glds_has_shape(int shape, bool bf) {
   static const int shapes[] = {411, 412, 414, 418, 421, 422, 424, 221, 222, 224, 241, 242, 141, 142};
+  static const int shapes_bf[] = {411, 422, 424, 221, 141};
+  if (bf) {
+    for (int v : shapes_bf)
+      if (v == shape) return true;
+    return false;
+  }
   for (int v : shapes)
     if (v == shape) return true;
   return false;
 }
 
+size_t btc_apply_glds_lds_bytes(int shape, int kc, int K, bool bf) {
+  const int tm = 16 * (shape / 100), tn = 16 * ((shape / 10) % 10) * (shape % 10);
+  const size_t a_bytes = ((size_t)tm * kc * (bf ? 2 : 4) + 1023) / 1024 * 1024;
+  return (size_t)G_STAGES * (a_bytes + (size_t)kc * tn * 4) + (size_t)(tm * K + K + 1) * sizeof(int32_t);
+}
+
 bool btc_apply_glds_supported(int K, int Cred, int Cres) { return K <= 64 && Cred % 16 == 0 && Cres % 16 == 0 && Cred >= 16; }
 
-// shape = WR*100 + WC*10 + NTW (waves: WR row groups x WC column groups of NTW 16-column tiles), kc = reduction chunk
-int btc_launch_apply_glds(bool trans_w, int shape, int kc, int xcd, const float* feat, const float* W, const float* bias,
-                          const int32_t* nbr, int n_rows, int K, int Cred, int Cres, float* out, hipStream_t stream) {
+// shape = WR*100 + WC*10 + NTW (waves: WR row groups x WC column groups of NTW 16-column tiles), kc = reduction chunk,
+// bf = activations (feat, out) are bfloat16
+int btc_launch_apply_glds(bool trans_w, int shape, int kc, int xcd, bool bf, const void* feat, const float* W, const float* bias,
+                          const int32_t* nbr, int n_rows, int K, int Cred, int Cres, void* out, hipStream_t stream) {
   if (n_rows <= 0) return BTC_OK;
   const int wr = shape / 100, wc = (shape / 10) % 10, ntw = shape % 10;
   BTC_CHECK_ARG(btc_apply_glds_supported(K, Cred, Cres) && wc * ntw > 0 && Cres % (16 * wc * ntw) == 0 && Cred % kc == 0 &&
                     (kc == 16 || kc == 32 || kc == 64),
                 "conv_apply_g: unsupported K=%d Cred=%d Cres=%d shape=%d kc=%d", K, Cred, Cres, shape, kc);
-  return trans_w ? launch_g_shape<true>(wr, wc, ntw, kc, G_ARGS) : launch_g_shape<false>(wr, wc, ntw, kc, G_ARGS);
+  return trans_w ? launch_g_shape<true>(wr, wc, ntw, kc, bf, G_ARGS) : launch_g_shape<false>(wr, wc, ntw, kc, bf, G_ARGS);
 }

@@ -323,7 +323,7 @@ __global__ __launch_bounds__(WS_WAVES * 64) void conv_apply_ws(const float* __re
 // dW partial: part[s][k][ci][co] = sum over the split's rows of feat[nbr[i][k]][ci] * dout[i][co]
 // block = (k, split, tile of 64 Cin x NT*16 Cout); wave w owns dW rows [m0 + 16w, m0 + 16w + 16)
 constexpr int WG_LDA = 64 + 16;
-template <int NT>
+template <int NT, bool BF>
 __global__ __launch_bounds__(256) void conv_wgrad_partial(const float* __restrict__ feat, const float* __restrict__ dout,
                                                           const int32_t* __restrict__ nbr, int n_out, int K, int Cin,
                                                           int Cout, int tiles_per_split, int n_cblk, float* __restrict__ part) {
@@ -360,12 +360,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_partial(const float* __restric
       for (int i = 0; i < 4; ++i) {
         int e = i * 256 + tid, r = e >> 4, c = (e & 15) * 4;
         int jj = s_j[r];
-        va[i] = (jj >= 0 && m0 + c < Cin) ? *reinterpret_cast<const float4*>(feat + (size_t)jj * Cin + m0 + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        va[i] = (jj >= 0 && m0 + c < Cin) ? btc_ld4<BF>(feat, (size_t)jj * Cin + m0 + c) : make_float4(0.f, 0.f, 0.f, 0.f);
       }
 #pragma unroll
       for (int i = 0; i < NT; ++i) {
         int e = i * 256 + tid, r = e / (NT * 4), c = (e % (NT * 4)) * 4;
-        vd[i] = (s_j[r] >= 0 && n0 + c < Cout) ? *reinterpret_cast<const float4*>(dout + (size_t)(row0 + r) * Cout + n0 + c)
+        vd[i] = (s_j[r] >= 0 && n0 + c < Cout) ? btc_ld4<BF>(dout, (size_t)(row0 + r) * Cout + n0 + c)
                                                : make_float4(0.f, 0.f, 0.f, 0.f);
       }
 #pragma unroll
@@ -386,12 +386,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_partial(const float* __restric
       for (int i = 0; i < 16; ++i) {
         int e = i * 256 + tid, r = e >> 6, c = e & 63;
         int jj = s_j[r];
-        va[i] = (jj >= 0 && m0 + c < Cin) ? feat[(size_t)jj * Cin + m0 + c] : 0.f;
+        va[i] = (jj >= 0 && m0 + c < Cin) ? btc_ld1<BF>(feat, (size_t)jj * Cin + m0 + c) : 0.f;
       }
 #pragma unroll
       for (int i = 0; i < NT * 4; ++i) {
         int e = i * 256 + tid, r = e / (NT * 16), c = e % (NT * 16);
-        vd[i] = (s_j[r] >= 0 && n0 + c < Cout) ? dout[(size_t)(row0 + r) * Cout + n0 + c] : 0.f;
+        vd[i] = (s_j[r] >= 0 && n0 + c < Cout) ? btc_ld1<BF>(dout, (size_t)(row0 + r) * Cout + n0 + c) : 0.f;
       }
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
@@ -437,7 +437,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_partial(const float* __restric
 // walk and is written out once.  (The offset-major kernel below re-reads dOut K times and reads the map column-wise.)
 //   MT, NT : 16-wide tiles of Cin / Cout;  KB : offsets per LDS phase;  PH : phases per offset group
 // ------------------------------------------------------------------------------------------------------------
-template <int MT, int NT, int KB, int PH>
+template <int MT, int NT, int KB, int PH, bool BF>
 __global__ __launch_bounds__(256) void conv_wgrad_rows(const float* __restrict__ feat, const float* __restrict__ dout,
                                                        const int32_t* __restrict__ nbr, int n_out, int K, int Cin, int Cout,
                                                        float* __restrict__ part, int swap) {
@@ -480,7 +480,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_rows(const float* __restrict__
 #pragma unroll
       for (int i = 0; i < NT; ++i) {
         int e = i * 256 + tid, r = e / (NT * 4), c = (e % (NT * 4)) * 4;
-        v[i] = (row0 + r < n_out && c < Cout) ? *reinterpret_cast<const float4*>(dout + (size_t)(row0 + r) * Cout + c)
+        v[i] = (row0 + r < n_out && c < Cout) ? btc_ld4<BF>(dout, (size_t)(row0 + r) * Cout + c)
                                               : make_float4(0.f, 0.f, 0.f, 0.f);
       }
 #pragma unroll
@@ -494,7 +494,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_rows(const float* __restrict__
 #pragma unroll
       for (int i = 0; i < NT * 4; ++i) {
         int e = i * 256 + tid, r = e / (NT * 16), c = e % (NT * 16);
-        v[i] = (row0 + r < n_out && c < Cout) ? dout[(size_t)(row0 + r) * Cout + c] : 0.f;
+        v[i] = (row0 + r < n_out && c < Cout) ? btc_ld1<BF>(dout, (size_t)(row0 + r) * Cout + c) : 0.f;
       }
 #pragma unroll
       for (int i = 0; i < NT * 4; ++i) {
@@ -517,7 +517,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_rows(const float* __restrict__
         for (int i = 0; i < KB * MT; ++i) {
           int e = i * 256 + tid, c = (e % (MT * 4)) * 4, r = (e / (MT * 4)) % TM, kb = e / (MT * 4 * TM);
           int j = (k0 + kb < K) ? s_nbr[r * K + k0 + kb] : -1;
-          v[i] = (j >= 0 && c < Cin) ? *reinterpret_cast<const float4*>(feat + (size_t)j * Cin + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+          v[i] = (j >= 0 && c < Cin) ? btc_ld4<BF>(feat, (size_t)j * Cin + c) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
         for (int i = 0; i < KB * MT; ++i) {
@@ -531,7 +531,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_rows(const float* __restrict__
         for (int i = 0; i < KB * MT * 4; ++i) {
           int e = i * 256 + tid, c = e % (MT * 16), r = (e / (MT * 16)) % TM, kb = e / (MT * 16 * TM);
           int j = (k0 + kb < K) ? s_nbr[r * K + k0 + kb] : -1;
-          v[i] = (j >= 0 && c < Cin) ? feat[(size_t)j * Cin + c] : 0.f;
+          v[i] = (j >= 0 && c < Cin) ? btc_ld1<BF>(feat, (size_t)j * Cin + c) : 0.f;
         }
 #pragma unroll
         for (int i = 0; i < KB * MT * 4; ++i) {
@@ -653,8 +653,11 @@ void launch_apply_t(dim3 grid, size_t lds, hipStream_t stream, bool vec, const f
 
 template <bool TRANS_W>
 int launch_apply(const float* feat, const float* W, const float* bias, const int32_t* nbr, int n_rows, int K, int Cred,
-                 int Cres, float* out, hipStream_t stream) {
+                 int Cres, float* out, hipStream_t stream, bool bf = false) {
+  // bf: feat / out are bfloat16 (passed through the float* parameters); only the LDS-DMA kernel has that variant
   if (n_rows <= 0) return BTC_OK;
+  BTC_CHECK_ARG(!bf || btc_apply_glds_supported(K, Cred, Cres),
+                "bf16 activations need channel counts that are multiples of 16 (K=%d, %d -> %d): convert to fp32", K, Cred, Cres);
   int nt = Cres <= 16 ? 1 : (Cres <= 32 ? 2 : (Cres <= 64 ? 4 : 8));
   const int t_kernel = btc_tune_get(BTC_TUNE_APPLY_KERNEL), t_nt = btc_tune_get(BTC_TUNE_APPLY_NT),
             t_xcd = btc_tune_get(BTC_TUNE_APPLY_XCD);
@@ -662,13 +665,13 @@ int launch_apply(const float* feat, const float* W, const float* bias, const int
   // 200 K-row occupancy-branch layers where the register-staged kernel below measures 5-10 % faster.  Wave shapes from
   // tools/conv_bench.py on MI355X (us per launch, register-staged -> LDS-DMA): 14 K rows 64->64: 80 -> 53, 128->128: 225 -> 158,
   // 256->128: 456 -> 309; 3 K rows 64->64: 65 -> 40; 30 K rows 64->64: 119 -> 99.
-  if (t_kernel != 1 && btc_apply_glds_supported(K, Cred, Cres) && (t_kernel == 2 || n_rows < 100000)) {
+  if (bf || (t_kernel != 1 && btc_apply_glds_supported(K, Cred, Cres) && (t_kernel == 2 || n_rows < 100000))) {
     int shape, kc = (Cred % 64 == 0) ? 64 : ((Cred % 32 == 0) ? 32 : 16);
     if (Cres % 128 == 0) shape = 424;                       // 64 rows x 128 columns, 8 waves
     else if (Cres % 64 == 0) shape = n_rows < 8192 ? 141 : 422;  // few rows: 16-row workgroups, 4 waves across the columns
     else if (Cres % 32 == 0) shape = 221;
     else shape = 411;
-    if (t_nt > 8) {  // tuning run: BTC_TUNE_APPLY_NT carries the wave shape WR*100 + WC*10 + NTW
+    if (t_nt > 8 && !bf) {  // tuning run: BTC_TUNE_APPLY_NT carries the wave shape WR*100 + WC*10 + NTW
       int wc = (t_nt / 10) % 10, ntw = t_nt % 10;
       while (ntw > 1 && Cres % (16 * wc * ntw)) ntw >>= 1;
       while (wc > 1 && Cres % (16 * wc * ntw)) wc >>= 1;
@@ -677,9 +680,8 @@ int launch_apply(const float* feat, const float* W, const float* bias, const int
     }
     const int t_kc = btc_tune_get(BTC_TUNE_APPLY_KC);
     if (t_kc && Cred % t_kc == 0) kc = t_kc;
-    const int tm = 16 * (shape / 100), tn = 16 * ((shape / 10) % 10) * (shape % 10);
-    while (kc > 16 && (size_t)(3 * (tm * kc + kc * tn) + tm * K + K + 1) * 4 > 160 * 1024) kc >>= 1;  // 3-stage ring + map tile
-    return btc_launch_apply_glds(TRANS_W, shape, kc, t_xcd == 2, feat, W, bias, nbr, n_rows, K, Cred, Cres, out, stream);
+    while (kc > 16 && btc_apply_glds_lds_bytes(shape, kc, K, bf) > 160 * 1024) kc >>= 1;  // 3-stage ring + map tile
+    return btc_launch_apply_glds(TRANS_W, shape, kc, t_xcd == 2, bf, feat, W, bias, nbr, n_rows, K, Cred, Cres, out, stream);
   }
   // weight-stationary persistent kernel (one 16-wave workgroup per CU).  Measured on MI355X: its dword-granular register
   // gather wins 2.5x for Cred <= 8 (the dgrad of the 2/3-channel occupancy heads, the 4/6-channel input layers) and loses
@@ -801,6 +803,19 @@ extern "C" int btc_conv_fwd(const float* feat, const float* W, const float* bias
   return launch_apply<false>(feat, W, bias, nbr_out, n_out, K, Cin, Cout, out, (hipStream_t)stream);
 }
 
+extern "C" int btc_conv_fwd_bf16(const void* feat, const float* W, const float* bias, const int32_t* nbr_out, int n_out, int K,
+                                 int Cin, int Cout, void* out, void* stream) {
+  BTC_CHECK_ARG(K >= 1 && Cin >= 1 && Cout >= 1 && n_out >= 0, "btc_conv_fwd_bf16: bad sizes");
+  return launch_apply<false>((const float*)feat, W, bias, nbr_out, n_out, K, Cin, Cout, (float*)out, (hipStream_t)stream, true);
+}
+
+extern "C" int btc_conv_dgrad_bf16(const void* dout, const float* W, const int32_t* nbr_in, int n_in, int K, int Cin, int Cout,
+                                   void* din, void* stream) {
+  BTC_CHECK_ARG(K >= 1 && Cin >= 1 && Cout >= 1 && n_in >= 0, "btc_conv_dgrad_bf16: bad sizes");
+  return launch_apply<true>((const float*)dout, W, nullptr, nbr_in, n_in, K, /*Cred=*/Cout, /*Cres=*/Cin, (float*)din,
+                            (hipStream_t)stream, true);
+}
+
 extern "C" int btc_conv_dgrad(const float* dout, const float* W, const int32_t* nbr_in, int n_in, int K, int Cin, int Cout,
                               float* din, void* stream) {
   BTC_CHECK_ARG(K >= 1 && Cin >= 1 && Cout >= 1 && n_in >= 0, "btc_conv_dgrad: bad sizes");
@@ -813,8 +828,9 @@ extern "C" size_t btc_conv_wgrad_ws_bytes(int n_out, int K, int Cin, int Cout, i
   return btc_align((size_t)p.S * K * Cin * Cout * sizeof(float));
 }
 
-extern "C" int btc_conv_wgrad(const float* feat, const float* dout, const int32_t* nbr_out, int n_out, const int32_t* nbr_in,
-                              int n_in, int K, int Cin, int Cout, float* dW, void* ws, size_t ws_bytes, void* stream_) {
+template <bool BF>
+static int wgrad_impl(const float* feat, const float* dout, const int32_t* nbr_out, int n_out, const int32_t* nbr_in,
+                      int n_in, int K, int Cin, int Cout, float* dW, void* ws, size_t ws_bytes, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   BTC_CHECK_ARG(K >= 1 && Cin >= 1 && Cout >= 1 && n_out >= 0, "btc_conv_wgrad: bad sizes");
   if (!nbr_in) n_in = -1;
@@ -835,7 +851,7 @@ extern "C" int btc_conv_wgrad(const float* feat, const float* dout, const int32_
     dim3 grid(p.S, p.groups);
     size_t lds = (size_t)(p.kb * TM * ldb_of(p.mt) + TM * ldb_of(p.nt)) * sizeof(float) + (size_t)(TM * K + K) * sizeof(int32_t);
 #define BTC_WG_ROWS(MT_, NT_, KB_, PH_) \
-  conv_wgrad_rows<MT_, NT_, KB_, PH_><<<grid, 256, lds, stream>>>(g_, c_, map_, p.rows, K, Cg, Cc, part, p.swap)
+  conv_wgrad_rows<MT_, NT_, KB_, PH_, BF><<<grid, 256, lds, stream>>>(g_, c_, map_, p.rows, K, Cg, Cc, part, p.swap)
 #define BTC_WG_ROWS_PH(MT_, NT_, KB_)               \
   do {                                              \
     if (p.ph == 1) BTC_WG_ROWS(MT_, NT_, KB_, 1);   \
@@ -861,15 +877,25 @@ extern "C" int btc_conv_wgrad(const float* feat, const float* dout, const int32_
   dim3 grid(K, p.S, p.n_mblk * p.n_cblk);
   size_t lds = (size_t)(TM * WG_LDA + TM * ldb_of(p.nt)) * sizeof(float) + TM * sizeof(int32_t);
   switch (p.nt) {
-    case 1: conv_wgrad_partial<1><<<grid, 256, lds, stream>>>(feat, dout, nbr_out, n_out, K, Cin, Cout, p.tiles_per_split, p.n_cblk, part); break;
-    case 2: conv_wgrad_partial<2><<<grid, 256, lds, stream>>>(feat, dout, nbr_out, n_out, K, Cin, Cout, p.tiles_per_split, p.n_cblk, part); break;
-    case 4: conv_wgrad_partial<4><<<grid, 256, lds, stream>>>(feat, dout, nbr_out, n_out, K, Cin, Cout, p.tiles_per_split, p.n_cblk, part); break;
-    default: conv_wgrad_partial<8><<<grid, 256, lds, stream>>>(feat, dout, nbr_out, n_out, K, Cin, Cout, p.tiles_per_split, p.n_cblk, part); break;
+    case 1: conv_wgrad_partial<1, BF><<<grid, 256, lds, stream>>>(feat, dout, nbr_out, n_out, K, Cin, Cout, p.tiles_per_split, p.n_cblk, part); break;
+    case 2: conv_wgrad_partial<2, BF><<<grid, 256, lds, stream>>>(feat, dout, nbr_out, n_out, K, Cin, Cout, p.tiles_per_split, p.n_cblk, part); break;
+    case 4: conv_wgrad_partial<4, BF><<<grid, 256, lds, stream>>>(feat, dout, nbr_out, n_out, K, Cin, Cout, p.tiles_per_split, p.n_cblk, part); break;
+    default: conv_wgrad_partial<8, BF><<<grid, 256, lds, stream>>>(feat, dout, nbr_out, n_out, K, Cin, Cout, p.tiles_per_split, p.n_cblk, part); break;
   }
   BTC_LAUNCH_CHECK();
   wgrad_reduce<<<btc_cdiv(count, 256), 256, 0, stream>>>(part, p.S, count, dW);
   BTC_LAUNCH_CHECK();
   return BTC_OK;
+}
+
+extern "C" int btc_conv_wgrad(const float* feat, const float* dout, const int32_t* nbr_out, int n_out, const int32_t* nbr_in,
+                              int n_in, int K, int Cin, int Cout, float* dW, void* ws, size_t ws_bytes, void* stream) {
+  return wgrad_impl<false>(feat, dout, nbr_out, n_out, nbr_in, n_in, K, Cin, Cout, dW, ws, ws_bytes, stream);
+}
+
+extern "C" int btc_conv_wgrad_bf16(const void* feat, const void* dout, const int32_t* nbr_out, int n_out, const int32_t* nbr_in,
+                                   int n_in, int K, int Cin, int Cout, float* dW, void* ws, size_t ws_bytes, void* stream) {
+  return wgrad_impl<true>((const float*)feat, (const float*)dout, nbr_out, n_out, nbr_in, n_in, K, Cin, Cout, dW, ws, ws_bytes, stream);
 }
 
 extern "C" int btc_maxpool_fwd(const float* feat, const int32_t* nbr_out, int n_out, int K, int C, float* out, void* stream) {

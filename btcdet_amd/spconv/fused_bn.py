@@ -29,7 +29,8 @@ class BatchNormReLUFunction(torch.autograd.Function):
         rstd = torch.empty((C,), dtype=torch.float32, device=x.device)
         ws, need = _ws(x.device, C)
         use_batch = bool(training or running_mean is None)
-        check(lib().btc_bn_relu_fwd(ptr(x), N, C, ptr(weight), ptr(bias), ptr(running_mean) if training else ptr(running_mean),
+        fwd = lib().btc_bn_relu_fwd_bf16 if x.dtype == torch.bfloat16 else lib().btc_bn_relu_fwd
+        check(fwd(ptr(x), N, C, ptr(weight), ptr(bias), ptr(running_mean) if training else ptr(running_mean),
                                     ptr(running_var), ptr(num_batches_tracked) if training else None, float(momentum), float(eps),
                                     int(use_batch), int(relu), ptr(y), ptr(mean), ptr(rstd), ptr(ws), need, stream_ptr()),
               "btc_bn_relu_fwd")
@@ -41,13 +42,14 @@ class BatchNormReLUFunction(torch.autograd.Function):
     def backward(ctx, dy):
         x, y, weight, mean, rstd = ctx.saved_tensors
         use_batch, relu = ctx.flags
-        dy = dy.contiguous()
+        dy = (dy if dy.dtype == x.dtype else dy.to(x.dtype)).contiguous()
         N, C = x.shape
         dx = torch.empty_like(x)
         dgamma = torch.empty((C,), dtype=torch.float32, device=x.device)
         dbeta = torch.empty((C,), dtype=torch.float32, device=x.device)
         ws, need = _ws(x.device, C)
-        check(lib().btc_bn_relu_bwd(ptr(x), ptr(y), ptr(dy), N, C, ptr(weight), ptr(mean), ptr(rstd), int(use_batch), int(relu),
+        bwd = lib().btc_bn_relu_bwd_bf16 if x.dtype == torch.bfloat16 else lib().btc_bn_relu_bwd
+        check(bwd(ptr(x), ptr(y), ptr(dy), N, C, ptr(weight), ptr(mean), ptr(rstd), int(use_batch), int(relu),
                                     ptr(dx), ptr(dgamma), ptr(dbeta), ptr(ws), need, stream_ptr()), "btc_bn_relu_bwd")
         return dx, (dgamma if weight is not None else None), (dbeta if weight is not None else None), None, None, None, None, None, None, None
 

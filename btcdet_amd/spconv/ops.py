@@ -220,6 +220,13 @@ def _f32c(t):
     return t.contiguous()
 
 
+def _actc(t):
+    """activations: float32, or bfloat16 ("bf16 features", BASELINE.json configs[2])"""
+    if t.dtype not in (torch.float32, torch.bfloat16):
+        raise _lib.BtcHipError(f"float32 or bfloat16 features expected, got {t.dtype}")
+    return t.contiguous()
+
+
 def _conv_cost(nbr, n_res, K, cred, cres):
     """SURVEY.md §8d, sparse conv fwd (dgrad is the same launch with the channel roles swapped):
     bytes = 4 (sum_k P_k (Cin + Cout) + K Cin Cout + N_out Cout), flops = 2 sum_k P_k Cin Cout"""
@@ -238,18 +245,19 @@ class SparseConvFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, features, weight, bias, map_fwd, map_bwd):
-        features = _f32c(features)
+        features = _actc(features)
+        bf = features.dtype == torch.bfloat16
         w = _f32c(weight)
         cin, cout = w.shape[-2], w.shape[-1]
         K = map_fwd.shape[1]
         if w.numel() != K * cin * cout or features.shape[1] != cin:
             raise _lib.BtcHipError(f"weight {tuple(w.shape)} does not match K={K}, Cin={features.shape[1]}")
         n_res = map_fwd.shape[0]
-        out = torch.empty((n_res, cout), dtype=torch.float32, device=features.device)
+        out = torch.empty((n_res, cout), dtype=features.dtype, device=features.device)
         b = _f32c(bias) if bias is not None else None
+        fwd = lib().btc_conv_fwd_bf16 if bf else lib().btc_conv_fwd
         with _span("conv_apply", lambda: _conv_cost(map_fwd, n_res, K, cin, cout)):
-            check(lib().btc_conv_fwd(ptr(features), ptr(w), ptr(b), ptr(map_fwd), n_res, K, cin, cout, ptr(out),
-                                     stream_ptr()), "btc_conv_fwd")
+            check(fwd(ptr(features), ptr(w), ptr(b), ptr(map_fwd), n_res, K, cin, cout, ptr(out), stream_ptr()), "btc_conv_fwd")
         if CAPTURE is not None:
             CAPTURE.append((features, w, b, map_fwd, map_bwd))
         ctx.save_for_backward(features, w, map_fwd, map_bwd)
@@ -260,10 +268,12 @@ class SparseConvFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out):
         features, w, map_fwd, map_bwd = ctx.saved_tensors
-        grad_out = _f32c(grad_out)
+        bf = features.dtype == torch.bfloat16
+        grad_out = _actc(grad_out if grad_out.dtype == features.dtype else grad_out.to(features.dtype))
         cin, cout = w.shape[-2], w.shape[-1]
         K = map_fwd.shape[1]
         L = lib()
+        wgrad, dgrad = (L.btc_conv_wgrad_bf16, L.btc_conv_dgrad_bf16) if bf else (L.btc_conv_wgrad, L.btc_conv_dgrad)
         din = dw = db = None
         need_din, need_dw = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         # dgrad and wgrad are independent and each is latency bound on its own at BtcDet's sizes: wgrad goes to a side
@@ -278,7 +288,7 @@ class SparseConvFunction(torch.autograd.Function):
                 with torch.cuda.stream(side):
                     dw = torch.empty(ctx.wshape, dtype=torch.float32, device=grad_out.device)
                     ws = workspace(ws_bytes, grad_out.device)
-                    check(L.btc_conv_wgrad(ptr(features), ptr(grad_out), ptr(map_fwd), n_res, ptr(map_bwd), n_src, K, cin, cout,
+                    check(wgrad(ptr(features), ptr(grad_out), ptr(map_fwd), n_res, ptr(map_bwd), n_src, K, cin, cout,
                                            ptr(dw), ptr(ws), ws_bytes, stream_ptr()), "btc_conv_wgrad")
                 for t in (features, grad_out, map_fwd, map_bwd):
                     t.record_stream(side)
@@ -286,16 +296,16 @@ class SparseConvFunction(torch.autograd.Function):
                 dw = torch.empty(ctx.wshape, dtype=torch.float32, device=grad_out.device)
                 ws = workspace(ws_bytes, grad_out.device)
                 with _span("conv_wgrad", lambda: _wgrad_cost(map_fwd, n_res, K, cin, cout)):
-                    check(L.btc_conv_wgrad(ptr(features), ptr(grad_out), ptr(map_fwd), n_res, ptr(map_bwd), n_src, K, cin, cout,
+                    check(wgrad(ptr(features), ptr(grad_out), ptr(map_fwd), n_res, ptr(map_bwd), n_src, K, cin, cout,
                                            ptr(dw), ptr(ws), ws_bytes, stream_ptr()), "btc_conv_wgrad")
         if need_din:
             n_src = map_bwd.shape[0]
-            din = torch.empty((n_src, cin), dtype=torch.float32, device=grad_out.device)
+            din = torch.empty((n_src, cin), dtype=features.dtype, device=grad_out.device)
             with _span("conv_apply", lambda: _conv_cost(map_bwd, n_src, K, cout, cin)):
-                check(L.btc_conv_dgrad(ptr(grad_out), ptr(w), ptr(map_bwd), n_src, K, cin, cout, ptr(din), stream_ptr()),
+                check(dgrad(ptr(grad_out), ptr(w), ptr(map_bwd), n_src, K, cin, cout, ptr(din), stream_ptr()),
                       "btc_conv_dgrad")
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = grad_out.sum(0)
+            db = grad_out.sum(0, dtype=torch.float32)
         if side is not None:
             torch.cuda.current_stream().wait_stream(side)  # join: dW is consumed on the main stream from here on
             dw.record_stream(torch.cuda.current_stream())
@@ -356,10 +366,16 @@ class ToDenseFunction(torch.autograd.Function):
 
 
 def indice_conv(features, weight, bias, rulebook, inverse=False):
+    if features.dtype == torch.bfloat16 and (weight.shape[-2] % 16 or weight.shape[-1] % 16):
+        # bf16 activations exist in the LDS-DMA kernel only (channel counts that are multiples of 16); the few other layers
+        # (4 / 6 / 34 input channels, 2 / 3-channel heads) run in fp32 and round their result
+        return indice_conv(features.float(), weight, bias, rulebook, inverse).to(torch.bfloat16)
     if inverse:
         return SparseConvFunction.apply(features, weight, bias, rulebook.nbr_in, rulebook.nbr_out)
     return SparseConvFunction.apply(features, weight, bias, rulebook.nbr_out, rulebook.nbr_in)
 
 
 def indice_maxpool(features, rulebook):
+    if features.dtype == torch.bfloat16:  # max of bf16 values is exact in either type
+        return indice_maxpool(features.float(), rulebook).to(torch.bfloat16)
     return SparseMaxPoolFunction.apply(features, rulebook.nbr_out, rulebook.nbr_in)

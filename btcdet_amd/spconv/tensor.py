@@ -27,6 +27,9 @@ class SparseConvTensor(object):
         return self.indice_dict.get(key, None)
 
     def dense(self, channels_first=True):
+        if self.features.dtype == torch.bfloat16:  # dense maps (head logits, BEV map) are fp32; the widening is exact
+            t = SparseConvTensor(self.features.float(), self.indices, self.spatial_shape, self.batch_size)
+            return t.dense(channels_first)
         idx = self.indices
         shape = [int(v) for v in self.spatial_shape]
         if idx.shape[1] == 3:  # 2-D tensor [b,y,x]: densify as depth-1 volume then drop the axis

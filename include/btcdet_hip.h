@@ -151,6 +151,18 @@ size_t btc_conv_wgrad_ws_bytes(int n_out, int K, int Cin, int Cout, int n_in);
 int btc_conv_wgrad(const float* feat, const float* dout, const int32_t* nbr_out, int n_out, const int32_t* nbr_in,
                    int n_in, int K, int Cin, int Cout, float* dW, void* ws, size_t ws_bytes, void* stream);
 
+/* "bf16 features" (BASELINE.json configs[2] and [4]): the activations -- feat / out, dout / din -- are bfloat16 in HBM
+ * (half the gather traffic); weights, bias, accumulation and dW stay fp32.  A result is the round-to-nearest-even bf16 of
+ * exactly the fp32 fmaf chain btc_conv_fwd / btc_conv_dgrad compute on the same inputs, so parity with the oracle stays
+ * bit-exact.  Forward / dgrad need Cin and Cout to be multiples of 16 (BTC_EINVAL otherwise: convert that layer's
+ * activations to fp32 and call the fp32 entry point, as btcdet_amd/spconv/ops.py does for the 4/6/34-channel layers). */
+int btc_conv_fwd_bf16(const void* feat, const float* W, const float* bias, const int32_t* nbr_out, int n_out, int K, int Cin,
+                      int Cout, void* out, void* stream);
+int btc_conv_dgrad_bf16(const void* dout, const float* W, const int32_t* nbr_in, int n_in, int K, int Cin, int Cout,
+                        void* din, void* stream);
+int btc_conv_wgrad_bf16(const void* feat, const void* dout, const int32_t* nbr_out, int n_out, const int32_t* nbr_in,
+                        int n_in, int K, int Cin, int Cout, float* dW, void* ws, size_t ws_bytes, void* stream);
+
 /* Sparse max-pool (spconv indice_maxpool, App. B.6): out = max(0, max_k feat[nbr_out[i][k]]);
  * backward routes dout to every input equal to its output. */
 int btc_maxpool_fwd(const float* feat, const int32_t* nbr_out, int n_out, int K, int C, float* out, void* stream);
@@ -242,6 +254,13 @@ int btc_bn_relu_fwd(const float* x, int N, int C, const float* gamma, const floa
 int btc_bn_relu_bwd(const float* x, const float* y, const float* dy, int N, int C, const float* gamma,
                     const float* save_mean, const float* save_rstd, int training, int relu, float* dx, float* dgamma,
                     float* dbeta, void* ws, size_t ws_bytes, void* stream);
+/* bfloat16 activations (x, y, dy, dx); parameters, statistics (fp64 partial sums) and their gradients stay fp32 */
+int btc_bn_relu_fwd_bf16(const void* x, int N, int C, const float* gamma, const float* beta, float* running_mean,
+                         float* running_var, long long* num_batches_tracked, float momentum, float eps, int training,
+                         int relu, void* y, float* save_mean, float* save_rstd, void* ws, size_t ws_bytes, void* stream);
+int btc_bn_relu_bwd_bf16(const void* x, const void* y, const void* dy, int N, int C, const float* gamma,
+                         const float* save_mean, const float* save_rstd, int training, int relu, void* dx, float* dgamma,
+                         float* dbeta, void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * PassOccVox, fused.  Replaces /root/reference/btcdet/models/occ_pnt/pass_occ_vox.py:10-59 with

@@ -250,3 +250,14 @@ def revoxelize(points, coords):
     vox = np.zeros((uniq.shape[0], int(cnt.max()), points.shape[1]), np.float32)
     vox[inv[order], slot] = points[order]
     return vox, cnt.astype(np.int64), uniq.astype(np.int64)
+
+
+def bf16_round(x):
+    """float32 -> nearest bfloat16 (ties to even), returned as float32: the storage rounding of "bf16 features"
+    (BASELINE.json configs[2]); NaN stays NaN"""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    u = x.view(np.uint32).astype(np.uint64)
+    r = ((u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000).astype(np.uint32)
+    out = r.view(np.float32).copy()
+    out[np.isnan(x)] = np.nan
+    return out.reshape(x.shape)
