@@ -86,7 +86,7 @@ def make_step(model, ddp, proc, opts):
                    "bm_points": batch["bm_points"], "rot_z": batch["rot_z"], "is_train": True})
         ret, tb, _ = ddp(bd)
         # occupancy loss (real) + L2 stand-ins for the out-of-scope consumers of the detection branch
-        loss = ret["loss_occ"] + 1e-3 * ret["spatial_features"].pow(2).mean() + 1e-3 * ret["x_combine"].pow(2).mean()
+        loss = ret["loss_occ"] + 1e-3 * ret["spatial_features"].pow(2).mean() + 1e-3 * ret["x_combine"].float().pow(2).mean()
         loss.backward()
         for o in opts:
             o.step()
@@ -185,6 +185,9 @@ def main():
     ap.add_argument("--workload", choices=["kitti", "waymo"], default="kitti",
                     help="kitti: the configuration BASELINE.json's metric is quoted on (default); waymo: the Waymo-shaped synthetic "
                          "scenes of configs[4] (~166 k points/scene, 1504 x 1504 x 40 grid) -- same path, 6x the work per scene")
+    ap.add_argument("--features", choices=["fp32", "bf16"], default="fp32",
+                    help="fp32: the reference's precision (default, the headline number); bf16: BASELINE.json configs[2] -- bfloat16 "
+                         "activations between sparse layers, fp32 weights / accumulation / statistics")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -219,6 +222,9 @@ def main():
     np.random.seed(666 + rank)
     waymo = args.workload == "waymo"
     cfg = load_cfg(os.path.join(ROOT, "btcdet_amd", "cfgs", "btcdet_waymo_synth.yaml") if waymo else None)
+    if args.features == "bf16":
+        cfg.MODEL.OCC.BACKBONE_3D["FEATURE_DTYPE"] = "bf16"
+        cfg.MODEL.BACKBONE_3D["FEATURE_DTYPE"] = "bf16"
     model = BtcHotPath(cfg, device=device).to(device)
     model.train()
     ddp = model
@@ -281,7 +287,8 @@ def main():
         result = {
             "metric": "scenes/s fwd+bwd %s bs=2/GPU (BtcDet hot path)" % ("Waymo-shaped synthetic" if waymo else "KITTI-Car"), "value": round(scenes / dt, 3), "unit": "scenes/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if args.features == "fp32" else "bf16 activations, f32 weights + accumulate", "data": "synthetic",
             "config": {"workload": ("btcdet_waymo_synth (configs[4] shape) hot path, bs=2/GPU, ~166k pts/scene: HIP voxelize" if waymo else
                                     "btcdet_kitti_car hot path, bs=2/GPU, ~28.6k pts/scene: HIP voxelize") + " (occ+det grids) -> OccTargets3D -> "
                                    "MeanVFE -> VoxelBackBoneDeconv -> OccHead3D+loss -> PassOccVox -> OccVFE -> VoxelBackBone8xOcc -> "

@@ -227,16 +227,17 @@ def _actc(t):
     return t.contiguous()
 
 
-def _conv_cost(nbr, n_res, K, cred, cres):
+def _conv_cost(nbr, n_res, K, cred, cres, act_bytes=4):
     """SURVEY.md §8d, sparse conv fwd (dgrad is the same launch with the channel roles swapped):
-    bytes = 4 (sum_k P_k (Cin + Cout) + K Cin Cout + N_out Cout), flops = 2 sum_k P_k Cin Cout"""
+    bytes = s (sum_k P_k (Cin + Cout) + N_out Cout) + 4 K Cin Cout, flops = 2 sum_k P_k Cin Cout (s = 4 fp32 / 2 bf16 activations)"""
     P = _num_pairs(nbr)
-    return 4 * (P * (cred + cres) + K * cred * cres + n_res * cres), 2 * P * cred * cres, dict(rows=n_res, K=K, cred=cred, cres=cres, pairs=P)
+    return (act_bytes * (P * (cred + cres) + n_res * cres) + 4 * K * cred * cres, 2 * P * cred * cres,
+            dict(rows=n_res, K=K, cred=cred, cres=cres, pairs=P))
 
 
-def _wgrad_cost(nbr, n_res, K, cin, cout):
+def _wgrad_cost(nbr, n_res, K, cin, cout, act_bytes=4):
     P = _num_pairs(nbr)
-    return 4 * (P * (cin + cout) + K * cin * cout), 2 * P * cin * cout, dict(rows=n_res, K=K, cred=cin, cres=cout, pairs=P)
+    return act_bytes * P * (cin + cout) + 4 * K * cin * cout, 2 * P * cin * cout, dict(rows=n_res, K=K, cred=cin, cres=cout, pairs=P)
 
 
 class SparseConvFunction(torch.autograd.Function):
@@ -256,7 +257,7 @@ class SparseConvFunction(torch.autograd.Function):
         out = torch.empty((n_res, cout), dtype=features.dtype, device=features.device)
         b = _f32c(bias) if bias is not None else None
         fwd = lib().btc_conv_fwd_bf16 if bf else lib().btc_conv_fwd
-        with _span("conv_apply", lambda: _conv_cost(map_fwd, n_res, K, cin, cout)):
+        with _span("conv_apply", lambda: _conv_cost(map_fwd, n_res, K, cin, cout, 2 if bf else 4)):
             check(fwd(ptr(features), ptr(w), ptr(b), ptr(map_fwd), n_res, K, cin, cout, ptr(out), stream_ptr()), "btc_conv_fwd")
         if CAPTURE is not None:
             CAPTURE.append((features, w, b, map_fwd, map_bwd))
@@ -295,13 +296,13 @@ class SparseConvFunction(torch.autograd.Function):
             else:
                 dw = torch.empty(ctx.wshape, dtype=torch.float32, device=grad_out.device)
                 ws = workspace(ws_bytes, grad_out.device)
-                with _span("conv_wgrad", lambda: _wgrad_cost(map_fwd, n_res, K, cin, cout)):
+                with _span("conv_wgrad", lambda: _wgrad_cost(map_fwd, n_res, K, cin, cout, 2 if bf else 4)):
                     check(wgrad(ptr(features), ptr(grad_out), ptr(map_fwd), n_res, ptr(map_bwd), n_src, K, cin, cout,
                                            ptr(dw), ptr(ws), ws_bytes, stream_ptr()), "btc_conv_wgrad")
         if need_din:
             n_src = map_bwd.shape[0]
             din = torch.empty((n_src, cin), dtype=features.dtype, device=grad_out.device)
-            with _span("conv_apply", lambda: _conv_cost(map_bwd, n_src, K, cout, cin)):
+            with _span("conv_apply", lambda: _conv_cost(map_bwd, n_src, K, cout, cin, 2 if bf else 4)):
                 check(dgrad(ptr(grad_out), ptr(w), ptr(map_bwd), n_src, K, cin, cout, ptr(din), stream_ptr()),
                       "btc_conv_dgrad")
         if ctx.has_bias and ctx.needs_input_grad[2]:
