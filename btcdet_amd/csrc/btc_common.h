@@ -119,6 +119,11 @@ struct BtcCarver {
 size_t btc_scan_ws_bytes(long long n);
 int btc_scan_exclusive_i32(const int32_t* in, int32_t* out, long long n, int32_t* total, void* ws, hipStream_t stream);
 
+// byte map (one byte per cell, 0 / 1) -> bitmap + exclusive popcount prefix (scan.hip); see rulebook.hip
+size_t btc_bytemap_bytes(long long nwords);
+int btc_bytemap_to_ranked_bitmap(const unsigned char* bytemap, long long nwords, unsigned* bitmap, int32_t* prefix, int32_t* total,
+                                 void* ws, hipStream_t stream);
+
 // Geometry passed by value to kernels.
 struct BtcGeom {
   int in_shape[3];

@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256) void subm_lookup(const int4* __restrict__ idx,
 
 // ------------------------------------------------------------------ conv / transpose / pool
 __global__ __launch_bounds__(256) void conv_mark(const int4* __restrict__ idx, int n, BtcGeom g, int ovol,
-                                                 unsigned* __restrict__ bitmap) {
+                                                 unsigned char* __restrict__ bytemap) {
   long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= (long long)n * g.K) return;
   int i = (int)(t / g.K), kk = (int)(t % g.K);
@@ -97,14 +97,7 @@ __global__ __launch_bounds__(256) void conv_mark(const int4* __restrict__ idx, i
   int oz, oy, ox;
   if (!out_cell(g, c.y, c.z, c.w, kk, &oz, &oy, &ox)) return;
   unsigned cell = (unsigned)(c.x * ovol + (oz * g.out_shape[1] + oy) * g.out_shape[2] + ox);
-  atomicOr(&bitmap[cell >> 5], 1u << (cell & 31));
-}
-
-__global__ __launch_bounds__(256) void bitmap_popc(const unsigned* __restrict__ bitmap, long long nwords,
-                                                   int32_t* __restrict__ counts) {
-  long long w = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (w > nwords) return;
-  counts[w] = (w < nwords) ? __popc(bitmap[w]) : 0;
+  bytemap[cell] = 1;  // plain store: every writer stores the same value
 }
 
 __global__ __launch_bounds__(256) void conv_fill(const int4* __restrict__ idx, int n, BtcGeom g, int ovol,
@@ -246,7 +239,7 @@ static long long conv_nwords(int batch, const int32_t* out_shape) {
 extern "C" size_t btc_rulebook_conv_ws_bytes(int batch, const int32_t* h_out_shape) {
   long long nw = conv_nwords(batch, h_out_shape);
   return btc_align((size_t)nw * sizeof(unsigned)) + btc_align((size_t)(nw + 1) * sizeof(int32_t)) +
-         btc_scan_ws_bytes(nw + 1);
+         btc_scan_ws_bytes(nw + 1) + btc_bytemap_bytes(nw);
 }
 
 extern "C" int btc_rulebook_conv_count(const int32_t* indices, int n, int batch, const int32_t* h_in_shape,
@@ -269,14 +262,13 @@ extern "C" int btc_rulebook_conv_count(const int32_t* indices, int n, int batch,
   unsigned* bitmap = cv.take<unsigned>(nw);
   int32_t* prefix = cv.take<int32_t>(nw + 1);
   void* scan_ws = cv.take<char>(btc_scan_ws_bytes(nw + 1));
-  BTC_HIP(hipMemsetAsync(bitmap, 0, (size_t)nw * sizeof(unsigned), stream));
+  unsigned char* bytemap = cv.take<unsigned char>(btc_bytemap_bytes(nw));
+  BTC_HIP(hipMemsetAsync(bytemap, 0, btc_bytemap_bytes(nw), stream));
   if (n > 0) {
-    conv_mark<<<btc_cdiv((long long)n * g.K, 256), 256, 0, stream>>>((const int4*)indices, n, g, (int)ovol, bitmap);
+    conv_mark<<<btc_cdiv((long long)n * g.K, 256), 256, 0, stream>>>((const int4*)indices, n, g, (int)ovol, bytemap);
     BTC_LAUNCH_CHECK();
   }
-  bitmap_popc<<<btc_cdiv(nw + 1, 256), 256, 0, stream>>>(bitmap, nw, prefix);
-  BTC_LAUNCH_CHECK();
-  return btc_scan_exclusive_i32(prefix, prefix, nw + 1, d_n_out, scan_ws, stream);
+  return btc_bytemap_to_ranked_bitmap(bytemap, nw, bitmap, prefix, d_n_out, scan_ws, stream);
 }
 
 extern "C" int btc_rulebook_conv_fill(const int32_t* indices, int n, int batch, const int32_t* h_in_shape,

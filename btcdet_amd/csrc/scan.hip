@@ -120,6 +120,61 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_final(const int32_t* __rest
   }
 }
 
+// ---- byte map -> ranked bitmap (rulebook of strided / transposed convs and pools) ------------------------------
+// The reachable output cells are marked with plain byte stores (many writers, one value: no atomics -- device-scope
+// atomicOr on a shared bitmap word runs at the memory side on this multi-XCD part and measured 40-80 us per rulebook).
+// bytes_to_bits packs 32 bytes into a bitmap word and leaves the per-block popcount sums for the scan.
+__global__ __launch_bounds__(SCAN_THREADS) void bytes_to_bits(const uint4* __restrict__ bytemap, long long nwords,
+                                                              unsigned* __restrict__ bitmap, int32_t* __restrict__ block_sums) {
+  __shared__ int s_wave[SCAN_THREADS / 64];
+  const long long wbase = (long long)blockIdx.x * SCAN_TILE;
+  int sum = 0;
+#pragma unroll
+  for (int j = 0; j < SCAN_ITEMS; ++j) {
+    const long long w = wbase + j * SCAN_THREADS + threadIdx.x;  // coalesced: consecutive lanes take consecutive words
+    if (w < nwords) {
+      const uint4 a = bytemap[2 * w], b = bytemap[2 * w + 1];
+      const unsigned d[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+      unsigned bits = 0;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) bits |= (((d[q] & 0x01010101u) * 0x01020408u) >> 24) << (4 * q);  // bytes are 0 / 1
+      bitmap[w] = bits;
+      sum += __popc(bits);
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) sum += __shfl_down(sum, o, 64);
+  if ((threadIdx.x & 63) == 0) s_wave[threadIdx.x >> 6] = sum;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int t = 0;
+#pragma unroll
+    for (int w = 0; w < SCAN_THREADS / 64; ++w) t += s_wave[w];
+    block_sums[blockIdx.x] = t;
+  }
+}
+
+// prefix[w] = number of set bits in words [0, w), w in [0, nwords] (block_sums already scanned)
+__global__ __launch_bounds__(SCAN_THREADS) void bitmap_prefix(const unsigned* __restrict__ bitmap, long long nwords,
+                                                              const int32_t* __restrict__ block_sums, int32_t* __restrict__ prefix) {
+  __shared__ int s_wave[SCAN_THREADS / 64 + 1];
+  long long base = (long long)blockIdx.x * SCAN_TILE + (long long)threadIdx.x * SCAN_ITEMS;
+  int v[SCAN_ITEMS];
+  int sum = 0;
+#pragma unroll
+  for (int j = 0; j < SCAN_ITEMS; ++j) {
+    v[j] = (base + j < nwords) ? __popc(bitmap[base + j]) : 0;
+    sum += v[j];
+  }
+  int tot;
+  int ex = block_excl_scan<SCAN_THREADS>(sum, s_wave, &tot) + block_sums[blockIdx.x];
+#pragma unroll
+  for (int j = 0; j < SCAN_ITEMS; ++j) {
+    if (base + j <= nwords) prefix[base + j] = ex;
+    ex += v[j];
+  }
+}
+
 }  // namespace
 
 size_t btc_scan_ws_bytes(long long n) {
@@ -140,6 +195,28 @@ int btc_scan_exclusive_i32(const int32_t* in, int32_t* out, long long n, int32_t
   scan_block_sums<<<1, 1024, 0, stream>>>(block_sums, nblocks, total);
   BTC_LAUNCH_CHECK();
   scan_final<<<nblocks, SCAN_THREADS, 0, stream>>>(in, out, n, block_sums);
+  BTC_LAUNCH_CHECK();
+  return BTC_OK;
+}
+
+// bytemap: one byte per cell (0 / 1), padded with zeros to btc_bytemap_bytes(nwords); bitmap: nwords words;
+// prefix: nwords + 1 entries (prefix[nwords] = *total = number of marked cells); ws: btc_scan_ws_bytes(nwords + 1)
+size_t btc_bytemap_bytes(long long nwords) { return btc_align((size_t)nwords * 32); }
+
+int btc_bytemap_to_ranked_bitmap(const unsigned char* bytemap, long long nwords, unsigned* bitmap, int32_t* prefix, int32_t* total,
+                                 void* ws, hipStream_t stream) {
+  if (nwords <= 0) {
+    BTC_HIP(hipMemsetAsync(prefix, 0, sizeof(int32_t), stream));
+    if (total) BTC_HIP(hipMemsetAsync(total, 0, sizeof(int32_t), stream));
+    return BTC_OK;
+  }
+  const int nblocks = (int)((nwords + 1 + SCAN_TILE - 1) / SCAN_TILE);  // the prefix has nwords + 1 entries
+  int32_t* block_sums = (int32_t*)ws;
+  bytes_to_bits<<<nblocks, SCAN_THREADS, 0, stream>>>((const uint4*)bytemap, nwords, bitmap, block_sums);
+  BTC_LAUNCH_CHECK();
+  scan_block_sums<<<1, 1024, 0, stream>>>(block_sums, nblocks, total);
+  BTC_LAUNCH_CHECK();
+  bitmap_prefix<<<nblocks, SCAN_THREADS, 0, stream>>>(bitmap, nwords, block_sums, prefix);
   BTC_LAUNCH_CHECK();
   return BTC_OK;
 }
