@@ -299,4 +299,158 @@ class VoxelBackBone8xOcc(nn.Module):
         return batch_dict
 
 
-__all__ = {'VoxelBackBoneDeconv': VoxelBackBoneDeconv, 'VoxelBackBone8xOcc': VoxelBackBone8xOcc}
+# ----------------------------------------------------------------------------------------------------------------------
+# The backbone variants the reference can reach by changing BACKBONE_3D.NAME: residual blocks,
+# lateral "combine" decoders and the inverse-convolution decoder.  Same constructor arguments, parameter names and
+# batch_dict keys as /root/reference/btcdet/models/backbones_3d/spconv_backbone.py:50-88,226-627.
+# ----------------------------------------------------------------------------------------------------------------------
+class SparseBasicBlock(spconv.SparseModule):
+    """two SubM 3x3x3 convs (with bias) + BatchNorm, identity shortcut, ReLU (spconv_backbone.py:50-88)"""
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride=1, norm_fn=None, downsample=None, indice_key=None):
+        super().__init__()
+        assert norm_fn is not None
+        self.conv1 = spconv.SubMConv3d(inplanes, planes, kernel_size=3, stride=stride, padding=1, bias=True, indice_key=indice_key)
+        self.bn1 = norm_fn(planes)
+        self.relu = nn.ReLU()
+        self.conv2 = spconv.SubMConv3d(planes, planes, kernel_size=3, stride=stride, padding=1, bias=True, indice_key=indice_key)
+        self.bn2 = norm_fn(planes)
+        self.downsample = downsample
+        self.stride = stride
+
+    def forward(self, x):
+        identity = x.features if self.downsample is None else self.downsample(x).features
+        out = self.conv1(x)
+        out.features = _bn_act(self.bn1, out.features, True)
+        out = self.conv2(out)
+        out.features = torch.relu(_bn_act(self.bn2, out.features, False) + identity)
+        return out
+
+
+def _bn_act(bn, feats, relu):
+    """BatchNorm1d (+ ReLU) over sparse features through the fused HIP kernels when they apply"""
+    from .spconv import fused_bn
+    if feats.is_cuda and feats.dim() == 2 and feats.shape[0] > 0 and fused_bn.fusable(bn):
+        return fused_bn.batch_norm_relu(bn, feats, relu)
+    y = bn(feats)
+    return torch.relu(y) if relu else y
+
+
+def _lateral_combine(x_lateral, x_bottom, conv_expnd, comb_conv):
+    """decoder merge of the Res backbones (spconv_backbone.py:306-319): the lateral tensor goes through conv_expnd, its rows
+    are placed at the rows of x_bottom that hold the same cell (rank of the cell among the sorted unique cells of both --
+    which is the row of x_bottom because strided / transposed rulebooks emit rows in sorted cell order), absent cells get
+    zeros, and the concatenation goes through comb_conv"""
+    x_expnd = conv_expnd(x_lateral)
+    M = x_bottom.features.shape[0]
+    ind_all = torch.cat([x_bottom.indices, x_expnd.indices], dim=0)
+    _, rinds = torch.unique(ind_all, dim=0, return_inverse=True)
+    pad = torch.zeros((M, x_expnd.features.shape[1]), dtype=x_bottom.features.dtype, device=x_bottom.features.device)
+    pad[rinds[M:], :] = x_expnd.features.to(pad.dtype)
+    x_bottom.features = torch.cat([x_bottom.features, pad], dim=-1)
+    return comb_conv(x_bottom)
+
+
+class _ResDecoderBase(nn.Module):
+    """shared forward of VoxelBackBoneDeconvRes / VoxelBackBoneInverseRes (spconv_backbone.py:322-381,478-527)"""
+
+    def forward(self, batch_dict):
+        feats, coords = batch_dict['voxel_features'], batch_dict['voxel_coords'].int()
+        x = spconv.SparseConvTensor(features=feats, indices=coords, spatial_shape=self.sparse_shape, batch_size=batch_dict['batch_size'])
+        x1 = self.conv1(x)
+        x2 = self.conv2(x1)
+        x3 = self.conv3(x2)
+        x2d = _lateral_combine(x2, self.deconv2(x3), self.conv22, self.comb_conv2)
+        x1d = _lateral_combine(x1, self.deconv1(x2d), self.conv11, self.comb_conv1)
+        batch_dict.update({'encoded_spconv_tensor': x1d, 'encoded_spconv_tensor_stride': 1})
+        return batch_dict
+
+
+class VoxelBackBoneDeconvRes(_ResDecoderBase):
+    """encoder [/1, /2, /4] + transposed-conv decoder with lateral merges (spconv_backbone.py:226-381)"""
+
+    def __init__(self, model_cfg, input_channels, grid_size, **kwargs):
+        super().__init__()
+        self.model_cfg = model_cfg
+        norm_fn = partial(nn.BatchNorm1d, eps=1e-3, momentum=0.01)
+        self.sparse_shape = grid_size[::-1]
+        c = [16, 32, 64]
+        sp, dc = dict(conv_type='spconv'), dict(conv_type='spdeconv')
+        self.conv1 = _seq([(input_channels, c[0], 3, dict(padding=1, indice_key='spconv1', **sp))], norm_fn)
+        self.conv2 = _seq([(c[0], c[1], 3, dict(stride=2, padding=1, indice_key='spconv2', **sp)),
+                           (c[1], c[1], 3, dict(padding=1, indice_key='subm2'))], norm_fn)
+        self.conv3 = _seq([(c[1], c[2], 3, dict(stride=2, padding=1, indice_key='spconv3', **sp)),
+                           (c[2], c[2], 3, dict(padding=1, indice_key='subm3'))], norm_fn)
+        self.conv22 = _seq([(c[1], c[1], 3, dict(stride=1, padding=1, indice_key='spconv22', **sp))], norm_fn)
+        self.deconv2 = _seq([(c[2], c[1], 3, dict(stride=2, padding=1, indice_key='spconvd2', **dc))], norm_fn)
+        self.comb_conv2 = _seq([(c[1] + c[1], c[1], 3, dict(padding=1, indice_key='submd2'))], norm_fn)
+        self.conv11 = _seq([(c[0], c[0], 3, dict(stride=1, padding=1, indice_key='spconv11', **sp))], norm_fn)
+        self.deconv1 = _seq([(c[1], c[1], 3, dict(stride=2, padding=1, indice_key='spconvd1', **dc))], norm_fn)
+        self.comb_conv1 = _seq([(c[1] + c[0], c[1], 3, dict(padding=1, indice_key='submd1'))], norm_fn)
+        self.num_point_features = c[1]
+
+
+class VoxelBackBoneInverseRes(_ResDecoderBase):
+    """the same topology on submanifold laterals with SparseInverseConv3d decoders that reuse the encoder's strided
+    rulebooks ('spconv3', 'spconv2') and therefore restore the encoder's active sets exactly (spconv_backbone.py:385-527)"""
+
+    def __init__(self, model_cfg, input_channels, grid_size, **kwargs):
+        super().__init__()
+        self.model_cfg = model_cfg
+        norm_fn = partial(nn.BatchNorm1d, eps=1e-3, momentum=0.01)
+        self.sparse_shape = grid_size[::-1]
+        c = [16, 32, 64]
+        sp, inv = dict(conv_type='spconv'), dict(conv_type='inverseconv')
+        self.conv1 = _seq([(input_channels, c[0], 3, dict(padding=1, indice_key='subm1'))], norm_fn)
+        self.conv2 = _seq([(c[0], c[1], 3, dict(stride=2, padding=1, indice_key='spconv2', **sp)),
+                           (c[1], c[1], 3, dict(padding=1, indice_key='subm2'))], norm_fn)
+        self.conv3 = _seq([(c[1], c[2], 3, dict(stride=2, padding=1, indice_key='spconv3', **sp)),
+                           (c[2], c[2], 3, dict(padding=1, indice_key='subm3'))], norm_fn)
+        self.conv22 = _seq([(c[1], c[1], 3, dict(stride=1, padding=1, indice_key='subm2'))], norm_fn)
+        self.deconv2 = _seq([(c[2], c[1], 3, dict(stride=2, padding=1, indice_key='spconv3', **inv))], norm_fn)
+        self.comb_conv2 = _seq([(c[1] + c[1], c[1], 3, dict(padding=1, indice_key='subm2'))], norm_fn)
+        self.conv11 = _seq([(c[0], c[0], 3, dict(stride=1, padding=1, indice_key='subm1'))], norm_fn)
+        self.deconv1 = _seq([(c[1], c[1], 3, dict(stride=2, padding=1, indice_key='spconv2', **inv))], norm_fn)
+        self.comb_conv1 = _seq([(c[1] + c[0], c[1], 3, dict(padding=1, indice_key='subm1'))], norm_fn)
+        self.num_point_features = c[1]
+
+
+class VoxelResBackBone8x(nn.Module):
+    """8x-downsampling detection backbone built from SparseBasicBlocks (spconv_backbone.py:531-627)"""
+
+    def __init__(self, model_cfg, input_channels, grid_size, **kwargs):
+        super().__init__()
+        self.model_cfg = model_cfg
+        norm_fn = partial(nn.BatchNorm1d, eps=1e-3, momentum=0.01)
+        self.sparse_shape = grid_size[::-1] + [1, 0, 0]
+        self.conv_input = spconv.SparseSequential(spconv.SubMConv3d(input_channels, 16, 3, padding=1, bias=False, indice_key='subm1'),
+                                                  norm_fn(16), nn.ReLU())
+        res = lambda ch, key: SparseBasicBlock(ch, ch, norm_fn=norm_fn, indice_key=key)
+        down = lambda ci, co, pad, key: post_act_block(ci, co, 3, norm_fn=norm_fn, stride=2, padding=pad, indice_key=key, conv_type='spconv')
+        self.conv1 = spconv.SparseSequential(res(16, 'res1'), res(16, 'res1'))
+        self.conv2 = spconv.SparseSequential(down(16, 32, 1, 'spconv2'), res(32, 'res2'), res(32, 'res2'))
+        self.conv3 = spconv.SparseSequential(down(32, 64, 1, 'spconv3'), res(64, 'res3'), res(64, 'res3'))
+        self.conv4 = spconv.SparseSequential(down(64, 128, (0, 1, 1), 'spconv4'), res(128, 'res4'), res(128, 'res4'))
+        last_pad = self.model_cfg.get('last_pad', 0)
+        self.conv_out = spconv.SparseSequential(spconv.SparseConv3d(128, 128, (3, 1, 1), stride=(2, 1, 1), padding=last_pad, bias=False,
+                                                                    indice_key='spconv_down2'), norm_fn(128), nn.ReLU())
+        self.num_point_features = 128
+
+    def forward(self, batch_dict):
+        feats, coords = batch_dict['voxel_features'], batch_dict['voxel_coords'].int()
+        x = spconv.SparseConvTensor(features=feats, indices=coords, spatial_shape=self.sparse_shape, batch_size=batch_dict['batch_size'])
+        x = self.conv_input(x)
+        x1 = self.conv1(x)
+        x2 = self.conv2(x1)
+        x3 = self.conv3(x2)
+        x4 = self.conv4(x3)
+        out = self.conv_out(x4)
+        batch_dict.update({'encoded_spconv_tensor': out, 'encoded_spconv_tensor_stride': 8,
+                           'multi_scale_3d_features': {'x_conv1': x1, 'x_conv2': x2, 'x_conv3': x3, 'x_conv4': x4}})
+        return batch_dict
+
+
+__all__ = {'VoxelBackBoneDeconv': VoxelBackBoneDeconv, 'VoxelBackBone8xOcc': VoxelBackBone8xOcc,
+           'VoxelBackBoneDeconvRes': VoxelBackBoneDeconvRes, 'VoxelBackBoneInverseRes': VoxelBackBoneInverseRes,
+           'VoxelResBackBone8x': VoxelResBackBone8x}

@@ -1,0 +1,100 @@
+"""Drop-in check against the reference's OWN backbone file (runs only where /root/reference is mounted, i.e. in the build
+container -- never on the GPU box): /root/reference/btcdet/models/backbones_3d/spconv_backbone.py imports `spconv`; with
+btcdet_amd.install_as_spconv() it imports THIS implementation, its classes construct on top of it, and their state_dict
+(keys, shapes) is identical to the one of this repository's backbones, so reference checkpoints load key-for-key."""
+import importlib.util
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+REF = "/root/reference/btcdet/models/backbones_3d/spconv_backbone.py"
+pytestmark = pytest.mark.skipif(not os.path.exists(REF), reason="reference tree not mounted")
+
+
+@pytest.fixture(scope="module")
+def ref_mod():
+    import btcdet_amd
+    saved = {k: sys.modules.get(k) for k in ("spconv", "spconv.utils", "spconv.ops")}
+    btcdet_amd.install_as_spconv()
+    spec = importlib.util.spec_from_file_location("_ref_spconv_backbone", REF)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    yield mod
+    for k, v in saved.items():
+        if v is None:
+            sys.modules.pop(k, None)
+        else:
+            sys.modules[k] = v
+
+
+def _cfgs():
+    from btcdet_amd.config import load_cfg
+    cfg = load_cfg()
+    return cfg, cfg.MODEL.OCC.BACKBONE_3D, cfg.MODEL.BACKBONE_3D
+
+
+def _same_state(mine, ref):
+    a, b = mine.state_dict(), ref.state_dict()
+    assert list(a.keys()) == list(b.keys())
+    for k in a:
+        assert tuple(a[k].shape) == tuple(b[k].shape), k
+    mine.load_state_dict(b, strict=True)
+
+
+def test_reference_module_uses_this_spconv(ref_mod):
+    import btcdet_amd.spconv as sp
+    assert ref_mod.spconv is sp
+    blk = ref_mod.post_act_block(16, 32, 3, indice_key="k", stride=2, padding=1, conv_type="spconv",
+                                 norm_fn=lambda c: torch.nn.BatchNorm1d(c, eps=1e-3, momentum=0.01))
+    assert isinstance(blk, sp.SparseSequential) and isinstance(blk[0], sp.SparseConv3d)
+    assert tuple(blk[0].weight.shape) == (3, 3, 3, 16, 32)
+
+
+def test_occupancy_backbone_state_dict_matches_reference(ref_mod):
+    from btcdet_amd import backbones_3d
+    cfg, occ_cfg, _ = _cfgs()
+    grid = np.array([209, 157, 9])
+    kw = dict(model_cfg=occ_cfg, input_channels=4, grid_size=grid, voxel_size=[0.32, 0.5184, 0.36],
+              point_cloud_range=cfg.DATA_CONFIG.POINT_CLOUD_RANGE, original_num_rawpoint_features=4)
+    mine = backbones_3d.VoxelBackBoneDeconv(**kw)
+    ref = ref_mod.VoxelBackBoneDeconv(**kw)
+    _same_state(mine, ref)
+    assert mine.num_point_features == ref.num_point_features
+    assert list(mine.sparse_shape) == list(ref.sparse_shape)
+
+
+def test_detection_backbone_state_dict_matches_reference(ref_mod):
+    from btcdet_amd import backbones_3d
+    cfg, _, det_cfg = _cfgs()
+    grid = np.array([1408, 1600, 40])
+    kw = dict(model_cfg=det_cfg, input_channels=6, grid_size=grid, voxel_size=[0.05, 0.05, 0.1],
+              point_cloud_range=cfg.DATA_CONFIG.POINT_CLOUD_RANGE, original_num_rawpoint_features=4)
+    mine = backbones_3d.VoxelBackBone8xOcc(**kw)
+    ref = ref_mod.VoxelBackBone8xOcc(**kw)
+    _same_state(mine, ref)
+    assert mine.num_point_features == ref.num_point_features
+    assert list(mine.sparse_shape) == list(ref.sparse_shape)
+
+
+@pytest.mark.parametrize("name,cin,grid", [("VoxelBackBoneDeconvRes", 4, [209, 157, 9]), ("VoxelBackBoneInverseRes", 4, [209, 157, 9]),
+                                           ("VoxelResBackBone8x", 4, [1408, 1600, 40])])
+def test_unconfigured_backbone_variants_match_reference(ref_mod, name, cin, grid, capsys):
+    """the variants reachable through BACKBONE_3D.NAME"""
+    from btcdet_amd import backbones_3d
+    cfg, occ_cfg, _ = _cfgs()
+    kw = dict(model_cfg=occ_cfg, input_channels=cin, grid_size=np.array(grid))
+    mine = backbones_3d.__all__[name](**kw)
+    ref = getattr(ref_mod, name)(**kw)
+    _same_state(mine, ref)
+    assert mine.num_point_features == ref.num_point_features and list(mine.sparse_shape) == list(ref.sparse_shape)
+
+
+def test_sparse_basic_block_matches_reference(ref_mod):
+    from functools import partial
+    from btcdet_amd import backbones_3d
+    norm_fn = partial(torch.nn.BatchNorm1d, eps=1e-3, momentum=0.01)
+    _same_state(backbones_3d.SparseBasicBlock(32, 32, norm_fn=norm_fn, indice_key="res2"),
+                ref_mod.SparseBasicBlock(32, 32, norm_fn=norm_fn, indice_key="res2"))
