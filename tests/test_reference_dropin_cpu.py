@@ -98,3 +98,31 @@ def test_sparse_basic_block_matches_reference(ref_mod):
     norm_fn = partial(torch.nn.BatchNorm1d, eps=1e-3, momentum=0.01)
     _same_state(backbones_3d.SparseBasicBlock(32, 32, norm_fn=norm_fn, indice_key="res2"),
                 ref_mod.SparseBasicBlock(32, 32, norm_fn=norm_fn, indice_key="res2"))
+
+
+HOT = ("occ_modules.", "det_modules.vfe", "det_modules.backbone_3d", "det_modules.map_to_bev_module", "global_step")
+
+
+def _hot_path_state():
+    from btcdet_amd.btc_path import BtcHotPath
+    from btcdet_amd.config import load_cfg
+    return {k: list(v.shape) for k, v in BtcHotPath(load_cfg(), device="cpu").state_dict().items()}
+
+
+def test_reference_btcnet_builds_on_this_spconv_and_hot_path_state_dict_matches():
+    """the reference's OWN BtcNet (detector template, registries, yaml) constructs with `spconv` = btcdet_amd.spconv; the
+    hot-path part of its state_dict (occ_modules.*, det_modules.{vfe, backbone_3d, map_to_bev_module}) equals BtcHotPath's
+    key for key, shape for shape, in order -- so a reference checkpoint loads into the hot path and vice versa"""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tests", "golden", "ref_build_state.py")], capture_output=True, timeout=600)
+    assert out.returncode == 0, out.stderr.decode()[-2000:]
+    ref = json.loads(out.stdout.decode().strip().splitlines()[-1])["keys"]
+    assert len(ref) > 300  # the whole detector built, incl. the out-of-scope 2-D backbone and heads
+    hot = {k: v for k, v in ref.items() if k.startswith(HOT)}
+    mine = _hot_path_state()
+    assert list(hot.keys()) == list(mine.keys())
+    assert hot == mine
+    committed = json.load(open(os.path.join(root, "tests", "golden", "ref_state_keys.json")))["keys"]
+    assert committed == ref  # the fixture used where the reference is not mounted is current
