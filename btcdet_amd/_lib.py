@@ -62,6 +62,9 @@ _SIGS = {
     "btc_last_error": (ctypes.c_char_p, []),
     "btc_version": (ci, []),
     "btc_tune_set": (ci, [ci, ci]),
+    "btc_boxes_pairwise_bev": (ci, [vp, ci, vp, ci, ci, vp, vp]),
+    "btc_nms_ws_bytes": (sz, [ci]),
+    "btc_nms": (ci, [vp, ci, ctypes.c_float, ci, vp, vp, vp, sz, vp]),
     "btc_voxelize_ws_bytes": (sz, [ci, ci, ci]),
     "btc_voxelize": (ci, [vp, ci, ci, ci, ci, ci, vp, ci, c_f32p, c_f32p, c_i32p, ci, ci, vp, vp, vp, vp, vp, sz, vp]),
     "btc_cart_to_occ_coords": (ci, [vp, vp, ci, ci, ci, vp]),

@@ -1,0 +1,235 @@
+// Rotated BEV overlap / IoU and NMS for gfx950 (the first component next to the hot path).
+//
+// Replaces /root/reference/btcdet/ops/iou3d_nms/src/iou3d_nms_kernel.cu (box_overlap :107-233, iou_bev :235-243,
+// nms_kernel :268-309, nms_normal_kernel :325-362) and the host side of iou3d_nms.cpp:90-188, which for every NMS call
+// cudaMallocs the N x N/64 suppression mask, copies it to the host (10 MB at 9 000 proposals), walks it on one CPU core
+// and frees it again.  Here the mask never leaves the device: one kernel builds its upper triangle, one 256-thread
+// workgroup resolves the greedy chain 64 boxes at a time (the in-block dependency with v_readlane on the diagonal word,
+// the kept rows OR-ed into the remaining removal words by all threads) and writes the kept positions and their count;
+// no allocation, no copy, no host loop, one optional 4-byte read-back of the count.
+// Per pair the arithmetic follows the reference's fp32 formulation (edge intersections + corners inside the other box
+// with its 1 cm margin, ordered by atan2 about their centroid, fan area) so that IoU values -- and with them the NMS
+// decisions -- agree with it up to the last-ulp differences of cosf / sinf / atan2f.
+#include "btc_common.h"
+
+namespace {
+
+struct Pt {
+  float x, y;
+};
+
+__device__ __forceinline__ float cross3(Pt p1, Pt p2, Pt p0) { return (p1.x - p0.x) * (p2.y - p0.y) - (p2.x - p0.x) * (p1.y - p0.y); }
+
+__device__ __forceinline__ bool in_box2d(const float* box, Pt p) {
+  const float margin = 1e-2f;
+  const float c = cosf(-box[6]), s = sinf(-box[6]);
+  const float rx = (p.x - box[0]) * c + (p.y - box[1]) * (-s);
+  const float ry = (p.x - box[0]) * s + (p.y - box[1]) * c;
+  return fabsf(rx) < box[3] / 2 + margin && fabsf(ry) < box[4] / 2 + margin;
+}
+
+__device__ __forceinline__ bool seg_intersection(Pt p1, Pt p0, Pt q1, Pt q0, Pt* ans) {
+  if (!(fminf(p0.x, p1.x) <= fmaxf(q0.x, q1.x) && fminf(q0.x, q1.x) <= fmaxf(p0.x, p1.x) && fminf(p0.y, p1.y) <= fmaxf(q0.y, q1.y) &&
+        fminf(q0.y, q1.y) <= fmaxf(p0.y, p1.y)))
+    return false;
+  const float s1 = cross3(q0, p1, p0), s2 = cross3(p1, q1, p0), s3 = cross3(p0, q1, q0), s4 = cross3(q1, p1, q0);
+  if (!(s1 * s2 > 0 && s3 * s4 > 0)) return false;
+  const float s5 = cross3(q1, p1, p0);
+  if (fabsf(s5 - s1) > 1e-8f) {
+    ans->x = (s5 * q0.x - s1 * q1.x) / (s5 - s1);
+    ans->y = (s5 * q0.y - s1 * q1.y) / (s5 - s1);
+  } else {
+    const float a0 = p0.y - p1.y, b0 = p1.x - p0.x, c0 = p0.x * p1.y - p1.x * p0.y;
+    const float a1 = q0.y - q1.y, b1 = q1.x - q0.x, c1 = q0.x * q1.y - q1.x * q0.y;
+    const float D = a0 * b1 - a1 * b0;
+    ans->x = (b0 * c1 - b1 * c0) / D;
+    ans->y = (a1 * c0 - a0 * c1) / D;
+  }
+  return true;
+}
+
+__device__ __forceinline__ void corners(const float* box, Pt* c /* 5 */) {
+  const float hx = box[3] / 2, hy = box[4] / 2, co = cosf(box[6]), si = sinf(box[6]);
+  const float lx[4] = {box[0] - hx, box[0] + hx, box[0] + hx, box[0] - hx};
+  const float ly[4] = {box[1] - hy, box[1] - hy, box[1] + hy, box[1] + hy};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    c[k].x = (lx[k] - box[0]) * co + (ly[k] - box[1]) * (-si) + box[0];
+    c[k].y = (lx[k] - box[0]) * si + (ly[k] - box[1]) * co + box[1];
+  }
+  c[4] = c[0];
+}
+
+__device__ float box_overlap(const float* a, const float* b) {
+  Pt ca[5], cb[5], pts[16], ctr = {0.f, 0.f};
+  corners(a, ca);
+  corners(b, cb);
+  int cnt = 0;
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j)
+      if (seg_intersection(ca[i + 1], ca[i], cb[j + 1], cb[j], &pts[cnt])) {
+        ctr.x += pts[cnt].x;
+        ctr.y += pts[cnt].y;
+        ++cnt;
+      }
+  for (int k = 0; k < 4; ++k) {
+    if (in_box2d(a, cb[k])) {
+      ctr.x += cb[k].x;
+      ctr.y += cb[k].y;
+      pts[cnt++] = cb[k];
+    }
+    if (in_box2d(b, ca[k])) {
+      ctr.x += ca[k].x;
+      ctr.y += ca[k].y;
+      pts[cnt++] = ca[k];
+    }
+  }
+  if (cnt < 3) return 0.f;  // fewer than three points span no area (the reference's loops then add nothing either)
+  ctr.x /= cnt;
+  ctr.y /= cnt;
+  float ang[16];
+  for (int i = 0; i < cnt; ++i) ang[i] = atan2f(pts[i].y - ctr.y, pts[i].x - ctr.x);
+  for (int j = 0; j < cnt - 1; ++j)  // the reference's bubble sort (same swaps: it compares the same atan2 values)
+    for (int i = 0; i < cnt - j - 1; ++i)
+      if (ang[i] > ang[i + 1]) {
+        Pt t = pts[i]; pts[i] = pts[i + 1]; pts[i + 1] = t;
+        float u = ang[i]; ang[i] = ang[i + 1]; ang[i + 1] = u;
+      }
+  float area = 0.f;
+  for (int k = 0; k < cnt - 1; ++k) {
+    const float ax = pts[k].x - pts[0].x, ay = pts[k].y - pts[0].y, bx = pts[k + 1].x - pts[0].x, by = pts[k + 1].y - pts[0].y;
+    area += ax * by - ay * bx;
+  }
+  return fabsf(area) / 2.0f;
+}
+
+__device__ __forceinline__ float iou_bev(const float* a, const float* b) {
+  const float sa = a[3] * a[4], sb = b[3] * b[4], so = box_overlap(a, b);
+  return so / fmaxf(sa + sb - so, 1e-8f);
+}
+
+__device__ __forceinline__ float iou_normal(const float* a, const float* b) {
+  const float left = fmaxf(a[0] - a[3] / 2, b[0] - b[3] / 2), right = fminf(a[0] + a[3] / 2, b[0] + b[3] / 2);
+  const float top = fmaxf(a[1] - a[4] / 2, b[1] - b[4] / 2), bottom = fminf(a[1] + a[4] / 2, b[1] + b[4] / 2);
+  const float w = fmaxf(right - left, 0.f), h = fmaxf(bottom - top, 0.f), inter = w * h;
+  return inter / fmaxf(a[3] * a[4] + b[3] * b[4] - inter, 1e-8f);
+}
+
+// one thread per (a, b) pair; a 16 x 16 workgroup shares 16 + 16 boxes through LDS
+__global__ __launch_bounds__(256) void pairwise_bev(const float* __restrict__ boxes_a, int na, const float* __restrict__ boxes_b, int nb,
+                                                    int mode, float* __restrict__ out) {
+  __shared__ float sa[16 * 7], sb[16 * 7];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int a0 = blockIdx.y * 16, b0 = blockIdx.x * 16;
+  if (threadIdx.x < 112) {
+    const int r = threadIdx.x / 7, c = threadIdx.x % 7;
+    sa[threadIdx.x] = (a0 + r < na) ? boxes_a[(size_t)(a0 + r) * 7 + c] : 0.f;
+    sb[threadIdx.x] = (b0 + r < nb) ? boxes_b[(size_t)(b0 + r) * 7 + c] : 0.f;
+  }
+  __syncthreads();
+  const int ia = a0 + ty, ib = b0 + tx;
+  if (ia >= na || ib >= nb) return;
+  out[(size_t)ia * nb + ib] = mode ? iou_bev(sa + ty * 7, sb + tx * 7) : box_overlap(sa + ty * 7, sb + tx * 7);
+}
+
+// mask[i][cb] bit j: box 64 cb + j (> i) overlaps box i above the threshold; upper triangle of 64 x 64 blocks only
+__global__ __launch_bounds__(64) void nms_mask(const float* __restrict__ boxes, int n, float thresh, int rotated,
+                                               unsigned long long* __restrict__ mask) {
+  const int rb = blockIdx.y, cb = blockIdx.x;
+  if (cb < rb) return;
+  __shared__ float sbox[64 * 7];
+  const int col_blocks = (n + 63) / 64;
+  const int col_size = min(n - cb * 64, 64), row_size = min(n - rb * 64, 64);
+  for (int e = threadIdx.x; e < col_size * 7; e += 64) sbox[e] = boxes[(size_t)cb * 64 * 7 + e];
+  __syncthreads();
+  if ((int)threadIdx.x >= row_size) return;
+  const int i = rb * 64 + threadIdx.x;
+  float cur[7];
+#pragma unroll
+  for (int c = 0; c < 7; ++c) cur[c] = boxes[(size_t)i * 7 + c];
+  unsigned long long t = 0;
+  for (int j = (rb == cb) ? (int)threadIdx.x + 1 : 0; j < col_size; ++j) {
+    const float v = rotated ? iou_bev(cur, sbox + j * 7) : iou_normal(cur, sbox + j * 7);
+    if (v > thresh) t |= 1ull << j;
+  }
+  mask[(size_t)i * col_blocks + cb] = t;
+}
+
+// greedy chain over the mask, one 256-thread workgroup; keep: kept positions ascending, *num_keep their number
+__global__ __launch_bounds__(256) void nms_reduce(const unsigned long long* __restrict__ mask, int n, long long* __restrict__ keep,
+                                                  int32_t* __restrict__ num_keep) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  unsigned long long* remv = (unsigned long long*)smem;  // [col_blocks]
+  __shared__ unsigned long long s_kept;
+  const int col_blocks = (n + 63) / 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int j = tid; j < col_blocks; j += 256) remv[j] = 0ull;
+  __syncthreads();
+  int nk = 0;
+  for (int b = 0; b < col_blocks; ++b) {
+    const int rows = min(n - b * 64, 64);
+    if (wave == 0) {
+      const unsigned long long diag = (lane < rows) ? mask[(size_t)(b * 64 + lane) * col_blocks + b] : 0ull;
+      const unsigned dlo = (unsigned)diag, dhi = (unsigned)(diag >> 32);
+      unsigned long long rem = remv[b], kept = 0ull;
+      for (int i = 0; i < rows; ++i) {  // wave-uniform
+        if (!((rem >> i) & 1ull)) {
+          kept |= 1ull << i;
+          rem |= ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)dhi, i) << 32) |
+                 (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)dlo, i);  // (unsigned): no sign extension
+        }
+      }
+      if ((kept >> lane) & 1ull) keep[nk + __popcll(kept & ((1ull << lane) - 1ull))] = (long long)b * 64 + lane;
+      if (lane == 0) s_kept = kept;
+    }
+    __syncthreads();
+    const unsigned long long kept = s_kept;
+    nk += __popcll(kept);
+    for (int j = b + 1 + tid; j < col_blocks; j += 256) {
+      unsigned long long acc = remv[j], m = kept;
+      while (m) {
+        const int i = __ffsll((long long)m) - 1;
+        m &= m - 1;
+        acc |= mask[(size_t)(b * 64 + i) * col_blocks + j];
+      }
+      remv[j] = acc;
+    }
+    __syncthreads();
+  }
+  if (tid == 0) *num_keep = nk;
+}
+
+}  // namespace
+
+extern "C" int btc_boxes_pairwise_bev(const float* boxes_a, int na, const float* boxes_b, int nb, int mode, float* out, void* stream) {
+  BTC_CHECK_ARG(na >= 0 && nb >= 0 && (mode == 0 || mode == 1), "btc_boxes_pairwise_bev: bad arguments");
+  if (na == 0 || nb == 0) return BTC_OK;
+  dim3 grid(btc_cdiv(nb, 16), btc_cdiv(na, 16));
+  pairwise_bev<<<grid, 256, 0, (hipStream_t)stream>>>(boxes_a, na, boxes_b, nb, mode, out);
+  BTC_LAUNCH_CHECK();
+  return BTC_OK;
+}
+
+extern "C" size_t btc_nms_ws_bytes(int n) {
+  const size_t cb = (size_t)(n + 63) / 64;
+  return btc_align((size_t)(n > 0 ? n : 1) * cb * sizeof(unsigned long long));
+}
+
+extern "C" int btc_nms(const float* boxes_sorted, int n, float thresh, int rotated, long long* keep, int32_t* d_num_keep, void* ws,
+                       size_t ws_bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  BTC_CHECK_ARG(n >= 0, "btc_nms: bad size");
+  BTC_CHECK_ARG(ws_bytes >= btc_nms_ws_bytes(n), "btc_nms: workspace too small");
+  if (n == 0) {
+    BTC_HIP(hipMemsetAsync(d_num_keep, 0, sizeof(int32_t), stream));
+    return BTC_OK;
+  }
+  const int cb = (n + 63) / 64;
+  BTC_CHECK_ARG((size_t)cb * 8 <= 64 * 1024, "btc_nms: %d boxes exceed the removal words that fit the LDS (max 524288)", n);
+  unsigned long long* mask = (unsigned long long*)ws;
+  nms_mask<<<dim3(cb, cb), 64, 0, stream>>>(boxes_sorted, n, thresh, rotated, mask);
+  BTC_LAUNCH_CHECK();
+  nms_reduce<<<1, 256, (size_t)cb * 8, stream>>>(mask, n, keep, d_num_keep);
+  BTC_LAUNCH_CHECK();
+  return BTC_OK;
+}

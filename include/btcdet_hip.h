@@ -308,6 +308,23 @@ int btc_occ_loss_bwd(const float* logit, const float* res, const float* res_targ
                      const uint8_t* cls_mask, const float* cls_w, const uint8_t* reg_mask, const float* reg_w, int B,
                      long long ncell, float beta, const float* norms2, const float* grad2, float* d_logit, float* d_res, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Rotated BEV overlap / IoU and NMS (SURVEY.md §8f row 1, next to the hot path).  Replaces the compiled module
+ * btcdet.ops.iou3d_nms.iou3d_nms_cuda (/root/reference/btcdet/ops/iou3d_nms/src/iou3d_nms.cpp:40-188:
+ * boxes_overlap_bev_gpu, boxes_iou_bev_gpu, nms_gpu, nms_normal_gpu; kernels iou3d_nms_kernel.cu:107-362).
+ * boxes: (N,7) float32 [x, y, z, dx, dy, dz, heading].
+ *   btc_boxes_pairwise_bev : out (na, nb) = overlap area (mode 0) or BEV IoU (mode 1)
+ *   btc_nms                : boxes already sorted by descending score; box j > i is suppressed by a kept box i when
+ *                            iou(i, j) > thresh (rotated = 1: rotated BEV IoU, 0: axis-aligned, the "normal" variant);
+ *                            keep (n) int64 gets the kept positions ascending, *d_num_keep (device int32) their number.
+ *                            The suppression mask stays in `ws` on the device (the reference copies it to the host and
+ *                            walks it there); nothing is synchronised.
+ * ------------------------------------------------------------------------------------------------ */
+int btc_boxes_pairwise_bev(const float* boxes_a, int na, const float* boxes_b, int nb, int mode, float* out, void* stream);
+size_t btc_nms_ws_bytes(int n);
+int btc_nms(const float* boxes_sorted, int n, float thresh, int rotated, long long* keep, int32_t* d_num_keep, void* ws,
+            size_t ws_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

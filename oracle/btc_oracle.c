@@ -329,3 +329,124 @@ void orc_dense(const float* feat, const int* indices, int n, int C, int B, const
     for (int ch = 0; ch < C; ++ch) out[((size_t)c[0] * C + ch) * vol + sp] = feat[(size_t)i * C + ch];
   }
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* Rotated BEV overlap / IoU and NMS.  Restates, in float32 like the      */
+/* reference's kernels, /root/reference/btcdet/ops/iou3d_nms/src/iou3d_nms_kernel.cu:           */
+/*   box_overlap :107-233 (edge intersections :66-98 + corners inside the other box :55-64,     */
+/*   ordered by atan2 about their centroid :101-103 with a bubble sort :198-208, fan area),     */
+/*   iou_bev :235-243, nms_kernel :268-309 + the host reduction iou3d_nms.cpp:104-136,          */
+/*   iou_normal / nms_normal_kernel :312-362.                                                   */
+/* PARITY UNPINNED: the reference's own CPU twin (iou3d_cpu.cpp) includes cuda.h and torch      */
+/* headers and cannot be built here, and the reference holds no test vectors for these ops;     */
+/* tests/test_oracle_iou3d.py pins this restatement against an independent float64 polygon      */
+/* clipper and closed-form cases instead.  boxes are (N,7) [x, y, z, dx, dy, dz, heading].      */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct { float x, y; } orc_pt;
+
+static float orc_cross3(orc_pt p1, orc_pt p2, orc_pt p0) { return (p1.x - p0.x) * (p2.y - p0.y) - (p2.x - p0.x) * (p1.y - p0.y); }
+
+static int orc_in_box2d(const float* box, orc_pt p) {
+  const float margin = 1e-2f;
+  float c = cosf(-box[6]), s = sinf(-box[6]);
+  float rx = (p.x - box[0]) * c + (p.y - box[1]) * (-s);
+  float ry = (p.x - box[0]) * s + (p.y - box[1]) * c;
+  return fabsf(rx) < box[3] / 2 + margin && fabsf(ry) < box[4] / 2 + margin;
+}
+
+static int orc_seg_intersection(orc_pt p1, orc_pt p0, orc_pt q1, orc_pt q0, orc_pt* ans) {
+  if (!(fminf(p0.x, p1.x) <= fmaxf(q0.x, q1.x) && fminf(q0.x, q1.x) <= fmaxf(p0.x, p1.x) &&
+        fminf(p0.y, p1.y) <= fmaxf(q0.y, q1.y) && fminf(q0.y, q1.y) <= fmaxf(p0.y, p1.y)))
+    return 0;
+  float s1 = orc_cross3(q0, p1, p0), s2 = orc_cross3(p1, q1, p0), s3 = orc_cross3(p0, q1, q0), s4 = orc_cross3(q1, p1, q0);
+  if (!(s1 * s2 > 0 && s3 * s4 > 0)) return 0;
+  float s5 = orc_cross3(q1, p1, p0);
+  if (fabsf(s5 - s1) > 1e-8f) {
+    ans->x = (s5 * q0.x - s1 * q1.x) / (s5 - s1);
+    ans->y = (s5 * q0.y - s1 * q1.y) / (s5 - s1);
+  } else {
+    float a0 = p0.y - p1.y, b0 = p1.x - p0.x, c0 = p0.x * p1.y - p1.x * p0.y;
+    float a1 = q0.y - q1.y, b1 = q1.x - q0.x, c1 = q0.x * q1.y - q1.x * q0.y;
+    float D = a0 * b1 - a1 * b0;
+    ans->x = (b0 * c1 - b1 * c0) / D;
+    ans->y = (a1 * c0 - a0 * c1) / D;
+  }
+  return 1;
+}
+
+static void orc_corners(const float* box, orc_pt* c /* 5 */) {
+  float hx = box[3] / 2, hy = box[4] / 2, co = cosf(box[6]), si = sinf(box[6]);
+  const float lx[4] = {box[0] - hx, box[0] + hx, box[0] + hx, box[0] - hx};
+  const float ly[4] = {box[1] - hy, box[1] - hy, box[1] + hy, box[1] + hy};
+  for (int k = 0; k < 4; ++k) {
+    c[k].x = (lx[k] - box[0]) * co + (ly[k] - box[1]) * (-si) + box[0];
+    c[k].y = (lx[k] - box[0]) * si + (ly[k] - box[1]) * co + box[1];
+  }
+  c[4] = c[0];
+}
+
+float orc_box_overlap_bev(const float* a, const float* b) {
+  orc_pt ca[5], cb[5], pts[16], ctr = {0.f, 0.f};
+  orc_corners(a, ca);
+  orc_corners(b, cb);
+  int cnt = 0;
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j)
+      if (orc_seg_intersection(ca[i + 1], ca[i], cb[j + 1], cb[j], &pts[cnt])) {
+        ctr.x += pts[cnt].x; ctr.y += pts[cnt].y;
+        ++cnt;
+      }
+  for (int k = 0; k < 4; ++k) {
+    if (orc_in_box2d(a, cb[k])) { ctr.x += cb[k].x; ctr.y += cb[k].y; pts[cnt++] = cb[k]; }
+    if (orc_in_box2d(b, ca[k])) { ctr.x += ca[k].x; ctr.y += ca[k].y; pts[cnt++] = ca[k]; }
+  }
+  ctr.x /= cnt; ctr.y /= cnt;  /* cnt == 0: the loops below do not run (as in the reference) */
+  for (int j = 0; j < cnt - 1; ++j)
+    for (int i = 0; i < cnt - j - 1; ++i)
+      if (atan2f(pts[i].y - ctr.y, pts[i].x - ctr.x) > atan2f(pts[i + 1].y - ctr.y, pts[i + 1].x - ctr.x)) {
+        orc_pt t = pts[i]; pts[i] = pts[i + 1]; pts[i + 1] = t;
+      }
+  float area = 0.f;
+  for (int k = 0; k < cnt - 1; ++k) {
+    float ax = pts[k].x - pts[0].x, ay = pts[k].y - pts[0].y, bx = pts[k + 1].x - pts[0].x, by = pts[k + 1].y - pts[0].y;
+    area += ax * by - ay * bx;
+  }
+  return fabsf(area) / 2.0f;
+}
+
+float orc_iou_bev(const float* a, const float* b) {
+  float sa = a[3] * a[4], sb = b[3] * b[4], so = orc_box_overlap_bev(a, b);
+  return so / fmaxf(sa + sb - so, 1e-8f);
+}
+
+static float orc_iou_normal(const float* a, const float* b) {
+  float left = fmaxf(a[0] - a[3] / 2, b[0] - b[3] / 2), right = fminf(a[0] + a[3] / 2, b[0] + b[3] / 2);
+  float top = fmaxf(a[1] - a[4] / 2, b[1] - b[4] / 2), bottom = fminf(a[1] + a[4] / 2, b[1] + b[4] / 2);
+  float w = fmaxf(right - left, 0.f), h = fmaxf(bottom - top, 0.f), inter = w * h;
+  return inter / fmaxf(a[3] * a[4] + b[3] * b[4] - inter, 1e-8f);
+}
+
+/* mode 0: overlap area, 1: BEV IoU; out (na, nb) */
+void orc_boxes_pairwise_bev(const float* boxes_a, int na, const float* boxes_b, int nb, int mode, float* out) {
+  for (int i = 0; i < na; ++i)
+    for (int j = 0; j < nb; ++j)
+      out[(size_t)i * nb + j] = mode ? orc_iou_bev(boxes_a + 7 * i, boxes_b + 7 * j) : orc_box_overlap_bev(boxes_a + 7 * i, boxes_b + 7 * j);
+}
+
+/* greedy NMS over boxes already sorted by descending score: box j > i is suppressed by a kept box i when iou > thresh.    */
+/* rotated = 0: axis-aligned IoU (nms_normal).  keep gets the kept positions in ascending order; returns their number.     */
+int orc_nms(const float* boxes, int n, float thresh, int rotated, long long* keep) {
+  unsigned char* removed = (unsigned char*)calloc((size_t)(n > 0 ? n : 1), 1);
+  int nk = 0;
+  for (int i = 0; i < n; ++i) {
+    if (removed[i]) continue;
+    keep[nk++] = i;
+    for (int j = i + 1; j < n; ++j) {
+      if (removed[j]) continue;
+      float v = rotated ? orc_iou_bev(boxes + 7 * i, boxes + 7 * j) : orc_iou_normal(boxes + 7 * i, boxes + 7 * j);
+      if (v > thresh) removed[j] = 1;
+    }
+  }
+  free(removed);
+  return nk;
+}

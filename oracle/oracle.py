@@ -261,3 +261,42 @@ def bf16_round(x):
     out = r.view(np.float32).copy()
     out[np.isnan(x)] = np.nan
     return out.reshape(x.shape)
+
+
+# ---- rotated BEV overlap / IoU / NMS (parity unpinned, see btc_oracle.c) ----
+def boxes_overlap_bev(boxes_a, boxes_b, iou=False):
+    a = np.ascontiguousarray(boxes_a, dtype=np.float32).reshape(-1, 7)
+    b = np.ascontiguousarray(boxes_b, dtype=np.float32).reshape(-1, 7)
+    out = np.zeros((a.shape[0], b.shape[0]), dtype=np.float32)
+    lib().orc_boxes_pairwise_bev(_fp(a), a.shape[0], _fp(b), b.shape[0], int(bool(iou)), _fp(out))
+    return out
+
+
+def boxes_iou_bev(boxes_a, boxes_b):
+    return boxes_overlap_bev(boxes_a, boxes_b, iou=True)
+
+
+def boxes_iou3d(boxes_a, boxes_b):
+    """iou3d_nms_utils.boxes_iou3d_gpu:48-78: BEV overlap x height overlap over the union volume"""
+    a = np.asarray(boxes_a, dtype=np.float32).reshape(-1, 7)
+    b = np.asarray(boxes_b, dtype=np.float32).reshape(-1, 7)
+    ov = boxes_overlap_bev(a, b)
+    hmax = np.minimum((a[:, 2] + a[:, 5] / 2)[:, None], (b[:, 2] + b[:, 5] / 2)[None, :])
+    hmin = np.maximum((a[:, 2] - a[:, 5] / 2)[:, None], (b[:, 2] - b[:, 5] / 2)[None, :])
+    o3 = ov * np.clip(hmax - hmin, 0, None)
+    va, vb = (a[:, 3] * a[:, 4] * a[:, 5])[:, None], (b[:, 3] * b[:, 4] * b[:, 5])[None, :]
+    return (o3 / np.clip(va + vb - o3, 1e-6, None)).astype(np.float32)
+
+
+def nms(boxes, scores, thresh, pre_maxsize=None, rotated=True):
+    """iou3d_nms_utils.nms_gpu / nms_normal_gpu :81-115: stable descending sort, greedy suppression; returns kept ORIGINAL indices"""
+    boxes = np.ascontiguousarray(boxes, dtype=np.float32).reshape(-1, 7)
+    order = np.argsort(-np.asarray(scores, dtype=np.float32), kind="stable")
+    if pre_maxsize is not None:
+        order = order[:pre_maxsize]
+    sb = np.ascontiguousarray(boxes[order])
+    keep = np.zeros((max(sb.shape[0], 1),), dtype=np.int64)
+    L = lib()
+    L.orc_nms.restype = ctypes.c_int
+    n = L.orc_nms(_fp(sb), sb.shape[0], ctypes.c_float(thresh), int(bool(rotated)), keep.ctypes.data_as(ctypes.c_void_p))
+    return order[keep[:n]]

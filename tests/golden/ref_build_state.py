@@ -45,7 +45,9 @@ class _EasyDict(dict):
         except KeyError: raise AttributeError(k)
 _mod("easydict", EasyDict=_EasyDict)
 _mod("skimage"); _mod("skimage.draw", line_aa=None); _mod("skimage.io")
-for n in ["btcdet.ops.roiaware_pool3d.roiaware_pool3d_cuda","btcdet.ops.iou3d_nms.iou3d_nms_cuda","btcdet.ops.pointnet2.pointnet2_stack.pointnet2_stack_cuda","btcdet.ops.pointnet2.pointnet2_batch.pointnet2_batch_cuda"]:
+from btcdet_amd import iou3d_nms as _amd_nms
+_amd_nms.install_as_iou3d_nms_cuda()  # the reference's iou3d_nms_utils.py binds to this stand-in for its compiled module
+for n in ["btcdet.ops.roiaware_pool3d.roiaware_pool3d_cuda","btcdet.ops.pointnet2.pointnet2_stack.pointnet2_stack_cuda","btcdet.ops.pointnet2.pointnet2_batch.pointnet2_batch_cuda"]:
     _mod(n)
 import yaml
 cfg = yaml.safe_load(open(os.path.join(REF,"tools/cfgs/model_configs/btcdet_kitti_car.yaml")))
@@ -68,4 +70,7 @@ ds.depth_downsample_factor=None
 net=BtcNet(model_cfg=cfg.MODEL, num_class=len(cfg.CLASS_NAMES), dataset=ds, full_config=cfg)
 sd={k:list(v.shape) for k,v in net.state_dict().items()}
 sys.stdout = sys.__stdout__
-print(json.dumps({"n": len(sd), "keys": sd}))
+from btcdet.ops.iou3d_nms import iou3d_nms_utils as _ref_nms_utils
+_nms_bound = (_ref_nms_utils.iou3d_nms_cuda is _amd_nms.iou3d_nms_cuda and
+              all(hasattr(_ref_nms_utils.iou3d_nms_cuda, f) for f in ("boxes_overlap_bev_gpu", "boxes_iou_bev_gpu", "nms_gpu", "nms_normal_gpu", "boxes_iou_bev_cpu")))
+print(json.dumps({"n": len(sd), "keys": sd, "iou3d_nms_utils_bound_to_btcdet_amd": bool(_nms_bound)}))

@@ -118,7 +118,10 @@ def test_reference_btcnet_builds_on_this_spconv_and_hot_path_state_dict_matches(
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, os.path.join(root, "tests", "golden", "ref_build_state.py")], capture_output=True, timeout=600)
     assert out.returncode == 0, out.stderr.decode()[-2000:]
-    ref = json.loads(out.stdout.decode().strip().splitlines()[-1])["keys"]
+    res = json.loads(out.stdout.decode().strip().splitlines()[-1])
+    # the reference's iou3d_nms_utils.py imported with its compiled module resolved to btcdet_amd.iou3d_nms.iou3d_nms_cuda
+    assert res["iou3d_nms_utils_bound_to_btcdet_amd"] is True
+    ref = res["keys"]
     assert len(ref) > 300  # the whole detector built, incl. the out-of-scope 2-D backbone and heads
     hot = {k: v for k, v in ref.items() if k.startswith(HOT)}
     mine = _hot_path_state()
