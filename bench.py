@@ -59,7 +59,8 @@ def build_batches(n_batches, rank, device, batch_size=2, profile="kitti"):
     batches = []
     for i in range(n_batches):
         seeds = rank_seeds(rank, i, batch_size)
-        b = synth.make_batch(seeds, profile=profile)
+        kw = {"az_step": float(os.environ["BTC_BENCH_AZ_STEP"])} if os.environ.get("BTC_BENCH_AZ_STEP") else {}  # tiny scenes: host-cost probe
+        b = synth.make_batch(seeds, profile=profile, **kw)
         batches.append({
             "batch_size": batch_size,
             "points5": torch.from_numpy(b["points"]).to(device),                       # [b,x,y,z,i] (collate layout)

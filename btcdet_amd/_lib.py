@@ -133,20 +133,24 @@ def check(rc, what):
         raise BtcHipError(f"{what} failed (code {rc}): {msg}")
 
 
+_raw_stream = torch._C._cuda_getCurrentRawStream
+_cur_device = torch._C._cuda_getDevice
+
+
 def stream_ptr():
-    """the current HIP stream of the current device as a void* (raw query: ~10x cheaper than torch.cuda.current_stream())"""
-    return vp(torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()))
+    """the current HIP stream of the current device as an integer handle (raw query: ~10x cheaper than
+    torch.cuda.current_stream()); ctypes converts it to the void* the ABI takes"""
+    return _raw_stream(_cur_device())
 
 
 def ptr(t):
-    """Device pointer of a contiguous CUDA(HIP) tensor, or NULL for None."""
+    """device address of a contiguous GPU tensor (None -> NULL).  Plain int / None: every entry point declares c_void_p
+    argtypes, and this is called ~600 times per step on the launch-rate-bound path."""
     if t is None:
-        return vp(0)
-    if not t.is_cuda:
-        raise BtcHipError("expected a tensor on the GPU (HIP) device")
-    if not t.is_contiguous():
-        raise BtcHipError("expected a contiguous tensor")
-    return vp(t.data_ptr())
+        return None
+    if not (t.is_cuda and t.is_contiguous()):
+        raise BtcHipError("expected a contiguous tensor on the GPU (HIP) device")
+    return t.data_ptr()
 
 
 _I3_CACHE = {}

@@ -67,6 +67,23 @@ class fixSparseConv3d(spconv.SparseConv3d):
         self.weight.data.fill_(defaultvalue)
 
 
+def _strided(seq):
+    """first sparse layer of a SparseSequential stage if it builds its own (strided / transposed / dilating) rulebook"""
+    m = seq[0]
+    while isinstance(m, spconv.SparseSequential):
+        m = m[0]
+    return m if isinstance(m, spconv.SparseConvolution) and not m.subm and not m.inverse else None
+
+
+def _chain_lookahead(stages):
+    """stage i's rulebook-building layer announces stage i+1's: its row count starts on the side stream as soon as the level
+    it consumes exists (spconv/ops.py LOOKAHEAD).  Plain attribute, not a submodule registration."""
+    layers = [l for l in (_strided(s) for s in stages) if l is not None]
+    for a, b in zip(layers[:-1], layers[1:]):
+        a.__dict__['lookahead'] = (b,)
+    return layers[0] if layers else None
+
+
 def _seq(specs, norm_fn):
     """specs: list of (cin, cout, k, dict(kwargs)) -> SparseSequential of post_act_blocks"""
     return spconv.SparseSequential(*[post_act_block(ci, co, k, norm_fn=norm_fn, **kw) for ci, co, k, kw in specs])
@@ -95,6 +112,7 @@ class VoxelBackBoneDeconv(nn.Module):
         self.deconv5 = _seq([(c[1], c[1], 3, dict(stride=2, padding=1, indice_key='spconv5', conv_type='spdeconv')),
                              (c[1], c[1], 3, dict(padding=1, indice_key='subm5'))], norm_fn)
         self.num_point_features = c[1]
+        _chain_lookahead([self.conv1, self.conv2, self.conv3, self.deconv4, self.deconv5])
 
     def forward(self, batch_dict):
         voxel_features, voxel_coords = batch_dict['voxel_features'], batch_dict['voxel_coords'].int()
@@ -182,6 +200,10 @@ class VoxelBackBone8xOcc(nn.Module):
                 setattr(self, 'squeeze_z_conv%d' % (i + 1), spconv.SparseSequential(post_act_block(
                     ch, ch // 2, 3, norm_fn=norm_fn, padding=1, indice_key='submsqueez%d' % (i + 1), conv_type='subm2d')))
         self._build_combine_net(norm_fn, c, self.out_feat_type[4])
+        stages = [self.conv2, self.conv3, self.conv4, self.conv_out]
+        if getattr(self, "squeezeBev", None) is not None:
+            stages.append(self.squeezeBev)
+        self.__dict__['_first_strided'] = _chain_lookahead(stages)
 
     def _build_occ_net(self, kind, i):
         """occupancy-code side branch at level i (1..3): maxpool / learned / fixed-mean / avg (spconv_backbone.py:793-866)"""
@@ -263,12 +285,16 @@ class VoxelBackBone8xOcc(nn.Module):
             feats = feats.to(self.feature_dtype)
         bs = batch_dict['batch_size']
         x = spconv.SparseConvTensor(features=feats, indices=coords, spatial_shape=self.sparse_shape, batch_size=bs)
+        if self._first_strided is not None:  # conv2's row count runs beside conv1 (rulebook lookahead, spconv/ops.py)
+            self._first_strided.prefetch(coords, self.sparse_shape, bs, x.indice_dict)
         n_occ = len(self.occ_conv_exec)
         x1 = self.conv1(x)
         occ = None
         if n_occ > 0:
             occ = spconv.SparseConvTensor(features=batch_dict["occ_voxel_features"], indices=coords,
                                           spatial_shape=self.sparse_shape, batch_size=bs)
+            # rulebooks are pure functions of (indices, geometry): the side branch's pools share the main branch's builds
+            occ.indice_dict["__geometry_cache__"] = x.indice_dict.setdefault("__geometry_cache__", {})
             if self.occ_conv_exec[0]:
                 x1 = self.sparse_cat([x1, occ])
                 if self.out_att[0]:

@@ -19,21 +19,39 @@ def _ws(device, C):
     return buf, need
 
 
+def bn_forward(x, weight, bias, running_mean, running_var, num_batches_tracked, use_batch, momentum, eps, relu):
+    """y = [relu](batchnorm(x)); returns (y, mean, rstd).  Running statistics / num_batches_tracked are updated in the kernel
+    when given (training)."""
+    N, C = x.shape
+    y = torch.empty_like(x)
+    stats = torch.empty((2, C), dtype=torch.float32, device=x.device)  # one allocation for mean | rstd
+    mean, rstd = stats[0], stats[1]
+    ws, need = _ws(x.device, C)
+    fwd = lib().btc_bn_relu_fwd_bf16 if x.dtype == torch.bfloat16 else lib().btc_bn_relu_fwd
+    check(fwd(ptr(x), N, C, ptr(weight), ptr(bias), ptr(running_mean), ptr(running_var), ptr(num_batches_tracked), float(momentum),
+              float(eps), int(use_batch), int(relu), ptr(y), ptr(mean), ptr(rstd), ptr(ws), need, stream_ptr()), "btc_bn_relu_fwd")
+    return y, mean, rstd
+
+
+def bn_backward(x, y, dy, weight, mean, rstd, use_batch, relu):
+    N, C = x.shape
+    dx = torch.empty_like(x)
+    dparam = torch.empty((2, C), dtype=torch.float32, device=x.device)  # one allocation for dgamma | dbeta
+    dgamma, dbeta = dparam[0], dparam[1]
+    ws, need = _ws(x.device, C)
+    bwd = lib().btc_bn_relu_bwd_bf16 if x.dtype == torch.bfloat16 else lib().btc_bn_relu_bwd
+    check(bwd(ptr(x), ptr(y), ptr(dy), N, C, ptr(weight), ptr(mean), ptr(rstd), int(use_batch), int(relu), ptr(dx), ptr(dgamma), ptr(dbeta),
+              ptr(ws), need, stream_ptr()), "btc_bn_relu_bwd")
+    return dx, dgamma, dbeta
+
+
 class BatchNormReLUFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, running_mean, running_var, num_batches_tracked, training, momentum, eps, relu):
         x = x.contiguous()
-        N, C = x.shape
-        y = torch.empty_like(x)
-        mean = torch.empty((C,), dtype=torch.float32, device=x.device)
-        rstd = torch.empty((C,), dtype=torch.float32, device=x.device)
-        ws, need = _ws(x.device, C)
         use_batch = bool(training or running_mean is None)
-        fwd = lib().btc_bn_relu_fwd_bf16 if x.dtype == torch.bfloat16 else lib().btc_bn_relu_fwd
-        check(fwd(ptr(x), N, C, ptr(weight), ptr(bias), ptr(running_mean) if training else ptr(running_mean),
-                                    ptr(running_var), ptr(num_batches_tracked) if training else None, float(momentum), float(eps),
-                                    int(use_batch), int(relu), ptr(y), ptr(mean), ptr(rstd), ptr(ws), need, stream_ptr()),
-              "btc_bn_relu_fwd")
+        y, mean, rstd = bn_forward(x, weight, bias, running_mean, running_var, num_batches_tracked if training else None, use_batch,
+                                   momentum, eps, relu)
         ctx.save_for_backward(x, y, weight, mean, rstd)
         ctx.flags = (use_batch, bool(relu))
         return y
@@ -43,14 +61,7 @@ class BatchNormReLUFunction(torch.autograd.Function):
         x, y, weight, mean, rstd = ctx.saved_tensors
         use_batch, relu = ctx.flags
         dy = (dy if dy.dtype == x.dtype else dy.to(x.dtype)).contiguous()
-        N, C = x.shape
-        dx = torch.empty_like(x)
-        dgamma = torch.empty((C,), dtype=torch.float32, device=x.device)
-        dbeta = torch.empty((C,), dtype=torch.float32, device=x.device)
-        ws, need = _ws(x.device, C)
-        bwd = lib().btc_bn_relu_bwd_bf16 if x.dtype == torch.bfloat16 else lib().btc_bn_relu_bwd
-        check(bwd(ptr(x), ptr(y), ptr(dy), N, C, ptr(weight), ptr(mean), ptr(rstd), int(use_batch), int(relu),
-                                    ptr(dx), ptr(dgamma), ptr(dbeta), ptr(ws), need, stream_ptr()), "btc_bn_relu_bwd")
+        dx, dgamma, dbeta = bn_backward(x, y, dy, weight, mean, rstd, use_batch, relu)
         return dx, (dgamma if weight is not None else None), (dbeta if weight is not None else None), None, None, None, None, None, None, None
 
 

@@ -12,6 +12,7 @@ from .tensor import SparseConvTensor
 import torch as _torch
 
 nn_float32 = _torch.float32
+FUSE_CONV_BN = True  # hand the BatchNorm (+ReLU) that follows a sparse conv to the conv's autograd node
 FUSE_BN_RELU = True  # set False to run BatchNorm1d / ReLU through torch (used by the parity test)
 
 
@@ -70,6 +71,7 @@ class SparseSequential(SparseModule):
 
     def forward(self, input):
         from . import fused_bn
+        from .conv import SparseConvolution
         mods = list(self._modules.values())
         i = 0
         while i < len(mods):
@@ -77,7 +79,16 @@ class SparseSequential(SparseModule):
             i += 1
             if is_spconv_module(module):
                 assert isinstance(input, SparseConvTensor)
-                input = module(input)
+                nxt = mods[i] if i < len(mods) else None
+                f = input.features
+                if FUSE_CONV_BN and FUSE_BN_RELU and nxt is not None and isinstance(module, SparseConvolution) and fused_bn.fusable(nxt) and f.is_cuda \
+                        and f.dtype in (nn_float32, _torch.bfloat16) and f.shape[0] != 0:
+                    # conv -> BatchNorm1d (-> ReLU): one autograd node, the same kernels (ops.SparseConvBNReLUFunction)
+                    relu = i + 1 < len(mods) and type(mods[i + 1]) is nn.ReLU
+                    input = module(input, fuse_bn=(nxt, relu))
+                    i += 1 + int(relu)
+                else:
+                    input = module(input)
             else:
                 if isinstance(input, SparseConvTensor):
                     if input.indices.shape[0] != 0:

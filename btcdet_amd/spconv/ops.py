@@ -6,6 +6,8 @@ SparseInverseConv3d / SparseMaxPool3d (/root/reference/btcdet/models/backbones_3
 spconv_backbone.py:12-29).  The rulebook is kept as two dense neighbour maps (see
 include/btcdet_hip.h); ``Rulebook.indice_pairs()`` gives spconv's (2,K,N)/(K,) view on demand.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -62,7 +64,7 @@ class _NoSpan(object):
 
 PROFILE = None  # set to a LaunchProfile() to instrument
 CAPTURE = None  # set to a list to record (features, weight, bias, map_fwd, map_bwd) of every sparse conv (tools/conv_bench.py)
-OVERLAP_WGRAD = True  # run wgrad on a side stream concurrently with dgrad (backward of every sparse conv)
+OVERLAP_WGRAD = os.environ.get("BTC_OVERLAP_WGRAD", "1") != "0"  # run wgrad on a side stream concurrently with dgrad (backward of every sparse conv)
 _SIDE = {}
 
 
@@ -76,10 +78,11 @@ def _side_stream(device):
 _NOSPAN = _NoSpan()
 
 
-def _span(name, nbytes_fn):
+def _span(name, cost_fn, args):
+    """profile span around a launch; cost_fn(*args) is evaluated only while profiling (no closure on the hot path)"""
     if PROFILE is None:
         return _NOSPAN
-    r = nbytes_fn()
+    r = cost_fn(*args)
     return PROFILE.span(name, r[0], r[1], r[2] if len(r) > 2 else None)
 
 
@@ -155,7 +158,7 @@ def build_rulebook(indices, batch_size, spatial_shape, ksize, stride=1, padding=
     mode = MODE_SUBM if subm else (MODE_TRANSPOSE if transpose else MODE_CONV)
     out_sh = np.zeros(3, dtype=np.int32)
     check(L.btc_out_shape(i3p(in_sh), i3p(k3), i3p(s3), i3p(p3), i3p(d3), i3p(op3), mode, i3p(out_sh)), "btc_out_shape")
-    if PROFILE is not None:
+    if PROFILE is not None and subm:
         return _build_rulebook_profiled(indices, batch_size, spatial_shape, ksize, stride, padding, dilation, out_padding,
                                         subm, transpose)
     return _build_rulebook(indices, batch_size, in_sh, out_sh, k3, s3, p3, d3, K, mode, subm)
@@ -190,20 +193,121 @@ def _build_rulebook(indices, batch_size, in_sh, out_sh, k3, s3, p3, d3, K, mode,
         check(L.btc_rulebook_subm(ptr(indices), n, int(batch_size), i3p(in_sh), i3p(k3), i3p(d3), ptr(nbr_out),
                                   ptr(nbr_in), ptr(ws), ws_bytes, stream_ptr()), "btc_rulebook_subm")
         return Rulebook(indices, indices, nbr_out, nbr_in, in_sh.tolist(), out_sh.tolist(), K, mode)
+    return _start_conv_rulebook(indices, batch_size, in_sh, out_sh, k3, s3, p3, d3, K, mode, None).finish()
+
+
+# ---- strided / transposed rulebooks in two halves -------------------------------------------------------------------
+# The number of output rows of such a rulebook is data dependent, and every tensor downstream is sized by it: the host
+# must read it back (spconv syncs at the same point).  A blocking read-back drains the stream -- and after each one the
+# host has to refill the queue kernel by kernel while the GPU runs dry (13 read-backs per step made ~2 of 10.6 ms idle).
+# So the COUNT half (mark reachable cells, rank them, n_out -> pinned host memory) runs on a side stream as soon as the
+# input indices exist -- a layer's `lookahead` list names the strided layers that consume its output level
+# (spconv/conv.py) -- and the FILL half runs in the consumer's forward: by then the count is long finished, the host
+# waits on its event only (not on the main stream) and keeps running ahead of the GPU.
+# Measured at KITTI size: neutral (10.7-11.0 ms per step either way) -- the step is bound by the host's launch rate, not by
+# these gaps -- so the lookahead is OFF by default (BTC_LOOKAHEAD=1 enables it); the two-half structure and the shared
+# geometry cache stay.
+LOOKAHEAD = os.environ.get("BTC_LOOKAHEAD", "0") != "0"  # opt-in: measured neutral while the step is host-bound (see below)
+_RB_STREAM = {}
+_PIN = {}
+
+
+def _rb_stream(device):
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    st = _RB_STREAM.get(key)
+    if st is None:
+        st = torch.cuda.Stream(device=device)
+        _RB_STREAM[key] = st
+    return st
+
+
+def _pinned_slot():
+    """one int32 of pinned host memory from a small ring (a slot is reused 256 read-backs later)"""
+    ring = _PIN.get("ring")
+    if ring is None:
+        ring = _PIN["ring"] = torch.zeros((256,), dtype=torch.int32).pin_memory()
+        _PIN["next"] = 0
+    i = _PIN["next"]
+    _PIN["next"] = (i + 1) % 256
+    return ring[i:i + 1]
+
+
+class PendingRulebook(object):
+    """count half issued, fill half outstanding"""
+
+    def __init__(self, indices, batch_size, in_sh, out_sh, k3, s3, p3, d3, K, mode, ws, ws_bytes, host_n, event, prof_ev):
+        self.args = (indices, batch_size, in_sh, out_sh, k3, s3, p3, d3, K, mode)
+        self.ws, self.ws_bytes, self.host_n, self.event, self.prof_ev = ws, ws_bytes, host_n, event, prof_ev
+
+    def finish(self):
+        indices, batch_size, in_sh, out_sh, k3, s3, p3, d3, K, mode = self.args
+        dev, n, L = indices.device, indices.shape[0], lib()
+        self.event.synchronize()                        # host: the count (on the side stream) is done; the main stream is not drained
+        n_out = int(self.host_n[0])
+        main = torch.cuda.current_stream()
+        main.wait_event(self.event)                     # device: the fill below reads the bitmap / ranks the count wrote
+        self.ws.record_stream(main)
+        prof = PROFILE
+        if prof is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        out_indices = torch.empty((n_out, 4), dtype=torch.int32, device=dev)
+        nbr_out = torch.empty((n_out, K), dtype=torch.int32, device=dev)
+        nbr_in = torch.empty((n, K), dtype=torch.int32, device=dev)
+        check(L.btc_rulebook_conv_fill(ptr(indices), n, int(batch_size), i3p(in_sh), i3p(out_sh), i3p(k3), i3p(s3),
+                                       i3p(p3), i3p(d3), mode, n_out, ptr(out_indices), ptr(nbr_out), ptr(nbr_in), ptr(self.ws),
+                                       self.ws_bytes, stream_ptr()), "btc_rulebook_conv_fill")
+        rb = Rulebook(out_indices, indices, nbr_out, nbr_in, in_sh.tolist(), out_sh.tolist(), K, mode)
+        if prof is not None:
+            e1.record()
+            c0, c1 = self.prof_ev
+            # SURVEY.md §8d, rulebook: 16 N_in + 16 N_out + 8 sum_k P_k bytes (attributed to the fill half; the count half adds time only)
+            info = dict(rows=rb.n_out, n_in=rb.n_in, K=rb.K, pairs=_num_pairs(rb.nbr_out), mode=rb.mode, out_shape=list(rb.out_shape))
+            prof.records.append(("rulebook", c0, c1, 0, 0, dict(info, half="count")))
+            prof.records.append(("rulebook", e0, e1, 16 * rb.n_in + 16 * rb.n_out + 8 * _num_pairs(rb.nbr_out), 0, dict(info, half="fill")))
+        self.ws = None
+        return rb
+
+
+def _start_conv_rulebook(indices, batch_size, in_sh, out_sh, k3, s3, p3, d3, K, mode, side):
+    """issue the count half on `side` (a torch stream) or, side=None, on the current stream"""
+    dev, n, L = indices.device, indices.shape[0], lib()
     ws_bytes = L.btc_rulebook_conv_ws_bytes(int(batch_size), i3p(out_sh))
-    ws = workspace(ws_bytes, dev)
-    d_n_out = torch.empty((1,), dtype=torch.int32, device=dev)
-    check(L.btc_rulebook_conv_count(ptr(indices), n, int(batch_size), i3p(in_sh), i3p(out_sh), i3p(k3), i3p(s3),
-                                    i3p(p3), i3p(d3), mode, ptr(d_n_out), ptr(ws), ws_bytes, stream_ptr()),
-          "btc_rulebook_conv_count")
-    n_out = int(d_n_out.item())  # the one read-back of the build (spconv syncs here too)
-    out_indices = torch.empty((n_out, 4), dtype=torch.int32, device=dev)
-    nbr_out = torch.empty((n_out, K), dtype=torch.int32, device=dev)
-    nbr_in = torch.empty((n, K), dtype=torch.int32, device=dev)
-    check(L.btc_rulebook_conv_fill(ptr(indices), n, int(batch_size), i3p(in_sh), i3p(out_sh), i3p(k3), i3p(s3),
-                                   i3p(p3), i3p(d3), mode, n_out, ptr(out_indices), ptr(nbr_out), ptr(nbr_in), ptr(ws),
-                                   ws_bytes, stream_ptr()), "btc_rulebook_conv_fill")
-    return Rulebook(out_indices, indices, nbr_out, nbr_in, in_sh.tolist(), out_sh.tolist(), K, mode)
+    main = torch.cuda.current_stream()
+    if side is not None:
+        side.wait_stream(main)                          # the indices are produced on the main stream
+    ctx = torch.cuda.stream(side) if side is not None else _NOSPAN
+    prof_ev = None
+    with ctx:
+        if PROFILE is not None:
+            prof_ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            prof_ev[0].record()
+        ws = workspace(ws_bytes, dev)
+        d_n_out = torch.empty((1,), dtype=torch.int32, device=dev)
+        check(L.btc_rulebook_conv_count(ptr(indices), n, int(batch_size), i3p(in_sh), i3p(out_sh), i3p(k3), i3p(s3),
+                                        i3p(p3), i3p(d3), mode, ptr(d_n_out), ptr(ws), ws_bytes, stream_ptr()),
+              "btc_rulebook_conv_count")
+        if prof_ev is not None:
+            prof_ev[1].record()
+        host_n = _pinned_slot()
+        host_n.copy_(d_n_out, non_blocking=True)
+        event = torch.cuda.Event()
+        event.record()
+    if side is not None:
+        indices.record_stream(side)
+    return PendingRulebook(indices, batch_size, in_sh, out_sh, k3, s3, p3, d3, K, mode, ws, ws_bytes, host_n, event, prof_ev)
+
+
+def prefetch_conv_rulebook(indices, batch_size, spatial_shape, ksize, stride=1, padding=0, dilation=1, out_padding=0, transpose=False):
+    """count half of a strided / transposed rulebook on the side stream; .finish() on the result gives the Rulebook"""
+    indices = _as_idx(indices)
+    k3, s3, p3, d3, op3 = i3(ksize), i3(stride), i3(padding), i3(dilation), i3(out_padding)
+    in_sh = i3([int(v) for v in spatial_shape])
+    K = int(np.prod(k3))
+    mode = MODE_TRANSPOSE if transpose else MODE_CONV
+    out_sh = np.zeros(3, dtype=np.int32)
+    check(lib().btc_out_shape(i3p(in_sh), i3p(k3), i3p(s3), i3p(p3), i3p(d3), i3p(op3), mode, i3p(out_sh)), "btc_out_shape")
+    return _start_conv_rulebook(indices, batch_size, in_sh, out_sh, k3, s3, p3, d3, K, mode, _rb_stream(indices.device))
 
 
 def get_indice_pairs(indices, batch_size, spatial_shape, ksize=3, stride=1, padding=0, dilation=1, out_padding=0,
@@ -240,6 +344,64 @@ def _wgrad_cost(nbr, n_res, K, cin, cout, act_bytes=4):
     return act_bytes * P * (cin + cout) + 4 * K * cin * cout, 2 * P * cin * cout, dict(rows=n_res, K=K, cred=cin, cres=cout, pairs=P)
 
 
+# wgrad goes to a side HIP stream (fork / join with events, no host sync) beside dgrad only for layers with at least this
+# many rows: below it the step is bound by the host's launch rate (tools/host_phases.py: 10.1 ms per step on 2.5 k-point
+# scenes against 10.7 ms on 57 k-point ones) and the stream switches cost more host time than the overlap returns
+OVERLAP_MIN_ROWS = 60000
+
+
+def _conv_forward(features, w, b, map_fwd):
+    bf = features.dtype == torch.bfloat16
+    cin, cout = w.shape[-2], w.shape[-1]
+    K = map_fwd.shape[1]
+    if w.numel() != K * cin * cout or features.shape[1] != cin:
+        raise _lib.BtcHipError(f"weight {tuple(w.shape)} does not match K={K}, Cin={features.shape[1]}")
+    n_res = map_fwd.shape[0]
+    out = torch.empty((n_res, cout), dtype=features.dtype, device=features.device)
+    fwd = lib().btc_conv_fwd_bf16 if bf else lib().btc_conv_fwd
+    with _span("conv_apply", _conv_cost, (map_fwd, n_res, K, cin, cout, 2 if bf else 4)):
+        check(fwd(ptr(features), ptr(w), ptr(b), ptr(map_fwd), n_res, K, cin, cout, ptr(out), stream_ptr()), "btc_conv_fwd")
+    return out
+
+
+def _conv_backward(features, w, map_fwd, map_bwd, grad_out, wshape, need_din, need_dw):
+    bf = features.dtype == torch.bfloat16
+    cin, cout = w.shape[-2], w.shape[-1]
+    K = map_fwd.shape[1]
+    L = lib()
+    wgrad, dgrad = (L.btc_conv_wgrad_bf16, L.btc_conv_dgrad_bf16) if bf else (L.btc_conv_wgrad, L.btc_conv_dgrad)
+    din = dw = None
+    dev = grad_out.device
+    n_res, n_src = map_fwd.shape[0], map_bwd.shape[0]
+    side = _side_stream(dev) if (need_din and need_dw and OVERLAP_WGRAD and PROFILE is None and n_res >= OVERLAP_MIN_ROWS) else None
+    if need_dw:
+        ws_bytes = L.btc_conv_wgrad_ws_bytes(n_res, K, cin, cout, n_src)
+        if side is not None:
+            main = torch.cuda.current_stream()
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                dw = torch.empty(wshape, dtype=torch.float32, device=dev)
+                ws = workspace(ws_bytes, dev)
+                check(wgrad(ptr(features), ptr(grad_out), ptr(map_fwd), n_res, ptr(map_bwd), n_src, K, cin, cout, ptr(dw), ptr(ws), ws_bytes,
+                            stream_ptr()), "btc_conv_wgrad")
+            for t in (features, grad_out, map_fwd, map_bwd):
+                t.record_stream(side)
+        else:
+            dw = torch.empty(wshape, dtype=torch.float32, device=dev)
+            ws = workspace(ws_bytes, dev)
+            with _span("conv_wgrad", _wgrad_cost, (map_fwd, n_res, K, cin, cout, 2 if bf else 4)):
+                check(wgrad(ptr(features), ptr(grad_out), ptr(map_fwd), n_res, ptr(map_bwd), n_src, K, cin, cout, ptr(dw), ptr(ws), ws_bytes,
+                            stream_ptr()), "btc_conv_wgrad")
+    if need_din:
+        din = torch.empty((n_src, cin), dtype=features.dtype, device=dev)
+        with _span("conv_apply", _conv_cost, (map_bwd, n_src, K, cout, cin, 2 if bf else 4)):
+            check(dgrad(ptr(grad_out), ptr(w), ptr(map_bwd), n_src, K, cin, cout, ptr(din), stream_ptr()), "btc_conv_dgrad")
+    if side is not None:
+        torch.cuda.current_stream().wait_stream(side)  # join: dW is consumed on the main stream from here on
+        dw.record_stream(torch.cuda.current_stream())
+    return din, dw
+
+
 class SparseConvFunction(torch.autograd.Function):
     """indice_conv / indice_subm_conv / indice_inverse_conv in one function.
     map_fwd (n_res,K): source row gathered by result row i at offset k; map_bwd (n_src,K) its transpose."""
@@ -247,18 +409,9 @@ class SparseConvFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, features, weight, bias, map_fwd, map_bwd):
         features = _actc(features)
-        bf = features.dtype == torch.bfloat16
         w = _f32c(weight)
-        cin, cout = w.shape[-2], w.shape[-1]
-        K = map_fwd.shape[1]
-        if w.numel() != K * cin * cout or features.shape[1] != cin:
-            raise _lib.BtcHipError(f"weight {tuple(w.shape)} does not match K={K}, Cin={features.shape[1]}")
-        n_res = map_fwd.shape[0]
-        out = torch.empty((n_res, cout), dtype=features.dtype, device=features.device)
         b = _f32c(bias) if bias is not None else None
-        fwd = lib().btc_conv_fwd_bf16 if bf else lib().btc_conv_fwd
-        with _span("conv_apply", lambda: _conv_cost(map_fwd, n_res, K, cin, cout, 2 if bf else 4)):
-            check(fwd(ptr(features), ptr(w), ptr(b), ptr(map_fwd), n_res, K, cin, cout, ptr(out), stream_ptr()), "btc_conv_fwd")
+        out = _conv_forward(features, w, b, map_fwd)
         if CAPTURE is not None:
             CAPTURE.append((features, w, b, map_fwd, map_bwd))
         ctx.save_for_backward(features, w, map_fwd, map_bwd)
@@ -269,48 +422,43 @@ class SparseConvFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out):
         features, w, map_fwd, map_bwd = ctx.saved_tensors
-        bf = features.dtype == torch.bfloat16
         grad_out = _actc(grad_out if grad_out.dtype == features.dtype else grad_out.to(features.dtype))
-        cin, cout = w.shape[-2], w.shape[-1]
-        K = map_fwd.shape[1]
-        L = lib()
-        wgrad, dgrad = (L.btc_conv_wgrad_bf16, L.btc_conv_dgrad_bf16) if bf else (L.btc_conv_wgrad, L.btc_conv_dgrad)
-        din = dw = db = None
-        need_din, need_dw = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
-        # dgrad and wgrad are independent and each is latency bound on its own at BtcDet's sizes: wgrad goes to a side
-        # HIP stream (fork / join with events, no host sync) so the two kernels share the GPU
-        side = _side_stream(grad_out.device) if (need_din and need_dw and OVERLAP_WGRAD and PROFILE is None) else None
-        if need_dw:
-            n_res, n_src = map_fwd.shape[0], map_bwd.shape[0]
-            ws_bytes = L.btc_conv_wgrad_ws_bytes(n_res, K, cin, cout, n_src)
-            if side is not None:
-                main = torch.cuda.current_stream()
-                side.wait_stream(main)
-                with torch.cuda.stream(side):
-                    dw = torch.empty(ctx.wshape, dtype=torch.float32, device=grad_out.device)
-                    ws = workspace(ws_bytes, grad_out.device)
-                    check(wgrad(ptr(features), ptr(grad_out), ptr(map_fwd), n_res, ptr(map_bwd), n_src, K, cin, cout,
-                                           ptr(dw), ptr(ws), ws_bytes, stream_ptr()), "btc_conv_wgrad")
-                for t in (features, grad_out, map_fwd, map_bwd):
-                    t.record_stream(side)
-            else:
-                dw = torch.empty(ctx.wshape, dtype=torch.float32, device=grad_out.device)
-                ws = workspace(ws_bytes, grad_out.device)
-                with _span("conv_wgrad", lambda: _wgrad_cost(map_fwd, n_res, K, cin, cout, 2 if bf else 4)):
-                    check(wgrad(ptr(features), ptr(grad_out), ptr(map_fwd), n_res, ptr(map_bwd), n_src, K, cin, cout,
-                                           ptr(dw), ptr(ws), ws_bytes, stream_ptr()), "btc_conv_wgrad")
-        if need_din:
-            n_src = map_bwd.shape[0]
-            din = torch.empty((n_src, cin), dtype=features.dtype, device=grad_out.device)
-            with _span("conv_apply", lambda: _conv_cost(map_bwd, n_src, K, cout, cin, 2 if bf else 4)):
-                check(dgrad(ptr(grad_out), ptr(w), ptr(map_bwd), n_src, K, cin, cout, ptr(din), stream_ptr()),
-                      "btc_conv_dgrad")
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = grad_out.sum(0, dtype=torch.float32)
-        if side is not None:
-            torch.cuda.current_stream().wait_stream(side)  # join: dW is consumed on the main stream from here on
-            dw.record_stream(torch.cuda.current_stream())
+        din, dw = _conv_backward(features, w, map_fwd, map_bwd, grad_out, ctx.wshape, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        db = grad_out.sum(0, dtype=torch.float32) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
         return din, dw, db, None, None
+
+
+class SparseConvBNReLUFunction(torch.autograd.Function):
+    """sparse conv -> BatchNorm1d (-> ReLU) as ONE autograd node (the reference's post_act_block triple,
+    spconv_backbone.py:33-43): same kernels as SparseConvFunction + fused_bn.BatchNormReLUFunction, half the Python / autograd
+    dispatch per layer -- the step is bound by the host's launch rate at BtcDet's sizes."""
+
+    @staticmethod
+    def forward(ctx, features, weight, bias, map_fwd, map_bwd, gamma, beta, running_mean, running_var, nbt, training, momentum, eps, relu):
+        from . import fused_bn
+        features = _actc(features)
+        w = _f32c(weight)
+        b = _f32c(bias) if bias is not None else None
+        x = _conv_forward(features, w, b, map_fwd)
+        if CAPTURE is not None:
+            CAPTURE.append((features, w, b, map_fwd, map_bwd))
+        use_batch = bool(training or running_mean is None)
+        y, mean, rstd = fused_bn.bn_forward(x, gamma, beta, running_mean, running_var, nbt if training else None, use_batch, momentum, eps, relu)
+        ctx.save_for_backward(features, w, map_fwd, map_bwd, x, y, gamma, mean, rstd)
+        ctx.flags = (bias is not None, tuple(weight.shape), use_batch, bool(relu))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import fused_bn
+        features, w, map_fwd, map_bwd, x, y, gamma, mean, rstd = ctx.saved_tensors
+        has_bias, wshape, use_batch, relu = ctx.flags
+        dy = (dy if dy.dtype == x.dtype else dy.to(x.dtype)).contiguous()
+        dx, dgamma, dbeta = fused_bn.bn_backward(x, y, dy, gamma, mean, rstd, use_batch, relu)
+        din, dw = _conv_backward(features, w, map_fwd, map_bwd, dx, wshape, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        db = dx.sum(0, dtype=torch.float32) if (has_bias and ctx.needs_input_grad[2]) else None
+        affine = gamma is not None
+        return (din, dw, db, None, None, dgamma if affine else None, dbeta if affine else None, None, None, None, None, None, None, None)
 
 
 class SparseMaxPoolFunction(torch.autograd.Function):
@@ -374,6 +522,20 @@ def indice_conv(features, weight, bias, rulebook, inverse=False):
     if inverse:
         return SparseConvFunction.apply(features, weight, bias, rulebook.nbr_in, rulebook.nbr_out)
     return SparseConvFunction.apply(features, weight, bias, rulebook.nbr_out, rulebook.nbr_in)
+
+
+def indice_conv_bn_relu(features, weight, bias, rulebook, bn, relu, inverse=False):
+    """indice_conv followed by bn (a fusable BatchNorm1d, see fused_bn.fusable) and optionally ReLU, as one autograd node"""
+    if features.dtype == torch.bfloat16 and (weight.shape[-2] % 16 or weight.shape[-1] % 16):
+        from . import fused_bn
+        return fused_bn.batch_norm_relu(bn, indice_conv(features, weight, bias, rulebook, inverse), relu)
+    training = bn.training or not bn.track_running_stats
+    nbt = bn.num_batches_tracked if (bn.training and bn.track_running_stats) else None
+    rm = bn.running_mean if bn.track_running_stats else None
+    rv = bn.running_var if bn.track_running_stats else None
+    maps = (rulebook.nbr_in, rulebook.nbr_out) if inverse else (rulebook.nbr_out, rulebook.nbr_in)
+    return SparseConvBNReLUFunction.apply(features, weight, bias, maps[0], maps[1], bn.weight, bn.bias, rm, rv, nbt, training, bn.momentum,
+                                          bn.eps, relu)
 
 
 def indice_maxpool(features, rulebook):

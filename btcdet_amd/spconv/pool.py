@@ -3,7 +3,7 @@ reduction.  Call site: /root/reference/btcdet/models/backbones_3d/spconv_backbon
 import torch
 
 from . import ops
-from .conv import _ntuple
+from .conv import _ntuple, geometry_key
 from .modules import SparseModule
 from .tensor import SparseConvTensor
 
@@ -30,15 +30,28 @@ class SparseMaxPool(SparseModule):
         else:
             out_spatial_shape = spatial_shape
         indices = input.indices
-        if self.ndim == 2:
-            indices = torch.cat([indices[:, :1], torch.zeros_like(indices[:, :1]), indices[:, 1:]], dim=1)
-            spatial_shape = [1] + spatial_shape
-        rb = ops.build_rulebook(indices, input.batch_size, spatial_shape, self._k3(self.kernel_size, 1),
-                                self._k3(self.stride, 1), self._k3(self.padding, 0), self._k3(self.dilation, 1), 0,
-                                self.subm, False)
+        # same geometry cache as the convolutions (conv.py): a pool beside a SparseConv3d with the same kernel / stride /
+        # padding on the same index tensor shares its rulebook (and a prefetched count half is finished here)
+        geom = input.indice_dict.setdefault("__geometry_cache__", {})
+        gkey = geometry_key(indices, spatial_shape, self.kernel_size, self.dilation, self.subm, False, self.stride, self.padding,
+                            [0] * self.ndim)
+        hit = geom.get(gkey, None)
+        if hit is not None:
+            rb = hit[0]
+            if isinstance(rb, ops.PendingRulebook):
+                rb = rb.finish()
+                geom[gkey] = (rb, indices)
+        else:
+            idx4, shape3 = indices, spatial_shape
+            if self.ndim == 2:
+                idx4 = torch.cat([indices[:, :1], torch.zeros_like(indices[:, :1]), indices[:, 1:]], dim=1)
+                shape3 = [1] + spatial_shape
+            rb = ops.build_rulebook(idx4, input.batch_size, shape3, self._k3(self.kernel_size, 1), self._k3(self.stride, 1),
+                                    self._k3(self.padding, 0), self._k3(self.dilation, 1), 0, self.subm, False)
+            geom[gkey] = (rb, indices)
         out_features = ops.indice_maxpool(input.features, rb)
         outids = rb.out_indices
-        if self.ndim == 2:
+        if self.ndim == 2 and outids.shape[1] == 4:
             outids = torch.cat([outids[:, :1], outids[:, 2:]], dim=1).contiguous()
         out_tensor = SparseConvTensor(out_features, outids, out_spatial_shape, input.batch_size)
         out_tensor.indice_dict = input.indice_dict
