@@ -143,25 +143,53 @@ def _as_idx(indices):
     return indices.contiguous()
 
 
+class _Geometry(object):
+    """host-side constants of one rulebook geometry, built once: int32[3] arrays, their ctypes pointers, K, mode, output
+    shape (the launch-rate-bound forward builds ~18 rulebooks per step; re-deriving these cost ~25 us each)"""
+    __slots__ = ("in_sh", "out_sh", "k3", "s3", "p3", "d3", "K", "mode", "subm", "p_in", "p_out", "p_k", "p_s", "p_p", "p_d",
+                 "in_list", "out_list", "ws_bytes")
+
+    def __init__(self, spatial_shape, ksize, stride, padding, dilation, out_padding, subm, transpose):
+        self.k3, self.s3, self.p3, self.d3 = i3(ksize), i3(stride), i3(padding), i3(dilation)
+        op3 = i3(out_padding)
+        self.in_sh = i3([int(v) for v in spatial_shape])
+        self.K = int(np.prod(self.k3))
+        self.subm = bool(subm)
+        self.mode = MODE_SUBM if subm else (MODE_TRANSPOSE if transpose else MODE_CONV)
+        out_sh = np.zeros(3, dtype=np.int32)
+        check(lib().btc_out_shape(i3p(self.in_sh), i3p(self.k3), i3p(self.s3), i3p(self.p3), i3p(self.d3), i3p(op3), self.mode,
+                                  out_sh.ctypes.data_as(_lib.c_i32p)), "btc_out_shape")
+        self.out_sh = i3(out_sh)
+        self.p_in, self.p_out, self.p_k = i3p(self.in_sh), i3p(self.out_sh), i3p(self.k3)
+        self.p_s, self.p_p, self.p_d = i3p(self.s3), i3p(self.p3), i3p(self.d3)
+        self.in_list, self.out_list = self.in_sh.tolist(), self.out_sh.tolist()
+        self.ws_bytes = {}  # batch size -> conv workspace bytes
+
+
+_GEOMETRIES = {}
+
+
+def _geometry(spatial_shape, ksize, stride, padding, dilation, out_padding, subm, transpose):
+    def t3(v):
+        return (int(v),) * 3 if isinstance(v, (int, np.integer)) else tuple(int(x) for x in v)
+    key = (tuple(int(v) for v in spatial_shape), t3(ksize), t3(stride), t3(padding), t3(dilation), t3(out_padding), bool(subm), bool(transpose))
+    g = _GEOMETRIES.get(key)
+    if g is None:
+        g = _GEOMETRIES[key] = _Geometry(spatial_shape, ksize, stride, padding, dilation, out_padding, subm, transpose)
+    return g
+
+
 def build_rulebook(indices, batch_size, spatial_shape, ksize, stride=1, padding=0, dilation=1, out_padding=0,
                    subm=False, transpose=False):
     """ops.get_indice_pairs replacement.  indices (N,4) int32 [b,z,y,x] on the GPU."""
     indices = _as_idx(indices)
     if indices.dim() != 2 or indices.shape[1] != 4:
         raise _lib.BtcHipError(f"indices must be (N,4) [b,z,y,x], got {tuple(indices.shape)}")
-    dev = indices.device
-    n = indices.shape[0]
-    L = lib()
-    k3, s3, p3, d3, op3 = i3(ksize), i3(stride), i3(padding), i3(dilation), i3(out_padding)
-    in_sh = i3([int(v) for v in spatial_shape])
-    K = int(np.prod(k3))
-    mode = MODE_SUBM if subm else (MODE_TRANSPOSE if transpose else MODE_CONV)
-    out_sh = np.zeros(3, dtype=np.int32)
-    check(L.btc_out_shape(i3p(in_sh), i3p(k3), i3p(s3), i3p(p3), i3p(d3), i3p(op3), mode, i3p(out_sh)), "btc_out_shape")
+    g = _geometry(spatial_shape, ksize, stride, padding, dilation, out_padding, subm, transpose)
     if PROFILE is not None and subm:
         return _build_rulebook_profiled(indices, batch_size, spatial_shape, ksize, stride, padding, dilation, out_padding,
                                         subm, transpose)
-    return _build_rulebook(indices, batch_size, in_sh, out_sh, k3, s3, p3, d3, K, mode, subm)
+    return _build_rulebook(indices, batch_size, g)
 
 
 def _build_rulebook_profiled(indices, batch_size, spatial_shape, ksize, stride, padding, dilation, out_padding, subm, transpose):
@@ -181,19 +209,46 @@ def _build_rulebook_profiled(indices, batch_size, spatial_shape, ksize, stride, 
     return rb
 
 
-def _build_rulebook(indices, batch_size, in_sh, out_sh, k3, s3, p3, d3, K, mode, subm):
+def _build_rulebook(indices, batch_size, g):
     dev = indices.device
     n = indices.shape[0]
     L = lib()
-    if subm:
-        nbr_out = torch.empty((n, K), dtype=torch.int32, device=dev)
-        nbr_in = torch.empty((n, K), dtype=torch.int32, device=dev)
+    K = g.K
+    if g.subm:
+        nbr = torch.empty((2, n, K), dtype=torch.int32, device=dev)  # one allocation for nbr_out | nbr_in
+        nbr_out, nbr_in = nbr[0], nbr[1]
         ws_bytes = L.btc_rulebook_subm_ws_bytes(n)
         ws = workspace(ws_bytes, dev)
-        check(L.btc_rulebook_subm(ptr(indices), n, int(batch_size), i3p(in_sh), i3p(k3), i3p(d3), ptr(nbr_out),
-                                  ptr(nbr_in), ptr(ws), ws_bytes, stream_ptr()), "btc_rulebook_subm")
-        return Rulebook(indices, indices, nbr_out, nbr_in, in_sh.tolist(), out_sh.tolist(), K, mode)
-    return _start_conv_rulebook(indices, batch_size, in_sh, out_sh, k3, s3, p3, d3, K, mode, None).finish()
+        check(L.btc_rulebook_subm(ptr(indices), n, int(batch_size), g.p_in, g.p_k, g.p_d, ptr(nbr_out), ptr(nbr_in), ptr(ws), ws_bytes,
+                                  stream_ptr()), "btc_rulebook_subm")
+        return Rulebook(indices, indices, nbr_out, nbr_in, g.in_list, g.out_list, K, g.mode)
+    if PROFILE is not None:
+        return _start_conv_rulebook(indices, batch_size, g, None).finish()
+    # synchronous build: count, one blocking 4-byte read-back (spconv syncs at the same point), fill
+    ws_bytes = _conv_ws_bytes(g, batch_size)
+    ws = workspace(ws_bytes, dev)
+    d_n_out = torch.empty((1,), dtype=torch.int32, device=dev)
+    st = stream_ptr()
+    check(L.btc_rulebook_conv_count(ptr(indices), n, int(batch_size), g.p_in, g.p_out, g.p_k, g.p_s, g.p_p, g.p_d, g.mode, ptr(d_n_out),
+                                    ptr(ws), ws_bytes, st), "btc_rulebook_conv_count")
+    return _fill_conv_rulebook(indices, batch_size, g, int(d_n_out.item()), ws, ws_bytes)
+
+
+def _conv_ws_bytes(g, batch_size):
+    b = g.ws_bytes.get(int(batch_size))
+    if b is None:
+        b = g.ws_bytes[int(batch_size)] = lib().btc_rulebook_conv_ws_bytes(int(batch_size), g.p_out)
+    return b
+
+
+def _fill_conv_rulebook(indices, batch_size, g, n_out, ws, ws_bytes):
+    dev, n, K = indices.device, indices.shape[0], g.K
+    out_indices = torch.empty((n_out, 4), dtype=torch.int32, device=dev)
+    nbr_out = torch.empty((n_out, K), dtype=torch.int32, device=dev)
+    nbr_in = torch.empty((n, K), dtype=torch.int32, device=dev)
+    check(lib().btc_rulebook_conv_fill(ptr(indices), n, int(batch_size), g.p_in, g.p_out, g.p_k, g.p_s, g.p_p, g.p_d, g.mode, n_out,
+                                       ptr(out_indices), ptr(nbr_out), ptr(nbr_in), ptr(ws), ws_bytes, stream_ptr()), "btc_rulebook_conv_fill")
+    return Rulebook(out_indices, indices, nbr_out, nbr_in, g.in_list, g.out_list, K, g.mode)
 
 
 # ---- strided / transposed rulebooks in two halves -------------------------------------------------------------------
@@ -235,13 +290,11 @@ def _pinned_slot():
 class PendingRulebook(object):
     """count half issued, fill half outstanding"""
 
-    def __init__(self, indices, batch_size, in_sh, out_sh, k3, s3, p3, d3, K, mode, ws, ws_bytes, host_n, event, prof_ev):
-        self.args = (indices, batch_size, in_sh, out_sh, k3, s3, p3, d3, K, mode)
+    def __init__(self, indices, batch_size, g, ws, ws_bytes, host_n, event, prof_ev):
+        self.indices, self.batch_size, self.g = indices, batch_size, g
         self.ws, self.ws_bytes, self.host_n, self.event, self.prof_ev = ws, ws_bytes, host_n, event, prof_ev
 
     def finish(self):
-        indices, batch_size, in_sh, out_sh, k3, s3, p3, d3, K, mode = self.args
-        dev, n, L = indices.device, indices.shape[0], lib()
         self.event.synchronize()                        # host: the count (on the side stream) is done; the main stream is not drained
         n_out = int(self.host_n[0])
         main = torch.cuda.current_stream()
@@ -251,13 +304,7 @@ class PendingRulebook(object):
         if prof is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        out_indices = torch.empty((n_out, 4), dtype=torch.int32, device=dev)
-        nbr_out = torch.empty((n_out, K), dtype=torch.int32, device=dev)
-        nbr_in = torch.empty((n, K), dtype=torch.int32, device=dev)
-        check(L.btc_rulebook_conv_fill(ptr(indices), n, int(batch_size), i3p(in_sh), i3p(out_sh), i3p(k3), i3p(s3),
-                                       i3p(p3), i3p(d3), mode, n_out, ptr(out_indices), ptr(nbr_out), ptr(nbr_in), ptr(self.ws),
-                                       self.ws_bytes, stream_ptr()), "btc_rulebook_conv_fill")
-        rb = Rulebook(out_indices, indices, nbr_out, nbr_in, in_sh.tolist(), out_sh.tolist(), K, mode)
+        rb = _fill_conv_rulebook(self.indices, self.batch_size, self.g, n_out, self.ws, self.ws_bytes)
         if prof is not None:
             e1.record()
             c0, c1 = self.prof_ev
@@ -269,13 +316,12 @@ class PendingRulebook(object):
         return rb
 
 
-def _start_conv_rulebook(indices, batch_size, in_sh, out_sh, k3, s3, p3, d3, K, mode, side):
+def _start_conv_rulebook(indices, batch_size, g, side):
     """issue the count half on `side` (a torch stream) or, side=None, on the current stream"""
     dev, n, L = indices.device, indices.shape[0], lib()
-    ws_bytes = L.btc_rulebook_conv_ws_bytes(int(batch_size), i3p(out_sh))
-    main = torch.cuda.current_stream()
+    ws_bytes = _conv_ws_bytes(g, batch_size)
     if side is not None:
-        side.wait_stream(main)                          # the indices are produced on the main stream
+        side.wait_stream(torch.cuda.current_stream())   # the indices are produced on the main stream
     ctx = torch.cuda.stream(side) if side is not None else _NOSPAN
     prof_ev = None
     with ctx:
@@ -284,9 +330,8 @@ def _start_conv_rulebook(indices, batch_size, in_sh, out_sh, k3, s3, p3, d3, K, 
             prof_ev[0].record()
         ws = workspace(ws_bytes, dev)
         d_n_out = torch.empty((1,), dtype=torch.int32, device=dev)
-        check(L.btc_rulebook_conv_count(ptr(indices), n, int(batch_size), i3p(in_sh), i3p(out_sh), i3p(k3), i3p(s3),
-                                        i3p(p3), i3p(d3), mode, ptr(d_n_out), ptr(ws), ws_bytes, stream_ptr()),
-              "btc_rulebook_conv_count")
+        check(L.btc_rulebook_conv_count(ptr(indices), n, int(batch_size), g.p_in, g.p_out, g.p_k, g.p_s, g.p_p, g.p_d, g.mode, ptr(d_n_out),
+                                        ptr(ws), ws_bytes, stream_ptr()), "btc_rulebook_conv_count")
         if prof_ev is not None:
             prof_ev[1].record()
         host_n = _pinned_slot()
@@ -295,19 +340,14 @@ def _start_conv_rulebook(indices, batch_size, in_sh, out_sh, k3, s3, p3, d3, K, 
         event.record()
     if side is not None:
         indices.record_stream(side)
-    return PendingRulebook(indices, batch_size, in_sh, out_sh, k3, s3, p3, d3, K, mode, ws, ws_bytes, host_n, event, prof_ev)
+    return PendingRulebook(indices, batch_size, g, ws, ws_bytes, host_n, event, prof_ev)
 
 
 def prefetch_conv_rulebook(indices, batch_size, spatial_shape, ksize, stride=1, padding=0, dilation=1, out_padding=0, transpose=False):
     """count half of a strided / transposed rulebook on the side stream; .finish() on the result gives the Rulebook"""
     indices = _as_idx(indices)
-    k3, s3, p3, d3, op3 = i3(ksize), i3(stride), i3(padding), i3(dilation), i3(out_padding)
-    in_sh = i3([int(v) for v in spatial_shape])
-    K = int(np.prod(k3))
-    mode = MODE_TRANSPOSE if transpose else MODE_CONV
-    out_sh = np.zeros(3, dtype=np.int32)
-    check(lib().btc_out_shape(i3p(in_sh), i3p(k3), i3p(s3), i3p(p3), i3p(d3), i3p(op3), mode, i3p(out_sh)), "btc_out_shape")
-    return _start_conv_rulebook(indices, batch_size, in_sh, out_sh, k3, s3, p3, d3, K, mode, _rb_stream(indices.device))
+    g = _geometry(spatial_shape, ksize, stride, padding, dilation, out_padding, False, transpose)
+    return _start_conv_rulebook(indices, batch_size, g, _rb_stream(indices.device))
 
 
 def get_indice_pairs(indices, batch_size, spatial_shape, ksize=3, stride=1, padding=0, dilation=1, out_padding=0,
