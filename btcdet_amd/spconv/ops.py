@@ -384,10 +384,11 @@ def _wgrad_cost(nbr, n_res, K, cin, cout, act_bytes=4):
     return act_bytes * P * (cin + cout) + 4 * K * cin * cout, 2 * P * cin * cout, dict(rows=n_res, K=K, cred=cin, cres=cout, pairs=P)
 
 
-# wgrad goes to a side HIP stream (fork / join with events, no host sync) beside dgrad only for layers with at least this
-# many rows: below it the step is bound by the host's launch rate (tools/host_phases.py: 10.1 ms per step on 2.5 k-point
-# scenes against 10.7 ms on 57 k-point ones) and the stream switches cost more host time than the overlap returns
-OVERLAP_MIN_ROWS = 60000
+# wgrad goes to a side HIP stream (fork / join with events, no host sync) beside dgrad for layers with at least this many
+# rows; on smaller layers the stream switches cost more host time than the overlap returns (the forward pass is bound by
+# the host's launch rate, the backward pass by the GPU: tools/host_phases.py).  Measured: 60000 -> 191, 20000 -> 194,
+# 0 -> 194 scenes/s
+OVERLAP_MIN_ROWS = int(os.environ.get("BTC_OVERLAP_MIN_ROWS", "20000"))
 
 
 def _conv_forward(features, w, b, map_fwd):
