@@ -173,14 +173,21 @@ __global__ __launch_bounds__(BN_T) void bn_bwd_stats(const float* __restrict__ x
       const float m = mean[c], rs = rstd[c];
       const long long stride = (long long)gridDim.x * S.rpi;
       long long r = (long long)blockIdx.x * S.rpi + rr;
-      for (; r + stride < S.N; r += 2 * stride) {  // 6 independent loads in flight
-        const long long i0 = r * S.C + c, i1 = (r + stride) * S.C + c;
-        float g0 = btc_ld1<BF>(dy, i0), g1 = btc_ld1<BF>(dy, i1), y0 = btc_ld1<BF>(y, i0), y1 = btc_ld1<BF>(y, i1), x0 = btc_ld1<BF>(x, i0),
-              x1 = btc_ld1<BF>(x, i1);
-        if (relu && !(y0 > 0.f)) g0 = 0.f;
-        if (relu && !(y1 > 0.f)) g1 = 0.f;
-        a += (double)g0 + (double)g1;
-        b += (double)g0 * ((x0 - m) * rs) + (double)g1 * ((x1 - m) * rs);
+      for (; r + 3 * stride < S.N; r += 4 * stride) {  // 12 independent loads in flight (the kernel is latency bound)
+        float g[4], yv[4], xv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const long long i = (r + u * stride) * S.C + c;
+          g[u] = btc_ld1<BF>(dy, i);
+          yv[u] = btc_ld1<BF>(y, i);
+          xv[u] = btc_ld1<BF>(x, i);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (relu && !(yv[u] > 0.f)) g[u] = 0.f;
+          a += (double)g[u];
+          b += (double)g[u] * ((xv[u] - m) * rs);
+        }
       }
       for (; r < S.N; r += stride) {
         float g = btc_ld1<BF>(dy, r * S.C + c);
@@ -286,6 +293,14 @@ BnShape bn_shape(int N, int C) {
   return S;
 }
 
+// bwd: three input streams per row and no dependent second pass behind it -> more, thinner workgroups
+int bn_grid_bwd(int N, const BnShape& S) {
+  int g = btc_cdiv(N, S.rpi * 16);
+  if (g > 512) g = 512;
+  if (g < 1) g = 1;
+  return g;
+}
+
 int bn_grid(int N, const BnShape& S) {
   int g = btc_cdiv(N, S.rpi * 64);  // >= 64 rows per thread-row before adding another workgroup: the last-arriver
   if (g > 256) g = 256;            // reduction walks all partials, so few, fat workgroups win at BtcDet's sizes
@@ -332,7 +347,7 @@ static int bn_bwd_impl(const float* x, const float* y, const float* dy, int N, i
   int32_t* counter = (int32_t*)ws;
   double* partial = (double*)((char*)ws + 256);
   BnShape S = bn_shape(N, C);
-  bn_bwd_stats<BF><<<bn_grid(N, S), BN_T, 0, stream>>>(x, y, dy, save_mean, save_rstd, S, relu, partial, counter, dgamma, dbeta);
+  bn_bwd_stats<BF><<<bn_grid_bwd(N, S), BN_T, 0, stream>>>(x, y, dy, save_mean, save_rstd, S, relu, partial, counter, dgamma, dbeta);
   BTC_LAUNCH_CHECK();
   long long total = (long long)N * C;
   if ((C & 3) == 0)
