@@ -62,6 +62,8 @@ _SIGS = {
     "btc_last_error": (ctypes.c_char_p, []),
     "btc_version": (ci, []),
     "btc_tune_set": (ci, [ci, ci]),
+    "btc_mean_vfe": (ci, [vp, vp, ci, ci, ci, ci, vp, vp]),
+    "btc_occ_vfe": (ci, [vp, vp, ci, ci, ci, ci, ci, vp, vp, vp]),
     "btc_boxes_pairwise_bev": (ci, [vp, ci, vp, ci, ci, vp, vp]),
     "btc_nms_ws_bytes": (sz, [ci]),
     "btc_nms": (ci, [vp, ci, ctypes.c_float, ci, vp, vp, vp, sz, vp]),

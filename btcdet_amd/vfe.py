@@ -7,6 +7,19 @@ the occupancy code channels)."""
 import torch
 import torch.nn as nn
 
+FUSED = True  # one HIP launch per encoder (csrc/vfe.hip) for float32 GPU inputs; False: the torch formulation below
+
+
+def _fusable(vox, num):
+    return FUSED and vox.is_cuda and vox.dtype == torch.float32 and vox.dim() == 3 and num.dtype in (torch.float32, torch.int32, torch.int64) \
+        and not vox.requires_grad
+
+
+def _num_arg(num):
+    if num.dtype == torch.int64:  # PassOccVox hands over int64 counts (as the reference's torch.unique does)
+        num = num.to(torch.int32)
+    return num.contiguous(), int(num.dtype == torch.float32)
+
 
 class VFETemplate(nn.Module):
     def __init__(self, model_cfg, **kwargs):
@@ -40,6 +53,15 @@ class MeanVFE(VFETemplate):
 
     def forward(self, batch_dict, **kwargs):
         vox, num = batch_dict['voxels'], batch_dict['voxel_num_points']
+        if not self.maxprob and self.OCC_CODE is None and _fusable(vox, num):
+            from ._lib import check, lib, ptr, stream_ptr
+            vox = vox.contiguous()
+            M, P, C = vox.shape
+            out = torch.empty((M, C), dtype=torch.float32, device=vox.device)
+            n, isf = _num_arg(num)
+            check(lib().btc_mean_vfe(ptr(vox), ptr(n), isf, M, P, C, ptr(out), stream_ptr()), "btc_mean_vfe")
+            batch_dict['voxel_features'] = out
+            return batch_dict
         normalizer = torch.clamp_min(num.view(-1, 1), min=1.0).type_as(vox)
         if not self.maxprob:
             batch_dict['voxel_features'] = (vox.sum(dim=1) / normalizer).contiguous()
@@ -81,6 +103,16 @@ class OccVFE(VFETemplate):
     def forward(self, batch_dict, **kwargs):
         vox, num = batch_dict['voxels'], batch_dict['voxel_num_points']
         R = self.num_raw_features
+        if _fusable(vox, num) and vox.shape[2] > R:
+            from ._lib import check, lib, ptr, stream_ptr
+            vox = vox.contiguous()
+            M, P, F = vox.shape
+            feat = torch.empty((M, F), dtype=torch.float32, device=vox.device)
+            occ = torch.empty((M, F - R), dtype=torch.float32, device=vox.device)
+            n, isf = _num_arg(num)
+            check(lib().btc_occ_vfe(ptr(vox), ptr(n), isf, M, P, F, R, ptr(feat), ptr(occ), stream_ptr()), "btc_occ_vfe")
+            batch_dict['voxel_features'], batch_dict['occ_voxel_features'] = feat, occ
+            return batch_dict
         mask = _slot_mask(num, vox.shape[1])
         is_occ = vox[:, :, -1] >= 0.05
         raw_mask, occ_mask = (~is_occ) & mask, is_occ & mask

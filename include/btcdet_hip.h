@@ -309,6 +309,19 @@ int btc_occ_loss_bwd(const float* logit, const float* res, const float* res_targ
                      long long ncell, float beta, const float* norms2, const float* grad2, float* d_logit, float* d_res, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Voxel feature encoders, one launch each.  Replace the torch arithmetic of
+ * /root/reference/btcdet/models/backbones_3d/vfe/mean_vfe.py:27-38 (maxprob = False) and occ_vfe.py:24-55.
+ * voxels (M,P,C) float32; num_points (M,) float32 (num_is_float = 1, as load_data_to_gpu leaves it) or int32 (0).
+ *   btc_mean_vfe : out (M,C) = sum over the P slots / max(count, 1)
+ *   btc_occ_vfe  : slots whose last channel is >= 0.05 are occupancy points; feat (M,F) = [mean of the R raw channels
+ *                  over the raw slots (over the occupancy slots for voxels holding only occupancy points) | max of the
+ *                  F - R code channels over ALL P slots]; occ (M,F-R) = those maxima
+ * ------------------------------------------------------------------------------------------------ */
+int btc_mean_vfe(const float* voxels, const void* num_points, int num_is_float, int M, int P, int C, float* out, void* stream);
+int btc_occ_vfe(const float* voxels, const void* num_points, int num_is_float, int M, int P, int F, int R, float* feat,
+                float* occ, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Rotated BEV overlap / IoU and NMS (SURVEY.md §8f row 1, next to the hot path).  Replaces the compiled module
  * btcdet.ops.iou3d_nms.iou3d_nms_cuda (/root/reference/btcdet/ops/iou3d_nms/src/iou3d_nms.cpp:40-188:
  * boxes_overlap_bev_gpu, boxes_iou_bev_gpu, nms_gpu, nms_normal_gpu; kernels iou3d_nms_kernel.cu:107-362).

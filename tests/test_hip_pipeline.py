@@ -66,6 +66,34 @@ def test_vfe_modules(G):
     np.testing.assert_array_equal(d["occ_voxel_features"].cpu().numpy(), g["occvfe_occ_voxel_features"])
 
 
+@pytest.mark.parametrize("num_dtype", [torch.float32, torch.int32, torch.int64])
+def test_vfe_kernels_equal_torch_formulation(num_dtype):
+    """csrc/vfe.hip (one launch per encoder) against the module's torch formulation (the restatement pinned by the goldens)"""
+    from btcdet_amd import vfe
+    from btcdet_amd.config import load_cfg
+    cfg = load_cfg()
+    torch.manual_seed(3)
+    M, P = 5000, 5
+    num = torch.randint(0, P + 1, (M,), device=DEV)
+    vox = torch.randn(M, P, 6, device=DEV)
+    vox[..., 4] = torch.rand(M, P, device=DEV) * (torch.rand(M, P, device=DEV) > 0.6)   # code channels: 0 for raw points
+    vox[..., 5] = (vox[..., 4] > 0).float()
+    vox = vox * (torch.arange(P, device=DEV).view(1, -1) < num.view(-1, 1)).unsqueeze(-1)  # padding slots are zero
+    occ = vfe.OccVFE(cfg.MODEL.VFE, num_point_features=6, data_cfg=cfg.DATA_CONFIG, maxprob=True)
+    mean = vfe.MeanVFE(cfg.MODEL.OCC.VFE, num_point_features=4, data_cfg=cfg.DATA_CONFIG, maxprob=False)
+    res = {}
+    for fused in (True, False):
+        vfe.FUSED = fused
+        try:
+            d = occ({"voxels": vox, "voxel_num_points": num.to(num_dtype)})
+            m = mean({"voxels": vox[..., :4].contiguous(), "voxel_num_points": num.to(num_dtype)})
+        finally:
+            vfe.FUSED = True
+        res[fused] = (d["voxel_features"], d["occ_voxel_features"], m["voxel_features"])
+    for a, b in zip(res[True], res[False]):
+        torch.testing.assert_close(a, b, rtol=1e-6, atol=1e-6)
+
+
 def reference_side_dict(g, bd, cfg, device):
     """batch_dict as the reference has it right after OccTargets3D + the synthetic head outputs (oracle = pinned)"""
     O = occ_oracle.OccOracle(cfg)
