@@ -149,11 +149,20 @@ class SparseConvolution(SparseModule):
         idx4 = indices
         if self.ndim == 2:
             idx4 = torch.cat([indices[:, :1], torch.zeros_like(indices[:, :1]), indices[:, 1:]], dim=1)
-        rb = ops.build_rulebook(idx4, batch_size, self._shape3(spatial_shape), self._k3(self.kernel_size, 1), self._k3(self.stride, 1),
-                                self._k3(self.padding, 0), self._k3(self.dilation, 1), self._k3(self.output_padding, 0), self.subm,
-                                self.transposed)
+        rb = ops.build_rulebook_g(idx4, batch_size, self._geometry(spatial_shape))
         geom[gkey] = (rb, indices)
         return rb
+
+    def _geometry(self, spatial_shape):
+        """ops._Geometry of this layer for an input shape (memoised: host-side constants and ctypes pointers)"""
+        key = tuple(int(v) for v in spatial_shape)
+        memo = self.__dict__.setdefault("_geometry_memo", {})
+        g = memo.get(key)
+        if g is None:
+            g = memo[key] = ops._geometry(self._shape3(spatial_shape), self._k3(self.kernel_size, 1), self._k3(self.stride, 1),
+                                          self._k3(self.padding, 0), self._k3(self.dilation, 1), self._k3(self.output_padding, 0), self.subm,
+                                          self.transposed)
+        return g
 
     def prefetch(self, indices, spatial_shape, batch_size, indice_dict):
         """start the count half of this layer's rulebook for `indices` (no-op for submanifold / inverse / 2-D / cached layers)"""

@@ -192,6 +192,14 @@ def build_rulebook(indices, batch_size, spatial_shape, ksize, stride=1, padding=
     return _build_rulebook(indices, batch_size, g)
 
 
+def build_rulebook_g(indices, batch_size, g):
+    """build_rulebook for a prepared geometry (the layers keep theirs, spconv/conv.py)"""
+    indices = _as_idx(indices)
+    if PROFILE is not None and g.subm:
+        return _build_rulebook_profiled(indices, batch_size, g.in_list, g.k3, g.s3, g.p3, g.d3, 0, True, False)
+    return _build_rulebook(indices, batch_size, g)
+
+
 def _build_rulebook_profiled(indices, batch_size, spatial_shape, ksize, stride, padding, dilation, out_padding, subm, transpose):
     global PROFILE
     prof, PROFILE = PROFILE, None
