@@ -129,6 +129,26 @@ def lib():
     return _lib
 
 
+_fast = False
+
+
+def fast():
+    """the compiled PyTorch binding (btcdet_amd/_btcfast*.so, csrc/binding.cpp) or None when it has not been built or
+    BTC_FASTPATH=0; the ctypes route above computes the same thing (it is the binding INTEGRATION.md documents)"""
+    global _fast
+    if _fast is False:
+        _fast = None
+        if os.environ.get("BTC_FASTPATH", "1") != "0":
+            try:
+                lib()  # load libbtcdet_hip.so first so that both bindings share one instance
+                from . import _btcfast
+                if _btcfast.abi_version() == lib().btc_version():
+                    _fast = _btcfast
+            except ImportError:
+                _fast = None
+    return _fast
+
+
 def check(rc, what):
     if rc != 0:
         msg = lib().btc_last_error().decode("utf-8", "replace")

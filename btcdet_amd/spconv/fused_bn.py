@@ -3,7 +3,7 @@
 state_dict keys stay the plain torch ones; only the arithmetic goes through btc_bn_relu_fwd / btc_bn_relu_bwd."""
 import torch
 
-from .._lib import check, lib, ptr, stream_ptr
+from .._lib import check, fast, lib, ptr, stream_ptr
 
 _WS = {}
 
@@ -20,29 +20,36 @@ def _ws(device, C):
 
 
 def bn_forward(x, weight, bias, running_mean, running_var, num_batches_tracked, use_batch, momentum, eps, relu):
-    """y = [relu](batchnorm(x)); returns (y, mean, rstd).  Running statistics / num_batches_tracked are updated in the kernel
-    when given (training)."""
+    """y = [relu](batchnorm(x)); returns (y, stats) with stats (2, C) = mean | rstd.  Running statistics / num_batches_tracked
+    are updated in the kernel when given (training)."""
     N, C = x.shape
-    y = torch.empty_like(x)
-    stats = torch.empty((2, C), dtype=torch.float32, device=x.device)  # one allocation for mean | rstd
-    mean, rstd = stats[0], stats[1]
     ws, need = _ws(x.device, C)
+    F = fast()
+    if F is not None:
+        return F.bn_fwd(x, weight, bias, running_mean, running_var, num_batches_tracked, bool(use_batch), float(momentum), float(eps),
+                        bool(relu), ws, need, stream_ptr())
+    y = torch.empty_like(x)
+    stats = torch.empty((2, C), dtype=torch.float32, device=x.device)
     fwd = lib().btc_bn_relu_fwd_bf16 if x.dtype == torch.bfloat16 else lib().btc_bn_relu_fwd
     check(fwd(ptr(x), N, C, ptr(weight), ptr(bias), ptr(running_mean), ptr(running_var), ptr(num_batches_tracked), float(momentum),
-              float(eps), int(use_batch), int(relu), ptr(y), ptr(mean), ptr(rstd), ptr(ws), need, stream_ptr()), "btc_bn_relu_fwd")
-    return y, mean, rstd
+              float(eps), int(use_batch), int(relu), ptr(y), ptr(stats[0]), ptr(stats[1]), ptr(ws), need, stream_ptr()), "btc_bn_relu_fwd")
+    return y, stats
 
 
-def bn_backward(x, y, dy, weight, mean, rstd, use_batch, relu):
+def bn_backward(x, y, dy, weight, stats, use_batch, relu):
+    """-> dx, dgamma, dbeta (the last two are rows of one (2, C) tensor)"""
     N, C = x.shape
-    dx = torch.empty_like(x)
-    dparam = torch.empty((2, C), dtype=torch.float32, device=x.device)  # one allocation for dgamma | dbeta
-    dgamma, dbeta = dparam[0], dparam[1]
     ws, need = _ws(x.device, C)
+    F = fast()
+    if F is not None:
+        dx, dparam = F.bn_bwd(x, y, dy, weight, stats, bool(use_batch), bool(relu), ws, need, stream_ptr())
+        return dx, dparam[0], dparam[1]
+    dx = torch.empty_like(x)
+    dparam = torch.empty((2, C), dtype=torch.float32, device=x.device)
     bwd = lib().btc_bn_relu_bwd_bf16 if x.dtype == torch.bfloat16 else lib().btc_bn_relu_bwd
-    check(bwd(ptr(x), ptr(y), ptr(dy), N, C, ptr(weight), ptr(mean), ptr(rstd), int(use_batch), int(relu), ptr(dx), ptr(dgamma), ptr(dbeta),
-              ptr(ws), need, stream_ptr()), "btc_bn_relu_bwd")
-    return dx, dgamma, dbeta
+    check(bwd(ptr(x), ptr(y), ptr(dy), N, C, ptr(weight), ptr(stats[0]), ptr(stats[1]), int(use_batch), int(relu), ptr(dx), ptr(dparam[0]),
+              ptr(dparam[1]), ptr(ws), need, stream_ptr()), "btc_bn_relu_bwd")
+    return dx, dparam[0], dparam[1]
 
 
 class BatchNormReLUFunction(torch.autograd.Function):
@@ -50,18 +57,18 @@ class BatchNormReLUFunction(torch.autograd.Function):
     def forward(ctx, x, weight, bias, running_mean, running_var, num_batches_tracked, training, momentum, eps, relu):
         x = x.contiguous()
         use_batch = bool(training or running_mean is None)
-        y, mean, rstd = bn_forward(x, weight, bias, running_mean, running_var, num_batches_tracked if training else None, use_batch,
-                                   momentum, eps, relu)
-        ctx.save_for_backward(x, y, weight, mean, rstd)
+        y, stats = bn_forward(x, weight, bias, running_mean, running_var, num_batches_tracked if training else None, use_batch,
+                              momentum, eps, relu)
+        ctx.save_for_backward(x, y, weight, stats)
         ctx.flags = (use_batch, bool(relu))
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, y, weight, mean, rstd = ctx.saved_tensors
+        x, y, weight, stats = ctx.saved_tensors
         use_batch, relu = ctx.flags
         dy = (dy if dy.dtype == x.dtype else dy.to(x.dtype)).contiguous()
-        dx, dgamma, dbeta = bn_backward(x, y, dy, weight, mean, rstd, use_batch, relu)
+        dx, dgamma, dbeta = bn_backward(x, y, dy, weight, stats, use_batch, relu)
         return dx, (dgamma if weight is not None else None), (dbeta if weight is not None else None), None, None, None, None, None, None, None
 
 

@@ -12,7 +12,7 @@ import numpy as np
 import torch
 
 from .. import _lib
-from .._lib import MODE_CONV, MODE_SUBM, MODE_TRANSPOSE, check, i3, i3p, lib, ptr, stream_ptr, workspace
+from .._lib import MODE_CONV, MODE_SUBM, MODE_TRANSPOSE, check, fast, i3, i3p, lib, ptr, stream_ptr, workspace
 
 
 class LaunchProfile(object):
@@ -147,7 +147,7 @@ class _Geometry(object):
     """host-side constants of one rulebook geometry, built once: int32[3] arrays, their ctypes pointers, K, mode, output
     shape (the launch-rate-bound forward builds ~18 rulebooks per step; re-deriving these cost ~25 us each)"""
     __slots__ = ("in_sh", "out_sh", "k3", "s3", "p3", "d3", "K", "mode", "subm", "p_in", "p_out", "p_k", "p_s", "p_p", "p_d",
-                 "in_list", "out_list", "ws_bytes")
+                 "a_in", "a_out", "a_k", "a_s", "a_p", "a_d", "in_list", "out_list", "ws_bytes")
 
     def __init__(self, spatial_shape, ksize, stride, padding, dilation, out_padding, subm, transpose):
         self.k3, self.s3, self.p3, self.d3 = i3(ksize), i3(stride), i3(padding), i3(dilation)
@@ -163,6 +163,9 @@ class _Geometry(object):
         self.p_in, self.p_out, self.p_k = i3p(self.in_sh), i3p(self.out_sh), i3p(self.k3)
         self.p_s, self.p_p, self.p_d = i3p(self.s3), i3p(self.p3), i3p(self.d3)
         self.in_list, self.out_list = self.in_sh.tolist(), self.out_sh.tolist()
+        # raw addresses of the (interned, read-only) int32[3] arrays for the compiled binding
+        self.a_in, self.a_out, self.a_k = self.in_sh.ctypes.data, self.out_sh.ctypes.data, self.k3.ctypes.data
+        self.a_s, self.a_p, self.a_d = self.s3.ctypes.data, self.p3.ctypes.data, self.d3.ctypes.data
         self.ws_bytes = {}  # batch size -> conv workspace bytes
 
 
@@ -222,6 +225,14 @@ def _build_rulebook(indices, batch_size, g):
     n = indices.shape[0]
     L = lib()
     K = g.K
+    F = fast() if PROFILE is None else None
+    if F is not None:
+        if g.subm:
+            nbr = F.rulebook_subm(indices, int(batch_size), g.a_in, g.a_k, g.a_d, K, stream_ptr())
+            return Rulebook(indices, indices, nbr[0], nbr[1], g.in_list, g.out_list, K, g.mode)
+        out_indices, nbr_out, nbr_in = F.rulebook_conv(indices, int(batch_size), g.a_in, g.a_out, g.a_k, g.a_s, g.a_p, g.a_d, g.mode, K,
+                                                       _conv_ws_bytes(g, batch_size), stream_ptr())
+        return Rulebook(out_indices, indices, nbr_out, nbr_in, g.in_list, g.out_list, K, g.mode)
     if g.subm:
         nbr = torch.empty((2, n, K), dtype=torch.int32, device=dev)  # one allocation for nbr_out | nbr_in
         nbr_out, nbr_in = nbr[0], nbr[1]
@@ -400,6 +411,10 @@ OVERLAP_MIN_ROWS = int(os.environ.get("BTC_OVERLAP_MIN_ROWS", "20000"))
 
 
 def _conv_forward(features, w, b, map_fwd):
+    if PROFILE is None:
+        F = fast()
+        if F is not None:
+            return F.conv_fwd(features, w, b, map_fwd, stream_ptr())
     bf = features.dtype == torch.bfloat16
     cin, cout = w.shape[-2], w.shape[-1]
     K = map_fwd.shape[1]
@@ -423,6 +438,10 @@ def _conv_backward(features, w, map_fwd, map_bwd, grad_out, wshape, need_din, ne
     dev = grad_out.device
     n_res, n_src = map_fwd.shape[0], map_bwd.shape[0]
     side = _side_stream(dev) if (need_din and need_dw and OVERLAP_WGRAD and PROFILE is None and n_res >= OVERLAP_MIN_ROWS) else None
+    if side is None and PROFILE is None:
+        F = fast()
+        if F is not None:
+            return F.conv_bwd(features, w, map_fwd, map_bwd, grad_out, bool(need_din), bool(need_dw), stream_ptr())
     if need_dw:
         ws_bytes = L.btc_conv_wgrad_ws_bytes(n_res, K, cin, cout, n_src)
         if side is not None:
@@ -488,22 +507,28 @@ class SparseConvBNReLUFunction(torch.autograd.Function):
         features = _actc(features)
         w = _f32c(weight)
         b = _f32c(bias) if bias is not None else None
-        x = _conv_forward(features, w, b, map_fwd)
+        use_batch = bool(training or running_mean is None)
+        F = fast() if PROFILE is None else None
+        if F is not None:
+            ws, need = fused_bn._ws(features.device, w.shape[-1])
+            x, y, stats = F.conv_bn_fwd(features, w, b, map_fwd, gamma, beta, running_mean, running_var, nbt if training else None, use_batch,
+                                        float(momentum), float(eps), bool(relu), ws, need, stream_ptr())
+        else:
+            x = _conv_forward(features, w, b, map_fwd)
+            y, stats = fused_bn.bn_forward(x, gamma, beta, running_mean, running_var, nbt if training else None, use_batch, momentum, eps, relu)
         if CAPTURE is not None:
             CAPTURE.append((features, w, b, map_fwd, map_bwd))
-        use_batch = bool(training or running_mean is None)
-        y, mean, rstd = fused_bn.bn_forward(x, gamma, beta, running_mean, running_var, nbt if training else None, use_batch, momentum, eps, relu)
-        ctx.save_for_backward(features, w, map_fwd, map_bwd, x, y, gamma, mean, rstd)
+        ctx.save_for_backward(features, w, map_fwd, map_bwd, x, y, gamma, stats)
         ctx.flags = (bias is not None, tuple(weight.shape), use_batch, bool(relu))
         return y
 
     @staticmethod
     def backward(ctx, dy):
         from . import fused_bn
-        features, w, map_fwd, map_bwd, x, y, gamma, mean, rstd = ctx.saved_tensors
+        features, w, map_fwd, map_bwd, x, y, gamma, stats = ctx.saved_tensors
         has_bias, wshape, use_batch, relu = ctx.flags
         dy = (dy if dy.dtype == x.dtype else dy.to(x.dtype)).contiguous()
-        dx, dgamma, dbeta = fused_bn.bn_backward(x, y, dy, gamma, mean, rstd, use_batch, relu)
+        dx, dgamma, dbeta = fused_bn.bn_backward(x, y, dy, gamma, stats, use_batch, relu)
         din, dw = _conv_backward(features, w, map_fwd, map_bwd, dx, wshape, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
         db = dx.sum(0, dtype=torch.float32) if (has_bias and ctx.needs_input_grad[2]) else None
         affine = gamma is not None

@@ -378,3 +378,44 @@ def test_fused_batchnorm_relu_matches_torch(n, c, relu, training):
     np.testing.assert_allclose(bn.running_mean.cpu().numpy(), ref.running_mean.cpu().numpy(), **tol)
     np.testing.assert_allclose(bn.running_var.cpu().numpy(), ref.running_var.cpu().numpy(), **tol)
     assert int(bn.num_batches_tracked) == int(ref.num_batches_tracked)
+
+
+# ------------------------------------------------------------------ the two bindings
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_compiled_binding_and_ctypes_binding_agree(dtype):
+    """btcdet_amd/_btcfast (csrc/binding.cpp) and the ctypes route (_lib.py) call the same C ABI: rulebooks, the fused
+    conv -> BatchNorm -> ReLU node and its gradients must be identical bit for bit"""
+    from btcdet_amd import _lib, spconv
+    from functools import partial
+    assert _lib.fast() is not None, "the compiled binding is not built (python -c 'import __graft_entry__ as g; g.build()')"
+    rng = np.random.default_rng(5)
+    shape, B = (8, 24, 20), 2
+    idx = rand_indices(rng, 1500, B, shape)
+    idx = idx[np.lexsort((idx[:, 3], idx[:, 2], idx[:, 1], idx[:, 0]))]
+    feats = rng.standard_normal((idx.shape[0], 16)).astype(np.float32)
+
+    def run():
+        torch.manual_seed(0)
+        bn = partial(torch.nn.BatchNorm1d, eps=1e-3, momentum=0.01)
+        net = spconv.SparseSequential(spconv.SubMConv3d(16, 32, 3, padding=1, bias=False, indice_key="s1"), bn(32), torch.nn.ReLU(),
+                                      spconv.SparseConv3d(32, 32, 3, stride=2, padding=1, bias=True, indice_key="c2"), bn(32), torch.nn.ReLU(),
+                                      spconv.SparseConvTranspose3d(32, 16, 3, stride=2, padding=1, bias=False, indice_key="t3"), bn(16)).to(dev())
+        f = torch.from_numpy(feats).to(dev()).to(dtype).requires_grad_(True)
+        x = spconv.SparseConvTensor(f, torch.from_numpy(idx).to(dev()), list(shape), B)
+        y = net(x)
+        y.features.float().pow(2).sum().backward()
+        torch.cuda.synchronize()
+        rb = x.indice_dict["c2"]
+        return [y.features.detach(), y.indices, f.grad, rb.nbr_out, rb.nbr_in, rb.out_indices] + [p.grad for p in net.parameters()] + \
+               [b.clone() for b in net.buffers()]
+
+    fast_res = run()
+    saved = _lib._fast
+    _lib._fast = None  # force the ctypes route
+    try:
+        ct_res = run()
+    finally:
+        _lib._fast = saved
+    assert len(fast_res) == len(ct_res)
+    for a, b in zip(fast_res, ct_res):
+        assert a.dtype == b.dtype and torch.equal(a, b)
