@@ -408,6 +408,7 @@ def _wgrad_cost(nbr, n_res, K, cin, cout, act_bytes=4):
 # the host's launch rate, the backward pass by the GPU: tools/host_phases.py).  Measured: 60000 -> 191, 20000 -> 194,
 # 0 -> 194 scenes/s
 OVERLAP_MIN_ROWS = int(os.environ.get("BTC_OVERLAP_MIN_ROWS", "20000"))
+OVERLAP_MAX_ROWS = int(os.environ.get("BTC_OVERLAP_MAX_ROWS", "100000"))  # above: both kernels fill the GPU alone, side by side 450 us vs 219 + 150
 
 
 def _conv_forward(features, w, b, map_fwd):
@@ -437,7 +438,7 @@ def _conv_backward(features, w, map_fwd, map_bwd, grad_out, wshape, need_din, ne
     din = dw = None
     dev = grad_out.device
     n_res, n_src = map_fwd.shape[0], map_bwd.shape[0]
-    side = _side_stream(dev) if (need_din and need_dw and OVERLAP_WGRAD and PROFILE is None and n_res >= OVERLAP_MIN_ROWS) else None
+    side = _side_stream(dev) if (need_din and need_dw and OVERLAP_WGRAD and PROFILE is None and OVERLAP_MIN_ROWS <= n_res < OVERLAP_MAX_ROWS) else None
     if side is None and PROFILE is None:
         F = fast()
         if F is not None:
