@@ -250,3 +250,47 @@ def test_merged_occ_heads_equal_separate_heads(G):
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
     for i in (2, 3, 4, 5):
         np.testing.assert_allclose(a[i].cpu().numpy(), b[i].cpu().numpy(), rtol=2e-4, atol=2e-4)
+
+
+def test_hot_path_eval_mode():
+    """tools/test.py's mode: model.eval(), is_train False -- BatchNorm uses (and does not touch) its running statistics,
+    PassOccVox applies EVAL_MAX_NUM_OCC_PNTS but -- like the reference, which computes an eval threshold and then masks with
+    self.occ_thresh anyway (add_occ_template.py:100-103) -- OCC_THRESH in both modes, OccTargets3D adds neg_mask
+    (occ_targets_template.py:377-379), and two runs of the same batch are identical"""
+    import bench
+    from btcdet_amd.btc_path import BtcHotPath
+    from btcdet_amd.config import load_cfg
+    cfg = load_cfg()
+    torch.manual_seed(0)
+    model = BtcHotPath(cfg, device=torch.device(DEV)).to(DEV)
+    batch = bench.build_batches(1, 3, torch.device(DEV))[0]
+    proc = model.dataset.data_processor
+
+    def run(train):
+        bd = proc.forward_batch(batch["points"], batch["pre_rot_points"], batch["scene_offsets"], batch["rot_z"])
+        bd.update({"batch_size": 2, "points": batch["points5"], "gt_boxes": batch["gt_boxes"], "gt_boxes_num": batch["gt_boxes_num"],
+                   "box_mirr_flag": batch["box_mirr_flag"], "bm_points": batch["bm_points"], "rot_z": batch["rot_z"], "is_train": train})
+        return model(bd)
+
+    model.train()
+    for _ in range(2):  # give the running statistics something other than their initial values
+        run(True)
+    model.eval()
+    buffers = {k: v.clone() for k, v in model.named_buffers()}
+    with torch.no_grad():
+        ret1, _, out1 = run(False)
+        ret2, _, out2 = run(False)
+    for k, v in model.named_buffers():
+        assert torch.equal(v, buffers[k]), k                                    # eval never updates running stats / counters
+    assert torch.equal(ret1["spatial_features"], ret2["spatial_features"])      # deterministic
+    assert torch.isfinite(ret1["spatial_features"]).all()
+    assert "neg_mask" in out1
+    occ_pnts = out1["occ_pnts"]
+    assert occ_pnts.shape[0] <= 2 * cfg.MODEL.OCC.PARAMS.EVAL_MAX_NUM_OCC_PNTS
+    if occ_pnts.shape[0] > 1:
+        assert float(occ_pnts[:, 3].min()) > cfg.MODEL.OCC.PARAMS.OCC_THRESH      # the reference's quirk: not EVAL_OCC_THRESH
+    # train-mode thresholds admit more cells than eval-mode ones on the same probabilities
+    model.train()
+    with torch.no_grad():
+        _, _, out_t = run(True)
+    assert out_t["occ_pnts"].shape[0] <= 2 * cfg.MODEL.OCC.PARAMS.MAX_NUM_OCC_PNTS
