@@ -25,7 +25,9 @@ def wrap(obj, name, label):
     setattr(obj, name, w)
 wrap(ops, "_conv_forward", "conv_forward(body)")
 wrap(fused_bn, "bn_forward", "bn_forward(body)")
-wrap(ops, "build_rulebook", "build_rulebook")
+wrap(ops, "build_rulebook_g", "build_rulebook_g")
+wrap(ops.SparseConvBNReLUFunction, "forward", "ConvBN.forward(py body)")
+wrap(modules.SparseSequential, "forward", "SparseSequential.forward(total, nested)")
 wrap(ops, "indice_conv_bn_relu", "indice_conv_bn_relu(total)")
 wrap(conv.SparseConvolution, "forward", "SparseConvolution.forward(total)")
 def fwd(batch):
