@@ -702,11 +702,10 @@ int launch_apply(const float* feat, const float* W, const float* bias, const int
     BTC_LAUNCH_CHECK();
     return BTC_OK;
   }
-  // rows per workgroup: 64 when there are >= 4 tiles per CU, else 32, else 16 (latency hiding by occupancy)
-  // (measured: 32- and 16-row workgroups are ~2x SLOWER on every BtcDet layer -- each workgroup re-reads all K weight
-  //  panels, so L2->LDS weight traffic scales with the number of workgroups; the 128/64-thread variants stay available)
-  int threads = 256;
-  const int tm = threads / 4;
+  // 64 rows per workgroup (256 threads).  Measured: 32- and 16-row workgroups of this register-staged kernel are ~2x SLOWER on
+  // every BtcDet layer -- each workgroup re-reads all K weight panels, so L2->LDS weight traffic scales with the number of
+  // workgroups (the template keeps the THREADS parameter; only the 256-thread instances are built).
+  const int tm = 64;
   const int n_tiles = btc_cdiv(n_rows, tm);
   // still too few workgroups (deep, narrow levels): also split the result channels
   while (nt > 2 && (long long)n_tiles * btc_cdiv(Cres, nt * 16) < 512) nt >>= 1;
@@ -714,12 +713,7 @@ int launch_apply(const float* feat, const float* W, const float* bias, const int
   dim3 grid(n_tiles, btc_cdiv(Cres, nt * 16));
   size_t lds = (size_t)(tm * LDA + KC * ldb_of(nt)) * sizeof(float) + (size_t)(tm * K + K + 1) * sizeof(int32_t);
   const bool vec = (Cred & 3) == 0;
-#define BTC_APPLY(NT_)                                                                                                          \
-  do {                                                                                                                          \
-    if (threads == 256) launch_apply_t<NT_, TRANS_W, 256>(grid, lds, stream, vec, feat, W, bias, nbr, n_rows, K, Cred, Cres, out);      \
-    else if (threads == 128) launch_apply_t<NT_, TRANS_W, 128>(grid, lds, stream, vec, feat, W, bias, nbr, n_rows, K, Cred, Cres, out); \
-    else launch_apply_t<NT_, TRANS_W, 64>(grid, lds, stream, vec, feat, W, bias, nbr, n_rows, K, Cred, Cres, out);                      \
-  } while (0)
+#define BTC_APPLY(NT_) launch_apply_t<NT_, TRANS_W, 256>(grid, lds, stream, vec, feat, W, bias, nbr, n_rows, K, Cred, Cres, out)
   switch (nt) {
     case 1: BTC_APPLY(1); break;
     case 2: BTC_APPLY(2); break;
