@@ -4,14 +4,18 @@
 // this library.  It exists because the forward pass is bound by the host's launch rate (tools/host_phases.py,
 // tools/layer_host_split.py): per sparse layer the ctypes route spends ~30 us of Python on output allocation, argument
 // marshalling and attribute lookups around ~12 us of launches.  Here one call allocates the outputs with at::empty and
-// calls the C ABI (include/btcdet_hip.h) directly.  No HIP headers are needed: the stream comes in as an integer handle
-// (torch._C._cuda_getCurrentRawStream), memory comes from torch's caching allocator.  The ctypes route
-// (btcdet_amd/_lib.py) stays the reference binding and computes the same thing; tests run both.
+// calls the C ABI (include/btcdet_hip.h) directly; memory comes from torch's caching allocator, streams from c10::hip.  The
+// conv -> BatchNorm -> ReLU triple is additionally a C++ autograd node (no Python Function.apply per layer), with wgrad on a
+// side stream beside dgrad for mid-size layers.  The ctypes route (btcdet_amd/_lib.py) stays the reference binding
+//  and computes the same thing; tests run both.
 #include <torch/extension.h>
+#include <c10/hip/HIPStream.h>
+#include <hip/hip_runtime_api.h>
 
 #include <stdexcept>
 #include <string>
 #include <tuple>
+#include <vector>
 
 #include "../../include/btcdet_hip.h"
 
@@ -97,25 +101,55 @@ std::tuple<Tensor, Tensor> bn_bwd(const Tensor& x, const Tensor& y, const Tensor
   return std::make_tuple(dx, dparam);
 }
 
-// din (n_src, Cin), dw (shape of w); either may come back undefined (None) when not needed.  Same stream for both.
+// fork / join of a side stream around wgrad (one pair of events and one pooled stream per device, reused in stream order)
+struct SideStream {
+  hipStream_t side = nullptr;
+  hipEvent_t fork = nullptr, join = nullptr;
+};
+
+SideStream& side_of(int device) {
+  static SideStream tab[64];
+  SideStream& s = tab[device & 63];
+  if (!s.side) {
+    static std::vector<c10::hip::HIPStream> keep;  // keeps the pooled stream objects alive
+    keep.push_back(c10::hip::getStreamFromPool(false, (c10::DeviceIndex)device));
+    s.side = keep.back().stream();
+    if (hipEventCreateWithFlags(&s.fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&s.join, hipEventDisableTiming) != hipSuccess)
+      throw std::runtime_error("hipEventCreateWithFlags failed");
+  }
+  return s;
+}
+
+// din (n_src, Cin), dw (shape of w); either may come back undefined (None) when not needed.  overlap: wgrad runs on a side
+// stream beside dgrad (fork / join with events, no host sync); every temporary is released after the join has been enqueued,
+// so the caching allocator's stream-ordered reuse stays valid without recordStream.
 std::tuple<OptTensor, OptTensor> conv_bwd(const Tensor& features, const Tensor& w, const Tensor& map_fwd, const Tensor& map_bwd,
-                                          const Tensor& grad_out, bool need_din, bool need_dw, int64_t stream) {
+                                          const Tensor& grad_out, bool need_din, bool need_dw, bool overlap, int64_t stream) {
   const int64_t cin = w.size(-2), cout = w.size(-1), K = map_fwd.size(1), n_res = map_fwd.size(0), n_src = map_bwd.size(0);
   need(grad_out.is_contiguous() && grad_out.scalar_type() == features.scalar_type(), "conv_bwd: grad must be contiguous and of the activation type");
   const bool bf = features.scalar_type() == at::kBFloat16;
   OptTensor din, dw;
+  Tensor ws;
+  hipStream_t main = (hipStream_t)st(stream);
+  SideStream* ss = (overlap && need_din && need_dw) ? &side_of(features.get_device()) : nullptr;
+  void* wstream = st(stream);
+  if (ss) {
+    if (hipEventRecord(ss->fork, main) != hipSuccess || hipStreamWaitEvent(ss->side, ss->fork, 0) != hipSuccess)
+      throw std::runtime_error("side-stream fork failed");
+    wstream = (void*)ss->side;
+  }
   if (need_dw) {
     Tensor g = at::empty(w.sizes(), w.options());
     const size_t ws_bytes = btc_conv_wgrad_ws_bytes((int)n_res, (int)K, (int)cin, (int)cout, (int)n_src);
-    Tensor ws = at::empty({(int64_t)(ws_bytes > 256 ? ws_bytes : 256)}, features.options().dtype(at::kByte));
+    ws = at::empty({(int64_t)(ws_bytes > 256 ? ws_bytes : 256)}, features.options().dtype(at::kByte));
     if (bf)
       chk(btc_conv_wgrad_bf16(features.data_ptr(), grad_out.data_ptr(), (const int32_t*)map_fwd.data_ptr(), (int)n_res,
                               (const int32_t*)map_bwd.data_ptr(), (int)n_src, (int)K, (int)cin, (int)cout, (float*)g.data_ptr(), ws.data_ptr(),
-                              ws_bytes, st(stream)), "btc_conv_wgrad_bf16");
+                              ws_bytes, wstream), "btc_conv_wgrad_bf16");
     else
       chk(btc_conv_wgrad((const float*)features.data_ptr(), (const float*)grad_out.data_ptr(), (const int32_t*)map_fwd.data_ptr(), (int)n_res,
                          (const int32_t*)map_bwd.data_ptr(), (int)n_src, (int)K, (int)cin, (int)cout, (float*)g.data_ptr(), ws.data_ptr(),
-                         ws_bytes, st(stream)), "btc_conv_wgrad");
+                         ws_bytes, wstream), "btc_conv_wgrad");
     dw = g;
   }
   if (need_din) {
@@ -127,6 +161,10 @@ std::tuple<OptTensor, OptTensor> conv_bwd(const Tensor& features, const Tensor& 
       chk(btc_conv_dgrad((const float*)grad_out.data_ptr(), (const float*)w.data_ptr(), (const int32_t*)map_bwd.data_ptr(), (int)n_src, (int)K,
                          (int)cin, (int)cout, (float*)d.data_ptr(), st(stream)), "btc_conv_dgrad");
     din = d;
+  }
+  if (ss) {  // join: dW (and the release of ws / grad_out by the caller) is ordered after wgrad on the main stream
+    if (hipEventRecord(ss->join, ss->side) != hipSuccess || hipStreamWaitEvent(main, ss->join, 0) != hipSuccess)
+      throw std::runtime_error("side-stream join failed");
   }
   return std::make_tuple(din, dw);
 }
@@ -161,6 +199,65 @@ std::tuple<Tensor, Tensor, Tensor> rulebook_conv(const Tensor& indices, int64_t 
   return std::make_tuple(out_indices, nbr_out, nbr_in);
 }
 
+inline int64_t current_stream() { return reinterpret_cast<int64_t>(c10::hip::getCurrentHIPStream().stream()); }
+
+// conv -> BatchNorm1d (-> ReLU) as a C++ autograd node: the same three launches as ops.SparseConvBNReLUFunction without the
+// Python Function.apply / ctx bookkeeping per layer (the forward pass is bound by the host's launch rate).  wgrad runs on the
+// backward stream right before dgrad (no side-stream overlap here; Python keeps that variant for the 20 K - 100 K-row layers).
+struct ConvBNReLUNode : public torch::autograd::Function<ConvBNReLUNode> {
+  static Tensor forward(torch::autograd::AutogradContext* ctx, const Tensor& features, const Tensor& weight, const OptTensor& bias,
+                        const Tensor& map_fwd, const Tensor& map_bwd, const OptTensor& gamma, const OptTensor& beta, const OptTensor& rm,
+                        const OptTensor& rv, const OptTensor& nbt, bool use_batch, double momentum, double eps, bool relu, const Tensor& ws,
+                        int64_t ws_bytes, bool overlap) {
+    const int64_t stream = current_stream();
+    auto r = conv_bn_fwd(features, weight, bias, map_fwd, gamma, beta, rm, rv, nbt, use_batch, momentum, eps, relu, ws, ws_bytes, stream);
+    const Tensor g = (gamma.has_value() && gamma->defined()) ? *gamma : Tensor();
+    ctx->save_for_backward({features, weight, map_fwd, map_bwd, std::get<0>(r), std::get<1>(r), g, std::get<2>(r), ws});
+    ctx->saved_data["use_batch"] = use_batch;
+    ctx->saved_data["relu"] = relu;
+    ctx->saved_data["ws_bytes"] = ws_bytes;
+    ctx->saved_data["overlap"] = overlap;
+    ctx->saved_data["has_bias"] = bias.has_value() && bias->defined();
+    return std::get<1>(r);
+  }
+
+  static torch::autograd::variable_list backward(torch::autograd::AutogradContext* ctx, torch::autograd::variable_list grads) {
+    const auto saved = ctx->get_saved_variables();
+    const Tensor &features = saved[0], &w = saved[1], &map_fwd = saved[2], &map_bwd = saved[3], &x = saved[4], &y = saved[5], &gamma = saved[6],
+                 &stats = saved[7], &ws = saved[8];
+    const bool use_batch = ctx->saved_data["use_batch"].toBool(), relu = ctx->saved_data["relu"].toBool();
+    const int64_t ws_bytes = ctx->saved_data["ws_bytes"].toInt(), stream = current_stream();
+    Tensor dy = grads[0];
+    if (dy.scalar_type() != x.scalar_type()) dy = dy.to(x.scalar_type());
+    dy = dy.contiguous();
+    OptTensor og;
+    if (gamma.defined()) og = gamma;
+    auto b = bn_bwd(x, y, dy, og, stats, use_batch, relu, ws, ws_bytes, stream);
+    const Tensor& dx = std::get<0>(b);
+    const Tensor& dparam = std::get<1>(b);
+    auto cb = conv_bwd(features, w, map_fwd, map_bwd, dx, ctx->needs_input_grad(0), ctx->needs_input_grad(1),
+                       ctx->saved_data["overlap"].toBool(), stream);
+    Tensor din = std::get<0>(cb).has_value() ? *std::get<0>(cb) : Tensor();
+    Tensor dw = std::get<1>(cb).has_value() ? *std::get<1>(cb) : Tensor();
+    Tensor db;
+    if (ctx->saved_data["has_bias"].toBool() && ctx->needs_input_grad(2)) db = dx.sum(at::IntArrayRef{0}, false, at::kFloat);
+    Tensor dgamma, dbeta;
+    if (gamma.defined()) {
+      dgamma = dparam[0];
+      dbeta = dparam[1];
+    }
+    return {din, dw, db, Tensor(), Tensor(), dgamma, dbeta, Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(),
+            Tensor()};
+  }
+};
+
+Tensor conv_bn_relu(const Tensor& features, const Tensor& weight, const OptTensor& bias, const Tensor& map_fwd, const Tensor& map_bwd,
+                    const OptTensor& gamma, const OptTensor& beta, const OptTensor& rm, const OptTensor& rv, const OptTensor& nbt, bool use_batch,
+                    double momentum, double eps, bool relu, const Tensor& ws, int64_t ws_bytes, bool overlap) {
+  return ConvBNReLUNode::apply(features, weight, bias, map_fwd, map_bwd, gamma, beta, rm, rv, nbt, use_batch, momentum, eps, relu, ws, ws_bytes,
+                               overlap);
+}
+
 }  // namespace
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
@@ -170,6 +267,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("conv_bn_fwd", &conv_bn_fwd);
   m.def("bn_bwd", &bn_bwd);
   m.def("conv_bwd", &conv_bwd);
+  m.def("conv_bn_relu", &conv_bn_relu);
   m.def("rulebook_subm", &rulebook_subm);
   m.def("rulebook_conv", &rulebook_conv);
   m.def("abi_version", []() { return btc_version(); });

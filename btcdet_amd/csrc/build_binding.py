@@ -25,9 +25,9 @@ def build(force=False):
         raise RuntimeError("build libbtcdet_hip.so first (make -C btcdet_amd/csrc)")
     cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", src, "-o", out,
            "-D_GLIBCXX_USE_CXX11_ABI=%d" % int(torch._C._GLIBCXX_USE_CXX11_ABI), "-DTORCH_EXTENSION_NAME=_btcfast", "-DTORCH_API_INCLUDE_EXTENSION_H",
-           "-Wno-attributes"]
+           "-Wno-attributes", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM", "-I/opt/rocm/include"]
     cmd += ["-I" + i for i in ce.include_paths()] + ["-I" + sysconfig.get_paths()["include"]]
-    cmd += ["-L" + l for l in ce.library_paths()] + ["-ltorch", "-ltorch_cpu", "-lc10", "-ltorch_python"]
+    cmd += ["-L" + l for l in ce.library_paths()] + ["-ltorch", "-ltorch_cpu", "-lc10", "-lc10_hip", "-ltorch_python", "-lamdhip64"]
     cmd += ["-L" + PKG, "-lbtcdet_hip", "-Wl,-rpath,$ORIGIN"] + ["-Wl,-rpath," + l for l in ce.library_paths()]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:

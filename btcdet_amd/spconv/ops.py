@@ -407,8 +407,13 @@ def _wgrad_cost(nbr, n_res, K, cin, cout, act_bytes=4):
 # rows; on smaller layers the stream switches cost more host time than the overlap returns (the forward pass is bound by
 # the host's launch rate, the backward pass by the GPU: tools/host_phases.py).  Measured: 60000 -> 191, 20000 -> 194,
 # 0 -> 194 scenes/s
+NATIVE_AUTOGRAD = os.environ.get("BTC_NATIVE_AUTOGRAD", "1") != "0"  # conv -> BN -> ReLU as a C++ autograd node when _btcfast is built
 OVERLAP_MIN_ROWS = int(os.environ.get("BTC_OVERLAP_MIN_ROWS", "20000"))
 OVERLAP_MAX_ROWS = int(os.environ.get("BTC_OVERLAP_MAX_ROWS", "100000"))  # above: both kernels fill the GPU alone, side by side 450 us vs 219 + 150
+
+
+def _overlap_ok(n_res):
+    return OVERLAP_WGRAD and OVERLAP_MIN_ROWS <= n_res < OVERLAP_MAX_ROWS
 
 
 def _conv_forward(features, w, b, map_fwd):
@@ -438,11 +443,12 @@ def _conv_backward(features, w, map_fwd, map_bwd, grad_out, wshape, need_din, ne
     din = dw = None
     dev = grad_out.device
     n_res, n_src = map_fwd.shape[0], map_bwd.shape[0]
-    side = _side_stream(dev) if (need_din and need_dw and OVERLAP_WGRAD and PROFILE is None and OVERLAP_MIN_ROWS <= n_res < OVERLAP_MAX_ROWS) else None
-    if side is None and PROFILE is None:
+    overlap = bool(need_din and need_dw and _overlap_ok(n_res))
+    if PROFILE is None:
         F = fast()
         if F is not None:
-            return F.conv_bwd(features, w, map_fwd, map_bwd, grad_out, bool(need_din), bool(need_dw), stream_ptr())
+            return F.conv_bwd(features, w, map_fwd, map_bwd, grad_out, bool(need_din), bool(need_dw), overlap, stream_ptr())
+    side = _side_stream(dev) if (overlap and PROFILE is None) else None
     if need_dw:
         ws_bytes = L.btc_conv_wgrad_ws_bytes(n_res, K, cin, cout, n_src)
         if side is not None:
@@ -609,6 +615,13 @@ def indice_conv_bn_relu(features, weight, bias, rulebook, bn, relu, inverse=Fals
     rm = bn.running_mean if bn.track_running_stats else None
     rv = bn.running_var if bn.track_running_stats else None
     maps = (rulebook.nbr_in, rulebook.nbr_out) if inverse else (rulebook.nbr_out, rulebook.nbr_in)
+    F = fast() if (PROFILE is None and CAPTURE is None and NATIVE_AUTOGRAD) else None
+    if F is not None and features.is_cuda:
+        # C++ autograd node (csrc/binding.cpp ConvBNReLUNode): same launches, no Python Function.apply / ctx bookkeeping
+        from . import fused_bn
+        ws, need = fused_bn._ws(features.device, weight.shape[-1])
+        return F.conv_bn_relu(_actc(features), _f32c(weight), bias, maps[0], maps[1], bn.weight, bn.bias, rm, rv, nbt, bool(training or rm is None),
+                              float(bn.momentum), float(bn.eps), bool(relu), ws, need, bool(_overlap_ok(maps[0].shape[0])))
     return SparseConvBNReLUFunction.apply(features, weight, bias, maps[0], maps[1], bn.weight, bn.bias, rm, rv, nbt, training, bn.momentum,
                                           bn.eps, relu)
 
