@@ -77,7 +77,7 @@ def build_batches(n_batches, rank, device, batch_size=2, profile="kitti"):
     return batches
 
 
-def make_step(model, ddp, proc, opts):
+def make_step(model, ddp, proc, opts, grad_sync=None):
     def step(batch):
         for o in opts:
             o.zero_grad(set_to_none=True)
@@ -89,6 +89,8 @@ def make_step(model, ddp, proc, opts):
         # occupancy loss (real) + L2 stand-ins for the out-of-scope consumers of the detection branch
         loss = ret["loss_occ"] + 1e-3 * ret["spatial_features"].pow(2).mean() + 1e-3 * ret["x_combine"].float().pow(2).mean()
         loss.backward()
+        if grad_sync is not None:
+            grad_sync.finish()  # all-reduced mean gradients in param.grad (the detection bucket has been travelling since mid-backward)
         for o in opts:
             o.step()
         return loss
@@ -228,21 +230,31 @@ def main():
         cfg.MODEL.BACKBONE_3D["FEATURE_DTYPE"] = "bf16"
     model = BtcHotPath(cfg, device=device).to(device)
     model.train()
-    ddp = model
-    if use_dist:
-        # gradient_as_bucket_view: gradients are written straight into the all-reduce buckets (no per-parameter copy
-        # kernels); broadcast_buffers=False: BatchNorm running statistics stay rank-local between checkpoints instead of being
-        # re-broadcast from rank 0 before every forward (training-mode BN never reads them; the reference's default DDP
-        # re-broadcasts, tools/train.py:166-168); static_graph: the same parameters are used every step.
-        # Measured at world size 1 over RCCL on MI355X: DDP defaults 12.7 ms/step, these 11.4, no DDP 11.2.
+    ddp, grad_sync = model, None
+    occ_params = [p for p in model.occ_modules.parameters() if p.requires_grad]
+    det_params = [p for p in model.det_modules.parameters() if p.requires_grad]
+    if use_dist and os.environ.get("BTC_BENCH_SYNC", "bucketed") == "ddp":
+        # gradient_as_bucket_view: gradients are written straight into the all-reduce buckets; broadcast_buffers=False:
+        # BatchNorm running statistics stay rank-local between checkpoints instead of being re-broadcast from rank 0 before
+        # every forward (training-mode BN never reads them; the reference's default DDP re-broadcasts, tools/train.py:166-168);
+        # static_graph: the same parameters are used every step.
         kw = {"gradient_as_bucket_view": True, "broadcast_buffers": False, "static_graph": True}
         for item in os.environ.get("BTC_DDP_OPTS", "").split(","):  # e.g. gradient_as_bucket_view=1,broadcast_buffers=0
             if "=" in item:
                 k, v = item.split("=")
                 kw[k] = (float(v) if k == "bucket_cap_mb" else bool(int(v)))
         ddp = torch.nn.parallel.DistributedDataParallel(model, device_ids=[dev_index], find_unused_parameters=False, **kw)
-    occ_params = [p for p in model.occ_modules.parameters() if p.requires_grad]
-    det_params = [p for p in model.det_modules.parameters() if p.requires_grad]
+    elif use_dist:
+        # default: btcdet_amd/grad_sync.py -- two flat buckets (detection / occupancy parameters), the detection bucket's
+        # all-reduce overlapped with the occupancy branch's backward.  Measured at world size 1 over RCCL: DDP (tuned as above)
+        # 10.1 ms per step, this reducer see DESIGN.md, no reducer 9.2 ms.
+        from btcdet_amd.grad_sync import BucketedGradSync
+        for p in model.parameters():  # same start on every rank (DDP does this broadcast in its constructor)
+            dist.broadcast(p.data, src=0)
+        for b in model.buffers():
+            dist.broadcast(b.data, src=0)
+        head_param = next(p for p in model.occ_modules.occ_dense_head.parameters() if p.requires_grad)
+        grad_sync = BucketedGradSync([(det_params, head_param), (occ_params, None)])
     # adam_onecycle groups of the reference (optimization/__init__.py:36-40; LR is scheduled, yaml:331-372)
     # fused=True: one multi-tensor launch per optimizer instead of ~10 foreach launches with 60 us host gaps between them
     # the reference's two optimizers (occ / det) as the two parameter groups of one fused Adam: same update rule per
@@ -251,7 +263,7 @@ def main():
                               {"params": det_params, "lr": 3e-3, "weight_decay": 0.01}], betas=(0.9, 0.99), fused=True)]
     bs = 2
     batches = build_batches(4, rank, device, bs, args.workload)
-    step = make_step(model, ddp, model.dataset.data_processor, opts)
+    step = make_step(model, ddp, model.dataset.data_processor, opts, grad_sync)
 
     def sync():
         torch.cuda.synchronize()

@@ -1,0 +1,86 @@
+"""Gradient all-reduce for the data-parallel step: one process per GPU, RCCL (``backend="nccl"``) over xGMI.
+
+The reference wraps the model in DistributedDataParallel (tools/train.py:166-168).  On this path DDP's generality costs
+~0.9 ms of a 9.2 ms step (one bucket-view copy kernel per parameter, ~120 of them, plus per-parameter hooks), so the
+bench uses this reducer instead -- same result, the mean of the ranks' gradients in every ``param.grad``:
+
+* parameters are grouped into buckets (here: detection-branch modules, occupancy-branch modules -- the two parameter groups
+  of the reference's optimizers); each bucket owns one flat fp32 buffer;
+* a bucket may name a TRIGGER parameter outside itself: when that parameter's gradient is accumulated the bucket is
+  launched if all of its own gradients exist (otherwise it waits for ``finish()``).  The detection bucket is triggered by a
+  parameter of the occupancy head: the detection branch is detached from the occupancy branch (PASS_GRAD False) and its
+  autograd nodes were created later, so the engine runs all of them before the first occupancy node -- the detection
+  gradients (~90 % of the bytes) travel while the whole occupancy branch is still in backward.  Launch = one multi-tensor
+  copy into the flat buffer + one asynchronous all-reduce;
+* ``finish()`` (before the optimizer step) launches whatever has not been launched, waits, scales by 1/world and points
+  every ``param.grad`` at its slice of the flat buffer (no copy back).
+
+``BTC_BENCH_SYNC=ddp`` makes bench.py use DistributedDataParallel instead."""
+import torch
+import torch.distributed as dist
+
+
+class _Bucket(object):
+    def __init__(self, params, trigger):
+        self.params = [p for p in params if p.requires_grad]
+        self.trigger = trigger
+        n = sum(p.numel() for p in self.params)
+        dev = self.params[0].device if self.params else torch.device("cpu")
+        self.flat = torch.zeros((n,), dtype=torch.float32, device=dev)
+        self.views, off = [], 0
+        for p in self.params:
+            self.views.append(self.flat[off:off + p.numel()].view_as(p))
+            off += p.numel()
+        self.work = None
+        self.launched = False
+
+
+class BucketedGradSync(object):
+    def __init__(self, buckets, process_group=None):
+        """buckets: list of (parameters, trigger parameter or None); the trigger is the parameter whose gradient arrives last"""
+        self.group = process_group
+        self.world = dist.get_world_size(process_group)
+        self.stage_on_host = dist.get_backend(process_group) == "gloo"  # gloo's device path is very slow: reduce a host copy (as DDP does)
+        self.buckets = [_Bucket(list(params), trig) for params, trig in buckets]
+        self._handles = []
+        for b in self.buckets:
+            if b.trigger is not None:
+                self._handles.append(b.trigger.register_post_accumulate_grad_hook(lambda p, b=b: self._launch(b)))
+
+    def _launch(self, b, early=True):
+        if b.launched or not b.params:
+            return
+        grads = [p.grad for p in b.params]
+        if early and any(g is None for g in grads):
+            return  # not complete yet: finish() will send it
+        b.launched = True
+        have = [(v, g) for v, g in zip(b.views, grads) if g is not None]
+        if len(have) != len(grads):  # a parameter without gradient this step contributes zeros
+            b.flat.zero_()
+        if have:
+            torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
+        if self.stage_on_host and b.flat.is_cuda:
+            host = b.flat.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
+            b.flat.copy_(host)
+        else:
+            b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def finish(self):
+        """call after backward, before the optimizer step"""
+        for b in self.buckets:
+            self._launch(b, early=False)
+        for b in self.buckets:
+            if b.work is not None:
+                b.work.wait()
+                b.work = None
+            if b.params:
+                b.flat.mul_(1.0 / self.world)
+                for p, v in zip(b.params, b.views):
+                    p.grad = v
+            b.launched = False
+
+    def remove(self):
+        for h in self._handles:
+            h.remove()
+        self._handles = []

@@ -45,3 +45,51 @@ def test_ddp_gloo_world2():
     np.testing.assert_allclose(g0, 0.5 * (l0 + l1), rtol=1e-5, atol=1e-6)  # = mean of the per-rank gradients
     assert dt0 == dt1 == 0.2                                                # max over ranks
     assert not set(s0) & set(s1)                                            # disjoint scene shards
+
+
+def _sync_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    from btcdet_amd.grad_sync import BucketedGradSync
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(1)
+    # two detached branches like the hot path: `a` (created first, "occupancy") and `b` (created later, "detection")
+    a = torch.nn.Sequential(torch.nn.Linear(6, 8), torch.nn.ReLU(), torch.nn.Linear(8, 4))
+    b = torch.nn.Sequential(torch.nn.Linear(4, 8), torch.nn.ReLU(), torch.nn.Linear(8, 2))
+    launched = []
+    sync = BucketedGradSync([(list(b.parameters()), a[2].weight), (list(a.parameters()), None)])
+    orig = sync._launch
+    sync._launch = lambda bk, early=True: (launched.append((sync.buckets.index(bk), early, all(p.grad is not None for p in bk.params))), orig(bk, early))[1]
+    for h in sync._handles:
+        h.remove()
+    sync._handles = [a[2].weight.register_post_accumulate_grad_hook(lambda p: sync._launch(sync.buckets[0]))]
+    x = torch.from_numpy(np.random.default_rng(10 + rank).standard_normal((16, 6)).astype(np.float32))
+    local = None
+    for it in range(2):
+        for p in list(a.parameters()) + list(b.parameters()):
+            p.grad = None
+        ya = a(x)
+        loss = ya.pow(2).mean() + b(ya.detach()).pow(2).mean()
+        local = torch.autograd.grad(loss, list(b.parameters()) + list(a.parameters()), retain_graph=True)
+        loss.backward()
+        sync.finish()
+    g = torch.cat([p.grad.reshape(-1) for p in list(b.parameters()) + list(a.parameters())])
+    out[rank] = (g.numpy().copy(), torch.cat([t.reshape(-1) for t in local]).numpy(), launched)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bucketed_grad_sync_gloo_world2():
+    """btcdet_amd/grad_sync.py: the later-created (detection-like) branch's bucket is launched from the hook on the first
+    parameter of the other branch that receives a gradient -- with all of its gradients present -- and every rank ends with the
+    mean gradient in param.grad"""
+    world, port = 2, 29741
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_sync_worker, args=(world, port, out), nprocs=world, join=True)
+    g0, l0, launched0 = out[0]
+    g1, l1, _ = out[1]
+    np.testing.assert_allclose(g0, g1, rtol=0, atol=0)
+    np.testing.assert_allclose(g0, 0.5 * (l0 + l1), rtol=1e-5, atol=1e-7)
+    early = [e for e in launched0 if e[0] == 0 and e[1]]
+    assert early and all(e[2] for e in early)   # the early launch of bucket 0 saw a complete bucket
