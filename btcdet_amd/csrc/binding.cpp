@@ -14,6 +14,7 @@
 
 #include <stdexcept>
 #include <string>
+#include <memory>
 #include <tuple>
 #include <vector>
 
@@ -201,6 +202,76 @@ std::tuple<Tensor, Tensor, Tensor> rulebook_conv(const Tensor& indices, int64_t 
 
 inline int64_t current_stream() { return reinterpret_cast<int64_t>(c10::hip::getCurrentHIPStream().stream()); }
 
+// ---- strided / transposed rulebook in two halves (ops.py LOOKAHEAD): the count half runs on a side stream as soon as the
+// input level exists and writes n_out straight into pinned host memory; the fill half runs in the consumer's forward and
+// waits -- on the host -- for the count's event only, never for the main stream.
+struct RbLookahead {
+  hipStream_t side = nullptr;
+  hipEvent_t fork = nullptr;
+  hipEvent_t done[64] = {};
+  int32_t* host_n = nullptr;  // 64 pinned ints, device-visible
+  int next = 0;
+};
+
+RbLookahead& rb_of(int device) {
+  static RbLookahead tab[64];
+  RbLookahead& r = tab[device & 63];
+  if (!r.side) {
+    static std::vector<c10::hip::HIPStream> keep;
+    keep.push_back(c10::hip::getStreamFromPool(false, (c10::DeviceIndex)device));
+    r.side = keep.back().stream();
+    bool ok = hipEventCreateWithFlags(&r.fork, hipEventDisableTiming) == hipSuccess &&
+              hipHostMalloc((void**)&r.host_n, 64 * sizeof(int32_t), hipHostMallocDefault) == hipSuccess;
+    for (int i = 0; ok && i < 64; ++i) ok = hipEventCreateWithFlags(&r.done[i], hipEventDisableTiming) == hipSuccess;
+    if (!ok) throw std::runtime_error("rulebook lookahead: event / pinned-memory setup failed");
+  }
+  return r;
+}
+
+struct PendingRb {
+  Tensor indices, ws;
+  int64_t batch, p_in, p_out, p_k, p_s, p_p, p_d, mode, K, ws_bytes;
+  hipEvent_t done;
+  volatile int32_t* host_n;
+};
+
+std::shared_ptr<PendingRb> rulebook_conv_start(const Tensor& indices, int64_t batch, int64_t p_in, int64_t p_out, int64_t p_k, int64_t p_s,
+                                               int64_t p_p, int64_t p_d, int64_t mode, int64_t K, int64_t ws_bytes) {
+  auto p = std::make_shared<PendingRb>();
+  p->indices = indices; p->batch = batch; p->p_in = p_in; p->p_out = p_out; p->p_k = p_k; p->p_s = p_s; p->p_p = p_p; p->p_d = p_d;
+  p->mode = mode; p->K = K; p->ws_bytes = ws_bytes;
+  RbLookahead& r = rb_of(indices.get_device());
+  const int slot = r.next;
+  r.next = (r.next + 1) & 63;
+  p->done = r.done[slot];
+  p->host_n = r.host_n + slot;
+  p->ws = at::empty({ws_bytes > 256 ? ws_bytes : 256}, indices.options().dtype(at::kByte));
+  hipStream_t main = (hipStream_t)st(current_stream());
+  // fork after the allocation: the side stream is ordered behind every earlier user of that block and behind the kernels
+  // that produce `indices`
+  if (hipEventRecord(r.fork, main) != hipSuccess || hipStreamWaitEvent(r.side, r.fork, 0) != hipSuccess)
+    throw std::runtime_error("rulebook lookahead: fork failed");
+  chk(btc_rulebook_conv_count((const int32_t*)indices.data_ptr(), (int)indices.size(0), (int)batch, ip(p_in), ip(p_out), ip(p_k), ip(p_s),
+                              ip(p_p), ip(p_d), (int)mode, (int32_t*)p->host_n, p->ws.data_ptr(), (size_t)ws_bytes, (void*)r.side),
+      "btc_rulebook_conv_count");
+  if (hipEventRecord(p->done, r.side) != hipSuccess) throw std::runtime_error("rulebook lookahead: event record failed");
+  return p;
+}
+
+std::tuple<Tensor, Tensor, Tensor> rulebook_conv_finish(const std::shared_ptr<PendingRb>& p) {
+  if (hipEventSynchronize(p->done) != hipSuccess) throw std::runtime_error("rulebook lookahead: event synchronize failed");
+  const int64_t n_out = *p->host_n, n = p->indices.size(0), K = p->K;
+  hipStream_t main = (hipStream_t)st(current_stream());
+  if (hipStreamWaitEvent(main, p->done, 0) != hipSuccess) throw std::runtime_error("rulebook lookahead: join failed");
+  Tensor out_indices = at::empty({n_out, 4}, p->indices.options());
+  Tensor nbr_out = at::empty({n_out, K}, p->indices.options());
+  Tensor nbr_in = at::empty({n, K}, p->indices.options());
+  chk(btc_rulebook_conv_fill((const int32_t*)p->indices.data_ptr(), (int)n, (int)p->batch, ip(p->p_in), ip(p->p_out), ip(p->p_k), ip(p->p_s),
+                             ip(p->p_p), ip(p->p_d), (int)p->mode, (int)n_out, (int32_t*)out_indices.data_ptr(), (int32_t*)nbr_out.data_ptr(),
+                             (int32_t*)nbr_in.data_ptr(), p->ws.data_ptr(), (size_t)p->ws_bytes, (void*)main), "btc_rulebook_conv_fill");
+  return std::make_tuple(out_indices, nbr_out, nbr_in);
+}
+
 // conv -> BatchNorm1d (-> ReLU) as a C++ autograd node: the same three launches as ops.SparseConvBNReLUFunction without the
 // Python Function.apply / ctx bookkeeping per layer (the forward pass is bound by the host's launch rate).  wgrad runs on the
 // backward stream right before dgrad (no side-stream overlap here; Python keeps that variant for the 20 K - 100 K-row layers).
@@ -270,5 +341,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("conv_bn_relu", &conv_bn_relu);
   m.def("rulebook_subm", &rulebook_subm);
   m.def("rulebook_conv", &rulebook_conv);
+  py::class_<PendingRb, std::shared_ptr<PendingRb>>(m, "PendingRb");
+  m.def("rulebook_conv_start", &rulebook_conv_start);
+  m.def("rulebook_conv_finish", &rulebook_conv_finish);
   m.def("abi_version", []() { return btc_version(); });
 }

@@ -166,9 +166,9 @@ class SparseConvolution(SparseModule):
 
     def prefetch(self, indices, spatial_shape, batch_size, indice_dict):
         """start the count half of this layer's rulebook for `indices` (no-op for submanifold / inverse / 2-D / cached layers)"""
-        if not ops.LOOKAHEAD or self.subm or self.inverse or self.conv1x1 or self.ndim != 3 or not indices.is_cuda:
+        if self.subm or self.inverse or self.conv1x1 or self.ndim != 3 or not indices.is_cuda:
             return
-        if self.indice_key is not None and self.indice_key in indice_dict:
+        if not ops.lookahead_enabled() or (self.indice_key is not None and self.indice_key in indice_dict):
             return
         geom = indice_dict.setdefault("__geometry_cache__", {})
         gkey = self._gkey(indices, spatial_shape)

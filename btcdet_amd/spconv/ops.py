@@ -278,10 +278,20 @@ def _fill_conv_rulebook(indices, batch_size, g, n_out, ws, ws_bytes):
 # input indices exist -- a layer's `lookahead` list names the strided layers that consume its output level
 # (spconv/conv.py) -- and the FILL half runs in the consumer's forward: by then the count is long finished, the host
 # waits on its event only (not on the main stream) and keeps running ahead of the GPU.
-# Measured at KITTI size: neutral (10.7-11.0 ms per step either way) -- the step is bound by the host's launch rate, not by
-# these gaps -- so the lookahead is OFF by default (BTC_LOOKAHEAD=1 enables it); the two-half structure and the shared
-# geometry cache stay.
-LOOKAHEAD = os.environ.get("BTC_LOOKAHEAD", "0") != "0"  # opt-in: measured neutral while the step is host-bound (see below)
+# Measured at KITTI size: with the halves managed in Python (ctypes route) neutral to negative -- stream contexts, events
+# and the pinned copy cost the host what the wait saved; managed inside the compiled binding (_btcfast.rulebook_conv_start /
+# _finish) +1.5 % (221 -> 224.5 scenes/s) -- see lookahead_enabled().
+_LOOKAHEAD_ENV = os.environ.get("BTC_LOOKAHEAD", "auto")
+
+
+def lookahead_enabled():
+    """BTC_LOOKAHEAD=1 / 0 force it; default: on when the compiled binding manages the two halves (events, pinned slot and
+    side stream in C++: 221 -> 224.5 scenes/s), off on the ctypes route (its Python per event costs what the wait saved)"""
+    if _LOOKAHEAD_ENV in ("0", "1"):
+        return _LOOKAHEAD_ENV == "1"
+    return fast() is not None
+
+
 _RB_STREAM = {}
 _PIN = {}
 
@@ -362,10 +372,27 @@ def _start_conv_rulebook(indices, batch_size, g, side):
     return PendingRulebook(indices, batch_size, g, ws, ws_bytes, host_n, event, prof_ev)
 
 
+class _NativePending(PendingRulebook):
+    """the same two halves managed inside the compiled binding (events, pinned read-back slot and side stream in C++)"""
+
+    def __init__(self, F, handle, indices, g):
+        self.F, self.handle, self.indices, self.g = F, handle, indices, g
+
+    def finish(self):
+        g = self.g
+        out_indices, nbr_out, nbr_in = self.F.rulebook_conv_finish(self.handle)
+        self.handle = None
+        return Rulebook(out_indices, self.indices, nbr_out, nbr_in, g.in_list, g.out_list, g.K, g.mode)
+
+
 def prefetch_conv_rulebook(indices, batch_size, spatial_shape, ksize, stride=1, padding=0, dilation=1, out_padding=0, transpose=False):
     """count half of a strided / transposed rulebook on the side stream; .finish() on the result gives the Rulebook"""
     indices = _as_idx(indices)
     g = _geometry(spatial_shape, ksize, stride, padding, dilation, out_padding, False, transpose)
+    F = fast() if PROFILE is None else None
+    if F is not None:
+        h = F.rulebook_conv_start(indices, int(batch_size), g.a_in, g.a_out, g.a_k, g.a_s, g.a_p, g.a_d, g.mode, g.K, _conv_ws_bytes(g, batch_size))
+        return _NativePending(F, h, indices, g)
     return _start_conv_rulebook(indices, batch_size, g, _rb_stream(indices.device))
 
 
