@@ -292,6 +292,9 @@ def main():
     # fused=True: one multi-tensor launch per optimizer instead of ~10 foreach launches with 60 us host gaps between them
     # the reference's two optimizers (occ / det) as the two parameter groups of one fused Adam: same update rule per
     # group, half the host overhead per step
+    # weight gradients on a side stream for the whole backward pass, joined once at its end (not under DDP, whose hooks read
+    # them in mid-backward)
+    ops.set_defer_wgrad_join(ddp is model and os.environ.get("BTC_DEFER_WGRAD", "1") != "0")
     groups = [{"params": occ_params, "lr": 3e-3, "weight_decay": 0.001}, {"params": det_params, "lr": 3e-3, "weight_decay": 0.01}]
     if os.environ.get("BTC_BENCH_OPTIM", "lean") == "torch":
         opts = [torch.optim.Adam(groups, betas=(0.9, 0.99), fused=True)]

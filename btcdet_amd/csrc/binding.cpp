@@ -9,11 +9,15 @@
 // side stream beside dgrad for mid-size layers.  The ctypes route (btcdet_amd/_lib.py) stays the reference binding
 //  and computes the same thing; tests run both.
 #include <torch/extension.h>
+#include <c10/hip/HIPCachingAllocator.h>
 #include <c10/hip/HIPStream.h>
 #include <hip/hip_runtime_api.h>
+#include <torch/csrc/autograd/engine.h>
 
 #include <stdexcept>
 #include <string>
+#include <cstdio>
+#include <cstdlib>
 #include <memory>
 #include <tuple>
 #include <vector>
@@ -33,6 +37,15 @@ inline const float* fptr(const OptTensor& t) { return (t.has_value() && t->defin
 inline void* vptr(const OptTensor& t) { return (t.has_value() && t->defined()) ? t->data_ptr() : nullptr; }
 inline void* st(int64_t stream) { return reinterpret_cast<void*>(stream); }
 inline const int32_t* ip(int64_t p) { return reinterpret_cast<const int32_t*>(p); }
+
+// BTC_DEBUG_SYNC=1: synchronise the device after every binding call and name the call a fault surfaces in
+inline void dbg_sync(const char* where) {
+  static const bool on = getenv("BTC_DEBUG_SYNC") != nullptr;
+  if (!on) return;
+  hipError_t e = hipDeviceSynchronize();
+  fprintf(stderr, "[btcfast] %s: %s\n", where, hipGetErrorString(e));
+  fflush(stderr);
+}
 
 inline void need(bool ok, const char* msg) {
   if (!ok) throw std::runtime_error(msg);
@@ -106,14 +119,27 @@ std::tuple<Tensor, Tensor> bn_bwd(const Tensor& x, const Tensor& y, const Tensor
 struct SideStream {
   hipStream_t side = nullptr;
   hipEvent_t fork = nullptr, join = nullptr;
+  c10::hip::HIPStream* c10side = nullptr;
+  bool pending = false;          // deferred mode: wgrads are in flight on the side stream, the join is still owed
+  bool callback_queued = false;  // ... and will be paid by an engine callback at the end of this backward pass
 };
+
+// deferred join (set from Python): weight gradients are off the backward pass's critical path -- only dgrad feeds the next
+// node -- so the whole chain of wgrads runs on the side stream beside the main chain (BatchNorm backward + dgrad) and is
+// joined ONCE: by an autograd-engine callback at the end of backward, or earlier by join_wgrad() (a gradient reducer that
+// reads dW in mid-backward).  Everything a deferred wgrad touches is handed to the allocator with recordStream, and a layer
+// is deferred only if its weight is a leaf parameter (allow_defer): a dW that another autograd node consumes during
+// backward -- the occupancy head's merged weight goes through CatBackward -- must be complete when its node returns.
+bool g_defer_join = false;
 
 SideStream& side_of(int device) {
   static SideStream tab[64];
   SideStream& s = tab[device & 63];
   if (!s.side) {
     static std::vector<c10::hip::HIPStream> keep;  // keeps the pooled stream objects alive
+    keep.reserve(64);
     keep.push_back(c10::hip::getStreamFromPool(false, (c10::DeviceIndex)device));
+    s.c10side = &keep.back();
     s.side = keep.back().stream();
     if (hipEventCreateWithFlags(&s.fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&s.join, hipEventDisableTiming) != hipSuccess)
       throw std::runtime_error("hipEventCreateWithFlags failed");
@@ -121,18 +147,37 @@ SideStream& side_of(int device) {
   return s;
 }
 
+void join_side(SideStream& s, hipStream_t main) {
+  if (!s.pending) return;
+  if (hipEventRecord(s.join, s.side) != hipSuccess || hipStreamWaitEvent(main, s.join, 0) != hipSuccess)
+    throw std::runtime_error("side-stream join failed");
+  s.pending = false;
+}
+
+// make the current stream wait for every weight gradient still in flight on the side stream (no-op when nothing is owed)
+void join_wgrad() {
+  const int dev = (int)c10::hip::current_device();
+  join_side(side_of(dev), c10::hip::getCurrentHIPStream().stream());
+}
+
+void set_defer_wgrad_join(bool on) { g_defer_join = on; }
+
 // din (n_src, Cin), dw (shape of w); either may come back undefined (None) when not needed.  overlap: wgrad runs on a side
 // stream beside dgrad (fork / join with events, no host sync); every temporary is released after the join has been enqueued,
 // so the caching allocator's stream-ordered reuse stays valid without recordStream.
 std::tuple<OptTensor, OptTensor> conv_bwd(const Tensor& features, const Tensor& w, const Tensor& map_fwd, const Tensor& map_bwd,
-                                          const Tensor& grad_out, bool need_din, bool need_dw, bool overlap, int64_t stream) {
+                                          const Tensor& grad_out, bool need_din, bool need_dw, bool overlap, bool allow_defer,
+                                          int64_t stream) {
   const int64_t cin = w.size(-2), cout = w.size(-1), K = map_fwd.size(1), n_res = map_fwd.size(0), n_src = map_bwd.size(0);
   need(grad_out.is_contiguous() && grad_out.scalar_type() == features.scalar_type(), "conv_bwd: grad must be contiguous and of the activation type");
   const bool bf = features.scalar_type() == at::kBFloat16;
   OptTensor din, dw;
   Tensor ws;
   hipStream_t main = (hipStream_t)st(stream);
-  SideStream* ss = (overlap && need_din && need_dw) ? &side_of(features.get_device()) : nullptr;
+  // ... and only when AccumulateGrad will adopt dW as .grad without touching it (an existing .grad means a read-modify-write
+  // on the main stream in mid-backward)
+  const bool defer = g_defer_join && need_dw && allow_defer && w.is_leaf() && !w.grad().defined();
+  SideStream* ss = ((overlap && need_din && need_dw) || defer) ? &side_of(features.get_device()) : nullptr;
   void* wstream = st(stream);
   if (ss) {
     if (hipEventRecord(ss->fork, main) != hipSuccess || hipStreamWaitEvent(ss->side, ss->fork, 0) != hipSuccess)
@@ -163,10 +208,32 @@ std::tuple<OptTensor, OptTensor> conv_bwd(const Tensor& features, const Tensor& 
                          (int)cin, (int)cout, (float*)d.data_ptr(), st(stream)), "btc_conv_dgrad");
     din = d;
   }
-  if (ss) {  // join: dW (and the release of ws / grad_out by the caller) is ordered after wgrad on the main stream
-    if (hipEventRecord(ss->join, ss->side) != hipSuccess || hipStreamWaitEvent(main, ss->join, 0) != hipSuccess)
-      throw std::runtime_error("side-stream join failed");
+  if (ss && !defer) {  // join: dW (and the release of ws / grad_out by the caller) is ordered after wgrad on the main stream
+    ss->pending = true;
+    join_side(*ss, main);
+  } else if (ss) {     // deferred: the temporaries outlive this call on the side stream; one join at the end of backward
+    ss->pending = true;
+    c10::hip::HIPCachingAllocator::recordStream(grad_out.storage().data_ptr(), *ss->c10side);
+    c10::hip::HIPCachingAllocator::recordStream(ws.storage().data_ptr(), *ss->c10side);
+    c10::hip::HIPCachingAllocator::recordStream(features.storage().data_ptr(), *ss->c10side);
+    c10::hip::HIPCachingAllocator::recordStream(dw->storage().data_ptr(), *ss->c10side);
+    // the rulebook is kept alive by this node's saved tensors only: once the node has run it may be freed on the main stream
+    c10::hip::HIPCachingAllocator::recordStream(map_fwd.storage().data_ptr(), *ss->c10side);
+    c10::hip::HIPCachingAllocator::recordStream(map_bwd.storage().data_ptr(), *ss->c10side);
+    if (!ss->callback_queued) {
+      SideStream* sp = ss;
+      try {
+        torch::autograd::Engine::get_default_engine().queue_callback([sp]() {
+          sp->callback_queued = false;
+          join_side(*sp, c10::hip::getCurrentHIPStream().stream());
+        });
+        ss->callback_queued = true;
+      } catch (const std::exception&) {  // not inside a backward pass: nobody would pay the join later
+        join_side(*ss, main);
+      }
+    }
   }
+  dbg_sync("conv_bwd");
   return std::make_tuple(din, dw);
 }
 
@@ -255,6 +322,7 @@ std::shared_ptr<PendingRb> rulebook_conv_start(const Tensor& indices, int64_t ba
                               ip(p_p), ip(p_d), (int)mode, (int32_t*)p->host_n, p->ws.data_ptr(), (size_t)ws_bytes, (void*)r.side),
       "btc_rulebook_conv_count");
   if (hipEventRecord(p->done, r.side) != hipSuccess) throw std::runtime_error("rulebook lookahead: event record failed");
+  dbg_sync("rulebook_conv_start");
   return p;
 }
 
@@ -269,6 +337,7 @@ std::tuple<Tensor, Tensor, Tensor> rulebook_conv_finish(const std::shared_ptr<Pe
   chk(btc_rulebook_conv_fill((const int32_t*)p->indices.data_ptr(), (int)n, (int)p->batch, ip(p->p_in), ip(p->p_out), ip(p->p_k), ip(p->p_s),
                              ip(p->p_p), ip(p->p_d), (int)p->mode, (int)n_out, (int32_t*)out_indices.data_ptr(), (int32_t*)nbr_out.data_ptr(),
                              (int32_t*)nbr_in.data_ptr(), p->ws.data_ptr(), (size_t)p->ws_bytes, (void*)main), "btc_rulebook_conv_fill");
+  dbg_sync("rulebook_conv_finish");
   return std::make_tuple(out_indices, nbr_out, nbr_in);
 }
 
@@ -279,7 +348,7 @@ struct ConvBNReLUNode : public torch::autograd::Function<ConvBNReLUNode> {
   static Tensor forward(torch::autograd::AutogradContext* ctx, const Tensor& features, const Tensor& weight, const OptTensor& bias,
                         const Tensor& map_fwd, const Tensor& map_bwd, const OptTensor& gamma, const OptTensor& beta, const OptTensor& rm,
                         const OptTensor& rv, const OptTensor& nbt, bool use_batch, double momentum, double eps, bool relu, const Tensor& ws,
-                        int64_t ws_bytes, bool overlap) {
+                        int64_t ws_bytes, bool overlap, bool allow_defer) {
     const int64_t stream = current_stream();
     auto r = conv_bn_fwd(features, weight, bias, map_fwd, gamma, beta, rm, rv, nbt, use_batch, momentum, eps, relu, ws, ws_bytes, stream);
     const Tensor g = (gamma.has_value() && gamma->defined()) ? *gamma : Tensor();
@@ -288,6 +357,7 @@ struct ConvBNReLUNode : public torch::autograd::Function<ConvBNReLUNode> {
     ctx->saved_data["relu"] = relu;
     ctx->saved_data["ws_bytes"] = ws_bytes;
     ctx->saved_data["overlap"] = overlap;
+    ctx->saved_data["allow_defer"] = allow_defer;
     ctx->saved_data["has_bias"] = bias.has_value() && bias->defined();
     return std::get<1>(r);
   }
@@ -307,7 +377,7 @@ struct ConvBNReLUNode : public torch::autograd::Function<ConvBNReLUNode> {
     const Tensor& dx = std::get<0>(b);
     const Tensor& dparam = std::get<1>(b);
     auto cb = conv_bwd(features, w, map_fwd, map_bwd, dx, ctx->needs_input_grad(0), ctx->needs_input_grad(1),
-                       ctx->saved_data["overlap"].toBool(), stream);
+                       ctx->saved_data["overlap"].toBool(), ctx->saved_data["allow_defer"].toBool(), stream);
     Tensor din = std::get<0>(cb).has_value() ? *std::get<0>(cb) : Tensor();
     Tensor dw = std::get<1>(cb).has_value() ? *std::get<1>(cb) : Tensor();
     Tensor db;
@@ -318,15 +388,15 @@ struct ConvBNReLUNode : public torch::autograd::Function<ConvBNReLUNode> {
       dbeta = dparam[1];
     }
     return {din, dw, db, Tensor(), Tensor(), dgamma, dbeta, Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(),
-            Tensor()};
+            Tensor(), Tensor()};
   }
 };
 
 Tensor conv_bn_relu(const Tensor& features, const Tensor& weight, const OptTensor& bias, const Tensor& map_fwd, const Tensor& map_bwd,
                     const OptTensor& gamma, const OptTensor& beta, const OptTensor& rm, const OptTensor& rv, const OptTensor& nbt, bool use_batch,
-                    double momentum, double eps, bool relu, const Tensor& ws, int64_t ws_bytes, bool overlap) {
+                    double momentum, double eps, bool relu, const Tensor& ws, int64_t ws_bytes, bool overlap, bool allow_defer) {
   return ConvBNReLUNode::apply(features, weight, bias, map_fwd, map_bwd, gamma, beta, rm, rv, nbt, use_batch, momentum, eps, relu, ws, ws_bytes,
-                               overlap);
+                               overlap, allow_defer);
 }
 
 }  // namespace
@@ -339,6 +409,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("bn_bwd", &bn_bwd);
   m.def("conv_bwd", &conv_bwd);
   m.def("conv_bn_relu", &conv_bn_relu);
+  m.def("join_wgrad", &join_wgrad);
+  m.def("set_defer_wgrad_join", &set_defer_wgrad_join);
   m.def("rulebook_subm", &rulebook_subm);
   m.def("rulebook_conv", &rulebook_conv);
   py::class_<PendingRb, std::shared_ptr<PendingRb>>(m, "PendingRb");

@@ -54,6 +54,9 @@ class BucketedGradSync(object):
         if early and any(g is None for g in grads):
             return  # not complete yet: finish() will send it
         b.launched = True
+        if b.flat.is_cuda:
+            from .spconv import ops
+            ops.join_wgrad()  # weight gradients may still be in flight on the side stream (ops.set_defer_wgrad_join)
         have = [(v, g) for v, g in zip(b.views, grads) if g is not None]
         if len(have) != len(grads):  # a parameter without gradient this step contributes zeros
             b.flat.zero_()

@@ -439,6 +439,23 @@ OVERLAP_MIN_ROWS = int(os.environ.get("BTC_OVERLAP_MIN_ROWS", "20000"))
 OVERLAP_MAX_ROWS = int(os.environ.get("BTC_OVERLAP_MAX_ROWS", "100000"))  # above: both kernels fill the GPU alone, side by side 450 us vs 219 + 150
 
 
+def set_defer_wgrad_join(on):
+    """compiled binding only: run every weight gradient on the side stream and join it once, at the end of backward (an
+    autograd-engine callback) -- weight gradients are off the critical path of the backward chain.  A caller that reads
+    dW before backward returns (a gradient reducer launched from a hook) must call join_wgrad() first; DistributedDataParallel
+    does read in mid-backward, so leave this off under DDP."""
+    F = fast()
+    if F is not None:
+        F.set_defer_wgrad_join(bool(on))
+    return F is not None
+
+
+def join_wgrad():
+    F = fast()
+    if F is not None:
+        F.join_wgrad()
+
+
 def _overlap_ok(n_res):
     return OVERLAP_WGRAD and OVERLAP_MIN_ROWS <= n_res < OVERLAP_MAX_ROWS
 
@@ -461,7 +478,7 @@ def _conv_forward(features, w, b, map_fwd):
     return out
 
 
-def _conv_backward(features, w, map_fwd, map_bwd, grad_out, wshape, need_din, need_dw):
+def _conv_backward(features, w, map_fwd, map_bwd, grad_out, wshape, need_din, need_dw, allow_defer=False):
     bf = features.dtype == torch.bfloat16
     cin, cout = w.shape[-2], w.shape[-1]
     K = map_fwd.shape[1]
@@ -474,7 +491,7 @@ def _conv_backward(features, w, map_fwd, map_bwd, grad_out, wshape, need_din, ne
     if PROFILE is None:
         F = fast()
         if F is not None:
-            return F.conv_bwd(features, w, map_fwd, map_bwd, grad_out, bool(need_din), bool(need_dw), overlap, stream_ptr())
+            return F.conv_bwd(features, w, map_fwd, map_bwd, grad_out, bool(need_din), bool(need_dw), overlap, bool(allow_defer), stream_ptr())
     side = _side_stream(dev) if (overlap and PROFILE is None) else None
     if need_dw:
         ws_bytes = L.btc_conv_wgrad_ws_bytes(n_res, K, cin, cout, n_src)
@@ -519,13 +536,15 @@ class SparseConvFunction(torch.autograd.Function):
         ctx.save_for_backward(features, w, map_fwd, map_bwd)
         ctx.has_bias = bias is not None
         ctx.wshape = tuple(weight.shape)
+        ctx.leaf_w = bool(weight.is_leaf)  # a dW consumed by another autograd node (cat of head weights) must not be deferred
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
         features, w, map_fwd, map_bwd = ctx.saved_tensors
         grad_out = _actc(grad_out if grad_out.dtype == features.dtype else grad_out.to(features.dtype))
-        din, dw = _conv_backward(features, w, map_fwd, map_bwd, grad_out, ctx.wshape, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        din, dw = _conv_backward(features, w, map_fwd, map_bwd, grad_out, ctx.wshape, ctx.needs_input_grad[0], ctx.needs_input_grad[1],
+                                 ctx.leaf_w)
         db = grad_out.sum(0, dtype=torch.float32) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
         return din, dw, db, None, None
 
@@ -553,17 +572,17 @@ class SparseConvBNReLUFunction(torch.autograd.Function):
         if CAPTURE is not None:
             CAPTURE.append((features, w, b, map_fwd, map_bwd))
         ctx.save_for_backward(features, w, map_fwd, map_bwd, x, y, gamma, stats)
-        ctx.flags = (bias is not None, tuple(weight.shape), use_batch, bool(relu))
+        ctx.flags = (bias is not None, tuple(weight.shape), use_batch, bool(relu), bool(weight.is_leaf))
         return y
 
     @staticmethod
     def backward(ctx, dy):
         from . import fused_bn
         features, w, map_fwd, map_bwd, x, y, gamma, stats = ctx.saved_tensors
-        has_bias, wshape, use_batch, relu = ctx.flags
+        has_bias, wshape, use_batch, relu, leaf_w = ctx.flags
         dy = (dy if dy.dtype == x.dtype else dy.to(x.dtype)).contiguous()
         dx, dgamma, dbeta = fused_bn.bn_backward(x, y, dy, gamma, stats, use_batch, relu)
-        din, dw = _conv_backward(features, w, map_fwd, map_bwd, dx, wshape, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        din, dw = _conv_backward(features, w, map_fwd, map_bwd, dx, wshape, ctx.needs_input_grad[0], ctx.needs_input_grad[1], leaf_w)
         db = dx.sum(0, dtype=torch.float32) if (has_bias and ctx.needs_input_grad[2]) else None
         affine = gamma is not None
         return (din, dw, db, None, None, dgamma if affine else None, dbeta if affine else None, None, None, None, None, None, None, None)
@@ -648,7 +667,7 @@ def indice_conv_bn_relu(features, weight, bias, rulebook, bn, relu, inverse=Fals
         from . import fused_bn
         ws, need = fused_bn._ws(features.device, weight.shape[-1])
         return F.conv_bn_relu(_actc(features), _f32c(weight), bias, maps[0], maps[1], bn.weight, bn.bias, rm, rv, nbt, bool(training or rm is None),
-                              float(bn.momentum), float(bn.eps), bool(relu), ws, need, bool(_overlap_ok(maps[0].shape[0])))
+                              float(bn.momentum), float(bn.eps), bool(relu), ws, need, bool(_overlap_ok(maps[0].shape[0])), bool(weight.is_leaf))
     return SparseConvBNReLUFunction.apply(features, weight, bias, maps[0], maps[1], bn.weight, bn.bias, rm, rv, nbt, training, bn.momentum,
                                           bn.eps, relu)
 
