@@ -110,6 +110,23 @@ class LeanFusedAdam(object):
                                weight_decay=g["weight_decay"], eps=self.eps, amsgrad=False, maximize=False)
 
 
+class MeanSquare(torch.autograd.Function):
+    """scale * mean(x^2): the L2 stand-in for the out-of-scope consumers of the detection branch (BEV backbone + dense head,
+    point head), one reduction forward and one elementwise launch backward instead of autograd's pow / mean / mul chain"""
+
+    @staticmethod
+    def forward(ctx, x, scale):
+        ctx.save_for_backward(x)
+        ctx.k = float(scale) / max(x.numel(), 1)
+        n = torch.linalg.vector_norm(x.reshape(-1), dtype=torch.float32)
+        return n * n * ctx.k
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        return (x * (g * (2.0 * ctx.k)).to(x.dtype)), None
+
+
 def make_step(model, ddp, proc, opts, grad_sync=None):
     def step(batch):
         for o in opts:
@@ -120,7 +137,7 @@ def make_step(model, ddp, proc, opts, grad_sync=None):
                    "bm_points": batch["bm_points"], "rot_z": batch["rot_z"], "is_train": True})
         ret, tb, _ = ddp(bd)
         # occupancy loss (real) + L2 stand-ins for the out-of-scope consumers of the detection branch
-        loss = ret["loss_occ"] + 1e-3 * ret["spatial_features"].pow(2).mean() + 1e-3 * ret["x_combine"].float().pow(2).mean()
+        loss = ret["loss_occ"] + MeanSquare.apply(ret["spatial_features"], 1e-3) + MeanSquare.apply(ret["x_combine"], 1e-3)
         loss.backward()
         if grad_sync is not None:
             grad_sync.finish()  # all-reduced mean gradients in param.grad (the detection bucket has been travelling since mid-backward)

@@ -104,6 +104,8 @@ _SIGS = {
     "btc_bn_relu_bwd": (ci, [vp, vp, vp, ci, ci, vp, vp, vp, ci, ci, vp, vp, vp, vp, sz, vp]),
     "btc_bn_relu_fwd_bf16": (ci, [vp, ci, ci, vp, vp, vp, vp, vp, ctypes.c_float, ctypes.c_float, ci, ci, vp, vp, vp, vp, sz, vp]),
     "btc_bn_relu_bwd_bf16": (ci, [vp, vp, vp, ci, ci, vp, vp, vp, ci, ci, vp, vp, vp, vp, sz, vp]),
+    "btc_col_sum": (ci, [vp, ci, ci, vp, vp, sz, vp]),
+    "btc_col_sum_bf16": (ci, [vp, ci, ci, vp, vp, sz, vp]),
     "btc_occ_targets_ws_bytes": (sz, [ctypes.POINTER(BtcOccConfig)]),
     "btc_occ_targets": (ci, [ctypes.POINTER(BtcOccConfig), vp, vp, vp, ci, ci, ci, vp, vp, vp, vp, ci, vp, vp,
                              ctypes.POINTER(BtcOccBuffers), vp, sz, vp]),

@@ -275,8 +275,8 @@ class VoxelBackBone8xOcc(nn.Module):
         x4.features = torch.cat((x2.features, x3.features, x4.features), dim=1)
         if out_feat_type == "big_bev_combine":
             bev2d = self.compress_height(self.squeezeBev(bev))
-            inds = x4.indices.long()
-            x4.features = torch.cat((x4.features, bev2d[inds[..., 0], :, inds[..., 2], inds[..., 3]].to(x4.features.dtype)), dim=1)
+            x4.features = torch.cat((x4.features, _BevGather.apply(bev2d, x4.indices, tuple(x4.spatial_shape), x4.batch_size)
+                                     .to(x4.features.dtype)), dim=1)
         return self.down_combine(x4)
 
     def forward(self, batch_dict):
@@ -330,6 +330,27 @@ class VoxelBackBone8xOcc(nn.Module):
 # lateral "combine" decoders and the inverse-convolution decoder.  Same constructor arguments, parameter names and
 # batch_dict keys as /root/reference/btcdet/models/backbones_3d/spconv_backbone.py:50-88,226-627.
 # ----------------------------------------------------------------------------------------------------------------------
+class _BevGather(torch.autograd.Function):
+    """rows[r] = bev2d[b_r, :, y_r, x_r] for the active cells [b,z,y,x] of a sparse tensor (spconv_backbone.py:1045-1048 writes
+    this as advanced indexing).  Same forward; the backward of advanced indexing is index_put_(accumulate=True) -- ~20 launches
+    on ROCm (index linearisation, a radix sort, the segmented accumulation) -- and here the gradient rows are scattered into
+    the dense (B, C, D, H, W) volume (one launch, the .dense() kernel) and summed over D."""
+
+    @staticmethod
+    def forward(ctx, bev2d, indices, spatial_shape, batch_size):
+        inds = indices.long()
+        ctx.save_for_backward(indices)
+        ctx.meta = (spatial_shape, batch_size, bev2d.dtype)
+        return bev2d[inds[:, 0], :, inds[:, 2], inds[:, 3]]
+
+    @staticmethod
+    def backward(ctx, grad):
+        (indices,) = ctx.saved_tensors
+        spatial_shape, batch_size, dtype = ctx.meta
+        vol = spconv.SparseConvTensor(grad.contiguous(), indices, list(spatial_shape), batch_size).dense()
+        return vol.sum(2).to(dtype), None, None, None
+
+
 class SparseBasicBlock(spconv.SparseModule):
     """two SubM 3x3x3 convs (with bias) + BatchNorm, identity shortcut, ReLU (spconv_backbone.py:50-88)"""
     expansion = 1

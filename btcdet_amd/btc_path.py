@@ -86,6 +86,9 @@ class BtcHotPath(nn.Module):
         if batch_dict["is_train"]:
             use_occ_prob = prob <= self.percentage
         batch_dict["use_occ_prob"] = use_occ_prob
+        head = self.occ_modules.occ_dense_head
+        if hasattr(head, "premerge"):
+            head.premerge()  # the merged head weight is built before the backbone runs, so its CatBackward runs after it
         for mod in self.occ_module_list:
             batch_dict = mod(batch_dict)
         for mod in self.det_module_list:

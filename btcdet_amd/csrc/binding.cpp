@@ -176,7 +176,8 @@ std::tuple<OptTensor, OptTensor> conv_bwd(const Tensor& features, const Tensor& 
   hipStream_t main = (hipStream_t)st(stream);
   // ... and only when AccumulateGrad will adopt dW as .grad without touching it (an existing .grad means a read-modify-write
   // on the main stream in mid-backward)
-  const bool defer = g_defer_join && need_dw && allow_defer && w.is_leaf() && !w.grad().defined();
+  // on the main stream in mid-backward); for a non-leaf weight the caller vouches that its consumer joins first (allow_defer)
+  const bool defer = g_defer_join && need_dw && allow_defer && (!w.is_leaf() || !w.grad().defined());
   SideStream* ss = ((overlap && need_din && need_dw) || defer) ? &side_of(features.get_device()) : nullptr;
   void* wstream = st(stream);
   if (ss) {
@@ -381,7 +382,15 @@ struct ConvBNReLUNode : public torch::autograd::Function<ConvBNReLUNode> {
     Tensor din = std::get<0>(cb).has_value() ? *std::get<0>(cb) : Tensor();
     Tensor dw = std::get<1>(cb).has_value() ? *std::get<1>(cb) : Tensor();
     Tensor db;
-    if (ctx->saved_data["has_bias"].toBool() && ctx->needs_input_grad(2)) db = dx.sum(at::IntArrayRef{0}, false, at::kFloat);
+    if (ctx->saved_data["has_bias"].toBool() && ctx->needs_input_grad(2)) {  // the same column-sum kernel as ops._bias_grad
+      db = at::empty({dx.size(1)}, dx.options().dtype(at::kFloat));
+      if (dx.scalar_type() == at::kBFloat16)
+        chk(btc_col_sum_bf16(dx.data_ptr(), (int)dx.size(0), (int)dx.size(1), (float*)db.data_ptr(), ws.data_ptr(), (size_t)ws_bytes, st(stream)),
+            "btc_col_sum_bf16");
+      else
+        chk(btc_col_sum((const float*)dx.data_ptr(), (int)dx.size(0), (int)dx.size(1), (float*)db.data_ptr(), ws.data_ptr(), (size_t)ws_bytes,
+                        st(stream)), "btc_col_sum");
+    }
     Tensor dgamma, dbeta;
     if (gamma.defined()) {
       dgamma = dparam[0];

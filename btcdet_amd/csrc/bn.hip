@@ -282,6 +282,50 @@ __global__ __launch_bounds__(BN_T) void bn_bwd_apply(const float* __restrict__ x
   else btc_st1<BF>(dx, i, o[0]);
 }
 
+// column sums of an (N, C) matrix (the bias gradient of a sparse conv): same two-level, fixed-order scheme as bn_bwd_stats
+template <bool BF>
+__global__ __launch_bounds__(BN_T) void col_sum(const float* __restrict__ x, BnShape S, double* __restrict__ partial,
+                                                int32_t* __restrict__ counter, float* __restrict__ out) {
+  __shared__ double s_a[BN_T];
+  const int tid = threadIdx.x;
+  for (int c0 = 0; c0 < S.C; c0 += S.cpow) {
+    const int c = c0 + (tid % S.cpow), rr = tid / S.cpow;
+    double a = 0.0;
+    if (c < S.C) {
+      const long long stride = (long long)gridDim.x * S.rpi;
+      long long r = (long long)blockIdx.x * S.rpi + rr;
+      for (; r + 3 * stride < S.N; r += 4 * stride) {
+        float v0 = btc_ld1<BF>(x, r * S.C + c), v1 = btc_ld1<BF>(x, (r + stride) * S.C + c), v2 = btc_ld1<BF>(x, (r + 2 * stride) * S.C + c),
+              v3 = btc_ld1<BF>(x, (r + 3 * stride) * S.C + c);
+        a += ((double)v0 + (double)v1) + ((double)v2 + (double)v3);
+      }
+      for (; r < S.N; r += stride) a += (double)btc_ld1<BF>(x, r * S.C + c);
+    }
+    s_a[tid] = a;
+    __syncthreads();
+    if (rr == 0 && c < S.C) {
+      for (int q = 1; q < S.rpi; ++q) a += s_a[tid + q * S.cpow];
+      partial[(size_t)blockIdx.x * S.C + c] = a;
+    }
+    __syncthreads();
+  }
+  if (!last_block(counter)) return;
+  for (int c0 = 0; c0 < S.C; c0 += S.cpow) {
+    const int c = c0 + (tid % S.cpow), rr = tid / S.cpow;
+    double a = 0.0;
+    if (c < S.C)
+      for (int g = rr; g < (int)gridDim.x; g += S.rpi) a += partial[(size_t)g * S.C + c];
+    s_a[tid] = a;
+    __syncthreads();
+    if (rr == 0 && c < S.C) {
+      for (int q = 1; q < S.rpi; ++q) a += s_a[tid + q * S.cpow];
+      out[c] = (float)a;
+    }
+    __syncthreads();
+  }
+  if (tid == 0) __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 BnShape bn_shape(int N, int C) {
   BnShape S;
   S.N = N;
@@ -358,6 +402,26 @@ static int bn_bwd_impl(const float* x, const float* y, const float* dy, int N, i
                                                                    training, dx);
   BTC_LAUNCH_CHECK();
   return BTC_OK;
+}
+
+// out[c] = sum over rows of x[r][c] (fp64 accumulation, deterministic).  ws as for btc_bn_relu_fwd.
+template <bool BF>
+static int col_sum_impl(const float* x, int N, int C, float* out, void* ws, size_t ws_bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  BTC_CHECK_ARG(N >= 1 && C >= 1, "btc_col_sum: empty input");
+  BTC_CHECK_ARG(ws_bytes >= btc_bn_ws_bytes(C), "btc_col_sum: workspace too small");
+  BnShape S = bn_shape(N, C);
+  col_sum<BF><<<bn_grid_bwd(N, S), BN_T, 0, stream>>>(x, S, (double*)((char*)ws + 256), (int32_t*)ws, out);
+  BTC_LAUNCH_CHECK();
+  return BTC_OK;
+}
+
+extern "C" int btc_col_sum(const float* x, int N, int C, float* out, void* ws, size_t ws_bytes, void* stream) {
+  return col_sum_impl<false>(x, N, C, out, ws, ws_bytes, stream);
+}
+
+extern "C" int btc_col_sum_bf16(const void* x, int N, int C, float* out, void* ws, size_t ws_bytes, void* stream) {
+  return col_sum_impl<true>((const float*)x, N, C, out, ws, ws_bytes, stream);
 }
 
 extern "C" int btc_bn_relu_fwd(const float* x, int N, int C, const float* gamma, const float* beta, float* running_mean,

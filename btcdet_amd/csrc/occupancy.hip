@@ -461,7 +461,6 @@ extern "C" int btc_occ_targets(const BtcOccConfig* cfg, float* voxels, const int
   P.use_box_weight = cfg->use_box_weight;
 
   const size_t vol = (size_t)P.nx * P.ny * P.nz * P.B;
-  const size_t svol = (size_t)P.snx * P.sny * P.snz * P.B;
   uint8_t *smap, *occ_raw, *mirr_raw;
   float *sums, *colmin;
   int32_t *cnts, *ray_cnt;
@@ -469,15 +468,19 @@ extern "C" int btc_occ_targets(const BtcOccConfig* cfg, float* voxels, const int
   float *fore_sum = sums, *mirr_sum = sums + vol * 3, *bm_sum = sums + vol * 6;
   int32_t *fore_cnt = cnts, *mirr_cnt = cnts + vol, *bm_cnt = cnts + vol * 2;
 
-  BTC_HIP(hipMemsetAsync(smap, 0, svol, stream));
-  BTC_HIP(hipMemsetAsync(occ_raw, 0, vol, stream));
-  BTC_HIP(hipMemsetAsync(mirr_raw, 0, vol, stream));
-  BTC_HIP(hipMemsetAsync(sums, 0, vol * 9 * sizeof(float), stream));
-  BTC_HIP(hipMemsetAsync(cnts, 0, vol * 3 * sizeof(int32_t), stream));
-  BTC_HIP(hipMemsetAsync(out->vcc_mask, 0, vol, stream));
-  BTC_HIP(hipMemsetAsync(out->voxelwise_mask, 0, vol, stream));
-  BTC_HIP(hipMemsetAsync(out->fore_voxelwise_mask, 0, vol, stream));
-  BTC_HIP(hipMemsetAsync(out->bm_voxelwise_mask, 0, vol, stream));
+  // workspace: smap | occ_raw | mirr_raw | sums | cnts are carved back to back (occ_ws_layout) -> one memset
+  BTC_HIP(hipMemsetAsync(smap, 0, (size_t)((char*)ray_cnt - (char*)smap), stream));
+  uint8_t* m0 = (uint8_t*)out->vcc_mask;
+  if ((uint8_t*)out->voxelwise_mask == m0 + vol && (uint8_t*)out->bm_voxelwise_mask == m0 + 2 * vol &&
+      (uint8_t*)out->occ_voxelwise_mask == m0 + 3 * vol && (uint8_t*)out->fore_voxelwise_mask == m0 + 4 * vol) {
+    // the caller laid the five byte masks out as one (5, vol) block (occ_voxelwise_mask is overwritten by occ_finalize)
+    BTC_HIP(hipMemsetAsync(m0, 0, 5 * vol, stream));
+  } else {
+    BTC_HIP(hipMemsetAsync(out->vcc_mask, 0, vol, stream));
+    BTC_HIP(hipMemsetAsync(out->voxelwise_mask, 0, vol, stream));
+    BTC_HIP(hipMemsetAsync(out->fore_voxelwise_mask, 0, vol, stream));
+    BTC_HIP(hipMemsetAsync(out->bm_voxelwise_mask, 0, vol, stream));
+  }
   BTC_HIP(hipMemsetAsync(out->pos_all_num, 0, sizeof(int32_t), stream));
 
   const int T = 256;

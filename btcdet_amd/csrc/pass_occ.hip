@@ -54,7 +54,7 @@ __device__ __forceinline__ int block_excl_scan_i(int v, int* s_w, int* total) {
 }
 
 // find, scanning bins from the TOP, the bin where the running count reaches `want`; returns bin, writes the count above it
-__device__ __forceinline__ void find_bin(const int* __restrict__ hist /*2048 LDS*/, int want, int* s_w, int* s_res /*[2]*/) {
+__device__ __forceinline__ int find_bin(const int* __restrict__ hist /*2048 LDS*/, int want, int* s_w, int* s_res /*[2]*/) {
   // thread t owns bins 2047-2t and 2046-2t (descending order), exclusive scan of their sums
   const int t = threadIdx.x;
   int h0 = hist[2047 - 2 * t], h1 = hist[2046 - 2 * t];
@@ -63,6 +63,7 @@ __device__ __forceinline__ void find_bin(const int* __restrict__ hist /*2048 LDS
   if (ex < want && want <= ex + h0) { s_res[0] = 2047 - 2 * t; s_res[1] = ex; }
   else if (ex + h0 < want && want <= ex + h0 + h1) { s_res[0] = 2046 - 2 * t; s_res[1] = ex + h0; }
   __syncthreads();
+  return tot;
 }
 
 __global__ __launch_bounds__(1024) void pov_select(const float* __restrict__ probs, const uint8_t* __restrict__ use, PovGeom G, float thresh,
@@ -149,6 +150,171 @@ __global__ __launch_bounds__(1024) void pov_select(const float* __restrict__ pro
     eq_seen += tot_e;
   }
   if (tid == 0) counts[b] = base;
+}
+
+// ------------------------------------------------------------------ the same selection across many workgroups
+// pov_select walks a scene's 2.8 M cells five times with ONE workgroup (205 us for two KITTI scenes).  Same arithmetic, spread
+// over (chunks x scenes) workgroups: three histogram passes into a global histogram (each later pass re-derives the prefix
+// of the earlier ones from it), per-chunk counts of kept / tied cells, one scan per scene, and the ordered write.
+constexpr int POV_CHUNK = 16384;  // cells per workgroup = 4 iterations of the 1024 x 4 ordered-compaction tile
+
+struct PovSel { unsigned prefix, pmask; int want, all; };
+
+// prefix of the max_k-th largest key after `npass` radix passes (the passes' histograms are complete in ghist_b)
+__device__ PovSel pov_resolve(const int* __restrict__ ghist_b, int npass, int max_k, int* s_hist, int* s_w, int* s_res) {
+  PovSel r{0u, 0u, max_k, 0};
+  const int shifts[3] = {21, 10, 0};
+  const int widths[3] = {11, 11, 10};
+  for (int q = 0; q < npass; ++q) {
+    for (int i = threadIdx.x; i < 2048; i += 1024) s_hist[i] = ghist_b[q * 2048 + i];
+    __syncthreads();
+    const int tot = find_bin(s_hist, r.want, s_w, s_res);
+    if (q == 0 && tot <= max_k) { r.all = 1; return r; }  // fewer candidates than the cap: keep them all
+    const int bin = s_res[0], above = s_res[1];
+    r.want -= above;
+    r.prefix |= (unsigned)bin << shifts[q];
+    r.pmask |= ((1u << widths[q]) - 1u) << shifts[q];
+    __syncthreads();
+  }
+  return r;
+}
+
+template <int PASS>
+__global__ __launch_bounds__(1024) void pov_hist(const float* __restrict__ probs, const uint8_t* __restrict__ use, PovGeom G, float thresh,
+                                                 int* __restrict__ ghist) {
+  __shared__ int s_hist[2048];
+  __shared__ int s_w[1024 / 64 + 1];
+  __shared__ int s_res[2];
+  const int b = blockIdx.y, tid = threadIdx.x;
+  if (use && !use[b]) return;
+  int* gh = ghist + (size_t)b * 3 * 2048;
+  PovSel r = pov_resolve(gh, PASS, G.max_k, s_hist, s_w, s_res);
+  if (r.all) return;
+  for (int i = tid; i < 2048; i += 1024) s_hist[i] = 0;
+  __syncthreads();
+  const float* p = probs + (size_t)b * G.ncell;
+  const unsigned* pk = reinterpret_cast<const unsigned*>(p);
+  const int shifts[3] = {21, 10, 0};
+  const int widths[3] = {11, 11, 10};
+  const int lo = blockIdx.x * POV_CHUNK, hi = min(lo + POV_CHUNK, G.ncell);
+  for (int i = lo + tid; i < hi; i += 1024) {
+    const unsigned k = pk[i];
+    if (p[i] > thresh && (k & r.pmask) == r.prefix) atomicAdd(&s_hist[(k >> shifts[PASS]) & ((1u << widths[PASS]) - 1u)], 1);
+  }
+  __syncthreads();
+  for (int i = tid; i < 2048; i += 1024)
+    if (s_hist[i]) atomicAdd(&gh[PASS * 2048 + i], s_hist[i]);
+}
+
+// per chunk: cells kept outright (key > T, or every candidate) and cells tied at T; chunk 0 publishes (T, need_eq, all)
+__global__ __launch_bounds__(1024) void pov_chunk_count(const float* __restrict__ probs, const uint8_t* __restrict__ use, PovGeom G, float thresh,
+                                                        const int* __restrict__ ghist, int n_chunk, int32_t* __restrict__ cc,
+                                                        int32_t* __restrict__ state) {
+  __shared__ int s_hist[2048];
+  __shared__ int s_w[1024 / 64 + 1];
+  __shared__ int s_res[2];
+  __shared__ int s_nf, s_ne;
+  const int b = blockIdx.y, tid = threadIdx.x;
+  if (use && !use[b]) return;
+  PovSel r = pov_resolve(ghist + (size_t)b * 3 * 2048, 3, G.max_k, s_hist, s_w, s_res);
+  const unsigned T = r.all ? 0u : r.prefix;
+  if (tid == 0) { s_nf = 0; s_ne = 0; }
+  __syncthreads();
+  const float* p = probs + (size_t)b * G.ncell;
+  const unsigned* pk = reinterpret_cast<const unsigned*>(p);
+  const int lo = blockIdx.x * POV_CHUNK, hi = min(lo + POV_CHUNK, G.ncell);
+  int nf = 0, ne = 0;
+  for (int i = lo + tid; i < hi; i += 1024) {
+    const bool cand = p[i] > thresh;
+    const unsigned k = pk[i];
+    nf += cand && (r.all || k > T);
+    ne += cand && !r.all && k == T;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { nf += __shfl_down(nf, o, 64); ne += __shfl_down(ne, o, 64); }
+  if ((tid & 63) == 0) { atomicAdd(&s_nf, nf); atomicAdd(&s_ne, ne); }
+  __syncthreads();
+  if (tid == 0) {
+    cc[((size_t)b * n_chunk + blockIdx.x) * 2 + 0] = s_nf;
+    cc[((size_t)b * n_chunk + blockIdx.x) * 2 + 1] = s_ne;
+    if (blockIdx.x == 0) { state[b * 4 + 0] = (int)T; state[b * 4 + 1] = r.all ? 0 : r.want; state[b * 4 + 2] = r.all; }
+  }
+}
+
+// one workgroup per scene: chunk -> (first output slot, ties seen before the chunk); counts[b] = cells selected
+__global__ __launch_bounds__(1024) void pov_chunk_scan(const uint8_t* __restrict__ use, int n_chunk, const int32_t* __restrict__ cc,
+                                                       const int32_t* __restrict__ state, int32_t* __restrict__ co,
+                                                       int32_t* __restrict__ counts) {
+  __shared__ int s_w[1024 / 64 + 1];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  if (use && !use[b]) {
+    if (tid == 0) counts[b] = 0;
+    return;
+  }
+  const int need_eq = state[b * 4 + 1];
+  int base_t = 0, base_e = 0;
+  for (int c0 = 0; c0 < n_chunk; c0 += 1024) {
+    const int c = c0 + tid;
+    const int nf = c < n_chunk ? cc[((size_t)b * n_chunk + c) * 2 + 0] : 0, ne = c < n_chunk ? cc[((size_t)b * n_chunk + c) * 2 + 1] : 0;
+    int tot_e, tot_t;
+    const int ex_e = block_excl_scan_i<1024>(ne, s_w, &tot_e) + base_e;
+    int take_e = need_eq - ex_e;
+    take_e = take_e < 0 ? 0 : (take_e > ne ? ne : take_e);
+    const int ex_t = block_excl_scan_i<1024>(nf + take_e, s_w, &tot_t) + base_t;
+    if (c < n_chunk) {
+      co[((size_t)b * n_chunk + c) * 2 + 0] = ex_t;
+      co[((size_t)b * n_chunk + c) * 2 + 1] = ex_e;
+    }
+    base_t += tot_t;
+    base_e += tot_e;
+  }
+  if (tid == 0) counts[b] = base_t;
+}
+
+// ordered compaction of one chunk (the loop body of pov_select, started at the chunk's offsets)
+__global__ __launch_bounds__(1024) void pov_chunk_write(const float* __restrict__ probs, const uint8_t* __restrict__ use, PovGeom G, float thresh,
+                                                        int n_chunk, const int32_t* __restrict__ co, const int32_t* __restrict__ state,
+                                                        int32_t* __restrict__ sel) {
+  __shared__ int s_w[1024 / 64 + 1];
+  const int b = blockIdx.y, tid = threadIdx.x;
+  if (use && !use[b]) return;
+  const unsigned T = (unsigned)state[b * 4 + 0];
+  const int need_eq = state[b * 4 + 1];
+  const bool all = state[b * 4 + 2] != 0;
+  const float* p = probs + (size_t)b * G.ncell;
+  const unsigned* pk = reinterpret_cast<const unsigned*>(p);
+  int base = co[((size_t)b * n_chunk + blockIdx.x) * 2 + 0], eq_seen = co[((size_t)b * n_chunk + blockIdx.x) * 2 + 1];
+  int32_t* out = sel + (size_t)b * G.max_k;
+  const int lo = blockIdx.x * POV_CHUNK, hi = min(lo + POV_CHUNK, G.ncell);
+  for (int start = lo; start < hi; start += 1024 * 4) {
+    const int i0 = start + tid * 4;
+    int f[4], e[4], ne = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int i = i0 + j;
+      bool cand = i < hi && p[i] > thresh;
+      unsigned k = cand ? pk[i] : 0u;
+      f[j] = cand && (all || k > T);
+      e[j] = cand && !all && k == T;
+      ne += e[j];
+    }
+    int tot_e, tot_f;
+    const int ex_e = block_excl_scan_i<1024>(ne, s_w, &tot_e) + eq_seen;
+    int te = 0, take[4], nt = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      take[j] = f[j] || (e[j] && (ex_e + te) < need_eq);
+      te += e[j];
+      nt += take[j];
+    }
+    const int ex_t = block_excl_scan_i<1024>(nt, s_w, &tot_f) + base;
+    int pos = ex_t;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (take[j]) out[pos++] = i0 + j;
+    base += tot_f;
+    eq_seen += tot_e;
+  }
 }
 
 // selected occupancy cell -> added point [x,y,z,prob] and its detection-grid cell key (add_occ_template.py:131-146,78-88)
@@ -328,7 +494,8 @@ __global__ __launch_bounds__(256) void pov_compact_occ(const float* __restrict__
 }
 
 struct PovWs {
-  int32_t *sel, *counts, *info, *point_row, *cnt, *offs, *cursor, *perm, *prefix, *d_m;
+  int32_t *sel, *counts, *info, *point_row, *cnt, *offs, *cursor, *perm, *prefix, *d_m, *ghist, *cc, *co, *state;
+  int n_chunk;
   float* occ_xyzp;
   unsigned *occ_key, *bitmap;
   void* scan_ws;
@@ -343,16 +510,22 @@ PovWs pov_carve(void* ws, const PovGeom& G) {
   BtcCarver cv(ws);
   w.sel = cv.take<int32_t>((size_t)G.B * G.max_k);
   w.counts = cv.take<int32_t>(G.B);
-  w.info = cv.take<int32_t>(2 + G.B);
   w.d_m = cv.take<int32_t>(1);
   w.occ_xyzp = cv.take<float>((size_t)G.B * G.max_k * 4);
   w.occ_key = cv.take<unsigned>((size_t)G.B * G.max_k);
+  w.n_chunk = btc_cdiv(G.ncell, POV_CHUNK);
+  w.cc = cv.take<int32_t>((size_t)G.B * w.n_chunk * 2);
+  w.co = cv.take<int32_t>((size_t)G.B * w.n_chunk * 2);
+  w.state = cv.take<int32_t>((size_t)G.B * 4);
+  // the arrays that start zeroed are adjacent: one memset covers [info, prefix)
+  w.info = cv.take<int32_t>(2 + G.B);
+  w.ghist = cv.take<int32_t>((size_t)G.B * 3 * 2048);
+  w.cnt = cv.take<int32_t>(w.nv + 1);
+  w.cursor = cv.take<int32_t>(w.nv + 1);
   w.bitmap = cv.take<unsigned>(w.nw);
   w.prefix = cv.take<int32_t>(w.nw + 1);
   w.point_row = cv.take<int32_t>(w.nv + 1);
-  w.cnt = cv.take<int32_t>(w.nv + 1);
   w.offs = cv.take<int32_t>(w.nv + 1);
-  w.cursor = cv.take<int32_t>(w.nv + 1);
   w.perm = cv.take<int32_t>(w.nv + 1);
   long long big = w.nw + 1 > w.nv + 1 ? w.nw + 1 : w.nv + 1;
   w.scan_ws = cv.take<char>(btc_scan_ws_bytes(big));
@@ -392,6 +565,8 @@ extern "C" size_t btc_pass_occ_vox_ws_bytes(const BtcPovConfig* c, int M, int P)
   s += btc_align((size_t)G.B * G.max_k * 16);
   s += btc_align((size_t)nw * 4) + btc_align((size_t)(nw + 1) * 4) + 5 * btc_align((size_t)(nv + 1) * 4);
   s += btc_scan_ws_bytes(big);
+  const size_t n_chunk = (size_t)btc_cdiv(c->occ_grid[0] * c->occ_grid[1] * c->occ_grid[2], POV_CHUNK);
+  s += 2 * btc_align((size_t)G.B * n_chunk * 2 * 4) + btc_align((size_t)G.B * 4 * 4) + btc_align((size_t)G.B * 3 * 2048 * 4);
   return s;
 }
 
@@ -405,12 +580,20 @@ extern "C" int btc_pass_occ_vox_count(const BtcPovConfig* cfg, const float* prob
   int rc = pov_geom(&G, cfg, M, P, C);
   if (rc) return rc;
   PovWs w = pov_carve(ws, G);
-  BTC_HIP(hipMemsetAsync(w.bitmap, 0, (size_t)w.nw * 4, stream));
-  BTC_HIP(hipMemsetAsync(w.cnt, 0, (size_t)(w.nv + 1) * 4, stream));
-  BTC_HIP(hipMemsetAsync(w.cursor, 0, (size_t)(w.nv + 1) * 4, stream));
-  BTC_HIP(hipMemsetAsync(w.info, 0, (size_t)(2 + G.B) * 4, stream));
-  pov_select<<<G.B, 1024, 0, stream>>>(probs, use_occ, G, cfg->occ_thresh, w.sel, w.counts);
-  BTC_LAUNCH_CHECK();
+  BTC_HIP(hipMemsetAsync(w.info, 0, (size_t)((char*)w.prefix - (char*)w.info), stream));
+  if (btc_tune_get(BTC_TUNE_POV_SELECT) == 1) {  // the single-workgroup selection (kept as the in-tree cross-check of the one below)
+    pov_select<<<G.B, 1024, 0, stream>>>(probs, use_occ, G, cfg->occ_thresh, w.sel, w.counts);
+    BTC_LAUNCH_CHECK();
+  } else {
+    const dim3 grid(w.n_chunk, G.B);
+    pov_hist<0><<<grid, 1024, 0, stream>>>(probs, use_occ, G, cfg->occ_thresh, w.ghist);
+    pov_hist<1><<<grid, 1024, 0, stream>>>(probs, use_occ, G, cfg->occ_thresh, w.ghist);
+    pov_hist<2><<<grid, 1024, 0, stream>>>(probs, use_occ, G, cfg->occ_thresh, w.ghist);
+    pov_chunk_count<<<grid, 1024, 0, stream>>>(probs, use_occ, G, cfg->occ_thresh, w.ghist, w.n_chunk, w.cc, w.state);
+    pov_chunk_scan<<<G.B, 1024, 0, stream>>>(use_occ, w.n_chunk, w.cc, w.state, w.co, w.counts);
+    pov_chunk_write<<<grid, 1024, 0, stream>>>(probs, use_occ, G, cfg->occ_thresh, w.n_chunk, w.co, w.state, w.sel);
+    BTC_LAUNCH_CHECK();
+  }
   pov_make_points<<<btc_cdiv(G.B * G.max_k, 256), 256, 0, stream>>>(w.sel, w.counts, probs, residuals, rot_z, G, w.occ_xyzp, w.occ_key);
   BTC_LAUNCH_CHECK();
   pov_mark<<<btc_cdiv(w.nv, 256), 256, 0, stream>>>(G, w.nv, det_coords, det_num, w.occ_key, w.bitmap);

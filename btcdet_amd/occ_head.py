@@ -105,6 +105,12 @@ MERGE_HEADS = True  # OccHead3D: conv_cls + conv_res as one launch per direction
 FUSED_LOSS = True  # OccHeadTemplate.get_loss through btc_occ_loss_* (False: the torch op chain of the reference)
 
 
+def _join_wgrad_hook(grad):
+    from .spconv import ops
+    ops.join_wgrad()
+    return None
+
+
 class OccHeadTemplate(nn.Module):
     def __init__(self, model_cfg, data_cfg, num_class, grid_size):
         super().__init__()
@@ -201,13 +207,34 @@ class OccHead3D(OccHeadTemplate):
                 spconv.SubMConv3d(input_channels, (self.stride ** 3) * self.num_class * self.res_num_dim, 3, padding=1,
                                   bias=False, indice_key='res_ind'))
 
-    def _merged_heads(self, x):
-        """conv_cls and conv_res see the same tensor with the same geometry: run them as ONE sparse conv with the two
-        weight tensors concatenated along Cout (parameters / state_dict untouched; autograd splits the gradient back)"""
+    def _merge_ok(self):
+        return MERGE_HEADS and self.reg and len(self.conv_cls) == 1 and len(self.conv_res) == 1 \
+            and self.conv_cls[0].kernel_size == self.conv_res[0].kernel_size and self.conv_cls[0].dilation == self.conv_res[0].dilation
+
+    def premerge(self):
+        """build the concatenated head weight EARLY in the forward pass (BtcHotPath.forward calls this before the occupancy
+        backbone): autograd runs nodes latest-created first, so the CatBackward that splits dW runs after the whole backbone's
+        backward, and the head's weight gradient (150 us at 210 K rows) can stay on the side stream until then
+        (ops.set_defer_wgrad_join); the hook below is the join in front of that consumer."""
+        if not (self._merge_ok() and self.conv_cls[0].weight.is_cuda):
+            return
+        from .spconv import ops
         cls, res = self.conv_cls[0], self.conv_res[0]
         w = torch.cat([cls.weight, res.weight], dim=-1)
         bias = torch.cat([cls.bias if cls.bias is not None else cls.weight.new_zeros(cls.out_channels),
                           res.bias if res.bias is not None else res.weight.new_zeros(res.out_channels)])
+        if w.requires_grad and torch.is_grad_enabled():
+            w.register_hook(_join_wgrad_hook)
+            w._btc_join_before_use = True  # SparseConvFunction: this non-leaf weight's gradient may be deferred
+        self._merged = (w, bias)
+
+    def _merged_heads(self, x):
+        """conv_cls and conv_res see the same tensor with the same geometry: run them as ONE sparse conv with the two
+        weight tensors concatenated along Cout (parameters / state_dict untouched; autograd splits the gradient back)"""
+        cls, res = self.conv_cls[0], self.conv_res[0]
+        if getattr(self, "_merged", None) is None:
+            self.premerge()
+        (w, bias), self._merged = self._merged, None
         from .spconv import ops
         from .spconv.conv import _ntuple
         geom = x.indice_dict.setdefault("__geometry_cache__", {})
@@ -230,8 +257,7 @@ class OccHead3D(OccHeadTemplate):
     def forward(self, data_dict):
         data_dict = self.prepare_loss_map(data_dict)
         x = data_dict['encoded_spconv_tensor']
-        if MERGE_HEADS and self.reg and x.features.is_cuda and len(self.conv_cls) == 1 and len(self.conv_res) == 1 \
-                and self.conv_cls[0].kernel_size == self.conv_res[0].kernel_size and self.conv_cls[0].dilation == self.conv_res[0].dilation:
+        if self._merge_ok() and x.features.is_cuda:
             t_cls, t_res = self._merged_heads(x)
             logit = t_cls.dense()
             prob = self.logit2prob(logit)[:, -1:, ...]

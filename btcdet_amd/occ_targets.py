@@ -103,7 +103,11 @@ class OccTargets3D(nn.Module):
         M, P, C = vox.shape
         shape = (bs, self.nz, self.ny, self.nx)
         out = {}
-        for k in OCC_BUFFER_FIELDS:
+        zeroed = OCC_BUFFER_FIELDS[:5]  # the byte masks the kernels accumulate into: one block, one memset in btc_occ_targets
+        block = torch.empty((len(zeroed),) + shape, dtype=torch.uint8, device=dev)
+        for i, k in enumerate(zeroed):
+            out[k] = block[i]
+        for k in OCC_BUFFER_FIELDS[5:]:
             if k == "res_mtrx":
                 out[k] = torch.empty((bs, 3, self.nz, self.ny, self.nx), dtype=torch.float32, device=dev)
             elif k == "pos_all_num":

@@ -52,6 +52,17 @@ def bn_backward(x, y, dy, weight, stats, use_batch, relu):
     return dx, dparam[0], dparam[1]
 
 
+def col_sum(x):
+    """x.sum(0) of a contiguous (N, C) fp32 / bf16 CUDA matrix in fp32 (one launch, fp64 accumulation in a fixed order):
+    the bias gradient of a sparse conv.  torch's column reduction of a 200 K x 5 matrix runs on 2 workgroups (120 us)."""
+    N, C = x.shape
+    ws, need = _ws(x.device, C)
+    out = torch.empty((C,), dtype=torch.float32, device=x.device)
+    fn = lib().btc_col_sum_bf16 if x.dtype == torch.bfloat16 else lib().btc_col_sum
+    check(fn(ptr(x), N, C, ptr(out), ptr(ws), need, stream_ptr()), "btc_col_sum")
+    return out
+
+
 class BatchNormReLUFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, running_mean, running_var, num_batches_tracked, training, momentum, eps, relu):

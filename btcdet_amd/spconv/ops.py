@@ -521,6 +521,13 @@ def _conv_backward(features, w, map_fwd, map_bwd, grad_out, wshape, need_din, ne
     return din, dw
 
 
+def _bias_grad(g):
+    if g.is_cuda and g.dim() == 2 and g.shape[0] >= 1 and g.is_contiguous() and g.dtype in (torch.float32, torch.bfloat16):
+        from . import fused_bn
+        return fused_bn.col_sum(g)
+    return g.sum(0, dtype=torch.float32)
+
+
 class SparseConvFunction(torch.autograd.Function):
     """indice_conv / indice_subm_conv / indice_inverse_conv in one function.
     map_fwd (n_res,K): source row gathered by result row i at offset k; map_bwd (n_src,K) its transpose."""
@@ -536,7 +543,8 @@ class SparseConvFunction(torch.autograd.Function):
         ctx.save_for_backward(features, w, map_fwd, map_bwd)
         ctx.has_bias = bias is not None
         ctx.wshape = tuple(weight.shape)
-        ctx.leaf_w = bool(weight.is_leaf)  # a dW consumed by another autograd node (cat of head weights) must not be deferred
+        # a dW consumed by another autograd node (cat of head weights) must not be deferred unless that consumer joins first
+        ctx.leaf_w = bool(weight.is_leaf or getattr(weight, "_btc_join_before_use", False))
         return out
 
     @staticmethod
@@ -545,7 +553,7 @@ class SparseConvFunction(torch.autograd.Function):
         grad_out = _actc(grad_out if grad_out.dtype == features.dtype else grad_out.to(features.dtype))
         din, dw = _conv_backward(features, w, map_fwd, map_bwd, grad_out, ctx.wshape, ctx.needs_input_grad[0], ctx.needs_input_grad[1],
                                  ctx.leaf_w)
-        db = grad_out.sum(0, dtype=torch.float32) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        db = _bias_grad(grad_out) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
         return din, dw, db, None, None
 
 
@@ -583,7 +591,7 @@ class SparseConvBNReLUFunction(torch.autograd.Function):
         dy = (dy if dy.dtype == x.dtype else dy.to(x.dtype)).contiguous()
         dx, dgamma, dbeta = fused_bn.bn_backward(x, y, dy, gamma, stats, use_batch, relu)
         din, dw = _conv_backward(features, w, map_fwd, map_bwd, dx, wshape, ctx.needs_input_grad[0], ctx.needs_input_grad[1], leaf_w)
-        db = dx.sum(0, dtype=torch.float32) if (has_bias and ctx.needs_input_grad[2]) else None
+        db = _bias_grad(dx) if (has_bias and ctx.needs_input_grad[2]) else None
         affine = gamma is not None
         return (din, dw, db, None, None, dgamma if affine else None, dbeta if affine else None, None, None, None, None, None, None, None)
 

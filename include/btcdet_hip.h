@@ -58,6 +58,7 @@ int btc_version(void);
 #define BTC_TUNE_APPLY_KC 4
 #define BTC_TUNE_WGRAD_PH 5   /* conv_wgrad_rows: phases (of KB offsets) per offset group: 1, 2, 4, 7 */
 #define BTC_TUNE_WGRAD_WGS 6  /* conv_wgrad_rows: target number of workgroups (row splits x offset groups) */
+#define BTC_TUNE_POV_SELECT 7 /* PassOccVox top-k: 1 = single-workgroup pov_select (cross-check of the multi-workgroup path) */
 #define BTC_TUNE_APPLY_DEBUG 3 /* timing experiments only (WRONG results): 1 = no MFMA phase, 2 = no loads in the main loop */
 int btc_tune_set(int key, int value);
 
@@ -261,6 +262,10 @@ int btc_bn_relu_fwd_bf16(const void* x, int N, int C, const float* gamma, const 
 int btc_bn_relu_bwd_bf16(const void* x, const void* y, const void* dy, int N, int C, const float* gamma,
                          const float* save_mean, const float* save_rstd, int training, int relu, void* dx, float* dgamma,
                          float* dbeta, void* ws, size_t ws_bytes, void* stream);
+/* out[c] = sum_r x[r][c] of an (N,C) matrix: the bias gradient of a sparse conv (grad_out.sum(0) in the reference's
+ * autograd graph, spconv v1.2.1 SparseConvFunction.backward).  fp64 accumulation in a fixed order.  ws as above. */
+int btc_col_sum(const float* x, int N, int C, float* out, void* ws, size_t ws_bytes, void* stream);
+int btc_col_sum_bf16(const void* x, int N, int C, float* out, void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * PassOccVox, fused.  Replaces /root/reference/btcdet/models/occ_pnt/pass_occ_vox.py:10-59 with

@@ -294,3 +294,44 @@ def test_hot_path_eval_mode():
     with torch.no_grad():
         _, _, out_t = run(True)
     assert out_t["occ_pnts"].shape[0] <= 2 * cfg.MODEL.OCC.PARAMS.MAX_NUM_OCC_PNTS
+
+
+@pytest.mark.parametrize("case", ["ties_capped", "all_kept", "one_scene_off"])
+def test_pass_occ_vox_multi_workgroup_topk_equals_single_workgroup(G, case):
+    """the top-k of PassOccVox spread over (chunks x scenes) workgroups (pov_hist / pov_chunk_*) against the one-workgroup
+    pov_select (BTC_TUNE_POV_SELECT = 1): same cells, same order, with heavy ties at the cut (probabilities quantised to
+    1/64), with fewer candidates than the cap, and with a scene switched off"""
+    from btcdet_amd._lib import lib, check
+    g, scenes, bd, cfg, model = G
+    mod = model.occ_modules.occ_pnt_update
+    gen = torch.Generator(device="cpu").manual_seed(11)
+    outs = []
+    for single in (1, 0):
+        d = reference_side_dict(g, bd, cfg, DEV)
+        shape = d["batch_pred_occ_prob"].shape
+        p = torch.rand(shape, generator=torch.Generator(device="cpu").manual_seed(5))
+        if case == "all_kept":
+            p = torch.where(torch.rand(shape, generator=gen) < 1e-3, 0.5 + 0.5 * p, 0.25 * p)   # a few hundred candidates per scene
+        else:
+            p = torch.round(p * 64) / 64                                                         # ~ncell/128 cells per distinct value
+        gen.manual_seed(11)
+        d["batch_pred_occ_prob"] = p.to(DEV)
+        if case == "one_scene_off":
+            d["use_occ_prob"] = np.array([True, False])
+        check(lib().btc_tune_set(7, single), "btc_tune_set")
+        try:
+            d = mod(d)
+        finally:
+            check(lib().btc_tune_set(7, 0), "btc_tune_set")
+        outs.append({k: d[k].cpu().numpy() for k in ("occ_pnts", "added_occ_b_ind", "voxels", "voxel_coords", "voxel_num_points")})
+    a, b = outs
+    n_sel = a["occ_pnts"].shape[0]
+    cap = mod.max_add_occpnts_num
+    if case == "ties_capped":
+        assert n_sel == 2 * cap
+    elif case == "all_kept":
+        assert 0 < n_sel < cap
+    else:
+        assert n_sel == cap and set(a["added_occ_b_ind"].tolist()) == {0}
+    for k in a:
+        np.testing.assert_array_equal(a[k], b[k], err_msg=k)

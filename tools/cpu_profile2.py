@@ -17,6 +17,9 @@ def fwd(batch):
     bd.update({"batch_size": batch["batch_size"], "points": batch["points5"], "gt_boxes": batch["gt_boxes"], "gt_boxes_num": batch["gt_boxes_num"],
                "box_mirr_flag": batch["box_mirr_flag"], "bm_points": batch["bm_points"], "rot_z": batch["rot_z"], "is_train": True})
     ret, tb, _ = model(bd)
+    if os.environ.get("PROFILE_LOSS") == "1":
+        loss = ret["loss_occ"] + bench.MeanSquare.apply(ret["spatial_features"], 1e-3) + bench.MeanSquare.apply(ret["x_combine"], 1e-3)
+        return loss
     return ret
 for i in range(5):
     fwd(batches[i % 2])

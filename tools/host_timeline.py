@@ -1,0 +1,75 @@
+"""who waits for whom in the steady-state step (full-size scenes, no profiler): host time stamps at the phase boundaries of a
+step with NO synchronisation, plus one event per boundary.  lag = (time the GPU reaches the boundary) - (time the host
+enqueued it): ~0 means the GPU is starved by the host at that point, large means the host runs ahead of a busy GPU."""
+import os, sys, time
+import numpy as np
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench
+from btcdet_amd.btc_path import BtcHotPath
+from btcdet_amd.config import load_cfg
+from btcdet_amd.spconv import ops
+dev = torch.device("cuda:0")
+torch.manual_seed(0)
+model = BtcHotPath(load_cfg(), device=dev).to(dev).train()
+occ = [p for p in model.occ_modules.parameters() if p.requires_grad]
+det = [p for p in model.det_modules.parameters() if p.requires_grad]
+opt = bench.LeanFusedAdam([{"params": occ, "lr": 3e-3, "weight_decay": 0.001}, {"params": det, "lr": 3e-3, "weight_decay": 0.01}], betas=(0.9, 0.99))
+ops.set_defer_wgrad_join(os.environ.get("BTC_DEFER_WGRAD", "1") != "0")
+batches = bench.build_batches(2, 0, dev)
+proc = model.dataset.data_processor
+NAMES = ["zero_grad+voxelize", "occ branch", "det branch", "loss", "backward", "optimizer"]
+
+
+def step(batch, rec):
+    marks = []
+    def mark():
+        if rec is not None:
+            e = torch.cuda.Event(enable_timing=True); e.record(); marks.append((time.perf_counter(), e))
+    mark()
+    opt.zero_grad(set_to_none=True)
+    bd = proc.forward_batch(batch["points"], batch["pre_rot_points"], batch["scene_offsets"], batch["rot_z"])
+    bd.update({"batch_size": batch["batch_size"], "points": batch["points5"], "gt_boxes": batch["gt_boxes"], "gt_boxes_num": batch["gt_boxes_num"],
+               "box_mirr_flag": batch["box_mirr_flag"], "bm_points": batch["bm_points"], "rot_z": batch["rot_z"], "is_train": True})
+    bd["use_occ_prob"] = [True, True]
+    mark()
+    head = model.occ_modules.occ_dense_head
+    if hasattr(head, "premerge"):
+        head.premerge()
+    for mod in model.occ_module_list:
+        bd = mod(bd)
+    mark()
+    for mod in model.det_module_list:
+        bd = mod(bd)
+    mark()
+    loss_occ, tb = head.get_loss(bd)
+    loss = loss_occ + bench.MeanSquare.apply(bd["spatial_features"], 1e-3) + bench.MeanSquare.apply(bd["multi_scale_3d_features"]["x_combine"].features, 1e-3)
+    mark()
+    loss.backward()
+    mark()
+    opt.step()
+    mark()
+    if rec is not None:
+        rec.append(marks)
+
+
+for i in range(15):
+    step(batches[i % len(batches)], None)
+torch.cuda.synchronize()
+rec = []
+e0 = torch.cuda.Event(enable_timing=True); e0.record(); torch.cuda.synchronize(); h0 = time.perf_counter()
+N = 60
+for i in range(N):
+    step(batches[i % len(batches)], rec)
+torch.cuda.synchronize()
+h1 = time.perf_counter()
+print("step %.3f ms (with 7 event records per step)" % ((h1 - h0) / N * 1e3))
+host = np.array([[m[0] for m in marks] for marks in rec])
+gpu = np.array([[h0 + e0.elapsed_time(m[1]) * 1e-3 for m in marks] for marks in rec])
+hd, gd, lag = np.diff(host, axis=1) * 1e3, np.diff(gpu, axis=1) * 1e3, (gpu - host) * 1e3
+print("%-20s %9s %9s %12s" % ("phase", "host ms", "gpu ms", "lag at end ms"))
+for j, n in enumerate(NAMES):
+    print("%-20s %9.3f %9.3f %12.3f" % (n, hd[10:, j].mean(), gd[10:, j].mean(), lag[10:, j + 1].mean()))
+print("%-20s %9.3f %9.3f" % ("sum", hd[10:].sum(1).mean(), gd[10:].sum(1).mean()))
+print("lag at step start %.3f ms" % lag[10:, 0].mean())
