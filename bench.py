@@ -127,22 +127,44 @@ class MeanSquare(torch.autograd.Function):
         return (x * (g * (2.0 * ctx.k)).to(x.dtype)), None
 
 
-def make_step(model, ddp, proc, opts, grad_sync=None):
-    def step(batch):
+def make_step(model, ddp, proc, opts, grad_sync=None, prefetch_stream=None, threaded=True):
+    """one training step of the hot path.  With prefetch_stream, the weight-independent front of the NEXT batch (voxelizations,
+    occupancy targets, the occupancy branch's rulebooks: BtcHotPath.prepare) runs on that stream beside this batch's backward
+    pass -- the role DataLoader workers play for the reference's CPU voxelizer: from a worker thread while the main thread
+    sits in loss.backward() (threaded), or from this thread once the backward pass is enqueued.  Every step still does
+    exactly one batch's worth of that work."""
+    pending = {}
+    pool = None
+    if prefetch_stream is not None and threaded:
+        from concurrent.futures import ThreadPoolExecutor
+        pool = ThreadPoolExecutor(max_workers=1)
+
+    def prep(next_batch):
+        torch.cuda.set_device(prefetch_stream.device)
+        return model.prepare(next_batch, stream=prefetch_stream)
+
+    def step(batch, next_batch=None):
         for o in opts:
             o.zero_grad(set_to_none=True)
-        bd = proc.forward_batch(batch["points"], batch["pre_rot_points"], batch["scene_offsets"], batch["rot_z"])
-        bd.update({"batch_size": batch["batch_size"], "points": batch["points5"], "gt_boxes": batch["gt_boxes"],
-                   "gt_boxes_num": batch["gt_boxes_num"], "box_mirr_flag": batch["box_mirr_flag"],
-                   "bm_points": batch["bm_points"], "rot_z": batch["rot_z"], "is_train": True})
+        bd = pending.pop(id(batch), None)
+        if bd is None:
+            bd = model.prepare(batch)
+        pending.clear()
         ret, tb, _ = ddp(bd)
         # occupancy loss (real) + L2 stand-ins for the out-of-scope consumers of the detection branch
         loss = ret["loss_occ"] + MeanSquare.apply(ret["spatial_features"], 1e-3) + MeanSquare.apply(ret["x_combine"], 1e-3)
+        ahead = prefetch_stream is not None and next_batch is not None
+        fut = pool.submit(prep, next_batch) if (ahead and pool is not None) else None
         loss.backward()
+        if fut is not None:
+            pending[id(next_batch)] = fut.result()
         if grad_sync is not None:
             grad_sync.finish()  # all-reduced mean gradients in param.grad (the detection bucket has been travelling since mid-backward)
         for o in opts:
             o.step()
+        if ahead and pool is None:
+            pending[id(next_batch)] = model.prepare(next_batch, stream=prefetch_stream)
+        model.mark_step_end()
         return loss
     return step
 
@@ -319,7 +341,10 @@ def main():
         opts = [LeanFusedAdam(groups, betas=(0.9, 0.99))]
     bs = 2
     batches = build_batches(4, rank, device, bs, args.workload)
-    step = make_step(model, ddp, model.dataset.data_processor, opts, grad_sync)
+    # the next batch's weight-independent front runs on a high-priority side stream beside this batch's backward
+    prefetch = torch.cuda.Stream(device=device, priority=-1) if os.environ.get("BTC_PREFETCH", "2") != "0" else None
+    step = make_step(model, ddp, model.dataset.data_processor, opts, grad_sync, prefetch, threaded=os.environ.get("BTC_PREFETCH", "2") == "2")
+    nb = len(batches)
 
     def sync():
         torch.cuda.synchronize()
@@ -328,11 +353,11 @@ def main():
             torch.cuda.synchronize()
 
     for i in range(args.warmup):
-        step(batches[i % len(batches)])
+        step(batches[i % nb], batches[(i + 1) % nb])
     sync()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(batches[i % len(batches)])
+    for i in range(args.warmup, args.warmup + args.steps):  # each step prepares its successor: K steps, K preparations
+        step(batches[i % nb], batches[(i + 1) % nb])
     sync()
     dt = time.perf_counter() - t0
     # roofline leg: the SAME steps once more with a HIP event pair around every sparse-conv / rulebook launch

@@ -122,11 +122,32 @@ class VoxelBackBoneDeconv(nn.Module):
             voxel_features, voxel_coords = self.add_shift(voxel_features, voxel_coords)
         x = spconv.SparseConvTensor(features=voxel_features, indices=voxel_coords, spatial_shape=self.sparse_shape,
                                     batch_size=batch_dict['batch_size'])
+        ready = batch_dict.pop('occ_geometry', None)
+        if ready is not None and ready[0] is voxel_coords:  # rulebooks of this very coordinate tensor (prefetch_geometry)
+            x.indice_dict = ready[1]
         for stage in (self.conv1, self.conv2, self.conv3, self.deconv4, self.deconv5):
             x = stage(x)
         if self.y_shift > 0:
             x = self.remove_shift(x)
         batch_dict.update({'encoded_spconv_tensor': x, 'encoded_spconv_tensor_stride': 1})
+        return batch_dict
+
+    def prefetch_geometry(self, batch_dict, head=None):
+        """every rulebook forward (and the occupancy head) will need, built from the voxel coordinates alone -- they do not
+        depend on the weights, so a training loop can build them for the NEXT batch while this batch's backward runs
+        (BtcHotPath.prepare).  Stored as batch_dict['occ_geometry'] = (coords, indice_dict); forward picks it up when it is
+        handed the same coordinate tensor."""
+        if self.y_shift > 0:
+            return batch_dict
+        voxel_coords = batch_dict['voxel_coords'].int()
+        if not voxel_coords.is_cuda:
+            return batch_dict
+        x = spconv.SparseConvTensor(features=None, indices=voxel_coords, spatial_shape=self.sparse_shape, batch_size=batch_dict['batch_size'])
+        for stage in (self.conv1, self.conv2, self.conv3, self.deconv4, self.deconv5):
+            x = stage.forward_geometry(x)
+        if head is not None and hasattr(head, "forward_geometry"):
+            head.forward_geometry(x)
+        batch_dict['occ_geometry'] = (voxel_coords, x.indice_dict)
         return batch_dict
 
     # azimuth wrap-around padding (SHIFT, off in the configured model)

@@ -79,8 +79,92 @@ class BtcHotPath(nn.Module):
         self.det_module_list = [dvfe, dbb, bev]
         self.percentage = d.OCC.get("USEOCC_PERCENTAGE", 1.0)
 
+    # ------------------------------------------------------------------------------------------------------------------
+    # The weight-independent front of a step.  In the reference the voxelizations run in DataLoader workers (dataset.py:
+    # 185-192, DataProcessor.transform_points_to_voxels) and overlap the GPU step for free; here they are GPU work, and so are
+    # the occupancy targets (functions of the voxels and the boxes) and every rulebook of the occupancy branch (functions of
+    # the voxel coordinates).  prepare() runs all of that for one batch; given a side stream it runs THERE, so a training loop
+    # calls it for batch k+1 right after enqueueing batch k's backward: the read-backs inside (voxel counts, rulebook row
+    # counts) then wait for the side stream only, not for the backward pass still running on the main stream, and the next
+    # forward finds its first ~1.5 ms of host work free of synchronisation points.
+    # ------------------------------------------------------------------------------------------------------------------
+    def assemble(self, batch, is_train=True):
+        """raw scene batch (synth.make_batch keys on the device) -> batch_dict after both voxelizations"""
+        proc = self.dataset.data_processor
+        bd = proc.forward_batch(batch["points"], batch["pre_rot_points"], batch["scene_offsets"], batch["rot_z"])
+        bd.update({"batch_size": batch["batch_size"], "points": batch["points5"], "gt_boxes": batch["gt_boxes"],
+                   "gt_boxes_num": batch["gt_boxes_num"], "box_mirr_flag": batch["box_mirr_flag"], "bm_points": batch["bm_points"],
+                   "rot_z": batch["rot_z"], "is_train": is_train})
+        return bd
+
+    def _prepare(self, batch, is_train):
+        bd = self.assemble(batch, is_train)
+        n_done = 0
+        for mod in self.occ_module_list[:2]:  # occupancy targets, parameter-free VFE
+            if any(p.requires_grad for p in mod.parameters()):
+                break
+            bd = mod(bd)
+            n_done += 1
+        bb = self.occ_modules.backbone_3d
+        if n_done == 2 and hasattr(bb, "prefetch_geometry"):
+            bd = bb.prefetch_geometry(bd, self.occ_modules.occ_dense_head)
+        bd["__prepared__"] = n_done
+        return bd
+
+    def prepare(self, batch, stream=None, is_train=True):
+        """-> batch_dict for forward().  stream: a torch.cuda.Stream to run on (see above); may be called from a worker thread
+        while the main thread sits in loss.backward().  The tensors produced on `stream` live in that stream's allocator pool:
+        a generation of them is kept alive here until the step that consumed it has ended on the main stream
+        (mark_step_end()) AND the side stream has been made to wait for that point -- only then may the pool hand its blocks
+        to a later prepare().  The batch's own tensors must be complete when this is called."""
+        if stream is None or not batch["points"].is_cuda:
+            return self._prepare(batch, is_train)
+        st = self.__dict__.setdefault("_prep_state", {"gens": [], "next": 0, "consumed": -1})
+        gens = st["gens"]
+        if st["next"] == 0:
+            stream.wait_stream(torch.cuda.current_stream())  # whatever produced the first batch
+        keep = []
+        for g in gens:
+            if g["ended"] is not None:      # consumed, its step has ended: order the side stream behind that, then release
+                stream.wait_event(g["ended"])
+            elif len(gens) - len(keep) > 3:  # nobody calls mark_step_end(): fall back to "behind everything enqueued so far"
+                stream.wait_stream(torch.cuda.current_stream())
+            else:
+                keep.append(g)
+        gens[:] = keep
+        with torch.cuda.stream(stream):
+            bd = self._prepare(batch, is_train)
+            ready = torch.cuda.Event()
+            ready.record(stream)
+        bd["__ready_event__"] = ready
+        bd["__generation__"] = st["next"]
+        gens.append({"id": st["next"], "refs": list(bd.values()), "ended": None})
+        st["next"] += 1
+        return bd
+
+    def mark_step_end(self):
+        """call once per training step after the backward pass (and optimizer) have been enqueued: the generations of
+        prepared tensors consumed so far may be recycled once the main stream has passed this point"""
+        st = self.__dict__.get("_prep_state")
+        if not st:
+            return
+        ev = None
+        for g in st["gens"]:
+            if g["ended"] is None and g["id"] <= st["consumed"]:
+                if ev is None:
+                    ev = torch.cuda.Event()
+                    ev.record(torch.cuda.current_stream())
+                g["ended"] = ev
+
     def forward(self, batch_dict):
         """BtcNet.forward up to the BEV map (btcnet.py:32-56) + the occupancy loss (btcnet.py:91-101)"""
+        ready = batch_dict.pop("__ready_event__", None)
+        if ready is not None:
+            torch.cuda.current_stream().wait_event(ready)
+        n_done = batch_dict.pop("__prepared__", 0)
+        gen = batch_dict.pop("__generation__", None)
+        if gen is not None:
+            self._prep_state["consumed"] = max(self._prep_state["consumed"], gen)
         use_occ_prob = [True] * batch_dict["batch_size"]
         prob = np.random.uniform(size=batch_dict["batch_size"], high=0.9999)  # the reference consumes this stream too
         if batch_dict["is_train"]:
@@ -89,7 +173,7 @@ class BtcHotPath(nn.Module):
         head = self.occ_modules.occ_dense_head
         if hasattr(head, "premerge"):
             head.premerge()  # the merged head weight is built before the backbone runs, so its CatBackward runs after it
-        for mod in self.occ_module_list:
+        for mod in self.occ_module_list[n_done:]:
             batch_dict = mod(batch_dict)
         for mod in self.det_module_list:
             batch_dict = mod(batch_dict)

@@ -412,18 +412,18 @@ Tensor conv_bn_relu(const Tensor& features, const Tensor& weight, const OptTenso
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.doc() = "compiled PyTorch binding of libbtcdet_hip.so's hot entry points";
-  m.def("conv_fwd", &conv_fwd);
-  m.def("bn_fwd", &bn_fwd);
-  m.def("conv_bn_fwd", &conv_bn_fwd);
-  m.def("bn_bwd", &bn_bwd);
-  m.def("conv_bwd", &conv_bwd);
-  m.def("conv_bn_relu", &conv_bn_relu);
-  m.def("join_wgrad", &join_wgrad);
+  m.def("conv_fwd", &conv_fwd, py::call_guard<py::gil_scoped_release>());
+  m.def("bn_fwd", &bn_fwd, py::call_guard<py::gil_scoped_release>());
+  m.def("conv_bn_fwd", &conv_bn_fwd, py::call_guard<py::gil_scoped_release>());
+  m.def("bn_bwd", &bn_bwd, py::call_guard<py::gil_scoped_release>());
+  m.def("conv_bwd", &conv_bwd, py::call_guard<py::gil_scoped_release>());
+  m.def("conv_bn_relu", &conv_bn_relu, py::call_guard<py::gil_scoped_release>());
+  m.def("join_wgrad", &join_wgrad, py::call_guard<py::gil_scoped_release>());
   m.def("set_defer_wgrad_join", &set_defer_wgrad_join);
-  m.def("rulebook_subm", &rulebook_subm);
-  m.def("rulebook_conv", &rulebook_conv);
+  m.def("rulebook_subm", &rulebook_subm, py::call_guard<py::gil_scoped_release>());
+  m.def("rulebook_conv", &rulebook_conv, py::call_guard<py::gil_scoped_release>());
   py::class_<PendingRb, std::shared_ptr<PendingRb>>(m, "PendingRb");
-  m.def("rulebook_conv_start", &rulebook_conv_start);
-  m.def("rulebook_conv_finish", &rulebook_conv_finish);
+  m.def("rulebook_conv_start", &rulebook_conv_start, py::call_guard<py::gil_scoped_release>());
+  m.def("rulebook_conv_finish", &rulebook_conv_finish, py::call_guard<py::gil_scoped_release>());
   m.def("abi_version", []() { return btc_version(); });
 }

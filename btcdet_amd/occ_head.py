@@ -101,6 +101,58 @@ class OccLossFunction(torch.autograd.Function):
         return d_logit, d_res, None, None, None, None, None, None, None, None, None
 
 
+class LazyScalar(object):
+    """a float that is still on its way from the GPU: reads (float(), '%f', format, comparisons, arithmetic) wait for the copy"""
+    __slots__ = ("_host", "_i", "_event", "_value")
+
+    def __init__(self, host, i, event):
+        self._host, self._i, self._event, self._value = host, i, event, None
+
+    def item(self):
+        if self._value is None:
+            self._event.synchronize()
+            self._value = float(self._host[self._i])
+            self._host = self._event = None
+        return self._value
+
+    __float__ = item
+
+    def __repr__(self):
+        return repr(self.item())
+
+    def __format__(self, spec):
+        return format(self.item(), spec)
+
+    def __eq__(self, o): return self.item() == float(o)
+    def __lt__(self, o): return self.item() < float(o)
+    def __le__(self, o): return self.item() <= float(o)
+    def __gt__(self, o): return self.item() > float(o)
+    def __ge__(self, o): return self.item() >= float(o)
+    def __hash__(self): return hash(self.item())
+    def __add__(self, o): return self.item() + float(o)
+    __radd__ = __add__
+    def __sub__(self, o): return self.item() - float(o)
+    def __rsub__(self, o): return float(o) - self.item()
+    def __mul__(self, o): return self.item() * float(o)
+    __rmul__ = __mul__
+    def __truediv__(self, o): return self.item() / float(o)
+    def __rtruediv__(self, o): return float(o) / self.item()
+    def __neg__(self): return -self.item()
+    def __abs__(self): return abs(self.item())
+    def __bool__(self): return bool(self.item())
+
+
+def _lazy_scalars(t, n):
+    """first n elements of a small fp32 tensor as host numbers; CUDA tensors: asynchronous copy + LazyScalar"""
+    if not t.is_cuda:
+        return t.tolist()[:n]
+    host = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+    host.copy_(t, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+    return [LazyScalar(host, i, ev) for i in range(n)]
+
+
 MERGE_HEADS = True  # OccHead3D: conv_cls + conv_res as one launch per direction
 FUSED_LOSS = True  # OccHeadTemplate.get_loss through btc_occ_loss_* (False: the torch op chain of the reference)
 
@@ -178,7 +230,10 @@ class OccHeadTemplate(nn.Module):
                 batch_dict["pos_mask"], batch_dict['general_cls_loss_mask'], batch_dict["general_cls_loss_mask_float"],
                 batch_dict["general_reg_loss_mask"] if reg else None, batch_dict["general_reg_loss_mask_float"] if reg else None,
                 lw['res_beta'], self.occ_fore_cls_weight, self.occ_fore_res_weight)
-            vals = out.detach().tolist()  # the scalars the reference logs with .item() (one read-back for both)
+            # the scalars the reference logs with .item() (occ_head_template.py:163,171): one asynchronous copy to pinned
+            # memory for both; the wait happens when a value is READ (float(), formatting, arithmetic), not here -- an .item()
+            # at this point stalls the host until the whole forward pass has drained
+            vals = _lazy_scalars(out.detach(), 2 if reg else 1)
             tb_dict = {'occ_loss_cls': vals[0]}
             if reg:
                 tb_dict['occ_loss_res'] = vals[1]
@@ -228,15 +283,10 @@ class OccHead3D(OccHeadTemplate):
             w._btc_join_before_use = True  # SparseConvFunction: this non-leaf weight's gradient may be deferred
         self._merged = (w, bias)
 
-    def _merged_heads(self, x):
-        """conv_cls and conv_res see the same tensor with the same geometry: run them as ONE sparse conv with the two
-        weight tensors concatenated along Cout (parameters / state_dict untouched; autograd splits the gradient back)"""
-        cls, res = self.conv_cls[0], self.conv_res[0]
-        if getattr(self, "_merged", None) is None:
-            self.premerge()
-        (w, bias), self._merged = self._merged, None
+    def _head_rulebook(self, x):
+        """the one submanifold rulebook conv_cls and conv_res share (geometry cache of x.indice_dict)"""
         from .spconv import ops
-        from .spconv.conv import _ntuple
+        cls, res = self.conv_cls[0], self.conv_res[0]
         geom = x.indice_dict.setdefault("__geometry_cache__", {})
         gkey = (x.indices.data_ptr(), tuple(x.indices.shape), tuple(int(v) for v in x.spatial_shape), tuple(cls.kernel_size),
                 tuple(cls.dilation), True, False)
@@ -249,6 +299,26 @@ class OccHead3D(OccHeadTemplate):
         for m in (cls, res):
             if m.indice_key is not None:
                 x.indice_dict[m.indice_key] = rb
+        return rb
+
+    def forward_geometry(self, x):
+        """the rulebook(s) forward will need on the backbone's output active set, without the feature kernels"""
+        if self._merge_ok() and x.indices.is_cuda:
+            self._head_rulebook(x)
+        else:
+            self.conv_cls.forward_geometry(x)
+            if self.reg:
+                self.conv_res.forward_geometry(x)
+
+    def _merged_heads(self, x):
+        """conv_cls and conv_res see the same tensor with the same geometry: run them as ONE sparse conv with the two
+        weight tensors concatenated along Cout (parameters / state_dict untouched; autograd splits the gradient back)"""
+        cls, res = self.conv_cls[0], self.conv_res[0]
+        if getattr(self, "_merged", None) is None:
+            self.premerge()
+        (w, bias), self._merged = self._merged, None
+        from .spconv import ops
+        rb = self._head_rulebook(x)
         out = ops.indice_conv(x.features, w, bias, rb)
         nc = cls.out_channels
         mk = lambda f: spconv.SparseConvTensor(f, x.indices, x.spatial_shape, x.batch_size)

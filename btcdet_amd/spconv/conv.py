@@ -82,27 +82,44 @@ class SparseConvolution(SparseModule):
             out_tensor.indice_dict = input.indice_dict
             out_tensor.grid = input.grid
             return out_tensor
+        rb, outids, out_spatial_shape = self._resolve_rulebook(input, out_spatial_shape)
+        out_features = self._conv_apply(features, rb, self.inverse, fuse_bn)
+        out_tensor = SparseConvTensor(out_features, outids, out_spatial_shape, batch_size)
+        out_tensor.indice_dict = input.indice_dict
+        out_tensor.grid = input.grid
+        return out_tensor
+
+    def _resolve_rulebook(self, input, out_spatial_shape):
+        """the geometry half of forward: this layer's rulebook (cached under indice_key / the geometry cache, or built now), the
+        output index tensor and spatial shape; announces the next strided layers (lookahead)"""
+        indices, spatial_shape, batch_size = input.indices, input.spatial_shape, input.batch_size
         rb = input.find_indice_pair(self.indice_key)
         if self.inverse:
             assert rb is not None and self.indice_key is not None, "inverse conv needs the cached rulebook of its indice_key"
             assert rb.K == int(np.prod(self.kernel_size)), "inverse conv kernel does not match the cached rulebook"
-            out_features = self._conv_apply(features, rb, True, fuse_bn)
-            outids, out_spatial_shape = rb.in_indices, rb.in_shape[3 - self.ndim:]
-        else:
-            if rb is None:
-                rb = self._rulebook(indices, spatial_shape, batch_size, input.indice_dict)
-                if self.indice_key is not None:
-                    input.indice_dict[self.indice_key] = rb
-            # on a cache hit the layer uses the cached rulebook without checking its own geometry (App. B.5)
-            outids = rb.out_indices
-            if self.ndim == 2 and outids.shape[1] == 4:
-                outids = torch.cat([outids[:, :1], outids[:, 2:]], dim=1).contiguous()
-            # the strided layers that consume this output level start counting their rows now, on the side stream,
-            # while this layer's (and the following submanifold layers') feature kernels run (ops.py, LOOKAHEAD)
-            for nxt in getattr(self, "lookahead", ()):
-                nxt.prefetch(outids, out_spatial_shape, batch_size, input.indice_dict)
-            out_features = self._conv_apply(features, rb, False, fuse_bn)
-        out_tensor = SparseConvTensor(out_features, outids, out_spatial_shape, batch_size)
+            return rb, rb.in_indices, rb.in_shape[3 - self.ndim:]
+        if rb is None:
+            rb = self._rulebook(indices, spatial_shape, batch_size, input.indice_dict)
+            if self.indice_key is not None:
+                input.indice_dict[self.indice_key] = rb
+        # on a cache hit the layer uses the cached rulebook without checking its own geometry (App. B.5)
+        outids = rb.out_indices
+        if self.ndim == 2 and outids.shape[1] == 4:
+            outids = torch.cat([outids[:, :1], outids[:, 2:]], dim=1).contiguous()
+        # the strided layers that consume this output level start counting their rows now, on the side stream,
+        # while this layer's (and the following submanifold layers') feature kernels run (ops.py, LOOKAHEAD)
+        for nxt in getattr(self, "lookahead", ()):
+            nxt.prefetch(outids, out_spatial_shape, batch_size, input.indice_dict)
+        return rb, outids, out_spatial_shape
+
+    def forward_geometry(self, input):
+        """forward without the feature kernels: builds (and caches in input.indice_dict) what forward would build and returns a
+        feature-less SparseConvTensor on the output active set.  A later forward over the same indice_dict finds every
+        rulebook ready (BtcHotPath.prepare: the occupancy branch's geometry is a function of the input coordinates only)"""
+        if self.conv1x1:
+            return input
+        rb, outids, out_spatial_shape = self._resolve_rulebook(input, self._out_shape(input.spatial_shape))
+        out_tensor = SparseConvTensor(None, outids, out_spatial_shape, input.batch_size)
         out_tensor.indice_dict = input.indice_dict
         out_tensor.grid = input.grid
         return out_tensor

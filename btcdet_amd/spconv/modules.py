@@ -69,6 +69,13 @@ class SparseSequential(SparseModule):
                 raise KeyError("name exists")
         self.add_module(name, module)
 
+    def forward_geometry(self, input):
+        """the sparse layers' rulebooks only (SparseConvolution.forward_geometry); dense modules are skipped"""
+        for module in self._modules.values():
+            if is_spconv_module(module):
+                input = module.forward_geometry(input)
+        return input
+
     def forward(self, input):
         from . import fused_bn
         from .conv import SparseConvolution

@@ -121,7 +121,7 @@ def test_occ_loss_vs_golden(G, fused):
         loss, tb = model.occ_modules.occ_dense_head.get_loss(d)
     finally:
         occ_head.FUSED_LOSS = True
-    np.testing.assert_allclose([float(loss), tb["occ_loss_cls"], tb["occ_loss_res"]], g["head_loss"], rtol=2e-5)
+    np.testing.assert_allclose([float(loss), float(tb["occ_loss_cls"]), float(tb["occ_loss_res"])], g["head_loss"], rtol=2e-5)
     loss.backward()
     d64 = {k: (v.detach().cpu().double() if torch.is_tensor(v) and v.is_floating_point() else (v.cpu() if torch.is_tensor(v) else v)) for k, v in d.items()}
     d64["pred_occ_logit"].requires_grad_(True)

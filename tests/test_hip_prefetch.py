@@ -1,0 +1,103 @@
+"""BtcHotPath.prepare: the weight-independent front of a step (both voxelizations, occupancy targets, parameter-free VFE, the
+occupancy branch's rulebooks via SparseConvolution.forward_geometry) run ahead of the step that consumes it, on a side stream,
+beside the previous step's backward pass (from the training thread, or from a worker thread while the training thread sits in
+loss.backward()).  Losses and parameter gradients must equal the in-order schedule's over a loop without device
+synchronisation.  The comparison allows 1e-5 of each tensor's largest magnitude: the occupancy targets accumulate per-voxel
+residual sums with float atomics (as the reference's scatter-mean does), so two runs of the SAME schedule already differ in the
+last bits on some scenes; a race or a recycled buffer shows up as garbage, not as 1e-7."""
+import os
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def _run(mode, steps, defer):
+    import bench
+    from btcdet_amd.btc_path import BtcHotPath
+    from btcdet_amd.config import load_cfg
+    from btcdet_amd.spconv import ops
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    model = BtcHotPath(load_cfg(), device=dev).to(dev).train()
+    ops.set_defer_wgrad_join(defer)
+    try:
+        batches = bench.build_batches(3, 0, dev)
+        params = [p for p in model.parameters() if p.requires_grad]
+        side = torch.cuda.Stream(priority=-1) if mode in ("side_stream", "thread") else None
+        pool = None
+        if mode == "thread":
+            from concurrent.futures import ThreadPoolExecutor
+            pool = ThreadPoolExecutor(max_workers=1)
+        out, nxt = [], None
+        for it in range(steps):
+            b = batches[it % len(batches)]
+            if mode == "inline":      # the modules called one after the other by forward(), nothing prepared
+                bd = model.assemble(b)
+            else:
+                bd = nxt if nxt is not None else model.prepare(b)
+            assert ("occ_geometry" in bd) == (mode != "inline")
+            ret, _, _ = model(bd)
+            loss = ret["loss_occ"] + bench.MeanSquare.apply(ret["spatial_features"], 1e-3) + bench.MeanSquare.apply(ret["x_combine"], 1e-3)
+            for p in params:
+                p.grad = None
+            fut = pool.submit(model.prepare, batches[(it + 1) % len(batches)], side) if pool is not None else None
+            loss.backward()
+            if fut is not None:
+                nxt = fut.result()
+            elif mode != "inline":
+                nxt = model.prepare(batches[(it + 1) % len(batches)], stream=side)
+            model.mark_step_end()
+            out.append([loss.detach().clone()] + [None if p.grad is None else p.grad.clone() for p in params])
+        torch.cuda.synchronize()
+        return out
+    finally:
+        ops.set_defer_wgrad_join(False)
+
+
+@pytest.mark.parametrize("defer", [False, True])
+def test_prepared_steps_equal_inline_steps(defer):
+    steps = 7
+    ref = _run("inline", steps, defer)
+    for mode in ("same_stream", "side_stream", "thread"):
+        got = _run(mode, steps, defer)
+        n = 0
+        for it in range(steps):
+            for a, b in zip(ref[it], got[it]):
+                assert (a is None) == (b is None)
+                if a is not None:
+                    assert float((a - b).abs().max()) <= 1e-5 * float(a.abs().max()) + 1e-30, (mode, it)
+                    n += 1
+        assert n > 50 * steps
+
+
+def test_forward_geometry_builds_the_rulebooks_forward_uses():
+    """after prefetch_geometry the occupancy backbone + head forward must not build a single rulebook"""
+    import bench
+    from btcdet_amd.btc_path import BtcHotPath
+    from btcdet_amd.config import load_cfg
+    from btcdet_amd.spconv import ops
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    model = BtcHotPath(load_cfg(), device=dev).to(dev).train()
+    b = bench.build_batches(1, 0, dev)[0]
+    bd = model.prepare(b)
+    coords, geom = bd["occ_geometry"]
+    keys_before = set(geom.keys()) | set(geom["__geometry_cache__"].keys())
+    built = []
+    orig = ops.build_rulebook_g
+    ops.build_rulebook_g = lambda *a, **k: (built.append(1), orig(*a, **k))[1]
+    try:
+        bd["use_occ_prob"] = [True, True]
+        for mod in model.occ_module_list[2:4]:
+            bd = mod(bd)
+    finally:
+        ops.build_rulebook_g = orig
+    assert not built
+    x = bd["encoded_spconv_tensor"]
+    assert x.indice_dict is geom
+    assert set(geom.keys()) | set(geom["__geometry_cache__"].keys()) == keys_before

@@ -19,25 +19,32 @@ opt = bench.LeanFusedAdam([{"params": occ, "lr": 3e-3, "weight_decay": 0.001}, {
 ops.set_defer_wgrad_join(os.environ.get("BTC_DEFER_WGRAD", "1") != "0")
 batches = bench.build_batches(2, 0, dev)
 proc = model.dataset.data_processor
-NAMES = ["zero_grad+voxelize", "occ branch", "det branch", "loss", "backward", "optimizer"]
+PREFETCH = os.environ.get("BTC_PREFETCH", "1") != "0"
+side = torch.cuda.Stream(priority=-1) if PREFETCH else None
+NAMES = ["zero_grad+voxelize" if not PREFETCH else "zero_grad", "occ branch", "det branch", "loss", "backward", "optimizer"] + (["prepare next"] if PREFETCH else [])
+pending = {}
 
 
-def step(batch, rec):
+def step(batch, rec, nxt=None):
     marks = []
     def mark():
         if rec is not None:
             e = torch.cuda.Event(enable_timing=True); e.record(); marks.append((time.perf_counter(), e))
     mark()
     opt.zero_grad(set_to_none=True)
-    bd = proc.forward_batch(batch["points"], batch["pre_rot_points"], batch["scene_offsets"], batch["rot_z"])
-    bd.update({"batch_size": batch["batch_size"], "points": batch["points5"], "gt_boxes": batch["gt_boxes"], "gt_boxes_num": batch["gt_boxes_num"],
-               "box_mirr_flag": batch["box_mirr_flag"], "bm_points": batch["bm_points"], "rot_z": batch["rot_z"], "is_train": True})
+    bd = pending.pop(id(batch), None)
+    if bd is None:
+        bd = model.assemble(batch)
+    ready = bd.pop("__ready_event__", None)
+    if ready is not None:
+        torch.cuda.current_stream().wait_event(ready)
+    n_done = bd.pop("__prepared__", 0)
     bd["use_occ_prob"] = [True, True]
     mark()
     head = model.occ_modules.occ_dense_head
     if hasattr(head, "premerge"):
         head.premerge()
-    for mod in model.occ_module_list:
+    for mod in model.occ_module_list[n_done:]:
         bd = mod(bd)
     mark()
     for mod in model.det_module_list:
@@ -50,18 +57,23 @@ def step(batch, rec):
     mark()
     opt.step()
     mark()
+    if PREFETCH and nxt is not None:
+        pending.clear()
+        pending[id(nxt)] = model.prepare(nxt, stream=side)
+        mark()
     if rec is not None:
         rec.append(marks)
 
 
+nb = len(batches)
 for i in range(15):
-    step(batches[i % len(batches)], None)
+    step(batches[i % nb], None, batches[(i + 1) % nb])
 torch.cuda.synchronize()
 rec = []
 e0 = torch.cuda.Event(enable_timing=True); e0.record(); torch.cuda.synchronize(); h0 = time.perf_counter()
 N = 60
-for i in range(N):
-    step(batches[i % len(batches)], rec)
+for i in range(15, 15 + N):
+    step(batches[i % nb], rec, batches[(i + 1) % nb])
 torch.cuda.synchronize()
 h1 = time.perf_counter()
 print("step %.3f ms (with 7 event records per step)" % ((h1 - h0) / N * 1e3))
