@@ -104,6 +104,13 @@ _SIGS = {
     "btc_bn_relu_bwd": (ci, [vp, vp, vp, ci, ci, vp, vp, vp, ci, ci, vp, vp, vp, vp, sz, vp]),
     "btc_bn_relu_fwd_bf16": (ci, [vp, ci, ci, vp, vp, vp, vp, vp, ctypes.c_float, ctypes.c_float, ci, ci, vp, vp, vp, vp, sz, vp]),
     "btc_bn_relu_bwd_bf16": (ci, [vp, vp, vp, ci, ci, vp, vp, vp, ci, ci, vp, vp, vp, vp, sz, vp]),
+    "btc_ball_query": (ci, [vp, vp, vp, vp, ci, ci, ctypes.c_float, ctypes.c_float, ci, vp, vp]),
+    "btc_group_points": (ci, [vp, vp, vp, vp, ci, ci, ci, ci, vp, vp]),
+    "btc_group_points_grad": (ci, [vp, vp, vp, vp, ci, ci, ci, ci, ci, vp, vp]),
+    "btc_furthest_point_sampling": (ci, [vp, ci, ci, ci, vp, vp, vp]),
+    "btc_three_nn": (ci, [vp, vp, vp, vp, ci, ci, vp, vp, vp]),
+    "btc_three_interpolate": (ci, [vp, vp, vp, ci, ci, vp, vp]),
+    "btc_three_interpolate_grad": (ci, [vp, vp, vp, ci, ci, ci, vp, vp]),
     "btc_col_sum": (ci, [vp, ci, ci, vp, vp, sz, vp]),
     "btc_col_sum_bf16": (ci, [vp, ci, ci, vp, vp, sz, vp]),
     "btc_occ_targets_ws_bytes": (sz, [ctypes.POINTER(BtcOccConfig)]),

@@ -1,0 +1,333 @@
+"""pointnet2_stack on MI355X: the operator surface of
+/root/reference/btcdet/ops/pointnet2/pointnet2_stack/pointnet2_utils.py (ball_query, grouping_operation, QueryAndGroup,
+furthest_point_sample, three_nn, three_interpolate) and pointnet2_modules.py (StackSAModuleMSG, StackPointnetFPModule) over the
+HIP kernels of csrc/pointnet2.hip -- same names, argument order, return values and quirks -- plus `pointnet2_stack_cuda`, a
+stand-in for the reference's compiled module with its eight `*_wrapper` entry points (src/pointnet2_api.cpp), so that the
+reference's own pointnet2_utils.py binds it unchanged.  Consumers in the reference: the ROI head's grid
+pooling (models/roi_heads/conv_head.py:53-70,283-343) and the point feature encoders (backbones_3d/pfe)."""
+from typing import List
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch.autograd import Function
+
+from ._lib import check, lib, ptr, stream_ptr
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("pointnet2_stack: the HIP kernels need CUDA (ROCm) tensors; there is no CPU fallback")
+
+
+class _Cuda(object):
+    """`pointnet2_stack_cuda` of the reference: same function names and positional arguments, results written in place"""
+
+    @staticmethod
+    def ball_query_wrapper(B, M, radius, nsample, new_xyz, new_xyz_batch_cnt, xyz, xyz_batch_cnt, idx):
+        _need_cuda(new_xyz, xyz, idx)
+        check(lib().btc_ball_query(ptr(new_xyz), ptr(new_xyz_batch_cnt), ptr(xyz), ptr(xyz_batch_cnt), int(B), int(M), -1.0, float(radius),
+                                   int(nsample), ptr(idx), stream_ptr()), "btc_ball_query")
+
+    @staticmethod
+    def shell_query_wrapper(B, M, inner_radius, outer_radius, nsample, new_xyz, new_xyz_batch_cnt, xyz, xyz_batch_cnt, idx):
+        _need_cuda(new_xyz, xyz, idx)
+        check(lib().btc_ball_query(ptr(new_xyz), ptr(new_xyz_batch_cnt), ptr(xyz), ptr(xyz_batch_cnt), int(B), int(M), float(inner_radius),
+                                   float(outer_radius), int(nsample), ptr(idx), stream_ptr()), "btc_ball_query")
+
+    @staticmethod
+    def group_points_wrapper(B, M, C, nsample, features, features_batch_cnt, idx, idx_batch_cnt, out):
+        _need_cuda(features, idx, out)
+        check(lib().btc_group_points(ptr(features), ptr(features_batch_cnt), ptr(idx), ptr(idx_batch_cnt), int(B), int(M), int(C), int(nsample),
+                                     ptr(out), stream_ptr()), "btc_group_points")
+
+    @staticmethod
+    def group_points_grad_wrapper(B, M, C, N, nsample, grad_out, idx, idx_batch_cnt, features_batch_cnt, grad_features):
+        _need_cuda(grad_out, idx, grad_features)
+        check(lib().btc_group_points_grad(ptr(grad_out), ptr(idx), ptr(idx_batch_cnt), ptr(features_batch_cnt), int(B), int(M), int(C), int(N),
+                                          int(nsample), ptr(grad_features), stream_ptr()), "btc_group_points_grad")
+
+    @staticmethod
+    def furthest_point_sampling_wrapper(B, N, npoint, xyz, temp, out):
+        _need_cuda(xyz, temp, out)
+        check(lib().btc_furthest_point_sampling(ptr(xyz), int(B), int(N), int(npoint), ptr(temp), ptr(out), stream_ptr()),
+              "btc_furthest_point_sampling")
+
+    @staticmethod
+    def three_nn_wrapper(unknown, unknown_batch_cnt, known, known_batch_cnt, dist2, idx):
+        _need_cuda(unknown, known, dist2, idx)
+        check(lib().btc_three_nn(ptr(unknown), ptr(unknown_batch_cnt), ptr(known), ptr(known_batch_cnt), int(unknown_batch_cnt.shape[0]),
+                                 int(unknown.shape[0]), ptr(dist2), ptr(idx), stream_ptr()), "btc_three_nn")
+
+    @staticmethod
+    def three_interpolate_wrapper(features, idx, weight, out):
+        _need_cuda(features, idx, weight, out)
+        check(lib().btc_three_interpolate(ptr(features), ptr(idx), ptr(weight), int(idx.shape[0]), int(features.shape[1]), ptr(out),
+                                          stream_ptr()), "btc_three_interpolate")
+
+    @staticmethod
+    def three_interpolate_grad_wrapper(grad_out, idx, weight, grad_features):
+        _need_cuda(grad_out, idx, weight, grad_features)
+        check(lib().btc_three_interpolate_grad(ptr(grad_out), ptr(idx), ptr(weight), int(grad_out.shape[0]), int(grad_out.shape[1]),
+                                               int(grad_features.shape[0]), ptr(grad_features), stream_ptr()), "btc_three_interpolate_grad")
+
+
+pointnet2_stack_cuda = _Cuda()
+pointnet2 = pointnet2_stack_cuda
+
+
+def install_as_pointnet2_stack_cuda(package="btcdet.ops.pointnet2.pointnet2_stack"):
+    """register the stand-in under the name the reference imports (`from . import pointnet2_stack_cuda`)"""
+    import sys
+    import types
+    mod = types.ModuleType(package + ".pointnet2_stack_cuda")
+    for name in dir(_Cuda):
+        if name.endswith("_wrapper"):
+            setattr(mod, name, getattr(_Cuda, name))
+    sys.modules[package + ".pointnet2_stack_cuda"] = mod
+    return mod
+
+
+class BallQuery(Function):
+    @staticmethod
+    def forward(ctx, radius, nsample: int, xyz: torch.Tensor, xyz_batch_cnt: torch.Tensor, new_xyz: torch.Tensor, new_xyz_batch_cnt):
+        """idx (M, nsample) int32 LOCAL to each scene (empty balls zeroed), empty_ball_mask (M,) -- pointnet2_utils.py:11-40;
+        radius: float, or [inner, outer] for the shell query"""
+        assert new_xyz.is_contiguous() and new_xyz_batch_cnt.is_contiguous() and xyz.is_contiguous() and xyz_batch_cnt.is_contiguous()
+        B, M = xyz_batch_cnt.shape[0], new_xyz.shape[0]
+        idx = torch.empty((M, nsample), dtype=torch.int32, device=new_xyz.device)  # zeroed by the call
+        if isinstance(radius, (list, tuple)):
+            pointnet2.shell_query_wrapper(B, M, radius[0], radius[1], nsample, new_xyz, new_xyz_batch_cnt, xyz, xyz_batch_cnt, idx)
+        else:
+            pointnet2.ball_query_wrapper(B, M, radius, nsample, new_xyz, new_xyz_batch_cnt, xyz, xyz_batch_cnt, idx)
+        empty_ball_mask = (idx[:, 0] == -1)
+        idx[empty_ball_mask] = 0
+        ctx.mark_non_differentiable(idx, empty_ball_mask)
+        return idx, empty_ball_mask
+
+    @staticmethod
+    def backward(ctx, a=None, b=None):
+        return None, None, None, None, None, None
+
+
+ball_query = BallQuery.apply
+
+
+class GroupingOperation(Function):
+    @staticmethod
+    def forward(ctx, features: torch.Tensor, features_batch_cnt: torch.Tensor, idx: torch.Tensor, idx_batch_cnt: torch.Tensor):
+        """features (N1+N2.., C), idx (M1+M2.., nsample) -> (M1+M2.., C, nsample) -- pointnet2_utils.py:52-84"""
+        assert features.is_contiguous() and features_batch_cnt.is_contiguous() and idx.is_contiguous() and idx_batch_cnt.is_contiguous()
+        assert features.shape[0] == features_batch_cnt.sum(), 'features: %s, features_batch_cnt: %s' % (str(features.shape), str(features_batch_cnt))
+        assert idx.shape[0] == idx_batch_cnt.sum(), 'idx: %s, idx_batch_cnt: %s' % (str(idx.shape), str(idx_batch_cnt))
+        M, nsample = idx.size()
+        N, C = features.size()
+        B = idx_batch_cnt.shape[0]
+        output = torch.empty((M, C, nsample), dtype=torch.float32, device=features.device)
+        pointnet2.group_points_wrapper(B, M, C, nsample, features, features_batch_cnt, idx, idx_batch_cnt, output)
+        ctx.for_backwards = (B, N, idx, features_batch_cnt, idx_batch_cnt)
+        return output
+
+    @staticmethod
+    def backward(ctx, grad_out: torch.Tensor):
+        B, N, idx, features_batch_cnt, idx_batch_cnt = ctx.for_backwards
+        M, C, nsample = grad_out.size()
+        grad_features = torch.empty((N, C), dtype=torch.float32, device=grad_out.device)  # zeroed by the call
+        pointnet2.group_points_grad_wrapper(B, M, C, N, nsample, grad_out.contiguous(), idx, idx_batch_cnt, features_batch_cnt, grad_features)
+        return grad_features, None, None, None
+
+
+grouping_operation = GroupingOperation.apply
+
+
+class QueryAndGroup(nn.Module):
+    """pointnet2_utils.py:111-188, including the reference's rotation / scaling of the grouped offsets and its handling of a
+    trailing empty scene"""
+
+    def __init__(self, radius, nsample: int, use_xyz: bool = True):
+        super().__init__()
+        self.radius, self.nsample, self.use_xyz = radius, nsample, use_xyz
+
+    def forward(self, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, features=None, rotateMatrix=None, xyscales=None, zscales=None):
+        assert xyz.shape[0] == xyz_batch_cnt.sum(), 'xyz: %s, xyz_batch_cnt: %s' % (str(xyz.shape), str(new_xyz_batch_cnt))
+        assert new_xyz.shape[0] == new_xyz_batch_cnt.sum(), 'new_xyz: %s, new_xyz_batch_cnt: %s' % (str(new_xyz.shape), str(new_xyz_batch_cnt))
+        idx, empty_ball_mask = ball_query(self.radius, self.nsample, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt)
+        if len(xyz_batch_cnt) > 1 and xyz_batch_cnt[-1] == 0:
+            grouped_xyz = grouping_operation(xyz, xyz_batch_cnt[0:-1], idx[:-new_xyz_batch_cnt[-1]], new_xyz_batch_cnt[0:-1])
+            grouped_xyz = torch.cat([grouped_xyz, torch.zeros_like(grouped_xyz[:new_xyz_batch_cnt[-1]])], dim=0)
+        else:
+            grouped_xyz = grouping_operation(xyz, xyz_batch_cnt, idx, new_xyz_batch_cnt)  # (M1 + M2, 3, nsample)
+        grouped_xyz = grouped_xyz - new_xyz.unsqueeze(-1)
+        grouped_xyz[empty_ball_mask] = 0
+        pre_rot_grouped_xyz = None
+        if rotateMatrix is not None:
+            pre_rot_grouped_xyz = grouped_xyz
+            grouped_xyz = self.rotate(grouped_xyz, rotateMatrix)
+        if xyscales is not None:
+            grouped_xyz = torch.cat([grouped_xyz[..., :2, :] / xyscales, grouped_xyz[..., 2:3, :] / zscales], dim=-2)
+        if features is not None:
+            if len(xyz_batch_cnt) > 1 and xyz_batch_cnt[1] == 0:  # (sic) the reference tests index 1 here, -1 above
+                grouped_features = grouping_operation(features, xyz_batch_cnt[0:-1], idx[:-new_xyz_batch_cnt[-1]], new_xyz_batch_cnt[0:-1])
+                grouped_features = torch.cat([grouped_features, torch.zeros_like(grouped_features[:new_xyz_batch_cnt[-1]])], dim=0)
+            else:
+                grouped_features = grouping_operation(features, xyz_batch_cnt, idx, new_xyz_batch_cnt)
+            grouped_features[empty_ball_mask] = 0
+            new_features = torch.cat([grouped_xyz, grouped_features], dim=1) if self.use_xyz else grouped_features
+        else:
+            assert self.use_xyz, "Cannot have not features and not use xyz as a feature!"
+            new_features = grouped_xyz
+        if rotateMatrix is not None:
+            return new_features, idx, pre_rot_grouped_xyz
+        return new_features, idx
+
+    def rotate(self, grouped_xyz, rotateMatrix):
+        BN = rotateMatrix.shape[0]
+        BNG = grouped_xyz.shape[0]
+        rotateMatrix = rotateMatrix.view(BN, 1, 3, 3).repeat(1, BNG // BN, 1, 1).view(BNG, 3, 3)
+        rot = torch.einsum("nmj,nij->nmi", grouped_xyz.permute(0, 2, 1), rotateMatrix)
+        return rot.permute(0, 2, 1)
+
+
+class FurthestPointSampling(Function):
+    @staticmethod
+    def forward(ctx, xyz: torch.Tensor, npoint: int):
+        """xyz (B, N, 3) -> (B, npoint) int32 -- pointnet2_utils.py:194-213"""
+        assert xyz.is_contiguous()
+        B, N, _ = xyz.size()
+        output = torch.empty((B, npoint), dtype=torch.int32, device=xyz.device)
+        temp = torch.full((B, N), 1e10, dtype=torch.float32, device=xyz.device)
+        pointnet2.furthest_point_sampling_wrapper(B, N, npoint, xyz, temp, output)
+        ctx.mark_non_differentiable(output)
+        return output
+
+    @staticmethod
+    def backward(xyz, a=None):
+        return None, None
+
+
+furthest_point_sample = FurthestPointSampling.apply
+
+
+class ThreeNN(Function):
+    @staticmethod
+    def forward(ctx, unknown, unknown_batch_cnt, known, known_batch_cnt):
+        """-> dist (N,3) l2 distances to, and idx (N,3) global rows of, the three nearest known points -- pointnet2_utils.py:222-247"""
+        assert unknown.shape.__len__() == 2 and unknown.shape[1] == 3
+        assert known.shape.__len__() == 2 and known.shape[1] == 3
+        assert unknown_batch_cnt.__len__() == known_batch_cnt.__len__()
+        dist2 = unknown.new_zeros(unknown.shape)
+        idx = unknown_batch_cnt.new_zeros(unknown.shape).int()
+        pointnet2.three_nn_wrapper(unknown.contiguous(), unknown_batch_cnt.contiguous(), known.contiguous(), known_batch_cnt.contiguous(), dist2, idx)
+        ctx.mark_non_differentiable(idx)
+        return torch.sqrt(dist2), idx
+
+    @staticmethod
+    def backward(ctx, a=None, b=None):
+        return None, None, None, None
+
+
+three_nn = ThreeNN.apply
+
+
+class ThreeInterpolate(Function):
+    @staticmethod
+    def forward(ctx, features: torch.Tensor, idx: torch.Tensor, weight: torch.Tensor):
+        """features (M1+M2.., C), idx / weight (N1+N2.., 3) -> (N1+N2.., C) -- pointnet2_utils.py:256-272"""
+        assert idx.shape[0] == weight.shape[0] and idx.shape[1] == weight.shape[1] == 3
+        ctx.three_interpolate_for_backward = (idx, weight, features.shape[0])
+        output = features.new_empty((idx.shape[0], features.shape[1]))
+        pointnet2.three_interpolate_wrapper(features.contiguous(), idx.contiguous(), weight.contiguous(), output)
+        return output
+
+    @staticmethod
+    def backward(ctx, grad_out: torch.Tensor):
+        idx, weight, M = ctx.three_interpolate_for_backward
+        grad_features = grad_out.new_empty((M, grad_out.shape[1]))  # zeroed by the call
+        pointnet2.three_interpolate_grad_wrapper(grad_out.contiguous(), idx.contiguous(), weight.contiguous(), grad_features)
+        return grad_features, None, None
+
+
+three_interpolate = ThreeInterpolate.apply
+
+
+class StackSAModuleMSG(nn.Module):
+    """pointnet2_modules.py:10-111: multi-scale grouping -> shared MLP (1x1 Conv2d + BatchNorm2d + ReLU, vendor kernels) -> pool"""
+
+    def __init__(self, *, radii: List[float], nsamples: List[int], mlps: List[List[int]], use_xyz: bool = True, pool_method='max_pool'):
+        super().__init__()
+        assert len(radii) == len(nsamples) == len(mlps)
+        self.groupers = nn.ModuleList()
+        self.mlps = nn.ModuleList()
+        for i in range(len(radii)):
+            self.groupers.append(QueryAndGroup(radii[i], nsamples[i], use_xyz=use_xyz))
+            mlp_spec = mlps[i]
+            if use_xyz:
+                mlp_spec[0] += 3  # in place, as the reference does (the caller's list is modified)
+            shared_mlps = []
+            for k in range(len(mlp_spec) - 1):
+                shared_mlps.extend([nn.Conv2d(mlp_spec[k], mlp_spec[k + 1], kernel_size=1, bias=False), nn.BatchNorm2d(mlp_spec[k + 1]), nn.ReLU()])
+            self.mlps.append(nn.Sequential(*shared_mlps))
+        self.pool_method = pool_method
+        self.init_weights()
+
+    def init_weights(self):
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight)
+                if m.bias is not None:
+                    nn.init.constant_(m.bias, 0)
+            if isinstance(m, nn.BatchNorm2d):
+                nn.init.constant_(m.weight, 1.0)
+                nn.init.constant_(m.bias, 0)
+
+    def forward(self, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, features=None, empty_voxel_set_zeros=True, rotateMatrix=None, xyscales=None,
+                zscales=None, vis=False):
+        new_features_list, points_lst, prerot_points_lst = [], [], []
+        prerot_xyz = None
+        for k in range(len(self.groupers)):
+            result_lst = self.groupers[k](xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, features, rotateMatrix=rotateMatrix, xyscales=xyscales,
+                                          zscales=zscales)
+            if rotateMatrix is not None:
+                new_features, ball_idxs, prerot_xyz = result_lst
+            else:
+                new_features, ball_idxs = result_lst
+            new_features = new_features.permute(1, 0, 2).unsqueeze(dim=0)  # (1, C, M1 + M2 ..., nsample)
+            if vis:
+                points_lst.append(torch.split(new_features[0].permute(1, 2, 0)[..., :3], new_xyz_batch_cnt.tolist())[0])
+                if prerot_xyz is not None:
+                    prerot_points_lst.append(torch.split(prerot_xyz.permute(0, 2, 1), new_xyz_batch_cnt.tolist())[0])
+            new_features = self.mlps[k](new_features)
+            if self.pool_method == 'max_pool':
+                new_features = F.max_pool2d(new_features, kernel_size=[1, new_features.size(3)]).squeeze(dim=-1)
+            elif self.pool_method == 'avg_pool':
+                new_features = F.avg_pool2d(new_features, kernel_size=[1, new_features.size(3)]).squeeze(dim=-1)
+            else:
+                raise NotImplementedError
+            new_features_list.append(new_features.squeeze(dim=0).permute(1, 0))  # (M1 + M2 ..., C)
+        new_features = torch.cat(new_features_list, dim=1)
+        if vis:
+            return new_xyz, new_features, [points_lst, prerot_points_lst]
+        return new_xyz, new_features
+
+
+class StackPointnetFPModule(nn.Module):
+    """pointnet2_modules.py:114-153: three-NN inverse-distance interpolation -> shared MLP"""
+
+    def __init__(self, *, mlp: List[int]):
+        super().__init__()
+        shared_mlps = []
+        for k in range(len(mlp) - 1):
+            shared_mlps.extend([nn.Conv2d(mlp[k], mlp[k + 1], kernel_size=1, bias=False), nn.BatchNorm2d(mlp[k + 1]), nn.ReLU()])
+        self.mlp = nn.Sequential(*shared_mlps)
+
+    def forward(self, unknown, unknown_batch_cnt, known, known_batch_cnt, unknown_feats=None, known_feats=None):
+        dist, idx = three_nn(unknown, unknown_batch_cnt, known, known_batch_cnt)
+        dist_recip = 1.0 / (dist + 1e-8)
+        norm = torch.sum(dist_recip, dim=-1, keepdim=True)
+        weight = dist_recip / norm
+        interpolated_feats = three_interpolate(known_feats, idx, weight)
+        new_features = torch.cat([interpolated_feats, unknown_feats], dim=1) if unknown_feats is not None else interpolated_feats
+        new_features = new_features.permute(1, 0)[None, :, :, None]
+        new_features = self.mlp(new_features)
+        return new_features.squeeze(dim=0).squeeze(dim=-1).permute(1, 0)

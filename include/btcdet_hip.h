@@ -343,6 +343,35 @@ size_t btc_nms_ws_bytes(int n);
 int btc_nms(const float* boxes_sorted, int n, float thresh, int rotated, long long* keep, int32_t* d_num_keep, void* ws,
             size_t ws_bytes, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * pointnet2_stack.  Entry points = the functions the reference binds from its compiled module
+ * `pointnet2_stack_cuda` (/root/reference/btcdet/ops/pointnet2/pointnet2_stack/src/pointnet2_api.cpp; call sites
+ * pointnet2_utils.py:34-36,76,98,208,237,271,289).  Stacked batches: rows of scene b are contiguous, *_batch_cnt (B) i32.
+ *   btc_ball_query: idx (M,nsample) i32 = the first nsample points of the query's scene, in index order, with
+ *     inner_radius^2 <= d^2 < outer_radius^2 (inner_radius < 0: plain ball), as indices LOCAL to the scene; unused slots
+ *     repeat the first hit; a query without hits gets idx[q][0] = -1 and zeros (ball_query_gpu.cu:15-66,
+ *     shell_query_gpu.cu:15-68; the reference zero-fills idx before the launch, so does this call)
+ *   btc_group_points: out (M,C,nsample) = features[scene start + idx]; _grad accumulates into grad_features (N,C),
+ *     zeroed by the call (group_points_gpu.cu:14-46,64-97)
+ *   btc_furthest_point_sampling: xyz (B,N,3), temp (B,N) running distances (1e10 on entry), idx (B,npoint); ties are
+ *     resolved exactly as the reference's strided scan + tree reduction does -- among equal maxima the smallest
+ *     bit-reversed (k mod T), then the smallest k, T = the reference's thread count for N (sampling_gpu.cu:16-142)
+ *   btc_three_nn: dist2 / idx (N,3): squared distances and GLOBAL row indices of the three nearest known points of the
+ *     same scene, first-found wins ties (interpolate_gpu.cu:14-69); btc_three_interpolate(_grad): :106-121,141-158
+ * ---------------------------------------------------------------------------------------------- */
+int btc_ball_query(const float* new_xyz, const int32_t* new_xyz_batch_cnt, const float* xyz, const int32_t* xyz_batch_cnt, int B,
+                   int M, float inner_radius, float outer_radius, int nsample, int32_t* idx, void* stream);
+int btc_group_points(const float* features, const int32_t* features_batch_cnt, const int32_t* idx, const int32_t* idx_batch_cnt,
+                     int B, int M, int C, int nsample, float* out, void* stream);
+int btc_group_points_grad(const float* grad_out, const int32_t* idx, const int32_t* idx_batch_cnt, const int32_t* features_batch_cnt,
+                          int B, int M, int C, int N, int nsample, float* grad_features, void* stream);
+int btc_furthest_point_sampling(const float* xyz, int B, int N, int npoint, float* temp, int32_t* idx, void* stream);
+int btc_three_nn(const float* unknown, const int32_t* unknown_batch_cnt, const float* known, const int32_t* known_batch_cnt, int B,
+                 int N, float* dist2, int32_t* idx, void* stream);
+int btc_three_interpolate(const float* features, const int32_t* idx, const float* weight, int N, int C, float* out, void* stream);
+int btc_three_interpolate_grad(const float* grad_out, const int32_t* idx, const float* weight, int N, int C, int M,
+                               float* grad_features, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

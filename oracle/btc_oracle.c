@@ -450,3 +450,165 @@ int orc_nms(const float* boxes, int n, float thresh, int rotated, long long* kee
   free(removed);
   return nk;
 }
+
+/* ======================================================================================================================
+ * pointnet2_stack: sequential restatement of the reference's CUDA kernels, one loop body per
+ * CUDA thread.  PARITY: unpinned against an execution of the reference (the ops exist only as CUDA sources there and the
+ * reference has no tests for them); anchored on the kernels cited per function and cross-checked against independent numpy
+ * formulations (tests/test_oracle_pointnet2.py).
+ * ====================================================================================================================== */
+static int orc_scene_of(int pt, const int32_t* cnt, int B, const int32_t* other, int* start_other) {
+  int bs = 0, acc = cnt[0];
+  for (int k = 1; k < B; ++k) {
+    if (pt < acc) break;
+    acc += cnt[k];
+    bs = k;
+  }
+  int s = 0;
+  for (int k = 0; k < bs; ++k) s += other[k];
+  *start_other = s;
+  return bs;
+}
+
+/* ball_query_gpu.cu:15-66 / shell_query_gpu.cu:15-68 (inner_radius < 0: ball).  idx (M,nsample) must be zero on entry
+ * (pointnet2_utils.py:32). */
+void orc_ball_query(const float* new_xyz, const int32_t* new_cnt, const float* xyz, const int32_t* cnt, int B, int M,
+                    float inner_radius, float outer_radius, int nsample, int32_t* idx) {
+  const float outer2 = outer_radius * outer_radius, inner2 = inner_radius * inner_radius;
+  for (int pt = 0; pt < M; ++pt) {
+    int start;
+    const int bs = orc_scene_of(pt, new_cnt, B, cnt, &start);
+    const float* q = new_xyz + (size_t)pt * 3;
+    const float* p = xyz + (size_t)start * 3;
+    int32_t* out = idx + (size_t)pt * nsample;
+    const int n = cnt[bs];
+    int c = 0;
+    for (int k = 0; k < n; ++k) {
+      const float x = p[k * 3 + 0], y = p[k * 3 + 1], z = p[k * 3 + 2];
+      const float d2 = (q[0] - x) * (q[0] - x) + (q[1] - y) * (q[1] - y) + (q[2] - z) * (q[2] - z);
+      if ((inner_radius < 0.f || d2 >= inner2) && d2 < outer2) {
+        if (c == 0)
+          for (int l = 0; l < nsample; ++l) out[l] = k;
+        out[c] = k;
+        if (++c >= nsample) break;
+      }
+    }
+    if (c == 0) out[0] = -1;
+  }
+}
+
+/* group_points_gpu.cu:64-97 */
+void orc_group_points(const float* features, const int32_t* f_cnt, const int32_t* idx, const int32_t* idx_cnt, int B, int M, int C,
+                      int nsample, float* out) {
+  for (int pt = 0; pt < M; ++pt) {
+    int fstart;
+    orc_scene_of(pt, idx_cnt, B, f_cnt, &fstart);
+    for (int c = 0; c < C; ++c)
+      for (int s = 0; s < nsample; ++s)
+        out[((size_t)pt * C + c) * nsample + s] = features[(size_t)(fstart + idx[(size_t)pt * nsample + s]) * C + c];
+  }
+}
+
+/* group_points_gpu.cu:14-46 (atomicAdd there: summation order unspecified; here ascending (pt, c, sample)) */
+void orc_group_points_grad(const float* grad_out, const int32_t* idx, const int32_t* idx_cnt, const int32_t* f_cnt, int B, int M, int C,
+                           int N, int nsample, float* grad_features) {
+  for (size_t i = 0; i < (size_t)N * C; ++i) grad_features[i] = 0.f;
+  for (int pt = 0; pt < M; ++pt) {
+    int fstart;
+    orc_scene_of(pt, idx_cnt, B, f_cnt, &fstart);
+    for (int c = 0; c < C; ++c)
+      for (int s = 0; s < nsample; ++s)
+        grad_features[(size_t)(fstart + idx[(size_t)pt * nsample + s]) * C + c] += grad_out[((size_t)pt * C + c) * nsample + s];
+  }
+}
+
+/* sampling_gpu.cu:16-142: block_size = opt_n_threads(n) threads, thread t scans k = t, t + T, ... keeping its first
+ * strict maximum, then the pairwise tree (tid, tid + half) where the lower tid wins ties.  temp (B,n) is 1e10 on entry. */
+void orc_furthest_point_sampling(const float* xyz, int B, int n, int m, float* temp, int32_t* idxs) {
+  if (m <= 0) return;
+  int T = 1;
+  while (T * 2 <= n && T < 1024) T *= 2;
+  float* dv = (float*)malloc(sizeof(float) * (size_t)T);
+  int* di = (int*)malloc(sizeof(int) * (size_t)T);
+  for (int b = 0; b < B; ++b) {
+    const float* d = xyz + (size_t)b * n * 3;
+    float* tp = temp + (size_t)b * n;
+    int32_t* out = idxs + (size_t)b * m;
+    int old = 0;
+    out[0] = 0;
+    for (int j = 1; j < m; ++j) {
+      const float x1 = d[old * 3 + 0], y1 = d[old * 3 + 1], z1 = d[old * 3 + 2];
+      for (int t = 0; t < T; ++t) {
+        int besti = 0;
+        float best = -1.f;
+        for (int k = t; k < n; k += T) {
+          const float x2 = d[k * 3 + 0], y2 = d[k * 3 + 1], z2 = d[k * 3 + 2];
+          const float dd = (x2 - x1) * (x2 - x1) + (y2 - y1) * (y2 - y1) + (z2 - z1) * (z2 - z1);
+          const float d2 = fminf(dd, tp[k]);
+          tp[k] = d2;
+          besti = d2 > best ? k : besti;
+          best = d2 > best ? d2 : best;
+        }
+        dv[t] = best;
+        di[t] = besti;
+      }
+      for (int half = T / 2; half >= 1; half /= 2)
+        for (int t = 0; t < half; ++t) {
+          const float v1 = dv[t], v2 = dv[t + half];
+          const int i1 = di[t], i2 = di[t + half];
+          dv[t] = v1 > v2 ? v1 : v2;  /* max(v1, v2) */
+          di[t] = v2 > v1 ? i2 : i1;
+        }
+      old = di[0];
+      out[j] = old;
+    }
+  }
+  free(dv);
+  free(di);
+}
+
+/* interpolate_gpu.cu:14-69 */
+void orc_three_nn(const float* unknown, const int32_t* u_cnt, const float* known, const int32_t* k_cnt, int B, int N, float* dist2,
+                  int32_t* idx) {
+  for (int pt = 0; pt < N; ++pt) {
+    int kstart;
+    const int bs = orc_scene_of(pt, u_cnt, B, k_cnt, &kstart);
+    const float* kn = known + (size_t)kstart * 3;
+    const float ux = unknown[(size_t)pt * 3 + 0], uy = unknown[(size_t)pt * 3 + 1], uz = unknown[(size_t)pt * 3 + 2];
+    double best1 = 1e40, best2 = 1e40, best3 = 1e40;
+    int b1 = 0, b2 = 0, b3 = 0;
+    for (int k = 0; k < k_cnt[bs]; ++k) {
+      const float x = kn[k * 3 + 0], y = kn[k * 3 + 1], z = kn[k * 3 + 2];
+      const float d = (ux - x) * (ux - x) + (uy - y) * (uy - y) + (uz - z) * (uz - z);
+      if (d < best1) { best3 = best2; b3 = b2; best2 = best1; b2 = b1; best1 = d; b1 = k; }
+      else if (d < best2) { best3 = best2; b3 = b2; best2 = d; b2 = k; }
+      else if (d < best3) { best3 = d; b3 = k; }
+    }
+    dist2[(size_t)pt * 3 + 0] = (float)best1; dist2[(size_t)pt * 3 + 1] = (float)best2; dist2[(size_t)pt * 3 + 2] = (float)best3;
+    idx[(size_t)pt * 3 + 0] = b1 + kstart; idx[(size_t)pt * 3 + 1] = b2 + kstart; idx[(size_t)pt * 3 + 2] = b3 + kstart;
+  }
+}
+
+/* interpolate_gpu.cu:106-121 */
+void orc_three_interpolate(const float* features, const int32_t* idx, const float* weight, int N, int C, float* out) {
+  for (int pt = 0; pt < N; ++pt)
+    for (int c = 0; c < C; ++c) {
+      const int32_t* id = idx + (size_t)pt * 3;
+      const float* w = weight + (size_t)pt * 3;
+      out[(size_t)pt * C + c] = w[0] * features[(size_t)id[0] * C + c] + w[1] * features[(size_t)id[1] * C + c] + w[2] * features[(size_t)id[2] * C + c];
+    }
+}
+
+/* interpolate_gpu.cu:141-158 (atomicAdd there) */
+void orc_three_interpolate_grad(const float* grad_out, const int32_t* idx, const float* weight, int N, int C, int M, float* grad_features) {
+  for (size_t i = 0; i < (size_t)M * C; ++i) grad_features[i] = 0.f;
+  for (int pt = 0; pt < N; ++pt)
+    for (int c = 0; c < C; ++c) {
+      const int32_t* id = idx + (size_t)pt * 3;
+      const float* w = weight + (size_t)pt * 3;
+      const float g = grad_out[(size_t)pt * C + c];
+      grad_features[(size_t)id[0] * C + c] += g * w[0];
+      grad_features[(size_t)id[1] * C + c] += g * w[1];
+      grad_features[(size_t)id[2] * C + c] += g * w[2];
+    }
+}

@@ -300,3 +300,79 @@ def nms(boxes, scores, thresh, pre_maxsize=None, rotated=True):
     L.orc_nms.restype = ctypes.c_int
     n = L.orc_nms(_fp(sb), sb.shape[0], ctypes.c_float(thresh), int(bool(rotated)), keep.ctypes.data_as(ctypes.c_void_p))
     return order[keep[:n]]
+
+
+# ------------------------------------------------------------------ pointnet2_stack (btc_oracle.c)
+def _i32(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=np.int32))
+
+
+def _f32(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=np.float32))
+
+
+def ball_query(radius, nsample, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt):
+    """pointnet2_utils.BallQuery.forward:11-40 -> (idx (M,nsample) int32 with empty balls zeroed, empty_ball_mask (M,) bool);
+    radius: float, or [inner, outer] for the shell query"""
+    xyz, new_xyz, cnt, ncnt = _f32(xyz).reshape(-1, 3), _f32(new_xyz).reshape(-1, 3), _i32(xyz_batch_cnt), _i32(new_xyz_batch_cnt)
+    M = new_xyz.shape[0]
+    idx = np.zeros((M, int(nsample)), dtype=np.int32)
+    inner, outer = (float(radius[0]), float(radius[1])) if isinstance(radius, (list, tuple)) else (-1.0, float(radius))
+    lib().orc_ball_query(_fp(new_xyz), _ip(ncnt), _fp(xyz), _ip(cnt), int(cnt.shape[0]), M, ctypes.c_float(inner), ctypes.c_float(outer),
+                         int(nsample), _ip(idx))
+    empty = idx[:, 0] == -1
+    idx[empty] = 0
+    return idx, empty
+
+
+def group_points(features, features_batch_cnt, idx, idx_batch_cnt):
+    """GroupingOperation.forward:52-84 -> (M, C, nsample)"""
+    f, fc, idx, ic = _f32(features), _i32(features_batch_cnt), _i32(idx), _i32(idx_batch_cnt)
+    M, ns = idx.shape
+    out = np.empty((M, f.shape[1], ns), dtype=np.float32)
+    lib().orc_group_points(_fp(f), _ip(fc), _ip(idx), _ip(ic), int(ic.shape[0]), M, int(f.shape[1]), ns, _fp(out))
+    return out
+
+
+def group_points_grad(grad_out, idx, idx_batch_cnt, features_batch_cnt, N):
+    """GroupingOperation.backward:86-104 -> (N, C)"""
+    g, idx, ic, fc = _f32(grad_out), _i32(idx), _i32(idx_batch_cnt), _i32(features_batch_cnt)
+    M, C, ns = g.shape
+    out = np.empty((int(N), C), dtype=np.float32)
+    lib().orc_group_points_grad(_fp(g), _ip(idx), _ip(ic), _ip(fc), int(ic.shape[0]), M, C, int(N), ns, _fp(out))
+    return out
+
+
+def furthest_point_sample(xyz, npoint):
+    """FurthestPointSampling.forward:194-213: xyz (B,N,3) -> (B,npoint) int32"""
+    xyz = _f32(xyz)
+    B, N, _ = xyz.shape
+    temp = np.full((B, N), 1e10, dtype=np.float32)
+    out = np.zeros((B, int(npoint)), dtype=np.int32)
+    lib().orc_furthest_point_sampling(_fp(xyz), B, N, int(npoint), _fp(temp), _ip(out))
+    return out
+
+
+def three_nn(unknown, unknown_batch_cnt, known, known_batch_cnt):
+    """ThreeNN.forward:222-247 -> (dist (N,3) = sqrt of the squared distances, idx (N,3) global rows)"""
+    u, uc, k, kc = _f32(unknown).reshape(-1, 3), _i32(unknown_batch_cnt), _f32(known).reshape(-1, 3), _i32(known_batch_cnt)
+    N = u.shape[0]
+    d2 = np.zeros((N, 3), dtype=np.float32)
+    idx = np.zeros((N, 3), dtype=np.int32)
+    lib().orc_three_nn(_fp(u), _ip(uc), _fp(k), _ip(kc), int(uc.shape[0]), N, _fp(d2), _ip(idx))
+    with np.errstate(invalid="ignore"):
+        return np.sqrt(d2), idx
+
+
+def three_interpolate(features, idx, weight):
+    f, idx, w = _f32(features), _i32(idx), _f32(weight)
+    out = np.empty((idx.shape[0], f.shape[1]), dtype=np.float32)
+    lib().orc_three_interpolate(_fp(f), _ip(idx), _fp(w), int(idx.shape[0]), int(f.shape[1]), _fp(out))
+    return out
+
+
+def three_interpolate_grad(grad_out, idx, weight, M):
+    g, idx, w = _f32(grad_out), _i32(idx), _f32(weight)
+    out = np.empty((int(M), g.shape[1]), dtype=np.float32)
+    lib().orc_three_interpolate_grad(_fp(g), _ip(idx), _fp(w), int(g.shape[0]), int(g.shape[1]), int(M), _fp(out))
+    return out
