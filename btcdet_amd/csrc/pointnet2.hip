@@ -138,22 +138,31 @@ __global__ __launch_bounds__(256) void group_points_grad_k(const float* __restri
 struct FpsBest {
   float v;
   int key, k;  // key = bit-reversed (k mod T) of the reference launch; ties: smallest (key, k)
+  float x, y, z;  // the candidate's coordinates travel with it: the next iteration starts without a global load
 };
 
-__device__ __forceinline__ FpsBest fps_better(FpsBest a, FpsBest b) {
-  if (b.v > a.v) return b;
-  if (b.v < a.v || !(b.v == a.v)) return a;  // NaN never wins a strict '>' in the reference either
-  if (b.key < a.key || (b.key == a.key && b.k < a.k)) return b;
-  return a;
+__device__ __forceinline__ bool fps_wins(const FpsBest& b, const FpsBest& a) {  // does b replace a?
+  if (b.v > a.v) return true;
+  if (!(b.v == a.v)) return false;  // smaller, or NaN (which never wins a strict '>' in the reference either)
+  return b.key < a.key || (b.key == a.key && b.k < a.k);
 }
 
-template <int PER, bool REG>
-__global__ __launch_bounds__(1024) void fps_k(int n, int m, int T, int log2T, const float* __restrict__ dataset, float* __restrict__ temp,
+__device__ __forceinline__ FpsBest fps_shfl_down(const FpsBest& b, int o) {
+  return FpsBest{__shfl_down(b.v, o, 64), __shfl_down(b.key, o, 64), __shfl_down(b.k, o, 64), __shfl_down(b.x, o, 64),
+                 __shfl_down(b.y, o, 64), __shfl_down(b.z, o, 64)};
+}
+
+// One barrier per iteration: every wave reduces its candidates with shuffles, lane 0 publishes the wave's winner (value, tie
+// key, index, coordinates) in a double-buffered LDS table, and after the barrier EVERY wave reduces the 16 entries itself.
+// Register budget: the per-thread point arrays must not spill (a scratch access per iteration costs more than the whole
+// reduction): 1024 threads x 4 points (<= 4 K points), or 512 threads x 32 points with 2 waves per SIMD = 256 VGPRs per lane.
+template <int PER, bool REG, int THREADS>
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(THREADS / 256, THREADS / 256))) void fps_k(int n, int m, int T, int log2T, const float* __restrict__ dataset, float* __restrict__ temp,
                                               int32_t* __restrict__ idxs) {
   if (m <= 0) return;
-  __shared__ float s_v[16];
-  __shared__ int s_key[16], s_k[16];
-  __shared__ int s_old;
+  constexpr int NW = THREADS / 64;
+  __shared__ float s_v[2][NW], s_x[2][NW], s_y[2][NW], s_z[2][NW];
+  __shared__ int s_key[2][NW], s_k[2][NW];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   dataset += (size_t)blockIdx.x * n * 3;
   temp += (size_t)blockIdx.x * n;
@@ -162,65 +171,90 @@ __global__ __launch_bounds__(1024) void fps_k(int n, int m, int T, int log2T, co
   if (REG) {
 #pragma unroll
     for (int u = 0; u < PER; ++u) {
-      const int k = tid + u * 1024;
+      const int k = tid + u * THREADS;
       if (k < n) { px[u] = dataset[k * 3 + 0]; py[u] = dataset[k * 3 + 1]; pz[u] = dataset[k * 3 + 2]; pt[u] = temp[k]; }
     }
   }
-  int old = 0;
+  auto key_of = [&](int k) { return log2T ? (int)(__brev((unsigned)(k & (T - 1))) >> (32 - log2T)) : 0; };
+  float x1 = dataset[0], y1 = dataset[1], z1 = dataset[2];
   if (tid == 0) idxs[0] = 0;
   for (int j = 1; j < m; ++j) {
-    const float x1 = dataset[old * 3 + 0], y1 = dataset[old * 3 + 1], z1 = dataset[old * 3 + 2];
-    FpsBest best{-1.f, 0x7fffffff, 0};
+    // a thread without a candidate above the reference's initial best (-1) contributes (v = -1, index 0), like the reference
+    FpsBest best{-1.f, 0, 0, 0.f, 0.f, 0.f};
     bool any = false;
     if (REG) {
+      // in the loop only (value, slot) are live; key and coordinates are looked up once, after it (register pressure)
+      float bv = -1.f;
+      int bu = -1;
 #pragma unroll
       for (int u = 0; u < PER; ++u) {
-        const int k = tid + u * 1024;
+        const int k = tid + u * THREADS;
         if (k < n) {
           const float d = (px[u] - x1) * (px[u] - x1) + (py[u] - y1) * (py[u] - y1) + (pz[u] - z1) * (pz[u] - z1);
           const float d2 = fminf(d, pt[u]);
           pt[u] = d2;
-          FpsBest c{d2, log2T ? (int)(__brev((unsigned)(k & (T - 1))) >> (32 - log2T)) : 0, k};
-          best = any ? fps_better(best, c) : (d2 > -1.f ? c : best);
-          any = any || d2 > -1.f;
+          bool take = d2 > bv;
+          if (!take && bu >= 0 && d2 == bv) {  // tie inside the thread: smaller (key, k) wins; k grows with u
+            take = key_of(k) < key_of(tid + bu * THREADS);
+          }
+          if (take) { bv = d2; bu = u; }
         }
       }
+      if (bu >= 0) {
+        any = true;
+        best.v = bv;
+        best.k = tid + bu * THREADS;
+        best.key = key_of(best.k);
+#pragma unroll
+        for (int u = 0; u < PER; ++u)
+          if (u == bu) { best.x = px[u]; best.y = py[u]; best.z = pz[u]; }
+      }
     } else {
-      for (int k = tid; k < n; k += 1024) {
+      for (int k = tid; k < n; k += THREADS) {
         const float x2 = dataset[k * 3 + 0], y2 = dataset[k * 3 + 1], z2 = dataset[k * 3 + 2];
         const float d = (x2 - x1) * (x2 - x1) + (y2 - y1) * (y2 - y1) + (z2 - z1) * (z2 - z1);
         const float d2 = fminf(d, temp[k]);
         temp[k] = d2;
-        FpsBest c{d2, log2T ? (int)(__brev((unsigned)(k & (T - 1))) >> (32 - log2T)) : 0, k};
-        best = any ? fps_better(best, c) : (d2 > -1.f ? c : best);
-        any = any || d2 > -1.f;
+        const FpsBest c{d2, key_of(k), k, x2, y2, z2};
+        if (any ? fps_wins(c, best) : d2 > -1.f) { best = c; any = true; }
       }
     }
-    // a thread without a candidate above the reference's initial best (-1) contributes (v = -1, index 0), like the reference
-    if (!any) best = FpsBest{-1.f, 0, 0};
+    // wave winner of (value, tie key, index) by shuffles; its coordinates are published by the lane that owns it
+    const int own_k = any ? best.k : -1;
+    const float ox = best.x, oy = best.y, oz = best.z;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
-      FpsBest other{__shfl_down(best.v, o, 64), __shfl_down(best.key, o, 64), __shfl_down(best.k, o, 64)};
-      best = fps_better(best, other);
+      const float ov = __shfl_down(best.v, o, 64);
+      const int okey = __shfl_down(best.key, o, 64), ok = __shfl_down(best.k, o, 64);
+      if (ov > best.v || (ov == best.v && (okey < best.key || (okey == best.key && ok < best.k)))) { best.v = ov; best.key = okey; best.k = ok; }
     }
-    if (lane == 0) { s_v[wave] = best.v; s_key[wave] = best.key; s_k[wave] = best.k; }
+    const int buf = j & 1;
+    const float wv = __shfl(best.v, 0, 64);
+    const int wk = __shfl(best.k, 0, 64);
+    if (lane == 0) { s_v[buf][wave] = best.v; s_key[buf][wave] = best.key; s_k[buf][wave] = best.k; }
+    if (wv > -1.f) {
+      if (own_k == wk) { s_x[buf][wave] = ox; s_y[buf][wave] = oy; s_z[buf][wave] = oz; }
+    } else if (lane == 0) {  // no candidate in the whole wave: the reference's (-1, index 0)
+      s_x[buf][wave] = dataset[0]; s_y[buf][wave] = dataset[1]; s_z[buf][wave] = dataset[2];
+    }
     __syncthreads();
-    if (wave == 0) {
-      FpsBest b = lane < 16 ? FpsBest{s_v[lane], s_key[lane], s_k[lane]} : FpsBest{-2.f, 0x7fffffff, 0};
+    const int l = lane & (NW - 1);
+    float bv = s_v[buf][l];
+    int bkey = s_key[buf][l], bk = s_k[buf][l], bw = l;
 #pragma unroll
-      for (int o = 8; o > 0; o >>= 1) {
-        FpsBest other{__shfl_down(b.v, o, 64), __shfl_down(b.key, o, 64), __shfl_down(b.k, o, 64)};
-        b = fps_better(b, other);
-      }
-      if (lane == 0) { s_old = b.k; idxs[j] = b.k; }
+    for (int o = NW / 2; o > 0; o >>= 1) {  // lanes 0..NW-1 hold the waves' winners; the lanes above mirror them and are ignored
+      const float ov = __shfl_down(bv, o, 64);
+      const int okey = __shfl_down(bkey, o, 64), ok = __shfl_down(bk, o, 64), ow = __shfl_down(bw, o, 64);
+      if (l + o < NW && (ov > bv || (ov == bv && (okey < bkey || (okey == bkey && ok < bk))))) { bv = ov; bkey = okey; bk = ok; bw = ow; }
     }
-    __syncthreads();
-    old = s_old;
+    const int win_w = __shfl(bw, 0, 64), win_k = __shfl(bk, 0, 64);
+    x1 = s_x[buf][win_w]; y1 = s_y[buf][win_w]; z1 = s_z[buf][win_w];
+    if (tid == 0) idxs[j] = win_k;
   }
   if (REG) {
 #pragma unroll
     for (int u = 0; u < PER; ++u) {
-      const int k = tid + u * 1024;
+      const int k = tid + u * THREADS;
       if (k < n) temp[k] = pt[u];
     }
   }
@@ -346,9 +380,9 @@ extern "C" int btc_furthest_point_sampling(const float* xyz, int B, int N, int n
   if (B == 0 || npoint == 0) return BTC_OK;
   int T = 1, log2T = 0;  // threads the reference launches for n points: the largest power of two <= n, capped at 1024 (opt_n_threads)
   while (T * 2 <= N && T < 1024) { T *= 2; ++log2T; }
-  if (N <= 4 * 1024) fps_k<4, true><<<B, 1024, 0, stream>>>(N, npoint, T, log2T, xyz, temp, idx);
-  else if (N <= 16 * 1024) fps_k<16, true><<<B, 1024, 0, stream>>>(N, npoint, T, log2T, xyz, temp, idx);
-  else fps_k<1, false><<<B, 1024, 0, stream>>>(N, npoint, T, log2T, xyz, temp, idx);
+  if (N <= 4 * 1024) fps_k<4, true, 1024><<<B, 1024, 0, stream>>>(N, npoint, T, log2T, xyz, temp, idx);
+  else if (N <= 16 * 1024) fps_k<32, true, 512><<<B, 512, 0, stream>>>(N, npoint, T, log2T, xyz, temp, idx);
+  else fps_k<1, false, 1024><<<B, 1024, 0, stream>>>(N, npoint, T, log2T, xyz, temp, idx);
   BTC_LAUNCH_CHECK();
   return BTC_OK;
 }

@@ -665,7 +665,9 @@ int launch_apply(const float* feat, const float* W, const float* bias, const int
   // 200 K-row occupancy-branch layers where the register-staged kernel below measures 5-10 % faster.  Wave shapes from
   // tools/conv_bench.py on MI355X (us per launch, register-staged -> LDS-DMA): 14 K rows 64->64: 80 -> 53, 128->128: 225 -> 158,
   // 256->128: 456 -> 309; 3 K rows 64->64: 65 -> 40; 30 K rows 64->64: 119 -> 99.
-  if (bf || (t_kernel != 1 && btc_apply_glds_supported(K, Cred, Cres) && (t_kernel == 2 || n_rows < 100000))) {
+  // (the 100 K-row exception is about the 32-channel occupancy-branch layers; wide layers -- the ROI head's 128-channel
+  // micro-scene pyramid at 130 K rows -- stay on the LDS-DMA kernel at any row count)
+  if (bf || (t_kernel != 1 && btc_apply_glds_supported(K, Cred, Cres) && (t_kernel == 2 || n_rows < 100000 || (Cred >= 64 && Cres >= 64)))) {
     int shape, kc = (Cred % 64 == 0) ? 64 : ((Cred % 32 == 0) ? 32 : 16);
     if (Cres % 128 == 0) shape = 424;                       // 64 rows x 128 columns, 8 waves
     else if (Cres % 64 == 0) shape = n_rows < 8192 ? 141 : 422;  // few rows: 16-row workgroups, 4 waves across the columns

@@ -1,0 +1,103 @@
+"""The third spconv consumer of the reference: the ROI head's `x_combine` pyramid runs
+batch_size * 128 rois * 3^3 grid points = 6 912 MICRO-SCENES of [2, 4, 12] cells through three anisotropic SparseConv3d
+(kernel / stride / padding per axis, btcdet_kitti_car.yaml:281-289; conv_head.py:117-126,361-370) and reads `.dense()`.
+Rulebooks bit-exact against the C oracle at the full micro-scene count; conv forward / dgrad bit-exact and wgrad within
+the fp32 tolerance on the configured 128-channel layers; the SparseSequential of post_act_blocks end to end."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+GRID = (2, 4, 12)
+LAYERS = [((3, 3, 3), (1, 1, 2), (1, 1, 1)), ((3, 3, 3), (1, 2, 2), (1, 1, 1)), ((2, 2, 3), (2, 2, 3), (0, 0, 0))]
+
+
+def micro_scenes(rng, n_scene, fill):
+    vol = int(np.prod(GRID))
+    keep = rng.random((n_scene, vol)) < fill
+    keep[rng.integers(0, n_scene, n_scene // 50)] = False      # some micro-scenes are empty
+    b, lin = np.nonzero(keep)
+    z, rem = lin // (GRID[1] * GRID[2]), lin % (GRID[1] * GRID[2])
+    return np.stack([b, z, rem // GRID[2], rem % GRID[2]], axis=1).astype(np.int32)
+
+
+def test_rulebooks_at_full_micro_scene_count():
+    from btcdet_amd.spconv import ops
+    rng = np.random.default_rng(0)
+    B = 6912
+    idx = micro_scenes(rng, B, 0.2)
+    assert idx.shape[0] > 100000
+    shape = GRID
+    for k, s, p in LAYERS:
+        o_idx, o_out, o_in, o_sh = orc.rulebook(idx, shape, k, s, p, 1, orc.MODE_CONV)
+        rb = ops.build_rulebook(torch.from_numpy(idx).to(DEV), B, shape, k, s, p, 1, 0, False, False)
+        assert list(rb.out_shape) == list(o_sh)
+        np.testing.assert_array_equal(rb.out_indices.cpu().numpy(), o_idx)
+        np.testing.assert_array_equal(rb.nbr_out.cpu().numpy(), o_out)
+        np.testing.assert_array_equal(rb.nbr_in.cpu().numpy(), o_in)
+        idx, shape = o_idx, tuple(int(v) for v in o_sh)
+    assert shape == (1, 1, 1)
+    assert np.all(np.diff(idx[:, 0]) > 0)                       # one output row per non-empty micro-scene, ascending
+
+
+def test_configured_128_channel_layers_vs_oracle():
+    from btcdet_amd.spconv import ops
+    rng = np.random.default_rng(1)
+    B, C = 640, 128
+    idx = micro_scenes(rng, B, 0.25)
+    shape = GRID
+    for li, (k, s, p) in enumerate(LAYERS):
+        o_idx, o_out, o_in, o_sh = orc.rulebook(idx, shape, k, s, p, 1, orc.MODE_CONV)
+        rb = ops.build_rulebook(torch.from_numpy(idx).to(DEV), B, shape, k, s, p, 1, 0, False, False)
+        feat = rng.standard_normal((idx.shape[0], C)).astype(np.float32)
+        W = (rng.standard_normal(tuple(k) + (C, C)) / np.sqrt(C * 8)).astype(np.float32)
+        dout = rng.standard_normal((o_idx.shape[0], C)).astype(np.float32)
+        f = torch.from_numpy(feat).to(DEV).requires_grad_(True)
+        w = torch.from_numpy(W).to(DEV).requires_grad_(True)
+        out = ops.indice_conv(f, w, None, rb)
+        out.backward(torch.from_numpy(dout).to(DEV))
+        np.testing.assert_array_equal(out.detach().cpu().numpy(), orc.conv_fwd(feat, W, None, o_out))
+        np.testing.assert_array_equal(f.grad.cpu().numpy(), orc.conv_dgrad(dout, W, o_in))
+        ref_dw = orc.conv_wgrad(feat, dout, o_out, W.shape)
+        assert np.abs(w.grad.cpu().numpy() - ref_dw).max() <= 1e-4 * (np.abs(ref_dw).max() + 1e-6), li
+        idx, shape = o_idx, tuple(int(v) for v in o_sh)
+
+
+def test_roi_pyramid_sequential_end_to_end():
+    """the module the reference builds (conv_head.py:122): SparseSequential of three post_act_blocks (SparseConv3d +
+    BatchNorm1d + ReLU), eval-mode BatchNorm, .dense() -> (6912, 128, 1, 1, 1); against the oracle chain"""
+    import btcdet_amd.spconv as spconv
+    from btcdet_amd.backbones_3d import post_act_block
+    from functools import partial
+    rng = np.random.default_rng(2)
+    torch.manual_seed(0)
+    B, chans = 6912, [16, 16, 16, 16]        # full micro-scene count, narrow channels (the oracle is a scalar CPU loop)
+    norm_fn = partial(torch.nn.BatchNorm1d, eps=1e-3, momentum=0.01)
+    seq = spconv.SparseSequential(*[post_act_block(chans[i], chans[i + 1], list(LAYERS[i][0]), norm_fn=norm_fn, stride=list(LAYERS[i][1]),
+                                                   padding=list(LAYERS[i][2]), indice_key='x_combine_spconv%d' % i, conv_type='spconv')
+                                    for i in range(3)]).to(DEV).eval()
+    for m in seq.modules():
+        if isinstance(m, torch.nn.BatchNorm1d):
+            m.running_mean.uniform_(-0.1, 0.1)
+            m.running_var.uniform_(0.5, 1.5)
+    idx = micro_scenes(rng, B, 0.2)
+    feat = rng.standard_normal((idx.shape[0], chans[0])).astype(np.float32)
+    x = spconv.SparseConvTensor(torch.from_numpy(feat).to(DEV), torch.from_numpy(idx).to(DEV), list(GRID), B)
+    with torch.no_grad():
+        dense = seq(x).dense()
+    assert tuple(dense.shape) == (B, chans[-1], 1, 1, 1)
+    cur_idx, cur_feat, shape = idx, feat, GRID
+    for i, (k, s, p) in enumerate(LAYERS):
+        conv, bn = seq[i][0], seq[i][1]
+        o_idx, o_out, _, o_sh = orc.rulebook(cur_idx, shape, k, s, p, 1, orc.MODE_CONV)
+        y = orc.conv_fwd(cur_feat, conv.weight.detach().cpu().numpy(), None, o_out)
+        g, b_ = bn.weight.detach().cpu().numpy(), bn.bias.detach().cpu().numpy()
+        mu, var = bn.running_mean.cpu().numpy(), bn.running_var.cpu().numpy()
+        y = np.maximum((y - mu) / np.sqrt(var + 1e-3) * g + b_, 0).astype(np.float32)
+        cur_idx, cur_feat, shape = o_idx, y, tuple(int(v) for v in o_sh)
+    ref = np.zeros((B, chans[-1]), np.float32)
+    ref[cur_idx[:, 0]] = cur_feat
+    np.testing.assert_allclose(dense.cpu().numpy().reshape(B, -1), ref, rtol=1e-5, atol=1e-5)

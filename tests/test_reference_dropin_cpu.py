@@ -129,3 +129,46 @@ def test_reference_btcnet_builds_on_this_spconv_and_hot_path_state_dict_matches(
     assert hot == mine
     committed = json.load(open(os.path.join(root, "tests", "golden", "ref_state_keys.json")))["keys"]
     assert committed == ref  # the fixture used where the reference is not mounted is current
+
+
+def test_reference_pointnet2_stack_binds_the_stand_in():
+    """the reference's pointnet2_utils.py / pointnet2_modules.py import `pointnet2_stack_cuda`; with
+    btcdet_amd.pointnet2_stack.install_as_pointnet2_stack_cuda() they import this implementation's entry points, and the
+    reference's StackSAModuleMSG has the same parameters as this repository's"""
+    import types
+    from btcdet_amd import pointnet2_stack as p2
+    pkg = "btcdet.ops.pointnet2.pointnet2_stack"
+    root = "/root/reference/btcdet/ops/pointnet2/pointnet2_stack"
+    saved = {k: sys.modules.get(k) for k in list(sys.modules) if k == "btcdet" or k.startswith("btcdet.")}
+    try:
+        parts = pkg.split(".")
+        for i in range(1, len(parts) + 1):
+            name = ".".join(parts[:i])
+            m = types.ModuleType(name)
+            m.__path__ = []
+            sys.modules[name] = m
+        stand_in = p2.install_as_pointnet2_stack_cuda(pkg)
+        mods = {}
+        for fname in ("pointnet2_utils", "pointnet2_modules"):
+            spec = importlib.util.spec_from_file_location(pkg + "." + fname, os.path.join(root, fname + ".py"))
+            mod = importlib.util.module_from_spec(spec)
+            sys.modules[pkg + "." + fname] = mod
+            setattr(sys.modules[pkg], fname, mod)
+            spec.loader.exec_module(mod)
+            mods[fname] = mod
+        assert mods["pointnet2_utils"].pointnet2 is stand_in
+        for name in ("ball_query_wrapper", "shell_query_wrapper", "group_points_wrapper", "group_points_grad_wrapper",
+                     "furthest_point_sampling_wrapper", "three_nn_wrapper", "three_interpolate_wrapper", "three_interpolate_grad_wrapper"):
+            assert callable(getattr(stand_in, name))
+        kw = dict(radii=[0.8, 1.6], nsamples=[16, 16], use_xyz=True, pool_method="max_pool")
+        ref = mods["pointnet2_modules"].StackSAModuleMSG(mlps=[[1, 16, 16], [1, 16, 16]], **kw)
+        mine = p2.StackSAModuleMSG(mlps=[[1, 16, 16], [1, 16, 16]], **kw)
+        _same_state(mine, ref)
+        ref_fp = mods["pointnet2_modules"].StackPointnetFPModule(mlp=[32, 16])
+        _same_state(p2.StackPointnetFPModule(mlp=[32, 16]), ref_fp)
+    finally:
+        for k in [k for k in sys.modules if k == "btcdet" or k.startswith("btcdet.")]:
+            sys.modules.pop(k, None)
+        for k, v in saved.items():
+            if v is not None:
+                sys.modules[k] = v
