@@ -38,14 +38,58 @@ __device__ __forceinline__ bool last_block(int32_t* counter) {
 }
 
 // partial[blk][0][c] = sum_x, partial[blk][1][c] = sum_x^2 over the block's rows
-template <bool BF>
-__global__ __launch_bounds__(BN_T) void bn_stats(const float* __restrict__ x, BnShape S, double* __restrict__ partial,
+// VEC: C % 4 == 0 -- a thread owns 4 adjacent channels and moves one float4 (bf16: 8 bytes) per row: a quarter of the load
+// instructions of the scalar walk for the same bytes (SV = the shape over C / 4 channel groups)
+template <bool BF, bool VEC>
+__global__ __launch_bounds__(BN_T) void bn_stats(const float* __restrict__ x, BnShape S, BnShape SV, double* __restrict__ partial,
                                                  int32_t* __restrict__ counter, float momentum, float eps, int training,
                                                  const float* __restrict__ running_mean_in, float* __restrict__ running_mean,
                                                  float* __restrict__ running_var, long long* __restrict__ num_batches,
                                                  float* __restrict__ mean_out, float* __restrict__ rstd_out) {
-  __shared__ double s_a[BN_T], s_b[BN_T];
+  __shared__ double s_a[BN_T * (VEC ? 4 : 1)], s_b[BN_T * (VEC ? 4 : 1)];
   const int tid = threadIdx.x;
+  if (VEC) {
+    const int CV = S.C >> 2;
+    for (int cv0 = 0; cv0 < CV; cv0 += SV.cpow) {
+      const int cv = cv0 + (tid % SV.cpow), rr = tid / SV.cpow;
+      double a[4] = {0.0, 0.0, 0.0, 0.0}, b[4] = {0.0, 0.0, 0.0, 0.0};
+      if (cv < CV) {
+        const long long stride = (long long)gridDim.x * SV.rpi;
+        long long r = (long long)blockIdx.x * SV.rpi + rr;
+        for (; r + 3 * stride < S.N; r += 4 * stride) {  // 4 independent 16-byte loads in flight
+          const float4 v0 = btc_ld4<BF>(x, r * S.C + cv * 4), v1 = btc_ld4<BF>(x, (r + stride) * S.C + cv * 4),
+                       v2 = btc_ld4<BF>(x, (r + 2 * stride) * S.C + cv * 4), v3 = btc_ld4<BF>(x, (r + 3 * stride) * S.C + cv * 4);
+          const float e0[4] = {v0.x, v0.y, v0.z, v0.w}, e1[4] = {v1.x, v1.y, v1.z, v1.w}, e2[4] = {v2.x, v2.y, v2.z, v2.w},
+                      e3[4] = {v3.x, v3.y, v3.z, v3.w};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            a[j] += (double)e0[j] + (double)e1[j] + (double)e2[j] + (double)e3[j];
+            b[j] += (double)e0[j] * e0[j] + (double)e1[j] * e1[j] + (double)e2[j] * e2[j] + (double)e3[j] * e3[j];
+          }
+        }
+        for (; r < S.N; r += stride) {
+          const float4 v = btc_ld4<BF>(x, r * S.C + cv * 4);
+          const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { a[j] += e[j]; b[j] += (double)e[j] * e[j]; }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { s_a[tid * 4 + j] = a[j]; s_b[tid * 4 + j] = b[j]; }
+      __syncthreads();
+      if (rr == 0 && cv < CV) {
+        for (int q = 1; q < SV.rpi; ++q)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { a[j] += s_a[(tid + q * SV.cpow) * 4 + j]; b[j] += s_b[(tid + q * SV.cpow) * 4 + j]; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          partial[((size_t)blockIdx.x * 2 + 0) * S.C + cv * 4 + j] = a[j];
+          partial[((size_t)blockIdx.x * 2 + 1) * S.C + cv * 4 + j] = b[j];
+        }
+      }
+      __syncthreads();
+    }
+  } else
   for (int c0 = 0; c0 < S.C; c0 += S.cpow) {
     const int c = c0 + (tid % S.cpow), rr = tid / S.cpow;
     double a = 0.0, b = 0.0;
@@ -159,13 +203,68 @@ __global__ __launch_bounds__(BN_T) void bn_apply(const float* __restrict__ x, co
 }
 
 // partial sums of g = dy * (y > 0) and g * xhat; the last block turns them into dbeta / dgamma
-template <bool BF>
+template <bool BF, bool VEC>
 __global__ __launch_bounds__(BN_T) void bn_bwd_stats(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ dy,
-                                                     const float* __restrict__ mean, const float* __restrict__ rstd, BnShape S, int relu,
+                                                     const float* __restrict__ mean, const float* __restrict__ rstd, BnShape S, BnShape SV, int relu,
                                                      double* __restrict__ partial, int32_t* __restrict__ counter,
                                                      float* __restrict__ dgamma, float* __restrict__ dbeta) {
-  __shared__ double s_a[BN_T], s_b[BN_T];
+  __shared__ double s_a[BN_T * (VEC ? 4 : 1)], s_b[BN_T * (VEC ? 4 : 1)];
   const int tid = threadIdx.x;
+  if (VEC) {
+    const int CV = S.C >> 2;
+    for (int cv0 = 0; cv0 < CV; cv0 += SV.cpow) {
+      const int cv = cv0 + (tid % SV.cpow), rr = tid / SV.cpow;
+      double a[4] = {0.0, 0.0, 0.0, 0.0}, b[4] = {0.0, 0.0, 0.0, 0.0};
+      if (cv < CV) {
+        float m[4], rs[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { m[j] = mean[cv * 4 + j]; rs[j] = rstd[cv * 4 + j]; }
+        const long long stride = (long long)gridDim.x * SV.rpi;
+        long long r = (long long)blockIdx.x * SV.rpi + rr;
+        for (; r + stride < S.N; r += 2 * stride) {  // 6 independent 16-byte loads in flight
+          const long long i0 = r * S.C + cv * 4, i1 = (r + stride) * S.C + cv * 4;
+          const float4 g0 = btc_ld4<BF>(dy, i0), y0 = btc_ld4<BF>(y, i0), x0 = btc_ld4<BF>(x, i0);
+          const float4 g1 = btc_ld4<BF>(dy, i1), y1 = btc_ld4<BF>(y, i1), x1 = btc_ld4<BF>(x, i1);
+          const float gg[2][4] = {{g0.x, g0.y, g0.z, g0.w}, {g1.x, g1.y, g1.z, g1.w}};
+          const float yy[2][4] = {{y0.x, y0.y, y0.z, y0.w}, {y1.x, y1.y, y1.z, y1.w}};
+          const float xx[2][4] = {{x0.x, x0.y, x0.z, x0.w}, {x1.x, x1.y, x1.z, x1.w}};
+#pragma unroll
+          for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const float g = (relu && !(yy[u][j] > 0.f)) ? 0.f : gg[u][j];
+              a[j] += (double)g;
+              b[j] += (double)g * ((xx[u][j] - m[j]) * rs[j]);
+            }
+        }
+        for (; r < S.N; r += stride) {
+          const long long i0 = r * S.C + cv * 4;
+          const float4 g0 = btc_ld4<BF>(dy, i0), y0 = btc_ld4<BF>(y, i0), x0 = btc_ld4<BF>(x, i0);
+          const float gg[4] = {g0.x, g0.y, g0.z, g0.w}, yy[4] = {y0.x, y0.y, y0.z, y0.w}, xx[4] = {x0.x, x0.y, x0.z, x0.w};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float g = (relu && !(yy[j] > 0.f)) ? 0.f : gg[j];
+            a[j] += (double)g;
+            b[j] += (double)g * ((xx[j] - m[j]) * rs[j]);
+          }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { s_a[tid * 4 + j] = a[j]; s_b[tid * 4 + j] = b[j]; }
+      __syncthreads();
+      if (rr == 0 && cv < CV) {
+        for (int q = 1; q < SV.rpi; ++q)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { a[j] += s_a[(tid + q * SV.cpow) * 4 + j]; b[j] += s_b[(tid + q * SV.cpow) * 4 + j]; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          partial[((size_t)blockIdx.x * 2 + 0) * S.C + cv * 4 + j] = a[j];
+          partial[((size_t)blockIdx.x * 2 + 1) * S.C + cv * 4 + j] = b[j];
+        }
+      }
+      __syncthreads();
+    }
+  } else
   for (int c0 = 0; c0 < S.C; c0 += S.cpow) {
     const int c = c0 + (tid % S.cpow), rr = tid / S.cpow;
     double a = 0.0, b = 0.0;
@@ -368,8 +467,16 @@ static int bn_fwd_impl(const float* x, int N, int C, const float* gamma, const f
   double* partial = (double*)((char*)ws + 256);
   BnShape S = bn_shape(N, C);
   if (training) {
-    bn_stats<BF><<<bn_grid(N, S), BN_T, 0, stream>>>(x, S, partial, counter, momentum, eps, training, running_mean, running_mean, running_var,
-                                                num_batches_tracked, save_mean, save_rstd);
+    if ((C & 3) == 0) {
+      const BnShape SV = bn_shape(N, C >> 2);
+      int g = btc_cdiv(N, SV.rpi * 16);  // >= 16 rows per thread-row before another workgroup is added
+      g = g > 256 ? 256 : (g < 1 ? 1 : g);
+      bn_stats<BF, true><<<g, BN_T, 0, stream>>>(x, S, SV, partial, counter, momentum, eps, training, running_mean, running_mean, running_var,
+                                                 num_batches_tracked, save_mean, save_rstd);
+    } else {
+      bn_stats<BF, false><<<bn_grid(N, S), BN_T, 0, stream>>>(x, S, S, partial, counter, momentum, eps, training, running_mean, running_mean,
+                                                          running_var, num_batches_tracked, save_mean, save_rstd);
+    }
   } else {
     bn_eval_stats<<<btc_cdiv(C, BN_T), BN_T, 0, stream>>>(running_mean, running_var, C, eps, save_mean, save_rstd);
   }
@@ -391,7 +498,14 @@ static int bn_bwd_impl(const float* x, const float* y, const float* dy, int N, i
   int32_t* counter = (int32_t*)ws;
   double* partial = (double*)((char*)ws + 256);
   BnShape S = bn_shape(N, C);
-  bn_bwd_stats<BF><<<bn_grid_bwd(N, S), BN_T, 0, stream>>>(x, y, dy, save_mean, save_rstd, S, relu, partial, counter, dgamma, dbeta);
+  if ((C & 3) == 0) {
+    const BnShape SV = bn_shape(N, C >> 2);
+    int g = btc_cdiv(N, SV.rpi * 4);
+    g = g > 512 ? 512 : (g < 1 ? 1 : g);
+    bn_bwd_stats<BF, true><<<g, BN_T, 0, stream>>>(x, y, dy, save_mean, save_rstd, S, SV, relu, partial, counter, dgamma, dbeta);
+  } else {
+    bn_bwd_stats<BF, false><<<bn_grid_bwd(N, S), BN_T, 0, stream>>>(x, y, dy, save_mean, save_rstd, S, S, relu, partial, counter, dgamma, dbeta);
+  }
   BTC_LAUNCH_CHECK();
   long long total = (long long)N * C;
   if ((C & 3) == 0)
