@@ -30,11 +30,11 @@ FP32_MFMA_PEAK_TF = 157.3   # same guide: fp32-input MFMA peak
 
 
 def pmc_traffic_per_launch():
-    """HBM bytes per conv_apply launch from the committed PMC passes (profiles/r01i_pmc_conv.json: rocprofv3 --pmc FETCH_SIZE and
+    """HBM bytes per conv_apply launch from the committed PMC passes (profiles/r01t_pmc_conv.json: rocprofv3 --pmc FETCH_SIZE and
     --pmc WRITE_SIZE in separate runs, FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md); PMC counters cannot be read
     inside the timed process, so this is null when the file is absent"""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01i_pmc_conv.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r01t_pmc_conv.json")) as f:
             return json.load(f)["conv_apply"]["hbm_bytes_per_launch"]
     except (OSError, KeyError, ValueError):
         return None
@@ -127,21 +127,34 @@ class MeanSquare(torch.autograd.Function):
         return (x * (g * (2.0 * ctx.k)).to(x.dtype)), None
 
 
-def make_step(model, ddp, proc, opts, grad_sync=None, prefetch_stream=None, threaded=True):
-    """one training step of the hot path.  With prefetch_stream, the weight-independent front of the NEXT batch (voxelizations,
-    occupancy targets, the occupancy branch's rulebooks: BtcHotPath.prepare) runs on that stream beside this batch's backward
-    pass -- the role DataLoader workers play for the reference's CPU voxelizer: from a worker thread while the main thread
-    sits in loss.backward() (threaded), or from this thread once the backward pass is enqueued.  Every step still does
-    exactly one batch's worth of that work."""
+def make_step(model, ddp, proc, opts, grad_sync=None, prefetch_stream=None, threaded=True, det_stream=None):
+    """one training step of the hot path.
+
+    prefetch_stream: the weight-independent front of the NEXT batch (voxelizations, occupancy targets, the occupancy branch's
+    rulebooks: BtcHotPath.prepare) runs on that stream beside this batch's backward pass -- the role DataLoader workers play
+    for the reference's CPU voxelizer: from a worker thread while the main thread sits in backward (threaded), or from this
+    thread once the backward pass is enqueued.  Every step still does exactly one batch's worth of that work.
+
+    det_stream (not under DistributedDataParallel, which wants one backward per forward): the detection branch is detached
+    from the occupancy branch (PASS_GRAD False), so the occupancy branch's BACKWARD does not have to wait for the detection
+    branch's FORWARD.  The worker thread calls loss_occ.backward() (autograd runs those nodes on the main stream, where
+    their forward ran) while this thread runs the detection branch on det_stream; both are chains of small launches that do
+    not fill the GPU alone.  The detection branch's backward follows on det_stream, and the main stream joins it before the
+    optimizer."""
     pending = {}
     pool = None
-    if prefetch_stream is not None and threaded:
+    if (prefetch_stream is not None and threaded) or det_stream is not None:
         from concurrent.futures import ThreadPoolExecutor
         pool = ThreadPoolExecutor(max_workers=1)
+    device = next(model.parameters()).device
 
     def prep(next_batch):
-        torch.cuda.set_device(prefetch_stream.device)
+        torch.cuda.set_device(device)
         return model.prepare(next_batch, stream=prefetch_stream)
+
+    def occ_backward(loss):
+        torch.cuda.set_device(device)
+        loss.backward()
 
     def step(batch, next_batch=None):
         for o in opts:
@@ -150,19 +163,36 @@ def make_step(model, ddp, proc, opts, grad_sync=None, prefetch_stream=None, thre
         if bd is None:
             bd = model.prepare(batch)
         pending.clear()
-        ret, tb, _ = ddp(bd)
-        # occupancy loss (real) + L2 stand-ins for the out-of-scope consumers of the detection branch
-        loss = ret["loss_occ"] + MeanSquare.apply(ret["spatial_features"], 1e-3) + MeanSquare.apply(ret["x_combine"], 1e-3)
         ahead = prefetch_stream is not None and next_batch is not None
-        fut = pool.submit(prep, next_batch) if (ahead and pool is not None) else None
-        loss.backward()
+        if det_stream is not None and ddp is model:
+            main = torch.cuda.current_stream()
+            bd, loss_occ, tb, inputs_ready = model.forward_occ(bd)
+            fut_occ = pool.submit(occ_backward, loss_occ)
+            with torch.cuda.stream(det_stream):
+                ret, bd = model.forward_det(bd, inputs_ready)
+                # L2 stand-ins for the out-of-scope consumers of the detection branch
+                loss_det = MeanSquare.apply(ret["spatial_features"], 1e-3) + MeanSquare.apply(ret["x_combine"], 1e-3)
+            fut_occ.result()
+            if grad_sync is not None:
+                grad_sync.launch_ready()  # the occupancy bucket travels during the detection branch's backward
+            fut = pool.submit(prep, next_batch) if (ahead and threaded) else None
+            with torch.cuda.stream(det_stream):
+                loss_det.backward()
+            main.wait_stream(det_stream)
+            loss = loss_occ.detach() + loss_det.detach()
+        else:
+            ret, tb, _ = ddp(bd)
+            # occupancy loss (real) + L2 stand-ins for the out-of-scope consumers of the detection branch
+            loss = ret["loss_occ"] + MeanSquare.apply(ret["spatial_features"], 1e-3) + MeanSquare.apply(ret["x_combine"], 1e-3)
+            fut = pool.submit(prep, next_batch) if (ahead and threaded) else None
+            loss.backward()
         if fut is not None:
             pending[id(next_batch)] = fut.result()
         if grad_sync is not None:
-            grad_sync.finish()  # all-reduced mean gradients in param.grad (the detection bucket has been travelling since mid-backward)
+            grad_sync.finish()  # all-reduced mean gradients in param.grad
         for o in opts:
             o.step()
-        if ahead and pool is None:
+        if ahead and not threaded:
             pending[id(next_batch)] = model.prepare(next_batch, stream=prefetch_stream)
         model.mark_step_end()
         return loss
@@ -343,7 +373,10 @@ def main():
     batches = build_batches(4, rank, device, bs, args.workload)
     # the next batch's weight-independent front runs on a high-priority side stream beside this batch's backward
     prefetch = torch.cuda.Stream(device=device, priority=-1) if os.environ.get("BTC_PREFETCH", "2") != "0" else None
-    step = make_step(model, ddp, model.dataset.data_processor, opts, grad_sync, prefetch, threaded=os.environ.get("BTC_PREFETCH", "2") == "2")
+    # the detection branch on its own stream, beside the occupancy branch's backward (make_step)
+    det_stream = torch.cuda.Stream(device=device) if (ddp is model and os.environ.get("BTC_SPLIT_BACKWARD", "0") == "1") else None
+    step = make_step(model, ddp, model.dataset.data_processor, opts, grad_sync, prefetch, threaded=os.environ.get("BTC_PREFETCH", "2") == "2",
+                     det_stream=det_stream)
     nb = len(batches)
 
     def sync():
@@ -369,8 +402,10 @@ def main():
         ops.PROFILE = prof
         prof_steps = min(args.steps, 8)
     if not args.no_roofline:
+        # one stream, one thread: the event pairs time kernels that run alone
+        plain_step = make_step(model, ddp, model.dataset.data_processor, opts, grad_sync)
         for i in range(min(args.steps, 8)):
-            step(batches[i % len(batches)])
+            plain_step(batches[i % len(batches)])
         sync()
     ops.PROFILE = None
     dt = max_over_ranks(dt, dist, device)

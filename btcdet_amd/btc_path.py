@@ -156,8 +156,11 @@ class BtcHotPath(nn.Module):
                     ev.record(torch.cuda.current_stream())
                 g["ended"] = ev
 
-    def forward(self, batch_dict):
-        """BtcNet.forward up to the BEV map (btcnet.py:32-56) + the occupancy loss (btcnet.py:91-101)"""
+    def forward_occ(self, batch_dict):
+        """the occupancy branch of BtcNet.forward (btcnet.py:32-44) and its loss (btcnet.py:91-101):
+        -> (batch_dict, occ_loss, tb_dict, event recorded when the detection branch's inputs are complete).  The detection
+        branch is detached from this one (PASS_GRAD False), so a training loop may run loss.backward() of this branch
+        while forward_det() runs on another stream (bench.make_step)."""
         ready = batch_dict.pop("__ready_event__", None)
         if ready is not None:
             torch.cuda.current_stream().wait_event(ready)
@@ -175,9 +178,31 @@ class BtcHotPath(nn.Module):
             head.premerge()  # the merged head weight is built before the backbone runs, so its CatBackward runs after it
         for mod in self.occ_module_list[n_done:]:
             batch_dict = mod(batch_dict)
+        det_inputs_ready = None
+        if torch.cuda.is_available() and batch_dict["voxels"].is_cuda:
+            det_inputs_ready = torch.cuda.Event()
+            det_inputs_ready.record()
+        occ_loss, tb_dict = head.get_loss(batch_dict)
+        return batch_dict, occ_loss, tb_dict, det_inputs_ready
+
+    def forward_det(self, batch_dict, inputs_ready=None):
+        """the detection branch up to the BEV map (btcnet.py:46-56) on the CURRENT stream; inputs_ready: the event of
+        forward_occ when that ran on another stream (the tensors it produced are then also registered with this stream)"""
+        if inputs_ready is not None:
+            cur = torch.cuda.current_stream()
+            cur.wait_event(inputs_ready)
+            for v in batch_dict.values():
+                if torch.is_tensor(v) and v.is_cuda:
+                    v.record_stream(cur)
         for mod in self.det_module_list:
             batch_dict = mod(batch_dict)
-        occ_loss, tb_dict = self.occ_modules.occ_dense_head.get_loss(batch_dict)
         # the two tensors the out-of-scope heads consume: the BEV map (BaseBEVBackbone) and x_combine (ConvHead)
-        return {"loss_occ": occ_loss, "spatial_features": batch_dict["spatial_features"],
-                "x_combine": batch_dict["multi_scale_3d_features"]["x_combine"].features}, tb_dict, batch_dict
+        return {"spatial_features": batch_dict["spatial_features"],
+                "x_combine": batch_dict["multi_scale_3d_features"]["x_combine"].features}, batch_dict
+
+    def forward(self, batch_dict):
+        """BtcNet.forward up to the BEV map (btcnet.py:32-56) + the occupancy loss (btcnet.py:91-101)"""
+        batch_dict, occ_loss, tb_dict, _ = self.forward_occ(batch_dict)
+        out, batch_dict = self.forward_det(batch_dict)
+        out["loss_occ"] = occ_loss
+        return out, tb_dict, batch_dict

@@ -69,6 +69,12 @@ class BucketedGradSync(object):
         else:
             b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
+    def launch_ready(self):
+        """launch every bucket whose gradients are all present (a training loop that runs the branches' backward passes one
+        after the other calls this in between)"""
+        for b in self.buckets:
+            self._launch(b, early=True)
+
     def finish(self):
         """call after backward, before the optimizer step"""
         for b in self.buckets:

@@ -9,9 +9,11 @@ _WS = {}
 
 
 def _ws(device, C):
-    """persistent per-device workspace; its head (arrival counter) starts zeroed and every call leaves it zeroed"""
+    """persistent workspace per (device, current stream): its head (arrival counter) starts zeroed and every call leaves it
+    zeroed; calls on one stream are serialised, calls on different streams (the occupancy branch's backward beside the
+    detection branch's forward, bench.make_step) must not share the partial sums"""
     need = lib().btc_bn_ws_bytes(int(C))
-    key = (device.type, device.index)
+    key = (device.index, stream_ptr()) if device.type == "cuda" else (device.type, device.index)
     buf = _WS.get(key)
     if buf is None or buf.numel() < need:
         buf = torch.zeros(int(lib().btc_bn_ws_bytes(max(int(C), 1024))), dtype=torch.uint8, device=device)

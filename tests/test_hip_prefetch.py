@@ -101,3 +101,49 @@ def test_forward_geometry_builds_the_rulebooks_forward_uses():
     x = bd["encoded_spconv_tensor"]
     assert x.indice_dict is geom
     assert set(geom.keys()) | set(geom["__geometry_cache__"].keys()) == keys_before
+
+
+def _run_bench_step(mode, steps, defer):
+    """bench.make_step itself (no optimizer: gradients are compared, not Adam-normalised updates)"""
+    import bench
+    from btcdet_amd.btc_path import BtcHotPath
+    from btcdet_amd.config import load_cfg
+    from btcdet_amd.spconv import ops
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    model = BtcHotPath(load_cfg(), device=dev).to(dev).train()
+    ops.set_defer_wgrad_join(defer)
+    try:
+        batches = bench.build_batches(3, 0, dev)
+        params = [p for p in model.parameters() if p.requires_grad]
+        side = torch.cuda.Stream(priority=-1) if mode != "plain" else None
+        det = torch.cuda.Stream() if mode == "split" else None
+        step = bench.make_step(model, model, model.dataset.data_processor, [], None, side, threaded=True, det_stream=det)
+        out = []
+        for it in range(steps):
+            for p in params:
+                p.grad = None
+            loss = step(batches[it % len(batches)], batches[(it + 1) % len(batches)] if side is not None else None)
+            out.append([loss.detach().clone()] + [None if p.grad is None else p.grad.clone() for p in params])
+        torch.cuda.synchronize()
+        return out
+    finally:
+        ops.set_defer_wgrad_join(False)
+
+
+@pytest.mark.parametrize("defer", [False, True])
+def test_bench_step_schedules_agree(defer):
+    """plain step == step with the next batch prepared from the worker thread == that plus the occupancy branch's backward
+    beside the detection branch's forward on a second stream (bench.make_step det_stream)"""
+    steps = 7
+    ref = _run_bench_step("plain", steps, defer)
+    for mode in ("prefetch", "split"):
+        got = _run_bench_step(mode, steps, defer)
+        n = 0
+        for it in range(steps):
+            for a, b in zip(ref[it], got[it]):
+                assert (a is None) == (b is None)
+                if a is not None:
+                    assert float((a - b).abs().max()) <= 1e-5 * float(a.abs().max()) + 1e-30, (mode, it)
+                    n += 1
+        assert n > 50 * steps
