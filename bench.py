@@ -90,6 +90,11 @@ class LeanFusedAdam(object):
                                     steps=[torch.zeros((), dtype=torch.float32, device=p.device) for p in params]))
         self.betas, self.eps = betas, eps
 
+    def read_grads_from(self, view_of):
+        """take the gradients from fixed buffers (a gradient reducer's flat buckets) instead of param.grad"""
+        for g in self.groups:
+            g["grad_views"] = [view_of(p) for p in g["params"]]
+
     def zero_grad(self, set_to_none=True):
         for g in self.groups:
             for p in g["params"]:
@@ -98,7 +103,7 @@ class LeanFusedAdam(object):
     @torch.no_grad()
     def step(self):
         for g in self.groups:
-            params, grads = g["params"], [p.grad for p in g["params"]]
+            params, grads = g["params"], (g["grad_views"] if "grad_views" in g else [p.grad for p in g["params"]])
             if any(gr is None for gr in grads):
                 keep = [i for i, gr in enumerate(grads) if gr is not None]
                 params, grads = [params[i] for i in keep], [grads[i] for i in keep]
@@ -356,7 +361,13 @@ def main():
         for b in model.buffers():
             dist.broadcast(b.data, src=0)
         head_param = next(p for p in model.occ_modules.occ_dense_head.parameters() if p.requires_grad)
-        grad_sync = BucketedGradSync([(det_params, head_param), (occ_params, None)])
+        mode = os.environ.get("BTC_SYNC_BUCKETS", "one")
+        if mode == "early":   # detection bucket launched from a hook in mid-backward (comm hidden, hook's Python in the engine thread)
+            grad_sync = BucketedGradSync([(det_params, head_param), (occ_params, None)])
+        elif mode == "two":
+            grad_sync = BucketedGradSync([(det_params, None), (occ_params, None)])
+        else:                 # one flat bucket sent after backward: the least host work; ~10 MB of all-reduce exposed
+            grad_sync = BucketedGradSync([(det_params + occ_params, None)], assign_grads=os.environ.get("BTC_BENCH_OPTIM", "lean") == "torch")
     # adam_onecycle groups of the reference (optimization/__init__.py:36-40; LR is scheduled, yaml:331-372)
     # fused=True: one multi-tensor launch per optimizer instead of ~10 foreach launches with 60 us host gaps between them
     # the reference's two optimizers (occ / det) as the two parameter groups of one fused Adam: same update rule per
@@ -369,6 +380,8 @@ def main():
         opts = [torch.optim.Adam(groups, betas=(0.9, 0.99), fused=True)]
     else:
         opts = [LeanFusedAdam(groups, betas=(0.9, 0.99))]
+        if grad_sync is not None and not grad_sync.assign_grads:
+            opts[0].read_grads_from(grad_sync.view_of)
     bs = 2
     batches = build_batches(4, rank, device, bs, args.workload)
     # the next batch's weight-independent front runs on a high-priority side stream beside this batch's backward
@@ -409,6 +422,10 @@ def main():
         sync()
     ops.PROFILE = None
     dt = max_over_ranks(dt, dist, device)
+    if grad_sync is not None and os.environ.get("BTC_SYNC_TIMING") == "1" and rank == 0:
+        from btcdet_amd import grad_sync as _gs
+        n = max(_gs._TIMING.get("n", 1), 1)
+        print("grad_sync host ms per step:", {k: round(v / n * 1e3, 3) for k, v in _gs._TIMING.items() if k != "n"}, file=sys.stderr)
 
     result = None
     if rank == 0:

@@ -20,6 +20,10 @@ import torch
 import torch.distributed as dist
 
 
+import os
+_TIMING = {} if os.environ.get("BTC_SYNC_TIMING") == "1" else None  # host seconds spent in _launch / finish (tools)
+
+
 class _Bucket(object):
     def __init__(self, params, trigger):
         self.params = [p for p in params if p.requires_grad]
@@ -36,11 +40,16 @@ class _Bucket(object):
 
 
 class BucketedGradSync(object):
-    def __init__(self, buckets, process_group=None):
-        """buckets: list of (parameters, trigger parameter or None); the trigger is the parameter whose gradient arrives last"""
+    def __init__(self, buckets, process_group=None, assign_grads=True):
+        """buckets: list of (parameters, trigger parameter or None); the trigger is the parameter whose gradient arrives last.
+        assign_grads=False: finish() leaves param.grad alone -- the optimizer reads the reduced gradients from view_of(param)
+        (saves one attribute store per parameter and step)"""
+        self.assign_grads = assign_grads
         self.group = process_group
         self.world = dist.get_world_size(process_group)
         self.stage_on_host = dist.get_backend(process_group) == "gloo"  # gloo's device path is very slow: reduce a host copy (as DDP does)
+        # RCCL averages in the collective (ncclAvg); elsewhere sum, then one scaling launch per bucket in finish()
+        self.reduce_op = dist.ReduceOp.AVG if dist.get_backend(process_group) == "nccl" else dist.ReduceOp.SUM
         self.buckets = [_Bucket(list(params), trig) for params, trig in buckets]
         self._handles = []
         for b in self.buckets:
@@ -50,6 +59,17 @@ class BucketedGradSync(object):
     def _launch(self, b, early=True):
         if b.launched or not b.params:
             return
+        if _TIMING is not None:
+            import time
+            t0 = time.perf_counter()
+            try:
+                return self._launch_impl(b, early)
+            finally:
+                _TIMING["launch"] = _TIMING.get("launch", 0.0) + time.perf_counter() - t0
+
+        return self._launch_impl(b, early)
+
+    def _launch_impl(self, b, early=True):
         grads = [p.grad for p in b.params]
         if early and any(g is None for g in grads):
             return  # not complete yet: finish() will send it
@@ -67,7 +87,7 @@ class BucketedGradSync(object):
             dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
             b.flat.copy_(host)
         else:
-            b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            b.work = dist.all_reduce(b.flat, op=self.reduce_op, group=self.group, async_op=True)
 
     def launch_ready(self):
         """launch every bucket whose gradients are all present (a training loop that runs the branches' backward passes one
@@ -77,6 +97,17 @@ class BucketedGradSync(object):
 
     def finish(self):
         """call after backward, before the optimizer step"""
+        if _TIMING is not None:
+            import time
+            t0 = time.perf_counter()
+            try:
+                return self._finish_impl()
+            finally:
+                _TIMING["finish"] = _TIMING.get("finish", 0.0) + time.perf_counter() - t0
+                _TIMING["n"] = _TIMING.get("n", 0) + 1
+        return self._finish_impl()
+
+    def _finish_impl(self):
         for b in self.buckets:
             self._launch(b, early=False)
         for b in self.buckets:
@@ -84,10 +115,19 @@ class BucketedGradSync(object):
                 b.work.wait()
                 b.work = None
             if b.params:
-                b.flat.mul_(1.0 / self.world)
-                for p, v in zip(b.params, b.views):
-                    p.grad = v
+                if self.reduce_op != dist.ReduceOp.AVG or self.stage_on_host:
+                    b.flat.mul_(1.0 / self.world)
+                if self.assign_grads:
+                    for p, v in zip(b.params, b.views):
+                        p.grad = v
             b.launched = False
+
+    def view_of(self, param):
+        """the slice of a flat bucket that holds `param`'s reduced gradient after finish()"""
+        m = self.__dict__.get("_view_map")
+        if m is None:
+            m = self._view_map = {id(p): v for b in self.buckets for p, v in zip(b.params, b.views)}
+        return m[id(param)]
 
     def remove(self):
         for h in self._handles:
