@@ -408,6 +408,27 @@ Tensor conv_bn_relu(const Tensor& features, const Tensor& weight, const OptTenso
                                overlap, allow_defer);
 }
 
+// a SparseSequential of conv -> BatchNorm -> ReLU layers whose rulebooks all exist already (the occupancy branch after
+// BtcHotPath.prepare): the same autograd nodes as one conv_bn_relu call per layer, entered from Python ONCE -- the per-layer
+// Python (module call, SparseConvolution.forward, argument marshalling: ~60 us a layer) is what bounds the forward pass
+Tensor conv_bn_relu_chain(const Tensor& features, const std::vector<Tensor>& weights, const std::vector<OptTensor>& biases,
+                          const std::vector<Tensor>& map_fwd, const std::vector<Tensor>& map_bwd, const std::vector<OptTensor>& gammas,
+                          const std::vector<OptTensor>& betas, const std::vector<OptTensor>& rms, const std::vector<OptTensor>& rvs,
+                          const std::vector<OptTensor>& nbts, const std::vector<bool>& use_batch, const std::vector<double>& momenta,
+                          const std::vector<double>& epss, const std::vector<bool>& relus, const Tensor& ws, const std::vector<int64_t>& ws_bytes,
+                          const std::vector<bool>& overlaps, const std::vector<bool>& allow_defers) {
+  const size_t L = weights.size();
+  need(L >= 1 && biases.size() == L && map_fwd.size() == L && map_bwd.size() == L && gammas.size() == L && betas.size() == L && rms.size() == L &&
+           rvs.size() == L && nbts.size() == L && use_batch.size() == L && momenta.size() == L && epss.size() == L && relus.size() == L &&
+           ws_bytes.size() == L && overlaps.size() == L && allow_defers.size() == L,
+       "conv_bn_relu_chain: per-layer argument lists differ in length");
+  Tensor x = features;
+  for (size_t i = 0; i < L; ++i)
+    x = ConvBNReLUNode::apply(x, weights[i], biases[i], map_fwd[i], map_bwd[i], gammas[i], betas[i], rms[i], rvs[i], nbts[i], use_batch[i],
+                              momenta[i], epss[i], relus[i], ws, ws_bytes[i], overlaps[i], allow_defers[i]);
+  return x;
+}
+
 }  // namespace
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
@@ -418,6 +439,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("bn_bwd", &bn_bwd, py::call_guard<py::gil_scoped_release>());
   m.def("conv_bwd", &conv_bwd, py::call_guard<py::gil_scoped_release>());
   m.def("conv_bn_relu", &conv_bn_relu, py::call_guard<py::gil_scoped_release>());
+  m.def("conv_bn_relu_chain", &conv_bn_relu_chain, py::call_guard<py::gil_scoped_release>());
   m.def("join_wgrad", &join_wgrad, py::call_guard<py::gil_scoped_release>());
   m.def("set_defer_wgrad_join", &set_defer_wgrad_join);
   m.def("rulebook_subm", &rulebook_subm, py::call_guard<py::gil_scoped_release>());

@@ -13,6 +13,7 @@ import torch as _torch
 
 nn_float32 = _torch.float32
 FUSE_CONV_BN = True  # hand the BatchNorm (+ReLU) that follows a sparse conv to the conv's autograd node
+CHAIN_LAYERS = True  # a container of conv -> BN -> ReLU layers with ready rulebooks runs as ONE compiled call (_chain_plan)
 FUSE_BN_RELU = True  # set False to run BatchNorm1d / ReLU through torch (used by the parity test)
 
 
@@ -76,9 +77,82 @@ class SparseSequential(SparseModule):
                 input = module.forward_geometry(input)
         return input
 
-    def forward(self, input):
-        from . import fused_bn
+    def _flat_modules(self):
+        """the leaf modules in execution order, nested plain SparseSequentials (post_act_blocks inside a stage) expanded"""
+        out = []
+        for m in self._modules.values():
+            if type(m) is SparseSequential:
+                out.extend(m._flat_modules())
+            else:
+                out.append(m)
+        return out
+
+    def _chain_plan(self, input):
+        """[(conv, bn, relu, rulebook, inverse)] when this container is nothing but conv -> BatchNorm1d (-> ReLU) layers whose
+        rulebooks ALL exist already in input.indice_dict (by indice_key or in the geometry cache -- the occupancy branch after
+        BtcHotPath.prepare), else None.  No rulebook is built and no dict is written here."""
+        from . import fused_bn, ops
         from .conv import SparseConvolution
+        f = input.features
+        if not (FUSE_CONV_BN and FUSE_BN_RELU and CHAIN_LAYERS and f is not None and f.is_cuda and f.shape[0] > 0
+                and f.dtype in (nn_float32, _torch.bfloat16)):
+            return None
+        mods = self._flat_modules()
+        plan, i = [], 0
+        indices, shape = input.indices, input.spatial_shape
+        geom = input.indice_dict.get("__geometry_cache__", None)
+        while i < len(mods):
+            conv = mods[i]
+            bn = mods[i + 1] if i + 1 < len(mods) else None
+            if not (isinstance(conv, SparseConvolution) and not conv.conv1x1 and conv.ndim == 3 and bn is not None and fused_bn.fusable(bn)):
+                return None
+            if f.dtype == _torch.bfloat16 and (conv.in_channels % 16 or conv.out_channels % 16):
+                return None
+            relu = i + 2 < len(mods) and type(mods[i + 2]) is nn.ReLU
+            rb = input.indice_dict.get(conv.indice_key, None) if conv.indice_key is not None else None
+            if conv.inverse:
+                if rb is None or rb.n_in == 0:
+                    return None
+                indices, shape = rb.in_indices, rb.in_shape[3 - conv.ndim:]
+            else:
+                if rb is None:
+                    hit = geom.get(conv._gkey(indices, shape), None) if geom is not None else None
+                    rb = hit[0] if hit is not None else None
+                if rb is None or isinstance(rb, ops.PendingRulebook) or rb.n_out == 0:
+                    return None
+                indices, shape = rb.out_indices, conv._out_shape(shape)
+            plan.append((conv, bn, relu, rb, conv.inverse))
+            i += 2 + int(relu)
+        return (plan, indices, shape) if plan else None
+
+    def _run_chain(self, input, plan, indices, shape):
+        from . import fused_bn, ops
+        F = ops.fast()
+        w, b, mf, mb, ga, be, rms, rvs, nbts, ub, mom, eps, relus, need, ov, dfr = ([] for _ in range(16))
+        ws = None
+        for conv, bn, relu, rb, inverse in plan:
+            maps = (rb.nbr_in, rb.nbr_out) if inverse else (rb.nbr_out, rb.nbr_in)
+            training = bn.training or not bn.track_running_stats
+            rm = bn.running_mean if bn.track_running_stats else None
+            ws, nb = fused_bn._ws(input.features.device, conv.weight.shape[-1])
+            w.append(ops._f32c(conv.weight)); b.append(conv.bias); mf.append(maps[0]); mb.append(maps[1])
+            ga.append(bn.weight); be.append(bn.bias); rms.append(rm); rvs.append(bn.running_var if bn.track_running_stats else None)
+            nbts.append(bn.num_batches_tracked if (bn.training and bn.track_running_stats) else None)
+            ub.append(bool(training or rm is None)); mom.append(float(bn.momentum)); eps.append(float(bn.eps)); relus.append(bool(relu))
+            need.append(int(nb)); ov.append(bool(ops._overlap_ok(maps[0].shape[0]))); dfr.append(bool(conv.weight.is_leaf))
+        out = F.conv_bn_relu_chain(ops._actc(input.features), w, b, mf, mb, ga, be, rms, rvs, nbts, ub, mom, eps, relus, ws, need, ov, dfr)
+        out_tensor = SparseConvTensor(out, indices, shape, input.batch_size)
+        out_tensor.indice_dict = input.indice_dict
+        out_tensor.grid = input.grid
+        return out_tensor
+
+    def forward(self, input):
+        from . import fused_bn, ops
+        from .conv import SparseConvolution
+        if isinstance(input, SparseConvTensor) and ops.PROFILE is None and ops.CAPTURE is None and ops.NATIVE_AUTOGRAD and ops.fast() is not None:
+            plan = self._chain_plan(input)
+            if plan is not None:
+                return self._run_chain(input, *plan)
         mods = list(self._modules.values())
         i = 0
         while i < len(mods):

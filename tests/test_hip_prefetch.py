@@ -147,3 +147,27 @@ def test_bench_step_schedules_agree(defer):
                     assert float((a - b).abs().max()) <= 1e-5 * float(a.abs().max()) + 1e-30, (mode, it)
                     n += 1
         assert n > 50 * steps
+
+
+def test_chained_layers_equal_layer_by_layer():
+    """SparseSequential._chain_plan: with the rulebooks prepared, every stage of the occupancy backbone runs as one compiled call
+    (binding.cpp conv_bn_relu_chain); same autograd nodes, so losses and gradients equal the layer-by-layer walk's"""
+    from btcdet_amd.spconv import modules
+    calls = []
+    orig = modules.SparseSequential._run_chain
+    modules.SparseSequential._run_chain = lambda self, inp, plan, idx, shp: (calls.append(len(plan)), orig(self, inp, plan, idx, shp))[1]
+    try:
+        got = _run("same_stream", 4, True)
+    finally:
+        modules.SparseSequential._run_chain = orig
+    assert sum(calls) >= 4 * 12 and max(calls) >= 2     # the 12 conv layers of the occupancy backbone, every step
+    modules.CHAIN_LAYERS = False
+    try:
+        ref = _run("same_stream", 4, True)
+    finally:
+        modules.CHAIN_LAYERS = True
+    for it in range(4):
+        for a, b in zip(ref[it], got[it]):
+            assert (a is None) == (b is None)
+            if a is not None:
+                assert float((a - b).abs().max()) <= 1e-5 * float(a.abs().max()) + 1e-30, it

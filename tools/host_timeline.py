@@ -19,9 +19,13 @@ opt = bench.LeanFusedAdam([{"params": occ, "lr": 3e-3, "weight_decay": 0.001}, {
 ops.set_defer_wgrad_join(os.environ.get("BTC_DEFER_WGRAD", "1") != "0")
 batches = bench.build_batches(2, 0, dev)
 proc = model.dataset.data_processor
-PREFETCH = os.environ.get("BTC_PREFETCH", "1") != "0"
+PREFETCH = os.environ.get("BTC_PREFETCH", "2") != "0"
+THREADED = os.environ.get("BTC_PREFETCH", "2") == "2"
+if THREADED:
+    from concurrent.futures import ThreadPoolExecutor
+    pool = ThreadPoolExecutor(max_workers=1)
 side = torch.cuda.Stream(priority=-1) if PREFETCH else None
-NAMES = ["zero_grad+voxelize" if not PREFETCH else "zero_grad", "occ branch", "det branch", "loss", "backward", "optimizer"] + (["prepare next"] if PREFETCH else [])
+NAMES = ["zero_grad+voxelize" if not PREFETCH else "zero_grad", "occ branch", "det branch", "loss", "backward" + (" (+prepare in a thread)" if THREADED else ""), "optimizer"] + (["prepare next"] if (PREFETCH and not THREADED) else [])
 pending = {}
 
 
@@ -53,14 +57,19 @@ def step(batch, rec, nxt=None):
     loss_occ, tb = head.get_loss(bd)
     loss = loss_occ + bench.MeanSquare.apply(bd["spatial_features"], 1e-3) + bench.MeanSquare.apply(bd["multi_scale_3d_features"]["x_combine"].features, 1e-3)
     mark()
+    fut = pool.submit(model.prepare, nxt, side) if (THREADED and PREFETCH and nxt is not None) else None
     loss.backward()
+    if fut is not None:
+        pending.clear()
+        pending[id(nxt)] = fut.result()
     mark()
     opt.step()
     mark()
-    if PREFETCH and nxt is not None:
+    if PREFETCH and not THREADED and nxt is not None:
         pending.clear()
         pending[id(nxt)] = model.prepare(nxt, stream=side)
         mark()
+    model.mark_step_end()
     if rec is not None:
         rec.append(marks)
 
