@@ -123,6 +123,10 @@ class LazyScalar(object):
     def __format__(self, spec):
         return format(self.item(), spec)
 
+    def __array__(self, dtype=None, copy=None):  # np.asarray([...LazyScalar...]) -> float array, not an object array
+        import numpy as np
+        return np.asarray(self.item(), dtype=dtype)
+
     def __eq__(self, o): return self.item() == float(o)
     def __lt__(self, o): return self.item() < float(o)
     def __le__(self, o): return self.item() <= float(o)
