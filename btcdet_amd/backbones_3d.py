@@ -9,7 +9,6 @@ The graphs are written as layer tables; every sparse layer is one fused HIP laun
 """
 from functools import partial
 
-import numpy as np
 import torch
 import torch.nn as nn
 

@@ -12,7 +12,6 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from . import _lib
 from ._lib import BtcOccBuffers, BtcOccConfig, OCC_BUFFER_FIELDS, check, lib, ptr, stream_ptr, workspace
 
 

@@ -15,7 +15,6 @@ from functools import partial
 import numpy as np
 import torch
 
-from . import _lib
 from ._lib import check, lib, ptr, stream_ptr
 from .spconv.utils import VoxelGeneratorV2
 
