@@ -440,6 +440,10 @@ def main():
                                    "MeanVFE -> VoxelBackBoneDeconv -> OccHead3D+loss -> PassOccVox -> OccVFE -> VoxelBackBone8xOcc -> "
                                    "HeightCompression (+L2 stand-in for the out-of-scope BEV heads), fwd+bwd+Adam (occ / det parameter groups), fp32",
                        "global_batch": bs * world, "parallelism": "dp%d" % world,
+                       "schedule": ("each step prepares the NEXT batch's weight-independent front (both voxelizations, occupancy targets, "
+                                    "occupancy-branch rulebooks) on a side stream beside its backward pass, one preparation per step; "
+                                    "weight gradients on a side stream, one join per backward" if prefetch is not None else "in order, one stream"),
+                       "grad_sync": (None if grad_sync is None else "one flat bucket, ncclAvg all-reduce after backward"),
                        "points_per_batch": [b["n_points"] for b in batches]},
         }
         if prof is not None:
