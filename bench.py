@@ -443,7 +443,8 @@ def main():
                        "schedule": ("each step prepares the NEXT batch's weight-independent front (both voxelizations, occupancy targets, "
                                     "occupancy-branch rulebooks) on a side stream beside its backward pass, one preparation per step; "
                                     "weight gradients on a side stream, one join per backward" if prefetch is not None else "in order, one stream"),
-                       "grad_sync": (None if grad_sync is None else "one flat bucket, ncclAvg all-reduce after backward"),
+                       "grad_sync": ("DistributedDataParallel" if ddp is not model else
+                                     (None if grad_sync is None else "btcdet_amd.grad_sync: flat bucket(s), all-reduce after backward")),
                        "points_per_batch": [b["n_points"] for b in batches]},
         }
         if prof is not None:
