@@ -141,8 +141,27 @@ class VoxelBackBoneDeconv(nn.Module):
         voxel_coords = batch_dict['voxel_coords'].int()
         if not voxel_coords.is_cuda:
             return batch_dict
-        x = spconv.SparseConvTensor(features=None, indices=voxel_coords, spatial_shape=self.sparse_shape, batch_size=batch_dict['batch_size'])
-        for stage in (self.conv1, self.conv2, self.conv3, self.deconv4, self.deconv5):
+        from .spconv import ops as sp_ops
+        stages = (self.conv1, self.conv2, self.conv3, self.deconv4, self.deconv5)
+        bs = batch_dict['batch_size']
+        merged_head = head is not None and hasattr(head, "_merge_ok") and head._merge_ok()
+        if sp_ops.fast() is not None and sp_ops.PROFILE is None and (head is None or merged_head or hasattr(head, "conv_cls")):
+            # one call of the compiled binding for all rulebooks (spconv/geometry.py); the plan is fixed per (model, batch size)
+            from .spconv.geometry import GeometryPlan, flatten_convs
+            plans = self.__dict__.setdefault("_geometry_plans", {})
+            key = (int(bs), id(head))
+            plan = plans.get(key)
+            if plan is None:
+                convs = flatten_convs(*stages)
+                if head is not None:
+                    convs += flatten_convs(head.conv_cls) + (flatten_convs(head.conv_res) if getattr(head, "reg", False) else [])
+                plan = plans[key] = GeometryPlan(convs, self.sparse_shape, bs)
+            indice_dict = {}
+            plan.run(voxel_coords, indice_dict)
+            batch_dict['occ_geometry'] = (voxel_coords, indice_dict)
+            return batch_dict
+        x = spconv.SparseConvTensor(features=None, indices=voxel_coords, spatial_shape=self.sparse_shape, batch_size=bs)
+        for stage in stages:
             x = stage.forward_geometry(x)
         if head is not None and hasattr(head, "forward_geometry"):
             head.forward_geometry(x)

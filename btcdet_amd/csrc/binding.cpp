@@ -408,6 +408,45 @@ Tensor conv_bn_relu(const Tensor& features, const Tensor& weight, const OptTenso
                                overlap, allow_defer);
 }
 
+// every rulebook of a chain of sparse layers from the input coordinates alone (BtcHotPath.prepare runs this in a worker thread
+// beside the backward pass: one call, GIL released, instead of a Python walk over the layers that competes with the autograd
+// thread for the GIL).  kind: 0 = build submanifold, 1 = build strided / transposed, 2 = inverse of layer ref (continue on ITS
+// input level), 3 = reuse layer ref's rulebook (continue on its output level).  Returns per built layer
+// {in_indices, out_indices, nbr_out, nbr_in}, an empty list for the others.
+std::vector<std::vector<Tensor>> geometry_walk(const Tensor& indices, int64_t batch, const std::vector<int64_t>& kind,
+                                               const std::vector<int64_t>& a_in, const std::vector<int64_t>& a_out,
+                                               const std::vector<int64_t>& a_k, const std::vector<int64_t>& a_s,
+                                               const std::vector<int64_t>& a_p, const std::vector<int64_t>& a_d,
+                                               const std::vector<int64_t>& mode, const std::vector<int64_t>& K,
+                                               const std::vector<int64_t>& ws_bytes, const std::vector<int64_t>& ref) {
+  const size_t n = kind.size();
+  need(a_in.size() == n && a_out.size() == n && a_k.size() == n && a_s.size() == n && a_p.size() == n && a_d.size() == n && mode.size() == n &&
+           K.size() == n && ws_bytes.size() == n && ref.size() == n, "geometry_walk: per-layer argument lists differ in length");
+  const int64_t stream = current_stream();
+  std::vector<std::vector<Tensor>> out(n);
+  std::vector<Tensor> level_in(n), level_out(n);
+  Tensor cur = indices;
+  for (size_t i = 0; i < n; ++i) {
+    if (kind[i] == 0) {
+      Tensor nbr = rulebook_subm(cur, batch, a_in[i], a_k[i], a_d[i], K[i], stream);
+      out[i] = {cur, cur, nbr.select(0, 0), nbr.select(0, 1)};
+      level_in[i] = level_out[i] = cur;
+    } else if (kind[i] == 1) {
+      auto t = rulebook_conv(cur, batch, a_in[i], a_out[i], a_k[i], a_s[i], a_p[i], a_d[i], mode[i], K[i], ws_bytes[i], stream);
+      out[i] = {cur, std::get<0>(t), std::get<1>(t), std::get<2>(t)};
+      level_in[i] = cur;
+      cur = std::get<0>(t);
+      level_out[i] = cur;
+    } else {
+      need(ref[i] >= 0 && (size_t)ref[i] < i, "geometry_walk: bad layer reference");
+      cur = kind[i] == 2 ? level_in[ref[i]] : level_out[ref[i]];
+      level_in[i] = kind[i] == 2 ? level_out[ref[i]] : level_in[ref[i]];
+      level_out[i] = cur;
+    }
+  }
+  return out;
+}
+
 // a SparseSequential of conv -> BatchNorm -> ReLU layers whose rulebooks all exist already (the occupancy branch after
 // BtcHotPath.prepare): the same autograd nodes as one conv_bn_relu call per layer, entered from Python ONCE -- the per-layer
 // Python (module call, SparseConvolution.forward, argument marshalling: ~60 us a layer) is what bounds the forward pass
@@ -439,6 +478,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("bn_bwd", &bn_bwd, py::call_guard<py::gil_scoped_release>());
   m.def("conv_bwd", &conv_bwd, py::call_guard<py::gil_scoped_release>());
   m.def("conv_bn_relu", &conv_bn_relu, py::call_guard<py::gil_scoped_release>());
+  m.def("geometry_walk", &geometry_walk, py::call_guard<py::gil_scoped_release>());
   m.def("conv_bn_relu_chain", &conv_bn_relu_chain, py::call_guard<py::gil_scoped_release>());
   m.def("join_wgrad", &join_wgrad, py::call_guard<py::gil_scoped_release>());
   m.def("set_defer_wgrad_join", &set_defer_wgrad_join);
