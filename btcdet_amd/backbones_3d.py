@@ -7,6 +7,7 @@ padding / indice_key tables -- so reference checkpoints load key-for-key):
   * ``VoxelBackBone8xOcc``  spconv_backbone.py:630-1019 (detection branch)
 The graphs are written as layer tables; every sparse layer is one fused HIP launch (sparse_conv.hip).
 """
+import os
 from functools import partial
 
 import torch
@@ -190,6 +191,9 @@ class VoxelBackBoneDeconv(nn.Module):
         return x
 
 
+DET_GEOMETRY_WALK = os.environ.get("BTC_DET_GEOMETRY_WALK", "1") != "0"  # VoxelBackBone8xOcc._walk_geometry
+
+
 class VoxelBackBone8xOcc(nn.Module):
     """Detection-branch 8x backbone that also consumes the occupancy code channels."""
 
@@ -243,6 +247,26 @@ class VoxelBackBone8xOcc(nn.Module):
         if getattr(self, "squeezeBev", None) is not None:
             stages.append(self.squeezeBev)
         self.__dict__['_first_strided'] = _chain_lookahead(stages)
+
+    def _walk_geometry(self, coords, bs, indice_dict):
+        """all rulebooks of the main chain (subm1, spconv2, subm2, ... spconv_down2, subm_down2) in one call of the compiled
+        binding before the first layer runs (spconv/geometry.py): every stage then finds its rulebooks ready and runs as one
+        compiled call (SparseSequential._chain_plan) instead of ~100 us of Python per layer; the side-branch pools and the
+        down2 / down3 / down_combine layers reuse these rulebooks through the geometry cache / their indice_keys as before.
+        False when the compiled binding is not in use (the layers then build their rulebooks one by one, with lookahead)."""
+        from .spconv import ops as sp_ops
+        if not (DET_GEOMETRY_WALK and coords.is_cuda and sp_ops.fast() is not None and sp_ops.PROFILE is None and sp_ops.CAPTURE is None):
+            return False
+        from .spconv.geometry import GeometryPlan, flatten_convs
+        plans = self.__dict__.setdefault("_geometry_plans", {})
+        plan = plans.get(int(bs))
+        if plan is None:
+            stages = [self.conv1, self.conv2, self.conv2_combine, self.conv3, self.conv3_combine, self.conv4, self.conv4_combine, self.conv_out]
+            if getattr(self, "squeezeBev", None) is not None:
+                stages.append(self.squeezeBev)
+            plan = plans[int(bs)] = GeometryPlan(flatten_convs(*stages), self.sparse_shape, bs)
+        plan.run(coords, indice_dict)
+        return True
 
     def _build_occ_net(self, kind, i):
         """occupancy-code side branch at level i (1..3): maxpool / learned / fixed-mean / avg (spconv_backbone.py:793-866)"""
@@ -324,7 +348,8 @@ class VoxelBackBone8xOcc(nn.Module):
             feats = feats.to(self.feature_dtype)
         bs = batch_dict['batch_size']
         x = spconv.SparseConvTensor(features=feats, indices=coords, spatial_shape=self.sparse_shape, batch_size=bs)
-        if self._first_strided is not None:  # conv2's row count runs beside conv1 (rulebook lookahead, spconv/ops.py)
+        if not self._walk_geometry(coords, bs, x.indice_dict) and self._first_strided is not None:
+            # conv2's row count runs beside conv1 (rulebook lookahead, spconv/ops.py)
             self._first_strided.prefetch(coords, self.sparse_shape, bs, x.indice_dict)
         n_occ = len(self.occ_conv_exec)
         x1 = self.conv1(x)
