@@ -89,52 +89,63 @@ def install_as_pointnet2_stack_cuda(package="btcdet.ops.pointnet2.pointnet2_stac
     return mod
 
 
+def _contig(*tensors):
+    for t in tensors:
+        if not t.is_contiguous():
+            raise AssertionError("pointnet2_stack: contiguous tensors expected")
+
+
 class BallQuery(Function):
-    @staticmethod
-    def forward(ctx, radius, nsample: int, xyz: torch.Tensor, xyz_batch_cnt: torch.Tensor, new_xyz: torch.Tensor, new_xyz_batch_cnt):
-        """idx (M, nsample) int32 LOCAL to each scene (empty balls zeroed), empty_ball_mask (M,) -- pointnet2_utils.py:11-40;
-        radius: float, or [inner, outer] for the shell query"""
-        assert new_xyz.is_contiguous() and new_xyz_batch_cnt.is_contiguous() and xyz.is_contiguous() and xyz_batch_cnt.is_contiguous()
-        B, M = xyz_batch_cnt.shape[0], new_xyz.shape[0]
-        idx = torch.empty((M, nsample), dtype=torch.int32, device=new_xyz.device)  # zeroed by the call
-        if isinstance(radius, (list, tuple)):
-            pointnet2.shell_query_wrapper(B, M, radius[0], radius[1], nsample, new_xyz, new_xyz_batch_cnt, xyz, xyz_batch_cnt, idx)
-        else:
-            pointnet2.ball_query_wrapper(B, M, radius, nsample, new_xyz, new_xyz_batch_cnt, xyz, xyz_batch_cnt, idx)
-        empty_ball_mask = (idx[:, 0] == -1)
-        idx[empty_ball_mask] = 0
-        ctx.mark_non_differentiable(idx, empty_ball_mask)
-        return idx, empty_ball_mask
+    """ball (radius: float) or shell (radius: [inner, outer]) query over stacked scenes -> (idx, empty_ball_mask);
+    idx (M, nsample) int32 is LOCAL to each query's scene, balls without a hit are zeroed and flagged (pointnet2_utils.py:11-40)"""
 
     @staticmethod
-    def backward(ctx, a=None, b=None):
-        return None, None, None, None, None, None
+    def forward(ctx, radius, nsample, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt):
+        _contig(new_xyz, new_xyz_batch_cnt, xyz, xyz_batch_cnt)
+        n_scene, n_query = xyz_batch_cnt.shape[0], new_xyz.shape[0]
+        idx = torch.empty((n_query, nsample), dtype=torch.int32, device=new_xyz.device)  # the C ABI call zero-fills it
+        if isinstance(radius, (list, tuple)):
+            pointnet2.shell_query_wrapper(n_scene, n_query, radius[0], radius[1], nsample, new_xyz, new_xyz_batch_cnt, xyz, xyz_batch_cnt, idx)
+        else:
+            pointnet2.ball_query_wrapper(n_scene, n_query, radius, nsample, new_xyz, new_xyz_batch_cnt, xyz, xyz_batch_cnt, idx)
+        empty = idx[:, 0] == -1
+        idx[empty] = 0
+        ctx.mark_non_differentiable(idx, empty)
+        return idx, empty
+
+    @staticmethod
+    def backward(ctx, *grads):
+        return (None,) * 6
 
 
 ball_query = BallQuery.apply
 
 
 class GroupingOperation(Function):
-    @staticmethod
-    def forward(ctx, features: torch.Tensor, features_batch_cnt: torch.Tensor, idx: torch.Tensor, idx_batch_cnt: torch.Tensor):
-        """features (N1+N2.., C), idx (M1+M2.., nsample) -> (M1+M2.., C, nsample) -- pointnet2_utils.py:52-84"""
-        assert features.is_contiguous() and features_batch_cnt.is_contiguous() and idx.is_contiguous() and idx_batch_cnt.is_contiguous()
-        assert features.shape[0] == features_batch_cnt.sum(), 'features: %s, features_batch_cnt: %s' % (str(features.shape), str(features_batch_cnt))
-        assert idx.shape[0] == idx_batch_cnt.sum(), 'idx: %s, idx_batch_cnt: %s' % (str(idx.shape), str(idx_batch_cnt))
-        M, nsample = idx.size()
-        N, C = features.size()
-        B = idx_batch_cnt.shape[0]
-        output = torch.empty((M, C, nsample), dtype=torch.float32, device=features.device)
-        pointnet2.group_points_wrapper(B, M, C, nsample, features, features_batch_cnt, idx, idx_batch_cnt, output)
-        ctx.for_backwards = (B, N, idx, features_batch_cnt, idx_batch_cnt)
-        return output
+    """features (N1+N2.., C) gathered at idx (M1+M2.., nsample) -> (M1+M2.., C, nsample); the backward scatter-adds
+    (pointnet2_utils.py:52-104)"""
 
     @staticmethod
-    def backward(ctx, grad_out: torch.Tensor):
-        B, N, idx, features_batch_cnt, idx_batch_cnt = ctx.for_backwards
-        M, C, nsample = grad_out.size()
-        grad_features = torch.empty((N, C), dtype=torch.float32, device=grad_out.device)  # zeroed by the call
-        pointnet2.group_points_grad_wrapper(B, M, C, N, nsample, grad_out.contiguous(), idx, idx_batch_cnt, features_batch_cnt, grad_features)
+    def forward(ctx, features, features_batch_cnt, idx, idx_batch_cnt):
+        _contig(features, features_batch_cnt, idx, idx_batch_cnt)
+        if features.shape[0] != int(features_batch_cnt.sum()):
+            raise AssertionError('features: %s, features_batch_cnt: %s' % (str(features.shape), str(features_batch_cnt)))
+        if idx.shape[0] != int(idx_batch_cnt.sum()):
+            raise AssertionError('idx: %s, idx_batch_cnt: %s' % (str(idx.shape), str(idx_batch_cnt)))
+        (n_query, nsample), (n_pts, ch) = idx.shape, features.shape
+        n_scene = idx_batch_cnt.shape[0]
+        grouped = torch.empty((n_query, ch, nsample), dtype=torch.float32, device=features.device)
+        pointnet2.group_points_wrapper(n_scene, n_query, ch, nsample, features, features_batch_cnt, idx, idx_batch_cnt, grouped)
+        ctx.for_backwards = (n_scene, n_pts, idx, features_batch_cnt, idx_batch_cnt)
+        return grouped
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        n_scene, n_pts, idx, features_batch_cnt, idx_batch_cnt = ctx.for_backwards
+        n_query, ch, nsample = grad_out.shape
+        grad_features = torch.empty((n_pts, ch), dtype=torch.float32, device=grad_out.device)  # zero-filled by the call
+        pointnet2.group_points_grad_wrapper(n_scene, n_query, ch, n_pts, nsample, grad_out.contiguous(), idx, idx_batch_cnt, features_batch_cnt,
+                                            grad_features)
         return grad_features, None, None, None
 
 
@@ -142,67 +153,67 @@ grouping_operation = GroupingOperation.apply
 
 
 class QueryAndGroup(nn.Module):
-    """pointnet2_utils.py:111-188, including the reference's rotation / scaling of the grouped offsets and its handling of a
-    trailing empty scene"""
+    """ball query + grouping of the offsets (and features) around every query, with the reference's extras
+    (pointnet2_utils.py:111-188): rotation of the offsets by a per-roi matrix, division by per-roi xy / z scales, zeroed
+    empty balls, and its handling of a trailing scene without points (whose queries get zero groups)"""
 
     def __init__(self, radius, nsample: int, use_xyz: bool = True):
         super().__init__()
         self.radius, self.nsample, self.use_xyz = radius, nsample, use_xyz
 
+    @staticmethod
+    def _group(values, cnt, idx, qcnt, drop_last):
+        if not drop_last:
+            return grouping_operation(values, cnt, idx, qcnt)
+        n_last = int(qcnt[-1])
+        g = grouping_operation(values, cnt[0:-1], idx[:-n_last], qcnt[0:-1])
+        return torch.cat([g, torch.zeros_like(g[:n_last])], dim=0)
+
     def forward(self, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, features=None, rotateMatrix=None, xyscales=None, zscales=None):
         assert xyz.shape[0] == xyz_batch_cnt.sum(), 'xyz: %s, xyz_batch_cnt: %s' % (str(xyz.shape), str(new_xyz_batch_cnt))
         assert new_xyz.shape[0] == new_xyz_batch_cnt.sum(), 'new_xyz: %s, new_xyz_batch_cnt: %s' % (str(new_xyz.shape), str(new_xyz_batch_cnt))
-        idx, empty_ball_mask = ball_query(self.radius, self.nsample, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt)
-        if len(xyz_batch_cnt) > 1 and xyz_batch_cnt[-1] == 0:
-            grouped_xyz = grouping_operation(xyz, xyz_batch_cnt[0:-1], idx[:-new_xyz_batch_cnt[-1]], new_xyz_batch_cnt[0:-1])
-            grouped_xyz = torch.cat([grouped_xyz, torch.zeros_like(grouped_xyz[:new_xyz_batch_cnt[-1]])], dim=0)
-        else:
-            grouped_xyz = grouping_operation(xyz, xyz_batch_cnt, idx, new_xyz_batch_cnt)  # (M1 + M2, 3, nsample)
-        grouped_xyz = grouped_xyz - new_xyz.unsqueeze(-1)
-        grouped_xyz[empty_ball_mask] = 0
-        pre_rot_grouped_xyz = None
+        idx, empty = ball_query(self.radius, self.nsample, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt)
+        several = len(xyz_batch_cnt) > 1
+        offsets = self._group(xyz, xyz_batch_cnt, idx, new_xyz_batch_cnt, several and xyz_batch_cnt[-1] == 0)  # (M, 3, nsample)
+        offsets = offsets - new_xyz.unsqueeze(-1)
+        offsets[empty] = 0
+        unrotated = offsets
         if rotateMatrix is not None:
-            pre_rot_grouped_xyz = grouped_xyz
-            grouped_xyz = self.rotate(grouped_xyz, rotateMatrix)
+            offsets = self.rotate(offsets, rotateMatrix)
         if xyscales is not None:
-            grouped_xyz = torch.cat([grouped_xyz[..., :2, :] / xyscales, grouped_xyz[..., 2:3, :] / zscales], dim=-2)
-        if features is not None:
-            if len(xyz_batch_cnt) > 1 and xyz_batch_cnt[1] == 0:  # (sic) the reference tests index 1 here, -1 above
-                grouped_features = grouping_operation(features, xyz_batch_cnt[0:-1], idx[:-new_xyz_batch_cnt[-1]], new_xyz_batch_cnt[0:-1])
-                grouped_features = torch.cat([grouped_features, torch.zeros_like(grouped_features[:new_xyz_batch_cnt[-1]])], dim=0)
-            else:
-                grouped_features = grouping_operation(features, xyz_batch_cnt, idx, new_xyz_batch_cnt)
-            grouped_features[empty_ball_mask] = 0
-            new_features = torch.cat([grouped_xyz, grouped_features], dim=1) if self.use_xyz else grouped_features
-        else:
+            offsets = torch.cat([offsets[..., :2, :] / xyscales, offsets[..., 2:3, :] / zscales], dim=-2)
+        if features is None:
             assert self.use_xyz, "Cannot have not features and not use xyz as a feature!"
-            new_features = grouped_xyz
-        if rotateMatrix is not None:
-            return new_features, idx, pre_rot_grouped_xyz
-        return new_features, idx
+            out = offsets
+        else:
+            # (sic) the reference tests scene 1 here and the last scene above
+            grouped = self._group(features, xyz_batch_cnt, idx, new_xyz_batch_cnt, several and xyz_batch_cnt[1] == 0)
+            grouped[empty] = 0
+            out = torch.cat([offsets, grouped], dim=1) if self.use_xyz else grouped
+        return (out, idx, unrotated) if rotateMatrix is not None else (out, idx)
 
     def rotate(self, grouped_xyz, rotateMatrix):
-        BN = rotateMatrix.shape[0]
-        BNG = grouped_xyz.shape[0]
-        rotateMatrix = rotateMatrix.view(BN, 1, 3, 3).repeat(1, BNG // BN, 1, 1).view(BNG, 3, 3)
-        rot = torch.einsum("nmj,nij->nmi", grouped_xyz.permute(0, 2, 1), rotateMatrix)
-        return rot.permute(0, 2, 1)
+        n_roi, n_query = rotateMatrix.shape[0], grouped_xyz.shape[0]
+        per_query = rotateMatrix.view(n_roi, 1, 3, 3).repeat(1, n_query // n_roi, 1, 1).view(n_query, 3, 3)
+        return torch.einsum("nmj,nij->nmi", grouped_xyz.permute(0, 2, 1), per_query).permute(0, 2, 1)
 
 
 class FurthestPointSampling(Function):
-    @staticmethod
-    def forward(ctx, xyz: torch.Tensor, npoint: int):
-        """xyz (B, N, 3) -> (B, npoint) int32 -- pointnet2_utils.py:194-213"""
-        assert xyz.is_contiguous()
-        B, N, _ = xyz.size()
-        output = torch.empty((B, npoint), dtype=torch.int32, device=xyz.device)
-        temp = torch.full((B, N), 1e10, dtype=torch.float32, device=xyz.device)
-        pointnet2.furthest_point_sampling_wrapper(B, N, npoint, xyz, temp, output)
-        ctx.mark_non_differentiable(output)
-        return output
+    """xyz (B, N, 3) -> indices (B, npoint) int32 of an iterative farthest-point subset that starts at point 0
+    (pointnet2_utils.py:194-213)"""
 
     @staticmethod
-    def backward(xyz, a=None):
+    def forward(ctx, xyz, npoint):
+        _contig(xyz)
+        n_scene, n_pts = xyz.shape[0], xyz.shape[1]
+        picked = torch.empty((n_scene, npoint), dtype=torch.int32, device=xyz.device)
+        running = torch.full((n_scene, n_pts), 1e10, dtype=torch.float32, device=xyz.device)
+        pointnet2.furthest_point_sampling_wrapper(n_scene, n_pts, npoint, xyz, running, picked)
+        ctx.mark_non_differentiable(picked)
+        return picked
+
+    @staticmethod
+    def backward(ctx, *grads):
         return None, None
 
 
@@ -210,12 +221,13 @@ furthest_point_sample = FurthestPointSampling.apply
 
 
 class ThreeNN(Function):
+    """for every `unknown` point the three nearest `known` points of its scene -> (distances (N,3), global row indices (N,3))
+    (pointnet2_utils.py:222-247)"""
+
     @staticmethod
     def forward(ctx, unknown, unknown_batch_cnt, known, known_batch_cnt):
-        """-> dist (N,3) l2 distances to, and idx (N,3) global rows of, the three nearest known points -- pointnet2_utils.py:222-247"""
-        assert unknown.shape.__len__() == 2 and unknown.shape[1] == 3
-        assert known.shape.__len__() == 2 and known.shape[1] == 3
-        assert unknown_batch_cnt.__len__() == known_batch_cnt.__len__()
+        assert unknown.dim() == 2 and unknown.shape[1] == 3 and known.dim() == 2 and known.shape[1] == 3
+        assert len(unknown_batch_cnt) == len(known_batch_cnt)
         dist2 = unknown.new_zeros(unknown.shape)
         idx = unknown_batch_cnt.new_zeros(unknown.shape).int()
         pointnet2.three_nn_wrapper(unknown.contiguous(), unknown_batch_cnt.contiguous(), known.contiguous(), known_batch_cnt.contiguous(), dist2, idx)
@@ -223,27 +235,28 @@ class ThreeNN(Function):
         return torch.sqrt(dist2), idx
 
     @staticmethod
-    def backward(ctx, a=None, b=None):
-        return None, None, None, None
+    def backward(ctx, *grads):
+        return (None,) * 4
 
 
 three_nn = ThreeNN.apply
 
 
 class ThreeInterpolate(Function):
-    @staticmethod
-    def forward(ctx, features: torch.Tensor, idx: torch.Tensor, weight: torch.Tensor):
-        """features (M1+M2.., C), idx / weight (N1+N2.., 3) -> (N1+N2.., C) -- pointnet2_utils.py:256-272"""
-        assert idx.shape[0] == weight.shape[0] and idx.shape[1] == weight.shape[1] == 3
-        ctx.three_interpolate_for_backward = (idx, weight, features.shape[0])
-        output = features.new_empty((idx.shape[0], features.shape[1]))
-        pointnet2.three_interpolate_wrapper(features.contiguous(), idx.contiguous(), weight.contiguous(), output)
-        return output
+    """out[n] = sum_j weight[n, j] * features[idx[n, j]] -> (N1+N2.., C); the backward scatter-adds (pointnet2_utils.py:256-289)"""
 
     @staticmethod
-    def backward(ctx, grad_out: torch.Tensor):
-        idx, weight, M = ctx.three_interpolate_for_backward
-        grad_features = grad_out.new_empty((M, grad_out.shape[1]))  # zeroed by the call
+    def forward(ctx, features, idx, weight):
+        assert idx.shape[0] == weight.shape[0] and idx.shape[1] == weight.shape[1] == 3
+        ctx.three_interpolate_for_backward = (idx, weight, features.shape[0])
+        out = features.new_empty((idx.shape[0], features.shape[1]))
+        pointnet2.three_interpolate_wrapper(features.contiguous(), idx.contiguous(), weight.contiguous(), out)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        idx, weight, n_known = ctx.three_interpolate_for_backward
+        grad_features = grad_out.new_empty((n_known, grad_out.shape[1]))  # zero-filled by the call
         pointnet2.three_interpolate_grad_wrapper(grad_out.contiguous(), idx.contiguous(), weight.contiguous(), grad_features)
         return grad_features, None, None
 
