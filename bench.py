@@ -8,7 +8,10 @@ One step = one pass of the hot path over one synthetic batch whose raw points al
   GPU voxelization of both grids (cylinder occupancy grid + Cartesian detection grid)
   -> OccTargets3D -> MeanVFE -> VoxelBackBoneDeconv -> OccHead3D (+ occupancy loss) -> PassOccVox
   -> OccVFE -> VoxelBackBone8xOcc -> HeightCompression (+ an L2 stand-in for the out-of-scope BEV heads)
-  -> backward (DDP gradient all-reduce over RCCL when N > 1) -> the two Adam steps of the reference.
+  -> backward (gradient all-reduce over RCCL when N > 1: btcdet_amd/grad_sync.py, or DDP with BTC_BENCH_SYNC=ddp)
+  -> one fused Adam step over the reference's two parameter groups.
+Every step also prepares the NEXT batch's weight-independent front (both voxelizations, occupancy targets, occupancy-branch
+rulebooks) on a side stream beside its backward pass -- one preparation per step (make_step; BTC_PREFETCH=0 runs in order).
 fp32 throughout.  Prints ONE JSON line on rank 0 (contract in the task statement), including
   roofline      the dominant kernel (conv_apply = fused sparse conv fwd/dgrad) timed live with HIP events
   cpu_baseline  the CPU oracle timed on the host cores for a bounded sample of the same workload (N = 1 only).
