@@ -93,3 +93,54 @@ def test_bucketed_grad_sync_gloo_world2():
     np.testing.assert_allclose(g0, 0.5 * (l0 + l1), rtol=1e-5, atol=1e-7)
     early = [e for e in launched0 if e[0] == 0 and e[1]]
     assert early and all(e[2] for e in early)   # the early launch of bucket 0 saw a complete bucket
+
+
+def _one_bucket_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    import bench
+    from btcdet_amd.grad_sync import BucketedGradSync
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(2)
+    net = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.ReLU(), torch.nn.Linear(7, 3))
+    ref = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.ReLU(), torch.nn.Linear(7, 3))
+    ref.load_state_dict(net.state_dict())
+    params = list(net.parameters())
+    sync = BucketedGradSync([(params, None)], assign_grads=False)     # bench.py's configuration for N > 1
+    try:
+        opt = bench.LeanFusedAdam([{"params": params, "lr": 1e-2, "weight_decay": 0.01}], betas=(0.9, 0.99))
+        opt.read_grads_from(sync.view_of)
+        ropt = torch.optim.Adam(ref.parameters(), lr=1e-2, weight_decay=0.01, betas=(0.9, 0.99))
+        for it in range(3):
+            xs = [torch.from_numpy(np.random.default_rng(100 * it + r).standard_normal((8, 5)).astype(np.float32)) for r in range(world)]
+            opt.zero_grad()
+            net(xs[rank]).pow(2).mean().backward()
+            local = [p.grad.clone() for p in params]
+            sync.launch_ready()                                        # everything is present: the bucket goes now
+            sync.finish()
+            assert all(torch.equal(p.grad, g) for p, g in zip(params, local))   # param.grad untouched (assign_grads=False)
+            opt.step()
+            ropt.zero_grad()
+            (sum(ref(x).pow(2).mean() for x in xs) / world).backward()          # the mean over ranks, computed locally
+            ropt.step()
+        out[rank] = ([p.detach().numpy().copy() for p in params], [p.detach().numpy().copy() for p in ref.parameters()])
+    except (RuntimeError, NotImplementedError) as e:
+        out[rank] = "skip: %s" % e
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_one_bucket_reducer_feeds_the_optimizer_gloo_world2():
+    """bench.py's N > 1 configuration: one flat bucket sent after backward, the fused Adam reads the reduced gradients from
+    the bucket's slices (param.grad is left alone); the parameters follow a single-process Adam on the mean loss"""
+    world, port = 2, 29751
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_one_bucket_worker, args=(world, port, out), nprocs=world, join=True)
+    if isinstance(out[0], str):
+        import pytest
+        pytest.skip(out[0])
+    (p0, r0), (p1, _) = out[0], out[1]
+    for a, b, r in zip(p0, p1, r0):
+        np.testing.assert_allclose(a, b, rtol=0, atol=0)              # ranks stay in lockstep
+        np.testing.assert_allclose(a, r, rtol=2e-5, atol=2e-6)
