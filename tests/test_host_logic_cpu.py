@@ -83,3 +83,31 @@ def test_lean_fused_adam_equals_torch_adam():
         pytest.skip("torch._fused_adam_ unavailable on CPU here: %s" % e)
     for p, q in zip(a1 + a2, b1 + b2):
         torch.testing.assert_close(q, p, rtol=1e-6, atol=1e-7)
+
+
+def test_geometry_plans_of_both_backbones():
+    """spconv/geometry.py: which layer builds, which reuses (by indice_key, or through an identical geometry on the same level) and
+    the shapes along the chain -- derived on the host, no GPU needed"""
+    from btcdet_amd.btc_path import BtcHotPath
+    from btcdet_amd.config import load_cfg
+    from btcdet_amd.spconv.geometry import GeometryPlan, flatten_convs
+    m = BtcHotPath(load_cfg(), device="cpu")
+    bb, head = m.occ_modules.backbone_3d, m.occ_modules.occ_dense_head
+    convs = flatten_convs(bb.conv1, bb.conv2, bb.conv3, bb.deconv4, bb.deconv5, head.conv_cls, head.conv_res)
+    plan = GeometryPlan(convs, bb.sparse_shape, 2)
+    kinds = [e[0] for e in plan.entries]
+    assert kinds == [1, 1, 0, 1, 0, 1, 0, 1, 0, 3, 3]                     # 9 builds, the two head convs reuse subm5's rulebook
+    assert [e[1] for e in plan.entries][-2:] == [8, 8]
+    assert plan.entries[1][4] == [5, 79, 105] and plan.entries[3][4] == [3, 40, 53] and plan.entries[7][4] == [9, 157, 209]
+    assert len(plan.args) == 11 and all(len(a) == len(convs) for a in plan.args)
+    det = m.det_modules.backbone_3d
+    stages = [det.conv1, det.conv2, det.conv2_combine, det.conv3, det.conv3_combine, det.conv4, det.conv4_combine, det.conv_out]
+    if getattr(det, "squeezeBev", None) is not None:
+        stages.append(det.squeezeBev)
+    dplan = GeometryPlan(flatten_convs(*stages), det.sparse_shape, 2)
+    dk = [(c.indice_key, e[0]) for c, e in zip(dplan.convs, dplan.entries)]
+    assert dk[:10] == [("subm1", 0), ("spconv2", 1), ("subm2", 0), ("subm2", 3), ("spconv3", 1), ("subm3", 0), ("subm3", 3), ("spconv4", 1),
+                       ("subm4", 0), ("subm4", 3)]
+    assert dplan.entries[10][4] == [2, 200, 176]                          # conv_out: (3,1,1) / stride (2,1,1) on [5, 200, 176]
+    with pytest.raises(TypeError):
+        flatten_convs(torch.nn.ReLU())
