@@ -71,6 +71,9 @@ _SIGS = {
     "btc_voxelize": (ci, [vp, ci, ci, ci, ci, ci, vp, ci, c_f32p, c_f32p, c_i32p, ci, ci, vp, vp, vp, vp, vp, sz, vp]),
     "btc_cart_to_occ_coords": (ci, [vp, vp, ci, ci, ci, vp]),
     "btc_voxel_shift_col": (ci, [vp, vp, ci, ci, ci, ci, vp, ctypes.c_float, vp]),
+    "btc_range_mask_ws_bytes": (sz, [ci]),
+    "btc_range_mask_compact": (ci, [vp, vp, ci, ci, ci, vp, ci, c_f32p, vp, vp, vp, vp, vp, sz, vp]),
+    "btc_gather_rows": (ci, [vp, vp, ci, ci, ci, vp, vp, vp]),
     "btc_out_shape": (ci, [c_i32p, c_i32p, c_i32p, c_i32p, c_i32p, c_i32p, ci, c_i32p]),
     "btc_rulebook_subm_ws_bytes": (sz, [ci]),
     "btc_rulebook_subm": (ci, [vp, ci, ci, c_i32p, c_i32p, c_i32p, vp, vp, vp, sz, vp]),

@@ -99,6 +99,27 @@ int btc_voxel_shift_col(float* voxels, const int32_t* coords, int m, int max_poi
                         const float* rot_by_batch, float sign, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Per-scene pre-steps on a resident batch (csrc/prestep.hip).
+ *
+ * btc_range_mask_compact replaces the point half of DataProcessor.mask_points_and_boxes_outside_range
+ * (/root/reference/btcdet/datasets/processor/data_processor.py:23-29 -> common_utils.mask_points_by_range,
+ * btcdet/utils/common_utils.py:59-62) for a whole batch: a row is kept iff x in [x_lo, x_hi] and y in [y_lo, y_hi]
+ * (inclusive, z not tested, NaN dropped); kept rows keep their order (numpy boolean indexing).  The same mask is applied to
+ * an optional second array (`pre_rot_points`, data_processor.py:27-28).
+ *   points (n, ld) f32, xy in columns 0,1 ; points_b (n, ld_b) f32 or NULL ; scene_offsets (batch+1) i32
+ *   h_range_xyxy  host float[4] = x_lo, y_lo, x_hi, y_hi
+ *   out (n, ld), out_b (n, ld_b): rows [0, n') valid ; out_offsets (batch+1) i32: scene offsets after masking,
+ *   out_offsets[batch] = n' ; keep_idx (n) i32 or NULL: source row of every kept row.  ws: btc_range_mask_ws_bytes(n).
+ *
+ * btc_gather_rows: out[i] = src[idx[i]] (DataProcessor.shuffle_points, data_processor.py:41-51: points[shuffle_idx]).
+ *   an index outside [0, n_src) writes a zero row and increments *bad_count (if given) instead of reading out of bounds. */
+size_t btc_range_mask_ws_bytes(int n);
+int btc_range_mask_compact(const float* points, const float* points_b, int n, int ld, int ld_b, const int32_t* scene_offsets, int batch,
+                           const float* h_range_xyxy, float* out, float* out_b, int32_t* out_offsets, int32_t* keep_idx, void* ws,
+                           size_t ws_bytes, void* stream);
+int btc_gather_rows(const float* src, const int32_t* idx, int n_out, int ld, int n_src, float* out, int32_t* bad_count, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Rulebook.  Replaces spconv ops.get_indice_pairs behind
  * SubMConv3d / SparseConv3d / SparseConvTranspose3d / SparseMaxPool3d
  * (/root/reference/btcdet/models/backbones_3d/spconv_backbone.py:12-29).

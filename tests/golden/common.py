@@ -38,3 +38,87 @@ def unsparse(g, key):
     a = np.zeros(int(np.prod(shape)), np.float32)
     a[g[key + "_idx"]] = g[key + "_val"]
     return a.reshape(shape)
+
+
+def init_by_name(module):
+    """deterministic, name-keyed values for every floating parameter / buffer of a torch module: the same function runs in
+    the golden generator on the REFERENCE's module and in the tests on this repository's module (their state_dict keys are
+    equal, tests/test_reference_dropin_cpu.py), so weights never have to be stored.  Scales keep activations O(1)."""
+    import zlib
+    import torch
+    with torch.no_grad():
+        for name, t in list(module.named_parameters()) + list(module.named_buffers()):
+            if t.numel() == 0 or not t.dtype.is_floating_point:
+                continue
+            u = torch.from_numpy(_hash01(t.numel(), zlib.crc32(name.encode()) & 0xFFFF)).reshape(t.shape)
+            if name.endswith("running_var"):
+                v = 0.5 + u
+            elif name.endswith("running_mean"):
+                v = 0.2 * u - 0.1
+            elif t.dim() == 1 and name.endswith(".weight"):      # BatchNorm gamma
+                v = 0.5 + u
+            elif t.dim() == 1:                                    # BatchNorm beta / conv bias
+                v = 0.4 * u - 0.2
+            else:                                                 # conv weight [k.., Cin, Cout]
+                fan = t.numel() / t.shape[-1]
+                v = (2.0 * u - 1.0) * float(np.sqrt(3.0 / fan))
+            t.copy_(v.to(t.dtype))
+
+
+def digest(a, n=8192):
+    """compact fingerprint of a float array: shape, float64 sum / abs-sum, and a strided sample of <= n elements"""
+    a = np.ascontiguousarray(a)
+    flat = a.reshape(-1)
+    stride = max(1, flat.size // n)
+    return {"shape": np.array(a.shape, dtype=np.int64), "sum": np.array(flat.sum(dtype=np.float64)),
+            "abssum": np.array(np.abs(flat).sum(dtype=np.float64)), "stride": np.array(stride),
+            "sample": flat[::stride][:n].astype(np.float32)}
+
+
+def put_digest(gold, key, a, n=8192):
+    for k, v in digest(a, n).items():
+        gold["%s__%s" % (key, k)] = v
+
+
+def check_digest(g, key, a, rtol, atol, what=""):
+    """-> (max abs error over the sample, relative error of the abs-sum); asserts shape, sample and sums"""
+    a = np.ascontiguousarray(a)
+    assert tuple(a.shape) == tuple(int(v) for v in g[key + "__shape"]), (what or key, a.shape, g[key + "__shape"])
+    flat = a.reshape(-1)
+    stride, ref = int(g[key + "__stride"]), g[key + "__sample"]
+    got = flat[::stride][:ref.size].astype(np.float32)
+    err = float(np.abs(got - ref).max()) if ref.size else 0.0
+    np.testing.assert_allclose(got, ref, rtol=rtol, atol=atol, err_msg=what or key)
+    s_ref = float(g[key + "__abssum"])
+    s_err = abs(float(np.abs(flat).sum(dtype=np.float64)) - s_ref) / max(s_ref, 1e-30)
+    assert s_err <= max(10 * rtol, 1e-6), (what or key, s_err)
+    return err, s_err
+
+
+def sha1(a):
+    import hashlib
+    return np.frombuffer(hashlib.sha1(np.ascontiguousarray(a).tobytes()).digest(), dtype=np.uint8).copy()
+
+
+def _synth():
+    from btcdet_amd import synth
+    return synth
+
+
+def raw_scene(spec):
+    """synth scene + points that leave the detection range (so the range mask has work to do); unshuffled order is
+    irrelevant -- the reference's shuffle_points permutes `points` (NOT pre_rot_points, data_processor.py:41-51)"""
+    s = _synth().make_scene(spec["seed"], n_boxes=spec.get("n_boxes"))
+    pts, pre = s["points"], s["pre_rot_points"]
+    if spec.get("keep") is not None:
+        pts, pre = pts[:spec["keep"]], pre[:spec["keep"]]
+    rng = np.random.default_rng(spec["seed"] + 7)
+    n_out = 400
+    junk = np.stack([rng.uniform(-6, 76, n_out), rng.uniform(-46, 46, n_out), rng.uniform(-2, 0.5, n_out), rng.uniform(0, 1, n_out)], 1).astype(np.float32)
+    inside = (junk[:, 0] >= 0) & (junk[:, 0] <= 70.4) & (junk[:, 1] >= -40) & (junk[:, 1] <= 40)
+    junk = junk[~inside]
+    pos = np.sort(rng.choice(pts.shape[0] + 1, junk.shape[0]))                    # interleave, do not append
+    raw = np.insert(pts, pos, junk, axis=0)
+    raw_pre = np.insert(pre, pos, np.concatenate([_synth()._rotz(junk[:, :3], -float(s["rot_z"])), junk[:, 3:]], 1), axis=0)
+    bm = s["bm_points"] if not spec.get("no_bm") else np.zeros((0, 3), np.float32)
+    return s, raw, raw_pre, bm
