@@ -50,6 +50,13 @@ class BtcOccBuffers(ctypes.Structure):
     _fields_ = [(k, ctypes.c_void_p) for k in OCC_BUFFER_FIELDS]
 
 
+class BtcChainLayer(ctypes.Structure):
+    """struct BtcChainLayer of include/btcdet_hip.h"""
+    _fields_ = [("kind", ctypes.c_int32), ("ref", ctypes.c_int32), ("mode", ctypes.c_int32), ("in_shape", ctypes.c_int32 * 3),
+                ("out_shape", ctypes.c_int32 * 3), ("k", ctypes.c_int32 * 3), ("s", ctypes.c_int32 * 3), ("p", ctypes.c_int32 * 3),
+                ("d", ctypes.c_int32 * 3)]
+
+
 class BtcPovConfig(ctypes.Structure):
     """struct BtcPovConfig of include/btcdet_hip.h"""
     _fields_ = [("batch", ctypes.c_int32), ("max_k", ctypes.c_int32), ("occ_grid", ctypes.c_int32 * 3), ("det_grid", ctypes.c_int32 * 3),
@@ -80,7 +87,12 @@ _SIGS = {
     "btc_rulebook_conv_ws_bytes": (sz, [ci, c_i32p]),
     "btc_rulebook_conv_count": (ci, [vp, ci, ci, c_i32p, c_i32p, c_i32p, c_i32p, c_i32p, c_i32p, ci, vp, vp, sz, vp]),
     "btc_rulebook_conv_fill": (ci, [vp, ci, ci, c_i32p, c_i32p, c_i32p, c_i32p, c_i32p, c_i32p, ci, ci, vp, vp, vp, vp, sz, vp]),
-    "btc_pairs_from_nbr": (ci, [vp, ci, ci, ci, vp, vp, vp]),
+    "btc_pairs_from_nbr_ws_bytes": (sz, [ci, ci]),
+    "btc_pairs_from_nbr": (ci, [vp, ci, ci, ci, vp, vp, vp, sz, vp]),
+    "btc_chain_ws_bytes": (sz, [vp, ci, ci, ci]),
+    "btc_chain_caps": (ci, [vp, ci, ci, ci, vp]),
+    "btc_chain_levels": (ci, [vp, ci, ci, vp, ci, vp, vp, vp, vp, sz, vp]),
+    "btc_chain_maps": (ci, [vp, ci, ci, vp, ci, vp, vp, vp, vp, vp, sz, vp]),
     "btc_conv_fwd": (ci, [vp, vp, vp, vp, ci, ci, ci, ci, vp, vp]),
     "btc_conv_dgrad": (ci, [vp, vp, vp, ci, ci, ci, ci, vp, vp]),
     "btc_conv_wgrad_ws_bytes": (sz, [ci, ci, ci, ci, ci]),

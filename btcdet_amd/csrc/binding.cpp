@@ -413,6 +413,9 @@ Tensor conv_bn_relu(const Tensor& features, const Tensor& weight, const OptTenso
 // thread for the GIL).  kind: 0 = build submanifold, 1 = build strided / transposed, 2 = inverse of layer ref (continue on ITS
 // input level), 3 = reuse layer ref's rulebook (continue on its output level).  Returns per built layer
 // {in_indices, out_indices, nbr_out, nbr_in}, an empty list for the others.
+// Two phases of the C ABI around ONE read-back for the whole chain (btc_chain_levels / btc_chain_maps, csrc/rulebook.hip): the
+// levels are built on the device with their row counts left there and their rows written into capacity-sized buffers (16
+// bytes a row -- HBM is 288 GB, the untouched tail costs nothing); the counts come back together; the maps are sized exactly.
 std::vector<std::vector<Tensor>> geometry_walk(const Tensor& indices, int64_t batch, const std::vector<int64_t>& kind,
                                                const std::vector<int64_t>& a_in, const std::vector<int64_t>& a_out,
                                                const std::vector<int64_t>& a_k, const std::vector<int64_t>& a_s,
@@ -422,21 +425,56 @@ std::vector<std::vector<Tensor>> geometry_walk(const Tensor& indices, int64_t ba
   const size_t n = kind.size();
   need(a_in.size() == n && a_out.size() == n && a_k.size() == n && a_s.size() == n && a_p.size() == n && a_d.size() == n && mode.size() == n &&
            K.size() == n && ws_bytes.size() == n && ref.size() == n, "geometry_walk: per-layer argument lists differ in length");
+  need(n >= 1 && n <= BTC_CHAIN_MAX_LAYERS, "geometry_walk: too many layers for one chain");
   const int64_t stream = current_stream();
-  std::vector<std::vector<Tensor>> out(n);
+  const int n0 = (int)indices.size(0);
+  std::vector<BtcChainLayer> layers(n);
+  for (size_t i = 0; i < n; ++i) {
+    BtcChainLayer& l = layers[i];
+    l.kind = (int32_t)kind[i];
+    l.ref = (int32_t)ref[i];
+    l.mode = (int32_t)mode[i];
+    for (int j = 0; j < 3; ++j) {
+      const bool built = kind[i] < 2;
+      l.in_shape[j] = built ? ip(a_in[i])[j] : 1;
+      l.out_shape[j] = built ? (kind[i] == 1 ? ip(a_out[i])[j] : ip(a_in[i])[j]) : 1;
+      l.k[j] = built ? ip(a_k[i])[j] : 1;
+      l.s[j] = (built && kind[i] == 1) ? ip(a_s[i])[j] : 1;
+      l.p[j] = (built && kind[i] == 1) ? ip(a_p[i])[j] : 0;
+      l.d[j] = built ? ip(a_d[i])[j] : 1;
+    }
+  }
+  std::vector<int64_t> cap(n, 0);
+  chk(btc_chain_caps(layers.data(), (int)n, (int)batch, n0, cap.data()), "btc_chain_caps");
+  const size_t wsb = btc_chain_ws_bytes(layers.data(), (int)n, (int)batch, n0);
+  need(wsb > 0, "geometry_walk: btc_chain_ws_bytes failed");
+  Tensor ws = at::empty({(int64_t)wsb}, indices.options().dtype(at::kByte));
+  Tensor d_counts = at::zeros({(int64_t)n}, indices.options());
+  std::vector<Tensor> out_idx(n);
+  std::vector<int32_t*> p_out_idx(n, nullptr), p_nbr_out(n, nullptr), p_nbr_in(n, nullptr);
+  for (size_t i = 0; i < n; ++i)
+    if (kind[i] == 1) {
+      out_idx[i] = at::empty({cap[i], 4}, indices.options());
+      p_out_idx[i] = (int32_t*)out_idx[i].data_ptr();
+    }
+  chk(btc_chain_levels((const int32_t*)indices.data_ptr(), n0, (int)batch, layers.data(), (int)n, p_out_idx.data(), cap.data(),
+                       (int32_t*)d_counts.data_ptr(), ws.data_ptr(), wsb, st(stream)), "btc_chain_levels");
+  Tensor h_counts = d_counts.to(at::kCPU);  // the one read-back of the chain (current stream only)
+  const int32_t* hc = (const int32_t*)h_counts.data_ptr();
+  // levels as the walk sees them
   std::vector<Tensor> level_in(n), level_out(n);
   Tensor cur = indices;
+  int64_t strided_elems = 0, other_elems = 0;
   for (size_t i = 0; i < n; ++i) {
     if (kind[i] == 0) {
-      Tensor nbr = rulebook_subm(cur, batch, a_in[i], a_k[i], a_d[i], K[i], stream);
-      out[i] = {cur, cur, nbr.select(0, 0), nbr.select(0, 1)};
       level_in[i] = level_out[i] = cur;
+      other_elems += 2 * cur.size(0) * K[i];
     } else if (kind[i] == 1) {
-      auto t = rulebook_conv(cur, batch, a_in[i], a_out[i], a_k[i], a_s[i], a_p[i], a_d[i], mode[i], K[i], ws_bytes[i], stream);
-      out[i] = {cur, std::get<0>(t), std::get<1>(t), std::get<2>(t)};
       level_in[i] = cur;
-      cur = std::get<0>(t);
+      cur = out_idx[i].narrow(0, 0, hc[i]);
       level_out[i] = cur;
+      strided_elems += (int64_t)hc[i] * K[i];
+      other_elems += level_in[i].size(0) * K[i];
     } else {
       need(ref[i] >= 0 && (size_t)ref[i] < i, "geometry_walk: bad layer reference");
       cur = kind[i] == 2 ? level_in[ref[i]] : level_out[ref[i]];
@@ -444,6 +482,31 @@ std::vector<std::vector<Tensor>> geometry_walk(const Tensor& indices, int64_t ba
       level_out[i] = cur;
     }
   }
+  // the strided layers' nbr_out in ONE buffer (one -1 fill for the chain), everything else in another
+  Tensor buf_s = at::empty({strided_elems > 0 ? strided_elems : 1}, indices.options());
+  Tensor buf_o = at::empty({other_elems > 0 ? other_elems : 1}, indices.options());
+  int64_t off_s = 0, off_o = 0;
+  std::vector<std::vector<Tensor>> out(n);
+  for (size_t i = 0; i < n; ++i) {
+    if (kind[i] > 1) continue;
+    const int64_t rows_in = level_in[i].size(0), rows_out = level_out[i].size(0);
+    Tensor nbr_out, nbr_in;
+    if (kind[i] == 1) {
+      nbr_out = buf_s.narrow(0, off_s, rows_out * K[i]).view({rows_out, K[i]});
+      off_s += rows_out * K[i];
+    } else {
+      nbr_out = buf_o.narrow(0, off_o, rows_out * K[i]).view({rows_out, K[i]});
+      off_o += rows_out * K[i];
+    }
+    nbr_in = buf_o.narrow(0, off_o, rows_in * K[i]).view({rows_in, K[i]});
+    off_o += rows_in * K[i];
+    p_nbr_out[i] = (int32_t*)nbr_out.data_ptr();
+    p_nbr_in[i] = (int32_t*)nbr_in.data_ptr();
+    out[i] = {level_in[i], level_out[i], nbr_out, nbr_in};
+  }
+  chk(btc_chain_maps((const int32_t*)indices.data_ptr(), n0, (int)batch, layers.data(), (int)n, hc, p_out_idx.data(), p_nbr_out.data(),
+                     p_nbr_in.data(), ws.data_ptr(), wsb, st(stream)), "btc_chain_maps");
+  dbg_sync("geometry_walk");
   return out;
 }
 

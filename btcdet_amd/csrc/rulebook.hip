@@ -6,31 +6,78 @@
 // (nondeterministic order) the rulebook is stored as two dense neighbour maps
 //     nbr_out (n_out,K): input row gathered by output row i at offset k (or -1)
 //     nbr_in  (n_in ,K): output row fed by input row j at offset k (or -1)
-// which are a pure function of (indices, geometry) and feed the fused output-stationary conv
-// kernels of sparse_conv.hip directly (no atomics in the apply stage).
+// which are a pure function of (indices, geometry) and feed the output-stationary conv kernels directly.
 //
-//  SubM   : cell -> row hash table (open addressing, int32 keys, L2 resident), one thread per
-//           (row, offset) probes its neighbour; nbr_in is the mirrored map (odd kernels).
-//  conv / transpose / pool: the set of reachable output cells is a BITMAP over the output grid
-//           (atomicOr), ranked by a popcount prefix sum -> output rows come out ascending in
-//           (b,z,y,x) with no sort, and rank(bitmap, cell) is also the cell -> output row lookup.
+// Data structure: a LEVEL = the active set of one resolution as a RANKED BITMAP over its grid
+//     words   : 1 bit per cell (cell = b * vol + (z * H + y) * W + x), 32-byte blocks of 8 words
+//     bprefix : per block, the number of set bits in front of it inside its 2048-word chunk
+//     cprefix : per chunk, the number of set bits in front of it (cprefix[nchunks] = total)
+// rank(cell) = cprefix[chunk] + bprefix[block] + popcount inside the block = the ROW of the cell, because every level
+// built here emits its rows in ascending cell order ((b,z,y,x)-sorted, what spconv's sort-unique yields).  One structure
+// answers every question of the stage: the sorted unique output set of a strided / transposed conv or pool (mark the
+// reachable cells, rank them -- no sort), cell -> output row for nbr_in, and cell -> row for the 27 neighbour probes of
+// every submanifold layer on that level (a bit test that mostly fails, then one 32-byte block + two prefix words).
+// Cost per level: grid volume / 8 bytes cleared and scanned once (det level [21,800,704] x 2: 2.9 MB), everything else is
+// proportional to the active rows.  The arbitrary (unsorted, un-ranked) input of a chain -- voxelizer order -- is served by
+// an open-addressing hash with 64-bit cell keys instead.
+//
+// A whole chain of layers (an encoder / decoder branch) is built in two phases around ONE read-back (btc_chain_levels /
+// btc_chain_maps): phase A builds every level on the device, each level's row count staying in device memory and the rows
+// of level l marking level l+1 from inside the kernel that emits them; the host reads all counts at once, sizes the maps,
+// and phase B fills every neighbour map of the chain in one multi-job launch.
 #include "btc_common.h"
 
 namespace {
 
-__device__ __forceinline__ bool out_cell(const BtcGeom& g, int z, int y, int x, int kk, int* oz, int* oy, int* ox) {
-  int kx = kk % g.k[2];
-  int ky = (kk / g.k[2]) % g.k[1];
-  int kz = kk / (g.k[2] * g.k[1]);
-  int c[3] = {z, y, x};
-  int kv[3] = {kz, ky, kx};
+constexpr int RB_T = 256;
+constexpr int RB_BLK = 8;           // words per rank block (one 32-byte sector)
+constexpr int RB_CHUNK = 256;       // blocks per chunk: one thread per block in rb_scan
+constexpr int RB_MAX_JOBS = 10;
+
+struct Level {
+  unsigned* words;
+  int32_t* bprefix;
+  int32_t* cprefix;
+  int shape[3];
+  int vol;             // cells per scene
+  long long nblk;      // 8-word blocks
+};
+
+__host__ __device__ __forceinline__ long long lvl_cell(const Level& L, int b, int z, int y, int x) {
+  return (long long)b * L.vol + ((long long)z * L.shape[1] + y) * L.shape[2] + x;
+}
+
+// rank of a cell of a scanned level, -1 if the cell is not active
+__device__ __forceinline__ int lvl_rank(const Level& L, long long cell) {
+  const long long w = cell >> 5;
+  const unsigned bit = (unsigned)cell & 31u;
+  const unsigned word = L.words[w];
+  if (!((word >> bit) & 1u)) return -1;
+  const long long blk = w >> 3;
+  const int wi = (int)(w & 7);
+  const uint4* p = reinterpret_cast<const uint4*>(L.words + blk * RB_BLK);
+  const uint4 a = p[0], b = p[1];
+  const unsigned ws[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+  int r = L.cprefix[blk / RB_CHUNK] + L.bprefix[blk] + __popc(word & ((1u << bit) - 1u));
+#pragma unroll
+  for (int j = 0; j < 7; ++j) r += (j < wi) ? __popc(ws[j]) : 0;
+  return r;
+}
+
+// forward map of a geometry: input cell + offset -> output cell (CONV: divisibility; TRANSPOSE: always integral)
+__device__ __forceinline__ bool fwd_cell(const BtcGeom& g, int z, int y, int x, int kk, int* oz, int* oy, int* ox) {
+  const int kx = kk % g.k[2];
+  const int ky = (kk / g.k[2]) % g.k[1];
+  const int kz = kk / (g.k[2] * g.k[1]);
+  const int c[3] = {z, y, x};
+  const int kv[3] = {kz, ky, kx};
   int o[3];
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
     if (g.mode == BTC_MODE_CONV) {
-      int t = c[j] + g.p[j] - kv[j] * g.d[j];
+      const int t = c[j] + g.p[j] - kv[j] * g.d[j];
       if (t < 0) return false;
-      int q = t / g.s[j];
+      const int q = t / g.s[j];
       if (q * g.s[j] != t) return false;
       o[j] = q;
     } else {
@@ -42,103 +89,227 @@ __device__ __forceinline__ bool out_cell(const BtcGeom& g, int z, int y, int x, 
   return true;
 }
 
-// ------------------------------------------------------------------ SubM
-__global__ __launch_bounds__(256) void subm_insert(const int4* __restrict__ idx, int n, BtcGeom g, unsigned mask,
-                                                   int32_t* __restrict__ keys, int32_t* __restrict__ vals) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
+// every cell an input row reaches, OR-ed into the output level's bitmap; bits of one word are merged in registers, and a
+// word that already holds them is not touched again (stride 2: ~8 inputs share an output cell)
+__device__ __forceinline__ void mark_row(const BtcGeom& g, const Level& out, int b, int z, int y, int x) {
+  long long cur_w = -1;
+  unsigned cur_bits = 0;
+  for (int kk = 0; kk < g.K; ++kk) {
+    int oz, oy, ox;
+    if (!fwd_cell(g, z, y, x, kk, &oz, &oy, &ox)) continue;
+    const long long cell = lvl_cell(out, b, oz, oy, ox);
+    const long long w = cell >> 5;
+    const unsigned bit = 1u << ((unsigned)cell & 31u);
+    if (w != cur_w) {
+      if (cur_bits && (__hip_atomic_load(&out.words[cur_w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & cur_bits) != cur_bits)
+        atomicOr(&out.words[cur_w], cur_bits);
+      cur_w = w;
+      cur_bits = 0;
+    }
+    cur_bits |= bit;
+  }
+  if (cur_bits && (__hip_atomic_load(&out.words[cur_w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & cur_bits) != cur_bits)
+    atomicOr(&out.words[cur_w], cur_bits);
+}
+
+// n rows: from d_n (device, the count of the producing level) when given, else n_host
+__global__ __launch_bounds__(RB_T) void rb_mark(const int4* __restrict__ idx, int n_host, const int32_t* __restrict__ d_n, BtcGeom g, Level out) {
+  const int n = d_n ? *d_n : n_host;
+  for (int i = blockIdx.x * RB_T + threadIdx.x; i < n; i += gridDim.x * RB_T) {
+    const int4 c = idx[i];
+    mark_row(g, out, c.x, c.y, c.z, c.w);
+  }
+}
+
+__device__ __forceinline__ int rb_wave_incl_scan(int v) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int t = __shfl_up(v, o, 64);
+    if (lane >= o) v += t;
+  }
+  return v;
+}
+
+// one thread per 32-byte block: chunk-relative block prefixes; the LAST workgroup to arrive turns the chunk sums into
+// chunk prefixes and publishes the level's row count (device, and a pinned host word when given)
+__global__ __launch_bounds__(RB_T) void rb_scan(Level L, int32_t* __restrict__ chunk_sums, int32_t* __restrict__ counter, int nchunks,
+                                                int32_t* __restrict__ d_total) {
+  __shared__ int s_wave[RB_T / 64 + 1];
+  __shared__ int s_last;
+  const long long blk = (long long)blockIdx.x * RB_CHUNK + threadIdx.x;
+  int cnt = 0;
+  if (blk < L.nblk) {
+    const uint4* p = reinterpret_cast<const uint4*>(L.words + blk * RB_BLK);
+    const uint4 a = p[0], b = p[1];
+    cnt = __popc(a.x) + __popc(a.y) + __popc(a.z) + __popc(a.w) + __popc(b.x) + __popc(b.y) + __popc(b.z) + __popc(b.w);
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int incl = rb_wave_incl_scan(cnt);
+  if (lane == 63) s_wave[wave] = incl;
+  __syncthreads();
+  int base = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < RB_T / 64; ++w) {
+    base += (w < wave) ? s_wave[w] : 0;
+    tot += s_wave[w];
+  }
+  if (blk < L.nblk) L.bprefix[blk] = base + incl - cnt;
+  if (threadIdx.x == 0) {
+    chunk_sums[blockIdx.x] = tot;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    const int t = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = (t == nchunks - 1);
+    if (s_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  }
+  __syncthreads();
+  if (!s_last) return;
+  // exclusive scan of the chunk sums in index order (deterministic), 256 at a time
+  int carry = 0;
+  for (int c0 = 0; c0 < nchunks; c0 += RB_T) {
+    const int c = c0 + threadIdx.x;
+    const int v = c < nchunks ? __hip_atomic_load(&chunk_sums[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+    const int inc = rb_wave_incl_scan(v);
+    __syncthreads();
+    if (lane == 63) s_wave[wave] = inc;
+    __syncthreads();
+    int b2 = 0, t2 = 0;
+#pragma unroll
+    for (int w = 0; w < RB_T / 64; ++w) {
+      b2 += (w < wave) ? s_wave[w] : 0;
+      t2 += s_wave[w];
+    }
+    if (c < nchunks) L.cprefix[c] = carry + b2 + inc - v;
+    carry += t2;
+  }
+  if (threadIdx.x == 0) {
+    L.cprefix[nchunks] = carry;
+    *d_total = carry;
+    __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+// rows of a scanned level in ascending cell order; with `fused`, every emitted row also marks the NEXT level of the chain
+__global__ __launch_bounds__(RB_T) void rb_emit(Level L, int4* __restrict__ out_idx, long long cap, int fused, BtcGeom g_next, Level next) {
+  const long long blk = (long long)blockIdx.x * RB_T + threadIdx.x;
+  if (blk >= L.nblk) return;
+  const uint4* p = reinterpret_cast<const uint4*>(L.words + blk * RB_BLK);
+  const uint4 a = p[0], b = p[1];
+  const unsigned ws[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+  if (!(ws[0] | ws[1] | ws[2] | ws[3] | ws[4] | ws[5] | ws[6] | ws[7])) return;
+  long long row = (long long)L.cprefix[blk / RB_CHUNK] + L.bprefix[blk];
+  const int hw = L.shape[1] * L.shape[2];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    unsigned bits = ws[j];
+    while (bits) {
+      const int bit = __ffs(bits) - 1;
+      bits &= bits - 1;
+      const long long cell = (blk * RB_BLK + j) * 32 + bit;
+      const int bb = (int)(cell / L.vol);
+      const int rem = (int)(cell - (long long)bb * L.vol);
+      const int z = rem / hw;
+      const int r2 = rem - z * hw;
+      const int y = r2 / L.shape[2], x = r2 - y * L.shape[2];
+      if (row < cap) out_idx[row] = make_int4(bb, z, y, x);
+      ++row;
+      if (fused) mark_row(g_next, next, bb, z, y, x);
+    }
+  }
+}
+
+// ---- 64-bit-key hash of an arbitrary (unsorted) input level: key = cell + 1, 0 = empty (one memset clears bitmaps and hash)
+__device__ __forceinline__ unsigned long long rb_hash64(unsigned long long k) {
+  k ^= k >> 33;
+  k *= 0xff51afd7ed558ccdULL;
+  k ^= k >> 29;
+  return k;
+}
+
+__global__ __launch_bounds__(RB_T) void rb_hash_insert(const int4* __restrict__ idx, int n, Level L, unsigned long long mask,
+                                                       unsigned long long* __restrict__ keys, int32_t* __restrict__ vals) {
+  const int i = blockIdx.x * RB_T + threadIdx.x;
   if (i >= n) return;
-  int4 c = idx[i];
-  int key = ((c.x * g.in_shape[0] + c.y) * g.in_shape[1] + c.z) * g.in_shape[2] + c.w;
-  unsigned slot = btc_hash32((unsigned)key) & mask;
+  const int4 c = idx[i];
+  const unsigned long long key = (unsigned long long)lvl_cell(L, c.x, c.y, c.z, c.w) + 1ull;
+  unsigned long long slot = rb_hash64(key) & mask;
   while (true) {
-    int prev = atomicCAS(&keys[slot], BTC_EMPTY_KEY, key);
-    if (prev == BTC_EMPTY_KEY || prev == key) break;
+    const unsigned long long prev = atomicCAS(&keys[slot], 0ull, key);
+    if (prev == 0ull || prev == key) break;
     slot = (slot + 1) & mask;
   }
   vals[slot] = i;
 }
 
-__global__ __launch_bounds__(256) void subm_lookup(const int4* __restrict__ idx, int n, BtcGeom g, unsigned mask,
-                                                   const int32_t* __restrict__ keys, const int32_t* __restrict__ vals,
-                                                   int32_t* __restrict__ nbr_out, int32_t* __restrict__ nbr_in) {
-  long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= (long long)n * g.K) return;
-  int i = (int)(t / g.K), kk = (int)(t % g.K);
-  int4 c = idx[i];
-  int kx = kk % g.k[2];
-  int ky = (kk / g.k[2]) % g.k[1];
-  int kz = kk / (g.k[2] * g.k[1]);
-  int z = c.y + (kz - g.k[0] / 2) * g.d[0];
-  int y = c.z + (ky - g.k[1] / 2) * g.d[1];
-  int x = c.w + (kx - g.k[2] / 2) * g.d[2];
-  int j = -1;
-  if (z >= 0 && z < g.in_shape[0] && y >= 0 && y < g.in_shape[1] && x >= 0 && x < g.in_shape[2]) {
-    int key = ((c.x * g.in_shape[0] + z) * g.in_shape[1] + y) * g.in_shape[2] + x;
-    unsigned slot = btc_hash32((unsigned)key) & mask;
-    while (true) {
-      int kq = keys[slot];
-      if (kq == key) { j = vals[slot]; break; }
-      if (kq == BTC_EMPTY_KEY) break;
-      slot = (slot + 1) & mask;
+__device__ __forceinline__ int rb_hash_find(unsigned long long key, unsigned long long mask, const unsigned long long* __restrict__ keys,
+                                            const int32_t* __restrict__ vals) {
+  unsigned long long slot = rb_hash64(key) & mask;
+  while (true) {
+    const unsigned long long kq = keys[slot];
+    if (kq == key) return vals[slot];
+    if (kq == 0ull) return -1;
+    slot = (slot + 1) & mask;
+  }
+}
+
+// ---- neighbour maps: every job of a chain in one launch
+enum { JOB_STRIDED = 0, JOB_SUBM_RANK = 1, JOB_SUBM_HASH = 2 };
+
+struct Job {
+  int type;
+  int n;                        // input rows
+  long long first_block;        // first workgroup of the job
+  BtcGeom g;
+  Level lvl;                    // STRIDED: the OUTPUT level; SUBM_*: the level itself (SUBM_HASH uses only its shape)
+  const int4* in_idx;
+  int32_t* nbr_out;
+  int32_t* nbr_in;
+  const unsigned long long* keys;
+  const int32_t* vals;
+  unsigned long long mask;
+};
+
+struct Jobs {
+  int count;
+  Job j[RB_MAX_JOBS];
+};
+
+__global__ __launch_bounds__(RB_T) void rb_fill(Jobs jobs) {
+  int ji = 0;
+#pragma unroll
+  for (int q = 1; q < RB_MAX_JOBS; ++q)
+    if (q < jobs.count && (long long)blockIdx.x >= jobs.j[q].first_block) ji = q;
+  const Job& J = jobs.j[ji];
+  const long long t = ((long long)blockIdx.x - J.first_block) * RB_T + threadIdx.x;
+  const int K = J.g.K;
+  if (t >= (long long)J.n * K) return;
+  const int i = (int)(t / K), kk = (int)(t - (long long)i * K);
+  const int4 c = J.in_idx[i];
+  if (J.type == JOB_STRIDED) {
+    int oz, oy, ox, row = -1;
+    if (fwd_cell(J.g, c.y, c.z, c.w, kk, &oz, &oy, &ox)) {
+      row = lvl_rank(J.lvl, lvl_cell(J.lvl, c.x, oz, oy, ox));   // always set: the level is the union of what is reachable
+      if (row >= 0) J.nbr_out[(size_t)row * K + kk] = i;
     }
+    J.nbr_in[t] = row;
+    return;
   }
-  nbr_out[t] = j;
-  // input i feeds, at the mirrored offset K-1-kk, exactly the output row that is its neighbour here
-  nbr_in[(size_t)i * g.K + (g.K - 1 - kk)] = j;
-}
-
-// ------------------------------------------------------------------ conv / transpose / pool
-__global__ __launch_bounds__(256) void conv_mark(const int4* __restrict__ idx, int n, BtcGeom g, int ovol,
-                                                 unsigned char* __restrict__ bytemap) {
-  long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= (long long)n * g.K) return;
-  int i = (int)(t / g.K), kk = (int)(t % g.K);
-  int4 c = idx[i];
-  int oz, oy, ox;
-  if (!out_cell(g, c.y, c.z, c.w, kk, &oz, &oy, &ox)) return;
-  unsigned cell = (unsigned)(c.x * ovol + (oz * g.out_shape[1] + oy) * g.out_shape[2] + ox);
-  bytemap[cell] = 1;  // plain store: every writer stores the same value
-}
-
-__global__ __launch_bounds__(256) void conv_fill(const int4* __restrict__ idx, int n, BtcGeom g, int ovol,
-                                                 const unsigned* __restrict__ bitmap, const int32_t* __restrict__ prefix,
-                                                 int32_t* __restrict__ nbr_out, int32_t* __restrict__ nbr_in) {
-  long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= (long long)n * g.K) return;
-  int i = (int)(t / g.K), kk = (int)(t % g.K);
-  int4 c = idx[i];
-  int oz, oy, ox;
-  int row = -1;
-  if (out_cell(g, c.y, c.z, c.w, kk, &oz, &oy, &ox)) {
-    unsigned cell = (unsigned)(c.x * ovol + (oz * g.out_shape[1] + oy) * g.out_shape[2] + ox);
-    unsigned w = cell >> 5, bit = cell & 31;
-    row = prefix[w] + __popc(bitmap[w] & ((1u << bit) - 1u));
-    nbr_out[(size_t)row * g.K + kk] = i;
+  const int kx = kk % J.g.k[2];
+  const int ky = (kk / J.g.k[2]) % J.g.k[1];
+  const int kz = kk / (J.g.k[2] * J.g.k[1]);
+  const int z = c.y + (kz - J.g.k[0] / 2) * J.g.d[0];
+  const int y = c.z + (ky - J.g.k[1] / 2) * J.g.d[1];
+  const int x = c.w + (kx - J.g.k[2] / 2) * J.g.d[2];
+  int j = -1;
+  if (z >= 0 && z < J.lvl.shape[0] && y >= 0 && y < J.lvl.shape[1] && x >= 0 && x < J.lvl.shape[2]) {
+    const long long cell = lvl_cell(J.lvl, c.x, z, y, x);
+    j = (J.type == JOB_SUBM_RANK) ? lvl_rank(J.lvl, cell) : rb_hash_find((unsigned long long)cell + 1ull, J.mask, J.keys, J.vals);
   }
-  nbr_in[t] = row;
+  J.nbr_out[t] = j;
+  J.nbr_in[(size_t)i * K + (K - 1 - kk)] = j;   // input i feeds, at the mirrored offset, exactly the row that is its neighbour here
 }
 
-__global__ __launch_bounds__(256) void conv_out_indices(const unsigned* __restrict__ bitmap, const int32_t* __restrict__ prefix,
-                                                        long long nwords, BtcGeom g, int ovol, int4* __restrict__ out_idx) {
-  long long w = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (w >= nwords) return;
-  unsigned bits = bitmap[w];
-  if (!bits) return;
-  int row = prefix[w];
-  const int hw = g.out_shape[1] * g.out_shape[2];
-  while (bits) {
-    int bit = __ffs(bits) - 1;
-    bits &= bits - 1;
-    unsigned cell = (unsigned)(w * 32 + bit);
-    int b = cell / ovol;
-    int rem = cell - b * ovol;
-    int z = rem / hw;
-    int r2 = rem - z * hw;
-    out_idx[row++] = make_int4(b, z, r2 / g.out_shape[2], r2 % g.out_shape[2]);
-  }
-}
-
-// ------------------------------------------------------------------ spconv-layout pair lists
+// ---- spconv-layout pair lists
 __global__ __launch_bounds__(256) void pairs_count(const int32_t* __restrict__ nbr_out, int n_out, int K,
                                                    int32_t* __restrict__ flags /* K*(n_out+1), offset-major */) {
   long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -185,6 +356,50 @@ int fill_geom(BtcGeom* g, const int32_t* in_shape, const int32_t* out_shape, con
   return BTC_OK;
 }
 
+// ---- host-side layout of a level inside a workspace
+struct LevelLayout {
+  long long ncell, nw, nblk;
+  int nchunks;
+  size_t words_bytes, bprefix_bytes, chunk_bytes;  // chunk_bytes covers chunk_sums (nchunks) and cprefix (nchunks + 1)
+};
+
+int level_layout(int batch, const int32_t* shape, LevelLayout* o) {
+  const long long vol = (long long)shape[0] * shape[1] * shape[2];
+  if (vol >= 0x7fffffffLL) {
+    btc_set_error("rulebook: a single scene's grid of %lld cells exceeds the 31-bit per-scene cell index", vol);
+    return BTC_ERANGE;
+  }
+  o->ncell = vol * batch;
+  o->nw = (o->ncell + 31) / 32;
+  o->nblk = (o->nw + RB_BLK - 1) / RB_BLK;
+  const long long nch = (o->nblk + RB_CHUNK - 1) / RB_CHUNK;
+  if (nch >= 0x7fffffffLL || o->ncell / 8 > (1ll << 40)) {
+    btc_set_error("rulebook: batch * grid of %lld cells is too large", o->ncell);
+    return BTC_ERANGE;
+  }
+  o->nchunks = (int)nch;
+  o->words_bytes = btc_align((size_t)o->nblk * RB_BLK * sizeof(unsigned));
+  o->bprefix_bytes = btc_align((size_t)o->nblk * sizeof(int32_t));
+  o->chunk_bytes = btc_align((size_t)(2 * o->nchunks + 1) * sizeof(int32_t));
+  return BTC_OK;
+}
+
+Level make_level(const LevelLayout& lo, const int32_t* shape, unsigned* words, int32_t* bprefix, int32_t* chunk) {
+  Level L;
+  L.words = words;
+  L.bprefix = bprefix;
+  L.cprefix = chunk + lo.nchunks;   // chunk_sums first, then cprefix
+  L.shape[0] = shape[0]; L.shape[1] = shape[1]; L.shape[2] = shape[2];
+  L.vol = shape[0] * shape[1] * shape[2];
+  L.nblk = lo.nblk;
+  return L;
+}
+
+int mark_grid(int n) {
+  int g = btc_cdiv(n > 0 ? n : 1, RB_T);
+  return g > 2048 ? 2048 : g;
+}
+
 }  // namespace
 
 extern "C" int btc_out_shape(const int32_t* in_shape, const int32_t* k, const int32_t* s, const int32_t* p, const int32_t* d,
@@ -198,9 +413,13 @@ extern "C" int btc_out_shape(const int32_t* in_shape, const int32_t* k, const in
   return BTC_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ single SubM rulebook
+// (arbitrary input order: hash)
+static unsigned long long subm_hash_cap(int n) { return btc_pow2_ge((unsigned long long)(n > 0 ? n : 1) * 2); }
+
 extern "C" size_t btc_rulebook_subm_ws_bytes(int n) {
-  unsigned cap = btc_pow2_ge((unsigned long long)(n > 0 ? n : 1) * 2);
-  return 2 * btc_align((size_t)cap * sizeof(int32_t));
+  const unsigned long long cap = subm_hash_cap(n);
+  return btc_align((size_t)cap * sizeof(unsigned long long)) + btc_align((size_t)cap * sizeof(int32_t));
 }
 
 extern "C" int btc_rulebook_subm(const int32_t* indices, int n, int batch, const int32_t* h_shape, const int32_t* h_k,
@@ -212,34 +431,48 @@ extern "C" int btc_rulebook_subm(const int32_t* indices, int n, int batch, const
   if (rc) return rc;
   BTC_CHECK_ARG((h_k[0] & 1) && (h_k[1] & 1) && (h_k[2] & 1), "btc_rulebook_subm: kernel sizes must be odd");
   BTC_CHECK_ARG(ws_bytes >= btc_rulebook_subm_ws_bytes(n), "btc_rulebook_subm: workspace too small");
-  long long vol = (long long)h_shape[0] * h_shape[1] * h_shape[2];
-  if (vol * batch >= 0x7fffffffLL) {
-    btc_set_error("btc_rulebook_subm: batch*grid volume %lld exceeds 32-bit cell keys", vol * batch);
-    return BTC_ERANGE;
-  }
+  LevelLayout lo;
+  rc = level_layout(batch, h_shape, &lo);
+  if (rc) return rc;
   if (n <= 0) return BTC_OK;
-  unsigned cap = btc_pow2_ge((unsigned long long)n * 2);
+  const unsigned long long cap = subm_hash_cap(n);
   BtcCarver cv(ws);
-  int32_t* keys = cv.take<int32_t>(cap);
+  unsigned long long* keys = cv.take<unsigned long long>(cap);
   int32_t* vals = cv.take<int32_t>(cap);
-  BTC_HIP(hipMemsetAsync(keys, 0xFF, (size_t)cap * sizeof(int32_t), stream));
-  subm_insert<<<btc_cdiv(n, 256), 256, 0, stream>>>((const int4*)indices, n, g, cap - 1, keys, vals);
+  BTC_HIP(hipMemsetAsync(keys, 0, (size_t)cap * sizeof(unsigned long long), stream));
+  Level L = make_level(lo, h_shape, nullptr, nullptr, nullptr);
+  rb_hash_insert<<<btc_cdiv(n, RB_T), RB_T, 0, stream>>>((const int4*)indices, n, L, cap - 1, keys, vals);
   BTC_LAUNCH_CHECK();
-  subm_lookup<<<btc_cdiv((long long)n * g.K, 256), 256, 0, stream>>>((const int4*)indices, n, g, cap - 1, keys, vals,
-                                                                     nbr_out, nbr_in);
+  Jobs jobs;
+  jobs.count = 1;
+  Job& J = jobs.j[0];
+  J.type = JOB_SUBM_HASH; J.n = n; J.first_block = 0; J.g = g; J.lvl = L; J.in_idx = (const int4*)indices;
+  J.nbr_out = nbr_out; J.nbr_in = nbr_in; J.keys = keys; J.vals = vals; J.mask = cap - 1;
+  rb_fill<<<btc_cdiv((long long)n * g.K, RB_T), RB_T, 0, stream>>>(jobs);
   BTC_LAUNCH_CHECK();
   return BTC_OK;
 }
 
-static long long conv_nwords(int batch, const int32_t* out_shape) {
-  long long cells = (long long)batch * out_shape[0] * out_shape[1] * out_shape[2];
-  return (cells + 31) / 32;
+// ------------------------------------------------------------------------------------------------ single strided rulebook
+extern "C" size_t btc_rulebook_conv_ws_bytes(int batch, const int32_t* h_out_shape) {
+  LevelLayout lo;
+  if (level_layout(batch, h_out_shape, &lo) != BTC_OK) return 0;
+  return lo.words_bytes + lo.bprefix_bytes + lo.chunk_bytes + 256;
 }
 
-extern "C" size_t btc_rulebook_conv_ws_bytes(int batch, const int32_t* h_out_shape) {
-  long long nw = conv_nwords(batch, h_out_shape);
-  return btc_align((size_t)nw * sizeof(unsigned)) + btc_align((size_t)(nw + 1) * sizeof(int32_t)) +
-         btc_scan_ws_bytes(nw + 1) + btc_bytemap_bytes(nw);
+static int conv_ws_carve(int batch, const int32_t* h_out_shape, void* ws, size_t ws_bytes, LevelLayout* lo, Level* L, int32_t** chunk_sums,
+                         int32_t** counter) {
+  int rc = level_layout(batch, h_out_shape, lo);
+  if (rc) return rc;
+  BTC_CHECK_ARG(ws_bytes >= lo->words_bytes + lo->bprefix_bytes + lo->chunk_bytes + 256, "btc_rulebook_conv: workspace too small");
+  char* base = (char*)ws;
+  unsigned* words = (unsigned*)base;
+  *counter = (int32_t*)(base + lo->words_bytes);                     // cleared together with the words
+  int32_t* bprefix = (int32_t*)(base + lo->words_bytes + 256);
+  int32_t* chunk = (int32_t*)(base + lo->words_bytes + 256 + lo->bprefix_bytes);
+  *chunk_sums = chunk;
+  *L = make_level(*lo, h_out_shape, words, bprefix, chunk);
+  return BTC_OK;
 }
 
 extern "C" int btc_rulebook_conv_count(const int32_t* indices, int n, int batch, const int32_t* h_in_shape,
@@ -251,24 +484,19 @@ extern "C" int btc_rulebook_conv_count(const int32_t* indices, int n, int batch,
   BtcGeom g;
   int rc = fill_geom(&g, h_in_shape, h_out_shape, h_k, h_s, h_p, h_d, mode);
   if (rc) return rc;
-  BTC_CHECK_ARG(ws_bytes >= btc_rulebook_conv_ws_bytes(batch, h_out_shape), "btc_rulebook_conv_count: workspace too small");
-  long long ovol = (long long)h_out_shape[0] * h_out_shape[1] * h_out_shape[2];
-  if (ovol * batch >= 0x7fffffffLL) {
-    btc_set_error("btc_rulebook_conv: batch*out volume %lld exceeds 32-bit cell keys", ovol * batch);
-    return BTC_ERANGE;
-  }
-  long long nw = conv_nwords(batch, h_out_shape);
-  BtcCarver cv(ws);
-  unsigned* bitmap = cv.take<unsigned>(nw);
-  int32_t* prefix = cv.take<int32_t>(nw + 1);
-  void* scan_ws = cv.take<char>(btc_scan_ws_bytes(nw + 1));
-  unsigned char* bytemap = cv.take<unsigned char>(btc_bytemap_bytes(nw));
-  BTC_HIP(hipMemsetAsync(bytemap, 0, btc_bytemap_bytes(nw), stream));
+  LevelLayout lo;
+  Level L;
+  int32_t *chunk_sums, *counter;
+  rc = conv_ws_carve(batch, h_out_shape, ws, ws_bytes, &lo, &L, &chunk_sums, &counter);
+  if (rc) return rc;
+  BTC_HIP(hipMemsetAsync(L.words, 0, lo.words_bytes + 256, stream));
   if (n > 0) {
-    conv_mark<<<btc_cdiv((long long)n * g.K, 256), 256, 0, stream>>>((const int4*)indices, n, g, (int)ovol, bytemap);
+    rb_mark<<<mark_grid(n), RB_T, 0, stream>>>((const int4*)indices, n, nullptr, g, L);
     BTC_LAUNCH_CHECK();
   }
-  return btc_bytemap_to_ranked_bitmap(bytemap, nw, bitmap, prefix, d_n_out, scan_ws, stream);
+  rb_scan<<<lo.nchunks, RB_T, 0, stream>>>(L, chunk_sums, counter, lo.nchunks, d_n_out);
+  BTC_LAUNCH_CHECK();
+  return BTC_OK;
 }
 
 extern "C" int btc_rulebook_conv_fill(const int32_t* indices, int n, int batch, const int32_t* h_in_shape,
@@ -280,49 +508,327 @@ extern "C" int btc_rulebook_conv_fill(const int32_t* indices, int n, int batch, 
   BtcGeom g;
   int rc = fill_geom(&g, h_in_shape, h_out_shape, h_k, h_s, h_p, h_d, mode);
   if (rc) return rc;
-  BTC_CHECK_ARG(ws_bytes >= btc_rulebook_conv_ws_bytes(batch, h_out_shape), "btc_rulebook_conv_fill: workspace too small");
-  long long ovol = (long long)h_out_shape[0] * h_out_shape[1] * h_out_shape[2];
-  long long nw = conv_nwords(batch, h_out_shape);
-  BtcCarver cv(ws);
-  unsigned* bitmap = cv.take<unsigned>(nw);
-  int32_t* prefix = cv.take<int32_t>(nw + 1);
-  if (n_out > 0) BTC_HIP(hipMemsetAsync(nbr_out, 0xFF, (size_t)n_out * g.K * sizeof(int32_t), stream));
-  if (n > 0) {
-    conv_fill<<<btc_cdiv((long long)n * g.K, 256), 256, 0, stream>>>((const int4*)indices, n, g, (int)ovol, bitmap, prefix,
-                                                                     nbr_out, nbr_in);
+  LevelLayout lo;
+  Level L;
+  int32_t *chunk_sums, *counter;
+  rc = conv_ws_carve(batch, h_out_shape, ws, ws_bytes, &lo, &L, &chunk_sums, &counter);
+  if (rc) return rc;
+  if (n_out > 0) {
+    BTC_HIP(hipMemsetAsync(nbr_out, 0xFF, (size_t)n_out * g.K * sizeof(int32_t), stream));
+    rb_emit<<<btc_cdiv(lo.nblk, RB_T), RB_T, 0, stream>>>(L, (int4*)out_indices, (long long)n_out, 0, g, L);
     BTC_LAUNCH_CHECK();
   }
-  if (n_out > 0) {
-    conv_out_indices<<<btc_cdiv(nw, 256), 256, 0, stream>>>(bitmap, prefix, nw, g, (int)ovol, (int4*)out_indices);
+  if (n > 0) {
+    Jobs jobs;
+    jobs.count = 1;
+    Job& J = jobs.j[0];
+    J.type = JOB_STRIDED; J.n = n; J.first_block = 0; J.g = g; J.lvl = L; J.in_idx = (const int4*)indices;
+    J.nbr_out = nbr_out; J.nbr_in = nbr_in; J.keys = nullptr; J.vals = nullptr; J.mask = 0;
+    rb_fill<<<btc_cdiv((long long)n * g.K, RB_T), RB_T, 0, stream>>>(jobs);
     BTC_LAUNCH_CHECK();
   }
   return BTC_OK;
 }
 
-// pairs/pair_num view; allocates nothing: uses hipMallocAsync-free path -> caller-provided buffers only.
-// Scratch for the K*(n_out+1) flags + scan is taken from the tail of `pairs` is NOT possible (sizes
-// differ), so this debugging/inspection entry point allocates its scratch with hipMalloc (it is not on
-// the training path; the apply kernels consume nbr_out / nbr_in directly).
-extern "C" int btc_pairs_from_nbr(const int32_t* nbr_out, int n_out, int K, int n_in, int32_t* pairs, int32_t* pair_num,
-                                  void* stream_) {
+// ------------------------------------------------------------------------------------------------ a chain of layers
+// Levels: 0 = the chain's input rows (arbitrary order, hash); every kind-1 layer creates a new level.
+namespace {
+
+struct ChainPlan {
+  int n_layers;
+  int lvl_in[BTC_CHAIN_MAX_LAYERS], lvl_out[BTC_CHAIN_MAX_LAYERS];   // level ids per layer
+  int n_levels;                                                      // including level 0
+  int producer[BTC_CHAIN_MAX_LAYERS + 1];                            // level -> layer that builds it (-1 for level 0)
+  bool need_hash;
+};
+
+int chain_plan(const BtcChainLayer* layers, int n_layers, ChainPlan* P) {
+  BTC_CHECK_ARG(n_layers >= 1 && n_layers <= BTC_CHAIN_MAX_LAYERS, "chain: 1..%d layers", BTC_CHAIN_MAX_LAYERS);
+  P->n_layers = n_layers;
+  P->n_levels = 1;
+  P->producer[0] = -1;
+  P->need_hash = false;
+  int cur = 0;
+  for (int i = 0; i < n_layers; ++i) {
+    const BtcChainLayer& l = layers[i];
+    if (l.kind == 0) {
+      BTC_CHECK_ARG((l.k[0] & 1) && (l.k[1] & 1) && (l.k[2] & 1), "chain: submanifold kernel sizes must be odd");
+      P->lvl_in[i] = P->lvl_out[i] = cur;
+      if (cur == 0) P->need_hash = true;
+    } else if (l.kind == 1) {
+      BTC_CHECK_ARG(l.mode == BTC_MODE_CONV || l.mode == BTC_MODE_TRANSPOSE, "chain: layer %d: bad mode", i);
+      P->lvl_in[i] = cur;
+      cur = P->n_levels++;
+      P->producer[cur] = i;
+      P->lvl_out[i] = cur;
+    } else if (l.kind == 2 || l.kind == 3) {
+      BTC_CHECK_ARG(l.ref >= 0 && l.ref < i, "chain: layer %d: bad reference", i);
+      const int r = l.ref;
+      P->lvl_in[i] = l.kind == 2 ? P->lvl_out[r] : P->lvl_in[r];
+      P->lvl_out[i] = l.kind == 2 ? P->lvl_in[r] : P->lvl_out[r];
+      cur = P->lvl_out[i];
+    } else {
+      btc_set_error("chain: layer %d: bad kind %d", i, l.kind);
+      return BTC_EINVAL;
+    }
+  }
+  return BTC_OK;
+}
+
+struct ChainWs {
+  LevelLayout lo[BTC_CHAIN_MAX_LAYERS + 1];
+  Level lv[BTC_CHAIN_MAX_LAYERS + 1];
+  int32_t* chunk_sums[BTC_CHAIN_MAX_LAYERS + 1];
+  int32_t* counters;            // one per level
+  unsigned long long* keys;
+  int32_t* vals;
+  unsigned long long hash_cap;
+  size_t zero_bytes;            // leading region cleared by one memset: all bitmaps, the counters, the hash keys
+  size_t total_bytes;
+};
+
+int chain_ws(const BtcChainLayer* layers, const ChainPlan& P, int batch, int n0, void* ws, ChainWs* W) {
+  size_t off = 0;
+  char* base = (char*)ws;
+  for (int lv = 1; lv < P.n_levels; ++lv) {   // bitmaps first (zeroed region)
+    const BtcChainLayer& l = layers[P.producer[lv]];
+    int rc = level_layout(batch, l.out_shape, &W->lo[lv]);
+    if (rc) return rc;
+    W->lv[lv].words = (unsigned*)(base + off);
+    off += W->lo[lv].words_bytes;
+  }
+  W->counters = (int32_t*)(base + off);
+  off += btc_align((size_t)(BTC_CHAIN_MAX_LAYERS + 1) * sizeof(int32_t));
+  W->hash_cap = P.need_hash ? subm_hash_cap(n0) : 0;
+  W->keys = (unsigned long long*)(base + off);
+  off += btc_align((size_t)W->hash_cap * sizeof(unsigned long long));
+  W->zero_bytes = off;
+  W->vals = (int32_t*)(base + off);
+  off += btc_align((size_t)W->hash_cap * sizeof(int32_t));
+  for (int lv = 1; lv < P.n_levels; ++lv) {
+    const BtcChainLayer& l = layers[P.producer[lv]];
+    unsigned* words = W->lv[lv].words;
+    int32_t* bprefix = (int32_t*)(base + off);
+    off += W->lo[lv].bprefix_bytes;
+    int32_t* chunk = (int32_t*)(base + off);
+    off += W->lo[lv].chunk_bytes;
+    W->chunk_sums[lv] = chunk;
+    W->lv[lv] = make_level(W->lo[lv], l.out_shape, words, bprefix, chunk);
+  }
+  W->total_bytes = off;
+  return BTC_OK;
+}
+
+BtcGeom geom_of(const BtcChainLayer& l) {
+  BtcGeom g;
+  for (int j = 0; j < 3; ++j) {
+    g.in_shape[j] = l.in_shape[j]; g.out_shape[j] = l.out_shape[j]; g.k[j] = l.k[j];
+    g.s[j] = l.s[j]; g.p[j] = l.p[j]; g.d[j] = l.d[j];
+  }
+  g.K = l.k[0] * l.k[1] * l.k[2];
+  g.mode = l.mode;
+  return g;
+}
+
+}  // namespace
+
+extern "C" size_t btc_chain_ws_bytes(const BtcChainLayer* layers, int n_layers, int batch, int n0) {
+  ChainPlan P;
+  if (chain_plan(layers, n_layers, &P) != BTC_OK) return 0;
+  ChainWs W;
+  if (chain_ws(layers, P, batch, n0, nullptr, &W) != BTC_OK) return 0;
+  return W.total_bytes + 256;
+}
+
+extern "C" int btc_chain_caps(const BtcChainLayer* layers, int n_layers, int batch, int n0, int64_t* h_cap) {
+  ChainPlan P;
+  int rc = chain_plan(layers, n_layers, &P);
+  if (rc) return rc;
+  long long cap_of[BTC_CHAIN_MAX_LAYERS + 1];
+  cap_of[0] = n0;
+  for (int i = 0; i < n_layers; ++i) {
+    h_cap[i] = 0;
+    if (layers[i].kind != 1) continue;
+    const long long K = (long long)layers[i].k[0] * layers[i].k[1] * layers[i].k[2];
+    const long long cells = (long long)batch * layers[i].out_shape[0] * layers[i].out_shape[1] * layers[i].out_shape[2];
+    long long c = cap_of[P.lvl_in[i]] * K;
+    if (c > cells) c = cells;
+    if (c < 1) c = 1;
+    cap_of[P.lvl_out[i]] = c;
+    h_cap[i] = c;
+  }
+  return BTC_OK;
+}
+
+extern "C" int btc_chain_levels(const int32_t* indices, int n0, int batch, const BtcChainLayer* layers, int n_layers,
+                                int32_t* const* out_indices, const int64_t* h_cap, int32_t* d_counts, void* ws, size_t ws_bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  ChainPlan P;
+  int rc = chain_plan(layers, n_layers, &P);
+  if (rc) return rc;
+  ChainWs W;
+  rc = chain_ws(layers, P, batch, n0, ws, &W);
+  if (rc) return rc;
+  BTC_CHECK_ARG(ws_bytes >= W.total_bytes, "btc_chain_levels: workspace too small");
+  BTC_HIP(hipMemsetAsync(ws, 0, W.zero_bytes, stream));
+  if (P.need_hash && n0 > 0) {
+    // level 0's grid is the input shape of the first layer that runs on it
+    int first = -1;
+    for (int i = 0; i < n_layers && first < 0; ++i)
+      if (P.lvl_in[i] == 0 && layers[i].kind <= 1) first = i;
+    LevelLayout l0;
+    rc = level_layout(batch, layers[first].in_shape, &l0);
+    if (rc) return rc;
+    Level L0 = make_level(l0, layers[first].in_shape, nullptr, nullptr, nullptr);
+    rb_hash_insert<<<btc_cdiv(n0, RB_T), RB_T, 0, stream>>>((const int4*)indices, n0, L0, W.hash_cap - 1, W.keys, W.vals);
+    BTC_LAUNCH_CHECK();
+  }
+  bool emitted[BTC_CHAIN_MAX_LAYERS + 1] = {false};
+  emitted[0] = true;
+  auto emit = [&](int lv, int fused_layer) -> int {
+    const int prod = P.producer[lv];
+    BtcGeom g = fused_layer >= 0 ? geom_of(layers[fused_layer]) : geom_of(layers[prod]);
+    const Level& next = fused_layer >= 0 ? W.lv[P.lvl_out[fused_layer]] : W.lv[lv];
+    rb_emit<<<btc_cdiv(W.lo[lv].nblk, RB_T), RB_T, 0, stream>>>(W.lv[lv], (int4*)out_indices[prod], (long long)h_cap[prod], fused_layer >= 0 ? 1 : 0,
+                                                                g, next);
+    BTC_LAUNCH_CHECK();
+    emitted[lv] = true;
+    return BTC_OK;
+  };
+  for (int i = 0; i < n_layers; ++i) {
+    if (layers[i].kind != 1) continue;
+    const int li = P.lvl_in[i], lo = P.lvl_out[i];
+    const BtcGeom g = geom_of(layers[i]);
+    if (li == 0) {
+      if (n0 > 0) {
+        rb_mark<<<mark_grid(n0), RB_T, 0, stream>>>((const int4*)indices, n0, nullptr, g, W.lv[lo]);
+        BTC_LAUNCH_CHECK();
+      }
+    } else if (!emitted[li]) {
+      rc = emit(li, i);   // the rows of level li mark level lo as they are written
+      if (rc) return rc;
+    } else {
+      const int prod = P.producer[li];
+      rb_mark<<<mark_grid((int)(h_cap[prod] > (1 << 20) ? (1 << 20) : h_cap[prod])), RB_T, 0, stream>>>((const int4*)out_indices[prod], 0, d_counts + prod, g,
+                                                                                                  W.lv[lo]);
+      BTC_LAUNCH_CHECK();
+    }
+    rb_scan<<<W.lo[lo].nchunks, RB_T, 0, stream>>>(W.lv[lo], W.chunk_sums[lo], W.counters + lo, W.lo[lo].nchunks, d_counts + i);
+    BTC_LAUNCH_CHECK();
+  }
+  for (int lv = 1; lv < P.n_levels; ++lv)
+    if (!emitted[lv]) {
+      rc = emit(lv, -1);
+      if (rc) return rc;
+    }
+  return BTC_OK;
+}
+
+extern "C" int btc_chain_maps(const int32_t* indices, int n0, int batch, const BtcChainLayer* layers, int n_layers, const int32_t* h_counts,
+                              int32_t* const* out_indices, int32_t* const* nbr_out, int32_t* const* nbr_in, void* ws, size_t ws_bytes,
+                              void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  ChainPlan P;
+  int rc = chain_plan(layers, n_layers, &P);
+  if (rc) return rc;
+  ChainWs W;
+  rc = chain_ws(layers, P, batch, n0, ws, &W);
+  if (rc) return rc;
+  BTC_CHECK_ARG(ws_bytes >= W.total_bytes, "btc_chain_maps: workspace too small");
+  int rows_of[BTC_CHAIN_MAX_LAYERS + 1];
+  const int32_t* idx_of[BTC_CHAIN_MAX_LAYERS + 1];
+  rows_of[0] = n0;
+  idx_of[0] = indices;
+  for (int lv = 1; lv < P.n_levels; ++lv) {
+    rows_of[lv] = h_counts[P.producer[lv]];
+    idx_of[lv] = out_indices[P.producer[lv]];
+  }
+  // nbr_out of the strided layers starts as -1; adjacent buffers are cleared by one memset
+  {
+    char* run_begin = nullptr;
+    size_t run_bytes = 0;
+    for (int i = 0; i <= n_layers; ++i) {
+      char* p = nullptr;
+      size_t bytes = 0;
+      if (i < n_layers && layers[i].kind == 1 && h_counts[i] > 0) {
+        p = (char*)nbr_out[i];
+        bytes = (size_t)h_counts[i] * layers[i].k[0] * layers[i].k[1] * layers[i].k[2] * sizeof(int32_t);
+      } else if (i < n_layers) {
+        continue;
+      }
+      if (p && run_begin && p >= run_begin + run_bytes && (size_t)(p - (run_begin + run_bytes)) < 256) {
+        run_bytes = (size_t)(p - run_begin) + bytes;   // contiguous up to alignment padding
+      } else {
+        if (run_begin) BTC_HIP(hipMemsetAsync(run_begin, 0xFF, run_bytes, stream));
+        run_begin = p;
+        run_bytes = bytes;
+      }
+    }
+  }
+  Jobs jobs;
+  jobs.count = 0;
+  long long blocks = 0;
+  auto flush = [&]() -> int {
+    if (jobs.count == 0) return BTC_OK;
+    rb_fill<<<(unsigned)blocks, RB_T, 0, stream>>>(jobs);
+    BTC_LAUNCH_CHECK();
+    jobs.count = 0;
+    blocks = 0;
+    return BTC_OK;
+  };
+  for (int i = 0; i < n_layers; ++i) {
+    if (layers[i].kind > 1) continue;
+    const int li = P.lvl_in[i];
+    const int n = rows_of[li];
+    if (n <= 0) continue;
+    const BtcGeom g = geom_of(layers[i]);
+    const long long nb = btc_cdiv((long long)n * g.K, RB_T);
+    if (jobs.count == RB_MAX_JOBS || blocks + nb > 0x7fffffffLL) {
+      rc = flush();
+      if (rc) return rc;
+    }
+    Job& J = jobs.j[jobs.count++];
+    J.n = n; J.first_block = blocks; J.g = g; J.in_idx = (const int4*)idx_of[li];
+    J.nbr_out = nbr_out[i]; J.nbr_in = nbr_in[i]; J.keys = W.keys; J.vals = W.vals; J.mask = W.hash_cap ? W.hash_cap - 1 : 0;
+    if (layers[i].kind == 1) {
+      J.type = JOB_STRIDED;
+      J.lvl = W.lv[P.lvl_out[i]];
+    } else if (li == 0) {
+      J.type = JOB_SUBM_HASH;
+      LevelLayout l0;
+      rc = level_layout(batch, layers[i].in_shape, &l0);
+      if (rc) return rc;
+      J.lvl = make_level(l0, layers[i].in_shape, nullptr, nullptr, nullptr);
+    } else {
+      J.type = JOB_SUBM_RANK;
+      J.lvl = W.lv[li];
+    }
+    blocks += nb;
+  }
+  return flush();
+}
+
+// ------------------------------------------------------------------------------------------------ spconv-layout view
+extern "C" size_t btc_pairs_from_nbr_ws_bytes(int n_out, int K) {
+  const long long cnt = (long long)K * (n_out + 1);
+  return btc_align((size_t)cnt * sizeof(int32_t)) + btc_scan_ws_bytes(cnt);
+}
+
+extern "C" int btc_pairs_from_nbr(const int32_t* nbr_out, int n_out, int K, int n_in, int32_t* pairs, int32_t* pair_num, void* ws,
+                                  size_t ws_bytes, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   BTC_CHECK_ARG(n_out >= 0 && K >= 1 && n_in >= 0, "btc_pairs_from_nbr: bad sizes");
+  BTC_CHECK_ARG(ws_bytes >= btc_pairs_from_nbr_ws_bytes(n_out, K), "btc_pairs_from_nbr: workspace too small");
   if (n_in > 0) BTC_HIP(hipMemsetAsync(pairs, 0xFF, (size_t)2 * K * n_in * sizeof(int32_t), stream));
-  long long cnt = (long long)K * (n_out + 1);
-  int32_t* flags = nullptr;
-  void* scan_ws = nullptr;
-  BTC_HIP(hipMalloc((void**)&flags, (size_t)cnt * sizeof(int32_t)));
-  BTC_HIP(hipMalloc(&scan_ws, btc_scan_ws_bytes(cnt)));
+  const long long cnt = (long long)K * (n_out + 1);
+  BtcCarver cv(ws);
+  int32_t* flags = cv.take<int32_t>(cnt);
+  void* scan_ws = cv.base + cv.off;
   pairs_count<<<btc_cdiv(cnt, 256), 256, 0, stream>>>(nbr_out, n_out, K, flags);
+  BTC_LAUNCH_CHECK();
   int rc = btc_scan_exclusive_i32(flags, flags, cnt, nullptr, scan_ws, stream);
-  if (rc == BTC_OK) {
-    pairs_write<<<btc_cdiv(cnt, 256), 256, 0, stream>>>(nbr_out, flags, n_out, K, n_in, pairs, pair_num);
-  }
-  hipError_t e = hipStreamSynchronize(stream);
-  (void)hipFree(flags);
-  (void)hipFree(scan_ws);
   if (rc) return rc;
-  BTC_HIP(e);
+  pairs_write<<<btc_cdiv(cnt, 256), 256, 0, stream>>>(nbr_out, flags, n_out, K, n_in, pairs, pair_num);
   BTC_LAUNCH_CHECK();
   return BTC_OK;
 }

@@ -132,7 +132,9 @@ class Rulebook(object):
         dev = self.nbr_out.device
         pairs = torch.empty((2, self.K, max(self.n_in, 1)), dtype=torch.int32, device=dev)
         num = torch.empty((self.K,), dtype=torch.int32, device=dev)
-        check(lib().btc_pairs_from_nbr(ptr(self.nbr_out), self.n_out, self.K, self.n_in, ptr(pairs), ptr(num),
+        ws_bytes = lib().btc_pairs_from_nbr_ws_bytes(self.n_out, self.K)
+        ws = workspace(ws_bytes, dev)
+        check(lib().btc_pairs_from_nbr(ptr(self.nbr_out), self.n_out, self.K, self.n_in, ptr(pairs), ptr(num), ptr(ws), ws_bytes,
                                        stream_ptr()), "btc_pairs_from_nbr")
         return pairs[:, :, :self.n_in], num
 

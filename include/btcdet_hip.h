@@ -37,7 +37,7 @@ extern "C" {
 #define BTC_OK 0
 #define BTC_EINVAL (-1)   /* bad argument */
 #define BTC_ELAUNCH (-2)  /* HIP launch / runtime error */
-#define BTC_ERANGE (-3)   /* problem too large for the 32-bit cell keys */
+#define BTC_ERANGE (-3)   /* problem too large for the cell index range (see the entry point) */
 
 #define BTC_MODE_SUBM 0
 #define BTC_MODE_CONV 1       /* also the geometry of SparseMaxPool3d */
@@ -128,18 +128,19 @@ int btc_gather_rows(const float* src, const int32_t* idx, int n_out, int ld, int
 int btc_out_shape(const int32_t* h_in_shape, const int32_t* h_k, const int32_t* h_s, const int32_t* h_p,
                   const int32_t* h_d, const int32_t* h_outpad, int mode, int32_t* h_out_shape);
 
-/* SubM: outputs are the inputs in input order.  Kernel sizes must be odd.
- * nbr_out, nbr_in: (n, K) int32, both fully written.  ws: btc_rulebook_subm_ws_bytes(n). */
+/* SubM: outputs are the inputs in input order (any order: the cell -> row lookup is a hash with 64-bit cell keys).
+ * Kernel sizes must be odd.  nbr_out, nbr_in: (n, K) int32, both fully written.  ws: btc_rulebook_subm_ws_bytes(n). */
 size_t btc_rulebook_subm_ws_bytes(int n);
 int btc_rulebook_subm(const int32_t* indices, int n, int batch, const int32_t* h_shape, const int32_t* h_k,
                       const int32_t* h_d, int32_t* nbr_out, int32_t* nbr_in, void* ws, size_t ws_bytes,
                       void* stream);
 
 /* Regular / transposed conv and pooling geometry, two phases around one 4-byte read-back:
- *   phase 1 (count): marks the set of reachable output cells and ranks it; *d_n_out = n_out.
+ *   phase 1 (count): marks the reachable output cells in a bitmap over the output grid (1 bit per cell) and ranks it
+ *                    (csrc/rulebook.hip, "LEVEL"); *d_n_out = n_out.
  *   phase 2 (fill) : out_indices (n_out,4) ascending in (b,z,y,x); nbr_out (n_out,K); nbr_in (n,K).
- * The same ws (btc_rulebook_conv_ws_bytes(batch, out_shape)) must be passed to both phases,
- * untouched in between. */
+ * The same ws (btc_rulebook_conv_ws_bytes(batch, out_shape) = out volume / 8 bytes + prefixes) must be passed to both
+ * phases, untouched in between.  Limits: one scene's grid < 2^31 cells, batch * grid < 2^43 cells. */
 size_t btc_rulebook_conv_ws_bytes(int batch, const int32_t* h_out_shape);
 int btc_rulebook_conv_count(const int32_t* indices, int n, int batch, const int32_t* h_in_shape,
                             const int32_t* h_out_shape, const int32_t* h_k, const int32_t* h_s,
@@ -150,10 +151,38 @@ int btc_rulebook_conv_fill(const int32_t* indices, int n, int batch, const int32
                            const int32_t* h_p, const int32_t* h_d, int mode, int n_out, int32_t* out_indices,
                            int32_t* nbr_out, int32_t* nbr_in, void* ws, size_t ws_bytes, void* stream);
 
+/* Every rulebook of a CHAIN of sparse layers (an encoder / decoder branch: the layers of
+ * /root/reference/btcdet/models/backbones_3d/spconv_backbone.py:106-128 or :656-767 in execution order) from the input
+ * coordinates alone, with ONE read-back for the whole chain instead of one per strided layer (spconv synchronises in every
+ * get_indice_pairs call).  A layer either builds a submanifold rulebook on the current level (kind 0), builds a strided /
+ * transposed one and moves to the level it creates (kind 1), is the inverse of layer `ref` (kind 2: continues on ref's
+ * input level) or reuses layer ref's rulebook (kind 3: indice_key hit or identical geometry; continues on its output level).
+ *   phase A  btc_chain_levels : builds every level on the device.  out_indices[i] (kind-1 layers; capacity h_cap[i] rows from
+ *            btc_chain_caps, 16 bytes a row) receives the level's rows in ascending (b,z,y,x) order, d_counts[i] its row
+ *            count.  Nothing is read back; level l+1 is marked by the kernel that emits the rows of level l.
+ *   -- the caller copies d_counts (n_layers int32) to the host and sizes the maps --
+ *   phase B  btc_chain_maps   : nbr_out[i] (rows_out_i, K_i) and nbr_in[i] (rows_in_i, K_i) of every kind-0 / kind-1 layer in
+ *            one multi-job launch (+ the -1 fill of the strided layers' nbr_out: hand in adjacent buffers to make it one).
+ * ws (btc_chain_ws_bytes) must be the same, untouched, for both phases. */
+#define BTC_CHAIN_MAX_LAYERS 32
+typedef struct BtcChainLayer {
+  int32_t kind, ref, mode;
+  int32_t in_shape[3], out_shape[3], k[3], s[3], p[3], d[3];
+} BtcChainLayer;
+size_t btc_chain_ws_bytes(const BtcChainLayer* h_layers, int n_layers, int batch, int n0);
+int btc_chain_caps(const BtcChainLayer* h_layers, int n_layers, int batch, int n0, int64_t* h_cap);
+int btc_chain_levels(const int32_t* indices, int n0, int batch, const BtcChainLayer* h_layers, int n_layers,
+                     int32_t* const* h_out_indices, const int64_t* h_cap, int32_t* d_counts, void* ws, size_t ws_bytes, void* stream);
+int btc_chain_maps(const int32_t* indices, int n0, int batch, const BtcChainLayer* h_layers, int n_layers, const int32_t* h_counts,
+                   int32_t* const* h_out_indices, int32_t* const* h_nbr_out, int32_t* const* h_nbr_in, void* ws, size_t ws_bytes,
+                   void* stream);
+
 /* spconv-layout view of a rulebook: pairs (2,K,n_in) int32 padded with -1, pair_num (K) int32,
- * pairs within an offset ordered by output row (the canonical order of SURVEY.md App. B.4). */
-int btc_pairs_from_nbr(const int32_t* nbr_out, int n_out, int K, int n_in, int32_t* pairs, int32_t* pair_num,
-                       void* stream);
+ * pairs within an offset ordered by output row (the canonical order of SURVEY.md App. B.4).
+ * ws: btc_pairs_from_nbr_ws_bytes(n_out, K); enqueued like everything else (no allocation, no synchronisation). */
+size_t btc_pairs_from_nbr_ws_bytes(int n_out, int K);
+int btc_pairs_from_nbr(const int32_t* nbr_out, int n_out, int K, int n_in, int32_t* pairs, int32_t* pair_num, void* ws,
+                       size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Sparse convolution apply.  Replaces spconv's indice_conv / indice_subm_conv /
