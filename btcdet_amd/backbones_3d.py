@@ -146,7 +146,7 @@ class VoxelBackBoneDeconv(nn.Module):
         stages = (self.conv1, self.conv2, self.conv3, self.deconv4, self.deconv5)
         bs = batch_dict['batch_size']
         merged_head = head is not None and hasattr(head, "_merge_ok") and head._merge_ok()
-        if sp_ops.fast() is not None and sp_ops.PROFILE is None and (head is None or merged_head or hasattr(head, "conv_cls")):
+        if sp_ops.fast() is not None and (head is None or merged_head or hasattr(head, "conv_cls")):
             # one call of the compiled binding for all rulebooks (spconv/geometry.py); the plan is fixed per (model, batch size)
             from .spconv.geometry import GeometryPlan, flatten_convs
             plans = self.__dict__.setdefault("_geometry_plans", {})
@@ -255,7 +255,7 @@ class VoxelBackBone8xOcc(nn.Module):
         down2 / down3 / down_combine layers reuse these rulebooks through the geometry cache / their indice_keys as before.
         False when the compiled binding is not in use (the layers then build their rulebooks one by one, with lookahead)."""
         from .spconv import ops as sp_ops
-        if not (DET_GEOMETRY_WALK and coords.is_cuda and sp_ops.fast() is not None and sp_ops.PROFILE is None and sp_ops.CAPTURE is None):
+        if not (DET_GEOMETRY_WALK and coords.is_cuda and sp_ops.fast() is not None and sp_ops.CAPTURE is None):
             return False
         from .spconv.geometry import GeometryPlan, flatten_convs
         plans = self.__dict__.setdefault("_geometry_plans", {})

@@ -23,7 +23,7 @@
 //
 // A whole chain of layers (an encoder / decoder branch) is built in two phases around ONE read-back (btc_chain_levels /
 // btc_chain_maps): phase A builds every level on the device, each level's row count staying in device memory and the rows
-// of level l marking level l+1 from inside the kernel that emits them; the host reads all counts at once, sizes the maps,
+// of level l marking level l+1 with their count read from device memory; the host reads all counts at once, sizes the maps,
 // and phase B fills every neighbour map of the chain in one multi-job launch.
 #include "btc_common.h"
 
@@ -64,60 +64,92 @@ __device__ __forceinline__ int lvl_rank(const Level& L, long long cell) {
   return r;
 }
 
-// forward map of a geometry: input cell + offset -> output cell (CONV: divisibility; TRANSPOSE: always integral)
-__device__ __forceinline__ bool fwd_cell(const BtcGeom& g, int z, int y, int x, int kk, int* oz, int* oy, int* ox) {
-  const int kx = kk % g.k[2];
-  const int ky = (kk / g.k[2]) % g.k[1];
-  const int kz = kk / (g.k[2] * g.k[1]);
-  const int c[3] = {z, y, x};
-  const int kv[3] = {kz, ky, kx};
-  int o[3];
-#pragma unroll
-  for (int j = 0; j < 3; ++j) {
-    if (g.mode == BTC_MODE_CONV) {
-      const int t = c[j] + g.p[j] - kv[j] * g.d[j];
-      if (t < 0) return false;
-      const int q = t / g.s[j];
-      if (q * g.s[j] != t) return false;
-      o[j] = q;
-    } else {
-      o[j] = c[j] * g.s[j] - g.p[j] + kv[j] * g.d[j];
-    }
-    if (o[j] < 0 || o[j] >= g.out_shape[j]) return false;
-  }
-  *oz = o[0]; *oy = o[1]; *ox = o[2];
-  return true;
+// integer division by the small runtime constants of a geometry is ~40 instructions on this ISA: the common values
+// (stride 1 / 2, 3x3x3 kernels) take shift / multiply paths
+__device__ __forceinline__ bool div_stride(int t, int s, int* q) {
+  if (s == 1) { *q = t; return true; }
+  if (s == 2) { *q = t >> 1; return !(t & 1); }
+  const int v = t / s;
+  *q = v;
+  return v * s == t;
 }
 
-// every cell an input row reaches, OR-ed into the output level's bitmap; bits of one word are merged in registers, and a
-// word that already holds them is not touched again (stride 2: ~8 inputs share an output cell)
-__device__ __forceinline__ void mark_row(const BtcGeom& g, const Level& out, int b, int z, int y, int x) {
+__device__ __forceinline__ void split_offset(const BtcGeom& g, int kk, int* kz, int* ky, int* kx) {
+  if (g.k[2] == 3 && g.k[1] == 3) {
+    *kx = kk % 3; *ky = (kk / 3) % 3; *kz = kk / 9;
+  } else if (g.k[2] == 1 && g.k[1] == 1) {
+    *kx = 0; *ky = 0; *kz = kk;
+  } else {
+    *kx = kk % g.k[2]; *ky = (kk / g.k[2]) % g.k[1]; *kz = kk / (g.k[2] * g.k[1]);
+  }
+}
+
+__device__ __forceinline__ void split_item(long long t, int K, int* i, int* kk) {
+  if (K == 27) { const long long q = t / 27; *i = (int)q; *kk = (int)(t - q * 27); }
+  else if (K == 1) { *i = (int)t; *kk = 0; }
+  else { const long long q = t / K; *i = (int)q; *kk = (int)(t - q * K); }
+}
+
+// one axis of the forward map: input coordinate + kernel offset -> output coordinate (CONV: divisibility; TRANSPOSE: integral)
+__device__ __forceinline__ bool fwd_axis(const BtcGeom& g, int j, int c, int kv, int* o) {
+  int q;
+  if (g.mode == BTC_MODE_CONV) {
+    const int t = c + g.p[j] - kv * g.d[j];
+    if (t < 0 || !div_stride(t, g.s[j], &q)) return false;
+  } else {
+    q = c * g.s[j] - g.p[j] + kv * g.d[j];
+  }
+  *o = q;
+  return q >= 0 && q < g.out_shape[j];
+}
+
+__device__ __forceinline__ bool fwd_cell(const BtcGeom& g, int z, int y, int x, int kk, int* oz, int* oy, int* ox) {
+  int kz, ky, kx;
+  split_offset(g, kk, &kz, &ky, &kx);
+  return fwd_axis(g, 0, z, kz, oz) && fwd_axis(g, 1, y, ky, oy) && fwd_axis(g, 2, x, kx, ox);
+}
+
+__device__ __forceinline__ void or_word(unsigned* words, long long w, unsigned bits) {
+  if ((__hip_atomic_load(&words[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bits) != bits) atomicOr(&words[w], bits);
+}
+
+// every cell an input row reaches along one (kz, ky) line of the kernel, OR-ed into the output level's bitmap; the bits of
+// one word are merged in registers, and a word that already holds them is not touched again (stride 2: ~8 inputs share an
+// output cell).  The axes are resolved once each (no per-offset divisions).
+__device__ __forceinline__ void mark_line(const BtcGeom& g, const Level& out, int b, int z, int y, int x, int kz, int ky) {
+  int oz, oy;
+  if (!fwd_axis(g, 0, z, kz, &oz) || !fwd_axis(g, 1, y, ky, &oy)) return;
+  const long long line = lvl_cell(out, b, oz, oy, 0);
   long long cur_w = -1;
   unsigned cur_bits = 0;
-  for (int kk = 0; kk < g.K; ++kk) {
-    int oz, oy, ox;
-    if (!fwd_cell(g, z, y, x, kk, &oz, &oy, &ox)) continue;
-    const long long cell = lvl_cell(out, b, oz, oy, ox);
+  for (int kx = 0; kx < g.k[2]; ++kx) {
+    int ox;
+    if (!fwd_axis(g, 2, x, kx, &ox)) continue;
+    const long long cell = line + ox;
     const long long w = cell >> 5;
-    const unsigned bit = 1u << ((unsigned)cell & 31u);
     if (w != cur_w) {
-      if (cur_bits && (__hip_atomic_load(&out.words[cur_w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & cur_bits) != cur_bits)
-        atomicOr(&out.words[cur_w], cur_bits);
+      if (cur_bits) or_word(out.words, cur_w, cur_bits);
       cur_w = w;
       cur_bits = 0;
     }
-    cur_bits |= bit;
+    cur_bits |= 1u << ((unsigned)cell & 31u);
   }
-  if (cur_bits && (__hip_atomic_load(&out.words[cur_w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & cur_bits) != cur_bits)
-    atomicOr(&out.words[cur_w], cur_bits);
+  if (cur_bits) or_word(out.words, cur_w, cur_bits);
 }
 
-// n rows: from d_n (device, the count of the producing level) when given, else n_host
+// n rows: from d_n (device, the count of the producing level) when given, else n_host; one thread per (row, kz, ky)
 __global__ __launch_bounds__(RB_T) void rb_mark(const int4* __restrict__ idx, int n_host, const int32_t* __restrict__ d_n, BtcGeom g, Level out) {
   const int n = d_n ? *d_n : n_host;
-  for (int i = blockIdx.x * RB_T + threadIdx.x; i < n; i += gridDim.x * RB_T) {
+  const int lines = g.k[0] * g.k[1];
+  const long long total = (long long)n * lines;
+  for (long long t = (long long)blockIdx.x * RB_T + threadIdx.x; t < total; t += (long long)gridDim.x * RB_T) {
+    int i, l;
+    if (lines == 9) { const long long q = t / 9; i = (int)q; l = (int)(t - q * 9); }
+    else { const long long q = t / lines; i = (int)q; l = (int)(t - q * lines); }
+    const int kz = (g.k[1] == 3) ? l / 3 : l / g.k[1];
+    const int ky = l - kz * g.k[1];
     const int4 c = idx[i];
-    mark_row(g, out, c.x, c.y, c.z, c.w);
+    mark_line(g, out, c.x, c.y, c.z, c.w, kz, ky);
   }
 }
 
@@ -189,32 +221,33 @@ __global__ __launch_bounds__(RB_T) void rb_scan(Level L, int32_t* __restrict__ c
   }
 }
 
-// rows of a scanned level in ascending cell order; with `fused`, every emitted row also marks the NEXT level of the chain
-__global__ __launch_bounds__(RB_T) void rb_emit(Level L, int4* __restrict__ out_idx, long long cap, int fused, BtcGeom g_next, Level next) {
-  const long long blk = (long long)blockIdx.x * RB_T + threadIdx.x;
-  if (blk >= L.nblk) return;
+// rows of a scanned level in ascending cell order: one thread per bitmap word (its rank base = chunk prefix + block prefix +
+// the words in front of it inside the 32-byte block)
+__global__ __launch_bounds__(RB_T) void rb_emit(Level L, int4* __restrict__ out_idx, long long cap) {
+  const long long w = (long long)blockIdx.x * RB_T + threadIdx.x;
+  if (w >= L.nblk * RB_BLK) return;
+  unsigned bits = L.words[w];
+  if (!bits) return;
+  const long long blk = w >> 3;
+  const int wi = (int)(w & 7);
   const uint4* p = reinterpret_cast<const uint4*>(L.words + blk * RB_BLK);
   const uint4 a = p[0], b = p[1];
   const unsigned ws[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-  if (!(ws[0] | ws[1] | ws[2] | ws[3] | ws[4] | ws[5] | ws[6] | ws[7])) return;
   long long row = (long long)L.cprefix[blk / RB_CHUNK] + L.bprefix[blk];
-  const int hw = L.shape[1] * L.shape[2];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    unsigned bits = ws[j];
-    while (bits) {
-      const int bit = __ffs(bits) - 1;
-      bits &= bits - 1;
-      const long long cell = (blk * RB_BLK + j) * 32 + bit;
-      const int bb = (int)(cell / L.vol);
-      const int rem = (int)(cell - (long long)bb * L.vol);
-      const int z = rem / hw;
-      const int r2 = rem - z * hw;
-      const int y = r2 / L.shape[2], x = r2 - y * L.shape[2];
-      if (row < cap) out_idx[row] = make_int4(bb, z, y, x);
-      ++row;
-      if (fused) mark_row(g_next, next, bb, z, y, x);
-    }
+  for (int j = 0; j < 7; ++j) row += (j < wi) ? __popc(ws[j]) : 0;
+  const int hw = L.shape[1] * L.shape[2];
+  while (bits) {
+    const int bit = __ffs(bits) - 1;
+    bits &= bits - 1;
+    const long long cell = w * 32 + bit;
+    const int bb = (int)(cell / L.vol);
+    const int rem = (int)(cell - (long long)bb * L.vol);
+    const int z = rem / hw;
+    const int r2 = rem - z * hw;
+    const int y = r2 / L.shape[2], x = r2 - y * L.shape[2];
+    if (row < cap) out_idx[row] = make_int4(bb, z, y, x);
+    ++row;
   }
 }
 
@@ -283,7 +316,8 @@ __global__ __launch_bounds__(RB_T) void rb_fill(Jobs jobs) {
   const long long t = ((long long)blockIdx.x - J.first_block) * RB_T + threadIdx.x;
   const int K = J.g.K;
   if (t >= (long long)J.n * K) return;
-  const int i = (int)(t / K), kk = (int)(t - (long long)i * K);
+  int i, kk;
+  split_item(t, K, &i, &kk);
   const int4 c = J.in_idx[i];
   if (J.type == JOB_STRIDED) {
     int oz, oy, ox, row = -1;
@@ -294,9 +328,8 @@ __global__ __launch_bounds__(RB_T) void rb_fill(Jobs jobs) {
     J.nbr_in[t] = row;
     return;
   }
-  const int kx = kk % J.g.k[2];
-  const int ky = (kk / J.g.k[2]) % J.g.k[1];
-  const int kz = kk / (J.g.k[2] * J.g.k[1]);
+  int kz, ky, kx;
+  split_offset(J.g, kk, &kz, &ky, &kx);
   const int z = c.y + (kz - J.g.k[0] / 2) * J.g.d[0];
   const int y = c.z + (ky - J.g.k[1] / 2) * J.g.d[1];
   const int x = c.w + (kx - J.g.k[2] / 2) * J.g.d[2];
@@ -395,9 +428,9 @@ Level make_level(const LevelLayout& lo, const int32_t* shape, unsigned* words, i
   return L;
 }
 
-int mark_grid(int n) {
-  int g = btc_cdiv(n > 0 ? n : 1, RB_T);
-  return g > 2048 ? 2048 : g;
+int mark_grid(long long n_lines) {
+  long long g = (n_lines + RB_T - 1) / RB_T;
+  return (int)(g > 4096 ? 4096 : (g < 1 ? 1 : g));
 }
 
 }  // namespace
@@ -491,7 +524,7 @@ extern "C" int btc_rulebook_conv_count(const int32_t* indices, int n, int batch,
   if (rc) return rc;
   BTC_HIP(hipMemsetAsync(L.words, 0, lo.words_bytes + 256, stream));
   if (n > 0) {
-    rb_mark<<<mark_grid(n), RB_T, 0, stream>>>((const int4*)indices, n, nullptr, g, L);
+    rb_mark<<<mark_grid((long long)n * g.k[0] * g.k[1]), RB_T, 0, stream>>>((const int4*)indices, n, nullptr, g, L);
     BTC_LAUNCH_CHECK();
   }
   rb_scan<<<lo.nchunks, RB_T, 0, stream>>>(L, chunk_sums, counter, lo.nchunks, d_n_out);
@@ -515,7 +548,7 @@ extern "C" int btc_rulebook_conv_fill(const int32_t* indices, int n, int batch, 
   if (rc) return rc;
   if (n_out > 0) {
     BTC_HIP(hipMemsetAsync(nbr_out, 0xFF, (size_t)n_out * g.K * sizeof(int32_t), stream));
-    rb_emit<<<btc_cdiv(lo.nblk, RB_T), RB_T, 0, stream>>>(L, (int4*)out_indices, (long long)n_out, 0, g, L);
+    rb_emit<<<btc_cdiv(lo.nblk * RB_BLK, RB_T), RB_T, 0, stream>>>(L, (int4*)out_indices, (long long)n_out);
     BTC_LAUNCH_CHECK();
   }
   if (n > 0) {
@@ -685,12 +718,9 @@ extern "C" int btc_chain_levels(const int32_t* indices, int n0, int batch, const
   }
   bool emitted[BTC_CHAIN_MAX_LAYERS + 1] = {false};
   emitted[0] = true;
-  auto emit = [&](int lv, int fused_layer) -> int {
+  auto emit = [&](int lv) -> int {
     const int prod = P.producer[lv];
-    BtcGeom g = fused_layer >= 0 ? geom_of(layers[fused_layer]) : geom_of(layers[prod]);
-    const Level& next = fused_layer >= 0 ? W.lv[P.lvl_out[fused_layer]] : W.lv[lv];
-    rb_emit<<<btc_cdiv(W.lo[lv].nblk, RB_T), RB_T, 0, stream>>>(W.lv[lv], (int4*)out_indices[prod], (long long)h_cap[prod], fused_layer >= 0 ? 1 : 0,
-                                                                g, next);
+    rb_emit<<<btc_cdiv(W.lo[lv].nblk * RB_BLK, RB_T), RB_T, 0, stream>>>(W.lv[lv], (int4*)out_indices[prod], (long long)h_cap[prod]);
     BTC_LAUNCH_CHECK();
     emitted[lv] = true;
     return BTC_OK;
@@ -701,16 +731,16 @@ extern "C" int btc_chain_levels(const int32_t* indices, int n0, int batch, const
     const BtcGeom g = geom_of(layers[i]);
     if (li == 0) {
       if (n0 > 0) {
-        rb_mark<<<mark_grid(n0), RB_T, 0, stream>>>((const int4*)indices, n0, nullptr, g, W.lv[lo]);
+        rb_mark<<<mark_grid((long long)n0 * g.k[0] * g.k[1]), RB_T, 0, stream>>>((const int4*)indices, n0, nullptr, g, W.lv[lo]);
         BTC_LAUNCH_CHECK();
       }
-    } else if (!emitted[li]) {
-      rc = emit(li, i);   // the rows of level li mark level lo as they are written
-      if (rc) return rc;
     } else {
-      const int prod = P.producer[li];
-      rb_mark<<<mark_grid((int)(h_cap[prod] > (1 << 20) ? (1 << 20) : h_cap[prod])), RB_T, 0, stream>>>((const int4*)out_indices[prod], 0, d_counts + prod, g,
-                                                                                                  W.lv[lo]);
+      if (!emitted[li]) {
+        rc = emit(li);
+        if (rc) return rc;
+      }
+      const int prod = P.producer[li];   // row-parallel over the producing level's rows; their count stays on the device
+      rb_mark<<<mark_grid(h_cap[prod] * g.k[0] * g.k[1]), RB_T, 0, stream>>>((const int4*)out_indices[prod], 0, d_counts + prod, g, W.lv[lo]);
       BTC_LAUNCH_CHECK();
     }
     rb_scan<<<W.lo[lo].nchunks, RB_T, 0, stream>>>(W.lv[lo], W.chunk_sums[lo], W.counters + lo, W.lo[lo].nchunks, d_counts + i);
@@ -718,7 +748,7 @@ extern "C" int btc_chain_levels(const int32_t* indices, int n0, int batch, const
   }
   for (int lv = 1; lv < P.n_levels; ++lv)
     if (!emitted[lv]) {
-      rc = emit(lv, -1);
+      rc = emit(lv);
       if (rc) return rc;
     }
   return BTC_OK;

@@ -73,7 +73,23 @@ class GeometryPlan(object):
     def run(self, indices, indice_dict):
         """build every rulebook of the plan for `indices` and file them in indice_dict (by indice_key) and in its geometry cache"""
         F = ops.fast()
+        prof = ops.PROFILE
+        if prof is not None:   # one span for the whole chain: two phases, one read-back (csrc/rulebook.hip)
+            import torch
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         built = F.geometry_walk(indices, self.batch_size, *self.args)
+        if prof is not None:
+            e1.record()
+            nbytes, rows, pairs, n_rb = 0, 0, 0, 0
+            for b in built:
+                if b:   # SURVEY.md section 8d, rulebook: 16 N_in + 16 N_out + 8 sum_k P_k bytes
+                    p_k = ops._num_pairs(b[2])
+                    nbytes += 16 * b[0].shape[0] + 16 * b[1].shape[0] + 8 * p_k
+                    rows += b[1].shape[0]
+                    pairs += p_k
+                    n_rb += 1
+            prof.records.append(("rulebook", e0, e1, nbytes, 0, dict(rows=rows, pairs=pairs, rulebooks=n_rb, chain=True)))
         geom = indice_dict.setdefault("__geometry_cache__", {})
         rbs = [None] * len(self.convs)
         for i, (conv, (kind, ref, g, in_shape, out_shape)) in enumerate(zip(self.convs, self.entries)):

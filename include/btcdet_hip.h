@@ -159,7 +159,7 @@ int btc_rulebook_conv_fill(const int32_t* indices, int n, int batch, const int32
  * input level) or reuses layer ref's rulebook (kind 3: indice_key hit or identical geometry; continues on its output level).
  *   phase A  btc_chain_levels : builds every level on the device.  out_indices[i] (kind-1 layers; capacity h_cap[i] rows from
  *            btc_chain_caps, 16 bytes a row) receives the level's rows in ascending (b,z,y,x) order, d_counts[i] its row
- *            count.  Nothing is read back; level l+1 is marked by the kernel that emits the rows of level l.
+ *            count.  Nothing is read back; level l+1 is marked from level l's rows with their count taken from d_counts.
  *   -- the caller copies d_counts (n_layers int32) to the host and sizes the maps --
  *   phase B  btc_chain_maps   : nbr_out[i] (rows_out_i, K_i) and nbr_in[i] (rows_in_i, K_i) of every kind-0 / kind-1 layer in
  *            one multi-job launch (+ the -1 fill of the strided layers' nbr_out: hand in adjacent buffers to make it one).

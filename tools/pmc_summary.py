@@ -5,7 +5,7 @@ HBM bytes per launch = 2 * FETCH_SIZE + WRITE_SIZE (KB -> x1024); FETCH_SIZE dou
 prescribes for gfx950 wide coalesced reads; WRITE_SIZE is uncalibrated there."""
 import csv, glob, json, os, sys
 
-FAMILIES = {"conv_apply": ("conv_apply",), "conv_wgrad": ("conv_wgrad", "wgrad_reduce")}
+FAMILIES = {"conv_apply": ("conv_apply",), "conv_wgrad": ("conv_wgrad", "wgrad_reduce"), "rulebook": ("rb_",)}
 
 
 def collect(d, counter):

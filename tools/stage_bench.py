@@ -41,6 +41,22 @@ for n in (30000, 300000, 3000000):
         written = 4 * 27 * (rb.n_in + rb.n_out) + 16 * rb.n_out        # the two dense neighbour maps + output indices actually stored
         out[name] = {"n_out": rb.n_out, "pairs": pairs, "us": round(t * 1e6, 1), "alg_GBps": round(alg / t / 1e9, 1),
                      "stored_map_GBps": round(written / t / 1e9, 1)}
+    # a whole encoder chain (subm, s2, subm, s2, subm, s2, subm) on this active set through the chain entry points: ONE
+    # read-back, levels ranked on the device (csrc/rulebook.hip)
+    if ops.fast() is not None:
+        from btcdet_amd import spconv
+        from btcdet_amd.spconv.geometry import GeometryPlan
+        convs = [spconv.SubMConv3d(4, 4, 3, padding=1, bias=False, indice_key="s1")]
+        for lv in (2, 3, 4):
+            convs += [spconv.SparseConv3d(4, 4, 3, stride=2, padding=1, bias=False, indice_key="c%d" % lv),
+                      spconv.SubMConv3d(4, 4, 3, padding=1, bias=False, indice_key="s%d" % lv)]
+        plan = GeometryPlan(convs, list(grid), 1)
+        rbs = plan.run(I, {})
+        alg = sum(16 * rb.n_in + 16 * rb.n_out + 8 * int((rb.nbr_out >= 0).sum()) for rb in rbs)
+        written = sum(4 * rb.K * (rb.n_in + rb.n_out) + (16 * rb.n_out if rb.mode != 0 else 0) for rb in rbs)
+        t = timed(lambda: plan.run(I, {}))
+        out["chain_7_layers"] = {"rows_per_level": [rb.n_out for rb in rbs[::2]], "us": round(t * 1e6, 1), "alg_GBps": round(alg / t / 1e9, 1),
+                                 "stored_map_GBps": round(written / t / 1e9, 1), "alg_MB": round(alg / 1e6, 1)}
     # voxelizer: 10 points per active cell on average, KITTI-like caps scaled
     pts_n = n * 4
     cell = idx[rng.integers(0, n, pts_n)]
