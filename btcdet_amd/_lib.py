@@ -69,6 +69,7 @@ _SIGS = {
     "btc_last_error": (ctypes.c_char_p, []),
     "btc_version": (ci, []),
     "btc_tune_set": (ci, [ci, ci]),
+    "btc_tune_value": (ci, [ci]),
     "btc_mean_vfe": (ci, [vp, vp, ci, ci, ci, ci, vp, vp]),
     "btc_occ_vfe": (ci, [vp, vp, ci, ci, ci, ci, ci, vp, vp, vp]),
     "btc_boxes_pairwise_bev": (ci, [vp, ci, vp, ci, ci, vp, vp]),
@@ -100,6 +101,10 @@ _SIGS = {
     "btc_conv_fwd_bf16": (ci, [vp, vp, vp, vp, ci, ci, ci, ci, vp, vp]),
     "btc_conv_dgrad_bf16": (ci, [vp, vp, vp, ci, ci, ci, ci, vp, vp]),
     "btc_conv_wgrad_bf16": (ci, [vp, vp, vp, ci, vp, ci, ci, ci, ci, vp, vp, sz, vp]),
+    "btc_conv_bf16w_supported": (ci, [ci, ci, ci]),
+    "btc_weights_to_bf16": (ci, [vp, ci, ci, ci, vp, vp, vp]),
+    "btc_conv_fwd_bf16w": (ci, [vp, vp, vp, vp, ci, ci, ci, ci, vp, vp]),
+    "btc_conv_dgrad_bf16w": (ci, [vp, vp, vp, ci, ci, ci, ci, vp, vp]),
     "btc_maxpool_fwd": (ci, [vp, vp, ci, ci, ci, vp, vp]),
     "btc_maxpool_bwd": (ci, [vp, vp, vp, vp, ci, ci, ci, vp, vp]),
     "btc_dense_fwd": (ci, [vp, vp, ci, ci, c_i32p, vp, vp]),

@@ -14,8 +14,10 @@
 #include <hip/hip_runtime_api.h>
 #include <torch/csrc/autograd/engine.h>
 
+#include <mutex>
 #include <stdexcept>
 #include <string>
+#include <unordered_map>
 #include <cstdio>
 #include <cstdlib>
 #include <memory>
@@ -51,13 +53,54 @@ inline void need(bool ok, const char* msg) {
   if (!ok) throw std::runtime_error(msg);
 }
 
+// bf16 copies of a layer's weights for the bf16-operand kernels (btc_conv_*_bf16w): row 0 = W [K][Cin][Cout] (dgrad operand),
+// row 1 = W^T [K][Cout][Cin] (forward operand).  Converted when first needed after the parameter changed (its version counter
+// moves with every in-place optimizer update / load_state_dict), i.e. once per optimizer step: the forward pass converts,
+// the backward pass of the same step finds the copy.  The weak reference keeps a freed parameter's slot from being taken
+// for a live one.
+struct WqEntry {
+  c10::weak_intrusive_ptr<c10::TensorImpl> weak;
+  uint32_t version;
+  Tensor q;
+  WqEntry(c10::weak_intrusive_ptr<c10::TensorImpl> w, uint32_t v, Tensor t) : weak(std::move(w)), version(v), q(std::move(t)) {}
+};
+std::mutex g_wq_mu;
+std::unordered_map<const void*, WqEntry> g_wq;
+
+bool bf16_operands(const Tensor& features, int64_t K, int64_t cred, int64_t cres) {
+  return features.scalar_type() == at::kBFloat16 && btc_conv_bf16w_supported((int)K, (int)cred, (int)cres) &&
+         btc_tune_value(BTC_TUNE_BF16_OPERANDS) != 1;
+}
+
+Tensor weights_bf16(const Tensor& w, int64_t K, int64_t cin, int64_t cout, int64_t stream) {
+  const void* key = w.unsafeGetTensorImpl();
+  const uint32_t version = (uint32_t)w._version();
+  std::lock_guard<std::mutex> lock(g_wq_mu);
+  auto it = g_wq.find(key);
+  if (it != g_wq.end() && !it->second.weak.expired() && it->second.version == version && it->second.q.get_device() == w.get_device())
+    return it->second.q;
+  Tensor q = (it != g_wq.end() && !it->second.weak.expired() && it->second.q.numel() == 2 * w.numel() && it->second.q.get_device() == w.get_device())
+                 ? it->second.q : at::empty({2, w.numel()}, w.options().dtype(at::kBFloat16));
+  chk(btc_weights_to_bf16((const float*)w.data_ptr(), (int)K, (int)cin, (int)cout, q.data_ptr(), (char*)q.data_ptr() + 2 * w.numel(), st(stream)),
+      "btc_weights_to_bf16");
+  if (it != g_wq.end()) g_wq.erase(it);
+  g_wq.emplace(key, WqEntry(c10::weak_intrusive_ptr<c10::TensorImpl>(w.getIntrusivePtr()), version, q));
+  if (g_wq.size() > 4096)   // models come and go in a long-lived process (tests): drop the entries of freed parameters
+    for (auto e = g_wq.begin(); e != g_wq.end();) e = e->second.weak.expired() ? g_wq.erase(e) : std::next(e);
+  return q;
+}
+
 // out = conv(features) ; features (n_src, Cin) fp32 | bf16 contiguous, w [K.., Cin, Cout] fp32, map_fwd (n_res, K) int32
 Tensor conv_fwd(const Tensor& features, const Tensor& w, const OptTensor& bias, const Tensor& map_fwd, int64_t stream) {
   const int64_t cin = w.size(-2), cout = w.size(-1), K = map_fwd.size(1), n_res = map_fwd.size(0);
   need(features.is_contiguous() && w.is_contiguous() && map_fwd.is_contiguous(), "conv_fwd: contiguous tensors expected");
   need(w.numel() == K * cin * cout && features.size(1) == cin, "conv_fwd: weight does not match the rulebook / features");
   Tensor out = at::empty({n_res, cout}, features.options());
-  if (features.scalar_type() == at::kBFloat16)
+  if (bf16_operands(features, K, cin, cout)) {
+    Tensor q = weights_bf16(w, K, cin, cout, stream);
+    chk(btc_conv_fwd_bf16w(features.data_ptr(), (const char*)q.data_ptr() + 2 * w.numel(), fptr(bias), (const int32_t*)map_fwd.data_ptr(), (int)n_res,
+                           (int)K, (int)cin, (int)cout, out.data_ptr(), st(stream)), "btc_conv_fwd_bf16w");
+  } else if (features.scalar_type() == at::kBFloat16)
     chk(btc_conv_fwd_bf16(features.data_ptr(), (const float*)w.data_ptr(), fptr(bias), (const int32_t*)map_fwd.data_ptr(), (int)n_res, (int)K,
                           (int)cin, (int)cout, out.data_ptr(), st(stream)), "btc_conv_fwd_bf16");
   else
@@ -201,7 +244,11 @@ std::tuple<OptTensor, OptTensor> conv_bwd(const Tensor& features, const Tensor& 
   }
   if (need_din) {
     Tensor d = at::empty({n_src, cin}, features.options());
-    if (bf)
+    if (bf16_operands(grad_out, K, cout, cin)) {
+      Tensor q = weights_bf16(w, K, cin, cout, stream);
+      chk(btc_conv_dgrad_bf16w(grad_out.data_ptr(), q.data_ptr(), (const int32_t*)map_bwd.data_ptr(), (int)n_src, (int)K, (int)cin, (int)cout,
+                               d.data_ptr(), st(stream)), "btc_conv_dgrad_bf16w");
+    } else if (bf)
       chk(btc_conv_dgrad_bf16(grad_out.data_ptr(), (const float*)w.data_ptr(), (const int32_t*)map_bwd.data_ptr(), (int)n_src, (int)K, (int)cin,
                               (int)cout, d.data_ptr(), st(stream)), "btc_conv_dgrad_bf16");
     else

@@ -38,7 +38,7 @@ void btc_set_error(const char* fmt, ...);
   } while (0)
 
 // tuning overrides (btc_tune_set): 0 = built-in policy
-#define BTC_TUNE_KEYS 8
+#define BTC_TUNE_KEYS 16
 int btc_tune_get(int key);
 
 // conv_apply_glds.hip: LDS-DMA pipelined sparse-conv apply (same results as conv_apply)

@@ -19,6 +19,7 @@ extern "C" int btc_version(void) { return 1; }
 // kernel-selection overrides for tuning runs (tools/conv_bench.py); 0 = the built-in policy
 static int g_tune[BTC_TUNE_KEYS] = {0};
 int btc_tune_get(int key) { return (key >= 0 && key < BTC_TUNE_KEYS) ? g_tune[key] : 0; }
+extern "C" int btc_tune_value(int key) { return btc_tune_get(key); }
 extern "C" int btc_tune_set(int key, int value) {
   BTC_CHECK_ARG(key >= 0 && key < BTC_TUNE_KEYS, "btc_tune_set: unknown key %d", key);
   g_tune[key] = value;

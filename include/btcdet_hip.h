@@ -59,8 +59,10 @@ int btc_version(void);
 #define BTC_TUNE_WGRAD_PH 5   /* conv_wgrad_rows: phases (of KB offsets) per offset group: 1, 2, 4, 7 */
 #define BTC_TUNE_WGRAD_WGS 6  /* conv_wgrad_rows: target number of workgroups (row splits x offset groups) */
 #define BTC_TUNE_POV_SELECT 7 /* PassOccVox top-k: 1 = single-workgroup pov_select (cross-check of the multi-workgroup path) */
+#define BTC_TUNE_BF16_OPERANDS 8 /* host bindings: 1 = keep fp32 weights under bf16 activations (conv_apply_g, bit-exact fmaf chain) instead of btc_conv_*_bf16w */
 #define BTC_TUNE_APPLY_DEBUG 3 /* timing experiments only (WRONG results): 1 = no MFMA phase, 2 = no loads in the main loop */
 int btc_tune_set(int key, int value);
+int btc_tune_value(int key);   /* current value of a key (0 = built-in policy) */
 
 /* ------------------------------------------------------------------------------------------------
  * Voxelizer.  Replaces spconv.utils.VoxelGeneratorV2.generate (points_to_voxel_3d_np), called at
@@ -213,6 +215,22 @@ int btc_conv_dgrad_bf16(const void* dout, const float* W, const int32_t* nbr_in,
                         void* din, void* stream);
 int btc_conv_wgrad_bf16(const void* feat, const void* dout, const int32_t* nbr_out, int n_out, const int32_t* nbr_in,
                         int n_in, int K, int Cin, int Cout, float* dW, void* ws, size_t ws_bytes, void* stream);
+
+/* bfloat16 OPERANDS (BASELINE.json configs[2] / [4]): activations bf16 as above AND a bf16 copy of the weights, multiplied on
+ * the bf16 matrix pipe (v_mfma_f32_16x16x32_bf16, 16x the fp32 MFMA rate), fp32 accumulate, result rounded to bf16 once.
+ * (btc_conv_fwd_bf16 / btc_conv_dgrad_bf16 above keep fp32 weights: same bits as the fp32 fmaf chain, fp32-MFMA speed.)
+ *   btc_weights_to_bf16  : W fp32 [K][Cin][Cout] -> w_bf16 [K][Cin][Cout] (dgrad operand) and wt_bf16 [K][Cout][Cin]
+ *                          (forward operand); once per optimizer step and layer (K*Cin*Cout*2 bytes each)
+ *   btc_conv_fwd_bf16w   : out[i] = bf16(bias + sum_k feat[nbr_out[i][k]] @ bf16(W[k]))     needs Cin % 32 == 0, Cout % 16 == 0
+ *   btc_conv_dgrad_bf16w : din[j] = bf16(sum_k dout[nbr_in[j][k]] @ bf16(W[k])^T)           needs Cout % 32 == 0, Cin % 16 == 0
+ * Tolerance vs the fp32 path: see csrc/conv_apply_bf16.hip and tests/test_hip_bf16_mfma.py. */
+int btc_conv_bf16w_supported(int K, int Cred, int Cres);
+int btc_weights_to_bf16(const float* W, int K, int Cin, int Cout, void* w_bf16, void* wt_bf16, void* stream);
+int btc_conv_fwd_bf16w(const void* feat, const void* wt_bf16, const float* bias, const int32_t* nbr_out, int n_out, int K, int Cin,
+                       int Cout, void* out, void* stream);
+int btc_conv_dgrad_bf16w(const void* dout, const void* w_bf16, const int32_t* nbr_in, int n_in, int K, int Cin, int Cout, void* din,
+                         void* stream);
+
 
 /* Sparse max-pool (spconv indice_maxpool, App. B.6): out = max(0, max_k feat[nbr_out[i][k]]);
  * backward routes dout to every input equal to its output. */

@@ -11,6 +11,16 @@ from test_hip_core import _rb_both, dev, rand_indices
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture
+def fp32_weights():
+    """BTC_TUNE_BF16_OPERANDS = 1: bf16 activations with FP32 weights on the fp32 MFMA (conv_apply_g) -- the bit-exact path.
+    The default under bf16 activations is bf16 operands on the bf16 matrix pipe (tests/test_hip_bf16_mfma.py)."""
+    from btcdet_amd._lib import check, lib
+    check(lib().btc_tune_set(8, 1), "btc_tune_set")
+    yield
+    check(lib().btc_tune_set(8, 0), "btc_tune_set")
+
+
 def _bits(t):
     return t.detach().contiguous().view(torch.int16).cpu().numpy()
 
@@ -26,7 +36,7 @@ CASES = [(16, 16, 500), (16, 32, 500), (32, 32, 500), (32, 64, 500), (64, 64, 50
 
 @pytest.mark.parametrize("cin,cout,n", CASES)
 @pytest.mark.parametrize("kind", ["subm", "conv"])
-def test_conv_bf16_features_bit_exact(cin, cout, n, kind):
+def test_conv_bf16_features_bit_exact(fp32_weights, cin, cout, n, kind):
     from btcdet_amd.spconv import ops
     rng = np.random.default_rng(cin * 1000 + cout + n)
     shape, B = ((12, 48, 44), 2) if n > 5000 else ((8, 20, 18), 2)
@@ -100,21 +110,26 @@ def test_fused_bn_relu_bf16(N, C):
 
 
 def test_hot_path_bf16_features_close_to_fp32():
-    """the whole hot path with FEATURE_DTYPE: bf16 in both backbones: runs forward + backward, every parameter gets a
-    finite gradient, and the BEV map / occupancy loss stay within bf16 accuracy of the fp32 run (same weights, same batch)"""
+    """the whole hot path with FEATURE_DTYPE: bf16 in both backbones (bf16 operands on the bf16 matrix pipe where the channel
+    counts allow): forward + backward run, every parameter gets a finite gradient, the occupancy branch stays within bf16
+    accuracy of the fp32 run (same weights, same batch), and the detection branch -- fed the SAME merged voxels in both
+    precisions, because its own input set is a top-k of the occupancy probabilities and a rounding can swap members --
+    reproduces the BEV map and x_combine to a measured relative L2 error (printed; bound = 2x the observed)"""
     import bench
     from btcdet_amd.btc_path import BtcHotPath
     from btcdet_amd.config import load_cfg
     d = dev()
     batch = bench.build_batches(1, 0, d)[0]
 
-    def run(dtype):
+    def build(dtype):
         cfg = load_cfg()
         cfg.MODEL.OCC.BACKBONE_3D["FEATURE_DTYPE"] = dtype
         cfg.MODEL.BACKBONE_3D["FEATURE_DTYPE"] = dtype
         torch.manual_seed(0)
         np.random.seed(0)
-        model = BtcHotPath(cfg, device=d).to(d).train()
+        return BtcHotPath(cfg, device=d).to(d).train()
+
+    def run(model):
         bd = model.dataset.data_processor.forward_batch(batch["points"], batch["pre_rot_points"], batch["scene_offsets"], batch["rot_z"])
         bd.update({"batch_size": 2, "points": batch["points5"], "gt_boxes": batch["gt_boxes"], "gt_boxes_num": batch["gt_boxes_num"],
                    "box_mirr_flag": batch["box_mirr_flag"], "bm_points": batch["bm_points"], "rot_z": batch["rot_z"], "is_train": True})
@@ -123,15 +138,27 @@ def test_hot_path_bf16_features_close_to_fp32():
         loss.backward()
         torch.cuda.synchronize()
         grads = {n: p.grad for n, p in model.named_parameters() if p.requires_grad}
-        return float(ret["loss_occ"].detach()), ret["spatial_features"].detach(), grads, out["batch_pred_occ_prob"].detach()
+        det_in = {k: out[k].detach().clone() for k in ("voxels", "voxel_num_points", "voxel_coords")}
+        return float(ret["loss_occ"].detach()), grads, out["batch_pred_occ_prob"].detach(), det_in
 
-    l32, bev32, g32, p32 = run("fp32")
-    l16, bev16, g16, p16 = run("bf16")
+    def det(model, det_in):
+        with torch.no_grad():
+            b = dict(det_in)
+            b["batch_size"] = 2
+            for mod in model.det_module_list:
+                b = mod(b)
+        return b["spatial_features"].float(), b["multi_scale_3d_features"]["x_combine"].features.float()
+
+    m32, m16 = build("fp32"), build("bf16")
+    l32, g32, p32, det_in = run(m32)
+    l16, g16, p16, _ = run(m16)
     assert all(g is not None and torch.isfinite(g).all() for g in g16.values())
+    print("occupancy loss fp32 %.6f bf16 %.6f; |dp| max %.2e mean %.2e" % (l32, l16, float((p16 - p32).abs().max()), float((p16 - p32).abs().mean())))
     assert abs(l16 - l32) <= 2e-2 * abs(l32) + 1e-3
-    # occupancy branch (9 sparse layers + BatchNorm on a fixed voxel set): probabilities within bf16 accuracy
     assert float((p16 - p32).abs().max()) < 3e-2 and float((p16 - p32).abs().mean()) < 2e-3
-    # detection branch: its voxel set is the top-k of those probabilities, so a rounding can swap members of the set;
-    # the BEV map is compared as a whole
-    rel = float((bev16 - bev32).norm() / bev32.norm())
-    assert rel < 0.35, rel
+    bev32, xc32 = det(m32, det_in)
+    bev16, xc16 = det(m16, det_in)
+    rel_bev = float((bev16 - bev32).norm() / bev32.norm())
+    rel_xc = float((xc16 - xc32).norm() / xc32.norm())
+    print("detection branch on identical inputs, bf16 vs fp32: BEV rel L2 %.3e, x_combine rel L2 %.3e" % (rel_bev, rel_xc))
+    assert rel_bev < 3e-2 and rel_xc < 3e-2, (rel_bev, rel_xc)     # observed ~1.2e-2 (20 layers of bf16 rounding + train-mode BatchNorm)
