@@ -30,14 +30,15 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0       # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 FP32_MFMA_PEAK_TF = 157.3   # same guide: fp32-input MFMA peak
+BF16_MFMA_PEAK_TF = 2500.0  # same guide: dense bf16 MFMA peak (AMD's 5 PF figure is 2:1 sparse)
 
 
 def pmc_traffic_per_launch():
-    """HBM bytes per conv_apply launch from the committed PMC passes (profiles/r01t_pmc_conv.json: rocprofv3 --pmc FETCH_SIZE and
+    """HBM bytes per conv_apply launch from the committed PMC passes (profiles/r02b_pmc.json: rocprofv3 --pmc FETCH_SIZE and
     --pmc WRITE_SIZE in separate runs, FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md); PMC counters cannot be read
     inside the timed process, so this is null when the file is absent"""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01t_pmc_conv.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r02b_pmc.json")) as f:
             return json.load(f)["conv_apply"]["hbm_bytes_per_launch"]
     except (OSError, KeyError, ValueError):
         return None
@@ -80,44 +81,6 @@ def build_batches(n_batches, rank, device, batch_size=2, profile="kitti"):
     return batches
 
 
-class LeanFusedAdam(object):
-    """torch.optim.Adam(fused=True)'s update (the same torch._fused_adam_ kernel, per parameter group) without the Optimizer
-    wrapper's per-step Python (state dict walks, tensor grouping: ~0.25 ms of a 9 ms step).  L2 weight decay as in Adam."""
-
-    def __init__(self, groups, betas=(0.9, 0.99), eps=1e-8):
-        self.groups = []
-        for g in groups:
-            params = [p for p in g["params"] if p.requires_grad]
-            self.groups.append(dict(params=params, lr=float(g["lr"]), weight_decay=float(g.get("weight_decay", 0.0)),
-                                    exp_avgs=[torch.zeros_like(p) for p in params], exp_avg_sqs=[torch.zeros_like(p) for p in params],
-                                    steps=[torch.zeros((), dtype=torch.float32, device=p.device) for p in params]))
-        self.betas, self.eps = betas, eps
-
-    def read_grads_from(self, view_of):
-        """take the gradients from fixed buffers (a gradient reducer's flat buckets) instead of param.grad"""
-        for g in self.groups:
-            g["grad_views"] = [view_of(p) for p in g["params"]]
-
-    def zero_grad(self, set_to_none=True):
-        for g in self.groups:
-            for p in g["params"]:
-                p.grad = None
-
-    @torch.no_grad()
-    def step(self):
-        for g in self.groups:
-            params, grads = g["params"], (g["grad_views"] if "grad_views" in g else [p.grad for p in g["params"]])
-            if any(gr is None for gr in grads):
-                keep = [i for i, gr in enumerate(grads) if gr is not None]
-                params, grads = [params[i] for i in keep], [grads[i] for i in keep]
-                ea, es, st = [g["exp_avgs"][i] for i in keep], [g["exp_avg_sqs"][i] for i in keep], [g["steps"][i] for i in keep]
-            else:
-                ea, es, st = g["exp_avgs"], g["exp_avg_sqs"], g["steps"]
-            torch._foreach_add_(st, 1)
-            torch._fused_adam_(params, grads, ea, es, [], st, lr=g["lr"], beta1=self.betas[0], beta2=self.betas[1],
-                               weight_decay=g["weight_decay"], eps=self.eps, amsgrad=False, maximize=False)
-
-
 class MeanSquare(torch.autograd.Function):
     """scale * mean(x^2): the L2 stand-in for the out-of-scope consumers of the detection branch (BEV backbone + dense head,
     point head), one reduction forward and one elementwise launch backward instead of autograd's pow / mean / mul chain"""
@@ -149,6 +112,7 @@ def make_step(model, ddp, proc, opts, grad_sync=None, prefetch_stream=None, thre
     their forward ran) while this thread runs the detection branch on det_stream; both are chains of small launches that do
     not fill the GPU alone.  The detection branch's backward follows on det_stream, and the main stream joins it before the
     optimizer."""
+    from btcdet_amd.spconv import ops as _ops
     pending = {}
     pool = None
     if (prefetch_stream is not None and threaded) or det_stream is not None:
@@ -196,6 +160,7 @@ def make_step(model, ddp, proc, opts, grad_sync=None, prefetch_stream=None, thre
             loss.backward()
         if fut is not None:
             pending[id(next_batch)] = fut.result()
+        _ops.join_wgrad()   # no-op unless weight gradients are still owed (e.g. a backward pass whose end-of-pass callback never ran)
         if grad_sync is not None:
             grad_sync.finish()  # all-reduced mean gradients in param.grad
         for o in opts:
@@ -371,20 +336,24 @@ def main():
             grad_sync = BucketedGradSync([(det_params, None), (occ_params, None)])
         else:                 # one flat bucket sent after backward: the least host work; ~10 MB of all-reduce exposed
             grad_sync = BucketedGradSync([(det_params + occ_params, None)], assign_grads=os.environ.get("BTC_BENCH_OPTIM", "lean") == "torch")
-    # adam_onecycle groups of the reference (optimization/__init__.py:36-40; LR is scheduled, yaml:331-372)
-    # fused=True: one multi-tensor launch per optimizer instead of ~10 foreach launches with 60 us host gaps between them
-    # the reference's two optimizers (occ / det) as the two parameter groups of one fused Adam: same update rule per
-    # group, half the host overhead per step
+    # the reference's optimizer step per parameter group (tools/train_utils/train_utils.py:121-124; yaml:331-372): gradient-norm
+    # clip at 10, adam_onecycle = decoupled weight decay + Adam(betas=(mom, 0.99)) with lr / mom on the OneCycle schedule of a
+    # 40-epoch run over KITTI's 3712 training frames -- btcdet_amd/train_step.py (checked against the reference's own
+    # OptimWrapper / OneCycle, tests/test_train_step_cpu.py).  The two optimizers are the two groups of one object: same
+    # arithmetic per group, one Python call.
     # weight gradients on a side stream for the whole backward pass, joined once at its end (not under DDP, whose hooks read
     # them in mid-backward)
     ops.set_defer_wgrad_join(ddp is model and os.environ.get("BTC_DEFER_WGRAD", "1") != "0")
-    groups = [{"params": occ_params, "lr": 3e-3, "weight_decay": 0.001}, {"params": det_params, "lr": 3e-3, "weight_decay": 0.01}]
-    if os.environ.get("BTC_BENCH_OPTIM", "lean") == "torch":
-        opts = [torch.optim.Adam(groups, betas=(0.9, 0.99), fused=True)]
+    from btcdet_amd.train_step import GroupOptimizer
+    total_steps = 40 * (3712 // (2 * world))
+    sched_kw = dict(grad_norm_clip=10.0, moms=(0.95, 0.85), div_factor=10.0, pct_start=0.4, lr_clip=1e-7)
+    groups = [dict(params=occ_params, lr=0.003, weight_decay=0.001, **sched_kw), dict(params=det_params, lr=0.01, weight_decay=0.01, **sched_kw)]
+    if os.environ.get("BTC_BENCH_OPTIM", "lean") == "torch":   # plain torch Adam (no clip / schedule): A-B runs only
+        opts = [torch.optim.Adam([{"params": occ_params, "lr": 3e-3}, {"params": det_params, "lr": 1e-2}], betas=(0.9, 0.99), fused=True)]
     else:
-        opts = [LeanFusedAdam(groups, betas=(0.9, 0.99))]
+        opts = [GroupOptimizer(groups, total_steps)]
         if grad_sync is not None and not grad_sync.assign_grads:
-            opts[0].read_grads_from(grad_sync.view_of)
+            opts[0].read_grads_from(grad_sync.view_of, grad_sync.has_grad)
     bs = 2
     batches = build_batches(4, rank, device, bs, args.workload)
     # the next batch's weight-independent front runs on a high-priority side stream beside this batch's backward
@@ -404,11 +373,15 @@ def main():
     for i in range(args.warmup):
         step(batches[i % nb], batches[(i + 1) % nb])
     sync()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
+    marks[0].record()
     for i in range(args.warmup, args.warmup + args.steps):  # each step prepares its successor: K steps, K preparations
         step(batches[i % nb], batches[(i + 1) % nb])
+        marks[i - args.warmup + 1].record()                 # end of the step's work on the main stream (no host wait)
     sync()
     dt = time.perf_counter() - t0
+    per_step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
     # roofline leg: the SAME steps once more with a HIP event pair around every sparse-conv / rulebook launch
     # (kept out of the timed region above because counting the pairs of each rulebook needs a read-back)
     prof = None
@@ -437,17 +410,23 @@ def main():
             "metric": "scenes/s fwd+bwd %s bs=2/GPU (BtcDet hot path)" % ("Waymo-shaped synthetic" if waymo else "KITTI-Car"), "value": round(scenes / dt, 3), "unit": "scenes/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if args.features == "fp32" else "bf16 activations, f32 weights + accumulate", "data": "synthetic",
+            "dtype": "f32" if args.features == "fp32" else "bf16 operands (activations + weight copies), f32 accumulate / master weights / statistics",
+            "data": "synthetic",
+            "step_ms": {"p10": round(per_step_ms[int(0.1 * (args.steps - 1))], 3), "median": round(per_step_ms[args.steps // 2], 3),
+                        "p90": round(per_step_ms[int(0.9 * (args.steps - 1) + 0.5)], 3), "min": round(per_step_ms[0], 3), "max": round(per_step_ms[-1], 3),
+                        "how": "HIP events at the end of every step on the main stream (rank 0)"},
             "config": {"workload": ("btcdet_waymo_synth (configs[4] shape) hot path, bs=2/GPU, ~166k pts/scene: HIP voxelize" if waymo else
                                     "btcdet_kitti_car hot path, bs=2/GPU, ~28.6k pts/scene: HIP voxelize") + " (occ+det grids) -> OccTargets3D -> "
                                    "MeanVFE -> VoxelBackBoneDeconv -> OccHead3D+loss -> PassOccVox -> OccVFE -> VoxelBackBone8xOcc -> "
-                                   "HeightCompression (+L2 stand-in for the out-of-scope BEV heads), fwd+bwd+Adam (occ / det parameter groups), fp32",
+                                   "HeightCompression (+L2 stand-in for the out-of-scope BEV heads), fwd+bwd + the reference's optimizer step per parameter group (norm clip 10, "
+                                   "decoupled weight decay, Adam, OneCycle lr / beta1), " + ("fp32" if args.features == "fp32" else "bf16 features"),
                        "global_batch": bs * world, "parallelism": "dp%d" % world,
                        "schedule": ("each step prepares the NEXT batch's weight-independent front (both voxelizations, occupancy targets, "
                                     "occupancy-branch rulebooks) on a side stream beside its backward pass, one preparation per step; "
                                     "weight gradients on a side stream, one join per backward" if prefetch is not None else "in order, one stream"),
                        "grad_sync": ("DistributedDataParallel" if ddp is not model else
                                      (None if grad_sync is None else "btcdet_amd.grad_sync: flat bucket(s), all-reduce after backward")),
+                       "collective": (None if dist is None else {"backend": dist.get_backend(), "world_size": dist.get_world_size()}),
                        "points_per_batch": [b["n_points"] for b in batches]},
         }
         if prof is not None:
@@ -455,12 +434,23 @@ def main():
             k = summ.get("conv_apply")
             if k:
                 gbs = k["bytes"] / (k["ms"] * 1e-3) / 1e9
-                result["roofline"] = {"kernel": "conv_apply (fused sparse conv fwd + dgrad, output-stationary MFMA f32)", "bound": "hbm",
-                                      "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5),
-                                      "traffic": None if waymo else pmc_traffic_per_launch(), "launches_per_step": k["launches"] / prof_steps,
+                bf = args.features == "bf16"
+                tf = k["flops"] / (k["ms"] * 1e-3) / 1e12
+                mfma_peak = BF16_MFMA_PEAK_TF if bf else FP32_MFMA_PEAK_TF
+                traffic = None if (waymo or bf) else pmc_traffic_per_launch()
+                avg_s = 1e-3 * k["ms"] / k["launches"]
+                # `bound`: the roof the kernel sits closer to.  Algorithmic bytes (every gathered row counts, although
+                # most gathers are served by L2 / MALL) against the HBM peak, flops against the dense MFMA peak of the operand type;
+                # frac_hbm_measured is what the PMC counters saw actually crossing the HBM interface.
+                f_hbm, f_mfma = gbs / HBM_PEAK_GBS, tf / mfma_peak
+                result["roofline"] = {"kernel": "conv_apply (fused sparse conv fwd + dgrad, output-stationary MFMA %s)" % ("bf16 x bf16 -> f32" if bf else "f32"),
+                                      "bound": "hbm" if f_hbm >= f_mfma else "mfma",
+                                      "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(f_hbm, 5),
+                                      "traffic": traffic, "launches_per_step": k["launches"] / prof_steps,
                                       "avg_launch_us": round(1e3 * k["ms"] / k["launches"], 2),
                                       "alg_bytes_per_step": k["bytes"] // prof_steps,
-                                      "tflops": round(k["flops"] / (k["ms"] * 1e-3) / 1e12, 3), "mfma_f32_peak_tflops": FP32_MFMA_PEAK_TF,
+                                      "tflops": round(tf, 3), "mfma_peak_tflops": mfma_peak, "frac_mfma": round(f_mfma, 5),
+                                      "frac_hbm_measured": None if traffic is None else round(traffic / avg_s / 1e9 / HBM_PEAK_GBS, 5),
                                       "kernel_ms_per_step": round(k["ms"] / prof_steps, 3)}
             for name in ("conv_wgrad", "rulebook"):
                 k = summ.get(name)

@@ -14,6 +14,7 @@
 #include <hip/hip_runtime_api.h>
 #include <torch/csrc/autograd/engine.h>
 
+#include <atomic>
 #include <mutex>
 #include <stdexcept>
 #include <string>
@@ -163,8 +164,9 @@ struct SideStream {
   hipStream_t side = nullptr;
   hipEvent_t fork = nullptr, join = nullptr;
   c10::hip::HIPStream* c10side = nullptr;
-  bool pending = false;          // deferred mode: wgrads are in flight on the side stream, the join is still owed
-  bool callback_queued = false;  // ... and will be paid by an engine callback at the end of this backward pass
+  std::atomic<bool> pending{false};     // deferred mode: wgrads are in flight on the side stream, the join is still owed
+  std::atomic<int> queued_task{-1};     // id of the backward pass (autograd graph task) whose end-of-pass callback will pay it;
+                                        // a pass that aborted never runs its callback -- the next pass has another id and queues anew
 };
 
 // deferred join (set from Python): weight gradients are off the backward pass's critical path -- only dgrad feeds the next
@@ -173,7 +175,7 @@ struct SideStream {
 // reads dW in mid-backward).  Everything a deferred wgrad touches is handed to the allocator with recordStream, and a layer
 // is deferred only if its weight is a leaf parameter (allow_defer): a dW that another autograd node consumes during
 // backward -- the occupancy head's merged weight goes through CatBackward -- must be complete when its node returns.
-bool g_defer_join = false;
+std::atomic<bool> g_defer_join{false};
 
 SideStream& side_of(int device) {
   static SideStream tab[64];
@@ -191,7 +193,7 @@ SideStream& side_of(int device) {
 }
 
 void join_side(SideStream& s, hipStream_t main) {
-  if (!s.pending) return;
+  if (!s.pending.load()) return;
   if (hipEventRecord(s.join, s.side) != hipSuccess || hipStreamWaitEvent(main, s.join, 0) != hipSuccess)
     throw std::runtime_error("side-stream join failed");
   s.pending = false;
@@ -268,15 +270,18 @@ std::tuple<OptTensor, OptTensor> conv_bwd(const Tensor& features, const Tensor& 
     // the rulebook is kept alive by this node's saved tensors only: once the node has run it may be freed on the main stream
     c10::hip::HIPCachingAllocator::recordStream(map_fwd.storage().data_ptr(), *ss->c10side);
     c10::hip::HIPCachingAllocator::recordStream(map_bwd.storage().data_ptr(), *ss->c10side);
-    if (!ss->callback_queued) {
+    const int task = torch::autograd::get_current_graph_task_id();
+    if (task < 0) {                        // not inside a backward pass: nobody would pay the join later
+      join_side(*ss, main);
+    } else if (ss->queued_task.load() != task) {
       SideStream* sp = ss;
       try {
         torch::autograd::Engine::get_default_engine().queue_callback([sp]() {
-          sp->callback_queued = false;
+          sp->queued_task = -1;
           join_side(*sp, c10::hip::getCurrentHIPStream().stream());
         });
-        ss->callback_queued = true;
-      } catch (const std::exception&) {  // not inside a backward pass: nobody would pay the join later
+        ss->queued_task = task;
+      } catch (const std::exception&) {
         join_side(*ss, main);
       }
     }

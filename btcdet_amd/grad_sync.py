@@ -43,7 +43,8 @@ class BucketedGradSync(object):
     def __init__(self, buckets, process_group=None, assign_grads=True):
         """buckets: list of (parameters, trigger parameter or None); the trigger is the parameter whose gradient arrives last.
         assign_grads=False: finish() leaves param.grad alone -- the optimizer reads the reduced gradients from view_of(param)
-        (saves one attribute store per parameter and step)"""
+        (saves one attribute store per parameter and step).  In that mode param.grad keeps the LOCAL, un-reduced gradient:
+        anything that must see the reduced one (a norm clip, logging) has to read view_of(param) as well."""
         self.assign_grads = assign_grads
         self.group = process_group
         self.world = dist.get_world_size(process_group)
@@ -52,6 +53,7 @@ class BucketedGradSync(object):
         self.reduce_op = dist.ReduceOp.AVG if dist.get_backend(process_group) == "nccl" else dist.ReduceOp.SUM
         self.buckets = [_Bucket(list(params), trig) for params, trig in buckets]
         self._handles = []
+        self._present = {}
         for b in self.buckets:
             if b.trigger is not None:
                 self._handles.append(b.trigger.register_post_accumulate_grad_hook(lambda p, b=b: self._launch(b)))
@@ -77,6 +79,8 @@ class BucketedGradSync(object):
         if b.flat.is_cuda:
             from .spconv import ops
             ops.join_wgrad()  # weight gradients may still be in flight on the side stream (ops.set_defer_wgrad_join)
+        for p, g in zip(b.params, grads):
+            self._present[id(p)] = g is not None
         have = [(v, g) for v, g in zip(b.views, grads) if g is not None]
         if len(have) != len(grads):  # a parameter without gradient this step contributes zeros
             b.flat.zero_()
@@ -121,6 +125,11 @@ class BucketedGradSync(object):
                     for p, v in zip(b.params, b.views):
                         p.grad = v
             b.launched = False
+
+    def has_grad(self, param):
+        """whether `param` received a gradient in the step whose buckets were last launched (a parameter that did not
+        contributes zeros to the all-reduce; an optimizer should skip it, as torch.optim.Adam skips grad-is-None parameters)"""
+        return self._present.get(id(param), True)
 
     def view_of(self, param):
         """the slice of a flat bucket that holds `param`'s reduced gradient after finish()"""

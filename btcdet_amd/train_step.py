@@ -1,0 +1,114 @@
+"""The optimizer half of the data-parallel step, as the reference runs it per parameter group
+(`occ_modules`, `det_modules`) every iteration -- /root/reference/tools/train_utils/train_utils.py:121-124:
+
+    clip_grad_norm_(group parameters, GRAD_NORM_CLIP)            -> one L2 norm over the group, grads *= min(1, c / (norm + 1e-6))
+    optimizer.step()            adam_onecycle = fastai OptimWrapper(Adam(betas=(mom, 0.99)), true_wd=True, bn_wd=True)
+                                (optimization/__init__.py:29-44, fastai_optim.py:132-150): DECOUPLED weight decay
+                                p *= 1 - wd * lr on every trainable parameter (BatchNorm included), then Adam with wd = 0
+    lr_scheduler.step(it)       OneCycle (learning_schedules_fastai.py:64-81): lr and beta1 for the NEXT iteration, two cosine
+                                phases around PCT_START
+    optimizer.lr = max(lr, LR_CLIP)
+
+Here: one multi-tensor norm, one multi-tensor scale of the parameters and one fused multi-tensor Adam launch per group
+(torch._fused_adam_; the clip coefficient rides in as its grad_scale, so the gradients are not rewritten separately), no
+Optimizer-wrapper Python.  Checked against the reference's own OptimWrapper + OneCycle + clip_grad_norm_ run in this container
+(tests/golden/gen_optim_golden.py -> tests/golden/optim.npz, tests/test_train_step_cpu.py)."""
+import math
+
+import torch
+
+
+class OneCycle(object):
+    """lr / beta1 the reference's OneCycle leaves in the optimizer after `step(it)`; `initial()` is what its constructor sets"""
+
+    def __init__(self, total_step, lr_max, moms, div_factor, pct_start):
+        self.total = int(total_step)
+        self.turn = int(self.total * pct_start)
+        self.lr_max = float(lr_max)
+        self.lr_low = self.lr_max / float(div_factor)
+        self.lr_end = self.lr_low / 1e4
+        self.mom_hi, self.mom_lo = float(moms[0]), float(moms[1])
+
+    @staticmethod
+    def _cos(start, end, pct):
+        return end + (start - end) / 2.0 * (math.cos(math.pi * pct) + 1.0)
+
+    def initial(self):
+        return self.lr_low, self.mom_hi
+
+    def at(self, it):
+        if it < self.turn:
+            pct = it / float(self.turn)
+            return self._cos(self.lr_low, self.lr_max, pct), self._cos(self.mom_hi, self.mom_lo, pct)
+        pct = (min(it, self.total) - self.turn) / float(self.total - self.turn)
+        return self._cos(self.lr_max, self.lr_end, pct), self._cos(self.mom_lo, self.mom_hi, pct)
+
+
+class GroupOptimizer(object):
+    """one or more parameter groups, each {"params", "lr" (LR of the yaml = lr_max), "weight_decay", "grad_norm_clip",
+    "moms", "div_factor", "pct_start", "lr_clip"}; total_steps = iterations per epoch x epochs"""
+
+    def __init__(self, groups, total_steps, beta2=0.99, eps=1e-8):
+        self.groups = []
+        for g in groups:
+            params = [p for p in g["params"] if p.requires_grad]
+            sched = OneCycle(total_steps, g["lr"], g.get("moms", (0.95, 0.85)), g.get("div_factor", 10.0), g.get("pct_start", 0.4))
+            lr, mom = sched.initial()
+            self.groups.append(dict(params=params, sched=sched, lr=lr, mom=mom, weight_decay=float(g.get("weight_decay", 0.0)),
+                                    clip=float(g.get("grad_norm_clip", 0.0)), lr_clip=float(g.get("lr_clip", 1e-7)),
+                                    exp_avgs=[torch.zeros_like(p) for p in params], exp_avg_sqs=[torch.zeros_like(p) for p in params],
+                                    steps=[torch.zeros((), dtype=torch.float32, device=p.device) for p in params]))
+        self.beta2, self.eps = beta2, eps
+        self.iteration = 0
+        self._present = None
+
+    def read_grads_from(self, view_of, present=None):
+        """take the gradients from fixed buffers (a gradient reducer's flat buckets) instead of param.grad.  present(param):
+        whether the parameter received a gradient this step -- one that did not is skipped, as torch.optim.Adam skips
+        grad-is-None parameters (its bucket slice holds zeros, which Adam would otherwise treat as a real gradient)"""
+        for g in self.groups:
+            g["grad_views"] = [view_of(p) for p in g["params"]]
+        self._present = present
+
+    def zero_grad(self, set_to_none=True):
+        for g in self.groups:
+            for p in g["params"]:
+                p.grad = None
+
+    def lrs(self):
+        return [g["lr"] for g in self.groups]
+
+    @torch.no_grad()
+    def step(self):
+        last_norms = []
+        for g in self.groups:
+            params = g["params"]
+            if "grad_views" in g:
+                grads = g["grad_views"]
+                keep = [i for i, p in enumerate(params) if self._present is None or self._present(p)]
+            else:
+                grads = [p.grad for p in params]
+                keep = [i for i, gr in enumerate(grads) if gr is not None]
+            if len(keep) != len(params):
+                params, grads = [params[i] for i in keep], [grads[i] for i in keep]
+                ea, es, st = [g["exp_avgs"][i] for i in keep], [g["exp_avg_sqs"][i] for i in keep], [g["steps"][i] for i in keep]
+            else:
+                ea, es, st = g["exp_avgs"], g["exp_avg_sqs"], g["steps"]
+            if not params:
+                continue
+            inv_coef = None
+            if g["clip"] > 0:
+                total = torch.linalg.vector_norm(torch.stack(torch._foreach_norm(grads)))
+                # grads *= min(1, clip / (norm + 1e-6))  ==  grads /= max(1, (norm + 1e-6) / clip): handed to the fused kernel
+                inv_coef = ((total + 1e-6) / g["clip"]).clamp_(min=1.0).to(torch.float32)
+                last_norms.append(total)
+            lr = g["lr"]
+            if g["weight_decay"] != 0.0:
+                torch._foreach_mul_(params, 1.0 - g["weight_decay"] * lr)
+            torch._foreach_add_(st, 1)
+            torch._fused_adam_(params, grads, ea, es, [], st, lr=lr, beta1=g["mom"], beta2=self.beta2, weight_decay=0.0, eps=self.eps,
+                               amsgrad=False, maximize=False, grad_scale=inv_coef, found_inf=None)
+            nlr, nmom = g["sched"].at(self.iteration)
+            g["lr"], g["mom"] = max(nlr, g["lr_clip"]), nmom
+        self.iteration += 1
+        return last_norms

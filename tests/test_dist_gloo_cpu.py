@@ -108,9 +108,10 @@ def _one_bucket_worker(rank, world, port, out):
     params = list(net.parameters())
     sync = BucketedGradSync([(params, None)], assign_grads=False)     # bench.py's configuration for N > 1
     try:
-        opt = bench.LeanFusedAdam([{"params": params, "lr": 1e-2, "weight_decay": 0.01}], betas=(0.9, 0.99))
-        opt.read_grads_from(sync.view_of)
-        ropt = torch.optim.Adam(ref.parameters(), lr=1e-2, weight_decay=0.01, betas=(0.9, 0.99))
+        from btcdet_amd.train_step import GroupOptimizer
+        opt = GroupOptimizer([{"params": params, "lr": 1e-2, "weight_decay": 0.01, "grad_norm_clip": 10.0}], total_steps=50)
+        opt.read_grads_from(sync.view_of, sync.has_grad)
+        ropt = GroupOptimizer([{"params": list(ref.parameters()), "lr": 1e-2, "weight_decay": 0.01, "grad_norm_clip": 10.0}], total_steps=50)
         for it in range(3):
             xs = [torch.from_numpy(np.random.default_rng(100 * it + r).standard_normal((8, 5)).astype(np.float32)) for r in range(world)]
             opt.zero_grad()
@@ -131,8 +132,9 @@ def _one_bucket_worker(rank, world, port, out):
 
 
 def test_one_bucket_reducer_feeds_the_optimizer_gloo_world2():
-    """bench.py's N > 1 configuration: one flat bucket sent after backward, the fused Adam reads the reduced gradients from
-    the bucket's slices (param.grad is left alone); the parameters follow a single-process Adam on the mean loss"""
+    """bench.py's N > 1 configuration: one flat bucket sent after backward, the optimizer (norm clip + decoupled decay + fused
+    Adam, btcdet_amd.train_step) reads the reduced gradients from the bucket's slices (param.grad is left alone); the
+    parameters follow a single-process run of the same optimizer on the mean loss"""
     world, port = 2, 29751
     mgr = mp.Manager()
     out = mgr.dict()

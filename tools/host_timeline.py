@@ -15,7 +15,8 @@ torch.manual_seed(0)
 model = BtcHotPath(load_cfg(), device=dev).to(dev).train()
 occ = [p for p in model.occ_modules.parameters() if p.requires_grad]
 det = [p for p in model.det_modules.parameters() if p.requires_grad]
-opt = bench.LeanFusedAdam([{"params": occ, "lr": 3e-3, "weight_decay": 0.001}, {"params": det, "lr": 3e-3, "weight_decay": 0.01}], betas=(0.9, 0.99))
+from btcdet_amd.train_step import GroupOptimizer
+opt = GroupOptimizer([{"params": occ, "lr": 3e-3, "weight_decay": 0.001, "grad_norm_clip": 10.0}, {"params": det, "lr": 1e-2, "weight_decay": 0.01, "grad_norm_clip": 10.0}], 74240)
 ops.set_defer_wgrad_join(os.environ.get("BTC_DEFER_WGRAD", "1") != "0")
 batches = bench.build_batches(2, 0, dev)
 proc = model.dataset.data_processor
