@@ -22,6 +22,13 @@ import os
 import sys
 import time
 
+if int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("BTC_BENCH_FORCE_DIST") == "1":
+    # HIP multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4).  The step keeps four streams busy
+    # (main, weight gradients, next-batch preparation, rulebook lookahead); RCCL's streams take queues of their own, and with
+    # the default the weight-gradient stream ends up sharing a queue with the main stream: measured at world size 1 over RCCL
+    # 8.3 ms per step with 4 queues, 7.3 ms with 8 (no effect without a process group).  Must be set before HIP initialises.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import numpy as np
 import torch
 
@@ -119,6 +126,7 @@ def make_step(model, ddp, proc, opts, grad_sync=None, prefetch_stream=None, thre
         from concurrent.futures import ThreadPoolExecutor
         pool = ThreadPoolExecutor(max_workers=1)
     device = next(model.parameters()).device
+    split_backward = grad_sync is not None and ddp is model and len(grad_sync.buckets) > 1 and getattr(grad_sync, "split_backward", False)
 
     def prep(next_batch):
         torch.cuda.set_device(device)
@@ -155,9 +163,19 @@ def make_step(model, ddp, proc, opts, grad_sync=None, prefetch_stream=None, thre
         else:
             ret, tb, _ = ddp(bd)
             # occupancy loss (real) + L2 stand-ins for the out-of-scope consumers of the detection branch
-            loss = ret["loss_occ"] + MeanSquare.apply(ret["spatial_features"], 1e-3) + MeanSquare.apply(ret["x_combine"], 1e-3)
+            loss_det = MeanSquare.apply(ret["spatial_features"], 1e-3) + MeanSquare.apply(ret["x_combine"], 1e-3)
             fut = pool.submit(prep, next_batch) if (ahead and threaded) else None
-            loss.backward()
+            if split_backward:
+                # the branches are detached (PASS_GRAD False): two backward passes give the same gradients as one over the sum.
+                # The detection bucket (~90 % of the bytes) is packed and all-reduced BETWEEN them, from this thread -- it travels
+                # over xGMI while the occupancy branch's backward runs, with no hook in the autograd thread
+                loss_det.backward()
+                grad_sync.launch_ready()
+                ret["loss_occ"].backward()
+                loss = ret["loss_occ"].detach() + loss_det.detach()
+            else:
+                loss = ret["loss_occ"] + loss_det
+                loss.backward()
         if fut is not None:
             pending[id(next_batch)] = fut.result()
         _ops.join_wgrad()   # no-op unless weight gradients are still owed (e.g. a backward pass whose end-of-pass callback never ran)
@@ -288,7 +306,7 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=device)
+            dist.init_process_group(backend="nccl", **({} if os.environ.get("BTC_BENCH_LAZY_NCCL") == "1" else {"device_id": device}))
         else:
             dist.init_process_group(backend=backend)
 
@@ -319,7 +337,7 @@ def main():
                 k, v = item.split("=")
                 kw[k] = (float(v) if k == "bucket_cap_mb" else bool(int(v)))
         ddp = torch.nn.parallel.DistributedDataParallel(model, device_ids=[dev_index], find_unused_parameters=False, **kw)
-    elif use_dist:
+    elif use_dist and os.environ.get("BTC_BENCH_NOSYNC") != "1":
         # default: btcdet_amd/grad_sync.py -- two flat buckets (detection / occupancy parameters), the detection bucket's
         # all-reduce overlapped with the occupancy branch's backward.  Measured at world size 1 over RCCL: DDP (tuned as above)
         # 10.1 ms per step, this reducer see DESIGN.md, no reducer 9.2 ms.
@@ -329,13 +347,17 @@ def main():
         for b in model.buffers():
             dist.broadcast(b.data, src=0)
         head_param = next(p for p in model.occ_modules.occ_dense_head.parameters() if p.requires_grad)
-        mode = os.environ.get("BTC_SYNC_BUCKETS", "one")
+        mode = os.environ.get("BTC_SYNC_BUCKETS", "split")
+        view = os.environ.get("BTC_BENCH_OPTIM", "lean") != "torch"     # the optimizer reads the buckets' slices (no param.grad stores)
         if mode == "early":   # detection bucket launched from a hook in mid-backward (comm hidden, hook's Python in the engine thread)
             grad_sync = BucketedGradSync([(det_params, head_param), (occ_params, None)])
         elif mode == "two":
             grad_sync = BucketedGradSync([(det_params, None), (occ_params, None)])
-        else:                 # one flat bucket sent after backward: the least host work; ~10 MB of all-reduce exposed
-            grad_sync = BucketedGradSync([(det_params + occ_params, None)], assign_grads=os.environ.get("BTC_BENCH_OPTIM", "lean") == "torch")
+        elif mode == "one":   # one flat bucket sent after backward: the least host work; ~10 MB of all-reduce exposed
+            grad_sync = BucketedGradSync([(det_params + occ_params, None)], assign_grads=not view)
+        else:                 # default: two buckets, the detection bucket's all-reduce overlapped with the occupancy branch's backward
+            grad_sync = BucketedGradSync([(det_params, None), (occ_params, None)], assign_grads=not view)   # (make_step: split_backward)
+            grad_sync.split_backward = True
     # the reference's optimizer step per parameter group (tools/train_utils/train_utils.py:121-124; yaml:331-372): gradient-norm
     # clip at 10, adam_onecycle = decoupled weight decay + Adam(betas=(mom, 0.99)) with lr / mom on the OneCycle schedule of a
     # 40-epoch run over KITTI's 3712 training frames -- btcdet_amd/train_step.py (checked against the reference's own
@@ -353,7 +375,7 @@ def main():
     else:
         opts = [GroupOptimizer(groups, total_steps)]
         if grad_sync is not None and not grad_sync.assign_grads:
-            opts[0].read_grads_from(grad_sync.view_of, grad_sync.has_grad)
+            opts[0].read_grads_from(grad_sync.view_of, grad_sync.has_grad, grad_sync.missing)
     bs = 2
     batches = build_batches(4, rank, device, bs, args.workload)
     # the next batch's weight-independent front runs on a high-priority side stream beside this batch's backward
@@ -425,7 +447,8 @@ def main():
                                     "occupancy-branch rulebooks) on a side stream beside its backward pass, one preparation per step; "
                                     "weight gradients on a side stream, one join per backward" if prefetch is not None else "in order, one stream"),
                        "grad_sync": ("DistributedDataParallel" if ddp is not model else
-                                     (None if grad_sync is None else "btcdet_amd.grad_sync: flat bucket(s), all-reduce after backward")),
+                                     (None if grad_sync is None else ("btcdet_amd.grad_sync: detection bucket all-reduced during the occupancy branch's backward, occupancy bucket after it"
+                                                                     if getattr(grad_sync, "split_backward", False) else "btcdet_amd.grad_sync: flat bucket(s), all-reduce after backward"))),
                        "collective": (None if dist is None else {"backend": dist.get_backend(), "world_size": dist.get_world_size()}),
                        "points_per_batch": [b["n_points"] for b in batches]},
         }

@@ -22,6 +22,7 @@ import torch.distributed as dist
 
 import os
 _TIMING = {} if os.environ.get("BTC_SYNC_TIMING") == "1" else None  # host seconds spent in _launch / finish (tools)
+_DRYRUN = os.environ.get("BTC_SYNC_DRYRUN") == "1"                   # A-B runs: everything but the collective itself
 
 
 class _Bucket(object):
@@ -37,6 +38,7 @@ class _Bucket(object):
             off += p.numel()
         self.work = None
         self.launched = False
+        self.missing = ()
 
 
 class BucketedGradSync(object):
@@ -53,7 +55,8 @@ class BucketedGradSync(object):
         self.reduce_op = dist.ReduceOp.AVG if dist.get_backend(process_group) == "nccl" else dist.ReduceOp.SUM
         self.buckets = [_Bucket(list(params), trig) for params, trig in buckets]
         self._handles = []
-        self._present = {}
+        self.use_comm_stream = os.environ.get("BTC_SYNC_COMM_STREAM", "1") != "0"
+        self._cs = {}
         for b in self.buckets:
             if b.trigger is not None:
                 self._handles.append(b.trigger.register_post_accumulate_grad_hook(lambda p, b=b: self._launch(b)))
@@ -76,12 +79,32 @@ class BucketedGradSync(object):
         if early and any(g is None for g in grads):
             return  # not complete yet: finish() will send it
         b.launched = True
+        if None in grads:   # rare: a conditionally used parameter
+            b.missing = {id(p) for p, g in zip(b.params, grads) if g is None}
+            have = [(v, g) for v, g in zip(b.views, grads) if g is not None]
+        else:
+            b.missing = ()
+            have = list(zip(b.views, grads))
+        if b.flat.is_cuda and not self.stage_on_host and self.use_comm_stream:
+            # pack + all-reduce on a communication stream: it waits for what the compute stream has enqueued so far (the
+            # gradients dgrad / BatchNorm produced) and for the weight gradients still in flight on the wgrad side stream
+            # (ops.join_wgrad joins into the CURRENT stream) -- the compute stream itself is not held up, so the next
+            # branch's backward keeps running beside the wgrads and the collective
+            cs = self._comm_stream(b.flat.device)
+            cs.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(cs):
+                from .spconv import ops
+                ops.join_wgrad()
+                if len(have) != len(grads):
+                    b.flat.zero_()
+                if have:
+                    torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
+                if not _DRYRUN:
+                    b.work = dist.all_reduce(b.flat, op=self.reduce_op, group=self.group, async_op=True)
+            return
         if b.flat.is_cuda:
             from .spconv import ops
             ops.join_wgrad()  # weight gradients may still be in flight on the side stream (ops.set_defer_wgrad_join)
-        for p, g in zip(b.params, grads):
-            self._present[id(p)] = g is not None
-        have = [(v, g) for v, g in zip(b.views, grads) if g is not None]
         if len(have) != len(grads):  # a parameter without gradient this step contributes zeros
             b.flat.zero_()
         if have:
@@ -92,6 +115,12 @@ class BucketedGradSync(object):
             b.flat.copy_(host)
         else:
             b.work = dist.all_reduce(b.flat, op=self.reduce_op, group=self.group, async_op=True)
+
+    def _comm_stream(self, device):
+        st = self._cs.get(device.index)
+        if st is None:
+            st = self._cs[device.index] = torch.cuda.Stream(device=device)
+        return st
 
     def launch_ready(self):
         """launch every bucket whose gradients are all present (a training loop that runs the branches' backward passes one
@@ -129,7 +158,14 @@ class BucketedGradSync(object):
     def has_grad(self, param):
         """whether `param` received a gradient in the step whose buckets were last launched (a parameter that did not
         contributes zeros to the all-reduce; an optimizer should skip it, as torch.optim.Adam skips grad-is-None parameters)"""
-        return self._present.get(id(param), True)
+        return not any(id(param) in b.missing for b in self.buckets)
+
+    def missing(self):
+        """ids of the parameters that had no gradient in the step whose buckets were last launched (normally empty)"""
+        out = set()
+        for b in self.buckets:
+            out.update(b.missing)
+        return out
 
     def view_of(self, param):
         """the slice of a flat bucket that holds `param`'s reduced gradient after finish()"""

@@ -60,15 +60,16 @@ class GroupOptimizer(object):
                                     steps=[torch.zeros((), dtype=torch.float32, device=p.device) for p in params]))
         self.beta2, self.eps = beta2, eps
         self.iteration = 0
-        self._present = None
+        self._present = self._missing = None
 
-    def read_grads_from(self, view_of, present=None):
+    def read_grads_from(self, view_of, present=None, missing=None):
         """take the gradients from fixed buffers (a gradient reducer's flat buckets) instead of param.grad.  present(param):
         whether the parameter received a gradient this step -- one that did not is skipped, as torch.optim.Adam skips
-        grad-is-None parameters (its bucket slice holds zeros, which Adam would otherwise treat as a real gradient)"""
+        grad-is-None parameters (its bucket slice holds zeros, which Adam would otherwise treat as a real gradient);
+        missing(): the set of ids of such parameters (normally empty: the per-parameter queries are then skipped)"""
         for g in self.groups:
             g["grad_views"] = [view_of(p) for p in g["params"]]
-        self._present = present
+        self._present, self._missing = present, missing
 
     def zero_grad(self, set_to_none=True):
         for g in self.groups:
@@ -85,7 +86,10 @@ class GroupOptimizer(object):
             params = g["params"]
             if "grad_views" in g:
                 grads = g["grad_views"]
-                keep = [i for i, p in enumerate(params) if self._present is None or self._present(p)]
+                if self._present is None or (self._missing is not None and not self._missing()):
+                    keep = params   # all present (only its length is used below)
+                else:
+                    keep = [i for i, p in enumerate(params) if self._present(p)]
             else:
                 grads = [p.grad for p in params]
                 keep = [i for i, gr in enumerate(grads) if gr is not None]
