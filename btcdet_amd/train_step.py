@@ -44,18 +44,35 @@ class OneCycle(object):
         return self._cos(self.lr_max, self.lr_end, pct), self._cos(self.mom_lo, self.mom_hi, pct)
 
 
+_BN_TYPES = (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d, torch.nn.BatchNorm3d, torch.nn.SyncBatchNorm)
+
+
+def reference_param_groups(module):
+    """the two torch param groups the reference's OptimWrapper.create builds for a module (optimization/__init__.py:29-44 ->
+    fastai_optim.split_bn_bias): trainable parameters of the non-BatchNorm leaf modules in traversal order, then those of the
+    BatchNorm leaves.  Their concatenation is the parameter numbering of its optimizer state_dict."""
+    leaves = [m for m in module.modules() if len(list(m.children())) == 0]
+    plain = [p for m in leaves if not isinstance(m, _BN_TYPES) for p in m.parameters() if p.requires_grad]
+    norm = [p for m in leaves if isinstance(m, _BN_TYPES) for p in m.parameters() if p.requires_grad]
+    return plain, norm
+
+
 class GroupOptimizer(object):
-    """one or more parameter groups, each {"params", "lr" (LR of the yaml = lr_max), "weight_decay", "grad_norm_clip",
-    "moms", "div_factor", "pct_start", "lr_clip"}; total_steps = iterations per epoch x epochs"""
+    """one or more parameter groups, each {"params" or "module", "lr" (LR of the yaml = lr_max), "weight_decay",
+    "grad_norm_clip", "moms", "div_factor", "pct_start", "lr_clip"}; total_steps = iterations per epoch x epochs.
+    With "module" the group's parameters are taken (and numbered, for state_dict_lst) as the reference's optimizer does."""
 
     def __init__(self, groups, total_steps, beta2=0.99, eps=1e-8):
         self.groups = []
         for g in groups:
+            if "module" in g:
+                plain, norm = reference_param_groups(g["module"])
+                g = dict(g, params=plain + norm, split=len(plain))
             params = [p for p in g["params"] if p.requires_grad]
             sched = OneCycle(total_steps, g["lr"], g.get("moms", (0.95, 0.85)), g.get("div_factor", 10.0), g.get("pct_start", 0.4))
             lr, mom = sched.initial()
             self.groups.append(dict(params=params, sched=sched, lr=lr, mom=mom, weight_decay=float(g.get("weight_decay", 0.0)),
-                                    clip=float(g.get("grad_norm_clip", 0.0)), lr_clip=float(g.get("lr_clip", 1e-7)),
+                                    clip=float(g.get("grad_norm_clip", 0.0)), lr_clip=float(g.get("lr_clip", 1e-7)), split=g.get("split", len(params)),
                                     exp_avgs=[torch.zeros_like(p) for p in params], exp_avg_sqs=[torch.zeros_like(p) for p in params],
                                     steps=[torch.zeros((), dtype=torch.float32, device=p.device) for p in params]))
         self.beta2, self.eps = beta2, eps
@@ -116,3 +133,41 @@ class GroupOptimizer(object):
             g["lr"], g["mom"] = max(nlr, g["lr_clip"]), nmom
         self.iteration += 1
         return last_norms
+
+    # ---- checkpoint format of the reference: one torch.optim.Adam state_dict per optimizer (train_utils.py:272-288) -------------
+    def state_dict_lst(self):
+        """[state_dict per group] in torch.optim.Adam's layout with the reference's two param groups (non-BatchNorm, BatchNorm)
+        and its parameter numbering, so that a checkpoint written here resumes in the reference and vice versa"""
+        out = []
+        for g in self.groups:
+            n, split = len(g["params"]), g["split"]
+            state = {}
+            for i in range(n):
+                if float(g["steps"][i]) > 0:
+                    state[i] = {"step": g["steps"][i].detach().clone(), "exp_avg": g["exp_avgs"][i].detach().clone(),
+                                "exp_avg_sq": g["exp_avg_sqs"][i].detach().clone()}
+            common = dict(lr=g["lr"], betas=(g["mom"], self.beta2), eps=self.eps, weight_decay=0, amsgrad=False, maximize=False, foreach=None,
+                          capturable=False, differentiable=False, fused=None)
+            pgs = [dict(common, params=list(range(0, split))), dict(common, params=list(range(split, n)))]
+            out.append({"state": state, "param_groups": pgs})
+        return out
+
+    def load_state_dict_lst(self, states, iteration=None):
+        """inverse of state_dict_lst; iteration: the `it` of the checkpoint (the OneCycle position; lr / beta1 are also restored
+        from the param groups, which is what the reference's resume does)"""
+        assert len(states) == len(self.groups)
+        for g, sd in zip(self.groups, states):
+            n = len(g["params"])
+            assert sum(len(pg["params"]) for pg in sd["param_groups"]) == n, "optimizer state does not match the parameter count"
+            for i in range(n):
+                st = sd["state"].get(i)
+                if st is None:
+                    g["steps"][i].zero_(); g["exp_avgs"][i].zero_(); g["exp_avg_sqs"][i].zero_()
+                else:
+                    g["steps"][i].fill_(float(st["step"]))
+                    g["exp_avgs"][i].copy_(st["exp_avg"])
+                    g["exp_avg_sqs"][i].copy_(st["exp_avg_sq"])
+            pg = sd["param_groups"][-1]
+            g["lr"], g["mom"] = float(pg["lr"]), float(pg["betas"][0])
+        if iteration is not None:
+            self.iteration = int(iteration)

@@ -61,6 +61,10 @@ if __name__ == "__main__":
             opt.lr = max(opt.lr, cfg.LR_CLIP)
             if it in (0, 1, 2, 15, 16, 17, 39, 42):
                 snaps.append(np.concatenate([p.detach().numpy().reshape(-1) for p in m.parameters()]))
+            if it == 16 and tag == "det":     # the reference's optimizer state in mid-run + its model state, for the resume test
+                import copy
+                torch.save({"epoch": 1, "it": 17, "model_state": copy.deepcopy(m.state_dict()), "optimizer_state_lst": [copy.deepcopy(opt.state_dict())],
+                            "version": "reference"}, os.path.join(HERE, "optim_resume_ref.pth"))
         gold[tag + "_lr"], gold[tag + "_mom"], gold[tag + "_params"] = np.array(lrs), np.array(moms), np.stack(snaps)
     gold["snap_iters"] = np.array([0, 1, 2, 15, 16, 17, 39, 42])
     gold["meta"] = np.array([total_it_each_epoch, epochs])
