@@ -122,3 +122,24 @@ def raw_scene(spec):
     raw_pre = np.insert(pre, pos, np.concatenate([_synth()._rotz(junk[:, :3], -float(s["rot_z"])), junk[:, 3:]], 1), axis=0)
     bm = s["bm_points"] if not spec.get("no_bm") else np.zeros((0, 3), np.float32)
     return s, raw, raw_pre, bm
+
+
+def make_gt_database(root, n_cars=40, n_peds=12, seed=5):
+    """a small ground-truth database in the reference's on-disk format (kitti_dataset.py:296-302: one float32 .bin of
+    box-centred points per object + a db_infos dict), written under `root`; deterministic"""
+    import pathlib
+    root = pathlib.Path(root)
+    (root / "gt_database").mkdir(parents=True, exist_ok=True)
+    rng = np.random.default_rng(seed)
+    infos = {"Car": [], "Pedestrian": []}
+    for name, count, lwh in (("Car", n_cars, (3.9, 1.6, 1.56)), ("Pedestrian", n_peds, (0.8, 0.6, 1.73))):
+        for i in range(count):
+            box = np.array([rng.uniform(5, 65), rng.uniform(-35, 35), rng.uniform(-1.2, -0.6), lwh[0] * rng.uniform(0.9, 1.1),
+                            lwh[1] * rng.uniform(0.9, 1.1), lwh[2] * rng.uniform(0.9, 1.1), rng.uniform(-3.1, 3.1)], dtype=np.float32)
+            n = int(rng.integers(3, 60))
+            pts = np.concatenate([rng.uniform(-0.5, 0.5, (n, 3)) * box[3:6], rng.uniform(0, 1, (n, 1))], axis=1).astype(np.float32)
+            rel = "gt_database/%06d_%s_%d.bin" % (100 + i, name, i % 4)
+            pts.tofile(str(root / rel))
+            infos[name].append({"name": name, "path": rel, "image_idx": "%06d" % (100 + i), "gt_idx": i % 4, "box3d_lidar": box,
+                                "num_points_in_gt": n, "difficulty": int(rng.integers(-1, 3)), "bbox": np.zeros(4, np.float32), "score": -1.0})
+    return infos
