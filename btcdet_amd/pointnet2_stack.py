@@ -264,83 +264,75 @@ class ThreeInterpolate(Function):
 three_interpolate = ThreeInterpolate.apply
 
 
+def _shared_mlp(widths):
+    """1x1 Conv2d (no bias) + BatchNorm2d + ReLU per consecutive pair of widths -- the per-point MLP both modules apply to a
+    (1, C, rows, samples) image; conv weights Kaiming-normal, BatchNorm at identity (what pointnet2_modules.py:43-51 sets)"""
+    layers = []
+    for cin, cout in zip(widths[:-1], widths[1:]):
+        conv, bn = nn.Conv2d(cin, cout, kernel_size=1, bias=False), nn.BatchNorm2d(cout)
+        nn.init.kaiming_normal_(conv.weight)
+        nn.init.ones_(bn.weight)
+        nn.init.zeros_(bn.bias)
+        layers += [conv, bn, nn.ReLU()]
+    return nn.Sequential(*layers)
+
+
+_POOLS = {"max_pool": lambda t: t.amax(dim=3), "avg_pool": lambda t: t.mean(dim=3)}
+
+
 class StackSAModuleMSG(nn.Module):
-    """pointnet2_modules.py:10-111: multi-scale grouping -> shared MLP (1x1 Conv2d + BatchNorm2d + ReLU, vendor kernels) -> pool"""
+    """Set abstraction with multi-scale grouping on stacked batches: for every (radius, nsample, mlp) scale, ball-query the
+    neighbours of each new point, run the shared MLP over the grouped (offset xyz + features) columns and pool over the
+    samples; the scales' outputs are concatenated.  Constructor keywords, submodule names (`groupers`, `mlps`) and the forward
+    signature are those the ROI head uses (/root/reference/btcdet/ops/pointnet2/pointnet2_stack/pointnet2_modules.py:10-111;
+    conv_head.py:117-126), so its checkpoints load."""
 
     def __init__(self, *, radii: List[float], nsamples: List[int], mlps: List[List[int]], use_xyz: bool = True, pool_method='max_pool'):
         super().__init__()
-        assert len(radii) == len(nsamples) == len(mlps)
-        self.groupers = nn.ModuleList()
-        self.mlps = nn.ModuleList()
-        for i in range(len(radii)):
-            self.groupers.append(QueryAndGroup(radii[i], nsamples[i], use_xyz=use_xyz))
-            mlp_spec = mlps[i]
-            if use_xyz:
-                mlp_spec[0] += 3  # in place, as the reference does (the caller's list is modified)
-            shared_mlps = []
-            for k in range(len(mlp_spec) - 1):
-                shared_mlps.extend([nn.Conv2d(mlp_spec[k], mlp_spec[k + 1], kernel_size=1, bias=False), nn.BatchNorm2d(mlp_spec[k + 1]), nn.ReLU()])
-            self.mlps.append(nn.Sequential(*shared_mlps))
+        if not (len(radii) == len(nsamples) == len(mlps)):
+            raise ValueError("one radius, sample count and MLP spec per scale")
+        if pool_method not in _POOLS:
+            raise NotImplementedError(pool_method)
         self.pool_method = pool_method
-        self.init_weights()
-
-    def init_weights(self):
-        for m in self.modules():
-            if isinstance(m, nn.Conv2d):
-                nn.init.kaiming_normal_(m.weight)
-                if m.bias is not None:
-                    nn.init.constant_(m.bias, 0)
-            if isinstance(m, nn.BatchNorm2d):
-                nn.init.constant_(m.weight, 1.0)
-                nn.init.constant_(m.bias, 0)
+        self.groupers, self.mlps = nn.ModuleList(), nn.ModuleList()
+        for radius, nsample, spec in zip(radii, nsamples, mlps):
+            if use_xyz:
+                spec[0] += 3    # the caller's list is widened in place by the xyz offsets -- callers of the reference rely on that
+            self.groupers.append(QueryAndGroup(radius, nsample, use_xyz=use_xyz))
+            self.mlps.append(_shared_mlp(spec))
 
     def forward(self, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, features=None, empty_voxel_set_zeros=True, rotateMatrix=None, xyscales=None,
                 zscales=None, vis=False):
-        new_features_list, points_lst, prerot_points_lst = [], [], []
-        prerot_xyz = None
-        for k in range(len(self.groupers)):
-            result_lst = self.groupers[k](xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, features, rotateMatrix=rotateMatrix, xyscales=xyscales,
-                                          zscales=zscales)
-            if rotateMatrix is not None:
-                new_features, ball_idxs, prerot_xyz = result_lst
-            else:
-                new_features, ball_idxs = result_lst
-            new_features = new_features.permute(1, 0, 2).unsqueeze(dim=0)  # (1, C, M1 + M2 ..., nsample)
+        pool = _POOLS[self.pool_method]
+        per_scale, seen, seen_prerot = [], [], []
+        first_scene = new_xyz_batch_cnt.tolist() if vis else None
+        for grouper, mlp in zip(self.groupers, self.mlps):
+            res = grouper(xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, features, rotateMatrix=rotateMatrix, xyscales=xyscales, zscales=zscales)
+            grouped = res[0]                                              # (rows, C, nsample)
+            image = grouped.permute(1, 0, 2).unsqueeze(0)                 # (1, C, rows, nsample)
             if vis:
-                points_lst.append(torch.split(new_features[0].permute(1, 2, 0)[..., :3], new_xyz_batch_cnt.tolist())[0])
-                if prerot_xyz is not None:
-                    prerot_points_lst.append(torch.split(prerot_xyz.permute(0, 2, 1), new_xyz_batch_cnt.tolist())[0])
-            new_features = self.mlps[k](new_features)
-            if self.pool_method == 'max_pool':
-                new_features = F.max_pool2d(new_features, kernel_size=[1, new_features.size(3)]).squeeze(dim=-1)
-            elif self.pool_method == 'avg_pool':
-                new_features = F.avg_pool2d(new_features, kernel_size=[1, new_features.size(3)]).squeeze(dim=-1)
-            else:
-                raise NotImplementedError
-            new_features_list.append(new_features.squeeze(dim=0).permute(1, 0))  # (M1 + M2 ..., C)
-        new_features = torch.cat(new_features_list, dim=1)
-        if vis:
-            return new_xyz, new_features, [points_lst, prerot_points_lst]
-        return new_xyz, new_features
+                seen.append(torch.split(image[0].permute(1, 2, 0)[..., :3], first_scene)[0])
+                if rotateMatrix is not None:
+                    seen_prerot.append(torch.split(res[2].permute(0, 2, 1), first_scene)[0])
+            per_scale.append(pool(mlp(image))[0].t())                     # (rows, C_out)
+        out = torch.cat(per_scale, dim=1)
+        return (new_xyz, out, [seen, seen_prerot]) if vis else (new_xyz, out)
 
 
 class StackPointnetFPModule(nn.Module):
-    """pointnet2_modules.py:114-153: three-NN inverse-distance interpolation -> shared MLP"""
+    """Feature propagation: every `unknown` point takes the inverse-distance weighted mean of the features of its three
+    nearest `known` points (same scene), optionally concatenated with its own features, through a shared MLP
+    (pointnet2_modules.py:114-153)."""
 
     def __init__(self, *, mlp: List[int]):
         super().__init__()
-        shared_mlps = []
-        for k in range(len(mlp) - 1):
-            shared_mlps.extend([nn.Conv2d(mlp[k], mlp[k + 1], kernel_size=1, bias=False), nn.BatchNorm2d(mlp[k + 1]), nn.ReLU()])
-        self.mlp = nn.Sequential(*shared_mlps)
+        self.mlp = _shared_mlp(mlp)
 
     def forward(self, unknown, unknown_batch_cnt, known, known_batch_cnt, unknown_feats=None, known_feats=None):
         dist, idx = three_nn(unknown, unknown_batch_cnt, known, known_batch_cnt)
-        dist_recip = 1.0 / (dist + 1e-8)
-        norm = torch.sum(dist_recip, dim=-1, keepdim=True)
-        weight = dist_recip / norm
-        interpolated_feats = three_interpolate(known_feats, idx, weight)
-        new_features = torch.cat([interpolated_feats, unknown_feats], dim=1) if unknown_feats is not None else interpolated_feats
-        new_features = new_features.permute(1, 0)[None, :, :, None]
-        new_features = self.mlp(new_features)
-        return new_features.squeeze(dim=0).squeeze(dim=-1).permute(1, 0)
+        w = (dist + 1e-8).reciprocal()
+        w = w / w.sum(dim=-1, keepdim=True)
+        feats = three_interpolate(known_feats, idx, w)
+        if unknown_feats is not None:
+            feats = torch.cat([feats, unknown_feats], dim=1)
+        return self.mlp(feats.t()[None, :, :, None])[0, :, :, 0].t()
