@@ -230,20 +230,8 @@ std::tuple<OptTensor, OptTensor> conv_bwd(const Tensor& features, const Tensor& 
       throw std::runtime_error("side-stream fork failed");
     wstream = (void*)ss->side;
   }
-  if (need_dw) {
-    Tensor g = at::empty(w.sizes(), w.options());
-    const size_t ws_bytes = btc_conv_wgrad_ws_bytes((int)n_res, (int)K, (int)cin, (int)cout, (int)n_src);
-    ws = at::empty({(int64_t)(ws_bytes > 256 ? ws_bytes : 256)}, features.options().dtype(at::kByte));
-    if (bf)
-      chk(btc_conv_wgrad_bf16(features.data_ptr(), grad_out.data_ptr(), (const int32_t*)map_fwd.data_ptr(), (int)n_res,
-                              (const int32_t*)map_bwd.data_ptr(), (int)n_src, (int)K, (int)cin, (int)cout, (float*)g.data_ptr(), ws.data_ptr(),
-                              ws_bytes, wstream), "btc_conv_wgrad_bf16");
-    else
-      chk(btc_conv_wgrad((const float*)features.data_ptr(), (const float*)grad_out.data_ptr(), (const int32_t*)map_fwd.data_ptr(), (int)n_res,
-                         (const int32_t*)map_bwd.data_ptr(), (int)n_src, (int)K, (int)cin, (int)cout, (float*)g.data_ptr(), ws.data_ptr(),
-                         ws_bytes, wstream), "btc_conv_wgrad");
-    dw = g;
-  }
+  // dgrad first: it feeds the next backward node (the critical path); the fork recorded above already marks where the side
+  // stream may start, so the weight gradient does not wait for it
   if (need_din) {
     Tensor d = at::empty({n_src, cin}, features.options());
     if (bf16_operands(grad_out, K, cout, cin)) {
@@ -257,6 +245,20 @@ std::tuple<OptTensor, OptTensor> conv_bwd(const Tensor& features, const Tensor& 
       chk(btc_conv_dgrad((const float*)grad_out.data_ptr(), (const float*)w.data_ptr(), (const int32_t*)map_bwd.data_ptr(), (int)n_src, (int)K,
                          (int)cin, (int)cout, (float*)d.data_ptr(), st(stream)), "btc_conv_dgrad");
     din = d;
+  }
+  if (need_dw) {
+    Tensor g = at::empty(w.sizes(), w.options());
+    const size_t ws_bytes = btc_conv_wgrad_ws_bytes((int)n_res, (int)K, (int)cin, (int)cout, (int)n_src);
+    ws = at::empty({(int64_t)(ws_bytes > 256 ? ws_bytes : 256)}, features.options().dtype(at::kByte));
+    if (bf)
+      chk(btc_conv_wgrad_bf16(features.data_ptr(), grad_out.data_ptr(), (const int32_t*)map_fwd.data_ptr(), (int)n_res,
+                              (const int32_t*)map_bwd.data_ptr(), (int)n_src, (int)K, (int)cin, (int)cout, (float*)g.data_ptr(), ws.data_ptr(),
+                              ws_bytes, wstream), "btc_conv_wgrad_bf16");
+    else
+      chk(btc_conv_wgrad((const float*)features.data_ptr(), (const float*)grad_out.data_ptr(), (const int32_t*)map_fwd.data_ptr(), (int)n_res,
+                         (const int32_t*)map_bwd.data_ptr(), (int)n_src, (int)K, (int)cin, (int)cout, (float*)g.data_ptr(), ws.data_ptr(),
+                         ws_bytes, wstream), "btc_conv_wgrad");
+    dw = g;
   }
   if (ss && !defer) {  // join: dW (and the release of ws / grad_out by the caller) is ordered after wgrad on the main stream
     ss->pending = true;

@@ -32,7 +32,7 @@ __device__ __forceinline__ int scene_of(const int32_t* __restrict__ off, int bat
 }
 
 __global__ __launch_bounds__(256) void vox_insert(const float* __restrict__ pts, const int32_t* __restrict__ off,
-                                                  VoxParams P, int32_t* __restrict__ keys, int32_t* __restrict__ lists,
+                                                  VoxParams P, long long* __restrict__ keys, int32_t* __restrict__ lists,
                                                   int32_t* __restrict__ cellslot) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= P.n) return;
@@ -51,11 +51,13 @@ __global__ __launch_bounds__(256) void vox_insert(const float* __restrict__ pts,
     return;
   }
   int b = scene_of(off, P.batch, i);
-  int key = b * P.vol + (c[2] * P.grid[1] + c[1]) * P.grid[0] + c[0];
-  unsigned slot = btc_hash32((unsigned)key) & P.mask;
+  // 64-bit cell keys: batch * grid volume may exceed 2^31 (the KITTI detection grid does from 24 scenes per batch on)
+  const int lin = (c[2] * P.grid[1] + c[1]) * P.grid[0] + c[0];
+  const long long key = (long long)b * P.vol + lin;
+  unsigned slot = btc_hash32((unsigned)lin ^ ((unsigned)b * 0x9E3779B9u)) & P.mask;
   while (true) {
-    int prev = atomicCAS(&keys[slot], BTC_EMPTY_KEY, key);
-    if (prev == BTC_EMPTY_KEY || prev == key) break;
+    const long long prev = (long long)atomicCAS((unsigned long long*)&keys[slot], (unsigned long long)-1LL, (unsigned long long)key);
+    if (prev == -1LL || prev == key) break;
     slot = (slot + 1) & P.mask;
   }
   cellslot[i] = (int)slot;
@@ -99,7 +101,7 @@ __global__ void vox_scene_info(const int32_t* __restrict__ excl, const int32_t* 
 
 __global__ __launch_bounds__(256) void vox_assign(const int32_t* __restrict__ cellslot, const int32_t* __restrict__ flags,
                                                   const int32_t* __restrict__ excl, const int32_t* __restrict__ off,
-                                                  const int32_t* __restrict__ scene_info, const int32_t* __restrict__ keys,
+                                                  const int32_t* __restrict__ scene_info, const long long* __restrict__ keys,
                                                   VoxParams P, int32_t* __restrict__ vox_slot, int32_t* __restrict__ coords) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= P.n || !flags[i]) return;
@@ -109,7 +111,7 @@ __global__ __launch_bounds__(256) void vox_assign(const int32_t* __restrict__ ce
   int vid = scene_info[2 * b + 1] + r;
   int slot = cellslot[i];
   vox_slot[vid] = slot;
-  int lin = keys[slot] - b * P.vol;
+  int lin = (int)(keys[slot] - (long long)b * P.vol);
   int x = lin % P.grid[0];
   int y = (lin / P.grid[0]) % P.grid[1];
   int z = lin / (P.grid[0] * P.grid[1]);
@@ -182,7 +184,7 @@ __global__ __launch_bounds__(256) void voxel_shift_col(float* __restrict__ voxel
 extern "C" size_t btc_voxelize_ws_bytes(int n, int batch, int max_points) {
   unsigned cap = btc_pow2_ge((unsigned long long)(n > 0 ? n : 1) * 2);
   size_t s = 0;
-  s += btc_align((size_t)cap * sizeof(int32_t));               // keys
+  s += btc_align((size_t)cap * sizeof(long long));             // keys (64-bit: batch * grid volume may exceed 2^31)
   s += btc_align((size_t)cap * max_points * sizeof(int32_t));  // lists
   s += btc_align((size_t)(n + 1) * sizeof(int32_t));           // cellslot
   s += btc_align((size_t)(n + 1) * sizeof(int32_t));           // flags
@@ -202,8 +204,8 @@ extern "C" int btc_voxelize(const float* points, int n, int ld, int xyz_col, int
   BTC_CHECK_ARG(xyz_col >= 0 && xyz_col + 3 <= ld && feat_col >= 0 && feat_col + C <= ld, "btc_voxelize: bad columns");
   BTC_CHECK_ARG(ws_bytes >= btc_voxelize_ws_bytes(n, batch, max_points), "btc_voxelize: workspace too small");
   long long vol = (long long)h_grid[0] * h_grid[1] * h_grid[2];
-  if (vol * batch >= 0x7fffffffLL) {
-    btc_set_error("btc_voxelize: batch*grid volume %lld exceeds 32-bit cell keys", vol * batch);
+  if (vol >= 0x7fffffffLL) {
+    btc_set_error("btc_voxelize: one scene's grid of %lld cells exceeds the 31-bit per-scene cell index", vol);
     return BTC_ERANGE;
   }
   if (n == 0) {
@@ -223,7 +225,7 @@ extern "C" int btc_voxelize(const float* points, int n, int ld, int xyz_col, int
   P.mask = cap - 1;
 
   BtcCarver cv(ws);
-  int32_t* keys = cv.take<int32_t>(cap);
+  long long* keys = cv.take<long long>(cap);
   int32_t* lists = cv.take<int32_t>((size_t)cap * max_points);
   int32_t* cellslot = cv.take<int32_t>(n + 1);
   int32_t* flags = cv.take<int32_t>(n + 1);
@@ -232,7 +234,7 @@ extern "C" int btc_voxelize(const float* points, int n, int ld, int xyz_col, int
   int32_t* scene_info = cv.take<int32_t>((size_t)batch * 2);
   void* scan_ws = cv.take<char>(btc_scan_ws_bytes(n + 1));
 
-  BTC_HIP(hipMemsetAsync(keys, 0xFF, (size_t)cap * sizeof(int32_t), stream));
+  BTC_HIP(hipMemsetAsync(keys, 0xFF, (size_t)cap * sizeof(long long), stream));
   BTC_HIP(hipMemsetAsync(lists, 0x7F, (size_t)cap * max_points * sizeof(int32_t), stream));
   const int T = 256;
   vox_insert<<<btc_cdiv(n, T), T, 0, stream>>>(points, scene_offsets, P, keys, lists, cellslot);

@@ -462,6 +462,31 @@ def _overlap_ok(n_res):
     return OVERLAP_WGRAD and OVERLAP_MIN_ROWS <= n_res < OVERLAP_MAX_ROWS
 
 
+_WQ = {}
+
+
+def _bf16_operands(features, K, cred, cres):
+    """bf16 activations + a bf16 copy of the weights on the bf16 matrix pipe (csrc/conv_apply_bf16.hip) unless the tuning key
+    BTC_TUNE_BF16_OPERANDS is 1; same policy as the compiled binding (binding.cpp bf16_operands)"""
+    L = lib()
+    return features.dtype == torch.bfloat16 and L.btc_conv_bf16w_supported(int(K), int(cred), int(cres)) == 1 and L.btc_tune_value(8) != 1
+
+
+def _weights_bf16(w, K, cin, cout):
+    """(2, numel) bf16: row 0 = W [K][Cin][Cout], row 1 = W^T [K][Cout][Cin]; rebuilt when the parameter's version counter moved"""
+    import weakref
+    hit = _WQ.get(id(w))
+    if hit is not None and hit[0]() is w and hit[1] == w._version:
+        return hit[2]
+    q = torch.empty((2, w.numel()), dtype=torch.bfloat16, device=w.device)
+    check(lib().btc_weights_to_bf16(ptr(w), int(K), int(cin), int(cout), ptr(q[0]), ptr(q[1]), stream_ptr()), "btc_weights_to_bf16")
+    if len(_WQ) > 4096:
+        for k in [k for k, v in _WQ.items() if v[0]() is None]:
+            del _WQ[k]
+    _WQ[id(w)] = (weakref.ref(w), w._version, q)
+    return q
+
+
 def _conv_forward(features, w, b, map_fwd):
     if PROFILE is None:
         F = fast()
@@ -474,6 +499,11 @@ def _conv_forward(features, w, b, map_fwd):
         raise _lib.BtcHipError(f"weight {tuple(w.shape)} does not match K={K}, Cin={features.shape[1]}")
     n_res = map_fwd.shape[0]
     out = torch.empty((n_res, cout), dtype=features.dtype, device=features.device)
+    if _bf16_operands(features, K, cin, cout):
+        q = _weights_bf16(w, K, cin, cout)
+        with _span("conv_apply", _conv_cost, (map_fwd, n_res, K, cin, cout, 2)):
+            check(lib().btc_conv_fwd_bf16w(ptr(features), ptr(q[1]), ptr(b), ptr(map_fwd), n_res, K, cin, cout, ptr(out), stream_ptr()), "btc_conv_fwd_bf16w")
+        return out
     fwd = lib().btc_conv_fwd_bf16 if bf else lib().btc_conv_fwd
     with _span("conv_apply", _conv_cost, (map_fwd, n_res, K, cin, cout, 2 if bf else 4)):
         check(fwd(ptr(features), ptr(w), ptr(b), ptr(map_fwd), n_res, K, cin, cout, ptr(out), stream_ptr()), "btc_conv_fwd")
@@ -516,7 +546,11 @@ def _conv_backward(features, w, map_fwd, map_bwd, grad_out, wshape, need_din, ne
     if need_din:
         din = torch.empty((n_src, cin), dtype=features.dtype, device=dev)
         with _span("conv_apply", _conv_cost, (map_bwd, n_src, K, cout, cin, 2 if bf else 4)):
-            check(dgrad(ptr(grad_out), ptr(w), ptr(map_bwd), n_src, K, cin, cout, ptr(din), stream_ptr()), "btc_conv_dgrad")
+            if _bf16_operands(grad_out, K, cout, cin):
+                q = _weights_bf16(w, K, cin, cout)
+                check(L.btc_conv_dgrad_bf16w(ptr(grad_out), ptr(q[0]), ptr(map_bwd), n_src, K, cin, cout, ptr(din), stream_ptr()), "btc_conv_dgrad_bf16w")
+            else:
+                check(dgrad(ptr(grad_out), ptr(w), ptr(map_bwd), n_src, K, cin, cout, ptr(din), stream_ptr()), "btc_conv_dgrad")
     if side is not None:
         torch.cuda.current_stream().wait_stream(side)  # join: dW is consumed on the main stream from here on
         dw.record_stream(torch.cuda.current_stream())
