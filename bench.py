@@ -396,6 +396,7 @@ def main():
         step(batches[i % nb], batches[(i + 1) % nb])
     sync()
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    allocs0 = torch.cuda.memory_stats(device).get("num_device_alloc", 0)
     t0 = time.perf_counter()
     marks[0].record()
     for i in range(args.warmup, args.warmup + args.steps):  # each step prepares its successor: K steps, K preparations
@@ -404,6 +405,7 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     per_step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    device_allocs = torch.cuda.memory_stats(device).get("num_device_alloc", 0) - allocs0   # hipMalloc calls inside the timed region
     # roofline leg: the SAME steps once more with a HIP event pair around every sparse-conv / rulebook launch
     # (kept out of the timed region above because counting the pairs of each rulebook needs a read-back)
     prof = None
@@ -436,7 +438,7 @@ def main():
             "data": "synthetic",
             "step_ms": {"p10": round(per_step_ms[int(0.1 * (args.steps - 1))], 3), "median": round(per_step_ms[args.steps // 2], 3),
                         "p90": round(per_step_ms[int(0.9 * (args.steps - 1) + 0.5)], 3), "min": round(per_step_ms[0], 3), "max": round(per_step_ms[-1], 3),
-                        "how": "HIP events at the end of every step on the main stream (rank 0)"},
+                        "how": "HIP events at the end of every step on the main stream (rank 0)", "device_allocs_in_timed_region": device_allocs},
             "config": {"workload": ("btcdet_waymo_synth (configs[4] shape) hot path, bs=2/GPU, ~166k pts/scene: HIP voxelize" if waymo else
                                     "btcdet_kitti_car hot path, bs=2/GPU, ~28.6k pts/scene: HIP voxelize") + " (occ+det grids) -> OccTargets3D -> "
                                    "MeanVFE -> VoxelBackBoneDeconv -> OccHead3D+loss -> PassOccVox -> OccVFE -> VoxelBackBone8xOcc -> "
