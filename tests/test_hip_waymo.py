@@ -130,14 +130,45 @@ def test_waymo_conv_full_size(det_voxels, cin, cout):
     assert np.abs(w.grad.cpu().numpy() - ref).max() <= 1e-4 * (np.abs(ref).max() + 1e-6)
 
 
-def test_waymo_hot_path_step(waymo_batch):
-    """one forward + backward of the whole hot path on the Waymo-shaped configuration: shapes of SURVEY.md §8a scaled to
-    this grid, finite loss, gradients on every parameter; detection-grid voxels equal the oracle's"""
+def test_waymo_conv_bf16_operands_full_size(det_voxels):
+    """BASELINE configs[4] ("mixed bf16") at full size: bf16 operands on the bf16 matrix pipe on the ~125 k-row stride-2 rulebook,
+    within one bf16 ulp + 2e-6 of the scale of the oracle's fp32 chain over the same bf16-rounded operands (forward and dgrad)"""
+    from btcdet_amd import _lib
+    from btcdet_amd.spconv import ops
+    if _lib.fast() is None:
+        pytest.skip("compiled binding not built")
+    _, idx = det_voxels
+    shape = [41, 1504, 1504]
+    rb = ops.build_rulebook(torch.from_numpy(idx).to(dev()), 2, shape, 3, 2, 1, 1, 0, False, False)
+    o_idx, o_out, o_in, _ = orc.rulebook(idx, shape, 3, 2, 1, 1, orc.MODE_CONV)
+    rng = np.random.default_rng(64)
+    feat = orc.bf16_round(rng.standard_normal((idx.shape[0], 64)).astype(np.float32))
+    W = (rng.standard_normal((3, 3, 3, 64, 64)) / 8.0).astype(np.float32)
+    dout = orc.bf16_round(rng.standard_normal((o_idx.shape[0], 64)).astype(np.float32))
+    f = torch.from_numpy(feat).to(dev()).to(torch.bfloat16).requires_grad_(True)
+    w = torch.from_numpy(W).to(dev()).requires_grad_(True)
+    out = ops.indice_conv(f, w, None, rb)
+    out.backward(torch.from_numpy(dout).to(dev()).to(torch.bfloat16))
+    Wq = orc.bf16_round(W)
+    for got, ref in ((out.detach().float().cpu().numpy(), orc.conv_fwd(feat, Wq, None, o_out)),
+                     (f.grad.float().cpu().numpy(), orc.conv_dgrad(dout, Wq, o_in))):
+        bound = 2.0 ** -8 * np.abs(ref) + 2e-6 * float(np.abs(ref).max())
+        assert float((np.abs(got - ref) / bound).max()) <= 1.0
+
+
+@pytest.mark.parametrize("features", ["fp32", "bf16"])
+def test_waymo_hot_path_step(waymo_batch, features):
+    """one forward + backward of the whole hot path on the Waymo-shaped configuration (fp32, and configs[4]'s mixed bf16):
+    shapes of SURVEY.md §8a scaled to this grid, finite loss, gradients on every parameter"""
     from btcdet_amd.btc_path import BtcHotPath
     from btcdet_amd.config import load_cfg
     b = waymo_batch
     torch.manual_seed(0)
-    model = BtcHotPath(load_cfg(WAYMO_CFG), device=dev()).to(dev()).train()
+    cfg = load_cfg(WAYMO_CFG)
+    if features == "bf16":
+        cfg.MODEL.OCC.BACKBONE_3D["FEATURE_DTYPE"] = "bf16"
+        cfg.MODEL.BACKBONE_3D["FEATURE_DTYPE"] = "bf16"
+    model = BtcHotPath(cfg, device=dev()).to(dev()).train()
     d = dev()
     bd = model.dataset.data_processor.forward_batch(
         torch.from_numpy(np.ascontiguousarray(b["points"][:, 1:])).to(d), torch.from_numpy(b["pre_rot_points"]).to(d),
@@ -148,7 +179,7 @@ def test_waymo_hot_path_step(waymo_batch):
                "rot_z": torch.from_numpy(b["rot_z"]).to(d), "is_train": True})
     assert list(model.dataset.det_grid_size) == [1504, 1504, 40] and list(model.dataset.occ_grid_size) == [325, 697, 9]
     ret, tb, out = model(bd)
-    loss = ret["loss_occ"] + 1e-3 * ret["spatial_features"].pow(2).mean() + 1e-3 * ret["x_combine"].pow(2).mean()
+    loss = ret["loss_occ"] + 1e-3 * ret["spatial_features"].pow(2).mean() + 1e-3 * ret["x_combine"].float().pow(2).mean()
     loss.backward()
     torch.cuda.synchronize()
     assert torch.isfinite(loss)
