@@ -105,7 +105,7 @@ class MeanSquare(torch.autograd.Function):
         return (x * (g * (2.0 * ctx.k)).to(x.dtype)), None
 
 
-def make_step(model, ddp, proc, opts, grad_sync=None, prefetch_stream=None, threaded=True, det_stream=None):
+def make_step(model, ddp, proc, opts, grad_sync=None, prefetch_stream=None, threaded=True, det_stream=None, opt_stream=None):
     """one training step of the hot path.
 
     prefetch_stream: the weight-independent front of the NEXT batch (voxelizations, occupancy targets, the occupancy branch's
@@ -118,7 +118,15 @@ def make_step(model, ddp, proc, opts, grad_sync=None, prefetch_stream=None, thre
     branch's FORWARD.  The worker thread calls loss_occ.backward() (autograd runs those nodes on the main stream, where
     their forward ran) while this thread runs the detection branch on det_stream; both are chains of small launches that do
     not fill the GPU alone.  The detection branch's backward follows on det_stream, and the main stream joins it before the
-    optimizer."""
+    optimizer.
+
+    opt_stream (single GPU, one GroupOptimizer whose groups are [occupancy, detection]): the branches are detached, so two
+    backward passes give the same gradients as one over the sum.  The detection branch's pass is called with opt_stream
+    current: its nodes still run on the main stream (autograd runs a node where its forward ran), but the end-of-pass
+    synchronisation -- the engine's wait for the gradient-producing streams and the join of the weight-gradient side stream
+    -- lands on opt_stream, and the detection group's optimizer step follows there, beside the occupancy branch's backward on
+    the main stream.  The main stream never waits for the detection branch's weight-gradient tail; it joins opt_stream at
+    the end of the step."""
     from btcdet_amd.spconv import ops as _ops
     pending = {}
     pool = None
@@ -165,7 +173,13 @@ def make_step(model, ddp, proc, opts, grad_sync=None, prefetch_stream=None, thre
             # occupancy loss (real) + L2 stand-ins for the out-of-scope consumers of the detection branch
             loss_det = MeanSquare.apply(ret["spatial_features"], 1e-3) + MeanSquare.apply(ret["x_combine"], 1e-3)
             fut = pool.submit(prep, next_batch) if (ahead and threaded) else None
-            if split_backward:
+            if opt_stream is not None:
+                with torch.cuda.stream(opt_stream):
+                    loss_det.backward()
+                    opts[0].step(groups=[1])
+                ret["loss_occ"].backward()
+                loss = ret["loss_occ"].detach() + loss_det.detach()
+            elif split_backward:
                 # the branches are detached (PASS_GRAD False): two backward passes give the same gradients as one over the sum.
                 # The detection bucket (~90 % of the bytes) is packed and all-reduced BETWEEN them, from this thread -- it travels
                 # over xGMI while the occupancy branch's backward runs, with no hook in the autograd thread
@@ -181,8 +195,12 @@ def make_step(model, ddp, proc, opts, grad_sync=None, prefetch_stream=None, thre
         _ops.join_wgrad()   # no-op unless weight gradients are still owed (e.g. a backward pass whose end-of-pass callback never ran)
         if grad_sync is not None:
             grad_sync.finish()  # all-reduced mean gradients in param.grad
-        for o in opts:
-            o.step()
+        if opt_stream is not None:
+            opts[0].step(groups=[0])
+            torch.cuda.current_stream().wait_stream(opt_stream)
+        else:
+            for o in opts:
+                o.step()
         if ahead and not threaded:
             pending[id(next_batch)] = model.prepare(next_batch, stream=prefetch_stream)
         model.mark_step_end()
@@ -382,8 +400,13 @@ def main():
     prefetch = torch.cuda.Stream(device=device, priority=-1) if os.environ.get("BTC_PREFETCH", "2") != "0" else None
     # the detection branch on its own stream, beside the occupancy branch's backward (make_step)
     det_stream = torch.cuda.Stream(device=device) if (ddp is model and os.environ.get("BTC_SPLIT_BACKWARD", "0") == "1") else None
+    # the detection group's optimizer step beside the occupancy branch's backward (make_step); single process only -- with a
+    # gradient reducer the detection bucket's all-reduce takes that slot
+    early_opt = (grad_sync is None and ddp is model and det_stream is None and isinstance(opts[0], GroupOptimizer)
+                 and os.environ.get("BTC_EARLY_OPT", "1") != "0")
+    opt_stream = torch.cuda.Stream(device=device) if early_opt else None
     step = make_step(model, ddp, model.dataset.data_processor, opts, grad_sync, prefetch, threaded=os.environ.get("BTC_PREFETCH", "2") == "2",
-                     det_stream=det_stream)
+                     det_stream=det_stream, opt_stream=opt_stream)
     nb = len(batches)
 
     def sync():

@@ -105,6 +105,9 @@ _SIGS = {
     "btc_weights_to_bf16": (ci, [vp, ci, ci, ci, vp, vp, vp]),
     "btc_conv_fwd_bf16w": (ci, [vp, vp, vp, vp, ci, ci, ci, ci, vp, vp]),
     "btc_conv_dgrad_bf16w": (ci, [vp, vp, vp, ci, ci, ci, ci, vp, vp]),
+    "btc_row_orders": (ci, [vp, c_i32p, c_i32p, ci, vp, vp]),
+    "btc_conv_apply_ordered": (ci, [ci, ci, vp, vp, vp, vp, vp, ci, ci, ci, ci, vp, vp]),
+    "btc_conv_wgrad_ordered": (ci, [ci, vp, vp, vp, ci, vp, ci, vp, vp, ci, ci, ci, vp, vp, sz, vp]),
     "btc_maxpool_fwd": (ci, [vp, vp, ci, ci, ci, vp, vp]),
     "btc_maxpool_bwd": (ci, [vp, vp, vp, vp, ci, ci, ci, vp, vp]),
     "btc_dense_fwd": (ci, [vp, vp, ci, ci, c_i32p, vp, vp]),

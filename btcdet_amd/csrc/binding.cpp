@@ -92,21 +92,29 @@ Tensor weights_bf16(const Tensor& w, int64_t K, int64_t cin, int64_t cout, int64
 }
 
 // out = conv(features) ; features (n_src, Cin) fp32 | bf16 contiguous, w [K.., Cin, Cout] fp32, map_fwd (n_res, K) int32
-Tensor conv_fwd(const Tensor& features, const Tensor& w, const OptTensor& bias, const Tensor& map_fwd, int64_t stream) {
+// a row-order hint of a map (csrc/row_order.hip): int32 (n_rows,), or nothing
+const int32_t* order_ptr(const OptTensor& o, int64_t n_rows, const char* what) {
+  if (!o.has_value() || !o->defined()) return nullptr;
+  need(o->scalar_type() == at::kInt && o->is_contiguous() && o->numel() == n_rows, what);
+  return (const int32_t*)o->data_ptr();
+}
+
+Tensor conv_fwd(const Tensor& features, const Tensor& w, const OptTensor& bias, const Tensor& map_fwd, const OptTensor& order_fwd, int64_t stream) {
   const int64_t cin = w.size(-2), cout = w.size(-1), K = map_fwd.size(1), n_res = map_fwd.size(0);
   need(features.is_contiguous() && w.is_contiguous() && map_fwd.is_contiguous(), "conv_fwd: contiguous tensors expected");
   need(w.numel() == K * cin * cout && features.size(1) == cin, "conv_fwd: weight does not match the rulebook / features");
+  const int32_t* order = order_ptr(order_fwd, n_res, "conv_fwd: the row order does not match the map");
   Tensor out = at::empty({n_res, cout}, features.options());
   if (bf16_operands(features, K, cin, cout)) {
     Tensor q = weights_bf16(w, K, cin, cout, stream);
-    chk(btc_conv_fwd_bf16w(features.data_ptr(), (const char*)q.data_ptr() + 2 * w.numel(), fptr(bias), (const int32_t*)map_fwd.data_ptr(), (int)n_res,
-                           (int)K, (int)cin, (int)cout, out.data_ptr(), st(stream)), "btc_conv_fwd_bf16w");
-  } else if (features.scalar_type() == at::kBFloat16)
-    chk(btc_conv_fwd_bf16(features.data_ptr(), (const float*)w.data_ptr(), fptr(bias), (const int32_t*)map_fwd.data_ptr(), (int)n_res, (int)K,
-                          (int)cin, (int)cout, out.data_ptr(), st(stream)), "btc_conv_fwd_bf16");
-  else
-    chk(btc_conv_fwd((const float*)features.data_ptr(), (const float*)w.data_ptr(), fptr(bias), (const int32_t*)map_fwd.data_ptr(), (int)n_res,
-                     (int)K, (int)cin, (int)cout, (float*)out.data_ptr(), st(stream)), "btc_conv_fwd");
+    chk(btc_conv_apply_ordered(BTC_PASS_FWD, BTC_OPERANDS_BF16, features.data_ptr(), (const char*)q.data_ptr() + 2 * w.numel(), fptr(bias),
+                               (const int32_t*)map_fwd.data_ptr(), order, (int)n_res, (int)K, (int)cin, (int)cout, out.data_ptr(), st(stream)),
+        "btc_conv_apply_ordered (fwd, bf16 operands)");
+  } else {
+    const int operands = features.scalar_type() == at::kBFloat16 ? BTC_OPERANDS_BF16_ACT : BTC_OPERANDS_F32;
+    chk(btc_conv_apply_ordered(BTC_PASS_FWD, operands, features.data_ptr(), w.data_ptr(), fptr(bias), (const int32_t*)map_fwd.data_ptr(), order,
+                               (int)n_res, (int)K, (int)cin, (int)cout, out.data_ptr(), st(stream)), "btc_conv_apply_ordered (fwd)");
+  }
   return out;
 }
 
@@ -132,10 +140,10 @@ std::tuple<Tensor, Tensor> bn_fwd(const Tensor& x, const OptTensor& gamma, const
 }
 
 std::tuple<Tensor, Tensor, Tensor> conv_bn_fwd(const Tensor& features, const Tensor& w, const OptTensor& bias, const Tensor& map_fwd,
-                                               const OptTensor& gamma, const OptTensor& beta, const OptTensor& rm, const OptTensor& rv,
+                                               const OptTensor& order_fwd, const OptTensor& gamma, const OptTensor& beta, const OptTensor& rm, const OptTensor& rv,
                                                const OptTensor& nbt, bool use_batch, double momentum, double eps, bool relu, const Tensor& ws,
                                                int64_t ws_bytes, int64_t stream) {
-  Tensor x = conv_fwd(features, w, bias, map_fwd, stream);
+  Tensor x = conv_fwd(features, w, bias, map_fwd, order_fwd, stream);
   auto ys = bn_fwd(x, gamma, beta, rm, rv, nbt, use_batch, momentum, eps, relu, ws, ws_bytes, stream);
   return std::make_tuple(x, std::get<0>(ys), std::get<1>(ys));
 }
@@ -211,11 +219,12 @@ void set_defer_wgrad_join(bool on) { g_defer_join = on; }
 // stream beside dgrad (fork / join with events, no host sync); every temporary is released after the join has been enqueued,
 // so the caching allocator's stream-ordered reuse stays valid without recordStream.
 std::tuple<OptTensor, OptTensor> conv_bwd(const Tensor& features, const Tensor& w, const Tensor& map_fwd, const Tensor& map_bwd,
-                                          const Tensor& grad_out, bool need_din, bool need_dw, bool overlap, bool allow_defer,
-                                          int64_t stream) {
+                                          const OptTensor& order_bwd, const Tensor& grad_out, bool need_din, bool need_dw, bool overlap,
+                                          bool allow_defer, int64_t stream) {
   const int64_t cin = w.size(-2), cout = w.size(-1), K = map_fwd.size(1), n_res = map_fwd.size(0), n_src = map_bwd.size(0);
   need(grad_out.is_contiguous() && grad_out.scalar_type() == features.scalar_type(), "conv_bwd: grad must be contiguous and of the activation type");
   const bool bf = features.scalar_type() == at::kBFloat16;
+  const int32_t* order = order_ptr(order_bwd, n_src, "conv_bwd: the row order does not match the map");
   OptTensor din, dw;
   Tensor ws;
   hipStream_t main = (hipStream_t)st(stream);
@@ -242,14 +251,12 @@ std::tuple<OptTensor, OptTensor> conv_bwd(const Tensor& features, const Tensor& 
     Tensor d = at::empty({n_src, cin}, features.options());
     if (bf16_operands(grad_out, K, cout, cin)) {
       Tensor q = weights_bf16(w, K, cin, cout, stream);
-      chk(btc_conv_dgrad_bf16w(grad_out.data_ptr(), q.data_ptr(), (const int32_t*)map_bwd.data_ptr(), (int)n_src, (int)K, (int)cin, (int)cout,
-                               d.data_ptr(), st(stream)), "btc_conv_dgrad_bf16w");
-    } else if (bf)
-      chk(btc_conv_dgrad_bf16(grad_out.data_ptr(), (const float*)w.data_ptr(), (const int32_t*)map_bwd.data_ptr(), (int)n_src, (int)K, (int)cin,
-                              (int)cout, d.data_ptr(), st(stream)), "btc_conv_dgrad_bf16");
-    else
-      chk(btc_conv_dgrad((const float*)grad_out.data_ptr(), (const float*)w.data_ptr(), (const int32_t*)map_bwd.data_ptr(), (int)n_src, (int)K,
-                         (int)cin, (int)cout, (float*)d.data_ptr(), st(stream)), "btc_conv_dgrad");
+      chk(btc_conv_apply_ordered(BTC_PASS_DGRAD, BTC_OPERANDS_BF16, grad_out.data_ptr(), q.data_ptr(), nullptr, (const int32_t*)map_bwd.data_ptr(),
+                                 order, (int)n_src, (int)K, (int)cin, (int)cout, d.data_ptr(), st(stream)), "btc_conv_apply_ordered (dgrad, bf16 operands)");
+    } else
+      chk(btc_conv_apply_ordered(BTC_PASS_DGRAD, bf ? BTC_OPERANDS_BF16_ACT : BTC_OPERANDS_F32, grad_out.data_ptr(), w.data_ptr(), nullptr,
+                                 (const int32_t*)map_bwd.data_ptr(), order, (int)n_src, (int)K, (int)cin, (int)cout, d.data_ptr(), st(stream)),
+          "btc_conv_apply_ordered (dgrad)");
     din = d;
   }
   };
@@ -302,6 +309,34 @@ std::tuple<OptTensor, OptTensor> conv_bwd(const Tensor& features, const Tensor& 
   return std::make_tuple(din, dw);
 }
 
+// row-order hints (csrc/row_order.hip) of several neighbour maps from ONE launch: order[j] is a slice of one buffer.  The apply
+// kernels tile the rows in that order (rows with the same offsets share a tile); results do not depend on it.
+std::vector<Tensor> row_orders(const std::vector<Tensor>& maps, int64_t stream) {
+  std::vector<Tensor> out(maps.size());
+  for (size_t base = 0; base < maps.size(); base += BTC_ROW_ORDER_MAX_MAPS) {
+    const size_t m = std::min(maps.size() - base, (size_t)BTC_ROW_ORDER_MAX_MAPS);
+    std::vector<const int32_t*> ptrs(m);
+    std::vector<int32_t> ns(m), ks(m);
+    int64_t total = 0;
+    for (size_t j = 0; j < m; ++j) {
+      const Tensor& t = maps[base + j];
+      need(t.dim() == 2 && t.scalar_type() == at::kInt && t.is_contiguous(), "row_orders: (n, K) int32 contiguous maps expected");
+      ptrs[j] = (const int32_t*)t.data_ptr();
+      ns[j] = (int32_t)t.size(0);
+      ks[j] = (int32_t)t.size(1);
+      total += t.size(0);
+    }
+    Tensor order = at::empty({total > 0 ? total : 1}, maps[base].options());
+    chk(btc_row_orders(ptrs.data(), ns.data(), ks.data(), (int)m, (int32_t*)order.data_ptr(), st(stream)), "btc_row_orders");
+    int64_t off = 0;
+    for (size_t j = 0; j < m; ++j) {
+      out[base + j] = order.narrow(0, off, ns[j]);
+      off += ns[j];
+    }
+  }
+  return out;
+}
+
 // submanifold rulebook: returns nbr (2, n, K) = nbr_out | nbr_in.  p_* are the addresses of int32[3] host arrays.
 Tensor rulebook_subm(const Tensor& indices, int64_t batch, int64_t p_in, int64_t p_k, int64_t p_d, int64_t K, int64_t stream) {
   const int64_t n = indices.size(0);
@@ -315,7 +350,7 @@ Tensor rulebook_subm(const Tensor& indices, int64_t batch, int64_t p_in, int64_t
 }
 
 // strided / transposed rulebook, synchronous: count, one blocking 4-byte read-back, fill
-std::tuple<Tensor, Tensor, Tensor> rulebook_conv(const Tensor& indices, int64_t batch, int64_t p_in, int64_t p_out, int64_t p_k, int64_t p_s,
+std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor> rulebook_conv(const Tensor& indices, int64_t batch, int64_t p_in, int64_t p_out, int64_t p_k, int64_t p_s,
                                                  int64_t p_p, int64_t p_d, int64_t mode, int64_t K, int64_t ws_bytes, int64_t stream) {
   const int64_t n = indices.size(0);
   Tensor ws = at::empty({ws_bytes > 256 ? ws_bytes : 256}, indices.options().dtype(at::kByte));
@@ -329,7 +364,8 @@ std::tuple<Tensor, Tensor, Tensor> rulebook_conv(const Tensor& indices, int64_t 
   chk(btc_rulebook_conv_fill((const int32_t*)indices.data_ptr(), (int)n, (int)batch, ip(p_in), ip(p_out), ip(p_k), ip(p_s), ip(p_p), ip(p_d),
                              (int)mode, (int)n_out, (int32_t*)out_indices.data_ptr(), (int32_t*)nbr_out.data_ptr(), (int32_t*)nbr_in.data_ptr(),
                              ws.data_ptr(), (size_t)ws_bytes, st(stream)), "btc_rulebook_conv_fill");
-  return std::make_tuple(out_indices, nbr_out, nbr_in);
+  auto ord = row_orders({nbr_out, nbr_in}, stream);
+  return std::make_tuple(out_indices, nbr_out, nbr_in, ord[0], ord[1]);
 }
 
 inline int64_t current_stream() { return reinterpret_cast<int64_t>(c10::hip::getCurrentHIPStream().stream()); }
@@ -391,7 +427,7 @@ std::shared_ptr<PendingRb> rulebook_conv_start(const Tensor& indices, int64_t ba
   return p;
 }
 
-std::tuple<Tensor, Tensor, Tensor> rulebook_conv_finish(const std::shared_ptr<PendingRb>& p) {
+std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor> rulebook_conv_finish(const std::shared_ptr<PendingRb>& p) {
   if (hipEventSynchronize(p->done) != hipSuccess) throw std::runtime_error("rulebook lookahead: event synchronize failed");
   const int64_t n_out = *p->host_n, n = p->indices.size(0), K = p->K;
   hipStream_t main = (hipStream_t)st(current_stream());
@@ -402,8 +438,9 @@ std::tuple<Tensor, Tensor, Tensor> rulebook_conv_finish(const std::shared_ptr<Pe
   chk(btc_rulebook_conv_fill((const int32_t*)p->indices.data_ptr(), (int)n, (int)p->batch, ip(p->p_in), ip(p->p_out), ip(p->p_k), ip(p->p_s),
                              ip(p->p_p), ip(p->p_d), (int)p->mode, (int)n_out, (int32_t*)out_indices.data_ptr(), (int32_t*)nbr_out.data_ptr(),
                              (int32_t*)nbr_in.data_ptr(), p->ws.data_ptr(), (size_t)p->ws_bytes, (void*)main), "btc_rulebook_conv_fill");
+  auto ord = row_orders({nbr_out, nbr_in}, (int64_t)(intptr_t)main);
   dbg_sync("rulebook_conv_finish");
-  return std::make_tuple(out_indices, nbr_out, nbr_in);
+  return std::make_tuple(out_indices, nbr_out, nbr_in, ord[0], ord[1]);
 }
 
 // conv -> BatchNorm1d (-> ReLU) as a C++ autograd node: the same three launches as ops.SparseConvBNReLUFunction without the
@@ -411,13 +448,15 @@ std::tuple<Tensor, Tensor, Tensor> rulebook_conv_finish(const std::shared_ptr<Pe
 // backward stream right before dgrad (no side-stream overlap here; Python keeps that variant for the 20 K - 100 K-row layers).
 struct ConvBNReLUNode : public torch::autograd::Function<ConvBNReLUNode> {
   static Tensor forward(torch::autograd::AutogradContext* ctx, const Tensor& features, const Tensor& weight, const OptTensor& bias,
-                        const Tensor& map_fwd, const Tensor& map_bwd, const OptTensor& gamma, const OptTensor& beta, const OptTensor& rm,
-                        const OptTensor& rv, const OptTensor& nbt, bool use_batch, double momentum, double eps, bool relu, const Tensor& ws,
-                        int64_t ws_bytes, bool overlap, bool allow_defer) {
+                        const Tensor& map_fwd, const Tensor& map_bwd, const OptTensor& order_fwd, const OptTensor& order_bwd,
+                        const OptTensor& gamma, const OptTensor& beta, const OptTensor& rm, const OptTensor& rv, const OptTensor& nbt,
+                        bool use_batch, double momentum, double eps, bool relu, const Tensor& ws, int64_t ws_bytes, bool overlap,
+                        bool allow_defer) {
     const int64_t stream = current_stream();
-    auto r = conv_bn_fwd(features, weight, bias, map_fwd, gamma, beta, rm, rv, nbt, use_batch, momentum, eps, relu, ws, ws_bytes, stream);
+    auto r = conv_bn_fwd(features, weight, bias, map_fwd, order_fwd, gamma, beta, rm, rv, nbt, use_batch, momentum, eps, relu, ws, ws_bytes, stream);
     const Tensor g = (gamma.has_value() && gamma->defined()) ? *gamma : Tensor();
-    ctx->save_for_backward({features, weight, map_fwd, map_bwd, std::get<0>(r), std::get<1>(r), g, std::get<2>(r), ws});
+    const Tensor ob = (order_bwd.has_value() && order_bwd->defined()) ? *order_bwd : Tensor();
+    ctx->save_for_backward({features, weight, map_fwd, map_bwd, std::get<0>(r), std::get<1>(r), g, std::get<2>(r), ws, ob});
     ctx->saved_data["use_batch"] = use_batch;
     ctx->saved_data["relu"] = relu;
     ctx->saved_data["ws_bytes"] = ws_bytes;
@@ -441,7 +480,9 @@ struct ConvBNReLUNode : public torch::autograd::Function<ConvBNReLUNode> {
     auto b = bn_bwd(x, y, dy, og, stats, use_batch, relu, ws, ws_bytes, stream);
     const Tensor& dx = std::get<0>(b);
     const Tensor& dparam = std::get<1>(b);
-    auto cb = conv_bwd(features, w, map_fwd, map_bwd, dx, ctx->needs_input_grad(0), ctx->needs_input_grad(1),
+    OptTensor order_bwd;
+    if (saved[9].defined()) order_bwd = saved[9];
+    auto cb = conv_bwd(features, w, map_fwd, map_bwd, order_bwd, dx, ctx->needs_input_grad(0), ctx->needs_input_grad(1),
                        ctx->saved_data["overlap"].toBool(), ctx->saved_data["allow_defer"].toBool(), stream);
     Tensor din = std::get<0>(cb).has_value() ? *std::get<0>(cb) : Tensor();
     Tensor dw = std::get<1>(cb).has_value() ? *std::get<1>(cb) : Tensor();
@@ -460,15 +501,15 @@ struct ConvBNReLUNode : public torch::autograd::Function<ConvBNReLUNode> {
       dgamma = dparam[0];
       dbeta = dparam[1];
     }
-    return {din, dw, db, Tensor(), Tensor(), dgamma, dbeta, Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(),
+    return {din, dw, db, Tensor(), Tensor(), Tensor(), Tensor(), dgamma, dbeta, Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(),
             Tensor(), Tensor()};
   }
 };
 
 Tensor conv_bn_relu(const Tensor& features, const Tensor& weight, const OptTensor& bias, const Tensor& map_fwd, const Tensor& map_bwd,
-                    const OptTensor& gamma, const OptTensor& beta, const OptTensor& rm, const OptTensor& rv, const OptTensor& nbt, bool use_batch,
+                    const OptTensor& order_fwd, const OptTensor& order_bwd, const OptTensor& gamma, const OptTensor& beta, const OptTensor& rm, const OptTensor& rv, const OptTensor& nbt, bool use_batch,
                     double momentum, double eps, bool relu, const Tensor& ws, int64_t ws_bytes, bool overlap, bool allow_defer) {
-  return ConvBNReLUNode::apply(features, weight, bias, map_fwd, map_bwd, gamma, beta, rm, rv, nbt, use_batch, momentum, eps, relu, ws, ws_bytes,
+  return ConvBNReLUNode::apply(features, weight, bias, map_fwd, map_bwd, order_fwd, order_bwd, gamma, beta, rm, rv, nbt, use_batch, momentum, eps, relu, ws, ws_bytes,
                                overlap, allow_defer);
 }
 
@@ -476,7 +517,8 @@ Tensor conv_bn_relu(const Tensor& features, const Tensor& weight, const OptTenso
 // beside the backward pass: one call, GIL released, instead of a Python walk over the layers that competes with the autograd
 // thread for the GIL).  kind: 0 = build submanifold, 1 = build strided / transposed, 2 = inverse of layer ref (continue on ITS
 // input level), 3 = reuse layer ref's rulebook (continue on its output level).  Returns per built layer
-// {in_indices, out_indices, nbr_out, nbr_in}, an empty list for the others.
+// {in_indices, out_indices, nbr_out, nbr_in} (+ {order_out, order_in}, the row-order hints, for strided / transposed layers), an
+// empty list for the others.
 // Two phases of the C ABI around ONE read-back for the whole chain (btc_chain_levels / btc_chain_maps, csrc/rulebook.hip): the
 // levels are built on the device with their row counts left there and their rows written into capacity-sized buffers (16
 // bytes a row -- HBM is 288 GB, the untouched tail costs nothing); the counts come back together; the maps are sized exactly.
@@ -570,6 +612,26 @@ std::vector<std::vector<Tensor>> geometry_walk(const Tensor& indices, int64_t ba
   }
   chk(btc_chain_maps((const int32_t*)indices.data_ptr(), n0, (int)batch, layers.data(), (int)n, hc, p_out_idx.data(), p_nbr_out.data(),
                      p_nbr_in.data(), ws.data_ptr(), wsb, st(stream)), "btc_chain_maps");
+  // row-order hints of the strided / transposed layers' maps (both directions), one launch for the chain: these are the maps
+  // whose 16-row tiles are mostly empty in coordinate order (csrc/row_order.hip).  BTC_ROW_ORDER=2 orders the SubM maps too
+  // (measured: within noise at KITTI sizes), 0 none.
+  static const int order_mode = getenv("BTC_ROW_ORDER") ? atoi(getenv("BTC_ROW_ORDER")) : 1;
+  auto wants_order = [&](size_t i) { return K[i] <= 64 && ((kind[i] == 1 && order_mode >= 1) || (kind[i] == 0 && order_mode >= 2)); };
+  std::vector<Tensor> to_order;
+  for (size_t i = 0; i < n; ++i)
+    if (wants_order(i)) {
+      to_order.push_back(out[i][2]);
+      to_order.push_back(out[i][3]);
+    }
+  if (!to_order.empty()) {
+    auto ord = row_orders(to_order, stream);
+    size_t q = 0;
+    for (size_t i = 0; i < n; ++i)
+      if (wants_order(i)) {
+        out[i].push_back(ord[q++]);
+        out[i].push_back(ord[q++]);
+      }
+  }
   dbg_sync("geometry_walk");
   return out;
 }
@@ -578,19 +640,20 @@ std::vector<std::vector<Tensor>> geometry_walk(const Tensor& indices, int64_t ba
 // BtcHotPath.prepare): the same autograd nodes as one conv_bn_relu call per layer, entered from Python ONCE -- the per-layer
 // Python (module call, SparseConvolution.forward, argument marshalling: ~60 us a layer) is what bounds the forward pass
 Tensor conv_bn_relu_chain(const Tensor& features, const std::vector<Tensor>& weights, const std::vector<OptTensor>& biases,
-                          const std::vector<Tensor>& map_fwd, const std::vector<Tensor>& map_bwd, const std::vector<OptTensor>& gammas,
+                          const std::vector<Tensor>& map_fwd, const std::vector<Tensor>& map_bwd, const std::vector<OptTensor>& order_fwd,
+                          const std::vector<OptTensor>& order_bwd, const std::vector<OptTensor>& gammas,
                           const std::vector<OptTensor>& betas, const std::vector<OptTensor>& rms, const std::vector<OptTensor>& rvs,
                           const std::vector<OptTensor>& nbts, const std::vector<bool>& use_batch, const std::vector<double>& momenta,
                           const std::vector<double>& epss, const std::vector<bool>& relus, const Tensor& ws, const std::vector<int64_t>& ws_bytes,
                           const std::vector<bool>& overlaps, const std::vector<bool>& allow_defers) {
   const size_t L = weights.size();
-  need(L >= 1 && biases.size() == L && map_fwd.size() == L && map_bwd.size() == L && gammas.size() == L && betas.size() == L && rms.size() == L &&
+  need(L >= 1 && biases.size() == L && map_fwd.size() == L && map_bwd.size() == L && order_fwd.size() == L && order_bwd.size() == L && gammas.size() == L && betas.size() == L && rms.size() == L &&
            rvs.size() == L && nbts.size() == L && use_batch.size() == L && momenta.size() == L && epss.size() == L && relus.size() == L &&
            ws_bytes.size() == L && overlaps.size() == L && allow_defers.size() == L,
        "conv_bn_relu_chain: per-layer argument lists differ in length");
   Tensor x = features;
   for (size_t i = 0; i < L; ++i)
-    x = ConvBNReLUNode::apply(x, weights[i], biases[i], map_fwd[i], map_bwd[i], gammas[i], betas[i], rms[i], rvs[i], nbts[i], use_batch[i],
+    x = ConvBNReLUNode::apply(x, weights[i], biases[i], map_fwd[i], map_bwd[i], order_fwd[i], order_bwd[i], gammas[i], betas[i], rms[i], rvs[i], nbts[i], use_batch[i],
                               momenta[i], epss[i], relus[i], ws, ws_bytes[i], overlaps[i], allow_defers[i]);
   return x;
 }
@@ -605,6 +668,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("bn_bwd", &bn_bwd, py::call_guard<py::gil_scoped_release>());
   m.def("conv_bwd", &conv_bwd, py::call_guard<py::gil_scoped_release>());
   m.def("conv_bn_relu", &conv_bn_relu, py::call_guard<py::gil_scoped_release>());
+  m.def("row_orders", &row_orders, py::call_guard<py::gil_scoped_release>());
   m.def("geometry_walk", &geometry_walk, py::call_guard<py::gil_scoped_release>());
   m.def("conv_bn_relu_chain", &conv_bn_relu_chain, py::call_guard<py::gil_scoped_release>());
   m.def("join_wgrad", &join_wgrad, py::call_guard<py::gil_scoped_release>());

@@ -45,8 +45,9 @@ __device__ __forceinline__ void wait_vm_b() {
 
 template <int WR, int WC, int NTW, int KC>
 __global__ __launch_bounds__(64 * WR * WC) void conv_apply_b(const unsigned short* __restrict__ feat, const unsigned short* __restrict__ Wq,
-                                                             const float* __restrict__ bias, const int32_t* __restrict__ nbr, int n_rows,
-                                                             int K, int Cred, int Cres, unsigned short* __restrict__ out, int xcd_swizzle) {
+                                                             const float* __restrict__ bias, const int32_t* __restrict__ nbr,
+                                                             const int32_t* __restrict__ order, int n_rows, int K, int Cred, int Cres,
+                                                             unsigned short* __restrict__ out, int xcd_swizzle) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NW = WR * WC, THREADS = 64 * NW;
   constexpr int TM = 16 * WR, TN = 16 * NTW * WC;
@@ -63,6 +64,7 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_apply_b(const unsigned shor
   int32_t* s_nbr = (int32_t*)(ring + B_STAGES * STAGE);  // [TM][K]
   int32_t* s_kact = s_nbr + TM * K;
   int32_t* s_nact = s_kact + K;
+  int32_t* s_row = s_nact + 1;                           // [TM] row of each tile slot (order[] or identity), -1 past the end
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave / WC, wc = wave % WC;
@@ -75,14 +77,14 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_apply_b(const unsigned shor
   const int n0 = blockIdx.y * TN;
 
   for (int e = tid; e < K; e += THREADS) s_kact[e] = 0;
+  for (int e = tid; e < TM; e += THREADS) s_row[e] = (row0 + e < n_rows) ? (order ? order[row0 + e] : row0 + e) : -1;
   __syncthreads();
-  {
-    const long long gbase = (long long)row0 * K, gend = (long long)n_rows * K;
-    for (int e = tid; e < TM * K; e += THREADS) {
-      const int v = (gbase + e < gend) ? nbr[gbase + e] : -1;
-      s_nbr[e] = v;
-      if (v >= 0) s_kact[e % K] = 1;
-    }
+  for (int e = tid; e < TM * K; e += THREADS) {
+    const int rloc = e / K, kk = e - rloc * K;
+    const int gr = s_row[rloc];
+    const int v = gr >= 0 ? nbr[(long long)gr * K + kk] : -1;
+    s_nbr[e] = v;
+    if (v >= 0) s_kact[kk] = 1;
   }
   __syncthreads();
   unsigned long long wave_act;
@@ -181,20 +183,20 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_apply_b(const unsigned shor
     const float bv0 = bias ? bias[col] : 0.f;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int row = row0 + wr * 16 + kq * 4 + r;
-      if (row < n_rows) out[(size_t)row * Cres + col] = btc_f32_to_bf16(bias ? (acc[nt][r] + bv0) : acc[nt][r]);
+      const int row = s_row[wr * 16 + kq * 4 + r];
+      if (row >= 0) out[(size_t)row * Cres + col] = btc_f32_to_bf16(bias ? (acc[nt][r] + bv0) : acc[nt][r]);
     }
   }
 }
 
 size_t lds_bytes_b(int tm, int tn, int kc, int K) {
   const size_t a = ((size_t)tm * kc * 2 + 1023) / 1024 * 1024, b = ((size_t)tn * kc * 2 + 1023) / 1024 * 1024;
-  return (size_t)B_STAGES * (a + b) + (size_t)(tm * K + K + 1) * sizeof(int32_t);
+  return (size_t)B_STAGES * (a + b) + (size_t)(tm * K + K + 1 + tm) * sizeof(int32_t);
 }
 
 template <int WR, int WC, int NTW, int KC>
-int launch_b(const unsigned short* feat, const unsigned short* Wq, const float* bias, const int32_t* nbr, int n_rows, int K, int Cred, int Cres,
-             unsigned short* out, int xcd, hipStream_t stream) {
+int launch_b(const unsigned short* feat, const unsigned short* Wq, const float* bias, const int32_t* nbr, const int32_t* order, int n_rows, int K, int Cred,
+             int Cres, unsigned short* out, int xcd, hipStream_t stream) {
   constexpr int TM = 16 * WR, TN = 16 * NTW * WC;
   const size_t lds = lds_bytes_b(TM, TN, KC, K);
   BTC_CHECK_ARG(lds <= 160 * 1024, "conv_apply_b: tile does not fit the LDS");
@@ -203,20 +205,20 @@ int launch_b(const unsigned short* feat, const unsigned short* Wq, const float* 
     (void)hipFuncSetAttribute((const void*)conv_apply_b<WR, WC, NTW, KC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   });
   dim3 grid(btc_cdiv(n_rows, TM), Cres / TN);
-  conv_apply_b<WR, WC, NTW, KC><<<grid, 64 * WR * WC, lds, stream>>>(feat, Wq, bias, nbr, n_rows, K, Cred, Cres, out, xcd);
+  conv_apply_b<WR, WC, NTW, KC><<<grid, 64 * WR * WC, lds, stream>>>(feat, Wq, bias, nbr, order, n_rows, K, Cred, Cres, out, xcd);
   BTC_LAUNCH_CHECK();
   return BTC_OK;
 }
 
 template <int WR, int WC, int NTW>
-int launch_b_kc(int kc, const unsigned short* feat, const unsigned short* Wq, const float* bias, const int32_t* nbr, int n_rows, int K, int Cred,
-                int Cres, unsigned short* out, int xcd, hipStream_t stream) {
-  if (kc == 64) return launch_b<WR, WC, NTW, 64>(feat, Wq, bias, nbr, n_rows, K, Cred, Cres, out, xcd, stream);
-  return launch_b<WR, WC, NTW, 32>(feat, Wq, bias, nbr, n_rows, K, Cred, Cres, out, xcd, stream);
+int launch_b_kc(int kc, const unsigned short* feat, const unsigned short* Wq, const float* bias, const int32_t* nbr, const int32_t* order, int n_rows,
+                int K, int Cred, int Cres, unsigned short* out, int xcd, hipStream_t stream) {
+  if (kc == 64) return launch_b<WR, WC, NTW, 64>(feat, Wq, bias, nbr, order, n_rows, K, Cred, Cres, out, xcd, stream);
+  return launch_b<WR, WC, NTW, 32>(feat, Wq, bias, nbr, order, n_rows, K, Cred, Cres, out, xcd, stream);
 }
 
-int apply_b(const void* feat_, const void* Wq_, const float* bias, const int32_t* nbr, int n_rows, int K, int Cred, int Cres, void* out_,
-            hipStream_t stream) {
+int apply_b(const void* feat_, const void* Wq_, const float* bias, const int32_t* nbr, const int32_t* order, int n_rows, int K, int Cred, int Cres,
+            void* out_, hipStream_t stream) {
   if (n_rows <= 0) return BTC_OK;
   const unsigned short* feat = (const unsigned short*)feat_;
   const unsigned short* Wq = (const unsigned short*)Wq_;
@@ -225,13 +227,13 @@ int apply_b(const void* feat_, const void* Wq_, const float* bias, const int32_t
   const int xcd = btc_tune_get(BTC_TUNE_APPLY_XCD) == 2;
   // wave shapes as conv_apply_g's policy (sparse_conv.hip): 64 rows x 128 columns on 8 waves for wide results, 16-row
   // workgroups with 4 waves across the columns when there are few rows
-  if (Cres % 128 == 0) return launch_b_kc<4, 2, 4>(kc, feat, Wq, bias, nbr, n_rows, K, Cred, Cres, out, xcd, stream);
+  if (Cres % 128 == 0) return launch_b_kc<4, 2, 4>(kc, feat, Wq, bias, nbr, order, n_rows, K, Cred, Cres, out, xcd, stream);
   if (Cres % 64 == 0) {
-    if (n_rows < 8192) return launch_b_kc<1, 4, 1>(kc, feat, Wq, bias, nbr, n_rows, K, Cred, Cres, out, xcd, stream);
-    return launch_b_kc<4, 2, 2>(kc, feat, Wq, bias, nbr, n_rows, K, Cred, Cres, out, xcd, stream);
+    if (n_rows < 8192) return launch_b_kc<1, 4, 1>(kc, feat, Wq, bias, nbr, order, n_rows, K, Cred, Cres, out, xcd, stream);
+    return launch_b_kc<4, 2, 2>(kc, feat, Wq, bias, nbr, order, n_rows, K, Cred, Cres, out, xcd, stream);
   }
-  if (Cres % 32 == 0) return launch_b_kc<2, 2, 1>(kc, feat, Wq, bias, nbr, n_rows, K, Cred, Cres, out, xcd, stream);
-  return launch_b_kc<4, 1, 1>(kc, feat, Wq, bias, nbr, n_rows, K, Cred, Cres, out, xcd, stream);
+  if (Cres % 32 == 0) return launch_b_kc<2, 2, 1>(kc, feat, Wq, bias, nbr, order, n_rows, K, Cred, Cres, out, xcd, stream);
+  return launch_b_kc<4, 1, 1>(kc, feat, Wq, bias, nbr, order, n_rows, K, Cred, Cres, out, xcd, stream);
 }
 
 __global__ __launch_bounds__(256) void weights_to_bf16(const float* __restrict__ W, int K, int Cin, int Cout, unsigned short* __restrict__ w_b,
@@ -249,6 +251,11 @@ __global__ __launch_bounds__(256) void weights_to_bf16(const float* __restrict__
 
 }  // namespace
 
+int btc_apply_bf16w(const void* src, const void* Wq, const float* bias, const int32_t* nbr, const int32_t* order, int n_rows, int K, int Cred,
+                    int Cres, void* dst, hipStream_t stream) {
+  return apply_b(src, Wq, bias, nbr, order, n_rows, K, Cred, Cres, dst, stream);
+}
+
 extern "C" int btc_conv_bf16w_supported(int K, int Cred, int Cres) { return K >= 1 && K <= 64 && Cred >= 32 && Cred % 32 == 0 && Cres % 16 == 0; }
 
 extern "C" int btc_weights_to_bf16(const float* W, int K, int Cin, int Cout, void* w_bf16, void* wt_bf16, void* stream) {
@@ -263,12 +270,12 @@ extern "C" int btc_conv_fwd_bf16w(const void* feat, const void* wt_bf16, const f
                                   int Cout, void* out, void* stream) {
   BTC_CHECK_ARG(n_out >= 0 && btc_conv_bf16w_supported(K, Cin, Cout), "btc_conv_fwd_bf16w: needs K <= 64, Cin %% 32 == 0, Cout %% 16 == 0 (K=%d, %d -> %d)",
                 K, Cin, Cout);
-  return apply_b(feat, wt_bf16, bias, nbr_out, n_out, K, /*Cred=*/Cin, /*Cres=*/Cout, out, (hipStream_t)stream);
+  return apply_b(feat, wt_bf16, bias, nbr_out, nullptr, n_out, K, /*Cred=*/Cin, /*Cres=*/Cout, out, (hipStream_t)stream);
 }
 
 extern "C" int btc_conv_dgrad_bf16w(const void* dout, const void* w_bf16, const int32_t* nbr_in, int n_in, int K, int Cin, int Cout, void* din,
                                     void* stream) {
   BTC_CHECK_ARG(n_in >= 0 && btc_conv_bf16w_supported(K, Cout, Cin), "btc_conv_dgrad_bf16w: needs K <= 64, Cout %% 32 == 0, Cin %% 16 == 0 (K=%d, %d -> %d)",
                 K, Cin, Cout);
-  return apply_b(dout, w_bf16, nullptr, nbr_in, n_in, K, /*Cred=*/Cout, /*Cres=*/Cin, din, (hipStream_t)stream);
+  return apply_b(dout, w_bf16, nullptr, nbr_in, nullptr, n_in, K, /*Cred=*/Cout, /*Cres=*/Cin, din, (hipStream_t)stream);
 }

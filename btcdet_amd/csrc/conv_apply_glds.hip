@@ -42,8 +42,8 @@ __device__ __forceinline__ void wait_vm() {
 template <int WR, int WC, int NTW, bool TRANS_W, int KC, bool BF>
 __global__ __launch_bounds__(64 * WR * WC) void conv_apply_g(const void* __restrict__ feat_, const float* __restrict__ W,
                                                              const float* __restrict__ bias, const int32_t* __restrict__ nbr,
-                                                             int n_rows, int K, int Cred, int Cres, void* __restrict__ out_,
-                                                             int xcd_swizzle, int dbg) {
+                                                             const int32_t* __restrict__ order, int n_rows, int K, int Cred, int Cres,
+                                                             void* __restrict__ out_, int xcd_swizzle, int dbg) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NW = WR * WC, THREADS = 64 * NW;
   constexpr int TM = 16 * WR, TN = 16 * NTW * WC, NG = NTW * WC;  // NG: 16-column groups of the B image
@@ -63,6 +63,7 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_apply_g(const void* __restr
   int32_t* s_nbr = (int32_t*)(ring + G_STAGES * STAGE);  // [TM][K]
   int32_t* s_kact = s_nbr + TM * K;                // [K] flags, then the compact list of active offsets
   int32_t* s_nact = s_kact + K;                    // [1]
+  int32_t* s_row = s_nact + 1;                     // [TM] the row each tile slot works on (order[] or identity), -1 past the end
   const char* feat = (const char*)feat_;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -76,15 +77,14 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_apply_g(const void* __restr
   const int n0 = blockIdx.y * TN;
 
   for (int e = tid; e < K; e += THREADS) s_kact[e] = 0;
+  for (int e = tid; e < TM; e += THREADS) s_row[e] = (row0 + e < n_rows) ? (order ? order[row0 + e] : row0 + e) : -1;
   __syncthreads();
-  {
-    const long long gbase = (long long)row0 * K;
-    const long long gend = (long long)n_rows * K;
-    for (int e = tid; e < TM * K; e += THREADS) {
-      int v = (gbase + e < gend) ? nbr[gbase + e] : -1;
-      s_nbr[e] = v;
-      if (v >= 0) s_kact[e % K] = 1;
-    }
+  for (int e = tid; e < TM * K; e += THREADS) {
+    const int rloc = e / K, kk = e - rloc * K;
+    const int gr = s_row[rloc];
+    const int v = gr >= 0 ? nbr[(long long)gr * K + kk] : -1;
+    s_nbr[e] = v;
+    if (v >= 0) s_kact[kk] = 1;
   }
   __syncthreads();
   // offsets this wave's 16-row group touches: lane k scans its column of the map (K <= 64)
@@ -216,8 +216,8 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_apply_g(const void* __restr
     const float bv0 = bias ? bias[col] : 0.f;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      int row = row0 + wr * 16 + kq * 4 + r;
-      if (row < n_rows) {
+      const int row = s_row[wr * 16 + kq * 4 + r];
+      if (row >= 0) {
         const float v = bias ? (acc[nt][r] + bv0) : acc[nt][r];
         if (!BF) ((float*)out_)[(size_t)row * Cres + col] = v;
         else ((unsigned short*)out_)[(size_t)row * Cres + col] = btc_f32_to_bf16(v);
@@ -227,8 +227,8 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_apply_g(const void* __restr
 }
 
 template <int WR, int WC, int NTW, bool TRANS_W, int KC, bool BF>
-int launch_g(const void* feat, const float* W, const float* bias, const int32_t* nbr, int n_rows, int K, int Cred, int Cres, void* out,
-             int xcd, hipStream_t stream) {
+int launch_g(const void* feat, const float* W, const float* bias, const int32_t* nbr, const int32_t* order, int n_rows, int K, int Cred,
+             int Cres, void* out, int xcd, hipStream_t stream) {
   constexpr int TM = 16 * WR, TN = 16 * NTW * WC;
   const size_t lds = btc_apply_glds_lds_bytes(WR * 100 + WC * 10 + NTW, KC, K, BF);
   BTC_CHECK_ARG(lds <= 160 * 1024, "conv_apply_g: tile does not fit the LDS");
@@ -239,16 +239,16 @@ int launch_g(const void* feat, const float* W, const float* bias, const int32_t*
     attr_set = true;
   }
   dim3 grid(btc_cdiv(n_rows, TM), Cres / TN);
-  conv_apply_g<WR, WC, NTW, TRANS_W, KC, BF><<<grid, 64 * WR * WC, lds, stream>>>(feat, W, bias, nbr, n_rows, K, Cred, Cres, out, xcd,
+  conv_apply_g<WR, WC, NTW, TRANS_W, KC, BF><<<grid, 64 * WR * WC, lds, stream>>>(feat, W, bias, nbr, order, n_rows, K, Cred, Cres, out, xcd,
                                                                                 btc_tune_get(BTC_TUNE_APPLY_DEBUG));
   BTC_LAUNCH_CHECK();
   return BTC_OK;
 }
 
-#define G_ARGS feat, W, bias, nbr, n_rows, K, Cred, Cres, out, xcd, stream
+#define G_ARGS feat, W, bias, nbr, order, n_rows, K, Cred, Cres, out, xcd, stream
 #define G_PARAMS                                                                                                             \
-  const void *feat, const float *W, const float *bias, const int32_t *nbr, int n_rows, int K, int Cred, int Cres, void *out, int xcd, \
-      hipStream_t stream
+  const void *feat, const float *W, const float *bias, const int32_t *nbr, const int32_t *order, int n_rows, int K, int Cred, int Cres, \
+      void *out, int xcd, hipStream_t stream
 
 template <int WR, int WC, int NTW, bool TRANS_W, bool BF>
 int launch_g_kc(int kc, G_PARAMS) {
@@ -302,7 +302,7 @@ bool btc_apply_glds_has_shape(int shape, bool bf) {
 size_t btc_apply_glds_lds_bytes(int shape, int kc, int K, bool bf) {
   const int tm = 16 * (shape / 100), tn = 16 * ((shape / 10) % 10) * (shape % 10);
   const size_t a_bytes = ((size_t)tm * kc * (bf ? 2 : 4) + 1023) / 1024 * 1024;
-  return (size_t)G_STAGES * (a_bytes + (size_t)kc * tn * 4) + (size_t)(tm * K + K + 1) * sizeof(int32_t);
+  return (size_t)G_STAGES * (a_bytes + (size_t)kc * tn * 4) + (size_t)(tm * K + K + 1 + tm) * sizeof(int32_t);
 }
 
 bool btc_apply_glds_supported(int K, int Cred, int Cres) { return K <= 64 && Cred % 16 == 0 && Cres % 16 == 0 && Cred >= 16; }
@@ -310,7 +310,7 @@ bool btc_apply_glds_supported(int K, int Cred, int Cres) { return K <= 64 && Cre
 // shape = WR*100 + WC*10 + NTW (waves: WR row groups x WC column groups of NTW 16-column tiles), kc = reduction chunk,
 // bf = activations (feat, out) are bfloat16
 int btc_launch_apply_glds(bool trans_w, int shape, int kc, int xcd, bool bf, const void* feat, const float* W, const float* bias,
-                          const int32_t* nbr, int n_rows, int K, int Cred, int Cres, void* out, hipStream_t stream) {
+                          const int32_t* nbr, const int32_t* order, int n_rows, int K, int Cred, int Cres, void* out, hipStream_t stream) {
   if (n_rows <= 0) return BTC_OK;
   const int wr = shape / 100, wc = (shape / 10) % 10, ntw = shape % 10;
   BTC_CHECK_ARG(btc_apply_glds_supported(K, Cred, Cres) && wc * ntw > 0 && Cres % (16 * wc * ntw) == 0 && Cred % kc == 0 &&

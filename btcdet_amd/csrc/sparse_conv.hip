@@ -439,8 +439,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_partial(const float* __restric
 // ------------------------------------------------------------------------------------------------------------
 template <int MT, int NT, int KB, int PH, bool BF>
 __global__ __launch_bounds__(256) void conv_wgrad_rows(const float* __restrict__ feat, const float* __restrict__ dout,
-                                                       const int32_t* __restrict__ nbr, int n_out, int K, int Cin, int Cout,
-                                                       float* __restrict__ part, int swap) {
+                                                       const int32_t* __restrict__ nbr, const int32_t* __restrict__ order, int n_out, int K,
+                                                       int Cin, int Cout, float* __restrict__ part, int swap) {
+  // order (optional, row_order.hip): tile slot t works on map row order[t]; rows with the same offsets share tiles, so fewer
+  // offset phases per tile are live.  dW is the fp32 sum over rows in walk order.
   // Naming follows the un-swapped case: `feat` = gathered operand (Cin channels, via the map), `dout` = contiguous
   // operand (Cout channels), one tile per 64 map rows.  swap = 1: the walk is over the INPUT rows instead (map =
   // nbr_in, gathered = dOut, contiguous = features) -- used when the layer has far fewer input than output rows
@@ -453,6 +455,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_rows(const float* __restrict__
   float* Ds = As + KB * TM * LDA;                 // [TM][LDB]
   int32_t* s_nbr = (int32_t*)(Ds + TM * LDB);     // [TM][K]
   int32_t* s_kact = s_nbr + TM * K;               // [K]
+  int32_t* s_row = s_kact + K;                    // [TM] map row of each tile slot, -1 past the end
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kq = lane >> 4;
   const int kg0 = blockIdx.y * (PH * KB);         // first offset of this workgroup's group
@@ -465,14 +468,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_rows(const float* __restrict__
   for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const int row0 = tile * TM;
     for (int e = tid; e < K; e += 256) s_kact[e] = 0;
+    if (tid < TM) s_row[tid] = (row0 + tid < n_out) ? (order ? order[row0 + tid] : row0 + tid) : -1;
     __syncthreads();
-    {
-      const long long gbase = (long long)row0 * K, gend = (long long)n_out * K;
-      for (int e = tid; e < TM * K; e += 256) {
-        int v = (gbase + e < gend) ? nbr[gbase + e] : -1;
-        s_nbr[e] = v;
-        if (v >= 0) s_kact[e % K] = 1;
-      }
+    for (int e = tid; e < TM * K; e += 256) {
+      const int rloc = e / K, kk = e - rloc * K;
+      const int gr = s_row[rloc];
+      const int v = gr >= 0 ? nbr[(long long)gr * K + kk] : -1;
+      s_nbr[e] = v;
+      if (v >= 0) s_kact[kk] = 1;
     }
     // dOut tile: all loads of a thread are issued before the first LDS store (one latency, not one per element)
     if ((Cout & 3) == 0) {
@@ -480,8 +483,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_rows(const float* __restrict__
 #pragma unroll
       for (int i = 0; i < NT; ++i) {
         int e = i * 256 + tid, r = e / (NT * 4), c = (e % (NT * 4)) * 4;
-        v[i] = (row0 + r < n_out && c < Cout) ? btc_ld4<BF>(dout, (size_t)(row0 + r) * Cout + c)
-                                              : make_float4(0.f, 0.f, 0.f, 0.f);
+        const int gr = s_row[r];
+        v[i] = (gr >= 0 && c < Cout) ? btc_ld4<BF>(dout, (size_t)gr * Cout + c) : make_float4(0.f, 0.f, 0.f, 0.f);
       }
 #pragma unroll
       for (int i = 0; i < NT; ++i) {
@@ -494,7 +497,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_rows(const float* __restrict__
 #pragma unroll
       for (int i = 0; i < NT * 4; ++i) {
         int e = i * 256 + tid, r = e / (NT * 16), c = e % (NT * 16);
-        v[i] = (row0 + r < n_out && c < Cout) ? btc_ld1<BF>(dout, (size_t)(row0 + r) * Cout + c) : 0.f;
+        const int gr = s_row[r];
+        v[i] = (gr >= 0 && c < Cout) ? btc_ld1<BF>(dout, (size_t)gr * Cout + c) : 0.f;
       }
 #pragma unroll
       for (int i = 0; i < NT * 4; ++i) {
@@ -653,7 +657,8 @@ void launch_apply_t(dim3 grid, size_t lds, hipStream_t stream, bool vec, const f
 
 template <bool TRANS_W>
 int launch_apply(const float* feat, const float* W, const float* bias, const int32_t* nbr, int n_rows, int K, int Cred,
-                 int Cres, float* out, hipStream_t stream, bool bf = false) {
+                 int Cres, float* out, hipStream_t stream, bool bf = false, const int32_t* order = nullptr) {
+  // order: optional row-order hint (row_order.hip); only the LDS-DMA kernel tiles by it, the others ignore it (same results)
   // bf: feat / out are bfloat16 (passed through the float* parameters); only the LDS-DMA kernel has that variant
   if (n_rows <= 0) return BTC_OK;
   BTC_CHECK_ARG(!bf || btc_apply_glds_supported(K, Cred, Cres),
@@ -669,10 +674,26 @@ int launch_apply(const float* feat, const float* W, const float* bias, const int
   // micro-scene pyramid at 130 K rows -- stay on the LDS-DMA kernel at any row count)
   if (bf || (t_kernel != 1 && btc_apply_glds_supported(K, Cred, Cres) && (t_kernel == 2 || n_rows < 100000 || (Cred >= 64 && Cres >= 64)))) {
     int shape, kc = (Cred % 64 == 0) ? 64 : ((Cred % 32 == 0) ? 32 : 16);
-    if (Cres % 128 == 0) shape = 424;                       // 64 rows x 128 columns, 8 waves
-    else if (Cres % 64 == 0) shape = n_rows < 8192 ? 141 : 422;  // few rows: 16-row workgroups, 4 waves across the columns
-    else if (Cres % 32 == 0) shape = 221;
-    else shape = 411;
+    // Wave shapes from a row-count sweep on MI355X (fp32, K = 27, a 7.7-pairs-per-row SubM map cut to n rows; us per launch).
+    // The time of a shape is a staircase in n with a step at every multiple of 256 CUs x TM rows, so the best TM depends on
+    // where n falls: 256 -> 128 at 4 K rows 296 (424) vs 148 (222), at 10 K rows 301 vs 196 (242), at 16 K rows 306 (424, one
+    // full round) vs 353, at 18 K rows 467 (424: a second, nearly empty round) vs 383 (242); 64 -> 64 at 10 K rows 52 (422)
+    // vs 37 (141), from 18 K rows on 80-133 (422) vs 67-122 (241); 32 -> 64 from 18 K rows on 50-76 (422) vs 41-71 (222).
+    if (bf) {
+      if (Cres % 128 == 0) shape = 424;                       // 64 rows x 128 columns, 8 waves
+      else if (Cres % 64 == 0) shape = n_rows < 8192 ? 141 : 422;  // few rows: 16-row workgroups, 4 waves across the columns
+      else if (Cres % 32 == 0) shape = 221;
+      else shape = 411;
+    } else if (Cres % 128 == 0) {
+      shape = n_rows < 7000 ? 222 : (n_rows < 13000 ? 242 : (n_rows <= 16384 ? 424 : (n_rows < 19500 ? 242 : 424)));
+    } else if (Cres % 64 == 0) {
+      if (kc == 64) shape = n_rows < 11000 ? 141 : 241;
+      else shape = n_rows < 13000 ? 141 : 222;
+    } else if (Cres % 32 == 0) {
+      shape = 221;
+    } else {
+      shape = 411;
+    }
     if (t_nt > 8 && !bf) {  // tuning run: BTC_TUNE_APPLY_NT carries the wave shape WR*100 + WC*10 + NTW
       int wc = (t_nt / 10) % 10, ntw = t_nt % 10;
       while (ntw > 1 && Cres % (16 * wc * ntw)) ntw >>= 1;
@@ -683,7 +704,7 @@ int launch_apply(const float* feat, const float* W, const float* bias, const int
     const int t_kc = btc_tune_get(BTC_TUNE_APPLY_KC);
     if (t_kc && Cred % t_kc == 0) kc = t_kc;
     while (kc > 16 && btc_apply_glds_lds_bytes(shape, kc, K, bf) > 160 * 1024) kc >>= 1;  // 3-stage ring + map tile
-    return btc_launch_apply_glds(TRANS_W, shape, kc, t_xcd == 2, bf, feat, W, bias, nbr, n_rows, K, Cred, Cres, out, stream);
+    return btc_launch_apply_glds(TRANS_W, shape, kc, t_xcd == 2, bf, feat, W, bias, nbr, order, n_rows, K, Cred, Cres, out, stream);
   }
   // weight-stationary persistent kernel (one 16-wave workgroup per CU).  Measured on MI355X: its dword-granular register
   // gather wins 2.5x for Cred <= 8 (the dgrad of the 2/3-channel occupancy heads, the 4/6-channel input layers) and loses
@@ -819,6 +840,24 @@ extern "C" int btc_conv_dgrad(const float* dout, const float* W, const int32_t* 
   return launch_apply<true>(dout, W, nullptr, nbr_in, n_in, K, /*Cred=*/Cout, /*Cres=*/Cin, din, (hipStream_t)stream);
 }
 
+extern "C" int btc_conv_apply_ordered(int pass, int operands, const void* src, const void* W, const float* bias, const int32_t* nbr,
+                                      const int32_t* order, int n_rows, int K, int Cin, int Cout, void* dst, void* stream) {
+  BTC_CHECK_ARG((pass == BTC_PASS_FWD || pass == BTC_PASS_DGRAD) && operands >= BTC_OPERANDS_F32 && operands <= BTC_OPERANDS_BF16,
+                "btc_conv_apply_ordered: pass=%d operands=%d", pass, operands);
+  BTC_CHECK_ARG(K >= 1 && K <= 512 && Cin >= 1 && Cout >= 1 && n_rows >= 0, "btc_conv_apply_ordered: bad sizes");
+  BTC_CHECK_ARG(pass == BTC_PASS_FWD || bias == nullptr, "btc_conv_apply_ordered: dgrad takes no bias");
+  const int Cred = pass == BTC_PASS_FWD ? Cin : Cout, Cres = pass == BTC_PASS_FWD ? Cout : Cin;
+  if (operands == BTC_OPERANDS_BF16) {
+    BTC_CHECK_ARG(btc_conv_bf16w_supported(K, Cred, Cres), "btc_conv_apply_ordered: bf16 operands need K <= 64, Cred %% 32 == 0, Cres %% 16 == 0 (K=%d, %d -> %d)",
+                  K, Cin, Cout);
+    return btc_apply_bf16w(src, W, bias, nbr, order, n_rows, K, Cred, Cres, dst, (hipStream_t)stream);
+  }
+  const bool bf = operands == BTC_OPERANDS_BF16_ACT;
+  if (pass == BTC_PASS_FWD)
+    return launch_apply<false>((const float*)src, (const float*)W, bias, nbr, n_rows, K, Cred, Cres, (float*)dst, (hipStream_t)stream, bf, order);
+  return launch_apply<true>((const float*)src, (const float*)W, nullptr, nbr, n_rows, K, Cred, Cres, (float*)dst, (hipStream_t)stream, bf, order);
+}
+
 extern "C" size_t btc_conv_wgrad_ws_bytes(int n_out, int K, int Cin, int Cout, int n_in) {
   WgradPlan p = wgrad_plan(n_out, K, Cin, Cout, n_in);
   return btc_align((size_t)p.S * K * Cin * Cout * sizeof(float));
@@ -826,7 +865,8 @@ extern "C" size_t btc_conv_wgrad_ws_bytes(int n_out, int K, int Cin, int Cout, i
 
 template <bool BF>
 static int wgrad_impl(const float* feat, const float* dout, const int32_t* nbr_out, int n_out, const int32_t* nbr_in,
-                      int n_in, int K, int Cin, int Cout, float* dW, void* ws, size_t ws_bytes, void* stream_) {
+                      int n_in, int K, int Cin, int Cout, float* dW, void* ws, size_t ws_bytes, void* stream_,
+                      const int32_t* order_out = nullptr, const int32_t* order_in = nullptr) {
   hipStream_t stream = (hipStream_t)stream_;
   BTC_CHECK_ARG(K >= 1 && Cin >= 1 && Cout >= 1 && n_out >= 0, "btc_conv_wgrad: bad sizes");
   if (!nbr_in) n_in = -1;
@@ -843,11 +883,12 @@ static int wgrad_impl(const float* feat, const float* dout, const int32_t* nbr_o
     const float* g_ = p.swap ? dout : feat;
     const float* c_ = p.swap ? feat : dout;
     const int32_t* map_ = p.swap ? nbr_in : nbr_out;
+    const int32_t* ord_ = p.swap ? order_in : order_out;
     const int Cg = p.swap ? Cout : Cin, Cc = p.swap ? Cin : Cout;
     dim3 grid(p.S, p.groups);
-    size_t lds = (size_t)(p.kb * TM * ldb_of(p.mt) + TM * ldb_of(p.nt)) * sizeof(float) + (size_t)(TM * K + K) * sizeof(int32_t);
+    size_t lds = (size_t)(p.kb * TM * ldb_of(p.mt) + TM * ldb_of(p.nt)) * sizeof(float) + (size_t)(TM * K + K + TM) * sizeof(int32_t);
 #define BTC_WG_ROWS(MT_, NT_, KB_, PH_) \
-  conv_wgrad_rows<MT_, NT_, KB_, PH_, BF><<<grid, 256, lds, stream>>>(g_, c_, map_, p.rows, K, Cg, Cc, part, p.swap)
+  conv_wgrad_rows<MT_, NT_, KB_, PH_, BF><<<grid, 256, lds, stream>>>(g_, c_, map_, ord_, p.rows, K, Cg, Cc, part, p.swap)
 #define BTC_WG_ROWS_PH(MT_, NT_, KB_)               \
   do {                                              \
     if (p.ph == 1) BTC_WG_ROWS(MT_, NT_, KB_, 1);   \
@@ -892,6 +933,16 @@ extern "C" int btc_conv_wgrad(const float* feat, const float* dout, const int32_
 extern "C" int btc_conv_wgrad_bf16(const void* feat, const void* dout, const int32_t* nbr_out, int n_out, const int32_t* nbr_in,
                                    int n_in, int K, int Cin, int Cout, float* dW, void* ws, size_t ws_bytes, void* stream) {
   return wgrad_impl<true>((const float*)feat, (const float*)dout, nbr_out, n_out, nbr_in, n_in, K, Cin, Cout, dW, ws, ws_bytes, stream);
+}
+
+extern "C" int btc_conv_wgrad_ordered(int bf16_act, const void* feat, const void* dout, const int32_t* nbr_out, int n_out, const int32_t* nbr_in,
+                                      int n_in, const int32_t* order_out, const int32_t* order_in, int K, int Cin, int Cout, float* dW, void* ws,
+                                      size_t ws_bytes, void* stream) {
+  if (bf16_act)
+    return wgrad_impl<true>((const float*)feat, (const float*)dout, nbr_out, n_out, nbr_in, n_in, K, Cin, Cout, dW, ws, ws_bytes, stream, order_out,
+                            order_in);
+  return wgrad_impl<false>((const float*)feat, (const float*)dout, nbr_out, n_out, nbr_in, n_in, K, Cin, Cout, dW, ws, ws_bytes, stream, order_out,
+                           order_in);
 }
 
 extern "C" int btc_maxpool_fwd(const float* feat, const int32_t* nbr_out, int n_out, int K, int C, float* out, void* stream) {

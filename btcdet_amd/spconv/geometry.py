@@ -94,8 +94,9 @@ class GeometryPlan(object):
         rbs = [None] * len(self.convs)
         for i, (conv, (kind, ref, g, in_shape, out_shape)) in enumerate(zip(self.convs, self.entries)):
             if kind < 2:
-                in_idx, out_idx, nbr_out, nbr_in = built[i]
-                rb = rbs[i] = ops.Rulebook(out_idx, in_idx, nbr_out, nbr_in, g.in_list, g.out_list, g.K, g.mode)
+                in_idx, out_idx, nbr_out, nbr_in = built[i][:4]
+                o_out, o_in = (built[i][4], built[i][5]) if (len(built[i]) > 4 and ops.ROW_ORDER) else (None, None)
+                rb = rbs[i] = ops.Rulebook(out_idx, in_idx, nbr_out, nbr_in, g.in_list, g.out_list, g.K, g.mode, o_out, o_in)
                 geom[conv._gkey(in_idx, in_shape)] = (rb, in_idx)
             else:
                 rb = rbs[i] = rbs[ref]

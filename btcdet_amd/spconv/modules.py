@@ -128,10 +128,12 @@ class SparseSequential(SparseModule):
     def _run_chain(self, input, plan, indices, shape):
         from . import fused_bn, ops
         F = ops.fast()
-        w, b, mf, mb, ga, be, rms, rvs, nbts, ub, mom, eps, relus, need, ov, dfr = ([] for _ in range(16))
+        w, b, mf, mb, of, ob, ga, be, rms, rvs, nbts, ub, mom, eps, relus, need, ov, dfr = ([] for _ in range(18))
         ws = None
         for conv, bn, relu, rb, inverse in plan:
             maps = (rb.nbr_in, rb.nbr_out) if inverse else (rb.nbr_out, rb.nbr_in)
+            ords = (rb.order_in, rb.order_out) if inverse else (rb.order_out, rb.order_in)
+            of.append(ords[0]); ob.append(ords[1])
             training = bn.training or not bn.track_running_stats
             rm = bn.running_mean if bn.track_running_stats else None
             ws, nb = fused_bn._ws(input.features.device, conv.weight.shape[-1])
@@ -140,7 +142,7 @@ class SparseSequential(SparseModule):
             nbts.append(bn.num_batches_tracked if (bn.training and bn.track_running_stats) else None)
             ub.append(bool(training or rm is None)); mom.append(float(bn.momentum)); eps.append(float(bn.eps)); relus.append(bool(relu))
             need.append(int(nb)); ov.append(bool(ops._overlap_ok(maps[0].shape[0]))); dfr.append(bool(conv.weight.is_leaf))
-        out = F.conv_bn_relu_chain(ops._actc(input.features), w, b, mf, mb, ga, be, rms, rvs, nbts, ub, mom, eps, relus, ws, need, ov, dfr)
+        out = F.conv_bn_relu_chain(ops._actc(input.features), w, b, mf, mb, of, ob, ga, be, rms, rvs, nbts, ub, mom, eps, relus, ws, need, ov, dfr)
         out_tensor = SparseConvTensor(out, indices, shape, input.batch_size)
         out_tensor.indice_dict = input.indice_dict
         out_tensor.grid = input.grid

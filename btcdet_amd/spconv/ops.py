@@ -110,13 +110,16 @@ def get_deconv_output_size(input_size, kernel_size, stride, padding, dilation, o
 class Rulebook(object):
     """One cached rulebook (what spconv stores in ``indice_dict[indice_key]``)."""
 
-    __slots__ = ("out_indices", "in_indices", "nbr_out", "nbr_in", "in_shape", "out_shape", "K", "mode")
+    __slots__ = ("out_indices", "in_indices", "nbr_out", "nbr_in", "in_shape", "out_shape", "K", "mode", "order_out", "order_in")
 
-    def __init__(self, out_indices, in_indices, nbr_out, nbr_in, in_shape, out_shape, K, mode):
+    def __init__(self, out_indices, in_indices, nbr_out, nbr_in, in_shape, out_shape, K, mode, order_out=None, order_in=None):
         self.out_indices, self.in_indices = out_indices, in_indices
         self.nbr_out, self.nbr_in = nbr_out, nbr_in
         self.in_shape, self.out_shape = list(in_shape), list(out_shape)
         self.K, self.mode = K, mode
+        # row-order hints of the two maps (csrc/row_order.hip): int32 permutations the apply kernels tile the rows by, or
+        # None = map order.  Built for strided / transposed rulebooks (their 16-row tiles are 17-30 % full in map order).
+        self.order_out, self.order_in = order_out, order_in
 
     @property
     def n_in(self):
@@ -137,6 +140,39 @@ class Rulebook(object):
         check(lib().btc_pairs_from_nbr(ptr(self.nbr_out), self.n_out, self.K, self.n_in, ptr(pairs), ptr(num), ptr(ws), ws_bytes,
                                        stream_ptr()), "btc_pairs_from_nbr")
         return pairs[:, :, :self.n_in], num
+
+
+ROW_ORDER = int(os.environ.get("BTC_ROW_ORDER", "1"))  # row-order hints: 1 = strided / transposed rulebooks, 2 = SubM too, 0 = none
+
+
+def row_orders(maps):
+    """row-order hints (csrc/row_order.hip) of several (n, K) neighbour maps from ONE launch: rows grouped by their first
+    present offset (stable) inside blocks of 4096 rows; one int32 permutation per map (slices of one buffer).  Any permutation gives the same
+    conv results."""
+    import ctypes
+    maps = list(maps)
+    out = []
+    for base in range(0, len(maps), 64):
+        part = maps[base:base + 64]
+        m = len(part)
+        total = sum(int(t.shape[0]) for t in part)
+        dev = part[0].device
+        order = torch.empty((max(total, 1),), dtype=torch.int32, device=dev)
+        ns = (ctypes.c_int32 * m)(*[int(t.shape[0]) for t in part])
+        ks = (ctypes.c_int32 * m)(*[int(t.shape[1]) for t in part])
+        ps = (ctypes.c_void_p * m)(*[ptr(t) for t in part])
+        check(lib().btc_row_orders(ps, ns, ks, m, ptr(order), stream_ptr()), "btc_row_orders")
+        off = 0
+        for t in part:
+            out.append(order[off:off + int(t.shape[0])])
+            off += int(t.shape[0])
+    return out
+
+
+def _with_orders(rb):
+    if ROW_ORDER and rb.K <= 64 and rb.order_out is None and (rb.mode != MODE_SUBM or ROW_ORDER >= 2):
+        rb.order_out, rb.order_in = row_orders([rb.nbr_out, rb.nbr_in])
+    return rb
 
 
 def _as_idx(indices):
@@ -232,9 +268,11 @@ def _build_rulebook(indices, batch_size, g):
         if g.subm:
             nbr = F.rulebook_subm(indices, int(batch_size), g.a_in, g.a_k, g.a_d, K, stream_ptr())
             return Rulebook(indices, indices, nbr[0], nbr[1], g.in_list, g.out_list, K, g.mode)
-        out_indices, nbr_out, nbr_in = F.rulebook_conv(indices, int(batch_size), g.a_in, g.a_out, g.a_k, g.a_s, g.a_p, g.a_d, g.mode, K,
-                                                       _conv_ws_bytes(g, batch_size), stream_ptr())
-        return Rulebook(out_indices, indices, nbr_out, nbr_in, g.in_list, g.out_list, K, g.mode)
+        out_indices, nbr_out, nbr_in, o_out, o_in = F.rulebook_conv(indices, int(batch_size), g.a_in, g.a_out, g.a_k, g.a_s, g.a_p, g.a_d, g.mode, K,
+                                                                    _conv_ws_bytes(g, batch_size), stream_ptr())
+        if not ROW_ORDER:
+            o_out = o_in = None
+        return Rulebook(out_indices, indices, nbr_out, nbr_in, g.in_list, g.out_list, K, g.mode, o_out, o_in)
     if g.subm:
         nbr = torch.empty((2, n, K), dtype=torch.int32, device=dev)  # one allocation for nbr_out | nbr_in
         nbr_out, nbr_in = nbr[0], nbr[1]
@@ -269,7 +307,7 @@ def _fill_conv_rulebook(indices, batch_size, g, n_out, ws, ws_bytes):
     nbr_in = torch.empty((n, K), dtype=torch.int32, device=dev)
     check(lib().btc_rulebook_conv_fill(ptr(indices), n, int(batch_size), g.p_in, g.p_out, g.p_k, g.p_s, g.p_p, g.p_d, g.mode, n_out,
                                        ptr(out_indices), ptr(nbr_out), ptr(nbr_in), ptr(ws), ws_bytes, stream_ptr()), "btc_rulebook_conv_fill")
-    return Rulebook(out_indices, indices, nbr_out, nbr_in, g.in_list, g.out_list, K, g.mode)
+    return _with_orders(Rulebook(out_indices, indices, nbr_out, nbr_in, g.in_list, g.out_list, K, g.mode))
 
 
 # ---- strided / transposed rulebooks in two halves -------------------------------------------------------------------
@@ -382,9 +420,11 @@ class _NativePending(PendingRulebook):
 
     def finish(self):
         g = self.g
-        out_indices, nbr_out, nbr_in = self.F.rulebook_conv_finish(self.handle)
+        out_indices, nbr_out, nbr_in, o_out, o_in = self.F.rulebook_conv_finish(self.handle)
         self.handle = None
-        return Rulebook(out_indices, self.indices, nbr_out, nbr_in, g.in_list, g.out_list, g.K, g.mode)
+        if not ROW_ORDER:
+            o_out = o_in = None
+        return Rulebook(out_indices, self.indices, nbr_out, nbr_in, g.in_list, g.out_list, g.K, g.mode, o_out, o_in)
 
 
 def prefetch_conv_rulebook(indices, batch_size, spatial_shape, ksize, stride=1, padding=0, dilation=1, out_padding=0, transpose=False):
@@ -487,11 +527,11 @@ def _weights_bf16(w, K, cin, cout):
     return q
 
 
-def _conv_forward(features, w, b, map_fwd):
+def _conv_forward(features, w, b, map_fwd, ord_fwd=None):
     if PROFILE is None:
         F = fast()
         if F is not None:
-            return F.conv_fwd(features, w, b, map_fwd, stream_ptr())
+            return F.conv_fwd(features, w, b, map_fwd, ord_fwd, stream_ptr())
     bf = features.dtype == torch.bfloat16
     cin, cout = w.shape[-2], w.shape[-1]
     K = map_fwd.shape[1]
@@ -502,20 +542,21 @@ def _conv_forward(features, w, b, map_fwd):
     if _bf16_operands(features, K, cin, cout):
         q = _weights_bf16(w, K, cin, cout)
         with _span("conv_apply", _conv_cost, (map_fwd, n_res, K, cin, cout, 2)):
-            check(lib().btc_conv_fwd_bf16w(ptr(features), ptr(q[1]), ptr(b), ptr(map_fwd), n_res, K, cin, cout, ptr(out), stream_ptr()), "btc_conv_fwd_bf16w")
+            check(lib().btc_conv_apply_ordered(0, 2, ptr(features), ptr(q[1]), ptr(b), ptr(map_fwd), ptr(ord_fwd), n_res, K, cin, cout, ptr(out),
+                                               stream_ptr()), "btc_conv_apply_ordered")
         return out
-    fwd = lib().btc_conv_fwd_bf16 if bf else lib().btc_conv_fwd
     with _span("conv_apply", _conv_cost, (map_fwd, n_res, K, cin, cout, 2 if bf else 4)):
-        check(fwd(ptr(features), ptr(w), ptr(b), ptr(map_fwd), n_res, K, cin, cout, ptr(out), stream_ptr()), "btc_conv_fwd")
+        check(lib().btc_conv_apply_ordered(0, 1 if bf else 0, ptr(features), ptr(w), ptr(b), ptr(map_fwd), ptr(ord_fwd), n_res, K, cin, cout,
+                                           ptr(out), stream_ptr()), "btc_conv_apply_ordered")
     return out
 
 
-def _conv_backward(features, w, map_fwd, map_bwd, grad_out, wshape, need_din, need_dw, allow_defer=False):
+def _conv_backward(features, w, map_fwd, map_bwd, grad_out, wshape, need_din, need_dw, allow_defer=False, ord_bwd=None):
     bf = features.dtype == torch.bfloat16
     cin, cout = w.shape[-2], w.shape[-1]
     K = map_fwd.shape[1]
     L = lib()
-    wgrad, dgrad = (L.btc_conv_wgrad_bf16, L.btc_conv_dgrad_bf16) if bf else (L.btc_conv_wgrad, L.btc_conv_dgrad)
+    wgrad = L.btc_conv_wgrad_bf16 if bf else L.btc_conv_wgrad
     din = dw = None
     dev = grad_out.device
     n_res, n_src = map_fwd.shape[0], map_bwd.shape[0]
@@ -523,7 +564,7 @@ def _conv_backward(features, w, map_fwd, map_bwd, grad_out, wshape, need_din, ne
     if PROFILE is None:
         F = fast()
         if F is not None:
-            return F.conv_bwd(features, w, map_fwd, map_bwd, grad_out, bool(need_din), bool(need_dw), overlap, bool(allow_defer), stream_ptr())
+            return F.conv_bwd(features, w, map_fwd, map_bwd, ord_bwd, grad_out, bool(need_din), bool(need_dw), overlap, bool(allow_defer), stream_ptr())
     side = _side_stream(dev) if (overlap and PROFILE is None) else None
     if need_dw:
         ws_bytes = L.btc_conv_wgrad_ws_bytes(n_res, K, cin, cout, n_src)
@@ -548,9 +589,11 @@ def _conv_backward(features, w, map_fwd, map_bwd, grad_out, wshape, need_din, ne
         with _span("conv_apply", _conv_cost, (map_bwd, n_src, K, cout, cin, 2 if bf else 4)):
             if _bf16_operands(grad_out, K, cout, cin):
                 q = _weights_bf16(w, K, cin, cout)
-                check(L.btc_conv_dgrad_bf16w(ptr(grad_out), ptr(q[0]), ptr(map_bwd), n_src, K, cin, cout, ptr(din), stream_ptr()), "btc_conv_dgrad_bf16w")
+                check(L.btc_conv_apply_ordered(1, 2, ptr(grad_out), ptr(q[0]), None, ptr(map_bwd), ptr(ord_bwd), n_src, K, cin, cout, ptr(din),
+                                               stream_ptr()), "btc_conv_apply_ordered")
             else:
-                check(dgrad(ptr(grad_out), ptr(w), ptr(map_bwd), n_src, K, cin, cout, ptr(din), stream_ptr()), "btc_conv_dgrad")
+                check(L.btc_conv_apply_ordered(1, 1 if bf else 0, ptr(grad_out), ptr(w), None, ptr(map_bwd), ptr(ord_bwd), n_src, K, cin, cout,
+                                               ptr(din), stream_ptr()), "btc_conv_apply_ordered")
     if side is not None:
         torch.cuda.current_stream().wait_stream(side)  # join: dW is consumed on the main stream from here on
         dw.record_stream(torch.cuda.current_stream())
@@ -569,11 +612,12 @@ class SparseConvFunction(torch.autograd.Function):
     map_fwd (n_res,K): source row gathered by result row i at offset k; map_bwd (n_src,K) its transpose."""
 
     @staticmethod
-    def forward(ctx, features, weight, bias, map_fwd, map_bwd):
+    def forward(ctx, features, weight, bias, map_fwd, map_bwd, ord_fwd=None, ord_bwd=None):
         features = _actc(features)
         w = _f32c(weight)
         b = _f32c(bias) if bias is not None else None
-        out = _conv_forward(features, w, b, map_fwd)
+        out = _conv_forward(features, w, b, map_fwd, ord_fwd)
+        ctx.ord_bwd = ord_bwd
         if CAPTURE is not None:
             CAPTURE.append((features, w, b, map_fwd, map_bwd))
         ctx.save_for_backward(features, w, map_fwd, map_bwd)
@@ -588,9 +632,9 @@ class SparseConvFunction(torch.autograd.Function):
         features, w, map_fwd, map_bwd = ctx.saved_tensors
         grad_out = _actc(grad_out if grad_out.dtype == features.dtype else grad_out.to(features.dtype))
         din, dw = _conv_backward(features, w, map_fwd, map_bwd, grad_out, ctx.wshape, ctx.needs_input_grad[0], ctx.needs_input_grad[1],
-                                 ctx.leaf_w)
+                                 ctx.leaf_w, ctx.ord_bwd)
         db = _bias_grad(grad_out) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
-        return din, dw, db, None, None
+        return din, dw, db, None, None, None, None
 
 
 class SparseConvBNReLUFunction(torch.autograd.Function):
@@ -599,7 +643,8 @@ class SparseConvBNReLUFunction(torch.autograd.Function):
     dispatch per layer -- the step is bound by the host's launch rate at BtcDet's sizes."""
 
     @staticmethod
-    def forward(ctx, features, weight, bias, map_fwd, map_bwd, gamma, beta, running_mean, running_var, nbt, training, momentum, eps, relu):
+    def forward(ctx, features, weight, bias, map_fwd, map_bwd, gamma, beta, running_mean, running_var, nbt, training, momentum, eps, relu,
+                ord_fwd=None, ord_bwd=None):
         from . import fused_bn
         features = _actc(features)
         w = _f32c(weight)
@@ -608,15 +653,16 @@ class SparseConvBNReLUFunction(torch.autograd.Function):
         F = fast() if PROFILE is None else None
         if F is not None:
             ws, need = fused_bn._ws(features.device, w.shape[-1])
-            x, y, stats = F.conv_bn_fwd(features, w, b, map_fwd, gamma, beta, running_mean, running_var, nbt if training else None, use_batch,
+            x, y, stats = F.conv_bn_fwd(features, w, b, map_fwd, ord_fwd, gamma, beta, running_mean, running_var, nbt if training else None, use_batch,
                                         float(momentum), float(eps), bool(relu), ws, need, stream_ptr())
         else:
-            x = _conv_forward(features, w, b, map_fwd)
+            x = _conv_forward(features, w, b, map_fwd, ord_fwd)
             y, stats = fused_bn.bn_forward(x, gamma, beta, running_mean, running_var, nbt if training else None, use_batch, momentum, eps, relu)
         if CAPTURE is not None:
             CAPTURE.append((features, w, b, map_fwd, map_bwd))
         ctx.save_for_backward(features, w, map_fwd, map_bwd, x, y, gamma, stats)
         ctx.flags = (bias is not None, tuple(weight.shape), use_batch, bool(relu), bool(weight.is_leaf))
+        ctx.ord_bwd = ord_bwd
         return y
 
     @staticmethod
@@ -626,10 +672,11 @@ class SparseConvBNReLUFunction(torch.autograd.Function):
         has_bias, wshape, use_batch, relu, leaf_w = ctx.flags
         dy = (dy if dy.dtype == x.dtype else dy.to(x.dtype)).contiguous()
         dx, dgamma, dbeta = fused_bn.bn_backward(x, y, dy, gamma, stats, use_batch, relu)
-        din, dw = _conv_backward(features, w, map_fwd, map_bwd, dx, wshape, ctx.needs_input_grad[0], ctx.needs_input_grad[1], leaf_w)
+        din, dw = _conv_backward(features, w, map_fwd, map_bwd, dx, wshape, ctx.needs_input_grad[0], ctx.needs_input_grad[1], leaf_w, ctx.ord_bwd)
         db = _bias_grad(dx) if (has_bias and ctx.needs_input_grad[2]) else None
         affine = gamma is not None
-        return (din, dw, db, None, None, dgamma if affine else None, dbeta if affine else None, None, None, None, None, None, None, None)
+        return (din, dw, db, None, None, dgamma if affine else None, dbeta if affine else None, None, None, None, None, None, None, None, None,
+                None)
 
 
 class SparseMaxPoolFunction(torch.autograd.Function):
@@ -691,8 +738,8 @@ def indice_conv(features, weight, bias, rulebook, inverse=False):
         # (4 / 6 / 34 input channels, 2 / 3-channel heads) run in fp32 and round their result
         return indice_conv(features.float(), weight, bias, rulebook, inverse).to(torch.bfloat16)
     if inverse:
-        return SparseConvFunction.apply(features, weight, bias, rulebook.nbr_in, rulebook.nbr_out)
-    return SparseConvFunction.apply(features, weight, bias, rulebook.nbr_out, rulebook.nbr_in)
+        return SparseConvFunction.apply(features, weight, bias, rulebook.nbr_in, rulebook.nbr_out, rulebook.order_in, rulebook.order_out)
+    return SparseConvFunction.apply(features, weight, bias, rulebook.nbr_out, rulebook.nbr_in, rulebook.order_out, rulebook.order_in)
 
 
 def indice_conv_bn_relu(features, weight, bias, rulebook, bn, relu, inverse=False):
@@ -705,15 +752,16 @@ def indice_conv_bn_relu(features, weight, bias, rulebook, bn, relu, inverse=Fals
     rm = bn.running_mean if bn.track_running_stats else None
     rv = bn.running_var if bn.track_running_stats else None
     maps = (rulebook.nbr_in, rulebook.nbr_out) if inverse else (rulebook.nbr_out, rulebook.nbr_in)
+    ords = (rulebook.order_in, rulebook.order_out) if inverse else (rulebook.order_out, rulebook.order_in)
     F = fast() if (PROFILE is None and CAPTURE is None and NATIVE_AUTOGRAD) else None
     if F is not None and features.is_cuda:
         # C++ autograd node (csrc/binding.cpp ConvBNReLUNode): same launches, no Python Function.apply / ctx bookkeeping
         from . import fused_bn
         ws, need = fused_bn._ws(features.device, weight.shape[-1])
-        return F.conv_bn_relu(_actc(features), _f32c(weight), bias, maps[0], maps[1], bn.weight, bn.bias, rm, rv, nbt, bool(training or rm is None),
+        return F.conv_bn_relu(_actc(features), _f32c(weight), bias, maps[0], maps[1], ords[0], ords[1], bn.weight, bn.bias, rm, rv, nbt, bool(training or rm is None),
                               float(bn.momentum), float(bn.eps), bool(relu), ws, need, bool(_overlap_ok(maps[0].shape[0])), bool(weight.is_leaf))
     return SparseConvBNReLUFunction.apply(features, weight, bias, maps[0], maps[1], bn.weight, bn.bias, rm, rv, nbt, training, bn.momentum,
-                                          bn.eps, relu)
+                                          bn.eps, relu, ords[0], ords[1])
 
 
 def indice_maxpool(features, rulebook):

@@ -74,10 +74,19 @@ class GroupOptimizer(object):
             self.groups.append(dict(params=params, sched=sched, lr=lr, mom=mom, weight_decay=float(g.get("weight_decay", 0.0)),
                                     clip=float(g.get("grad_norm_clip", 0.0)), lr_clip=float(g.get("lr_clip", 1e-7)), split=g.get("split", len(params)),
                                     exp_avgs=[torch.zeros_like(p) for p in params], exp_avg_sqs=[torch.zeros_like(p) for p in params],
-                                    steps=[torch.zeros((), dtype=torch.float32, device=p.device) for p in params]))
+                                    steps=[torch.zeros((), dtype=torch.float32, device=p.device) for p in params], it=0))
         self.beta2, self.eps = beta2, eps
-        self.iteration = 0
         self._present = self._missing = None
+
+    @property
+    def iteration(self):
+        """optimizer steps taken (the OneCycle position; groups stepped separately within a training step count once)"""
+        return max(g["it"] for g in self.groups) if self.groups else 0
+
+    @iteration.setter
+    def iteration(self, value):
+        for g in self.groups:
+            g["it"] = int(value)
 
     def read_grads_from(self, view_of, present=None, missing=None):
         """take the gradients from fixed buffers (a gradient reducer's flat buckets) instead of param.grad.  present(param):
@@ -97,9 +106,14 @@ class GroupOptimizer(object):
         return [g["lr"] for g in self.groups]
 
     @torch.no_grad()
-    def step(self):
+    def step(self, groups=None):
+        """groups: indices of the parameter groups to step (default: all).  The groups are independent -- own gradient-norm
+        clip, own schedule, as the reference's two optimizers are -- so a training loop may step a group as soon as ITS
+        gradients are complete (bench.py steps the detection branch's group while the occupancy branch is still in backward)."""
         last_norms = []
-        for g in self.groups:
+        for gi, g in enumerate(self.groups):
+            if groups is not None and gi not in groups:
+                continue
             params = g["params"]
             if "grad_views" in g:
                 grads = g["grad_views"]
@@ -115,7 +129,10 @@ class GroupOptimizer(object):
                 ea, es, st = [g["exp_avgs"][i] for i in keep], [g["exp_avg_sqs"][i] for i in keep], [g["steps"][i] for i in keep]
             else:
                 ea, es, st = g["exp_avgs"], g["exp_avg_sqs"], g["steps"]
-            if not params:
+            if not params:   # nothing to update (no gradient reached the group): the schedule still advances
+                nlr, nmom = g["sched"].at(g["it"])
+                g["lr"], g["mom"] = max(nlr, g["lr_clip"]), nmom
+                g["it"] += 1
                 continue
             inv_coef = None
             if g["clip"] > 0:
@@ -129,9 +146,9 @@ class GroupOptimizer(object):
             torch._foreach_add_(st, 1)
             torch._fused_adam_(params, grads, ea, es, [], st, lr=lr, beta1=g["mom"], beta2=self.beta2, weight_decay=0.0, eps=self.eps,
                                amsgrad=False, maximize=False, grad_scale=inv_coef, found_inf=None)
-            nlr, nmom = g["sched"].at(self.iteration)
+            nlr, nmom = g["sched"].at(g["it"])
             g["lr"], g["mom"] = max(nlr, g["lr_clip"]), nmom
-        self.iteration += 1
+            g["it"] += 1
         return last_norms
 
     # ---- checkpoint format of the reference: one torch.optim.Adam state_dict per optimizer (train_utils.py:272-288) -------------

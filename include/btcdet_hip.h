@@ -231,6 +231,34 @@ int btc_conv_fwd_bf16w(const void* feat, const void* wt_bf16, const float* bias,
 int btc_conv_dgrad_bf16w(const void* dout, const void* w_bf16, const int32_t* nbr_in, int n_in, int K, int Cin, int Cout, void* din,
                          void* stream);
 
+/* Row-order hints (csrc/row_order.hip).  The apply kernels work on tiles of 16 consecutive map rows and pay for every
+ * offset ANY row of the tile has; which rows share a tile changes no result.  btc_row_orders sorts the rows of up to
+ * BTC_ROW_ORDER_MAX_MAPS neighbour maps by their FIRST PRESENT OFFSET (lowest k with nbr[row][k] >= 0; K if none) -- a
+ * stable counting sort inside blocks of 4096 consecutive rows, one launch for all maps; rows of a strided layer's dgrad
+ * map that can share offsets at all end up together: order[off_j + t] = the row of map j that tile slot t works on,
+ * off_j = n_rows[0] + .. + n_rows[j-1] (K <= 64).  btc_conv_apply_ordered is btc_conv_fwd / _dgrad
+ * (+ _bf16 / _bf16w, by `operands`) with such a hint -- any permutation of 0..n_rows-1 is valid; order == NULL is the map
+ * order; the result is bit-identical either way.
+ *   pass     : BTC_PASS_FWD   dst[i] = bias + sum_k src[nbr[i][k]] @ W[k]        (nbr = nbr_out, n_rows = n_out)
+ *              BTC_PASS_DGRAD dst[j] = sum_k src[nbr[j][k]] @ W[k]^T             (nbr = nbr_in,  n_rows = n_in, bias NULL)
+ *   operands : BTC_OPERANDS_F32; BTC_OPERANDS_BF16_ACT (bf16 src / dst, fp32 W); BTC_OPERANDS_BF16 (bf16 src / dst and W =
+ *              the bf16 copy btc_weights_to_bf16 made for that pass: wt_bf16 for FWD, w_bf16 for DGRAD)
+ * btc_conv_wgrad_ordered: btc_conv_wgrad (bf16_act = 0) / btc_conv_wgrad_bf16 (1) walking the rows in the given order(s)
+ * (either may be NULL); dW is then the fp32 sum in THAT row order -- deterministic for a given order. */
+#define BTC_ROW_ORDER_MAX_MAPS 64
+#define BTC_PASS_FWD 0
+#define BTC_PASS_DGRAD 1
+#define BTC_OPERANDS_F32 0
+#define BTC_OPERANDS_BF16_ACT 1
+#define BTC_OPERANDS_BF16 2
+int btc_row_orders(const int32_t* const* nbrs /* host array of device pointers */, const int32_t* n_rows /* host */,
+                   const int32_t* Ks /* host */, int n_maps, int32_t* order /* device, sum n_rows */, void* stream);
+int btc_conv_apply_ordered(int pass, int operands, const void* src, const void* W, const float* bias, const int32_t* nbr,
+                           const int32_t* order, int n_rows, int K, int Cin, int Cout, void* dst, void* stream);
+int btc_conv_wgrad_ordered(int bf16_act, const void* feat, const void* dout, const int32_t* nbr_out, int n_out,
+                           const int32_t* nbr_in, int n_in, const int32_t* order_out, const int32_t* order_in, int K, int Cin,
+                           int Cout, float* dW, void* ws, size_t ws_bytes, void* stream);
+
 
 /* Sparse max-pool (spconv indice_maxpool, App. B.6): out = max(0, max_k feat[nbr_out[i][k]]);
  * backward routes dout to every input equal to its output. */

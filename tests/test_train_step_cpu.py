@@ -63,3 +63,35 @@ def test_one_cycle_endpoints():
     assert s.initial() == (0.001, 0.95)
     assert s.at(40)[0] == pytest.approx(0.01) and s.at(40)[1] == pytest.approx(0.85)
     assert s.at(100)[0] == pytest.approx(0.001 / 1e4) and s.at(1000) == s.at(100)
+
+
+def test_groups_stepped_separately_equal_one_step():
+    """bench.py steps the detection group while the occupancy branch is still in backward: group by group == all at once,
+    schedules included"""
+    torch.manual_seed(3)
+
+    def make():
+        torch.manual_seed(4)
+        a, b = torch.nn.Linear(5, 7), torch.nn.Linear(7, 3)
+        opt = GroupOptimizer([dict(params=list(a.parameters()), lr=0.003, weight_decay=0.001, grad_norm_clip=0.5),
+                              dict(params=list(b.parameters()), lr=0.01, weight_decay=0.01, grad_norm_clip=0.5)], total_steps=20)
+        return a, b, opt
+
+    runs = []
+    for split in (False, True):
+        a, b, opt = make()
+        torch.manual_seed(5)
+        for it in range(6):
+            x = torch.randn(4, 5)
+            opt.zero_grad()
+            b(a(x)).square().sum().backward()
+            if split:
+                opt.step(groups=[1])
+                assert opt.iteration == it + 1
+                opt.step(groups=[0])
+            else:
+                opt.step()
+            assert opt.iteration == it + 1
+        runs.append([p.detach().clone() for p in list(a.parameters()) + list(b.parameters())] + [torch.tensor(opt.lrs())])
+    for u, v in zip(*runs):
+        assert torch.equal(u, v)
