@@ -37,6 +37,27 @@ __device__ __forceinline__ bool last_block(int32_t* counter) {
   return true;
 }
 
+// the last workgroup's sum over all workgroups' partial pairs, in a fixed order: thread-row rr takes workgroups rr, rr + rpi, ...
+// with 8 pairs in flight (the walk is a chain of L2 round trips: at 4 pairs in flight and 512 workgroups it took longer than the
+// pass over the data -- 22 of the 45 us of a 210 K x 32 backward-statistics launch)
+__device__ __forceinline__ void reduce_partials(const double* __restrict__ partial, int G, int C, int rpi, int c, int rr, double& a, double& b) {
+  int g = rr;
+  for (; g + 7 * rpi < G; g += 8 * rpi) {
+    double av[8], bv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      av[u] = partial[((size_t)(g + u * rpi) * 2 + 0) * C + c];
+      bv[u] = partial[((size_t)(g + u * rpi) * 2 + 1) * C + c];
+    }
+    a += ((av[0] + av[1]) + (av[2] + av[3])) + ((av[4] + av[5]) + (av[6] + av[7]));
+    b += ((bv[0] + bv[1]) + (bv[2] + bv[3])) + ((bv[4] + bv[5]) + (bv[6] + bv[7]));
+  }
+  for (; g < G; g += rpi) {
+    a += partial[((size_t)g * 2 + 0) * C + c];
+    b += partial[((size_t)g * 2 + 1) * C + c];
+  }
+}
+
 // partial[blk][0][c] = sum_x, partial[blk][1][c] = sum_x^2 over the block's rows
 // VEC: C % 4 == 0 -- a thread owns 4 adjacent channels and moves one float4 (bf16: 8 bytes) per row: a quarter of the load
 // instructions of the scalar walk for the same bytes (SV = the shape over C / 4 channel groups)
@@ -126,22 +147,7 @@ __global__ __launch_bounds__(BN_T) void bn_stats(const float* __restrict__ x, Bn
   for (int c0 = 0; c0 < S.C; c0 += S.cpow) {
     const int c = c0 + (tid % S.cpow), rr = tid / S.cpow;
     double a = 0.0, b = 0.0;
-    if (c < S.C)
-    {
-      int g = rr;
-      for (; g + 3 * S.rpi < (int)gridDim.x; g += 4 * S.rpi) {  // 8 loads in flight, fixed order
-        double a0 = partial[((size_t)g * 2 + 0) * S.C + c], b0 = partial[((size_t)g * 2 + 1) * S.C + c];
-        double a1 = partial[((size_t)(g + S.rpi) * 2 + 0) * S.C + c], b1 = partial[((size_t)(g + S.rpi) * 2 + 1) * S.C + c];
-        double a2 = partial[((size_t)(g + 2 * S.rpi) * 2 + 0) * S.C + c], b2 = partial[((size_t)(g + 2 * S.rpi) * 2 + 1) * S.C + c];
-        double a3 = partial[((size_t)(g + 3 * S.rpi) * 2 + 0) * S.C + c], b3 = partial[((size_t)(g + 3 * S.rpi) * 2 + 1) * S.C + c];
-        a += ((a0 + a1) + (a2 + a3));
-        b += ((b0 + b1) + (b2 + b3));
-      }
-      for (; g < (int)gridDim.x; g += S.rpi) {
-        a += partial[((size_t)g * 2 + 0) * S.C + c];
-        b += partial[((size_t)g * 2 + 1) * S.C + c];
-      }
-    }
+    if (c < S.C) reduce_partials(partial, (int)gridDim.x, S.C, S.rpi, c, rr, a, b);
     s_a[tid] = a;
     s_b[tid] = b;
     __syncthreads();
@@ -312,22 +318,7 @@ __global__ __launch_bounds__(BN_T) void bn_bwd_stats(const float* __restrict__ x
   for (int c0 = 0; c0 < S.C; c0 += S.cpow) {
     const int c = c0 + (tid % S.cpow), rr = tid / S.cpow;
     double a = 0.0, b = 0.0;
-    if (c < S.C)
-    {
-      int g = rr;
-      for (; g + 3 * S.rpi < (int)gridDim.x; g += 4 * S.rpi) {  // 8 loads in flight, fixed order
-        double a0 = partial[((size_t)g * 2 + 0) * S.C + c], b0 = partial[((size_t)g * 2 + 1) * S.C + c];
-        double a1 = partial[((size_t)(g + S.rpi) * 2 + 0) * S.C + c], b1 = partial[((size_t)(g + S.rpi) * 2 + 1) * S.C + c];
-        double a2 = partial[((size_t)(g + 2 * S.rpi) * 2 + 0) * S.C + c], b2 = partial[((size_t)(g + 2 * S.rpi) * 2 + 1) * S.C + c];
-        double a3 = partial[((size_t)(g + 3 * S.rpi) * 2 + 0) * S.C + c], b3 = partial[((size_t)(g + 3 * S.rpi) * 2 + 1) * S.C + c];
-        a += ((a0 + a1) + (a2 + a3));
-        b += ((b0 + b1) + (b2 + b3));
-      }
-      for (; g < (int)gridDim.x; g += S.rpi) {
-        a += partial[((size_t)g * 2 + 0) * S.C + c];
-        b += partial[((size_t)g * 2 + 1) * S.C + c];
-      }
-    }
+    if (c < S.C) reduce_partials(partial, (int)gridDim.x, S.C, S.rpi, c, rr, a, b);
     s_a[tid] = a;
     s_b[tid] = b;
     __syncthreads();
@@ -451,6 +442,16 @@ int bn_grid(int N, const BnShape& S) {
   return g;
 }
 
+// vectorised statistics passes: one workgroup per `kb` KB of input (tuning keys override), at most one per CU.  Few, fat
+// workgroups: the last arriver walks every workgroup's partial sums, and that walk -- not the pass over the data -- bounds
+// these launches at BtcDet's sizes (tools/bn_bench.py)
+int bn_grid_bytes(long long bytes, int tune_key, int kb_default) {
+  const int t = btc_tune_get(tune_key);
+  const long long per = 1024LL * (t > 0 ? t : kb_default);
+  long long g = (bytes + per - 1) / per;
+  return (int)(g > 256 ? 256 : (g < 1 ? 1 : g));
+}
+
 }  // namespace
 
 extern "C" size_t btc_bn_ws_bytes(int C) { return 256 + btc_align((size_t)512 * 2 * C * sizeof(double)); }
@@ -469,8 +470,7 @@ static int bn_fwd_impl(const float* x, int N, int C, const float* gamma, const f
   if (training) {
     if ((C & 3) == 0) {
       const BnShape SV = bn_shape(N, C >> 2);
-      int g = btc_cdiv(N, SV.rpi * 16);  // >= 16 rows per thread-row before another workgroup is added
-      g = g > 256 ? 256 : (g < 1 ? 1 : g);
+      const int g = bn_grid_bytes((long long)N * C * (BF ? 2 : 4), BTC_TUNE_BN_FWD_KB, 64);
       bn_stats<BF, true><<<g, BN_T, 0, stream>>>(x, S, SV, partial, counter, momentum, eps, training, running_mean, running_mean, running_var,
                                                  num_batches_tracked, save_mean, save_rstd);
     } else {
@@ -500,8 +500,7 @@ static int bn_bwd_impl(const float* x, const float* y, const float* dy, int N, i
   BnShape S = bn_shape(N, C);
   if ((C & 3) == 0) {
     const BnShape SV = bn_shape(N, C >> 2);
-    int g = btc_cdiv(N, SV.rpi * 4);
-    g = g > 512 ? 512 : (g < 1 ? 1 : g);
+    const int g = bn_grid_bytes((long long)N * C * (BF ? 6 : 12), BTC_TUNE_BN_BWD_KB, 128);
     bn_bwd_stats<BF, true><<<g, BN_T, 0, stream>>>(x, y, dy, save_mean, save_rstd, S, SV, relu, partial, counter, dgamma, dbeta);
   } else {
     bn_bwd_stats<BF, false><<<bn_grid_bwd(N, S), BN_T, 0, stream>>>(x, y, dy, save_mean, save_rstd, S, S, relu, partial, counter, dgamma, dbeta);

@@ -60,6 +60,8 @@ int btc_version(void);
 #define BTC_TUNE_WGRAD_WGS 6  /* conv_wgrad_rows: target number of workgroups (row splits x offset groups) */
 #define BTC_TUNE_POV_SELECT 7 /* PassOccVox top-k: 1 = single-workgroup pov_select (cross-check of the multi-workgroup path) */
 #define BTC_TUNE_BF16_OPERANDS 8 /* host bindings: 1 = keep fp32 weights under bf16 activations (conv_apply_g, bit-exact fmaf chain) instead of btc_conv_*_bf16w */
+#define BTC_TUNE_BN_FWD_KB 9  /* bn_stats: KB of input per workgroup (0 = built-in 64) */
+#define BTC_TUNE_BN_BWD_KB 10 /* bn_bwd_stats: KB of input (x, y, dy) per workgroup (0 = built-in 128) */
 #define BTC_TUNE_APPLY_DEBUG 3 /* timing experiments only (WRONG results): 1 = no MFMA phase, 2 = no loads in the main loop */
 int btc_tune_set(int key, int value);
 int btc_tune_value(int key);   /* current value of a key (0 = built-in policy) */
