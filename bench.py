@@ -316,6 +316,10 @@ def main():
     dev_index = local_rank % torch.cuda.device_count() if backend != "nccl" else local_rank
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
+    # host threads of this rank next to its GPU (btcdet_amd/affinity.py): the step is launch-rate sensitive, and on a two-socket
+    # host an unpinned process that lands on the far socket loses 3-6 % (and makes the number box-dependent)
+    from btcdet_amd.affinity import pin_to_gpu
+    pinned = pin_to_gpu(dev_index, local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))
     dist = None
     # BTC_BENCH_FORCE_DIST=1: take the distributed path (process group, DDP wrapper, barriers) at world size 1 too --
     # the way to exercise the RCCL code path on a single-GPU box
@@ -475,6 +479,7 @@ def main():
                                      (None if grad_sync is None else ("btcdet_amd.grad_sync: detection bucket all-reduced during the occupancy branch's backward, occupancy bucket after it"
                                                                      if getattr(grad_sync, "split_backward", False) else "btcdet_amd.grad_sync: flat bucket(s), all-reduce after backward"))),
                        "collective": (None if dist is None else {"backend": dist.get_backend(), "world_size": dist.get_world_size()}),
+                       "host_cpus": (None if not pinned else "%d CPUs local to the GPU (sysfs local_cpulist), first %d" % (len(pinned), pinned[0])),
                        "points_per_batch": [b["n_points"] for b in batches]},
         }
         if prof is not None:

@@ -10,6 +10,8 @@
 //
 // Roofline: HBM/L2 bound at BtcDet's channel widths: per output row the kernel
 // moves (pairs * Cin + Cout) * 4 B and does 2 * pairs * Cin * Cout flop.
+#include <mutex>
+
 #include "btc_common.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -429,6 +431,139 @@ __global__ __launch_bounds__(256) void conv_wgrad_partial(const float* __restric
   }
 }
 
+// conv_wgrad_partial for channel counts that are multiples of 4, with
+//  * the next tile's loads in flight during this tile's MFMAs: the map column entry of tile t + 1 is read while tile t is being
+//    staged, its gathered rows and dOut rows are requested right after tile t's tiles are visible in LDS and sit in registers
+//    until tile t's MFMAs are done (same LDS footprint, same two barriers per tile);
+//  * per-tile packing: only the rows of the tile that HAVE the offset are staged, packed to the front of the LDS tiles (a wave
+//    ballot over the column gives every live row its slot), and the reduction runs over ceil(m / 4) 4-row steps instead of 16.
+//    Both operands are gathered per offset here anyway, so packing costs no indirection in the MFMA loop.  At the wide layers
+//    that land on this kernel (128 -> 128, 256 -> 128 on the 8x-downsampled level) 55 % of the (row, offset) slots are live.
+// Skipped terms are exact zeros; dW differs from the unpacked sum only in how rows group into 4-row MFMA steps.
+template <int NT, bool BF>
+__global__ __launch_bounds__(256) void conv_wgrad_partial_p(const float* __restrict__ feat, const float* __restrict__ dout,
+                                                            const int32_t* __restrict__ nbr, int n_out, int K, int Cin, int Cout,
+                                                            int tiles_per_split, int n_cblk, float* __restrict__ part) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int LDB = ldb_of(NT);
+  float* As = (float*)smem;       // [TM][WG_LDA]  gathered input rows (packed), 64 channels
+  float* Ds = As + TM * WG_LDA;   // [TM][LDB]     dout rows (packed), NT*16 channels
+  int32_t* s_src = (int32_t*)(Ds + TM * LDB);  // [2][TM] input row of packed slot t (-1: padding of the last 4-row step)
+  int32_t* s_dst = s_src + 2 * TM;             // [2][TM] output row of packed slot t
+  int32_t* s_m = s_dst + 2 * TM;               // [2] live rows of the tile
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int k = blockIdx.x, split = blockIdx.y;
+  const int m0 = (blockIdx.z / n_cblk) * 64;
+  const int n0 = (blockIdx.z % n_cblk) * (NT * 16);
+  const int n_tiles = (n_out + TM - 1) / TM;
+  const int t_begin = split * tiles_per_split;
+  const int t_end = min(n_tiles, t_begin + tiles_per_split);
+
+  f32x4 acc[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int kq = lane >> 4;
+  const bool wave_live = (m0 + wave * 16) < Cin;
+
+  float4 va[4], vd[NT];
+  auto load_j = [&](int t) {   // wave 0: map column entry of row `lane` of tile t
+    const int row = t * TM + lane;
+    return (wave == 0 && t < t_end && row < n_out) ? nbr[(size_t)row * K + k] : -1;
+  };
+  auto pack = [&](int t, int j, int b) {   // wave 0: packed slots of tile t into buffer b
+    if (wave != 0) return;
+    const unsigned long long live = __ballot(j >= 0);
+    const int m = __popcll(live);
+    if (j >= 0) {
+      const int slot = __popcll(live & ((1ull << lane) - 1ull));
+      s_src[b * TM + slot] = j;
+      s_dst[b * TM + slot] = t * TM + lane;
+    }
+    if (lane >= m && lane < ((m + 3) & ~3)) {
+      s_src[b * TM + lane] = -1;
+      s_dst[b * TM + lane] = -1;
+    }
+    if (lane == 0) s_m[b] = m;
+  };
+  auto load_tile = [&](int b) {
+    const int m4 = (s_m[b] + 3) & ~3;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = i * 256 + tid, r = e >> 4, c = (e & 15) * 4;
+      const int jj = r < m4 ? s_src[b * TM + r] : -1;
+      va[i] = (jj >= 0 && m0 + c < Cin) ? btc_ld4<BF>(feat, (size_t)jj * Cin + m0 + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+      const int e = i * 256 + tid, r = e / (NT * 4), c = (e % (NT * 4)) * 4;
+      const int ro = r < m4 ? s_dst[b * TM + r] : -1;
+      vd[i] = (ro >= 0 && n0 + c < Cout) ? btc_ld4<BF>(dout, (size_t)ro * Cout + n0 + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto store_tile = [&](int m4) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = i * 256 + tid, r = e >> 4, c = (e & 15) * 4;
+      if (r < m4) {
+        float* d = As + r * WG_LDA + c;
+        d[0] = va[i].x; d[1] = va[i].y; d[2] = va[i].z; d[3] = va[i].w;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+      const int e = i * 256 + tid, r = e / (NT * 4), c = (e % (NT * 4)) * 4;
+      if (r < m4) {
+        float* d = Ds + r * LDB + c;
+        d[0] = vd[i].x; d[1] = vd[i].y; d[2] = vd[i].z; d[3] = vd[i].w;
+      }
+    }
+  };
+
+  // prologue: the first tile's column and loads, the second tile's column
+  int m4 = 0, jn = -1;
+  if (t_begin < t_end) {
+    pack(t_begin, load_j(t_begin), 0);
+    __syncthreads();
+    m4 = (s_m[0] + 3) & ~3;
+    if (m4) load_tile(0);
+    jn = load_j(t_begin + 1);
+  }
+  for (int t = t_begin; t < t_end; ++t) {
+    const int cur = (t - t_begin) & 1;
+    if (m4) store_tile(m4);            // tile t: registers -> LDS (the previous tile's MFMAs ended at the barrier below)
+    pack(t + 1, jn, cur ^ 1);          // tile t + 1's packed slots
+    __syncthreads();                   // tile t in LDS; everyone sees tile t + 1's slots
+    const int m4_next = (s_m[cur ^ 1] + 3) & ~3;
+    if (m4_next) load_tile(cur ^ 1);   // in flight during the MFMAs below
+    jn = load_j(t + 2);
+    if (m4 && wave_live) {
+      const int steps = m4 >> 2;
+      const float* ap = As + kq * WG_LDA + wave * 16 + (lane & 15);
+      const float* bp = Ds + kq * LDB + (lane & 15);
+#pragma unroll 4
+      for (int q = 0; q < steps; ++q) {
+        const float a = ap[q * 4 * WG_LDA];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bp[q * 4 * LDB + nt * 16], acc[nt], 0, 0, 0);
+      }
+    }
+    __syncthreads();   // MFMAs of tile t done: the LDS tiles may be overwritten
+    m4 = m4_next;
+  }
+  float* P = part + ((size_t)split * K + k) * Cin * Cout;
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int col = n0 + nt * 16 + (lane & 15);
+    if (col >= Cout) continue;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      int ci = m0 + wave * 16 + kq * 4 + r;
+      if (ci < Cin) P[(size_t)ci * Cout + col] = acc[nt][r];
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // Row-stationary weight gradient for the large-N / small-C layers (the occupancy branch: up to 210 K rows at 32
 // channels).  A persistent workgroup walks row tiles; per tile the dOut rows and the neighbour-map rows are loaded
@@ -440,7 +575,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_partial(const float* __restric
 template <int MT, int NT, int KB, int PH, bool BF>
 __global__ __launch_bounds__(256) void conv_wgrad_rows(const float* __restrict__ feat, const float* __restrict__ dout,
                                                        const int32_t* __restrict__ nbr, const int32_t* __restrict__ order, int n_out, int K,
-                                                       int Cin, int Cout, float* __restrict__ part, int swap) {
+                                                       int Cin, int Cout, float* __restrict__ part, int swap, int dbg) {
   // order (optional, row_order.hip): tile slot t works on map row order[t]; rows with the same offsets share tiles, so fewer
   // offset phases per tile are live.  dW is the fp32 sum over rows in walk order.
   // Naming follows the un-swapped case: `feat` = gathered operand (Cin channels, via the map), `dout` = contiguous
@@ -521,6 +656,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_rows(const float* __restrict__
         for (int i = 0; i < KB * MT; ++i) {
           int e = i * 256 + tid, c = (e % (MT * 4)) * 4, r = (e / (MT * 4)) % TM, kb = e / (MT * 4 * TM);
           int j = (k0 + kb < K) ? s_nbr[r * K + k0 + kb] : -1;
+          if (dbg & 8) j = -1;  // timing experiments only (BTC_TUNE_APPLY_DEBUG, tools/wgrad_bench.py): no gathers
           v[i] = (j >= 0 && c < Cin) ? btc_ld4<BF>(feat, (size_t)j * Cin + c) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
@@ -546,6 +682,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_rows(const float* __restrict__
       __syncthreads();
 #pragma unroll
       for (int q = 0; q < TPP; ++q) {
+        if (dbg & 4) continue;       // timing experiments only: no MFMA phase
         const int l = q * 4 + wave;  // phase-local tile: (kb, mt, nt)
         const int nt = l % NT, mt = (l / NT) % MT, kb = l / (NT * MT);
         const float* ap = As + (size_t)kb * TM * LDA + mt * 16 + (lane & 15);
@@ -576,6 +713,171 @@ __global__ __launch_bounds__(256) void conv_wgrad_rows(const float* __restrict__
         if (ci < Cin) {
           if (!swap) P[((size_t)k * Cin + ci) * Cout + co] = acc[p * TPP + q][r];
           else P[((size_t)k * Cout + co) * Cin + ci] = acc[p * TPP + q][r];  // here ci indexes dOut channels, co feature channels
+        }
+      }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// conv_wgrad_rows, software-pipelined (gathered-operand channel counts that are multiples of 4).  tools/wgrad_bench.py on the
+// kernel above: removing the MFMA phase halves its time, removing the gathers changes nothing -- a workgroup alternates
+// between a staging round (issue the loads, wait one L2 / HBM latency, store to LDS, barrier: ~1.8 us) and an MFMA phase of
+// about the same length, and only the other workgroup of the CU fills the holes.  Here
+//  * the loads of item g + 1 (the gathered rows of the next phase; the map rows of the tile after next) are issued right
+//    after item g's barrier and land in registers while item g's MFMAs run; they are stored to the OTHER LDS buffer at the
+//    top of item g + 1: one barrier per item, no exposed load latency;
+//  * the contiguous operand never goes through LDS: 4 % NT == 0, so a wave's accumulator tiles all share ONE 16-column block
+//    (nt = wave % NT), and its MFMA B fragments for the 16 4-row steps of a tile are 16 registers, loaded once per tile
+//    (prefetched during the previous tile's last phase) and reused by every offset of the group.  Half the LDS reads of the
+//    MFMA loop, and the LDS footprint drops to the double-buffered gather tile: 41-64 KB, two to three workgroups per CU.
+// Same tiles, same 4-row MFMA steps, same order over rows as the kernel above.  Items are all (tile, phase) pairs: a phase
+// none of whose offsets occurs in the tile costs zeros -- at 64-row tiles that is < 10 % of the phases of the layers this
+// kernel takes.
+//   LDS: As[2][KB][TM][LDA] | s_nbr[3][TM][NOFF] (the group's offsets only) | s_row[3][TM]
+// ------------------------------------------------------------------------------------------------------------
+template <int MT, int NT, int KB, int PH, bool BF>
+__global__ __launch_bounds__(256) void conv_wgrad_rows_p(const float* __restrict__ feat, const float* __restrict__ dout,
+                                                         const int32_t* __restrict__ nbr, const int32_t* __restrict__ order, int n_out, int K,
+                                                         int Cin, int Cout, float* __restrict__ part, int swap) {
+  constexpr int TPP = KB * MT * NT / 4;
+  static_assert(KB * MT * NT % 4 == 0, "phase tiles must split evenly over the 4 waves");
+  static_assert(4 % NT == 0, "a wave's tiles must share one column block");
+  constexpr int LDA = ldb_of(MT);
+  constexpr int NOFF = PH * KB;
+  constexpr int NV = (TM * NOFF + 255) / 256;   // map entries per thread and tile
+  constexpr int NS = TM / 4;                    // 4-row MFMA steps per tile
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* As = (float*)smem;                              // [2][KB][TM][LDA]
+  int32_t* s_nbr = (int32_t*)(As + 2 * KB * TM * LDA);   // [3][TM][NOFF]
+  int32_t* s_row = s_nbr + 3 * TM * NOFF;                // [3][TM]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kq = lane >> 4;
+  const int kg0 = blockIdx.y * NOFF;
+  const int n_tiles = (n_out + TM - 1) / TM;
+  const int nt_wg = ((int)blockIdx.x < n_tiles) ? (n_tiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;   // tiles of this workgroup
+  const int bcol = (wave % NT) * 16 + (lane & 15);   // this lane's column of the contiguous operand
+
+  f32x4 acc[PH * TPP];
+#pragma unroll
+  for (int t = 0; t < PH * TPP; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  int nv[NV], nrow = -1;            // the map rows (this group's offsets) and row ids of a tile, in flight
+  float4 gv[KB * MT];               // the gathered rows of an item, in flight
+  float bcur[NS], bnext[NS];        // B fragments of the tile / of the next tile (in flight)
+
+  auto load_map = [&](int i) {      // tile i of this workgroup -> registers
+    const int row0 = (blockIdx.x + i * gridDim.x) * TM;
+    if (tid < TM) nrow = (row0 + tid < n_out) ? (order ? order[row0 + tid] : row0 + tid) : -1;
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+      const int e = u * 256 + tid, r = e / NOFF, o = e - r * NOFF;
+      int v = -1;
+      if (e < TM * NOFF && row0 + r < n_out && kg0 + o < K) {
+        const int gr = order ? order[row0 + r] : row0 + r;
+        v = nbr[(long long)gr * K + kg0 + o];
+      }
+      nv[u] = v;
+    }
+  };
+  auto store_map = [&](int i) {
+    int32_t* dn = s_nbr + (i % 3) * TM * NOFF;
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+      const int e = u * 256 + tid;
+      if (e < TM * NOFF) dn[e] = nv[u];
+    }
+    if (tid < TM) s_row[(i % 3) * TM + tid] = nrow;
+  };
+  auto load_b = [&](int i) {        // B fragments of tile i (its row ids are in LDS): row 4 s + kq, column bcol
+    const int32_t* rows = s_row + (i % 3) * TM + kq;
+#pragma unroll
+    for (int s2 = 0; s2 < NS; ++s2) {
+      const int gr = rows[s2 * 4];
+      bnext[s2] = (gr >= 0 && bcol < Cout) ? btc_ld1<BF>(dout, (size_t)gr * Cout + bcol) : 0.f;
+    }
+  };
+  auto load_g = [&](int i, int p) { // the gathered rows of phase p of tile i
+    const int32_t* mp = s_nbr + (i % 3) * TM * NOFF + p * KB;
+#pragma unroll
+    for (int u = 0; u < KB * MT; ++u) {
+      const int e = u * 256 + tid, c = (e % (MT * 4)) * 4, r = (e / (MT * 4)) % TM, kb = e / (MT * 4 * TM);
+      const int j = mp[r * NOFF + kb];
+      gv[u] = (j >= 0 && c < Cin) ? btc_ld4<BF>(feat, (size_t)j * Cin + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto store_g = [&](int buf) {
+    float* A = As + buf * KB * TM * LDA;
+#pragma unroll
+    for (int u = 0; u < KB * MT; ++u) {
+      const int e = u * 256 + tid, c = (e % (MT * 4)) * 4, r = (e / (MT * 4)) % TM, kb = e / (MT * 4 * TM);
+      float* d = A + (kb * TM + r) * LDA + c;
+      d[0] = gv[u].x; d[1] = gv[u].y; d[2] = gv[u].z; d[3] = gv[u].w;
+    }
+  };
+
+  if (nt_wg > 0) {
+    load_map(0);
+    store_map(0);
+    if (nt_wg > 1) {
+      load_map(1);
+      store_map(1);
+    }
+    __syncthreads();
+    load_b(0);
+    load_g(0, 0);
+  }
+  int buf = 0;
+  for (int i = 0; i < nt_wg; ++i) {
+#pragma unroll
+    for (int p = 0; p < PH; ++p) {
+      store_g(buf);
+      if (p == 0) {
+#pragma unroll
+        for (int s2 = 0; s2 < NS; ++s2) bcur[s2] = bnext[s2];
+      }
+      // the map rows that were loaded during the previous item: tile i + 2 (PH > 1: loaded at this tile's phase 0) or
+      // tile i + 1 (PH == 1: loaded during tile i - 1); tiles 0 and 1 come from the prologue
+      if (PH > 1 ? (p == 1 && i + 2 < nt_wg) : (i >= 1 && i + 1 < nt_wg)) store_map(PH > 1 ? i + 2 : i + 1);
+      __syncthreads();
+      // ---- loads for the next item, in flight during this item's MFMAs
+      if (p + 1 < PH) {
+        load_g(i, p + 1);
+      } else if (i + 1 < nt_wg) {
+        load_b(i + 1);
+        load_g(i + 1, 0);
+      }
+      if (PH > 1 ? (p == 0 && i + 2 < nt_wg) : (i + 2 < nt_wg)) load_map(i + 2);
+      // ---- MFMAs of item (i, p)
+      const float* A = As + buf * KB * TM * LDA;
+#pragma unroll
+      for (int q = 0; q < TPP; ++q) {
+        const int l = q * 4 + wave;  // phase-local tile: (kb, mt, nt), nt == wave % NT
+        const int mt = (l / NT) % MT, kb = l / (NT * MT);
+        const float* ap = A + (size_t)kb * TM * LDA + mt * 16 + (lane & 15) + kq * LDA;
+        f32x4 a4 = acc[p * TPP + q];
+#pragma unroll
+        for (int s2 = 0; s2 < NS; ++s2) a4 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[s2 * 4 * LDA], bcur[s2], a4, 0, 0, 0);
+        acc[p * TPP + q] = a4;
+      }
+      buf ^= 1;
+    }
+  }
+  float* P = part + (size_t)blockIdx.x * K * Cin * Cout;
+#pragma unroll
+  for (int p = 0; p < PH; ++p)
+#pragma unroll
+    for (int q = 0; q < TPP; ++q) {
+      const int l = q * 4 + wave;
+      const int nt = l % NT, mt = (l / NT) % MT, kb = l / (NT * MT);
+      const int k = kg0 + p * KB + kb;
+      const int co = nt * 16 + (lane & 15);
+      if (k >= K || co >= Cout) continue;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int ci = mt * 16 + kq * 4 + r;
+        if (ci < Cin) {
+          if (!swap) P[((size_t)k * Cin + ci) * Cout + co] = acc[p * TPP + q][r];
+          else P[((size_t)k * Cout + co) * Cin + ci] = acc[p * TPP + q][r];
         }
       }
     }
@@ -748,14 +1050,34 @@ int launch_apply(const float* feat, const float* W, const float* bias, const int
   return BTC_OK;
 }
 
+template <int MT, int NT, int KB, int PH, bool BF>
+void launch_wgrad_rows_p(dim3 grid, size_t lds, hipStream_t stream, const float* g, const float* c, const int32_t* map, const int32_t* ord, int rows,
+                         int K, int Cg, int Cc, float* part, int swap) {
+  static std::once_flag once;   // launches come from the training thread, the autograd thread and the prefetch thread
+  std::call_once(once, [] {
+    (void)hipFuncSetAttribute((const void*)conv_wgrad_rows_p<MT, NT, KB, PH, BF>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  });
+  conv_wgrad_rows_p<MT, NT, KB, PH, BF><<<grid, 256, lds, stream>>>(g, c, map, ord, rows, K, Cg, Cc, part, swap);
+}
+
 struct WgradPlan {
   int nt, n_cblk, n_mblk, S, tiles_per_split;
   int rows_kernel;  // 1 = conv_wgrad_rows (row-stationary), 0 = offset-major conv_wgrad_partial
   int mt, kb, ph, groups, swap, rows;
+  int pipe;         // rows kernel: 1 = conv_wgrad_rows_p (software-pipelined)
+  size_t lds;       // rows kernel: dynamic LDS bytes
 };
+
+size_t wgrad_rows_lds(int mt, int nt, int kb, int ph_built, int K, bool pipe) {
+  const int noff = kb * ph_built;
+  if (pipe) return (size_t)(2 * kb * TM * ldb_of(mt)) * sizeof(float) + (size_t)(3 * TM * noff + 3 * TM) * sizeof(int32_t);
+  return (size_t)(kb * TM * ldb_of(mt) + TM * ldb_of(nt)) * sizeof(float) + (size_t)(TM * K + K + TM) * sizeof(int32_t);
+}
 
 WgradPlan wgrad_plan(int n_out, int K, int Cin, int Cout, int n_in = -1) {
   WgradPlan p;
+  p.pipe = 0;
+  p.lds = 0;
   p.rows_kernel = 0;
   p.swap = 0;
   p.rows = n_out;
@@ -776,13 +1098,33 @@ WgradPlan wgrad_plan(int n_out, int K, int Cin, int Cout, int n_in = -1) {
       // longer fits two workgroups per CU) and more slab traffic; the largest PH <= 4 that still leaves >= 3 row tiles
       // per workgroup measured best from 12 K to 210 K rows (e.g. 32->32 at 210 K rows 307 -> 219 us, at 12 K rows 63 -> 30 us).
       const int t_ph = btc_tune_get(BTC_TUNE_WGRAD_PH), t_wgs = btc_tune_get(BTC_TUNE_WGRAD_WGS);
+      // software-pipelined variant (conv_wgrad_rows_p) when the gathered operand's channel count is a multiple of 4; it has its
+      // own (KB, PH) per tile shape (the B fragments live in registers: LDS holds the double-buffered gather tile only)
+      p.pipe = ((swap ? Cout : Cin) & 3) == 0 && btc_tune_get(BTC_TUNE_WGRAD_PIPE) != 1;
       const int wgs = t_wgs ? t_wgs : 512;
       const int n_tiles = btc_cdiv(rows, TM);
-      if (!(mt == 1 && ntt == 1)) {
-        ph = 1;
-        for (int cand = 4; cand > 1; cand >>= 1)
-          if ((long long)n_tiles * btc_cdiv(K, kb * cand) >= 3LL * wgs) { ph = cand; break; }
-        if (t_ph) ph = t_ph;
+      if (p.pipe) {
+        if (mt == 1 && ntt == 1) { kb = 4; ph = 4; }
+        else if (mt == 2 && ntt == 1) { kb = 2; ph = 8; }
+        else if (mt == 1 && ntt == 2) { kb = 4; ph = 4; }
+        else if (mt == 2 && ntt == 2) { kb = 2; ph = 8; }
+        else if (mt == 3 && ntt == 2) { kb = 2; ph = 4; }
+        else if (mt == 2 && ntt == 4) { kb = 2; ph = 4; }
+        else if (mt == 4 && ntt == 2) { kb = 1; ph = 8; }
+        else { kb = 1; ph = 4; }
+        // few tiles: half the phases per workgroup = twice the offset groups = twice the workgroups
+        if ((long long)n_tiles * btc_cdiv(K, kb * ph) < 3LL * wgs) ph >>= 1;
+        if (t_ph == ph * 2 || t_ph * 2 == ph) ph = t_ph;   // tuning runs: the other variant
+        p.lds = wgrad_rows_lds(mt, ntt, kb, ph, K, true);
+      } else {
+        if (!(mt == 1 && ntt == 1)) {
+          ph = 1;
+          for (int cand = 4; cand > 1; cand >>= 1)
+            if ((long long)n_tiles * btc_cdiv(K, kb * cand) >= 3LL * wgs) { ph = cand; break; }
+          if (t_ph) ph = t_ph;
+        }
+        const int ph_built = (mt == 1 && ntt == 1) ? 4 : ((ph == 1 || ph == 2 || ph == 4) ? ph : 7);   // the PH the launch macros instantiate
+        p.lds = wgrad_rows_lds(mt, ntt, kb, ph_built, K, false);
       }
       p.rows_kernel = 1;
       p.swap = swap; p.rows = rows;
@@ -886,9 +1228,31 @@ static int wgrad_impl(const float* feat, const float* dout, const int32_t* nbr_o
     const int32_t* ord_ = p.swap ? order_in : order_out;
     const int Cg = p.swap ? Cout : Cin, Cc = p.swap ? Cin : Cout;
     dim3 grid(p.S, p.groups);
-    size_t lds = (size_t)(p.kb * TM * ldb_of(p.mt) + TM * ldb_of(p.nt)) * sizeof(float) + (size_t)(TM * K + K + TM) * sizeof(int32_t);
+    const size_t lds = p.lds;
+    if (p.pipe) {
+#define BTC_WGP2(MT_, NT_, KB_, PH_) launch_wgrad_rows_p<MT_, NT_, KB_, PH_, BF>(grid, lds, stream, g_, c_, map_, ord_, p.rows, K, Cg, Cc, part, p.swap)
+#define BTC_WGP(MT_, NT_, KB_, PH_)                  \
+  do {                                               \
+    if (p.ph == PH_) BTC_WGP2(MT_, NT_, KB_, PH_);   \
+    else BTC_WGP2(MT_, NT_, KB_, (PH_ / 2));         \
+  } while (0)
+      if (p.mt == 1 && p.nt == 1) BTC_WGP(1, 1, 4, 4);
+      else if (p.mt == 2 && p.nt == 1) BTC_WGP(2, 1, 2, 8);
+      else if (p.mt == 1 && p.nt == 2) BTC_WGP(1, 2, 4, 4);
+      else if (p.mt == 2 && p.nt == 2) BTC_WGP(2, 2, 2, 8);
+      else if (p.mt == 3 && p.nt == 2) BTC_WGP(3, 2, 2, 4);
+      else if (p.mt == 2 && p.nt == 4) BTC_WGP(2, 4, 2, 4);
+      else if (p.mt == 4 && p.nt == 2) BTC_WGP(4, 2, 1, 8);
+      else BTC_WGP(4, 4, 1, 4);
+#undef BTC_WGP
+#undef BTC_WGP2
+      BTC_LAUNCH_CHECK();
+      wgrad_reduce<<<btc_cdiv(count, 256), 256, 0, stream>>>(part, p.S, count, dW);
+      BTC_LAUNCH_CHECK();
+      return BTC_OK;
+    }
 #define BTC_WG_ROWS(MT_, NT_, KB_, PH_) \
-  conv_wgrad_rows<MT_, NT_, KB_, PH_, BF><<<grid, 256, lds, stream>>>(g_, c_, map_, ord_, p.rows, K, Cg, Cc, part, p.swap)
+  conv_wgrad_rows<MT_, NT_, KB_, PH_, BF><<<grid, 256, lds, stream>>>(g_, c_, map_, ord_, p.rows, K, Cg, Cc, part, p.swap, btc_tune_get(BTC_TUNE_APPLY_DEBUG))
 #define BTC_WG_ROWS_PH(MT_, NT_, KB_)               \
   do {                                              \
     if (p.ph == 1) BTC_WG_ROWS(MT_, NT_, KB_, 1);   \
@@ -912,7 +1276,19 @@ static int wgrad_impl(const float* feat, const float* dout, const int32_t* nbr_o
     return BTC_OK;
   }
   dim3 grid(K, p.S, p.n_mblk * p.n_cblk);
-  size_t lds = (size_t)(TM * WG_LDA + TM * ldb_of(p.nt)) * sizeof(float) + TM * sizeof(int32_t);
+  size_t lds = (size_t)(TM * WG_LDA + TM * ldb_of(p.nt)) * sizeof(float) + (4 * TM + 2) * sizeof(int32_t);
+  if (((Cin | Cout) & 3) == 0 && btc_tune_get(BTC_TUNE_WGRAD_PIPE) != 1) {
+    switch (p.nt) {
+      case 1: conv_wgrad_partial_p<1, BF><<<grid, 256, lds, stream>>>(feat, dout, nbr_out, n_out, K, Cin, Cout, p.tiles_per_split, p.n_cblk, part); break;
+      case 2: conv_wgrad_partial_p<2, BF><<<grid, 256, lds, stream>>>(feat, dout, nbr_out, n_out, K, Cin, Cout, p.tiles_per_split, p.n_cblk, part); break;
+      case 4: conv_wgrad_partial_p<4, BF><<<grid, 256, lds, stream>>>(feat, dout, nbr_out, n_out, K, Cin, Cout, p.tiles_per_split, p.n_cblk, part); break;
+      default: conv_wgrad_partial_p<8, BF><<<grid, 256, lds, stream>>>(feat, dout, nbr_out, n_out, K, Cin, Cout, p.tiles_per_split, p.n_cblk, part); break;
+    }
+    BTC_LAUNCH_CHECK();
+    wgrad_reduce<<<btc_cdiv(count, 256), 256, 0, stream>>>(part, p.S, count, dW);
+    BTC_LAUNCH_CHECK();
+    return BTC_OK;
+  }
   switch (p.nt) {
     case 1: conv_wgrad_partial<1, BF><<<grid, 256, lds, stream>>>(feat, dout, nbr_out, n_out, K, Cin, Cout, p.tiles_per_split, p.n_cblk, part); break;
     case 2: conv_wgrad_partial<2, BF><<<grid, 256, lds, stream>>>(feat, dout, nbr_out, n_out, K, Cin, Cout, p.tiles_per_split, p.n_cblk, part); break;

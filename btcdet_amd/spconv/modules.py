@@ -108,6 +108,8 @@ class SparseSequential(SparseModule):
                 return None
             if f.dtype == _torch.bfloat16 and (conv.in_channels % 16 or conv.out_channels % 16):
                 return None
+            if ops.pads_in_channels(conv.in_channels):   # padded per layer (ops._pad_in_channels)
+                return None
             relu = i + 2 < len(mods) and type(mods[i + 2]) is nn.ReLU
             rb = input.indice_dict.get(conv.indice_key, None) if conv.indice_key is not None else None
             if conv.inverse:

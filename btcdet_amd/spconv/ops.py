@@ -732,7 +732,26 @@ class ToDenseFunction(torch.autograd.Function):
         return dfeat, None, None, None
 
 
+def pads_in_channels(cin):
+    """whether indice_conv zero-pads a layer's input channels (to the next multiple of 16)"""
+    return cin > 16 and cin % 16 != 0
+
+
+def _pad_in_channels(features, weight):
+    """A layer with 16 < Cin and Cin % 16 != 0 (the detection backbone's 34 -> 32 conv2_combine: 32 feature + 2 occupancy
+    channels) misses the LDS-DMA apply kernel and the pipelined weight-gradient kernel by a few channels: measured 103 / 95 /
+    176 us forward / dgrad / wgrad against 46 / 47 / 59 for the 32 -> 32 layer beside it.  Zero channels appended to the
+    features and zero rows to the weight add exact zeros to every fmaf chain, so the result bits do not change; autograd slices
+    the padding off the gradients."""
+    cin = weight.shape[-2]
+    if features.is_cuda and pads_in_channels(cin):
+        pad = 16 - cin % 16
+        return torch.nn.functional.pad(features, (0, pad)), torch.nn.functional.pad(weight, (0, 0, 0, pad))
+    return features, weight
+
+
 def indice_conv(features, weight, bias, rulebook, inverse=False):
+    features, weight = _pad_in_channels(features, weight)
     if features.dtype == torch.bfloat16 and (weight.shape[-2] % 16 or weight.shape[-1] % 16):
         # bf16 activations exist in the LDS-DMA kernel only (channel counts that are multiples of 16); the few other layers
         # (4 / 6 / 34 input channels, 2 / 3-channel heads) run in fp32 and round their result
@@ -744,6 +763,7 @@ def indice_conv(features, weight, bias, rulebook, inverse=False):
 
 def indice_conv_bn_relu(features, weight, bias, rulebook, bn, relu, inverse=False):
     """indice_conv followed by bn (a fusable BatchNorm1d, see fused_bn.fusable) and optionally ReLU, as one autograd node"""
+    features, weight = _pad_in_channels(features, weight)
     if features.dtype == torch.bfloat16 and (weight.shape[-2] % 16 or weight.shape[-1] % 16):
         from . import fused_bn
         return fused_bn.batch_norm_relu(bn, indice_conv(features, weight, bias, rulebook, inverse), relu)

@@ -62,6 +62,7 @@ int btc_version(void);
 #define BTC_TUNE_BF16_OPERANDS 8 /* host bindings: 1 = keep fp32 weights under bf16 activations (conv_apply_g, bit-exact fmaf chain) instead of btc_conv_*_bf16w */
 #define BTC_TUNE_BN_FWD_KB 9  /* bn_stats: KB of input per workgroup (0 = built-in 64) */
 #define BTC_TUNE_BN_BWD_KB 10 /* bn_bwd_stats: KB of input (x, y, dy) per workgroup (0 = built-in 128) */
+#define BTC_TUNE_WGRAD_PIPE 11 /* conv_wgrad_rows: 1 = the two-barrier kernel instead of the software-pipelined one */
 #define BTC_TUNE_APPLY_DEBUG 3 /* timing experiments only (WRONG results): 1 = no MFMA phase, 2 = no loads in the main loop */
 int btc_tune_set(int key, int value);
 int btc_tune_value(int key);   /* current value of a key (0 = built-in policy) */
