@@ -404,10 +404,12 @@ def main():
     prefetch = torch.cuda.Stream(device=device, priority=-1) if os.environ.get("BTC_PREFETCH", "2") != "0" else None
     # the detection branch on its own stream, beside the occupancy branch's backward (make_step)
     det_stream = torch.cuda.Stream(device=device) if (ddp is model and os.environ.get("BTC_SPLIT_BACKWARD", "0") == "1") else None
-    # the detection group's optimizer step beside the occupancy branch's backward (make_step); single process only -- with a
-    # gradient reducer the detection bucket's all-reduce takes that slot
+    # BTC_EARLY_OPT=1: the detection group's optimizer step beside the occupancy branch's backward (make_step; single process only
+    # -- with a gradient reducer the detection bucket's all-reduce takes that slot).  Worth 1.7 % while a group's step was ~10
+    # multi-tensor torch ops (333.8 -> 339.5 scenes/s); with the three-launch step of csrc/optim.hip there is nothing left to hide
+    # (349.9 without, 348.8 with), so it is off by default.
     early_opt = (grad_sync is None and ddp is model and det_stream is None and isinstance(opts[0], GroupOptimizer)
-                 and os.environ.get("BTC_EARLY_OPT", "1") != "0")
+                 and os.environ.get("BTC_EARLY_OPT", "0") == "1")
     opt_stream = torch.cuda.Stream(device=device) if early_opt else None
     step = make_step(model, ddp, model.dataset.data_processor, opts, grad_sync, prefetch, threaded=os.environ.get("BTC_PREFETCH", "2") == "2",
                      det_stream=det_stream, opt_stream=opt_stream)

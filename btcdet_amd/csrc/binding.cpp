@@ -658,6 +658,33 @@ Tensor conv_bn_relu_chain(const Tensor& features, const std::vector<Tensor>& wei
   return x;
 }
 
+// one parameter group's optimizer step (csrc/optim.hip): norm clip + decoupled decay + Adam over the group's flat buffers, the
+// gradients read where autograd left them.  The parameters are written through raw pointers, so their version counters are
+// bumped here (the bf16 weight copies above are keyed on them).
+void adam_group_step(const std::vector<Tensor>& params, const std::vector<Tensor>& grads, const Tensor& chunk_seg, const Tensor& chunk_off,
+                     const Tensor& chunk_len, const Tensor& chunk_flat, const std::vector<int64_t>& seg_chunk0, const Tensor& flat_p,
+                     const Tensor& flat_m, const Tensor& flat_v, int64_t step, double lr, double beta1, double beta2, double eps, double weight_decay,
+                     double clip, const Tensor& ws, int64_t stream) {
+  const size_t n = params.size();
+  need(grads.size() == n && seg_chunk0.size() == n + 1, "adam_group_step: list lengths differ");
+  std::vector<const float*> ptrs(n);
+  std::vector<int32_t> sc(n + 1);
+  for (size_t i = 0; i < n; ++i) {
+    const Tensor& g = grads[i];
+    need(g.defined() && g.is_contiguous() && g.scalar_type() == at::kFloat && g.numel() == params[i].numel() && g.get_device() == flat_p.get_device(),
+         "adam_group_step: every gradient must be a contiguous fp32 tensor of its parameter's size on the parameters' device");
+    ptrs[i] = (const float*)g.data_ptr();
+    sc[i] = (int32_t)seg_chunk0[i];
+  }
+  sc[n] = (int32_t)seg_chunk0[n];
+  chk(btc_adam_group_step(ptrs.data(), (int)n, (const int32_t*)chunk_seg.data_ptr(), (const int32_t*)chunk_off.data_ptr(),
+                          (const int32_t*)chunk_len.data_ptr(), (const int64_t*)chunk_flat.data_ptr(), sc.data(), (int)chunk_seg.numel(),
+                          (float*)flat_p.data_ptr(), (float*)flat_m.data_ptr(), (float*)flat_v.data_ptr(), (long long)step, (float)lr, (float)beta1,
+                          (float)beta2, (float)eps, (float)weight_decay, (float)clip, ws.data_ptr(), (size_t)ws.numel(), st(stream)),
+      "btc_adam_group_step");
+  for (size_t i = 0; i < n; ++i) params[i].unsafeGetTensorImpl()->bump_version();
+}
+
 }  // namespace
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
@@ -671,6 +698,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("row_orders", &row_orders, py::call_guard<py::gil_scoped_release>());
   m.def("geometry_walk", &geometry_walk, py::call_guard<py::gil_scoped_release>());
   m.def("conv_bn_relu_chain", &conv_bn_relu_chain, py::call_guard<py::gil_scoped_release>());
+  m.def("adam_group_step", &adam_group_step, py::call_guard<py::gil_scoped_release>());
   m.def("join_wgrad", &join_wgrad, py::call_guard<py::gil_scoped_release>());
   m.def("set_defer_wgrad_join", &set_defer_wgrad_join);
   m.def("rulebook_subm", &rulebook_subm, py::call_guard<py::gil_scoped_release>());

@@ -8,13 +8,13 @@
 // 3x3x3 SubM tile 38-64 % (full-size golden scene, tests/golden/btc_full_a.npz).  Which rows share a tile does not change any
 // result (a row's sum only involves its own map row), so the kernels accept a permutation `order` of the rows and tile THAT.
 //
-// The permutation: inside blocks of ORDER_BLK = 4096 consecutive rows, a STABLE counting sort of the rows by their first
+// The permutation: inside blocks of ORDER_BLK = 2048 consecutive rows, a STABLE counting sort of the rows by their first
 // present offset (the lowest k with nbr[row][k] >= 0; K for a row without neighbours).  Rows of different residue classes
-// have disjoint offset sets, hence different first offsets: every group is class-pure, and a strided dgrad tile is 98 % full
+// have disjoint offset sets, hence different first offsets: every group is class-pure, and a strided dgrad tile is 96 % full
 // (a device-wide sort by the full offset mask reaches 100 % but cost 95 us per chain, and a block-local bitonic sort of the
 // masks 106 us -- half of what either bought; this kernel reads the maps once and does three block-wide passes).  Strided
 // forward maps go from 17-25 % to 35-38 %, SubM maps gain little (38-64 % -> 46-69 %) and are not ordered by the callers.
-// Block-local also keeps the rows of a tile within 4096 rows of each other in coordinate order (the gathers' L2 locality).
+// Block-local also keeps the rows of a tile within 2048 rows of each other in coordinate order (the gathers' L2 locality).
 //
 // The order is a pure function of the map (stable sort): same map -> same order, so a weight gradient walked in this order
 // stays run-to-run deterministic.
@@ -23,8 +23,8 @@
 namespace {
 
 constexpr int MAX_MAPS = BTC_ROW_ORDER_MAX_MAPS;
-constexpr int ORDER_BLK = 4096;   // rows per sort block
-constexpr int ORDER_T = 1024;     // 16 waves, each owns 256 consecutive rows of the block
+constexpr int ORDER_BLK = 2048;   // rows per sort block
+constexpr int ORDER_T = 512;      // 8 waves, each owns 256 consecutive rows of the block
 constexpr int ORDER_W = ORDER_T / 64;
 constexpr int ORDER_BINS = 65;    // first offsets 0 .. 63, and "no neighbour"
 
@@ -53,21 +53,26 @@ __global__ __launch_bounds__(ORDER_T) void order_local(OrderJobs jobs, int32_t* 
   {
     const int32_t* base = jobs.nbr[j] + (size_t)row0 * K;   // rows * K consecutive ints: coalesced
     const int total = rows * K;
-    for (int e = tid; e < total; e += ORDER_T) {
-      if (base[e] >= 0) {
-        const int r = e / K;
-        atomicMin(&s_first[r], e - r * K);
-      }
+    for (int e0 = tid; e0 < total; e0 += 8 * ORDER_T) {     // 8 loads in flight per thread (the walk is latency bound otherwise)
+      int v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = (e0 + u * ORDER_T < total) ? base[e0 + u * ORDER_T] : -1;
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (v[u] >= 0) {
+          const int e = e0 + u * ORDER_T, r = e / K;
+          atomicMin(&s_first[r], e - r * K);
+        }
     }
   }
   __syncthreads();
-  // wave w owns rows [256 w, 256 w + 256) of the block, 64 at a time in row order
+  // wave w owns rows [256 w, 256 w + 256) of the block, 64 at a time in row order (ORDER_BLK / ORDER_W == 256)
   for (int it = 0; it < ORDER_BLK / ORDER_T; ++it) {
     const int r = wave * (ORDER_BLK / ORDER_W) + it * 64 + lane;
     if (r < rows) atomicAdd(&s_cnt[s_first[r] * ORDER_W + wave], 1);
   }
   __syncthreads();
-  if (wave == 0) {   // exclusive scan of s_cnt in (bin, wave) order: lane l takes entries [17 l, 17 l + 17) (64 * 17 >= 65 * 16)
+  if (wave == 0) {   // exclusive scan of s_cnt in (bin, wave) order: lane l takes PER consecutive entries
     constexpr int PER = (ORDER_BINS * ORDER_W + 63) / 64;
     int loc[PER], sum = 0;
 #pragma unroll

@@ -147,7 +147,7 @@ ROW_ORDER = int(os.environ.get("BTC_ROW_ORDER", "1"))  # row-order hints: 1 = st
 
 def row_orders(maps):
     """row-order hints (csrc/row_order.hip) of several (n, K) neighbour maps from ONE launch: rows grouped by their first
-    present offset (stable) inside blocks of 4096 rows; one int32 permutation per map (slices of one buffer).  Any permutation gives the same
+    present offset (stable) inside blocks of 2048 rows; one int32 permutation per map (slices of one buffer).  Any permutation gives the same
     conv results."""
     import ctypes
     maps = list(maps)

@@ -15,6 +15,8 @@ Optimizer-wrapper Python.  Checked against the reference's own OptimWrapper + On
 (tests/golden/gen_optim_golden.py -> tests/golden/optim.npz, tests/test_train_step_cpu.py)."""
 import math
 
+import os
+
 import torch
 
 
@@ -62,7 +64,11 @@ class GroupOptimizer(object):
     "grad_norm_clip", "moms", "div_factor", "pct_start", "lr_clip"}; total_steps = iterations per epoch x epochs.
     With "module" the group's parameters are taken (and numbered, for state_dict_lst) as the reference's optimizer does."""
 
-    def __init__(self, groups, total_steps, beta2=0.99, eps=1e-8):
+    def __init__(self, groups, total_steps, beta2=0.99, eps=1e-8, flat=None):
+        """flat (default: on for CUDA parameters when the compiled binding is there, BTC_FLAT_OPTIM=0 turns it off): a group's
+        parameters and Adam moments become views into one flat buffer each and the whole step of the group is three launches of
+        csrc/optim.hip instead of ~10 multi-tensor torch ops over ~120-tensor lists (same arithmetic; the host side of those ops
+        was what the GPU waited for).  A step in which some parameter has no (or an unusual) gradient takes the list path."""
         self.groups = []
         for g in groups:
             if "module" in g:
@@ -77,6 +83,68 @@ class GroupOptimizer(object):
                                     steps=[torch.zeros((), dtype=torch.float32, device=p.device) for p in params], it=0))
         self.beta2, self.eps = beta2, eps
         self._present = self._missing = None
+        if flat is None:
+            flat = os.environ.get("BTC_FLAT_OPTIM", "1") != "0"
+        if flat:
+            for g in self.groups:
+                self._make_flat(g)
+
+    def _make_flat(self, g):
+        from . import _lib
+        params = g["params"]
+        F = _lib.fast() if (params and all(p.is_cuda and p.dtype == torch.float32 for p in params)) else None
+        if F is None or len({p.device for p in params}) != 1:
+            return
+        dev = params[0].device
+        sizes = [p.numel() for p in params]
+        total = sum(sizes)
+        with torch.no_grad():
+            flat_p = torch.empty((total,), dtype=torch.float32, device=dev)
+            flat_m = torch.zeros((total,), dtype=torch.float32, device=dev)
+            flat_v = torch.zeros((total,), dtype=torch.float32, device=dev)
+            off, seg, coff, clen, cflat, seg0 = 0, [], [], [], [], [0]
+            for i, (p, n) in enumerate(zip(params, sizes)):
+                flat_p[off:off + n].copy_(p.detach().reshape(-1))
+                p.data = flat_p[off:off + n].view(p.shape)           # the module's parameter now lives in the flat buffer
+                flat_m[off:off + n].copy_(g["exp_avgs"][i].reshape(-1))
+                flat_v[off:off + n].copy_(g["exp_avg_sqs"][i].reshape(-1))
+                g["exp_avgs"][i] = flat_m[off:off + n].view(p.shape)
+                g["exp_avg_sqs"][i] = flat_v[off:off + n].view(p.shape)
+                for c0 in range(0, n, 1024):
+                    seg.append(i % 448); coff.append(c0); clen.append(min(1024, n - c0)); cflat.append(off + c0)
+                seg0.append(len(seg))
+                off += n
+            i32 = lambda v: torch.tensor(v, dtype=torch.int32, device=dev)
+            ws_bytes = _lib.lib().btc_adam_group_ws_bytes(len(seg))
+            g["flat"] = dict(F=F, p=flat_p, m=flat_m, v=flat_v, seg=i32(seg), off=i32(coff), len=i32(clen),
+                             flat=torch.tensor(cflat, dtype=torch.int64, device=dev), seg0=seg0,
+                             ws=torch.zeros((ws_bytes,), dtype=torch.uint8, device=dev), n=0, synced=True)
+
+    def _sync_steps(self, g):
+        """per-parameter step counters (list path, checkpoints) from the flat path's single count"""
+        fl = g.get("flat")
+        if fl is not None and not fl["synced"]:
+            for st in g["steps"]:
+                st.fill_(float(fl["n"]))
+            fl["synced"] = True
+
+    def _flat_step(self, g, grads):
+        """the group's step through csrc/optim.hip; False if this step has to take the list path"""
+        fl = g.get("flat")
+        if fl is None or fl["n"] < 0:
+            return False
+        for gr in grads:
+            if gr is None or gr.dtype != torch.float32 or not gr.is_contiguous():
+                self._sync_steps(g)
+                fl["n"] = -1        # per-parameter step counts may differ from here on: list path for good
+                return False
+        from ._lib import stream_ptr
+        fl["n"] += 1
+        fl["synced"] = False
+        fl["F"].adam_group_step(g["params"], grads, fl["seg"], fl["off"], fl["len"], fl["flat"], fl["seg0"], fl["p"], fl["m"], fl["v"], fl["n"],
+                                float(g["lr"]), float(g["mom"]), float(self.beta2), float(self.eps), float(g["weight_decay"]), float(g["clip"]),
+                                fl["ws"], stream_ptr())
+        return True
 
     @property
     def iteration(self):
@@ -124,6 +192,14 @@ class GroupOptimizer(object):
             else:
                 grads = [p.grad for p in params]
                 keep = [i for i, gr in enumerate(grads) if gr is not None]
+            # (a missing gradient retires the flat path of the group: per-parameter step counts differ from then on)
+            if params and "flat" in g and self._flat_step(g, grads if len(keep) == len(params) else [None]):
+                if g["clip"] > 0:
+                    last_norms.append(g["flat"]["ws"][:8].view(torch.float64).sqrt())
+                nlr, nmom = g["sched"].at(g["it"])
+                g["lr"], g["mom"] = max(nlr, g["lr_clip"]), nmom
+                g["it"] += 1
+                continue
             if len(keep) != len(params):
                 params, grads = [params[i] for i in keep], [grads[i] for i in keep]
                 ea, es, st = [g["exp_avgs"][i] for i in keep], [g["exp_avg_sqs"][i] for i in keep], [g["steps"][i] for i in keep]
@@ -157,6 +233,7 @@ class GroupOptimizer(object):
         and its parameter numbering, so that a checkpoint written here resumes in the reference and vice versa"""
         out = []
         for g in self.groups:
+            self._sync_steps(g)
             n, split = len(g["params"]), g["split"]
             state = {}
             for i in range(n):
@@ -186,5 +263,9 @@ class GroupOptimizer(object):
                     g["exp_avg_sqs"][i].copy_(st["exp_avg_sq"])
             pg = sd["param_groups"][-1]
             g["lr"], g["mom"] = float(pg["lr"]), float(pg["betas"][0])
+            if "flat" in g:   # one step count for the whole group, or the list path
+                counts = {int(float(st)) for st in g["steps"]}
+                g["flat"]["n"] = counts.pop() if len(counts) == 1 else -1
+                g["flat"]["synced"] = True
         if iteration is not None:
             self.iteration = int(iteration)

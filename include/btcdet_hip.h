@@ -237,7 +237,7 @@ int btc_conv_dgrad_bf16w(const void* dout, const void* w_bf16, const int32_t* nb
 /* Row-order hints (csrc/row_order.hip).  The apply kernels work on tiles of 16 consecutive map rows and pay for every
  * offset ANY row of the tile has; which rows share a tile changes no result.  btc_row_orders sorts the rows of up to
  * BTC_ROW_ORDER_MAX_MAPS neighbour maps by their FIRST PRESENT OFFSET (lowest k with nbr[row][k] >= 0; K if none) -- a
- * stable counting sort inside blocks of 4096 consecutive rows, one launch for all maps; rows of a strided layer's dgrad
+ * stable counting sort inside blocks of 2048 consecutive rows, one launch for all maps; rows of a strided layer's dgrad
  * map that can share offsets at all end up together: order[off_j + t] = the row of map j that tile slot t works on,
  * off_j = n_rows[0] + .. + n_rows[j-1] (K <= 64).  btc_conv_apply_ordered is btc_conv_fwd / _dgrad
  * (+ _bf16 / _bf16w, by `operands`) with such a hint -- any permutation of 0..n_rows-1 is valid; order == NULL is the map
@@ -262,6 +262,24 @@ int btc_conv_wgrad_ordered(int bf16_act, const void* feat, const void* dout, con
                            const int32_t* nbr_in, int n_in, const int32_t* order_out, const int32_t* order_in, int K, int Cin,
                            int Cout, float* dW, void* ws, size_t ws_bytes, void* stream);
 
+
+/* One parameter group's optimizer step of the reference's loop (tools/train_utils/train_utils.py:121-124: clip_grad_norm_,
+ * then OptimWrapper.step = decoupled weight decay + torch.optim.Adam) in three launches (csrc/optim.hip).  The group's
+ * parameters and the two Adam moments are ONE flat fp32 buffer each; gradient s (fp32, contiguous, the size of parameter s)
+ * is read where it lies through grads[s].  The parameters are cut into chunks of <= 1024 elements that never straddle two
+ * parameters: chunk c covers elements [chunk_off[c], chunk_off[c] + chunk_len[c]) of parameter s, which sit at
+ * chunk_flat[c] in the flat buffers, chunk_seg[c] = s % BTC_ADAM_MAX_SEGMENTS; seg_chunk0[s] = first chunk of parameter s,
+ * seg_chunk0[n_seg] = n_chunks (chunks ordered by parameter).  chunk_* are device arrays, grads / seg_chunk0 host arrays.
+ *   coef = 1 / max(1, (||g|| + 1e-6) / clip)   (clip <= 0: no clipping);   g *= coef;   p *= 1 - weight_decay * lr;
+ *   m = lerp(m, g, 1 - beta1);  v = beta2 v + (1 - beta2) g^2;  p -= lr / (1 - beta1^step) * m / (sqrt(v) / sqrt(1 - beta2^step) + eps)
+ * step = the 1-based count of this update.  ws: btc_adam_group_ws_bytes(n_chunks); its first 8 bytes hold ||g||^2 (double)
+ * after the call. */
+#define BTC_ADAM_MAX_SEGMENTS 448
+size_t btc_adam_group_ws_bytes(int n_chunks);
+int btc_adam_group_step(const float* const* grads, int n_seg, const int32_t* chunk_seg, const int32_t* chunk_off,
+                        const int32_t* chunk_len, const int64_t* chunk_flat, const int32_t* seg_chunk0, int n_chunks,
+                        float* params, float* exp_avg, float* exp_avg_sq, long long step, float lr, float beta1, float beta2,
+                        float eps, float weight_decay, float clip, void* ws, size_t ws_bytes, void* stream);
 
 /* Sparse max-pool (spconv indice_maxpool, App. B.6): out = max(0, max_k feat[nbr_out[i][k]]);
  * backward routes dout to every input equal to its output. */

@@ -1,4 +1,4 @@
-"""Row-order hints (csrc/row_order.hip): btc_row_orders against a numpy stable sort by first present offset in 4096-row blocks (exact), and the
+"""Row-order hints (csrc/row_order.hip): btc_row_orders against a numpy stable sort by first present offset in 2048-row blocks (exact), and the
 ordered apply / weight-gradient entry points against the plain ones -- forward and dgrad bit-identical for ANY permutation
 (a row's sum only involves its own map row), the weight gradient equal up to fp32 summation order and run-to-run identical."""
 import ctypes
@@ -34,8 +34,8 @@ def _expected_order(nbr):
     has = nbr >= 0
     key = np.where(has.any(1), has.argmax(1), nbr.shape[1])   # first present offset, K for a row without neighbours
     order = np.arange(nbr.shape[0], dtype=np.int32)
-    for s in range(0, nbr.shape[0], 4096):    # stable sort by that key inside blocks of 4096 consecutive rows
-        order[s:s + 4096] = s + np.argsort(key[s:s + 4096], kind="stable")
+    for s in range(0, nbr.shape[0], 2048):    # stable sort by that key inside blocks of 2048 consecutive rows
+        order[s:s + 2048] = s + np.argsort(key[s:s + 2048], kind="stable")
     return order
 
 

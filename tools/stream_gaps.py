@@ -17,6 +17,15 @@ steps = max(sum(1 for r in rows if "bn_stats" in r[0]) / 27.0, 1.0)
 print("window %.1f ms, ~%.1f steps (27 bn_stats per step) -> %.2f ms per step under the profiler" % ((t1 - t0) / 1e6, steps, (t1 - t0) / 1e6 / steps))
 for k, v in sorted(by.items(), key=lambda x: -x[1]):
     print("  stream %s: busy %.2f ms/step, %.0f launches/step%s" % (k, v / 1e6 / steps, cnt[k] / steps, "  <- main" if k == main else ""))
+fam = collections.defaultdict(float)
+famc = collections.Counter()
+short0 = lambda n: re.sub(r"[<(].*", "", n.replace("void ", "").replace("(anonymous namespace)::", "").replace("at::native::", ""))[:40]
+for n, s, q, a, b in rows:
+    fam[((s, q), short0(n))] += b - a
+    famc[((s, q), short0(n))] += 1
+for k in sorted(by, key=lambda x: -by[x])[:3]:
+    top = sorted(((v, n) for (kk, n), v in fam.items() if kk == k), reverse=True)[:12]
+    print("  stream %s top kernels (ms/step, launches/step): " % (k,) + ", ".join("%s %.3f/%.0f" % (n, v / 1e6 / steps, famc[(k, n)] / steps) for v, n in top))
 ev = sorted([(a, 1) for _, _, _, a, b in rows] + [(b, -1) for _, _, _, a, b in rows])
 act, last, union = 0, None, 0
 for t, d in ev:
