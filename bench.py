@@ -41,11 +41,11 @@ BF16_MFMA_PEAK_TF = 2500.0  # same guide: dense bf16 MFMA peak (AMD's 5 PF figur
 
 
 def pmc_traffic_per_launch():
-    """HBM bytes per conv_apply launch from the committed PMC passes (profiles/r02b_pmc.json: rocprofv3 --pmc FETCH_SIZE and
+    """HBM bytes per conv_apply launch from the committed PMC passes (profiles/r02h_pmc.json: rocprofv3 --pmc FETCH_SIZE and
     --pmc WRITE_SIZE in separate runs, FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md); PMC counters cannot be read
     inside the timed process, so this is null when the file is absent"""
     try:
-        with open(os.path.join(ROOT, "profiles", "r02b_pmc.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r02h_pmc.json")) as f:
             return json.load(f)["conv_apply"]["hbm_bytes_per_launch"]
     except (OSError, KeyError, ValueError):
         return None
@@ -319,6 +319,7 @@ def main():
     # host threads of this rank next to its GPU (btcdet_amd/affinity.py): the step is launch-rate sensitive, and on a two-socket
     # host an unpinned process that lands on the far socket loses 3-6 % (and makes the number box-dependent)
     from btcdet_amd.affinity import pin_to_gpu
+    all_cpus = os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else None
     pinned = pin_to_gpu(dev_index, local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))
     dist = None
     # BTC_BENCH_FORCE_DIST=1: take the distributed path (process group, DDP wrapper, barriers) at world size 1 too --
@@ -517,6 +518,8 @@ def main():
             if rb:
                 result["rulebook_hbm_GBps"] = round(rb["bytes"] / (rb["ms"] * 1e-3) / 1e9, 2)
         if world == 1 and not args.no_cpu_baseline and not waymo:
+            if pinned and all_cpus:   # the CPU legs (one core; one worker per host core) run unpinned
+                os.sched_setaffinity(0, all_cpus)
             result["cpu_baseline"] = cpu_baseline()
         print(json.dumps(result))
     if dist is not None:

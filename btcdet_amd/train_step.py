@@ -178,7 +178,7 @@ class GroupOptimizer(object):
         """groups: indices of the parameter groups to step (default: all).  The groups are independent -- own gradient-norm
         clip, own schedule, as the reference's two optimizers are -- so a training loop may step a group as soon as ITS
         gradients are complete (bench.py steps the detection branch's group while the occupancy branch is still in backward)."""
-        last_norms = []
+        last_norms = []   # per clipped group: the gradient norm (list path) / a view of the SQUARED norm, a double (flat path)
         for gi, g in enumerate(self.groups):
             if groups is not None and gi not in groups:
                 continue
@@ -194,8 +194,8 @@ class GroupOptimizer(object):
                 keep = [i for i, gr in enumerate(grads) if gr is not None]
             # (a missing gradient retires the flat path of the group: per-parameter step counts differ from then on)
             if params and "flat" in g and self._flat_step(g, grads if len(keep) == len(params) else [None]):
-                if g["clip"] > 0:
-                    last_norms.append(g["flat"]["ws"][:8].view(torch.float64).sqrt())
+                if g["clip"] > 0:   # the squared norm stays on the device (first 8 bytes of the workspace); no launch for logging
+                    last_norms.append(g["flat"]["ws"][:8].view(torch.float64))
                 nlr, nmom = g["sched"].at(g["it"])
                 g["lr"], g["mom"] = max(nlr, g["lr_clip"]), nmom
                 g["it"] += 1
