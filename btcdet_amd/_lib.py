@@ -160,6 +160,11 @@ def lib():
             fn = getattr(L, name)  # AttributeError if a declared symbol is not exported
             fn.restype = res
             fn.argtypes = args
+        # BTC_TUNE="key=value,key=value": tuning keys of include/btcdet_hip.h (BTC_TUNE_*) for A/B runs
+        for kv in filter(None, os.environ.get("BTC_TUNE", "").split(",")):
+            k, v = kv.split("=")
+            if L.btc_tune_set(int(k), int(v)) != 0:
+                raise BtcHipError("BTC_TUNE: bad entry %r" % kv)
         _lib = L
     return _lib
 

@@ -5,12 +5,11 @@ run() { # name, env assignments...
   env "$@" python bench.py --steps 150 --warmup 20 --no-cpu-baseline --no-roofline $EXTRA 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$name', d['value'], d['step_ms']['p10'], d['step_ms']['median'], d['step_ms']['p90'])"
 }
 for rep in 1 2 3; do
-run "base        " X=1
-run "early=0     " BTC_EARLY_OPT=0
-run "flat=0      " BTC_FLAT_OPTIM=0
+run "one-launch BN " X=1
+run "two-launch BN " BTC_TUNE=12=1
 done
 EXTRA="--features bf16"
 for rep in 1 2; do
-run "bf16 base   " X=1
-run "bf16 early=0" BTC_EARLY_OPT=0
+run "bf16 one-launch" X=1
+run "bf16 two-launch" BTC_TUNE=12=1
 done
