@@ -685,6 +685,25 @@ void adam_group_step(const std::vector<Tensor>& params, const std::vector<Tensor
   for (size_t i = 0; i < n; ++i) params[i].unsafeGetTensorImpl()->bump_version();
 }
 
+// pack half of a gradient bucket: flat <- the gradients, one launch (csrc/optim.hip grads_pack); chunk tables as adam_group_step
+void pack_grads(const std::vector<Tensor>& grads, const Tensor& chunk_seg, const Tensor& chunk_off, const Tensor& chunk_len, const Tensor& chunk_flat,
+                const std::vector<int64_t>& seg_chunk0, const std::vector<int64_t>& sizes, const Tensor& flat, int64_t stream) {
+  const size_t n = grads.size();
+  need(seg_chunk0.size() == n + 1 && sizes.size() == n, "pack_grads: list lengths differ");
+  std::vector<const float*> ptrs(n);
+  std::vector<int32_t> sc(n + 1);
+  for (size_t i = 0; i < n; ++i) {
+    const Tensor& g = grads[i];
+    need(g.defined() && g.is_contiguous() && g.scalar_type() == at::kFloat && g.numel() == sizes[i] && g.get_device() == flat.get_device(),
+         "pack_grads: every gradient must be a contiguous fp32 tensor of its parameter's size on the bucket's device");
+    ptrs[i] = (const float*)g.data_ptr();
+    sc[i] = (int32_t)seg_chunk0[i];
+  }
+  sc[n] = (int32_t)seg_chunk0[n];
+  chk(btc_grads_pack(ptrs.data(), (int)n, (const int32_t*)chunk_seg.data_ptr(), (const int32_t*)chunk_off.data_ptr(), (const int32_t*)chunk_len.data_ptr(),
+                     (const int64_t*)chunk_flat.data_ptr(), sc.data(), (float*)flat.data_ptr(), st(stream)), "btc_grads_pack");
+}
+
 }  // namespace
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
@@ -698,6 +717,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("row_orders", &row_orders, py::call_guard<py::gil_scoped_release>());
   m.def("geometry_walk", &geometry_walk, py::call_guard<py::gil_scoped_release>());
   m.def("conv_bn_relu_chain", &conv_bn_relu_chain, py::call_guard<py::gil_scoped_release>());
+  m.def("pack_grads", &pack_grads, py::call_guard<py::gil_scoped_release>());
   m.def("adam_group_step", &adam_group_step, py::call_guard<py::gil_scoped_release>());
   m.def("join_wgrad", &join_wgrad, py::call_guard<py::gil_scoped_release>());
   m.def("set_defer_wgrad_join", &set_defer_wgrad_join);

@@ -91,7 +91,42 @@ __global__ __launch_bounds__(256) void adam_apply(GradPtrs ptrs, const int32_t* 
   }
 }
 
+// flat[chunk_flat[c] + e] = gradient e of chunk c: the pack half of a gradient bucket (btcdet_amd/grad_sync.py), one launch instead
+// of a multi-tensor copy over a ~120-tensor list
+__global__ __launch_bounds__(256) void grads_pack(GradPtrs ptrs, const int32_t* __restrict__ chunk_seg, const int32_t* __restrict__ chunk_off,
+                                                  const int32_t* __restrict__ chunk_len, const int64_t* __restrict__ chunk_flat, int chunk0,
+                                                  float* __restrict__ flat) {
+  const int c = chunk0 + blockIdx.x;
+  const float* g = ptrs.g[chunk_seg[c]] + chunk_off[c];
+  const int len = chunk_len[c];
+  float* out = flat + chunk_flat[c];
+#pragma unroll
+  for (int u = 0; u < OPT_CHUNK / 256; ++u) {
+    const int e = u * 256 + threadIdx.x;
+    if (e < len) out[e] = g[e];
+  }
+}
+
 }  // namespace
+
+extern "C" int btc_grads_pack(const float* const* grads, int n_seg, const int32_t* chunk_seg, const int32_t* chunk_off, const int32_t* chunk_len,
+                              const int64_t* chunk_flat, const int32_t* seg_chunk0, float* flat, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  BTC_CHECK_ARG(n_seg >= 0, "btc_grads_pack: bad sizes");
+  for (int s0 = 0; s0 < n_seg; s0 += BTC_ADAM_MAX_SEGMENTS) {
+    const int s1 = s0 + BTC_ADAM_MAX_SEGMENTS < n_seg ? s0 + BTC_ADAM_MAX_SEGMENTS : n_seg;
+    GradPtrs ptrs;
+    for (int s = s0; s < s1; ++s) {
+      BTC_CHECK_ARG(grads[s] != nullptr, "btc_grads_pack: gradient %d is NULL", s);
+      ptrs.g[s - s0] = grads[s];
+    }
+    const int c0 = seg_chunk0[s0], c1 = seg_chunk0[s1];
+    if (c1 <= c0) continue;
+    grads_pack<<<c1 - c0, 256, 0, stream>>>(ptrs, chunk_seg, chunk_off, chunk_len, chunk_flat, c0, flat);
+    BTC_LAUNCH_CHECK();
+  }
+  return BTC_OK;
+}
 
 extern "C" size_t btc_adam_group_ws_bytes(int n_chunks) { return 256 + btc_align((size_t)(n_chunks > 0 ? n_chunks : 1) * sizeof(double)); }
 

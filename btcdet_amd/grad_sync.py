@@ -23,6 +23,7 @@ import torch.distributed as dist
 import os
 _TIMING = {} if os.environ.get("BTC_SYNC_TIMING") == "1" else None  # host seconds spent in _launch / finish (tools)
 _DRYRUN = os.environ.get("BTC_SYNC_DRYRUN") == "1"                   # A-B runs: everything but the collective itself
+_PACK_KERNEL = os.environ.get("BTC_SYNC_PACK", "1") != "0"            # one-launch pack (csrc/optim.hip) instead of a multi-tensor copy
 
 
 class _Bucket(object):
@@ -39,6 +40,7 @@ class _Bucket(object):
         self.work = None
         self.launched = False
         self.missing = ()
+        self.tables = None   # chunk tables of csrc/optim.hip (one-launch pack), built on first use on a GPU
 
 
 class BucketedGradSync(object):
@@ -95,26 +97,41 @@ class BucketedGradSync(object):
             with torch.cuda.stream(cs):
                 from .spconv import ops
                 ops.join_wgrad()
-                if len(have) != len(grads):
-                    b.flat.zero_()
-                if have:
-                    torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
+                self._pack(b, have, grads)
                 if not _DRYRUN:
                     b.work = dist.all_reduce(b.flat, op=self.reduce_op, group=self.group, async_op=True)
             return
         if b.flat.is_cuda:
             from .spconv import ops
             ops.join_wgrad()  # weight gradients may still be in flight on the side stream (ops.set_defer_wgrad_join)
-        if len(have) != len(grads):  # a parameter without gradient this step contributes zeros
-            b.flat.zero_()
-        if have:
-            torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
+        self._pack(b, have, grads)
         if self.stage_on_host and b.flat.is_cuda:
             host = b.flat.cpu()
             dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
             b.flat.copy_(host)
         else:
             b.work = dist.all_reduce(b.flat, op=self.reduce_op, group=self.group, async_op=True)
+
+    def _pack(self, b, have, grads):
+        """flat bucket <- gradients.  All present, fp32, contiguous, on the GPU and the compiled binding there: ONE launch through a
+        pointer table in the kernel arguments (csrc/optim.hip grads_pack); otherwise a multi-tensor copy over two ~120-tensor lists
+        (measured at world size 1 over RCCL: 305.7 vs 299.8 scenes/s)."""
+        if len(have) != len(grads):  # a parameter without gradient this step contributes zeros
+            b.flat.zero_()
+        if not have:
+            return
+        if b.flat.is_cuda and len(have) == len(grads) and _PACK_KERNEL:
+            from . import _lib
+            F = _lib.fast()
+            if F is not None and all(g.dtype == torch.float32 and g.is_contiguous() for g in grads):
+                if b.tables is None:
+                    from .train_step import chunk_tables
+                    b.sizes = [p.numel() for p in b.params]
+                    b.tables = chunk_tables(b.sizes, b.flat.device)
+                t = b.tables
+                F.pack_grads(grads, t["seg"], t["off"], t["len"], t["flat"], t["seg0"], b.sizes, b.flat, _lib.stream_ptr())
+                return
+        torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
 
     def _comm_stream(self, device):
         st = self._cs.get(device.index)

@@ -59,6 +59,20 @@ def reference_param_groups(module):
     return plain, norm
 
 
+def chunk_tables(sizes, device):
+    """chunk tables of csrc/optim.hip for parameters of the given sizes laid out back to back in a flat buffer: chunks of <= 1024
+    elements that never straddle two parameters -> dict(seg, off, len, flat: device tensors; seg0: host list, first chunk of each
+    parameter)"""
+    off, seg, coff, clen, cflat, seg0 = 0, [], [], [], [], [0]
+    for i, n in enumerate(sizes):
+        for c0 in range(0, n, 1024):
+            seg.append(i % 448); coff.append(c0); clen.append(min(1024, n - c0)); cflat.append(off + c0)
+        seg0.append(len(seg))
+        off += n
+    i32 = lambda v: torch.tensor(v, dtype=torch.int32, device=device)
+    return dict(seg=i32(seg), off=i32(coff), len=i32(clen), flat=torch.tensor(cflat, dtype=torch.int64, device=device), seg0=seg0)
+
+
 class GroupOptimizer(object):
     """one or more parameter groups, each {"params" or "module", "lr" (LR of the yaml = lr_max), "weight_decay",
     "grad_norm_clip", "moms", "div_factor", "pct_start", "lr_clip"}; total_steps = iterations per epoch x epochs.
@@ -102,7 +116,7 @@ class GroupOptimizer(object):
             flat_p = torch.empty((total,), dtype=torch.float32, device=dev)
             flat_m = torch.zeros((total,), dtype=torch.float32, device=dev)
             flat_v = torch.zeros((total,), dtype=torch.float32, device=dev)
-            off, seg, coff, clen, cflat, seg0 = 0, [], [], [], [], [0]
+            off = 0
             for i, (p, n) in enumerate(zip(params, sizes)):
                 flat_p[off:off + n].copy_(p.detach().reshape(-1))
                 p.data = flat_p[off:off + n].view(p.shape)           # the module's parameter now lives in the flat buffer
@@ -110,14 +124,10 @@ class GroupOptimizer(object):
                 flat_v[off:off + n].copy_(g["exp_avg_sqs"][i].reshape(-1))
                 g["exp_avgs"][i] = flat_m[off:off + n].view(p.shape)
                 g["exp_avg_sqs"][i] = flat_v[off:off + n].view(p.shape)
-                for c0 in range(0, n, 1024):
-                    seg.append(i % 448); coff.append(c0); clen.append(min(1024, n - c0)); cflat.append(off + c0)
-                seg0.append(len(seg))
                 off += n
-            i32 = lambda v: torch.tensor(v, dtype=torch.int32, device=dev)
-            ws_bytes = _lib.lib().btc_adam_group_ws_bytes(len(seg))
-            g["flat"] = dict(F=F, p=flat_p, m=flat_m, v=flat_v, seg=i32(seg), off=i32(coff), len=i32(clen),
-                             flat=torch.tensor(cflat, dtype=torch.int64, device=dev), seg0=seg0,
+            t = chunk_tables(sizes, dev)
+            ws_bytes = _lib.lib().btc_adam_group_ws_bytes(int(t["seg"].numel()))
+            g["flat"] = dict(F=F, p=flat_p, m=flat_m, v=flat_v, seg=t["seg"], off=t["off"], len=t["len"], flat=t["flat"], seg0=t["seg0"],
                              ws=torch.zeros((ws_bytes,), dtype=torch.uint8, device=dev), n=0, synced=True)
 
     def _sync_steps(self, g):

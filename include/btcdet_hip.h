@@ -276,6 +276,10 @@ int btc_conv_wgrad_ordered(int bf16_act, const void* feat, const void* dout, con
  * after the call. */
 #define BTC_ADAM_MAX_SEGMENTS 448
 size_t btc_adam_group_ws_bytes(int n_chunks);
+/* flat[chunk_flat[c] + e] = grads[s][chunk_off[c] + e]: packs a list of gradients into a flat bucket (the buffer a
+ * data-parallel all-reduce runs on) in one launch; same chunk tables as btc_adam_group_step */
+int btc_grads_pack(const float* const* grads, int n_seg, const int32_t* chunk_seg, const int32_t* chunk_off,
+                   const int32_t* chunk_len, const int64_t* chunk_flat, const int32_t* seg_chunk0, float* flat, void* stream);
 int btc_adam_group_step(const float* const* grads, int n_seg, const int32_t* chunk_seg, const int32_t* chunk_off,
                         const int32_t* chunk_len, const int64_t* chunk_flat, const int32_t* seg_chunk0, int n_chunks,
                         float* params, float* exp_avg, float* exp_avg_sq, long long step, float lr, float beta1, float beta2,

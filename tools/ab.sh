@@ -2,14 +2,13 @@
 # back-to-back A/B bench lines in one box (value, p10 / median / p90 step ms); edit the run lines for the knobs under test
 run() { # name, env assignments...
   name=$1; shift
-  env "$@" python bench.py --steps 150 --warmup 20 --no-cpu-baseline --no-roofline $EXTRA 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$name', d['value'], d['step_ms']['p10'], d['step_ms']['median'], d['step_ms']['p90'])"
+  env "$@" python bench.py --steps 150 --warmup 20 --no-cpu-baseline --no-roofline $EXTRA 2>/dev/null | grep '^{"metric' | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$name', d['value'], d['step_ms']['p10'], d['step_ms']['median'], d['step_ms']['p90'])"
 }
+D="BTC_BENCH_FORCE_DIST=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29512 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0"
 for rep in 1 2 3; do
-run "one-launch BN " X=1
-run "two-launch BN " BTC_TUNE=12=1
+run "single process      " X=1
+run "dist world 1        " $D
+run "dist, foreach pack  " $D BTC_SYNC_PACK=0
+run "dist, dry-run comm  " $D BTC_SYNC_DRYRUN=1
 done
-EXTRA="--features bf16"
-for rep in 1 2; do
-run "bf16 one-launch" X=1
-run "bf16 two-launch" BTC_TUNE=12=1
-done
+env $D BTC_SYNC_TIMING=1 python bench.py --steps 100 --warmup 20 --no-cpu-baseline --no-roofline 2>&1 | grep "grad_sync host"
