@@ -268,6 +268,34 @@ def test_wgrad_row_stationary_kernel(cin, cout, kind):
     assert np.abs(w.grad.cpu().numpy() - ref).max() <= 1e-4 * (np.abs(ref).max() + 1e-6)
 
 
+@pytest.mark.parametrize("cin,cout,full_ph", [(16, 16, 4), (32, 16, 8), (16, 32, 4), (32, 32, 8), (48, 32, 4), (32, 64, 4), (64, 32, 8), (64, 64, 4)])
+def test_wgrad_pipelined_kernel_both_phase_counts(cin, cout, full_ph):
+    """conv_wgrad_rows_p has two instances per tile shape (PH and PH / 2 phases per offset group; the plan takes the smaller one when
+    there are few row tiles): both against the oracle, and against each other up to fp32 summation order"""
+    from btcdet_amd._lib import lib
+    from btcdet_amd.spconv import ops
+    rng = np.random.default_rng(cin * 7 + cout)
+    shape, B = (12, 48, 44), 2
+    idx = rand_indices(rng, 9000, B, shape)
+    (o_idx, o_out, o_in, o_sh), rb = _rb_both(idx, B, shape, (3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 1, 1), "subm")
+    feat = rng.standard_normal((idx.shape[0], cin)).astype(np.float32)
+    W = (rng.standard_normal((3, 3, 3, cin, cout)) / np.sqrt(cin)).astype(np.float32)
+    dout = rng.standard_normal((o_idx.shape[0], cout)).astype(np.float32)
+    ref = orc.conv_wgrad(feat, dout, o_out, W.shape)
+    got = []
+    for ph in (0, full_ph):
+        lib().btc_tune_set(5, ph)
+        try:
+            f = torch.from_numpy(feat).to(dev())
+            w = torch.from_numpy(W).to(dev()).requires_grad_(True)
+            ops.indice_conv(f, w, None, rb).backward(torch.from_numpy(dout).to(dev()))
+            got.append(w.grad.cpu().numpy())
+        finally:
+            lib().btc_tune_set(5, 0)
+        assert np.abs(got[-1] - ref).max() <= 1e-4 * (np.abs(ref).max() + 1e-6)
+    assert np.abs(got[0] - got[1]).max() <= 2e-6 * np.abs(ref).max()
+
+
 @pytest.mark.parametrize("cin,cout", [(32, 32), (64, 32), (16, 32), (32, 3)])
 def test_wgrad_walks_smaller_side_for_transposed_conv(cin, cout):
     """transposed conv with n_out > 2 n_in: btc_conv_wgrad walks nbr_in (swap path of conv_wgrad_rows)"""
