@@ -7,8 +7,8 @@ run() { # name, env assignments...
 D="BTC_BENCH_FORCE_DIST=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29512 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0"
 for rep in 1 2 3; do
 run "single process      " X=1
-run "dist world 1        " $D
-run "dist, foreach pack  " $D BTC_SYNC_PACK=0
-run "dist, dry-run comm  " $D BTC_SYNC_DRYRUN=1
+run "dist split (default)" $D
+run "dist one bucket     " $D BTC_SYNC_BUCKETS=one
+run "dist two, no split  " $D BTC_SYNC_BUCKETS=two
+run "dist one, dry-run   " $D BTC_SYNC_BUCKETS=one BTC_SYNC_DRYRUN=1
 done
-env $D BTC_SYNC_TIMING=1 python bench.py --steps 100 --warmup 20 --no-cpu-baseline --no-roofline 2>&1 | grep "grad_sync host"
