@@ -187,7 +187,9 @@ std::atomic<bool> g_defer_join{false};
 
 SideStream& side_of(int device) {
   static SideStream tab[64];
+  static std::mutex mu;
   SideStream& s = tab[device & 63];
+  std::lock_guard<std::mutex> lock(mu);
   if (!s.side) {
     static std::vector<c10::hip::HIPStream> keep;  // keeps the pooled stream objects alive
     keep.reserve(64);
@@ -373,25 +375,32 @@ inline int64_t current_stream() { return reinterpret_cast<int64_t>(c10::hip::get
 // ---- strided / transposed rulebook in two halves (ops.py LOOKAHEAD): the count half runs on a side stream as soon as the
 // input level exists and writes n_out straight into pinned host memory; the fill half runs in the consumer's forward and
 // waits -- on the host -- for the count's event only, never for the main stream.
+// (BtcHotPath.prepare may run on a worker thread while the training thread is in forward: slots are handed out atomically, every
+// slot has its own fork / done events, and the per-device state is created under a mutex)
 struct RbLookahead {
   hipStream_t side = nullptr;
-  hipEvent_t fork = nullptr;
+  hipEvent_t fork[64] = {};
   hipEvent_t done[64] = {};
   int32_t* host_n = nullptr;  // 64 pinned ints, device-visible
-  int next = 0;
+  std::atomic<unsigned> next{0};
 };
 
 RbLookahead& rb_of(int device) {
   static RbLookahead tab[64];
+  static std::mutex mu;
   RbLookahead& r = tab[device & 63];
+  std::lock_guard<std::mutex> lock(mu);
   if (!r.side) {
     static std::vector<c10::hip::HIPStream> keep;
+    keep.reserve(64);
     keep.push_back(c10::hip::getStreamFromPool(false, (c10::DeviceIndex)device));
-    r.side = keep.back().stream();
-    bool ok = hipEventCreateWithFlags(&r.fork, hipEventDisableTiming) == hipSuccess &&
-              hipHostMalloc((void**)&r.host_n, 64 * sizeof(int32_t), hipHostMallocDefault) == hipSuccess;
-    for (int i = 0; ok && i < 64; ++i) ok = hipEventCreateWithFlags(&r.done[i], hipEventDisableTiming) == hipSuccess;
+    hipStream_t side = keep.back().stream();
+    bool ok = hipHostMalloc((void**)&r.host_n, 64 * sizeof(int32_t), hipHostMallocDefault) == hipSuccess;
+    for (int i = 0; ok && i < 64; ++i)
+      ok = hipEventCreateWithFlags(&r.done[i], hipEventDisableTiming) == hipSuccess &&
+           hipEventCreateWithFlags(&r.fork[i], hipEventDisableTiming) == hipSuccess;
     if (!ok) throw std::runtime_error("rulebook lookahead: event / pinned-memory setup failed");
+    r.side = side;
   }
   return r;
 }
@@ -409,15 +418,14 @@ std::shared_ptr<PendingRb> rulebook_conv_start(const Tensor& indices, int64_t ba
   p->indices = indices; p->batch = batch; p->p_in = p_in; p->p_out = p_out; p->p_k = p_k; p->p_s = p_s; p->p_p = p_p; p->p_d = p_d;
   p->mode = mode; p->K = K; p->ws_bytes = ws_bytes;
   RbLookahead& r = rb_of(indices.get_device());
-  const int slot = r.next;
-  r.next = (r.next + 1) & 63;
+  const int slot = (int)(r.next.fetch_add(1) & 63u);
   p->done = r.done[slot];
   p->host_n = r.host_n + slot;
   p->ws = at::empty({ws_bytes > 256 ? ws_bytes : 256}, indices.options().dtype(at::kByte));
   hipStream_t main = (hipStream_t)st(current_stream());
   // fork after the allocation: the side stream is ordered behind every earlier user of that block and behind the kernels
   // that produce `indices`
-  if (hipEventRecord(r.fork, main) != hipSuccess || hipStreamWaitEvent(r.side, r.fork, 0) != hipSuccess)
+  if (hipEventRecord(r.fork[slot], main) != hipSuccess || hipStreamWaitEvent(r.side, r.fork[slot], 0) != hipSuccess)
     throw std::runtime_error("rulebook lookahead: fork failed");
   chk(btc_rulebook_conv_count((const int32_t*)indices.data_ptr(), (int)indices.size(0), (int)batch, ip(p_in), ip(p_out), ip(p_k), ip(p_s),
                               ip(p_p), ip(p_d), (int)mode, (int32_t*)p->host_n, p->ws.data_ptr(), (size_t)ws_bytes, (void*)r.side),

@@ -7,6 +7,7 @@ spconv_backbone.py:12-29).  The rulebook is kept as two dense neighbour maps (se
 include/btcdet_hip.h); ``Rulebook.indice_pairs()`` gives spconv's (2,K,N)/(K,) view on demand.
 """
 import os
+import threading
 
 import numpy as np
 import torch
@@ -345,14 +346,19 @@ def _rb_stream(device):
     return st
 
 
+_PIN_LOCK = threading.Lock()
+
+
 def _pinned_slot():
-    """one int32 of pinned host memory from a small ring (a slot is reused 256 read-backs later)"""
-    ring = _PIN.get("ring")
-    if ring is None:
-        ring = _PIN["ring"] = torch.zeros((256,), dtype=torch.int32).pin_memory()
-        _PIN["next"] = 0
-    i = _PIN["next"]
-    _PIN["next"] = (i + 1) % 256
+    """one int32 of pinned host memory from a small ring (a slot is reused 256 read-backs later); prepare() may run on a worker
+    thread beside the training thread, so slots are handed out under a lock"""
+    with _PIN_LOCK:
+        ring = _PIN.get("ring")
+        if ring is None:
+            ring = _PIN["ring"] = torch.zeros((256,), dtype=torch.int32).pin_memory()
+            _PIN["next"] = 0
+        i = _PIN["next"]
+        _PIN["next"] = (i + 1) % 256
     return ring[i:i + 1]
 
 
