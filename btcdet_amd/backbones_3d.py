@@ -192,6 +192,7 @@ class VoxelBackBoneDeconv(nn.Module):
 
 
 DET_GEOMETRY_WALK = os.environ.get("BTC_DET_GEOMETRY_WALK", "1") != "0"  # VoxelBackBone8xOcc._walk_geometry
+DET_WALK_ASYNC = os.environ.get("BTC_DET_WALK_ASYNC", "1") != "0"        # ... with the strided levels built on a side stream beside conv1
 
 
 class VoxelBackBone8xOcc(nn.Module):
@@ -265,8 +266,25 @@ class VoxelBackBone8xOcc(nn.Module):
             if getattr(self, "squeezeBev", None) is not None:
                 stages.append(self.squeezeBev)
             plan = plans[int(bs)] = GeometryPlan(flatten_convs(*stages), self.sparse_shape, bs)
+        if DET_WALK_ASYNC and sp_ops.PROFILE is None and plan.entries[0][0] == 0:
+            # The first stage (conv1, conv1_combine) only needs the level-0 submanifold rulebook, which needs no read-back: build it
+            # alone, fork the rest of the walk (the strided levels and the read-back of their row counts) onto a side stream, and
+            # let the caller run the first stage before it joins (forward -> _finish_walk).  The walk's ~0.3 ms of kernels and its
+            # read-back bubble then sit beside the first stage's launches instead of in front of them.
+            conv0 = plan.convs[0]
+            rb0 = sp_ops.build_rulebook_g(coords, bs, conv0._geometry(self.sparse_shape))
+            if conv0.indice_key is not None:
+                indice_dict[conv0.indice_key] = rb0
+            indice_dict.setdefault("__geometry_cache__", {})[conv0._gkey(coords, self.sparse_shape)] = (rb0, coords)
+            return (plan, plan.start(coords), {0: rb0}, coords)
         plan.run(coords, indice_dict)
         return True
+
+    @staticmethod
+    def _finish_walk(walk, indice_dict):
+        if isinstance(walk, tuple):
+            plan, handle, have, coords = walk
+            plan.finish(handle, coords, indice_dict, have)
 
     def _build_occ_net(self, kind, i):
         """occupancy-code side branch at level i (1..3): maxpool / learned / fixed-mean / avg (spconv_backbone.py:793-866)"""
@@ -348,7 +366,8 @@ class VoxelBackBone8xOcc(nn.Module):
             feats = feats.to(self.feature_dtype)
         bs = batch_dict['batch_size']
         x = spconv.SparseConvTensor(features=feats, indices=coords, spatial_shape=self.sparse_shape, batch_size=bs)
-        if not self._walk_geometry(coords, bs, x.indice_dict) and self._first_strided is not None:
+        walk = self._walk_geometry(coords, bs, x.indice_dict)
+        if not walk and self._first_strided is not None:
             # conv2's row count runs beside conv1 (rulebook lookahead, spconv/ops.py)
             self._first_strided.prefetch(coords, self.sparse_shape, bs, x.indice_dict)
         n_occ = len(self.occ_conv_exec)
@@ -364,6 +383,7 @@ class VoxelBackBone8xOcc(nn.Module):
                 if self.out_att[0]:
                     x1 = self.apply_att(x1, self.att_conv1)
         x1 = self.conv1_combine(x1)
+        self._finish_walk(walk, x.indice_dict)   # the strided levels' rulebooks, built beside the first stage
         levels = [x1]
         cur = x1
         for lvl in (1, 2, 3):

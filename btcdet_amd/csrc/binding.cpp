@@ -530,21 +530,69 @@ Tensor conv_bn_relu(const Tensor& features, const Tensor& weight, const OptTenso
 // Two phases of the C ABI around ONE read-back for the whole chain (btc_chain_levels / btc_chain_maps, csrc/rulebook.hip): the
 // levels are built on the device with their row counts left there and their rows written into capacity-sized buffers (16
 // bytes a row -- HBM is 288 GB, the untouched tail costs nothing); the counts come back together; the maps are sized exactly.
-std::vector<std::vector<Tensor>> geometry_walk(const Tensor& indices, int64_t batch, const std::vector<int64_t>& kind,
-                                               const std::vector<int64_t>& a_in, const std::vector<int64_t>& a_out,
-                                               const std::vector<int64_t>& a_k, const std::vector<int64_t>& a_s,
-                                               const std::vector<int64_t>& a_p, const std::vector<int64_t>& a_d,
-                                               const std::vector<int64_t>& mode, const std::vector<int64_t>& K,
-                                               const std::vector<int64_t>& ws_bytes, const std::vector<int64_t>& ref) {
+// The walk in two halves.  start: phase A (the levels) and the read-back of the row counts, either on the current stream with
+// a blocking read-back, or -- `side` -- forked onto a side stream with the counts copied into pinned host memory, so that the
+// caller can keep launching on its own stream (the detection backbone runs its first stage, which only needs the level-0
+// submanifold rulebook, while the strided levels are being built).  finish: waits for the counts (host + current stream), sizes
+// the maps exactly and runs phase B (every map of the chain in one multi-job launch) and the row-order launch on the current
+// stream.  skip_maps: built submanifold layers whose maps the caller already has (no buffers, no fill job, an empty list back).
+struct WalkSide {
+  hipStream_t side = nullptr;
+  c10::hip::HIPStream* c10side = nullptr;
+  hipEvent_t fork[8] = {}, done[8] = {};
+  int32_t* host_counts = nullptr;   // 8 slots x BTC_CHAIN_MAX_LAYERS pinned ints
+  std::atomic<unsigned> next{0};
+};
+
+WalkSide& walk_of(int device) {
+  static WalkSide tab[64];
+  static std::mutex mu;
+  WalkSide& w = tab[device & 63];
+  std::lock_guard<std::mutex> lock(mu);
+  if (!w.side) {
+    static std::vector<c10::hip::HIPStream> keep;
+    keep.reserve(64);
+    keep.push_back(c10::hip::getStreamFromPool(false, (c10::DeviceIndex)device));
+    bool ok = hipHostMalloc((void**)&w.host_counts, 8 * BTC_CHAIN_MAX_LAYERS * sizeof(int32_t), hipHostMallocDefault) == hipSuccess;
+    for (int i = 0; ok && i < 8; ++i)
+      ok = hipEventCreateWithFlags(&w.fork[i], hipEventDisableTiming) == hipSuccess &&
+           hipEventCreateWithFlags(&w.done[i], hipEventDisableTiming) == hipSuccess;
+    if (!ok) throw std::runtime_error("geometry walk: event / pinned-memory setup failed");
+    w.c10side = &keep.back();
+    w.side = keep.back().stream();
+  }
+  return w;
+}
+
+struct PendingWalk {
+  Tensor indices, ws, d_counts, h_counts;
+  std::vector<Tensor> out_idx;
+  std::vector<BtcChainLayer> layers;
+  std::vector<int64_t> kind, K, ref;
+  size_t wsb = 0;
+  int n0 = 0;
+  int64_t batch = 0;
+  bool side = false;
+  hipEvent_t done = nullptr;
+  const int32_t* counts = nullptr;   // host: valid after the wait in finish
+};
+
+std::shared_ptr<PendingWalk> geometry_walk_start(const Tensor& indices, int64_t batch, const std::vector<int64_t>& kind,
+                                                 const std::vector<int64_t>& a_in, const std::vector<int64_t>& a_out,
+                                                 const std::vector<int64_t>& a_k, const std::vector<int64_t>& a_s,
+                                                 const std::vector<int64_t>& a_p, const std::vector<int64_t>& a_d,
+                                                 const std::vector<int64_t>& mode, const std::vector<int64_t>& K,
+                                                 const std::vector<int64_t>& ws_bytes, const std::vector<int64_t>& ref, bool side) {
   const size_t n = kind.size();
   need(a_in.size() == n && a_out.size() == n && a_k.size() == n && a_s.size() == n && a_p.size() == n && a_d.size() == n && mode.size() == n &&
            K.size() == n && ws_bytes.size() == n && ref.size() == n, "geometry_walk: per-layer argument lists differ in length");
   need(n >= 1 && n <= BTC_CHAIN_MAX_LAYERS, "geometry_walk: too many layers for one chain");
-  const int64_t stream = current_stream();
-  const int n0 = (int)indices.size(0);
-  std::vector<BtcChainLayer> layers(n);
+  auto p = std::make_shared<PendingWalk>();
+  p->indices = indices; p->batch = batch; p->kind = kind; p->K = K; p->ref = ref; p->side = side;
+  p->n0 = (int)indices.size(0);
+  p->layers.resize(n);
   for (size_t i = 0; i < n; ++i) {
-    BtcChainLayer& l = layers[i];
+    BtcChainLayer& l = p->layers[i];
     l.kind = (int32_t)kind[i];
     l.ref = (int32_t)ref[i];
     l.mode = (int32_t)mode[i];
@@ -559,33 +607,80 @@ std::vector<std::vector<Tensor>> geometry_walk(const Tensor& indices, int64_t ba
     }
   }
   std::vector<int64_t> cap(n, 0);
-  chk(btc_chain_caps(layers.data(), (int)n, (int)batch, n0, cap.data()), "btc_chain_caps");
-  const size_t wsb = btc_chain_ws_bytes(layers.data(), (int)n, (int)batch, n0);
-  need(wsb > 0, "geometry_walk: btc_chain_ws_bytes failed");
-  Tensor ws = at::empty({(int64_t)wsb}, indices.options().dtype(at::kByte));
-  Tensor d_counts = at::zeros({(int64_t)n}, indices.options());
-  std::vector<Tensor> out_idx(n);
-  std::vector<int32_t*> p_out_idx(n, nullptr), p_nbr_out(n, nullptr), p_nbr_in(n, nullptr);
+  chk(btc_chain_caps(p->layers.data(), (int)n, (int)batch, p->n0, cap.data()), "btc_chain_caps");
+  p->wsb = btc_chain_ws_bytes(p->layers.data(), (int)n, (int)batch, p->n0);
+  need(p->wsb > 0, "geometry_walk: btc_chain_ws_bytes failed");
+  p->ws = at::empty({(int64_t)p->wsb}, indices.options().dtype(at::kByte));
+  p->d_counts = at::zeros({(int64_t)n}, indices.options());
+  p->out_idx.resize(n);
+  std::vector<int32_t*> p_out_idx(n, nullptr);
   for (size_t i = 0; i < n; ++i)
     if (kind[i] == 1) {
-      out_idx[i] = at::empty({cap[i], 4}, indices.options());
-      p_out_idx[i] = (int32_t*)out_idx[i].data_ptr();
+      p->out_idx[i] = at::empty({cap[i], 4}, indices.options());
+      p_out_idx[i] = (int32_t*)p->out_idx[i].data_ptr();
     }
-  chk(btc_chain_levels((const int32_t*)indices.data_ptr(), n0, (int)batch, layers.data(), (int)n, p_out_idx.data(), cap.data(),
-                       (int32_t*)d_counts.data_ptr(), ws.data_ptr(), wsb, st(stream)), "btc_chain_levels");
-  Tensor h_counts = d_counts.to(at::kCPU);  // the one read-back of the chain (current stream only)
-  const int32_t* hc = (const int32_t*)h_counts.data_ptr();
+  hipStream_t main = (hipStream_t)st(current_stream());
+  hipStream_t run = main;
+  WalkSide* w = nullptr;
+  int slot = 0;
+  if (side) {
+    w = &walk_of(indices.get_device());
+    slot = (int)(w->next.fetch_add(1) & 7u);
+    run = w->side;
+    // fork after the allocations and the zero fill of d_counts: the side stream is ordered behind them and behind `indices`
+    if (hipEventRecord(w->fork[slot], main) != hipSuccess || hipStreamWaitEvent(run, w->fork[slot], 0) != hipSuccess)
+      throw std::runtime_error("geometry walk: fork failed");
+    for (const Tensor* t : {&p->ws, &p->d_counts, &p->indices}) c10::hip::HIPCachingAllocator::recordStream(t->storage().data_ptr(), *w->c10side);
+    for (const Tensor& t : p->out_idx)
+      if (t.defined()) c10::hip::HIPCachingAllocator::recordStream(t.storage().data_ptr(), *w->c10side);
+  }
+  chk(btc_chain_levels((const int32_t*)indices.data_ptr(), p->n0, (int)batch, p->layers.data(), (int)n, p_out_idx.data(), cap.data(),
+                       (int32_t*)p->d_counts.data_ptr(), p->ws.data_ptr(), p->wsb, (void*)run), "btc_chain_levels");
+  if (side) {
+    int32_t* host = w->host_counts + slot * BTC_CHAIN_MAX_LAYERS;
+    if (hipMemcpyAsync(host, p->d_counts.data_ptr(), n * sizeof(int32_t), hipMemcpyDeviceToHost, run) != hipSuccess ||
+        hipEventRecord(w->done[slot], run) != hipSuccess)
+      throw std::runtime_error("geometry walk: read-back enqueue failed");
+    p->done = w->done[slot];
+    p->counts = host;
+  } else {
+    p->h_counts = p->d_counts.to(at::kCPU);  // the one read-back of the chain (current stream only)
+    p->counts = (const int32_t*)p->h_counts.data_ptr();
+  }
+  dbg_sync("geometry_walk_start");
+  return p;
+}
+
+std::vector<std::vector<Tensor>> geometry_walk_finish(const std::shared_ptr<PendingWalk>& p, const std::vector<int64_t>& skip_maps) {
+  const size_t n = p->kind.size();
+  const std::vector<int64_t>&kind = p->kind, &K = p->K, &ref = p->ref;
+  const Tensor& indices = p->indices;
+  const int64_t stream = current_stream();
+  if (p->side) {
+    if (hipEventSynchronize(p->done) != hipSuccess || hipStreamWaitEvent((hipStream_t)st(stream), p->done, 0) != hipSuccess)
+      throw std::runtime_error("geometry walk: join failed");
+  }
+  int32_t hc_copy[BTC_CHAIN_MAX_LAYERS];
+  for (size_t i = 0; i < n; ++i) hc_copy[i] = p->counts[i];   // the pinned slot is recycled 8 walks later
+  const int32_t* hc = hc_copy;
+  std::vector<char> skip(n, 0);
+  for (int64_t i : skip_maps) {
+    need(i >= 0 && (size_t)i < n && kind[i] == 0, "geometry_walk: only built submanifold layers can skip their maps");
+    skip[i] = 1;
+  }
   // levels as the walk sees them
   std::vector<Tensor> level_in(n), level_out(n);
+  std::vector<int32_t*> p_out_idx(n, nullptr), p_nbr_out(n, nullptr), p_nbr_in(n, nullptr);
   Tensor cur = indices;
   int64_t strided_elems = 0, other_elems = 0;
   for (size_t i = 0; i < n; ++i) {
     if (kind[i] == 0) {
       level_in[i] = level_out[i] = cur;
-      other_elems += 2 * cur.size(0) * K[i];
+      if (!skip[i]) other_elems += 2 * cur.size(0) * K[i];
     } else if (kind[i] == 1) {
       level_in[i] = cur;
-      cur = out_idx[i].narrow(0, 0, hc[i]);
+      p_out_idx[i] = (int32_t*)p->out_idx[i].data_ptr();
+      cur = p->out_idx[i].narrow(0, 0, hc[i]);
       level_out[i] = cur;
       strided_elems += (int64_t)hc[i] * K[i];
       other_elems += level_in[i].size(0) * K[i];
@@ -602,7 +697,7 @@ std::vector<std::vector<Tensor>> geometry_walk(const Tensor& indices, int64_t ba
   int64_t off_s = 0, off_o = 0;
   std::vector<std::vector<Tensor>> out(n);
   for (size_t i = 0; i < n; ++i) {
-    if (kind[i] > 1) continue;
+    if (kind[i] > 1 || skip[i]) continue;
     const int64_t rows_in = level_in[i].size(0), rows_out = level_out[i].size(0);
     Tensor nbr_out, nbr_in;
     if (kind[i] == 1) {
@@ -618,13 +713,15 @@ std::vector<std::vector<Tensor>> geometry_walk(const Tensor& indices, int64_t ba
     p_nbr_in[i] = (int32_t*)nbr_in.data_ptr();
     out[i] = {level_in[i], level_out[i], nbr_out, nbr_in};
   }
-  chk(btc_chain_maps((const int32_t*)indices.data_ptr(), n0, (int)batch, layers.data(), (int)n, hc, p_out_idx.data(), p_nbr_out.data(),
-                     p_nbr_in.data(), ws.data_ptr(), wsb, st(stream)), "btc_chain_maps");
+  chk(btc_chain_maps((const int32_t*)indices.data_ptr(), p->n0, (int)p->batch, p->layers.data(), (int)n, hc, p_out_idx.data(), p_nbr_out.data(),
+                     p_nbr_in.data(), p->ws.data_ptr(), p->wsb, st(stream)), "btc_chain_maps");
   // row-order hints of the strided / transposed layers' maps (both directions), one launch for the chain: these are the maps
   // whose 16-row tiles are mostly empty in coordinate order (csrc/row_order.hip).  BTC_ROW_ORDER=2 orders the SubM maps too
   // (measured: within noise at KITTI sizes), 0 none.
   static const int order_mode = getenv("BTC_ROW_ORDER") ? atoi(getenv("BTC_ROW_ORDER")) : 1;
-  auto wants_order = [&](size_t i) { return K[i] <= 64 && ((kind[i] == 1 && order_mode >= 1) || (kind[i] == 0 && order_mode >= 2)); };
+  auto wants_order = [&](size_t i) {
+    return !skip[i] && K[i] <= 64 && ((kind[i] == 1 && order_mode >= 1) || (kind[i] == 0 && order_mode >= 2));
+  };
   std::vector<Tensor> to_order;
   for (size_t i = 0; i < n; ++i)
     if (wants_order(i)) {
@@ -642,6 +739,15 @@ std::vector<std::vector<Tensor>> geometry_walk(const Tensor& indices, int64_t ba
   }
   dbg_sync("geometry_walk");
   return out;
+}
+
+std::vector<std::vector<Tensor>> geometry_walk(const Tensor& indices, int64_t batch, const std::vector<int64_t>& kind,
+                                               const std::vector<int64_t>& a_in, const std::vector<int64_t>& a_out,
+                                               const std::vector<int64_t>& a_k, const std::vector<int64_t>& a_s,
+                                               const std::vector<int64_t>& a_p, const std::vector<int64_t>& a_d,
+                                               const std::vector<int64_t>& mode, const std::vector<int64_t>& K,
+                                               const std::vector<int64_t>& ws_bytes, const std::vector<int64_t>& ref) {
+  return geometry_walk_finish(geometry_walk_start(indices, batch, kind, a_in, a_out, a_k, a_s, a_p, a_d, mode, K, ws_bytes, ref, false), {});
 }
 
 // a SparseSequential of conv -> BatchNorm -> ReLU layers whose rulebooks all exist already (the occupancy branch after
@@ -724,6 +830,9 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("conv_bn_relu", &conv_bn_relu, py::call_guard<py::gil_scoped_release>());
   m.def("row_orders", &row_orders, py::call_guard<py::gil_scoped_release>());
   m.def("geometry_walk", &geometry_walk, py::call_guard<py::gil_scoped_release>());
+  py::class_<PendingWalk, std::shared_ptr<PendingWalk>>(m, "PendingWalk");
+  m.def("geometry_walk_start", &geometry_walk_start, py::call_guard<py::gil_scoped_release>());
+  m.def("geometry_walk_finish", &geometry_walk_finish, py::call_guard<py::gil_scoped_release>());
   m.def("conv_bn_relu_chain", &conv_bn_relu_chain, py::call_guard<py::gil_scoped_release>());
   m.def("pack_grads", &pack_grads, py::call_guard<py::gil_scoped_release>());
   m.def("adam_group_step", &adam_group_step, py::call_guard<py::gil_scoped_release>());

@@ -808,6 +808,7 @@ extern "C" int btc_chain_maps(const int32_t* indices, int n0, int batch, const B
   };
   for (int i = 0; i < n_layers; ++i) {
     if (layers[i].kind > 1) continue;
+    if (layers[i].kind == 0 && !nbr_out[i] && !nbr_in[i]) continue;   // the caller has this submanifold layer's maps already
     const int li = P.lvl_in[i];
     const int n = rows_of[li];
     if (n <= 0) continue;

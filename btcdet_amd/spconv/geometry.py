@@ -70,6 +70,18 @@ class GeometryPlan(object):
                      [ops._conv_ws_bytes(x[2], self.batch_size) if (x[2] is not None and not x[2].subm) else 0 for x in e],
                      [x[1] for x in e])
 
+    def start(self, indices):
+        """phase A of the walk (the levels + the read-back of their row counts) forked onto a side stream; finish() joins it.
+        Whatever runs on the current stream in between overlaps with it."""
+        return ops.fast().geometry_walk_start(indices, self.batch_size, *self.args, True)
+
+    def finish(self, handle, indices, indice_dict, have=None):
+        """join start(): size and fill the maps on the current stream and file the rulebooks as run() does.  have: {layer
+        index: Rulebook} for built submanifold layers whose rulebook the caller made itself (their maps are not built again)."""
+        have = have or {}
+        built = ops.fast().geometry_walk_finish(handle, sorted(have))
+        return self._file(built, indices, indice_dict, have)
+
     def run(self, indices, indice_dict):
         """build every rulebook of the plan for `indices` and file them in indice_dict (by indice_key) and in its geometry cache"""
         F = ops.fast()
@@ -90,10 +102,16 @@ class GeometryPlan(object):
                     pairs += p_k
                     n_rb += 1
             prof.records.append(("rulebook", e0, e1, nbytes, 0, dict(rows=rows, pairs=pairs, rulebooks=n_rb, chain=True)))
+        return self._file(built, indices, indice_dict, {})
+
+    def _file(self, built, indices, indice_dict, have):
         geom = indice_dict.setdefault("__geometry_cache__", {})
         rbs = [None] * len(self.convs)
         for i, (conv, (kind, ref, g, in_shape, out_shape)) in enumerate(zip(self.convs, self.entries)):
-            if kind < 2:
+            if i in have:
+                rb = rbs[i] = have[i]
+                geom[conv._gkey(rb.in_indices, in_shape)] = (rb, rb.in_indices)
+            elif kind < 2:
                 in_idx, out_idx, nbr_out, nbr_in = built[i][:4]
                 o_out, o_in = (built[i][4], built[i][5]) if (len(built[i]) > 4 and ops.ROW_ORDER) else (None, None)
                 rb = rbs[i] = ops.Rulebook(out_idx, in_idx, nbr_out, nbr_in, g.in_list, g.out_list, g.K, g.mode, o_out, o_in)

@@ -168,7 +168,9 @@ int btc_rulebook_conv_fill(const int32_t* indices, int n, int batch, const int32
  *   -- the caller copies d_counts (n_layers int32) to the host and sizes the maps --
  *   phase B  btc_chain_maps   : nbr_out[i] (rows_out_i, K_i) and nbr_in[i] (rows_in_i, K_i) of every kind-0 / kind-1 layer in
  *            one multi-job launch (+ the -1 fill of the strided layers' nbr_out: hand in adjacent buffers to make it one).
- * ws (btc_chain_ws_bytes) must be the same, untouched, for both phases. */
+ *            A kind-0 layer with nbr_out[i] == nbr_in[i] == NULL is skipped (the caller built that rulebook on its own).
+ * ws (btc_chain_ws_bytes) must be the same, untouched, for both phases; the phases may run on different streams as long
+ * as phase B is ordered behind phase A (the detection backbone runs phase A on a side stream beside its first stage). */
 #define BTC_CHAIN_MAX_LAYERS 32
 typedef struct BtcChainLayer {
   int32_t kind, ref, mode;

@@ -4,11 +4,12 @@ run() { # name, env assignments...
   name=$1; shift
   env "$@" python bench.py --steps 150 --warmup 20 --no-cpu-baseline --no-roofline $EXTRA 2>/dev/null | grep '^{"metric' | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$name', d['value'], d['step_ms']['p10'], d['step_ms']['median'], d['step_ms']['p90'])"
 }
-D="BTC_BENCH_FORCE_DIST=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29512 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0"
 for rep in 1 2 3; do
-run "single process      " X=1
-run "dist split (default)" $D
-run "dist one bucket     " $D BTC_SYNC_BUCKETS=one
-run "dist two, no split  " $D BTC_SYNC_BUCKETS=two
-run "dist one, dry-run   " $D BTC_SYNC_BUCKETS=one BTC_SYNC_DRYRUN=1
+run "walk beside conv1   " X=1
+run "walk in front       " BTC_DET_WALK_ASYNC=0
+done
+EXTRA="--features bf16"
+for rep in 1 2; do
+run "bf16 walk beside    " X=1
+run "bf16 walk in front  " BTC_DET_WALK_ASYNC=0
 done
