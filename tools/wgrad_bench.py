@@ -13,7 +13,12 @@ from btcdet_amd._lib import lib, ptr, check, stream_ptr
 from btcdet_amd.train_step import GroupOptimizer
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
-model = BtcHotPath(load_cfg(), device=dev).to(dev).train()
+cfg = load_cfg()
+BF = os.environ.get("BF") == "1"   # bf16 activations (bench.py --features bf16)
+if BF:
+    cfg.MODEL.OCC.BACKBONE_3D["FEATURE_DTYPE"] = "bf16"
+    cfg.MODEL.BACKBONE_3D["FEATURE_DTYPE"] = "bf16"
+model = BtcHotPath(cfg, device=dev).to(dev).train()
 opt = GroupOptimizer([dict(params=[p for p in model.parameters() if p.requires_grad], lr=1e-3)], 1000)
 batches = bench.build_batches(2, 0, dev)
 step = bench.make_step(model, model, model.dataset.data_processor, [opt])
@@ -39,14 +44,16 @@ for (f, w, b, mf, mb) in cap:
     cin, cout, K = w.shape[-2], w.shape[-1], mf.shape[1]
     n_res, n_src = mf.shape[0], mb.shape[0]
     pairs = int((mf >= 0).sum())
-    g = torch.randn((n_res, cout), device=dev)
+    g = torch.randn((n_res, cout), device=dev).to(f.dtype)
+    bf = f.dtype == torch.bfloat16
+    wg = L.btc_conv_wgrad_bf16 if bf else L.btc_conv_wgrad
     wsb = L.btc_conv_wgrad_ws_bytes(n_res, K, cin, cout, n_src)
     check(L.btc_tune_set(11, 1), "t")
     wsb = max(wsb, L.btc_conv_wgrad_ws_bytes(n_res, K, cin, cout, n_src))   # the two kernels split the rows differently
     check(L.btc_tune_set(11, 0), "t")
     ws = torch.empty((wsb,), dtype=torch.uint8, device=dev)
     dw = torch.empty_like(w)
-    fn = lambda: check(L.btc_conv_wgrad(ptr(f), ptr(g), ptr(mf), n_res, ptr(mb), n_src, K, cin, cout, ptr(dw), ptr(ws), wsb, stream_ptr()), "w")
+    fn = lambda: check(wg(ptr(f), ptr(g), ptr(mf), n_res, ptr(mb), n_src, K, cin, cout, ptr(dw), ptr(ws), wsb, stream_ptr()), "w")
     ts = [timed(fn)]
     ref = dw.clone()
     check(L.btc_tune_set(11, 1), "t")   # the two-barrier kernel, and its timing-only variants
@@ -58,7 +65,7 @@ for (f, w, b, mf, mb) in cap:
     check(L.btc_tune_set(3, 0), "t")
     check(L.btc_tune_set(11, 0), "t")
     tot += np.array(ts)
-    nbytes, flops = 4 * pairs * (cin + cout) + 4 * K * cin * cout, 2 * pairs * cin * cout
+    nbytes, flops = (2 if bf else 4) * pairs * (cin + cout) + 4 * K * cin * cout, 2 * pairs * cin * cout
     print("%7d %7d %3d %4d %4d %8d | %7.1f %6.0f %6.2f | %26.1f %8.1f %8.1f  %s" % (n_res, n_src, K, cin, cout, pairs, ts[0], nbytes / ts[0] / 1e3, flops / ts[0] / 1e6,
                                                                                  ts[1], ts[2], ts[3], same))
 print("totals us: %.0f; two-barrier kernel %.0f, no MFMA %.0f, no gathers %.0f" % tuple(tot))
