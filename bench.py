@@ -404,7 +404,18 @@ def main():
     # the next batch's weight-independent front runs on a high-priority side stream beside this batch's backward
     prefetch = torch.cuda.Stream(device=device, priority=-1) if os.environ.get("BTC_PREFETCH", "2") != "0" else None
     # the detection branch on its own stream, beside the occupancy branch's backward (make_step)
-    det_stream = torch.cuda.Stream(device=device) if (ddp is model and os.environ.get("BTC_SPLIT_BACKWARD", "0") == "1") else None
+    # Single process (default): the detection branch's forward runs on its own stream beside the occupancy branch's backward
+    # (make_step, det_stream; gradients equal the one-stream schedule's: tests/test_hip_prefetch.py).  Measured back to back:
+    # 353 -> 374 scenes/s fp32, 354 -> 412 bf16.  With a gradient reducer the detection bucket (90 % of the bytes) would only be
+    # complete at the very end of the step, its all-reduce exposed: 305-314 -> 280-284 at world size 1 over RCCL, so the
+    # distributed path keeps the split-backward schedule (BTC_SPLIT_BACKWARD=0/1 overrides either default).
+    split_default = "1" if (grad_sync is None and prefetch is not None) else "0"   # (BTC_PREFETCH=0 is the in-order, one-stream schedule)
+    det_stream = torch.cuda.Stream(device=device) if (ddp is model and os.environ.get("BTC_SPLIT_BACKWARD", split_default) == "1") else None
+    if det_stream is not None and "BTC_DET_WALK_ASYNC" not in os.environ:
+        # the detection branch's rulebook walk beside its first stage buys nothing once the whole branch runs beside the occupancy
+        # backward (377 vs 374 scenes/s without it): one stream less
+        import btcdet_amd.backbones_3d as _bb3d
+        _bb3d.DET_WALK_ASYNC = False
     # BTC_EARLY_OPT=1: the detection group's optimizer step beside the occupancy branch's backward (make_step; single process only
     # -- with a gradient reducer the detection bucket's all-reduce takes that slot).  Worth 1.7 % while a group's step was ~10
     # multi-tensor torch ops (333.8 -> 339.5 scenes/s); with the three-launch step of csrc/optim.hip there is nothing left to hide
@@ -475,9 +486,10 @@ def main():
                                    "HeightCompression (+L2 stand-in for the out-of-scope BEV heads), fwd+bwd + the reference's optimizer step per parameter group (norm clip 10, "
                                    "decoupled weight decay, Adam, OneCycle lr / beta1), " + ("fp32" if args.features == "fp32" else "bf16 features"),
                        "global_batch": bs * world, "parallelism": "dp%d" % world,
-                       "schedule": ("each step prepares the NEXT batch's weight-independent front (both voxelizations, occupancy targets, "
-                                    "occupancy-branch rulebooks) on a side stream beside its backward pass, one preparation per step; "
-                                    "weight gradients on a side stream, one join per backward" if prefetch is not None else "in order, one stream"),
+                       "schedule": (("each step prepares the NEXT batch's weight-independent front (both voxelizations, occupancy targets, "
+                                     "occupancy-branch rulebooks) on a side stream beside its backward pass, one preparation per step; "
+                                     "weight gradients on a side stream, one join per backward" if prefetch is not None else "in order, one stream")
+                                    + ("; the detection branch's forward on its own stream beside the occupancy branch's backward" if det_stream is not None else "")),
                        "grad_sync": ("DistributedDataParallel" if ddp is not model else
                                      (None if grad_sync is None else ("btcdet_amd.grad_sync: detection bucket all-reduced during the occupancy branch's backward, occupancy bucket after it"
                                                                      if getattr(grad_sync, "split_backward", False) else "btcdet_amd.grad_sync: flat bucket(s), all-reduce after backward"))),
