@@ -796,8 +796,27 @@ __global__ __launch_bounds__(256) void conv_wgrad_rows_p(const float* __restrict
       bnext[s2] = (gr >= 0 && bcol < Cout) ? btc_ld1<BF>(dout, (size_t)gr * Cout + bcol) : 0.f;
     }
   };
+  // bf16 activations with Cin % 8 == 0: 16-byte loads of 8 channels (half the load instructions of the 4-channel walk; the
+  // kernel is bound by issued instructions, not bytes), widened to fp32 on the way into LDS
+  constexpr int UPR8 = MT * 2;                             // 8-channel units per gathered row
+  constexpr int NU8 = BF ? (KB * TM * UPR8 + 255) / 256 : 1;   // units per thread and item
+  uint4 gq[NU8];
+  const bool wide = BF && (Cin & 7) == 0;
   auto load_g = [&](int i, int p) { // the gathered rows of phase p of tile i
     const int32_t* mp = s_nbr + (i % 3) * TM * NOFF + p * KB;
+    if (wide) {
+#pragma unroll
+      for (int u = 0; u < NU8; ++u) {
+        const int e = u * 256 + tid, c8 = e % UPR8, r = (e / UPR8) % TM, kb = e / (UPR8 * TM);
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (e < KB * TM * UPR8) {
+          const int j = mp[r * NOFF + kb];
+          if (j >= 0 && c8 * 8 < Cin) v = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(feat) + (size_t)j * Cin + c8 * 8);
+        }
+        gq[u] = v;
+      }
+      return;
+    }
 #pragma unroll
     for (int u = 0; u < KB * MT; ++u) {
       const int e = u * 256 + tid, c = (e % (MT * 4)) * 4, r = (e / (MT * 4)) % TM, kb = e / (MT * 4 * TM);
@@ -807,6 +826,22 @@ __global__ __launch_bounds__(256) void conv_wgrad_rows_p(const float* __restrict
   };
   auto store_g = [&](int buf) {
     float* A = As + buf * KB * TM * LDA;
+    if (wide) {
+#pragma unroll
+      for (int u = 0; u < NU8; ++u) {
+        const int e = u * 256 + tid, c8 = e % UPR8, r = (e / UPR8) % TM, kb = e / (UPR8 * TM);
+        if (e < KB * TM * UPR8) {
+          float* d = A + (kb * TM + r) * LDA + c8 * 8;
+          const unsigned w[4] = {gq[u].x, gq[u].y, gq[u].z, gq[u].w};
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            d[2 * q] = __uint_as_float(w[q] << 16);
+            d[2 * q + 1] = __uint_as_float(w[q] & 0xffff0000u);
+          }
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int u = 0; u < KB * MT; ++u) {
       const int e = u * 256 + tid, c = (e % (MT * 4)) * 4, r = (e / (MT * 4)) % TM, kb = e / (MT * 4 * TM);
