@@ -796,12 +796,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_rows_p(const float* __restrict
       bnext[s2] = (gr >= 0 && bcol < Cout) ? btc_ld1<BF>(dout, (size_t)gr * Cout + bcol) : 0.f;
     }
   };
-  // bf16 activations with Cin % 8 == 0: 16-byte loads of 8 channels (half the load instructions of the 4-channel walk; the
-  // kernel is bound by issued instructions, not bytes), widened to fp32 on the way into LDS
+  // bf16 activations (the launcher guarantees Cin % 8 == 0 for these instances): 16-byte loads of 8 channels -- half the load
+  // instructions of the 4-channel walk and half its staging registers (216 -> 152 VGPRs for the 64 x 64 shape: a third workgroup
+  // per CU) -- widened to fp32 on the way into LDS
   constexpr int UPR8 = MT * 2;                             // 8-channel units per gathered row
   constexpr int NU8 = BF ? (KB * TM * UPR8 + 255) / 256 : 1;   // units per thread and item
   uint4 gq[NU8];
-  const bool wide = BF && (Cin & 7) == 0;
+  constexpr bool wide = BF;
   auto load_g = [&](int i, int p) { // the gathered rows of phase p of tile i
     const int32_t* mp = s_nbr + (i % 3) * TM * NOFF + p * KB;
     if (wide) {
@@ -1109,7 +1110,7 @@ size_t wgrad_rows_lds(int mt, int nt, int kb, int ph_built, int K, bool pipe) {
   return (size_t)(kb * TM * ldb_of(mt) + TM * ldb_of(nt)) * sizeof(float) + (size_t)(TM * K + K + TM) * sizeof(int32_t);
 }
 
-WgradPlan wgrad_plan(int n_out, int K, int Cin, int Cout, int n_in = -1) {
+WgradPlan wgrad_plan(int n_out, int K, int Cin, int Cout, int n_in = -1, bool bf = false) {
   WgradPlan p;
   p.pipe = 0;
   p.lds = 0;
@@ -1135,7 +1136,7 @@ WgradPlan wgrad_plan(int n_out, int K, int Cin, int Cout, int n_in = -1) {
       const int t_ph = btc_tune_get(BTC_TUNE_WGRAD_PH), t_wgs = btc_tune_get(BTC_TUNE_WGRAD_WGS);
       // software-pipelined variant (conv_wgrad_rows_p) when the gathered operand's channel count is a multiple of 4; it has its
       // own (KB, PH) per tile shape (the B fragments live in registers: LDS holds the double-buffered gather tile only)
-      p.pipe = ((swap ? Cout : Cin) & 3) == 0 && btc_tune_get(BTC_TUNE_WGRAD_PIPE) != 1;
+      p.pipe = ((swap ? Cout : Cin) & (bf ? 7 : 3)) == 0 && btc_tune_get(BTC_TUNE_WGRAD_PIPE) != 1;   // bf16: 8-channel gathers
       const int wgs = t_wgs ? t_wgs : 512;
       const int n_tiles = btc_cdiv(rows, TM);
       if (p.pipe) {
@@ -1236,8 +1237,9 @@ extern "C" int btc_conv_apply_ordered(int pass, int operands, const void* src, c
 }
 
 extern "C" size_t btc_conv_wgrad_ws_bytes(int n_out, int K, int Cin, int Cout, int n_in) {
-  WgradPlan p = wgrad_plan(n_out, K, Cin, Cout, n_in);
-  return btc_align((size_t)p.S * K * Cin * Cout * sizeof(float));
+  // one size for both activation types (the bf16 instances of the pipelined kernel want Cin % 8 == 0, so the two plans can differ)
+  const WgradPlan p = wgrad_plan(n_out, K, Cin, Cout, n_in, false), q = wgrad_plan(n_out, K, Cin, Cout, n_in, true);
+  return btc_align((size_t)(p.S > q.S ? p.S : q.S) * K * Cin * Cout * sizeof(float));
 }
 
 template <bool BF>
@@ -1253,7 +1255,7 @@ static int wgrad_impl(const float* feat, const float* dout, const int32_t* nbr_o
     BTC_HIP(hipMemsetAsync(dW, 0, (size_t)count * sizeof(float), stream));
     return BTC_OK;
   }
-  WgradPlan p = wgrad_plan(n_out, K, Cin, Cout, n_in);
+  WgradPlan p = wgrad_plan(n_out, K, Cin, Cout, n_in, BF);
   float* part = (float*)ws;
   if (p.rows_kernel) {
     // operands of the walk: gathered rows (via the map) and contiguous rows, see conv_wgrad_rows
