@@ -144,7 +144,68 @@ def make_step(model, ddp, proc, opts, grad_sync=None, prefetch_stream=None, thre
         torch.cuda.set_device(device)
         loss.backward()
 
+    # pipelined variant of the det_stream schedule (single process): once the occupancy branch's backward has returned, the worker
+    # thread goes on -- the occupancy group's optimizer step (its gradients are complete), the next batch's weight-independent front
+    # on the prefetch stream and the next batch's OCCUPANCY FORWARD on the main stream with the updated occupancy weights -- while
+    # this thread runs the detection branch's backward and optimizer step on det_stream.  Nothing is skipped and nothing uses stale
+    # weights: the occupancy branch of step i + 1 needs the occupancy weights of step i (updated before it runs) and batch i + 1;
+    # the detection branch of step i + 1 starts behind step i's detection optimizer on det_stream.  Two backward passes never run at
+    # the same time (the weight-gradient side stream's join bookkeeping assumes one).
+    pipeline = (det_stream is not None and ddp is model and grad_sync is None and prefetch_stream is not None and threaded
+                and len(opts) == 1 and hasattr(opts[0], "groups") and len(opts[0].groups) == 2
+                and os.environ.get("BTC_PIPELINE_OCC", "1") != "0")
+    ahead_occ = {}
+
+    def occ_tail(loss_occ, next_batch, occ_done):
+        torch.cuda.set_device(device)
+        try:
+            loss_occ.backward()
+            _ops.join_wgrad()            # (no-op: the end-of-pass callback has joined the side stream into this thread's stream)
+        finally:
+            occ_done.set()
+        opts[0].step(groups=[0])         # occupancy group, on the main stream behind its backward
+        if next_batch is None:
+            return None
+        return occ_forward(model.prepare(next_batch, stream=prefetch_stream))
+
+    def occ_forward(bd):
+        out = model.forward_occ(bd)
+        done = torch.cuda.Event()
+        done.record()                    # the loss tensor is complete on this (the main) stream
+        return out + (done,)
+
+    def step_pipelined(batch, next_batch):
+        import threading
+        opts[0].zero_grad(set_to_none=True)
+        cur = ahead_occ.pop(id(batch), None)
+        ahead_occ.clear()
+        if cur is None:
+            bd = pending.pop(id(batch), None)
+            cur = occ_forward(bd if bd is not None else model.prepare(batch))
+        pending.clear()
+        bd, loss_occ, tb, inputs_ready, occ_fwd_done = cur
+        occ_done = threading.Event()
+        fut = pool.submit(occ_tail, loss_occ, next_batch, occ_done)
+        with torch.cuda.stream(det_stream):
+            ret, bd = model.forward_det(bd, inputs_ready)
+            loss_det = MeanSquare.apply(ret["spatial_features"], 1e-3) + MeanSquare.apply(ret["x_combine"], 1e-3)
+        occ_done.wait()
+        with torch.cuda.stream(det_stream):
+            loss_det.backward()
+            _ops.join_wgrad()
+            opts[0].step(groups=[1])     # detection group, on det_stream behind its backward
+            det_stream.wait_event(occ_fwd_done)
+            loss_occ.record_stream(det_stream)
+            loss = loss_occ.detach() + loss_det.detach()
+            model.mark_step_end(stream=det_stream, upto=bd.get("__gen_id__", -1))
+        nxt = fut.result()
+        if nxt is not None:
+            ahead_occ[id(next_batch)] = nxt
+        return loss
+
     def step(batch, next_batch=None):
+        if pipeline:
+            return step_pipelined(batch, next_batch)
         for o in opts:
             o.zero_grad(set_to_none=True)
         bd = pending.pop(id(batch), None)
@@ -205,6 +266,7 @@ def make_step(model, ddp, proc, opts, grad_sync=None, prefetch_stream=None, thre
             pending[id(next_batch)] = model.prepare(next_batch, stream=prefetch_stream)
         model.mark_step_end()
         return loss
+    step.end_stream = det_stream if pipeline else None   # where a step's last kernel runs (per-step timing marks)
     return step
 
 
@@ -439,10 +501,10 @@ def main():
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     allocs0 = torch.cuda.memory_stats(device).get("num_device_alloc", 0)
     t0 = time.perf_counter()
-    marks[0].record()
+    marks[0].record(step.end_stream)
     for i in range(args.warmup, args.warmup + args.steps):  # each step prepares its successor: K steps, K preparations
         step(batches[i % nb], batches[(i + 1) % nb])
-        marks[i - args.warmup + 1].record()                 # end of the step's work on the main stream (no host wait)
+        marks[i - args.warmup + 1].record(step.end_stream)  # end of the step's work on the stream its last kernel runs on (no host wait)
     sync()
     dt = time.perf_counter() - t0
     per_step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
@@ -489,7 +551,11 @@ def main():
                        "schedule": (("each step prepares the NEXT batch's weight-independent front (both voxelizations, occupancy targets, "
                                      "occupancy-branch rulebooks) on a side stream beside its backward pass, one preparation per step; "
                                      "weight gradients on a side stream, one join per backward" if prefetch is not None else "in order, one stream")
-                                    + ("; the detection branch's forward on its own stream beside the occupancy branch's backward" if det_stream is not None else "")),
+                                    + ("; the detection branch's forward on its own stream beside the occupancy branch's backward" if det_stream is not None else "")
+                                    + ("; the occupancy group's optimizer step and the NEXT batch's occupancy-branch forward (with those updated weights) "
+                                       "run from the worker thread beside the detection branch's backward and optimizer step: K steps contain K "
+                                       "occupancy forwards, K detection forwards, K backward passes and K optimizer steps per group"
+                                       if getattr(step, "end_stream", None) is not None else "")),
                        "grad_sync": ("DistributedDataParallel" if ddp is not model else
                                      (None if grad_sync is None else ("btcdet_amd.grad_sync: detection bucket all-reduced during the occupancy branch's backward, occupancy bucket after it"
                                                                      if getattr(grad_sync, "split_backward", False) else "btcdet_amd.grad_sync: flat bucket(s), all-reduce after backward"))),

@@ -142,18 +142,21 @@ class BtcHotPath(nn.Module):
         st["next"] += 1
         return bd
 
-    def mark_step_end(self):
+    def mark_step_end(self, stream=None, upto=None):
         """call once per training step after the backward pass (and optimizer) have been enqueued: the generations of
-        prepared tensors consumed so far may be recycled once the main stream has passed this point"""
+        prepared tensors consumed so far may be recycled once `stream` (default: the current stream) has passed this point.
+        upto: the generation of the batch whose step is ending (batch_dict["__gen_id__"]) -- a loop that runs the occupancy
+        branch of the NEXT batch before this step has ended (bench.make_step, pipelined) must not release that one yet."""
         st = self.__dict__.get("_prep_state")
         if not st:
             return
+        limit = st["consumed"] if upto is None else min(st["consumed"], upto)
         ev = None
         for g in st["gens"]:
-            if g["ended"] is None and g["id"] <= st["consumed"]:
+            if g["ended"] is None and g["id"] <= limit:
                 if ev is None:
                     ev = torch.cuda.Event()
-                    ev.record(torch.cuda.current_stream())
+                    ev.record(stream if stream is not None else torch.cuda.current_stream())
                 g["ended"] = ev
 
     def forward_occ(self, batch_dict):
@@ -168,6 +171,7 @@ class BtcHotPath(nn.Module):
         gen = batch_dict.pop("__generation__", None)
         if gen is not None:
             self._prep_state["consumed"] = max(self._prep_state["consumed"], gen)
+            batch_dict["__gen_id__"] = gen
         use_occ_prob = [True] * batch_dict["batch_size"]
         prob = np.random.uniform(size=batch_dict["batch_size"], high=0.9999)  # the reference consumes this stream too
         if batch_dict["is_train"]:

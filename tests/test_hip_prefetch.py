@@ -171,3 +171,56 @@ def test_chained_layers_equal_layer_by_layer():
             assert (a is None) == (b is None)
             if a is not None:
                 assert float((a - b).abs().max()) <= 1e-5 * float(a.abs().max()) + 1e-30, it
+
+
+def _run_training(mode, steps):
+    """bench.make_step WITH the reference's optimizer step (two groups): plain one-stream schedule, or the pipelined one (detection
+    branch on its own stream, the worker thread steps the occupancy group and runs the next batch's occupancy forward meanwhile)"""
+    import bench
+    from btcdet_amd.btc_path import BtcHotPath
+    from btcdet_amd.config import load_cfg
+    from btcdet_amd.spconv import ops
+    from btcdet_amd.train_step import GroupOptimizer
+    dev = torch.device("cuda:0")
+    import numpy as np
+    torch.manual_seed(3)
+    np.random.seed(3)
+    model = BtcHotPath(load_cfg(), device=dev).to(dev).train()
+    occ = [p for p in model.occ_modules.parameters() if p.requires_grad]
+    det = [p for p in model.det_modules.parameters() if p.requires_grad]
+    kw = dict(grad_norm_clip=10.0, moms=(0.95, 0.85), div_factor=10.0, pct_start=0.4, lr_clip=1e-7)
+    opt = GroupOptimizer([dict(params=occ, lr=0.003, weight_decay=0.001, **kw), dict(params=det, lr=0.01, weight_decay=0.01, **kw)], 1000)
+    ops.set_defer_wgrad_join(True)
+    try:
+        batches = bench.build_batches(3, 0, dev)
+        if mode == "plain":
+            step = bench.make_step(model, model, model.dataset.data_processor, [opt])
+        else:
+            step = bench.make_step(model, model, model.dataset.data_processor, [opt], None, torch.cuda.Stream(priority=-1), threaded=True,
+                                   det_stream=torch.cuda.Stream())
+            assert step.end_stream is not None          # the pipelined variant is the one that runs
+        losses = []
+        for it in range(steps):
+            loss = step(batches[it % 3], batches[(it + 1) % 3] if mode != "plain" else None)
+            losses.append(loss)
+        torch.cuda.synchronize()
+        norms = [float(torch.linalg.vector_norm(torch.cat([p.detach().reshape(-1) for p in g]))) for g in (occ, det)]
+        return [float(l) for l in losses], norms, opt.iteration
+    finally:
+        ops.set_defer_wgrad_join(False)
+
+
+def test_pipelined_training_steps_equal_plain_ones():
+    """same losses step by step and same parameters after 8 optimizer steps as the one-stream schedule: every forward pass sees
+    exactly the weights it would see there (tolerance: the occupancy targets' float atomics make two plain runs differ too)"""
+    steps = 8
+    a, na, ia = _run_training("plain", steps)
+    b, nb, ib = _run_training("plain", steps)
+    c, nc, ic = _run_training("pipeline", steps)
+    assert ia == ib == ic == steps
+    noise = max(abs(x - y) / abs(x) for x, y in zip(a, b))
+    dev = max(abs(x - y) / abs(x) for x, y in zip(a, c))
+    print("relative loss deviation: plain vs plain %.2e, plain vs pipelined %.2e" % (noise, dev))
+    assert dev <= max(20 * noise, 2e-4), (a, c)
+    for x, y in zip(na, nc):
+        assert abs(x - y) <= 1e-4 * abs(x)

@@ -4,15 +4,15 @@ run() { # name, env assignments...
   name=$1; shift
   env "$@" python bench.py --steps 150 --warmup 20 --no-cpu-baseline --no-roofline $EXTRA 2>/dev/null | grep '^{"metric' | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$name', d['value'], d['step_ms']['p10'], d['step_ms']['median'], d['step_ms']['p90'])"
 }
-for rep in 1 2; do
-run "default              " X=1
-run "wgrad first          " BTC_WGRAD_FIRST=1
-run "no deferred join     " BTC_DEFER_WGRAD=0
-run "row order off        " BTC_ROW_ORDER=0
-run "two-barrier wgrad    " BTC_TUNE=11=1
+for rep in 1 2 3; do
+run "pipelined occupancy branch   " X=1
+run "det fwd beside occ bwd only  " BTC_PIPELINE_OCC=0
 done
 EXTRA="--features bf16"
 for rep in 1 2; do
-run "bf16 default         " X=1
-run "bf16 dgrad first     " BTC_WGRAD_FIRST=0
+run "bf16 pipelined               " X=1
+run "bf16 not pipelined           " BTC_PIPELINE_OCC=0
 done
+EXTRA="--workload waymo"
+run "waymo pipelined              " X=1
+run "waymo not pipelined          " BTC_PIPELINE_OCC=0
