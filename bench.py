@@ -9,10 +9,16 @@ One step = one pass of the hot path over one synthetic batch whose raw points al
   -> OccTargets3D -> MeanVFE -> VoxelBackBoneDeconv -> OccHead3D (+ occupancy loss) -> PassOccVox
   -> OccVFE -> VoxelBackBone8xOcc -> HeightCompression (+ an L2 stand-in for the out-of-scope BEV heads)
   -> backward (gradient all-reduce over RCCL when N > 1: btcdet_amd/grad_sync.py, or DDP with BTC_BENCH_SYNC=ddp)
-  -> one fused Adam step over the reference's two parameter groups.
-Every step also prepares the NEXT batch's weight-independent front (both voxelizations, occupancy targets, occupancy-branch
-rulebooks) on a side stream beside its backward pass -- one preparation per step (make_step; BTC_PREFETCH=0 runs in order).
-fp32 throughout.  Prints ONE JSON line on rank 0 (contract in the task statement), including
+  -> the reference's optimizer step per parameter group (norm clip, decoupled weight decay, Adam, OneCycle: btcdet_amd/train_step.py).
+Schedule (make_step; config.schedule in the JSON names what ran): every step also prepares the NEXT batch's weight-independent front
+(both voxelizations, occupancy targets, occupancy-branch rulebooks) on a side stream beside its backward pass -- one preparation per
+step.  Single process: the detection branch (detached from the occupancy branch, PASS_GRAD False) runs on its own stream -- its
+forward beside the occupancy branch's backward, and its backward + optimizer step beside the occupancy group's optimizer step
+and the NEXT batch's occupancy-branch forward, which the worker thread launches with the occupancy weights it has just updated.
+K timed steps contain K of everything; every forward pass sees the weights the one-stream loop would give it
+(tests/test_hip_prefetch.py).  BTC_PIPELINE_OCC=0 / BTC_SPLIT_BACKWARD=0 / BTC_PREFETCH=0 step back to the one-stream, in-order
+loop; N > 1 keeps one stream for both branches and overlaps the detection bucket's all-reduce instead.
+fp32 throughout (--features bf16: BASELINE.json configs[2]).  Prints ONE JSON line on rank 0 (contract in the task statement), including
   roofline      the dominant kernel (conv_apply = fused sparse conv fwd/dgrad) timed live with HIP events
   cpu_baseline  the CPU oracle timed on the host cores for a bounded sample of the same workload (N = 1 only).
 """
