@@ -95,3 +95,27 @@ def test_groups_stepped_separately_equal_one_step():
         runs.append([p.detach().clone() for p in list(a.parameters()) + list(b.parameters())] + [torch.tensor(opt.lrs())])
     for u, v in zip(*runs):
         assert torch.equal(u, v)
+
+
+def test_chunk_tables_cover_every_parameter_once():
+    """chunk tables of csrc/optim.hip (shared by the flat optimizer step and the one-launch bucket pack): chunks of <= 1024 elements,
+    none straddling two parameters, each element of the flat layout covered exactly once, in order"""
+    from btcdet_amd.train_step import chunk_tables
+    sizes = [5, 1024, 1025, 1, 3000, 2048] + [7] * 460          # > 448 parameters: the pointer table wraps
+    t = chunk_tables(sizes, torch.device("cpu"))
+    seg, off, ln, flat, seg0 = (t[k].tolist() if k != "seg0" else t[k] for k in ("seg", "off", "len", "flat", "seg0"))
+    assert len(seg0) == len(sizes) + 1 and seg0[0] == 0 and seg0[-1] == len(seg)
+    starts = [0]
+    for n in sizes:
+        starts.append(starts[-1] + n)
+    covered = 0
+    for i, n in enumerate(sizes):
+        chunks = range(seg0[i], seg0[i + 1])
+        assert len(chunks) == -(-n // 1024)
+        pos = 0
+        for c in chunks:
+            assert seg[c] == i % 448 and off[c] == pos and 1 <= ln[c] <= 1024 and flat[c] == starts[i] + pos
+            pos += ln[c]
+        assert pos == n
+        covered += pos
+    assert covered == sum(sizes)
