@@ -7,20 +7,23 @@
 One step = one pass of the hot path over one synthetic batch whose raw points already sit in HBM:
   GPU voxelization of both grids (cylinder occupancy grid + Cartesian detection grid)
   -> OccTargets3D -> MeanVFE -> VoxelBackBoneDeconv -> OccHead3D (+ occupancy loss) -> PassOccVox
-  -> OccVFE -> VoxelBackBone8xOcc -> HeightCompression (+ an L2 stand-in for the out-of-scope BEV heads)
-  -> backward (gradient all-reduce over RCCL when N > 1: btcdet_amd/grad_sync.py, or DDP with BTC_BENCH_SYNC=ddp)
+  -> OccVFE -> VoxelBackBone8xOcc -> HeightCompression (+ L2 stand-ins for the heads behind the hot path; --heads rpn puts
+     BaseBEVBackbone + AnchorHeadSingle and the reference's RPN loss there)
+  -> backward (gradient all-reduce over RCCL when N > 1: btcdet_amd/grad_sync.py on a communicator of its own)
   -> the reference's optimizer step per parameter group (norm clip, decoupled weight decay, Adam, OneCycle: btcdet_amd/train_step.py).
-Schedule (make_step; config.schedule in the JSON names what ran): every step also prepares the NEXT batch's weight-independent front
-(both voxelizations, occupancy targets, occupancy-branch rulebooks) on a side stream beside its backward pass -- one preparation per
-step.  Single process: the detection branch (detached from the occupancy branch, PASS_GRAD False) runs on its own stream -- its
-forward beside the occupancy branch's backward, and its backward + optimizer step beside the occupancy group's optimizer step
-and the NEXT batch's occupancy-branch forward, which the worker thread launches with the occupancy weights it has just updated.
-K timed steps contain K of everything; every forward pass sees the weights the one-stream loop would give it
-(tests/test_hip_prefetch.py).  BTC_PIPELINE_OCC=0 / BTC_SPLIT_BACKWARD=0 / BTC_PREFETCH=0 step back to the one-stream, in-order
-loop; N > 1 keeps one stream for both branches and overlaps the detection bucket's all-reduce instead.
-fp32 throughout (--features bf16: BASELINE.json configs[2]).  Prints ONE JSON line on rank 0 (contract in the task statement), including
+The step and its schedules live in the package: btcdet_amd/trainer.py (HotPathTrainer; config.schedule in the JSON names what ran).
+Default "pipelined": every step prepares the NEXT batch's weight-independent front (both voxelizations, occupancy targets,
+occupancy-branch rulebooks) on a side stream; the detection branch (detached from the occupancy branch, PASS_GRAD False) runs on
+its own stream -- its forward beside the occupancy branch's backward, and its backward + all-reduce + optimizer step beside the
+occupancy bucket's all-reduce, the occupancy group's optimizer step and the NEXT batch's occupancy-branch forward, which a worker
+thread launches with the occupancy weights it has just updated.  K timed steps contain K of everything; every forward pass sees the
+weights the in-order loop would give it (tests/test_hip_prefetch.py).  The same schedule runs at N = 1 and N > 1.
+BTC_SCHEDULE=in_order|split|pipelined overrides.  fp32 throughout (--features bf16: BASELINE.json configs[2]).
+Prints ONE JSON line on rank 0 (contract in the task statement), including
   roofline      the dominant kernel (conv_apply = fused sparse conv fwd/dgrad) timed live with HIP events
-  cpu_baseline  the CPU oracle timed on the host cores for a bounded sample of the same workload (N = 1 only).
+  cpu_baseline  the CPU oracle timed on the host cores for a bounded sample of the same workload (N = 1 only)
+  config.in_order_scenes_per_s   the same modules driven in order on one stream (what the reference's own loop gets)
+  config.with_rpn_heads          the step with BaseBEVBackbone + AnchorHeadSingle behind the BEV map (second, shorter run).
 """
 import argparse
 import json
@@ -51,7 +54,8 @@ def pmc_traffic_per_launch():
     --pmc WRITE_SIZE in separate runs, FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md); PMC counters cannot be read
     inside the timed process, so this is null when the file is absent"""
     try:
-        with open(os.path.join(ROOT, "profiles", "r02h_pmc.json")) as f:
+        name = "r03_pmc.json" if os.path.exists(os.path.join(ROOT, "profiles", "r03_pmc.json")) else "r02h_pmc.json"
+        with open(os.path.join(ROOT, "profiles", name)) as f:
             return json.load(f)["conv_apply"]["hbm_bytes_per_launch"]
     except (OSError, KeyError, ValueError):
         return None
@@ -94,186 +98,9 @@ def build_batches(n_batches, rank, device, batch_size=2, profile="kitti"):
     return batches
 
 
-class MeanSquare(torch.autograd.Function):
-    """scale * mean(x^2): the L2 stand-in for the out-of-scope consumers of the detection branch (BEV backbone + dense head,
-    point head), one reduction forward and one elementwise launch backward instead of autograd's pow / mean / mul chain"""
-
-    @staticmethod
-    def forward(ctx, x, scale):
-        ctx.save_for_backward(x)
-        ctx.k = float(scale) / max(x.numel(), 1)
-        n = torch.linalg.vector_norm(x.reshape(-1), dtype=torch.float32)
-        return n * n * ctx.k
-
-    @staticmethod
-    def backward(ctx, g):
-        (x,) = ctx.saved_tensors
-        return (x * (g * (2.0 * ctx.k)).to(x.dtype)), None
-
-
-def make_step(model, ddp, proc, opts, grad_sync=None, prefetch_stream=None, threaded=True, det_stream=None, opt_stream=None):
-    """one training step of the hot path.
-
-    prefetch_stream: the weight-independent front of the NEXT batch (voxelizations, occupancy targets, the occupancy branch's
-    rulebooks: BtcHotPath.prepare) runs on that stream beside this batch's backward pass -- the role DataLoader workers play
-    for the reference's CPU voxelizer: from a worker thread while the main thread sits in backward (threaded), or from this
-    thread once the backward pass is enqueued.  Every step still does exactly one batch's worth of that work.
-
-    det_stream (not under DistributedDataParallel, which wants one backward per forward): the detection branch is detached
-    from the occupancy branch (PASS_GRAD False), so the occupancy branch's BACKWARD does not have to wait for the detection
-    branch's FORWARD.  The worker thread calls loss_occ.backward() (autograd runs those nodes on the main stream, where
-    their forward ran) while this thread runs the detection branch on det_stream; both are chains of small launches that do
-    not fill the GPU alone.  The detection branch's backward follows on det_stream, and the main stream joins it before the
-    optimizer.
-
-    opt_stream (single GPU, one GroupOptimizer whose groups are [occupancy, detection]): the branches are detached, so two
-    backward passes give the same gradients as one over the sum.  The detection branch's pass is called with opt_stream
-    current: its nodes still run on the main stream (autograd runs a node where its forward ran), but the end-of-pass
-    synchronisation -- the engine's wait for the gradient-producing streams and the join of the weight-gradient side stream
-    -- lands on opt_stream, and the detection group's optimizer step follows there, beside the occupancy branch's backward on
-    the main stream.  The main stream never waits for the detection branch's weight-gradient tail; it joins opt_stream at
-    the end of the step."""
-    from btcdet_amd.spconv import ops as _ops
-    pending = {}
-    pool = None
-    if (prefetch_stream is not None and threaded) or det_stream is not None:
-        from concurrent.futures import ThreadPoolExecutor
-        pool = ThreadPoolExecutor(max_workers=1)
-    device = next(model.parameters()).device
-    split_backward = grad_sync is not None and ddp is model and len(grad_sync.buckets) > 1 and getattr(grad_sync, "split_backward", False)
-
-    def prep(next_batch):
-        torch.cuda.set_device(device)
-        return model.prepare(next_batch, stream=prefetch_stream)
-
-    def occ_backward(loss):
-        torch.cuda.set_device(device)
-        loss.backward()
-
-    # pipelined variant of the det_stream schedule (single process): once the occupancy branch's backward has returned, the worker
-    # thread goes on -- the occupancy group's optimizer step (its gradients are complete), the next batch's weight-independent front
-    # on the prefetch stream and the next batch's OCCUPANCY FORWARD on the main stream with the updated occupancy weights -- while
-    # this thread runs the detection branch's backward and optimizer step on det_stream.  Nothing is skipped and nothing uses stale
-    # weights: the occupancy branch of step i + 1 needs the occupancy weights of step i (updated before it runs) and batch i + 1;
-    # the detection branch of step i + 1 starts behind step i's detection optimizer on det_stream.  Two backward passes never run at
-    # the same time (the weight-gradient side stream's join bookkeeping assumes one).
-    pipeline = (det_stream is not None and ddp is model and grad_sync is None and prefetch_stream is not None and threaded
-                and len(opts) == 1 and hasattr(opts[0], "groups") and len(opts[0].groups) == 2
-                and os.environ.get("BTC_PIPELINE_OCC", "1") != "0")
-    ahead_occ = {}
-
-    def occ_tail(loss_occ, next_batch, occ_done):
-        torch.cuda.set_device(device)
-        try:
-            loss_occ.backward()
-            _ops.join_wgrad()            # (no-op: the end-of-pass callback has joined the side stream into this thread's stream)
-        finally:
-            occ_done.set()
-        opts[0].step(groups=[0])         # occupancy group, on the main stream behind its backward
-        if next_batch is None:
-            return None
-        return occ_forward(model.prepare(next_batch, stream=prefetch_stream))
-
-    def occ_forward(bd):
-        out = model.forward_occ(bd)
-        done = torch.cuda.Event()
-        done.record()                    # the loss tensor is complete on this (the main) stream
-        return out + (done,)
-
-    def step_pipelined(batch, next_batch):
-        import threading
-        opts[0].zero_grad(set_to_none=True)
-        cur = ahead_occ.pop(id(batch), None)
-        ahead_occ.clear()
-        if cur is None:
-            bd = pending.pop(id(batch), None)
-            cur = occ_forward(bd if bd is not None else model.prepare(batch))
-        pending.clear()
-        bd, loss_occ, tb, inputs_ready, occ_fwd_done = cur
-        occ_done = threading.Event()
-        fut = pool.submit(occ_tail, loss_occ, next_batch, occ_done)
-        with torch.cuda.stream(det_stream):
-            ret, bd = model.forward_det(bd, inputs_ready)
-            loss_det = MeanSquare.apply(ret["spatial_features"], 1e-3) + MeanSquare.apply(ret["x_combine"], 1e-3)
-        occ_done.wait()
-        with torch.cuda.stream(det_stream):
-            loss_det.backward()
-            _ops.join_wgrad()
-            opts[0].step(groups=[1])     # detection group, on det_stream behind its backward
-            det_stream.wait_event(occ_fwd_done)
-            loss_occ.record_stream(det_stream)
-            loss = loss_occ.detach() + loss_det.detach()
-            model.mark_step_end(stream=det_stream, upto=bd.get("__gen_id__", -1))
-        nxt = fut.result()
-        if nxt is not None:
-            ahead_occ[id(next_batch)] = nxt
-        return loss
-
-    def step(batch, next_batch=None):
-        if pipeline:
-            return step_pipelined(batch, next_batch)
-        for o in opts:
-            o.zero_grad(set_to_none=True)
-        bd = pending.pop(id(batch), None)
-        if bd is None:
-            bd = model.prepare(batch)
-        pending.clear()
-        ahead = prefetch_stream is not None and next_batch is not None
-        if det_stream is not None and ddp is model:
-            main = torch.cuda.current_stream()
-            bd, loss_occ, tb, inputs_ready = model.forward_occ(bd)
-            fut_occ = pool.submit(occ_backward, loss_occ)
-            with torch.cuda.stream(det_stream):
-                ret, bd = model.forward_det(bd, inputs_ready)
-                # L2 stand-ins for the out-of-scope consumers of the detection branch
-                loss_det = MeanSquare.apply(ret["spatial_features"], 1e-3) + MeanSquare.apply(ret["x_combine"], 1e-3)
-            fut_occ.result()
-            if grad_sync is not None:
-                grad_sync.launch_ready()  # the occupancy bucket travels during the detection branch's backward
-            fut = pool.submit(prep, next_batch) if (ahead and threaded) else None
-            with torch.cuda.stream(det_stream):
-                loss_det.backward()
-            main.wait_stream(det_stream)
-            loss = loss_occ.detach() + loss_det.detach()
-        else:
-            ret, tb, _ = ddp(bd)
-            # occupancy loss (real) + L2 stand-ins for the out-of-scope consumers of the detection branch
-            loss_det = MeanSquare.apply(ret["spatial_features"], 1e-3) + MeanSquare.apply(ret["x_combine"], 1e-3)
-            fut = pool.submit(prep, next_batch) if (ahead and threaded) else None
-            if opt_stream is not None:
-                with torch.cuda.stream(opt_stream):
-                    loss_det.backward()
-                    opts[0].step(groups=[1])
-                ret["loss_occ"].backward()
-                loss = ret["loss_occ"].detach() + loss_det.detach()
-            elif split_backward:
-                # the branches are detached (PASS_GRAD False): two backward passes give the same gradients as one over the sum.
-                # The detection bucket (~90 % of the bytes) is packed and all-reduced BETWEEN them, from this thread -- it travels
-                # over xGMI while the occupancy branch's backward runs, with no hook in the autograd thread
-                loss_det.backward()
-                grad_sync.launch_ready()
-                ret["loss_occ"].backward()
-                loss = ret["loss_occ"].detach() + loss_det.detach()
-            else:
-                loss = ret["loss_occ"] + loss_det
-                loss.backward()
-        if fut is not None:
-            pending[id(next_batch)] = fut.result()
-        _ops.join_wgrad()   # no-op unless weight gradients are still owed (e.g. a backward pass whose end-of-pass callback never ran)
-        if grad_sync is not None:
-            grad_sync.finish()  # all-reduced mean gradients in param.grad
-        if opt_stream is not None:
-            opts[0].step(groups=[0])
-            torch.cuda.current_stream().wait_stream(opt_stream)
-        else:
-            for o in opts:
-                o.step()
-        if ahead and not threaded:
-            pending[id(next_batch)] = model.prepare(next_batch, stream=prefetch_stream)
-        model.mark_step_end()
-        return loss
-    step.end_stream = det_stream if pipeline else None   # where a step's last kernel runs (per-step timing marks)
-    return step
+# the training step, its schedules and the stand-in loss live in the package (btcdet_amd/trainer.py: HotPathTrainer, make_step);
+# the names stay importable from here for the tests and tools that grew up with them
+from btcdet_amd.trainer import MeanSquare, make_step  # noqa: E402,F401
 
 
 def cpu_baseline(seconds_budget=25.0, max_scenes=2):
@@ -364,12 +191,17 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the two secondary measurements (in-order rate, RPN-head run)")
     ap.add_argument("--workload", choices=["kitti", "waymo"], default="kitti",
                     help="kitti: the configuration BASELINE.json's metric is quoted on (default); waymo: the Waymo-shaped synthetic "
                          "scenes of configs[4] (~166 k points/scene, 1504 x 1504 x 40 grid) -- same path, 6x the work per scene")
     ap.add_argument("--features", choices=["fp32", "bf16"], default="fp32",
                     help="fp32: the reference's precision (default, the headline number); bf16: BASELINE.json configs[2] -- bfloat16 "
                          "activations between sparse layers, fp32 weights / accumulation / statistics")
+    ap.add_argument("--heads", choices=["standin", "rpn"], default="standin",
+                    help="standin (headline): L2 stand-ins on the two tensors the heads behind the hot path consume; rpn: BaseBEVBackbone + "
+                         "AnchorHeadSingle with the reference's RPN loss (btcnet.py:108-114) behind the BEV map, the ROI head's tensor keeps "
+                         "its stand-in (ConvHead is not built)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -390,7 +222,7 @@ def main():
     all_cpus = os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else None
     pinned = pin_to_gpu(dev_index, local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))
     dist = None
-    # BTC_BENCH_FORCE_DIST=1: take the distributed path (process group, DDP wrapper, barriers) at world size 1 too --
+    # BTC_BENCH_FORCE_DIST=1: take the distributed path (process group, reducer, barriers) at world size 1 too --
     # the way to exercise the RCCL code path on a single-GPU box
     use_dist = world > 1 or os.environ.get("BTC_BENCH_FORCE_DIST") == "1"
     if use_dist:
@@ -404,96 +236,22 @@ def main():
     from btcdet_amd.btc_path import BtcHotPath
     from btcdet_amd.config import load_cfg
     from btcdet_amd.spconv import ops
-
-    torch.manual_seed(666)
-    np.random.seed(666 + rank)
-    waymo = args.workload == "waymo"
-    cfg = load_cfg(os.path.join(ROOT, "btcdet_amd", "cfgs", "btcdet_waymo_synth.yaml") if waymo else None)
-    if args.features == "bf16":
-        cfg.MODEL.OCC.BACKBONE_3D["FEATURE_DTYPE"] = "bf16"
-        cfg.MODEL.BACKBONE_3D["FEATURE_DTYPE"] = "bf16"
-    model = BtcHotPath(cfg, device=device).to(device)
-    model.train()
-    ddp, grad_sync = model, None
-    occ_params = [p for p in model.occ_modules.parameters() if p.requires_grad]
-    det_params = [p for p in model.det_modules.parameters() if p.requires_grad]
-    if use_dist and os.environ.get("BTC_BENCH_SYNC", "bucketed") == "ddp":
-        # gradient_as_bucket_view: gradients are written straight into the all-reduce buckets; broadcast_buffers=False:
-        # BatchNorm running statistics stay rank-local between checkpoints instead of being re-broadcast from rank 0 before
-        # every forward (training-mode BN never reads them; the reference's default DDP re-broadcasts, tools/train.py:166-168);
-        # static_graph: the same parameters are used every step.
-        kw = {"gradient_as_bucket_view": True, "broadcast_buffers": False, "static_graph": True}
-        for item in os.environ.get("BTC_DDP_OPTS", "").split(","):  # e.g. gradient_as_bucket_view=1,broadcast_buffers=0
-            if "=" in item:
-                k, v = item.split("=")
-                kw[k] = (float(v) if k == "bucket_cap_mb" else bool(int(v)))
-        ddp = torch.nn.parallel.DistributedDataParallel(model, device_ids=[dev_index], find_unused_parameters=False, **kw)
-    elif use_dist and os.environ.get("BTC_BENCH_NOSYNC") != "1":
-        # default: btcdet_amd/grad_sync.py -- two flat buckets (detection / occupancy parameters), the detection bucket's
-        # all-reduce overlapped with the occupancy branch's backward.  Measured at world size 1 over RCCL: DDP (tuned as above)
-        # 10.1 ms per step, this reducer see DESIGN.md, no reducer 9.2 ms.
-        from btcdet_amd.grad_sync import BucketedGradSync
-        for p in model.parameters():  # same start on every rank (DDP does this broadcast in its constructor)
-            dist.broadcast(p.data, src=0)
-        for b in model.buffers():
-            dist.broadcast(b.data, src=0)
-        head_param = next(p for p in model.occ_modules.occ_dense_head.parameters() if p.requires_grad)
-        mode = os.environ.get("BTC_SYNC_BUCKETS", "split")
-        view = os.environ.get("BTC_BENCH_OPTIM", "lean") != "torch"     # the optimizer reads the buckets' slices (no param.grad stores)
-        if mode == "early":   # detection bucket launched from a hook in mid-backward (comm hidden, hook's Python in the engine thread)
-            grad_sync = BucketedGradSync([(det_params, head_param), (occ_params, None)])
-        elif mode == "two":
-            grad_sync = BucketedGradSync([(det_params, None), (occ_params, None)])
-        elif mode == "one":   # one flat bucket sent after backward: the least host work; ~10 MB of all-reduce exposed
-            grad_sync = BucketedGradSync([(det_params + occ_params, None)], assign_grads=not view)
-        else:                 # default: two buckets, the detection bucket's all-reduce overlapped with the occupancy branch's backward
-            grad_sync = BucketedGradSync([(det_params, None), (occ_params, None)], assign_grads=not view)   # (make_step: split_backward)
-            grad_sync.split_backward = True
-    # the reference's optimizer step per parameter group (tools/train_utils/train_utils.py:121-124; yaml:331-372): gradient-norm
-    # clip at 10, adam_onecycle = decoupled weight decay + Adam(betas=(mom, 0.99)) with lr / mom on the OneCycle schedule of a
-    # 40-epoch run over KITTI's 3712 training frames -- btcdet_amd/train_step.py (checked against the reference's own
-    # OptimWrapper / OneCycle, tests/test_train_step_cpu.py).  The two optimizers are the two groups of one object: same
-    # arithmetic per group, one Python call.
-    # weight gradients on a side stream for the whole backward pass, joined once at its end (not under DDP, whose hooks read
-    # them in mid-backward)
-    ops.set_defer_wgrad_join(ddp is model and os.environ.get("BTC_DEFER_WGRAD", "1") != "0")
+    from btcdet_amd.trainer import HotPathTrainer, reference_groups
     from btcdet_amd.train_step import GroupOptimizer
-    total_steps = 40 * (3712 // (2 * world))
-    sched_kw = dict(grad_norm_clip=10.0, moms=(0.95, 0.85), div_factor=10.0, pct_start=0.4, lr_clip=1e-7)
-    groups = [dict(params=occ_params, lr=0.003, weight_decay=0.001, **sched_kw), dict(params=det_params, lr=0.01, weight_decay=0.01, **sched_kw)]
-    if os.environ.get("BTC_BENCH_OPTIM", "lean") == "torch":   # plain torch Adam (no clip / schedule): A-B runs only
-        opts = [torch.optim.Adam([{"params": occ_params, "lr": 3e-3}, {"params": det_params, "lr": 1e-2}], betas=(0.9, 0.99), fused=True)]
-    else:
-        opts = [GroupOptimizer(groups, total_steps)]
-        if grad_sync is not None and not grad_sync.assign_grads:
-            opts[0].read_grads_from(grad_sync.view_of, grad_sync.has_grad, grad_sync.missing)
+
+    waymo = args.workload == "waymo"
     bs = 2
-    batches = build_batches(4, rank, device, bs, args.workload)
-    # the next batch's weight-independent front runs on a high-priority side stream beside this batch's backward
-    prefetch = torch.cuda.Stream(device=device, priority=-1) if os.environ.get("BTC_PREFETCH", "2") != "0" else None
-    # the detection branch on its own stream, beside the occupancy branch's backward (make_step)
-    # Single process (default): the detection branch's forward runs on its own stream beside the occupancy branch's backward
-    # (make_step, det_stream; gradients equal the one-stream schedule's: tests/test_hip_prefetch.py).  Measured back to back:
-    # 353 -> 374 scenes/s fp32, 354 -> 412 bf16.  With a gradient reducer the detection bucket (90 % of the bytes) would only be
-    # complete at the very end of the step, its all-reduce exposed: 305-314 -> 280-284 at world size 1 over RCCL, so the
-    # distributed path keeps the split-backward schedule (BTC_SPLIT_BACKWARD=0/1 overrides either default).
-    split_default = "1" if (grad_sync is None and prefetch is not None) else "0"   # (BTC_PREFETCH=0 is the in-order, one-stream schedule)
-    det_stream = torch.cuda.Stream(device=device) if (ddp is model and os.environ.get("BTC_SPLIT_BACKWARD", split_default) == "1") else None
-    if det_stream is not None and "BTC_DET_WALK_ASYNC" not in os.environ:
-        # the detection branch's rulebook walk beside its first stage buys nothing once the whole branch runs beside the occupancy
-        # backward (377 vs 374 scenes/s without it): one stream less
-        import btcdet_amd.backbones_3d as _bb3d
-        _bb3d.DET_WALK_ASYNC = False
-    # BTC_EARLY_OPT=1: the detection group's optimizer step beside the occupancy branch's backward (make_step; single process only
-    # -- with a gradient reducer the detection bucket's all-reduce takes that slot).  Worth 1.7 % while a group's step was ~10
-    # multi-tensor torch ops (333.8 -> 339.5 scenes/s); with the three-launch step of csrc/optim.hip there is nothing left to hide
-    # (349.9 without, 348.8 with), so it is off by default.
-    early_opt = (grad_sync is None and ddp is model and det_stream is None and isinstance(opts[0], GroupOptimizer)
-                 and os.environ.get("BTC_EARLY_OPT", "0") == "1")
-    opt_stream = torch.cuda.Stream(device=device) if early_opt else None
-    step = make_step(model, ddp, model.dataset.data_processor, opts, grad_sync, prefetch, threaded=os.environ.get("BTC_PREFETCH", "2") == "2",
-                     det_stream=det_stream, opt_stream=opt_stream)
-    nb = len(batches)
+
+    def build_model(heads):
+        torch.manual_seed(666)
+        np.random.seed(666 + rank)
+        cfg = load_cfg(os.path.join(ROOT, "btcdet_amd", "cfgs", "btcdet_waymo_synth.yaml") if waymo else None)
+        if args.features == "bf16":
+            cfg.MODEL.OCC.BACKBONE_3D["FEATURE_DTYPE"] = "bf16"
+            cfg.MODEL.BACKBONE_3D["FEATURE_DTYPE"] = "bf16"
+        m = BtcHotPath(cfg, device=device, heads=heads).to(device)
+        m.train()
+        return m
 
     def sync():
         torch.cuda.synchronize()
@@ -501,28 +259,60 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    model = build_model("rpn" if args.heads == "rpn" else None)
+    batches = build_batches(4, rank, device, bs, args.workload)
+    nb = len(batches)
+    # Schedule: HotPathTrainer's default ("pipelined": detection branch on its own stream, occupancy branch one step ahead, each
+    # thread's bucket all-reduced behind its backward when a process group exists).  BTC_SCHEDULE=in_order|split|pipelined
+    # overrides; BTC_PREFETCH=0 is the old spelling of in_order.
+    schedule = os.environ.get("BTC_SCHEDULE") or ("in_order" if os.environ.get("BTC_PREFETCH") == "0" else "pipelined")
+    # the reference's optimizer step per parameter group (tools/train_utils/train_utils.py:121-124; yaml:331-372): gradient-norm
+    # clip at 10, adam_onecycle = decoupled weight decay + Adam(betas=(mom, 0.99)) with lr / mom on the OneCycle schedule of a
+    # 40-epoch run over KITTI's 3712 training frames -- btcdet_amd/train_step.py (checked against the reference's own
+    # OptimWrapper / OneCycle, tests/test_train_step_cpu.py).  The two optimizers are the two groups of one object.
+    trainer = HotPathTrainer(model, schedule=schedule, distributed=use_dist, det_loss=model.det_loss)
+    step, grad_sync, opt = trainer._step, trainer.grad_sync, trainer.optimizer
+    if trainer.det_stream is not None and "BTC_DET_WALK_ASYNC" not in os.environ:
+        # the detection branch's rulebook walk beside its first stage buys nothing once the whole branch runs beside the occupancy
+        # backward (377 vs 374 scenes/s without it): one stream less
+        import btcdet_amd.backbones_3d as _bb3d
+        _bb3d.DET_WALK_ASYNC = False
+
+    def timed_run(step_fn, n_steps, n_warm, end_stream):
+        """n_warm untimed steps, then exactly n_steps timed ones bracketed by barrier + synchronize -> (seconds, per-step ms, hipMallocs)"""
+        for i in range(n_warm):
+            step_fn(batches[i % nb], batches[(i + 1) % nb])
+        sync()
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(n_steps + 1)]
+        allocs0 = torch.cuda.memory_stats(device).get("num_device_alloc", 0)
+        t0 = time.perf_counter()
+        marks[0].record(end_stream)
+        for i in range(n_warm, n_warm + n_steps):  # each step prepares its successor: K steps, K preparations
+            step_fn(batches[i % nb], batches[(i + 1) % nb])
+            marks[i - n_warm + 1].record(end_stream)  # end of the step's work on the stream its last kernel runs on (no host wait)
+        sync()
+        dt = time.perf_counter() - t0
+        ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(n_steps))
+        return dt, ms, torch.cuda.memory_stats(device).get("num_device_alloc", 0) - allocs0
+
     # Setup, before the W warmup steps: the caching allocator, the per-batch-size geometry plans and the flat optimizer buffers reach
     # their steady state only after every one of the 4 synthetic batches has been seen a few times; a short W (the driver's choice)
     # would otherwise leave hipMalloc calls and plan construction inside the timed region (config.priming_steps in the JSON).
     priming = max(0, 16 - args.warmup)
-    for i in range(priming):
-        step(batches[i % nb], batches[(i + 1) % nb])
-    for i in range(priming, priming + args.warmup):
-        step(batches[i % nb], batches[(i + 1) % nb])
-    sync()
-    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
-    allocs0 = torch.cuda.memory_stats(device).get("num_device_alloc", 0)
-    t0 = time.perf_counter()
-    marks[0].record(step.end_stream)
-    first = priming + args.warmup
-    for i in range(first, first + args.steps):  # each step prepares its successor: K steps, K preparations
-        step(batches[i % nb], batches[(i + 1) % nb])
-        marks[i - first + 1].record(step.end_stream)  # end of the step's work on the stream its last kernel runs on (no host wait)
-    sync()
-    dt = time.perf_counter() - t0
-    per_step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
-    device_allocs = torch.cuda.memory_stats(device).get("num_device_alloc", 0) - allocs0   # hipMalloc calls inside the timed region
-    # roofline leg: the SAME steps once more with a HIP event pair around every sparse-conv / rulebook launch
+    dt, per_step_ms, device_allocs = timed_run(step, args.steps, priming + args.warmup, step.end_stream)
+    dt = max_over_ranks(dt, dist, device)
+
+    # ---- secondary measurements (outside the timed region, N = 1 reporting only; --no-extras skips them)
+    extras = {}
+    want_extras = not args.no_extras and not waymo
+    plain_step = make_step(model, model, model.dataset.data_processor, [opt], grad_sync, det_loss=model.det_loss)   # one stream, one thread
+    if want_extras:
+        # what the reference's own loop (train_one_epoch_multi_opt) gets from these modules unchanged: in order, one stream
+        k_in = min(args.steps, 10)
+        dt_in, _, _ = timed_run(lambda b, nxt: plain_step(b), k_in, 2, None)
+        dt_in = max_over_ranks(dt_in, dist, device)
+        extras["in_order_scenes_per_s"] = round(bs * world * k_in / dt_in, 2)
+    # roofline leg: the SAME steps once more, in order, with a HIP event pair around every sparse-conv / rulebook launch
     # (kept out of the timed region above because counting the pairs of each rulebook needs a read-back)
     prof = None
     prof_steps = 0
@@ -531,21 +321,32 @@ def main():
         ops.PROFILE = prof
         prof_steps = min(args.steps, 8)
     if not args.no_roofline:
-        # one stream, one thread: the event pairs time kernels that run alone
-        plain_step = make_step(model, ddp, model.dataset.data_processor, opts, grad_sync)
         for i in range(min(args.steps, 8)):
-            plain_step(batches[i % len(batches)])
+            plain_step(batches[i % nb])
         sync()
     ops.PROFILE = None
-    dt = max_over_ranks(dt, dist, device)
     if grad_sync is not None and os.environ.get("BTC_SYNC_TIMING") == "1" and rank == 0:
         from btcdet_amd import grad_sync as _gs
         n = max(_gs._TIMING.get("n", 1), 1)
         print("grad_sync host ms per step:", {k: round(v / n * 1e3, 3) for k, v in _gs._TIMING.items() if k != "n"}, file=sys.stderr)
+    if want_extras and args.heads != "rpn" and os.environ.get("BTC_BENCH_RPN", "1") != "0":
+        # the same step with the §8f row-1 heads behind the BEV map (BaseBEVBackbone + AnchorHeadSingle, RPN loss of btcnet.py:108-114;
+        # dense 2-D convs = vendor library): a second model, trainer and optimizer, run after the headline measurement
+        del plain_step
+        model_r = build_model("rpn")
+        tr_r = HotPathTrainer(model_r, schedule=schedule, distributed=use_dist, det_loss=model_r.det_loss)
+        k_r = min(args.steps, 10)
+        dt_r, ms_r, _ = timed_run(tr_r._step, k_r, 12, tr_r._step.end_stream)
+        dt_r = max_over_ranks(dt_r, dist, device)
+        extras["with_rpn_heads"] = {"scenes_per_s": round(bs * world * k_r / dt_r, 2), "ms_per_step": round(1e3 * dt_r / k_r, 3), "steps": k_r,
+                                    "what": "BaseBEVBackbone + AnchorHeadSingle (RPN cls / loc / dir loss, targets assigned in the prepared front) "
+                                            "behind HeightCompression; x_combine keeps its L2 stand-in (ConvHead not built)"}
 
     result = None
     if rank == 0:
         scenes = bs * world * args.steps
+        heads_txt = ("(+L2 stand-in for the BEV heads and the ROI head)" if args.heads == "standin" else
+                     "-> BaseBEVBackbone -> AnchorHeadSingle + RPN loss (+L2 stand-in for the ROI head)")
         result = {
             "metric": "scenes/s fwd+bwd %s bs=2/GPU (BtcDet hot path)" % ("Waymo-shaped synthetic" if waymo else "KITTI-Car"), "value": round(scenes / dt, 3), "unit": "scenes/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
@@ -554,28 +355,34 @@ def main():
             "data": "synthetic",
             "step_ms": {"p10": round(per_step_ms[int(0.1 * (args.steps - 1))], 3), "median": round(per_step_ms[args.steps // 2], 3),
                         "p90": round(per_step_ms[int(0.9 * (args.steps - 1) + 0.5)], 3), "min": round(per_step_ms[0], 3), "max": round(per_step_ms[-1], 3),
-                        "how": "HIP events at the end of every step on the main stream (rank 0)", "device_allocs_in_timed_region": device_allocs},
+                        "how": "HIP events at the end of every step on the stream its last kernel runs on (rank 0)", "device_allocs_in_timed_region": device_allocs},
             "config": {"workload": ("btcdet_waymo_synth (configs[4] shape) hot path, bs=2/GPU, ~166k pts/scene: HIP voxelize" if waymo else
                                     "btcdet_kitti_car hot path, bs=2/GPU, ~28.6k pts/scene: HIP voxelize") + " (occ+det grids) -> OccTargets3D -> "
                                    "MeanVFE -> VoxelBackBoneDeconv -> OccHead3D+loss -> PassOccVox -> OccVFE -> VoxelBackBone8xOcc -> "
-                                   "HeightCompression (+L2 stand-in for the out-of-scope BEV heads), fwd+bwd + the reference's optimizer step per parameter group (norm clip 10, "
+                                   "HeightCompression " + heads_txt + ", fwd+bwd + the reference's optimizer step per parameter group (norm clip 10, "
                                    "decoupled weight decay, Adam, OneCycle lr / beta1), " + ("fp32" if args.features == "fp32" else "bf16 features"),
                        "global_batch": bs * world, "parallelism": "dp%d" % world,
-                       "schedule": (("each step prepares the NEXT batch's weight-independent front (both voxelizations, occupancy targets, "
-                                     "occupancy-branch rulebooks) on a side stream beside its backward pass, one preparation per step; "
-                                     "weight gradients on a side stream, one join per backward" if prefetch is not None else "in order, one stream")
-                                    + ("; the detection branch's forward on its own stream beside the occupancy branch's backward" if det_stream is not None else "")
-                                    + ("; the occupancy group's optimizer step and the NEXT batch's occupancy-branch forward (with those updated weights) "
-                                       "run from the worker thread beside the detection branch's backward and optimizer step: K steps contain K "
-                                       "occupancy forwards, K detection forwards, K backward passes and K optimizer steps per group"
-                                       if getattr(step, "end_stream", None) is not None else "")),
-                       "grad_sync": ("DistributedDataParallel" if ddp is not model else
-                                     (None if grad_sync is None else ("btcdet_amd.grad_sync: detection bucket all-reduced during the occupancy branch's backward, occupancy bucket after it"
-                                                                     if getattr(grad_sync, "split_backward", False) else "btcdet_amd.grad_sync: flat bucket(s), all-reduce after backward"))),
-                       "collective": (None if dist is None else {"backend": dist.get_backend(), "world_size": dist.get_world_size()}),
+                       "schedule": {"in_order": "in order, one stream (what the reference's own loop gets from these modules)",
+                                    "split": "one stream; next batch's weight-independent front on a side stream beside backward; backward in two passes "
+                                             "with the detection bucket's all-reduce between them",
+                                    "pipelined": "btcdet_amd.trainer.HotPathTrainer 'pipelined': each step prepares the NEXT batch's weight-independent front "
+                                                 "(both voxelizations, occupancy targets, occupancy-branch rulebooks) on a side stream; weight gradients on a "
+                                                 "side stream, one join per backward; the detection branch's forward on its own stream beside the occupancy "
+                                                 "branch's backward; the occupancy bucket's all-reduce (N > 1), the occupancy group's optimizer step and the "
+                                                 "NEXT batch's occupancy forward run from a worker thread beside the detection branch's backward, all-reduce "
+                                                 "and optimizer step: K steps contain K of everything"}[schedule if step.pipelined or schedule != "pipelined" else "split"],
+                       "grad_sync": (None if grad_sync is None else
+                                     "btcdet_amd.grad_sync over %s: two flat buckets (occupancy / detection parameters), one all-reduce each per step, "
+                                     "launched behind its branch's backward" % grad_sync.transport),
+                       "collective": (None if dist is None else {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
+                                                                 "transport": None if grad_sync is None else grad_sync.transport}),
                        "host_cpus": (None if not pinned else "%d CPUs local to the GPU (sysfs local_cpulist), first %d" % (len(pinned), pinned[0])),
-                       "points_per_batch": [b["n_points"] for b in batches], "priming_steps": priming},
+                       "points_per_batch": [b["n_points"] for b in batches], "priming_steps": priming, "heads": args.heads},
         }
+        result["config"].update(extras)
+        straggler = straggler_estimate()
+        if straggler is not None:
+            result["config"]["predicted_scaling_eff"] = straggler
         if prof is not None:
             summ = prof.summary()
             k = summ.get("conv_apply")
@@ -586,18 +393,25 @@ def main():
                 mfma_peak = BF16_MFMA_PEAK_TF if bf else FP32_MFMA_PEAK_TF
                 traffic = None if (waymo or bf) else pmc_traffic_per_launch()
                 avg_s = 1e-3 * k["ms"] / k["launches"]
-                # `bound`: the roof the kernel sits closer to.  Algorithmic bytes (every gathered row counts, although
-                # most gathers are served by L2 / MALL) against the HBM peak, flops against the dense MFMA peak of the operand type;
-                # frac_hbm_measured is what the PMC counters saw actually crossing the HBM interface.
+                # `bound`: algorithmic bytes (every gathered row counts, although most gathers are served by
+                # L2 / MALL) against the HBM peak, flops against the dense MFMA peak of the operand type, and -- from the committed PMC
+                # pass -- the bytes that really crossed the HBM interface.  If the kernel sits below 0.2 of BOTH real roofs (measured
+                # HBM traffic, MFMA flops) neither binds: it is bound by latency (launch + map-tile prologue + per-item barriers,
+                # LDS fragment reads), and the JSON says so instead of naming the nearer roof.
                 f_hbm, f_mfma = gbs / HBM_PEAK_GBS, tf / mfma_peak
+                f_meas = None if traffic is None else traffic / avg_s / 1e9 / HBM_PEAK_GBS
+                if (f_meas if f_meas is not None else f_hbm) < 0.2 and f_mfma < 0.2:
+                    bound = "latency"
+                else:
+                    bound = "hbm" if f_hbm >= f_mfma else "mfma"
                 result["roofline"] = {"kernel": "conv_apply (fused sparse conv fwd + dgrad, output-stationary MFMA %s)" % ("bf16 x bf16 -> f32" if bf else "f32"),
-                                      "bound": "hbm" if f_hbm >= f_mfma else "mfma",
+                                      "bound": bound, "nearer_roof": "hbm" if f_hbm >= f_mfma else "mfma",
                                       "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(f_hbm, 5),
                                       "traffic": traffic, "launches_per_step": k["launches"] / prof_steps,
                                       "avg_launch_us": round(1e3 * k["ms"] / k["launches"], 2),
                                       "alg_bytes_per_step": k["bytes"] // prof_steps,
                                       "tflops": round(tf, 3), "mfma_peak_tflops": mfma_peak, "frac_mfma": round(f_mfma, 5),
-                                      "frac_hbm_measured": None if traffic is None else round(traffic / avg_s / 1e9 / HBM_PEAK_GBS, 5),
+                                      "frac_hbm_measured": None if f_meas is None else round(f_meas, 5),
                                       "kernel_ms_per_step": round(k["ms"] / prof_steps, 3)}
             for name in ("conv_wgrad", "rulebook"):
                 k = summ.get(name)
@@ -616,6 +430,19 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def straggler_estimate():
+    """predicted weak-scaling efficiency at 8 ranks from the per-batch step-time distribution measured on ONE GPU
+    (tools/straggler.py -> profiles/*_straggler.json): the gradient all-reduce is a barrier, so a step takes as long as the
+    slowest of the 8 ranks' batches; E[mean] / E[max of 8 independent draws].  None when the file is absent."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r03_straggler.json")) as f:
+            d = json.load(f)
+        return {"world": 8, "efficiency": d["predicted_eff_world8"], "from": "profiles/r03_straggler.json: %d distinct seeded batches, step time "
+                "mean %.3f ms, sd %.3f ms" % (d["n_batches"], d["mean_ms"], d["sd_ms"])}
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 if __name__ == "__main__":

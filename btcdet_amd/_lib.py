@@ -109,6 +109,7 @@ _SIGS = {
     "btc_conv_apply_ordered": (ci, [ci, ci, vp, vp, vp, vp, vp, ci, ci, ci, ci, vp, vp]),
     "btc_conv_wgrad_ordered": (ci, [ci, vp, vp, vp, ci, vp, ci, vp, vp, ci, ci, ci, vp, vp, sz, vp]),
     "btc_adam_group_ws_bytes": (sz, [ci]),
+    "btc_adam_max_segments": (ci, []),
     "btc_grads_pack": (ci, [vp, ci, vp, vp, vp, vp, c_i32p, vp, vp]),
     "btc_adam_group_step": (ci, [vp, ci, vp, vp, vp, vp, c_i32p, ci, vp, vp, vp, ctypes.c_longlong, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                                  ctypes.c_float, ctypes.c_float, ctypes.c_float, vp, sz, vp]),

@@ -3,15 +3,17 @@ detection branch, with the module lists, registry names and ``occ_modules`` / ``
 /root/reference/btcdet/models/detectors/detector3d_template.py:28-113 and btcnet.py:32-56, so that
 ``state_dict`` keys line up with reference checkpoints (occ_modules.backbone_3d.conv1.0.0.weight, ...).
 
-Out of scope: BaseBEVBackbone, AnchorHeadSingle, ConvHead.  The detection branch therefore ends
-at HeightCompression; bench.py drives its backward with a stand-in L2 loss on the two tensors those heads
-consume (``spatial_features`` and ``multi_scale_3d_features['x_combine']``).
+The hot path proper ends at HeightCompression; a training step drives its backward with a stand-in L2
+loss on the two tensors the heads behind it consume (``spatial_features`` and ``multi_scale_3d_features['x_combine']``,
+btcdet_amd/trainer.py).  ``heads="rpn"`` appends the §8f row-1 glue -- BaseBEVBackbone + AnchorHeadSingle with the
+reference's module names (``det_modules.backbone_2d`` / ``det_modules.dense_head``) and its RPN loss (btcnet.py:108-114);
+the ROI head (ConvHead) is not built, ``x_combine`` keeps its stand-in.
 """
 import numpy as np
 import torch
 import torch.nn as nn
 
-from . import backbones_3d, height_compression, occ_head, occ_targets, pass_occ_vox, vfe
+from . import backbones_3d, bev_backbone, dense_head, height_compression, occ_head, occ_targets, pass_occ_vox, vfe
 from .processor import DataProcessor
 
 
@@ -35,9 +37,11 @@ class HotPathDataset(object):
 
 
 class BtcHotPath(nn.Module):
-    def __init__(self, cfg, dataset=None, device="cuda"):
+    def __init__(self, cfg, dataset=None, device="cuda", heads=None):
         super().__init__()
+        assert heads in (None, "rpn"), heads
         self.cfg = cfg
+        self.heads = heads
         self.dataset = dataset if dataset is not None else HotPathDataset(cfg)
         ds, m, d = self.dataset, cfg.MODEL, cfg.DATA_CONFIG
         self.register_buffer('global_step', torch.LongTensor(1).zero_())
@@ -77,6 +81,15 @@ class BtcHotPath(nn.Module):
         for name, mod in [("vfe", dvfe), ("backbone_3d", dbb), ("map_to_bev_module", bev)]:
             self.det_modules.add_module(name, mod)
         self.det_module_list = [dvfe, dbb, bev]
+        if heads == "rpn":   # module_topology continues: backbone_2d, dense_head (detector3d_template.py:28-30,252-289)
+            b2d = bev_backbone.__all__[m.BACKBONE_2D.NAME](model_cfg=m.BACKBONE_2D, input_channels=m.MAP_TO_BEV.NUM_BEV_FEATURES)
+            dh = dense_head.__all__[m.DENSE_HEAD.NAME](model_cfg=m.DENSE_HEAD, input_channels=b2d.num_bev_features,
+                                                       num_class=len(cfg.CLASS_NAMES) if not m.DENSE_HEAD.CLASS_AGNOSTIC else 1,
+                                                       class_names=cfg.CLASS_NAMES, grid_size=ds.det_grid_size,
+                                                       point_cloud_range=ds.point_cloud_range, predict_boxes_when_training=False)
+            self.det_modules.add_module("backbone_2d", b2d)
+            self.det_modules.add_module("dense_head", dh)
+            self.det_module_list += [b2d, dh]
         self.percentage = d.OCC.get("USEOCC_PERCENTAGE", 1.0)
 
     # ------------------------------------------------------------------------------------------------------------------
@@ -108,6 +121,11 @@ class BtcHotPath(nn.Module):
         bb = self.occ_modules.backbone_3d
         if n_done == 2 and hasattr(bb, "prefetch_geometry"):
             bd = bb.prefetch_geometry(bd, self.occ_modules.occ_dense_head)
+        if self.heads == "rpn" and bd["is_train"]:
+            # anchor targets are a function of the boxes alone (dense_head.AxisAlignedTargetAssigner: nonzero / argmax with host
+            # read-backs, as in the reference): part of the weight-independent front, off the training thread's stream
+            dh = self.det_modules.dense_head
+            bd["rpn_targets"] = dh.target_assigner.assign_targets(dh.anchors(bd["gt_boxes"].device), bd["gt_boxes"])
         bd["__prepared__"] = n_done
         return bd
 
@@ -200,9 +218,18 @@ class BtcHotPath(nn.Module):
                     v.record_stream(cur)
         for mod in self.det_module_list:
             batch_dict = mod(batch_dict)
-        # the two tensors the out-of-scope heads consume: the BEV map (BaseBEVBackbone) and x_combine (ConvHead)
+        # the two tensors the heads behind the hot path consume: the BEV map (BaseBEVBackbone) and x_combine (ConvHead)
         return {"spatial_features": batch_dict["spatial_features"],
                 "x_combine": batch_dict["multi_scale_3d_features"]["x_combine"].features}, batch_dict
+
+    def det_loss(self, ret, batch_dict):
+        """the detection branch's training loss (btcnet.py:108-129): with heads="rpn" the anchor head's RPN loss + the L2
+        stand-in for the ROI head's consumer tensor; without heads the two stand-ins of trainer.stand_in_det_loss"""
+        from .trainer import MeanSquare, stand_in_det_loss
+        if self.heads != "rpn":
+            return stand_in_det_loss(ret, batch_dict)
+        loss_rpn, tb = self.det_modules.dense_head.get_loss()
+        return loss_rpn + MeanSquare.apply(ret["x_combine"], 1e-3)
 
     def forward(self, batch_dict):
         """BtcNet.forward up to the BEV map (btcnet.py:32-56) + the occupancy loss (btcnet.py:91-101)"""

@@ -76,6 +76,12 @@ bool bf16_operands(const Tensor& features, int64_t K, int64_t cred, int64_t cres
 Tensor weights_bf16(const Tensor& w, int64_t K, int64_t cin, int64_t cout, int64_t stream) {
   const void* key = w.unsafeGetTensorImpl();
   const uint32_t version = (uint32_t)w._version();
+  if (!w.is_leaf()) {   // a temporary (the zero-padded 34 -> 48 channel weight is a fresh tensor every step): convert, do not cache
+    Tensor q = at::empty({2, w.numel()}, w.options().dtype(at::kBFloat16));
+    chk(btc_weights_to_bf16((const float*)w.data_ptr(), (int)K, (int)cin, (int)cout, q.data_ptr(), (char*)q.data_ptr() + 2 * w.numel(), st(stream)),
+        "btc_weights_to_bf16");
+    return q;
+  }
   std::lock_guard<std::mutex> lock(g_wq_mu);
   auto it = g_wq.find(key);
   if (it != g_wq.end() && !it->second.weak.expired() && it->second.version == version && it->second.q.get_device() == w.get_device())
@@ -86,8 +92,8 @@ Tensor weights_bf16(const Tensor& w, int64_t K, int64_t cin, int64_t cout, int64
       "btc_weights_to_bf16");
   if (it != g_wq.end()) g_wq.erase(it);
   g_wq.emplace(key, WqEntry(c10::weak_intrusive_ptr<c10::TensorImpl>(w.getIntrusivePtr()), version, q));
-  if (g_wq.size() > 4096)   // models come and go in a long-lived process (tests): drop the entries of freed parameters
-    for (auto e = g_wq.begin(); e != g_wq.end();) e = e->second.weak.expired() ? g_wq.erase(e) : std::next(e);
+  // models come and go in a long-lived process (tests): every miss drops the entries of freed parameters (a few dozen entries)
+  for (auto e = g_wq.begin(); e != g_wq.end();) e = e->second.weak.expired() ? g_wq.erase(e) : std::next(e);
   return q;
 }
 

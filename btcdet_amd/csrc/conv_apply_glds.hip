@@ -14,6 +14,8 @@
 // Rows without a neighbour at the offset read a zeroed device row (the DMA has no per-lane predicated zero fill).
 #include "btc_common.h"
 
+#include <mutex>
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
@@ -232,12 +234,11 @@ int launch_g(const void* feat, const float* W, const float* bias, const int32_t*
   constexpr int TM = 16 * WR, TN = 16 * NTW * WC;
   const size_t lds = btc_apply_glds_lds_bytes(WR * 100 + WC * 10 + NTW, KC, K, BF);
   BTC_CHECK_ARG(lds <= 160 * 1024, "conv_apply_g: tile does not fit the LDS");
-  static bool attr_set = false;
-  if (!attr_set) {
+  static std::once_flag once;   // launches come from the training thread, the autograd thread and the prefetch thread
+  std::call_once(once, [] {
     (void)hipFuncSetAttribute((const void*)conv_apply_g<WR, WC, NTW, TRANS_W, KC, BF>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               160 * 1024);
-    attr_set = true;
-  }
+  });
   dim3 grid(btc_cdiv(n_rows, TM), Cres / TN);
   conv_apply_g<WR, WC, NTW, TRANS_W, KC, BF><<<grid, 64 * WR * WC, lds, stream>>>(feat, W, bias, nbr, order, n_rows, K, Cred, Cres, out, xcd,
                                                                                 btc_tune_get(BTC_TUNE_APPLY_DEBUG));

@@ -109,6 +109,8 @@ __global__ __launch_bounds__(256) void grads_pack(GradPtrs ptrs, const int32_t* 
 
 }  // namespace
 
+extern "C" int btc_adam_max_segments(void) { return BTC_ADAM_MAX_SEGMENTS; }
+
 extern "C" int btc_grads_pack(const float* const* grads, int n_seg, const int32_t* chunk_seg, const int32_t* chunk_off, const int32_t* chunk_len,
                               const int64_t* chunk_flat, const int32_t* seg_chunk0, float* flat, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;

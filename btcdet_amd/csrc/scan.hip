@@ -2,6 +2,8 @@
 // block scan + offset).  Wave64 shuffles for the in-wave scan, LDS for the 4 waves of a block.
 #include <stdarg.h>
 
+#include <cstdlib>
+
 #include "btc_common.h"
 
 static thread_local char g_err[512] = "";
@@ -22,6 +24,10 @@ int btc_tune_get(int key) { return (key >= 0 && key < BTC_TUNE_KEYS) ? g_tune[ke
 extern "C" int btc_tune_value(int key) { return btc_tune_get(key); }
 extern "C" int btc_tune_set(int key, int value) {
   BTC_CHECK_ARG(key >= 0 && key < BTC_TUNE_KEYS, "btc_tune_set: unknown key %d", key);
+  // the one key that changes RESULTS (kernel phases switched off for timing experiments) needs an explicit unlock in the
+  // environment of the process: a stray BTC_TUNE entry must not be able to make a production run compute garbage
+  BTC_CHECK_ARG(key != BTC_TUNE_APPLY_DEBUG || value == 0 || getenv("BTC_ALLOW_WRONG_RESULTS") != nullptr,
+                "btc_tune_set: BTC_TUNE_APPLY_DEBUG produces wrong results; set BTC_ALLOW_WRONG_RESULTS=1 for timing experiments");
   g_tune[key] = value;
   return BTC_OK;
 }

@@ -1052,12 +1052,11 @@ int launch_apply(const float* feat, const float* W, const float* bias, const int
     int wgs = btc_cdiv(n_tiles16, WS_WAVES);
     if (wgs > 256) wgs = 256;
     size_t lds = ws_lds_bytes(K, Cred, nt);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::once_flag once;
+    std::call_once(once, [] {
       (void)hipFuncSetAttribute((const void*)conv_apply_ws<1, TRANS_W>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       (void)hipFuncSetAttribute((const void*)conv_apply_ws<2, TRANS_W>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      attr_set = true;
-    }
+    });
     if (nt == 1) conv_apply_ws<1, TRANS_W><<<wgs, WS_WAVES * 64, lds, stream>>>(feat, W, bias, nbr, n_rows, K, Cred, Cres, out);
     else conv_apply_ws<2, TRANS_W><<<wgs, WS_WAVES * 64, lds, stream>>>(feat, W, bias, nbr, n_rows, K, Cred, Cres, out);
     BTC_LAUNCH_CHECK();

@@ -235,7 +235,10 @@ class AnchorHeadSingle(nn.Module):
         if dirs is not None:
             self.forward_ret_dict["dir_cls_preds"] = dirs
         if self.training:
-            self.forward_ret_dict.update(self.target_assigner.assign_targets(self.anchors(x.device), data_dict["gt_boxes"]))
+            targets = data_dict.pop("rpn_targets", None)   # assigned ahead of the forward pass (BtcHotPath.prepare), else here
+            if targets is None:
+                targets = self.target_assigner.assign_targets(self.anchors(x.device), data_dict["gt_boxes"])
+            self.forward_ret_dict.update(targets)
         if not self.training or self.predict_boxes_when_training:
             data_dict["batch_cls_preds"], data_dict["batch_box_preds"] = self.generate_predicted_boxes(data_dict["batch_size"], cls, box, dirs)
             data_dict["cls_preds_normalized"] = False
@@ -270,7 +273,7 @@ class AnchorHeadSingle(nn.Module):
         cls_t = (labels * cared.type_as(labels)).long()
         one_hot = torch.zeros(*cls_t.shape, self.num_class + 1, dtype=cls_preds.dtype, device=cls_preds.device).scatter_(-1, cls_t.unsqueeze(-1), 1.0)[..., 1:]
         cls_loss = sigmoid_focal_loss(cls_preds.view(B, -1, self.num_class), one_hot, cls_w).sum() / B * w["cls_weight"]
-        tb = {"rpn_loss_cls": cls_loss.item()}
+        parts = [("rpn_loss_cls", cls_loss)]
         anchors = self._flat_anchors(cls_preds.device, B)
         box_preds, reg_t = f["box_preds"].view(B, -1, f["box_preds"].shape[-1] // self.num_anchors_per_location), f["box_reg_targets"]
         # sin(a - b) = sin a cos b - cos a sin b: the heading residual enters as that pair of products
@@ -279,7 +282,7 @@ class AnchorHeadSingle(nn.Module):
         t = torch.cat([reg_t[..., :6], t_rot, reg_t[..., 7:]], dim=-1)
         loc_loss = smooth_l1(p, t, reg_w).sum() / B * w["loc_weight"]
         box_loss = loc_loss
-        tb["rpn_loss_loc"] = loc_loss.item()
+        parts.append(("rpn_loss_loc", loc_loss))
         if "dir_cls_preds" in f:
             bins = self.model_cfg.NUM_DIR_BINS
             rot_gt = reg_t[..., 6] + anchors[..., 6]
@@ -288,9 +291,13 @@ class AnchorHeadSingle(nn.Module):
             dw = dw / torch.clamp(dw.sum(-1, keepdim=True), min=1.0)
             dir_loss = (F.cross_entropy(f["dir_cls_preds"].view(B, -1, bins).permute(0, 2, 1), dir_t, reduction="none") * dw).sum() / B * w["dir_weight"]
             box_loss = box_loss + dir_loss
-            tb["rpn_loss_dir"] = dir_loss.item()
+            parts.append(("rpn_loss_dir", dir_loss))
         loss = cls_loss + box_loss
-        tb["rpn_loss"] = loss.item()
+        parts.append(("rpn_loss", loss))
+        # the logged scalars (anchor_head_template.py: .item() per term) travel as ONE asynchronous copy and wait when read
+        from .occ_head import _lazy_scalars
+        vals = _lazy_scalars(torch.stack([v.detach().float() for _, v in parts]), len(parts))
+        tb = {k: v for (k, _), v in zip(parts, vals)}
         return loss, tb
 
 

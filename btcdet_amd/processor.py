@@ -128,10 +128,12 @@ class DataProcessor(object):
             pts = torch.from_numpy(np.ascontiguousarray(src, dtype=np.float32)).cuda()
             out = self._occ_gen.generate(cart_to_occ_coords(pts, self.occ_config.COORD_TYPE))
             out = {k: (v.cpu().numpy() if torch.is_tensor(v) else v) for k, v in out.items()}
-            if unrotated:   # azimuth of every slot, padded ones too, moves by the scene's rotation (:148-149)
+            if not data_dict["use_lead_xyz"]:   # the xyz columns go first (:141-142) ...
+                out["voxels"] = out["voxels"][..., 3:]
+            if unrotated:   # ... then column 1 of WHAT IS LEFT moves by the scene's rotation, padded slots too (:148-149)
                 data_dict.pop("pre_rot_points")
                 out["voxels"][..., 1] = out["voxels"][..., 1] - np.float32(data_dict["rot_z"])
-            return self._store(data_dict, "", out, data_dict["use_lead_xyz"])
+            return self._store(data_dict, "", out, True)
         return step
 
     def _build_det_voxels(self, cfg):

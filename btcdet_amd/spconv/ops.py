@@ -521,14 +521,15 @@ def _bf16_operands(features, K, cred, cres):
 def _weights_bf16(w, K, cin, cout):
     """(2, numel) bf16: row 0 = W [K][Cin][Cout], row 1 = W^T [K][Cout][Cin]; rebuilt when the parameter's version counter moved"""
     import weakref
-    hit = _WQ.get(id(w))
+    hit = _WQ.get(id(w)) if w.is_leaf else None
     if hit is not None and hit[0]() is w and hit[1] == w._version:
         return hit[2]
     q = torch.empty((2, w.numel()), dtype=torch.bfloat16, device=w.device)
     check(lib().btc_weights_to_bf16(ptr(w), int(K), int(cin), int(cout), ptr(q[0]), ptr(q[1]), stream_ptr()), "btc_weights_to_bf16")
-    if len(_WQ) > 4096:
-        for k in [k for k, v in _WQ.items() if v[0]() is None]:
-            del _WQ[k]
+    if not w.is_leaf:   # a temporary (the zero-padded 34 -> 48 channel weight is a fresh tensor every step): not cached
+        return q
+    for k in [k for k, v in _WQ.items() if v[0]() is None]:   # every miss drops the entries of freed parameters
+        del _WQ[k]
     _WQ[id(w)] = (weakref.ref(w), w._version, q)
     return q
 

@@ -63,10 +63,12 @@ def chunk_tables(sizes, device):
     """chunk tables of csrc/optim.hip for parameters of the given sizes laid out back to back in a flat buffer: chunks of <= 1024
     elements that never straddle two parameters -> dict(seg, off, len, flat: device tensors; seg0: host list, first chunk of each
     parameter)"""
+    from . import _lib
+    max_seg = int(_lib.lib().btc_adam_max_segments())   # pointer-table width of the loaded library (csrc/optim.hip GradPtrs)
     off, seg, coff, clen, cflat, seg0 = 0, [], [], [], [], [0]
     for i, n in enumerate(sizes):
         for c0 in range(0, n, 1024):
-            seg.append(i % 448); coff.append(c0); clen.append(min(1024, n - c0)); cflat.append(off + c0)
+            seg.append(i % max_seg); coff.append(c0); clen.append(min(1024, n - c0)); cflat.append(off + c0)
         seg0.append(len(seg))
         off += n
     i32 = lambda v: torch.tensor(v, dtype=torch.int32, device=device)

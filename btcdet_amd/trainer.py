@@ -1,0 +1,285 @@
+"""The data-parallel training step of the hot path: the body of the reference's loop
+(/root/reference/tools/train_utils/train_utils.py:103-124 -- zero_grad, model_fn, loss.backward, then per optimizer
+clip_grad_norm_ / step / lr_scheduler.step) with the schedules this repository measures.
+
+    trainer = HotPathTrainer(model, distributed=dist.is_initialized())      # BtcHotPath (+ optional dense heads)
+    for batch, next_batch in pairs(loader):
+        loss = trainer.step(batch, next_batch)
+
+Schedules (``schedule=``; config.schedule in bench.py's JSON names what ran):
+
+``in_order``    one stream, one thread, nothing ahead of its turn: prepare -> forward -> backward -> (all-reduce) -> both groups'
+                optimizer steps.  What a caller of the modules through the reference's own ``train_one_epoch_multi_opt`` gets
+                (bench.py reports it as ``config.in_order_scenes_per_s``).
+``split``       one stream; the branches are detached (PASS_GRAD False), so backward runs as two passes -- detection first -- and
+                the detection bucket's all-reduce travels during the occupancy branch's backward (round 2's N > 1 schedule).
+``pipelined``   (default) the detection branch on its own stream: its forward runs beside the occupancy branch's backward; once
+                that backward has returned, a worker thread all-reduces the occupancy bucket, steps the occupancy group, prepares
+                the NEXT batch's weight-independent front on the prefetch stream and runs the next batch's occupancy forward --
+                with the weights it has just updated -- while this thread runs the detection branch's backward, its bucket's
+                all-reduce and the detection group's step.  Every forward pass sees exactly the weights the in-order loop gives it
+                (tests/test_hip_prefetch.py); K steps contain K of everything.  With a process group the two collectives of a step
+                are issued in a fixed order on every rank (occupancy bucket of step i, detection bucket of step i, occupancy
+                bucket of step i + 1, ...: the worker hands over before the training thread launches), on one communicator.
+"""
+import os
+import threading
+
+import torch
+
+
+class MeanSquare(torch.autograd.Function):
+    """scale * mean(x^2): the L2 stand-in for consumers of the detection branch that are not built (the ROI head; without
+    --heads rpn also BEV backbone + anchor head), one reduction forward and one elementwise launch backward"""
+
+    @staticmethod
+    def forward(ctx, x, scale):
+        ctx.save_for_backward(x)
+        ctx.k = float(scale) / max(x.numel(), 1)
+        n = torch.linalg.vector_norm(x.reshape(-1), dtype=torch.float32)
+        return n * n * ctx.k
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        return (x * (g * (2.0 * ctx.k)).to(x.dtype)), None
+
+
+def stand_in_det_loss(ret, batch_dict):
+    """L2 stand-ins for both consumers of the detection branch (bench.py's headline configuration)"""
+    return MeanSquare.apply(ret["spatial_features"], 1e-3) + MeanSquare.apply(ret["x_combine"], 1e-3)
+
+
+def make_step(model, ddp, proc, opts, grad_sync=None, prefetch_stream=None, threaded=True, det_stream=None, opt_stream=None,
+              det_loss=None, pipeline=None):
+    """one training step of the hot path -> step(batch, next_batch=None) -> detached loss.
+
+    prefetch_stream: the weight-independent front of the NEXT batch (voxelizations, occupancy targets, the occupancy branch's
+    rulebooks: BtcHotPath.prepare) runs on that stream beside this batch's backward pass -- the role DataLoader workers play
+    for the reference's CPU voxelizer: from a worker thread while the main thread sits in backward (threaded), or from this
+    thread once the backward pass is enqueued.  Every step still does exactly one batch's worth of that work.
+
+    det_stream (not under DistributedDataParallel, which wants one backward per forward): the detection branch is detached
+    from the occupancy branch (PASS_GRAD False), so the occupancy branch's BACKWARD does not have to wait for the detection
+    branch's FORWARD.  The worker thread calls loss_occ.backward() (autograd runs those nodes on the main stream, where
+    their forward ran) while this thread runs the detection branch on det_stream.
+
+    grad_sync: a BucketedGradSync.  With `grad_sync.bucket_of = {"occ": i, "det": j}` (HotPathTrainer sets it) the pipelined
+    schedule runs under the reducer too: each thread launches and awaits ITS bucket behind its backward pass.  Without that
+    attribute the one-stream schedules are used (split_backward: detection bucket between the two backward passes).
+
+    det_loss(ret, batch_dict) -> scalar: the detection branch's loss (default: the L2 stand-ins)."""
+    from .spconv import ops as _ops
+    det_loss = det_loss or stand_in_det_loss
+    pending = {}
+    pool = None
+    if (prefetch_stream is not None and threaded) or det_stream is not None:
+        from concurrent.futures import ThreadPoolExecutor
+        pool = ThreadPoolExecutor(max_workers=1)
+    device = next(model.parameters()).device
+    split_backward = grad_sync is not None and ddp is model and len(grad_sync.buckets) > 1 and getattr(grad_sync, "split_backward", False)
+    bucket_of = getattr(grad_sync, "bucket_of", None) if grad_sync is not None else None
+
+    def prep(next_batch):
+        torch.cuda.set_device(device)
+        return model.prepare(next_batch, stream=prefetch_stream)
+
+    def occ_backward(loss):
+        torch.cuda.set_device(device)
+        loss.backward()
+
+    # pipelined variant of the det_stream schedule: once the occupancy branch's backward has returned, the worker thread goes on
+    # -- the occupancy bucket's all-reduce (process group), the occupancy group's optimizer step (its gradients are complete), the
+    # next batch's weight-independent front on the prefetch stream and the next batch's OCCUPANCY FORWARD on the main stream with
+    # the updated occupancy weights -- while this thread runs the detection branch's backward, its bucket's all-reduce and its
+    # optimizer step on det_stream.  Nothing is skipped and nothing uses stale weights: the occupancy branch of step i + 1 needs
+    # the occupancy weights of step i (updated before it runs) and batch i + 1; the detection branch of step i + 1 starts behind
+    # step i's detection optimizer on det_stream.  Two backward passes never run at the same time (the weight-gradient side
+    # stream's join bookkeeping assumes one).
+    if pipeline is None:
+        pipeline = os.environ.get("BTC_PIPELINE_OCC", "1") != "0"
+    pipeline = bool(pipeline and det_stream is not None and ddp is model and (grad_sync is None or bucket_of is not None)
+                    and prefetch_stream is not None and threaded and len(opts) == 1 and hasattr(opts[0], "groups") and len(opts[0].groups) == 2)
+    ahead_occ = {}
+
+    def occ_tail(loss_occ, next_batch, occ_done):
+        torch.cuda.set_device(device)
+        try:
+            loss_occ.backward()
+            _ops.join_wgrad()            # (no-op: the end-of-pass callback has joined the side stream into this thread's stream)
+            if grad_sync is not None:    # issued BEFORE the hand-over: every rank's order is occupancy bucket, then detection bucket
+                grad_sync.launch(bucket_of["occ"])
+        finally:
+            occ_done.set()
+        if grad_sync is not None:
+            grad_sync.wait(bucket_of["occ"])
+        opts[0].step(groups=[0])         # occupancy group, on the main stream behind its backward (and its all-reduce)
+        if next_batch is None:
+            return None
+        return occ_forward(model.prepare(next_batch, stream=prefetch_stream))
+
+    def occ_forward(bd):
+        out = model.forward_occ(bd)
+        done = torch.cuda.Event()
+        done.record()                    # the loss tensor is complete on this (the main) stream
+        return out + (done,)
+
+    def step_pipelined(batch, next_batch):
+        opts[0].zero_grad(set_to_none=True)
+        cur = ahead_occ.pop(id(batch), None)
+        ahead_occ.clear()
+        if cur is None:
+            bd = pending.pop(id(batch), None)
+            cur = occ_forward(bd if bd is not None else model.prepare(batch))
+        pending.clear()
+        bd, loss_occ, tb, inputs_ready, occ_fwd_done = cur
+        occ_done = threading.Event()
+        fut = pool.submit(occ_tail, loss_occ, next_batch, occ_done)
+        with torch.cuda.stream(det_stream):
+            ret, bd = model.forward_det(bd, inputs_ready)
+            loss_det = det_loss(ret, bd)
+        occ_done.wait()
+        with torch.cuda.stream(det_stream):
+            loss_det.backward()
+            _ops.join_wgrad()
+            if grad_sync is not None:
+                grad_sync.launch(bucket_of["det"])
+                grad_sync.wait(bucket_of["det"])
+            opts[0].step(groups=[1])     # detection group, on det_stream behind its backward (and its all-reduce)
+            det_stream.wait_event(occ_fwd_done)
+            loss_occ.record_stream(det_stream)
+            loss = loss_occ.detach() + loss_det.detach()
+            model.mark_step_end(stream=det_stream, upto=bd.get("__gen_id__", -1))
+        nxt = fut.result()
+        if nxt is not None:
+            ahead_occ[id(next_batch)] = nxt
+        return loss
+
+    def step(batch, next_batch=None):
+        if pipeline:
+            return step_pipelined(batch, next_batch)
+        for o in opts:
+            o.zero_grad(set_to_none=True)
+        bd = pending.pop(id(batch), None)
+        if bd is None:
+            bd = model.prepare(batch)
+        pending.clear()
+        ahead = prefetch_stream is not None and next_batch is not None
+        fut = None
+        if det_stream is not None and ddp is model:
+            main = torch.cuda.current_stream()
+            bd, loss_occ, tb, inputs_ready = model.forward_occ(bd)
+            fut_occ = pool.submit(occ_backward, loss_occ)
+            with torch.cuda.stream(det_stream):
+                ret, bd = model.forward_det(bd, inputs_ready)
+                loss_det = det_loss(ret, bd)
+            fut_occ.result()
+            if grad_sync is not None:
+                grad_sync.launch_ready()  # the occupancy bucket travels during the detection branch's backward
+            fut = pool.submit(prep, next_batch) if (ahead and threaded) else None
+            with torch.cuda.stream(det_stream):
+                loss_det.backward()
+            main.wait_stream(det_stream)
+            loss = loss_occ.detach() + loss_det.detach()
+        else:
+            ret, tb, bd = ddp(bd)
+            loss_det = det_loss(ret, bd)
+            fut = pool.submit(prep, next_batch) if (ahead and threaded) else None
+            if opt_stream is not None:
+                with torch.cuda.stream(opt_stream):
+                    loss_det.backward()
+                    opts[0].step(groups=[1])
+                ret["loss_occ"].backward()
+                loss = ret["loss_occ"].detach() + loss_det.detach()
+            elif split_backward:
+                # the branches are detached (PASS_GRAD False): two backward passes give the same gradients as one over the sum.
+                # The detection bucket (~90 % of the bytes) is packed and all-reduced BETWEEN them, from this thread -- it travels
+                # over xGMI while the occupancy branch's backward runs, with no hook in the autograd thread
+                loss_det.backward()
+                grad_sync.launch_ready()
+                ret["loss_occ"].backward()
+                loss = ret["loss_occ"].detach() + loss_det.detach()
+            else:
+                loss = ret["loss_occ"] + loss_det
+                loss.backward()
+        if fut is not None:
+            pending[id(next_batch)] = fut.result()
+        _ops.join_wgrad()   # no-op unless weight gradients are still owed (e.g. a backward pass whose end-of-pass callback never ran)
+        if grad_sync is not None:
+            grad_sync.finish()  # all-reduced mean gradients in the buckets (and in param.grad with assign_grads)
+        if opt_stream is not None:
+            opts[0].step(groups=[0])
+            torch.cuda.current_stream().wait_stream(opt_stream)
+        else:
+            for o in opts:
+                o.step()
+        if ahead and not threaded:
+            pending[id(next_batch)] = model.prepare(next_batch, stream=prefetch_stream)
+        model.mark_step_end()
+        return loss
+    step.end_stream = det_stream if pipeline else None   # where a step's last kernel runs (per-step timing marks)
+    step.pipelined = pipeline
+    return step
+
+
+def reference_groups(model, world=1, epochs=40, frames=3712, batch_size=2):
+    """the two parameter groups of the reference's two optimizers with the yaml's OPTIMIZATION / OCC_OPTIMIZATION constants
+    (btcdet_kitti_car.yaml:331-372: adam_onecycle, norm clip 10, OneCycle over `epochs` x `frames` KITTI training frames)
+    -> (groups for GroupOptimizer in the order [occupancy, detection], total optimizer steps)"""
+    occ = [p for p in model.occ_modules.parameters() if p.requires_grad]
+    det = [p for p in model.det_modules.parameters() if p.requires_grad]
+    sched = dict(grad_norm_clip=10.0, moms=(0.95, 0.85), div_factor=10.0, pct_start=0.4, lr_clip=1e-7)
+    groups = [dict(params=occ, lr=0.003, weight_decay=0.001, **sched), dict(params=det, lr=0.01, weight_decay=0.01, **sched)]
+    return groups, epochs * (frames // (batch_size * world))
+
+
+class HotPathTrainer(object):
+    """the step above as an object: owns the optimizer (GroupOptimizer over the reference's two groups), the gradient reducer
+    when a process group exists, the streams and the worker thread of the chosen schedule."""
+
+    def __init__(self, model, groups=None, total_steps=None, schedule=None, distributed=None, det_loss=None, process_group=None,
+                 optimizer=None):
+        import torch.distributed as dist
+        from .spconv import ops
+        from .train_step import GroupOptimizer
+        self.model = model
+        self.device = next(model.parameters()).device
+        if distributed is None:
+            distributed = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(process_group) if distributed else 1
+        schedule = schedule or os.environ.get("BTC_SCHEDULE", "pipelined")
+        if schedule not in ("in_order", "split", "pipelined"):
+            raise ValueError("schedule must be in_order, split or pipelined, got %r" % (schedule,))
+        self.schedule = schedule
+        if optimizer is None:
+            if groups is None:
+                groups, auto_total = reference_groups(model, self.world)
+                total_steps = total_steps or auto_total
+            optimizer = GroupOptimizer(groups, total_steps)
+        self.optimizer = optimizer
+        self.grad_sync = None
+        if distributed:
+            from .grad_sync import BucketedGradSync
+            for p in model.parameters():   # same start on every rank (DistributedDataParallel does this broadcast in its constructor)
+                dist.broadcast(p.data, src=0, group=process_group)
+            for b in model.buffers():
+                dist.broadcast(b.data, src=0, group=process_group)
+            gs = [g["params"] for g in optimizer.groups]
+            self.grad_sync = BucketedGradSync([(gs[0], None), (gs[1], None)], process_group=process_group, assign_grads=False)
+            self.grad_sync.bucket_of = {"occ": 0, "det": 1}
+            self.grad_sync.split_backward = schedule == "split"
+            if schedule == "split":    # the detection bucket goes first there (launch_ready between the two backward passes)
+                self.grad_sync.buckets.reverse()
+                self.grad_sync.bucket_of = {"occ": 1, "det": 0}
+            optimizer.read_grads_from(self.grad_sync.view_of, self.grad_sync.has_grad, self.grad_sync.missing)
+        ops.set_defer_wgrad_join(os.environ.get("BTC_DEFER_WGRAD", "1") != "0")
+        cuda = self.device.type == "cuda"
+        self.prefetch_stream = torch.cuda.Stream(device=self.device, priority=-1) if (cuda and schedule != "in_order") else None
+        self.det_stream = torch.cuda.Stream(device=self.device) if (cuda and schedule == "pipelined") else None
+        self._step = make_step(model, model, model.dataset.data_processor, [optimizer], self.grad_sync, self.prefetch_stream,
+                               threaded=True, det_stream=self.det_stream, det_loss=det_loss, pipeline=schedule == "pipelined")
+        self.end_stream = self._step.end_stream
+
+    def step(self, batch, next_batch=None):
+        """one optimizer step on `batch`; next_batch (optional) lets the schedule prepare / start it ahead"""
+        return self._step(batch, next_batch)

@@ -62,28 +62,13 @@ class MeanVFE(VFETemplate):
             check(lib().btc_mean_vfe(ptr(vox), ptr(n), isf, M, P, C, ptr(out), stream_ptr()), "btc_mean_vfe")
             batch_dict['voxel_features'] = out
             return batch_dict
+        if self.maxprob or self.OCC_CODE is not None:
+            # options of mean_vfe.py:47-67 that no configuration of this repository's scope reaches (the occupancy branch builds
+            # its VFE with maxprob=False, detector3d_template.py:160-162; OCC_CODE is absent from the yaml): refuse, like the
+            # other unconfigured options, rather than carry an untested transcription
+            raise NotImplementedError("MeanVFE: maxprob / OCC_CODE are not configured on the BtcDet hot path")
         normalizer = torch.clamp_min(num.view(-1, 1), min=1.0).type_as(vox)
-        if not self.maxprob:
-            batch_dict['voxel_features'] = (vox.sum(dim=1) / normalizer).contiguous()
-        else:
-            mask = _slot_mask(num, vox.shape[1])
-            raw_mask = (vox[:, :, -1] < 0.1) & mask
-            raw_norm = torch.clamp_min(raw_mask.sum(dim=1).view(-1, 1), min=1.0).type_as(vox)
-            xyz_mean = vox[:, :, :self.xyz_dim].sum(dim=1) / normalizer
-            inten_mean = vox[:, :, self.xyz_dim:self.num_raw_features].sum(dim=1) / raw_norm
-            occ_max = vox[:, :, self.num_raw_features:].max(dim=1)[0]
-            batch_dict['voxel_features'] = torch.cat([xyz_mean, inten_mean, occ_max], dim=-1).contiguous()
-        if self.OCC_CODE is not None:  # not configured for BtcDet-KITTI; kept for interface completeness
-            f = batch_dict['voxel_features']
-            M, F = f.shape
-            occ_bzyx = torch.nonzero((batch_dict["general_cls_loss_mask"] & (1 - batch_dict["voxelwise_mask"])) > 0)
-            N = occ_bzyx.shape[0]
-            batch_dict['voxel_coords'] = torch.cat([batch_dict['voxel_coords'], occ_bzyx], dim=0)
-            if not self.OCC_CODE:
-                batch_dict['voxel_features'] = torch.cat([f, f.new_zeros(N, F)], dim=0)
-            else:
-                batch_dict['voxel_features'] = torch.cat([torch.cat([f, f.new_ones(M, 1)], dim=-1),
-                                                          f.new_zeros(N, F + 1)], dim=0)
+        batch_dict['voxel_features'] = (vox.sum(dim=1) / normalizer).contiguous()
         return batch_dict
 
 

@@ -277,6 +277,7 @@ int btc_conv_wgrad_ordered(int bf16_act, const void* feat, const void* dout, con
  * step = the 1-based count of this update.  ws: btc_adam_group_ws_bytes(n_chunks); its first 8 bytes hold ||g||^2 (double)
  * after the call. */
 #define BTC_ADAM_MAX_SEGMENTS 448
+int btc_adam_max_segments(void);   /* = BTC_ADAM_MAX_SEGMENTS of the loaded library: what chunk_seg[] must be reduced by */
 size_t btc_adam_group_ws_bytes(int n_chunks);
 /* flat[chunk_flat[c] + e] = grads[s][chunk_off[c] + e]: packs a list of gradients into a flat bucket (the buffer a
  * data-parallel all-reduce runs on) in one launch; same chunk tables as btc_adam_group_step */

@@ -58,11 +58,12 @@ def _sync_worker(rank, world, port, out):
     b = torch.nn.Sequential(torch.nn.Linear(4, 8), torch.nn.ReLU(), torch.nn.Linear(8, 2))
     launched = []
     sync = BucketedGradSync([(list(b.parameters()), a[2].weight), (list(a.parameters()), None)])
-    orig = sync._launch
-    sync._launch = lambda bk, early=True: (launched.append((sync.buckets.index(bk), early, all(p.grad is not None for p in bk.params))), orig(bk, early))[1]
+    orig = sync.launch
+    sync.launch = lambda bk, only_if_complete=False: (launched.append((sync.buckets.index(bk), only_if_complete,
+                                                                         all(p.grad is not None for p in bk.params))), orig(bk, only_if_complete))[1]
     for h in sync._handles:
         h.remove()
-    sync._handles = [a[2].weight.register_post_accumulate_grad_hook(lambda p: sync._launch(sync.buckets[0]))]
+    sync._handles = [a[2].weight.register_post_accumulate_grad_hook(lambda p: sync.launch(sync.buckets[0], only_if_complete=True))]
     x = torch.from_numpy(np.random.default_rng(10 + rank).standard_normal((16, 6)).astype(np.float32))
     local = None
     for it in range(2):
@@ -146,3 +147,51 @@ def test_one_bucket_reducer_feeds_the_optimizer_gloo_world2():
     for a, b, r in zip(p0, p1, r0):
         np.testing.assert_allclose(a, b, rtol=0, atol=0)              # ranks stay in lockstep
         np.testing.assert_allclose(a, r, rtol=2e-5, atol=2e-6)
+
+
+def _missing_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    from btcdet_amd.grad_sync import BucketedGradSync, GradSyncError
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(3)
+    net = torch.nn.ModuleList([torch.nn.Linear(4, 4), torch.nn.Linear(4, 4)])
+    params = list(net.parameters())
+    sync = BucketedGradSync([(params, None)], assign_grads=False)
+    x = torch.ones(2, 4)
+    events = []
+    for it in range(3):
+        for p in params:
+            p.grad = None
+        # step 0: every rank uses both layers; step 1: rank 1 skips the second layer (its parameters get no gradient there);
+        # step 2: consistent again -- the launch of step 2 looks at step 1's reduced count and must raise on BOTH ranks
+        y = net[0](x)
+        if not (it == 1 and rank == 1):
+            y = net[1](y)
+        y.sum().backward()
+        try:
+            sync.finish()
+            events.append(("ok", sorted(sync.local_missing()) != [], all(sync.has_grad(p) for p in params)))
+        except GradSyncError as e:
+            events.append(("raised", str(e)[:40]))
+            break
+    out[rank] = events
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_reducer_raises_on_every_rank_when_ranks_disagree_on_used_parameters_gloo_world2():
+    """a parameter with a gradient on one rank and none on another used to make the ranks apply
+    different updates silently.  Now every parameter of a reduced bucket counts as present on every rank (zeros from the rank
+    that had none), and the disagreement -- carried through the same collective -- raises on every rank one step later, the
+    contract of DistributedDataParallel(find_unused_parameters=False) the reference trains under (tools/train.py:166-168)."""
+    world, port = 2, 29771
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_missing_worker, args=(world, port, out), nprocs=world, join=True)
+    for r in range(world):
+        ev = out[r]
+        assert ev[0][0] == "ok" and ev[0][1] is False and ev[0][2] is True
+        assert ev[1][0] == "ok" and ev[1][2] is True            # the inconsistent step itself: same (mean) update everywhere
+        assert ev[1][1] is (r == 1)                             # only rank 1 had local gaps
+        assert ev[2][0] == "raised", ev                         # ... and both ranks raise at the next launch
