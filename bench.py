@@ -222,16 +222,32 @@ def main():
     all_cpus = os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else None
     pinned = pin_to_gpu(dev_index, local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))
     dist = None
+
+    class _StdoutToStderr(object):
+        """RCCL prints a version banner to STDOUT when a communicator is created; this script's stdout is ONE JSON line"""
+
+        def __enter__(self):
+            sys.stdout.flush()
+            self.saved = os.dup(1)
+            os.dup2(2, 1)
+
+        def __exit__(self, *a):
+            sys.stdout.flush()
+            os.dup2(self.saved, 1)
+            os.close(self.saved)
+
     # BTC_BENCH_FORCE_DIST=1: take the distributed path (process group, reducer, barriers) at world size 1 too --
     # the way to exercise the RCCL code path on a single-GPU box
     use_dist = world > 1 or os.environ.get("BTC_BENCH_FORCE_DIST") == "1"
     if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if backend == "nccl":
-            dist.init_process_group(backend="nccl", **({} if os.environ.get("BTC_BENCH_LAZY_NCCL") == "1" else {"device_id": device}))
-        else:
-            dist.init_process_group(backend=backend)
+        with _StdoutToStderr():
+            if backend == "nccl":
+                dist.init_process_group(backend="nccl", **({} if os.environ.get("BTC_BENCH_LAZY_NCCL") == "1" else {"device_id": device}))
+            else:
+                dist.init_process_group(backend=backend)
+            dist.barrier()   # the communicator exists (and has printed its banner) before anything else happens
 
     from btcdet_amd.btc_path import BtcHotPath
     from btcdet_amd.config import load_cfg
@@ -270,7 +286,10 @@ def main():
     # clip at 10, adam_onecycle = decoupled weight decay + Adam(betas=(mom, 0.99)) with lr / mom on the OneCycle schedule of a
     # 40-epoch run over KITTI's 3712 training frames -- btcdet_amd/train_step.py (checked against the reference's own
     # OptimWrapper / OneCycle, tests/test_train_step_cpu.py).  The two optimizers are the two groups of one object.
-    trainer = HotPathTrainer(model, schedule=schedule, distributed=use_dist, det_loss=model.det_loss)
+    # (BTC_BENCH_NOSYNC=1: process group without a reducer -- an A/B knob for what the group itself costs)
+    with_reducer = use_dist and os.environ.get("BTC_BENCH_NOSYNC") != "1"
+    with _StdoutToStderr():
+        trainer = HotPathTrainer(model, schedule=schedule, distributed=with_reducer, det_loss=model.det_loss)
     step, grad_sync, opt = trainer._step, trainer.grad_sync, trainer.optimizer
     if trainer.det_stream is not None and "BTC_DET_WALK_ASYNC" not in os.environ:
         # the detection branch's rulebook walk beside its first stage buys nothing once the whole branch runs beside the occupancy
@@ -334,7 +353,8 @@ def main():
         # dense 2-D convs = vendor library): a second model, trainer and optimizer, run after the headline measurement
         del plain_step
         model_r = build_model("rpn")
-        tr_r = HotPathTrainer(model_r, schedule=schedule, distributed=use_dist, det_loss=model_r.det_loss)
+        with _StdoutToStderr():
+            tr_r = HotPathTrainer(model_r, schedule=schedule, distributed=with_reducer, det_loss=model_r.det_loss)
         k_r = min(args.steps, 10)
         dt_r, ms_r, _ = timed_run(tr_r._step, k_r, 12, tr_r._step.end_stream)
         dt_r = max_over_ranks(dt_r, dist, device)

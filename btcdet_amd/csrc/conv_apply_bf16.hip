@@ -68,6 +68,8 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_apply_b(const unsigned shor
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave / WC, wc = wave % WC;
+  const int mirror = (xcd_swizzle >> 1) & 1;   // bit 1: a submanifold FORWARD map read as the backward map (column K-1-k), see conv_apply_g
+  xcd_swizzle &= 1;
   int bx = blockIdx.x;
   if (xcd_swizzle) {
     const int nb = gridDim.x, per = nb >> 3, main = per << 3;
@@ -82,7 +84,7 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_apply_b(const unsigned shor
   for (int e = tid; e < TM * K; e += THREADS) {
     const int rloc = e / K, kk = e - rloc * K;
     const int gr = s_row[rloc];
-    const int v = gr >= 0 ? nbr[(long long)gr * K + kk] : -1;
+    const int v = gr >= 0 ? nbr[(long long)gr * K + (mirror ? K - 1 - kk : kk)] : -1;
     s_nbr[e] = v;
     if (v >= 0) s_kact[kk] = 1;
   }
@@ -218,13 +220,13 @@ int launch_b_kc(int kc, const unsigned short* feat, const unsigned short* Wq, co
 }
 
 int apply_b(const void* feat_, const void* Wq_, const float* bias, const int32_t* nbr, const int32_t* order, int n_rows, int K, int Cred, int Cres,
-            void* out_, hipStream_t stream) {
+            void* out_, hipStream_t stream, int mirror) {
   if (n_rows <= 0) return BTC_OK;
   const unsigned short* feat = (const unsigned short*)feat_;
   const unsigned short* Wq = (const unsigned short*)Wq_;
   unsigned short* out = (unsigned short*)out_;
   const int kc = (Cred % 64 == 0) ? 64 : 32;
-  const int xcd = btc_tune_get(BTC_TUNE_APPLY_XCD) == 2;
+  const int xcd = (btc_tune_get(BTC_TUNE_APPLY_XCD) == 2 ? 1 : 0) | (mirror ? 2 : 0);   // kernel flags: bit 0 XCD mapping, bit 1 mirrored map
   // wave shapes as conv_apply_g's policy (sparse_conv.hip): 64 rows x 128 columns on 8 waves for wide results, 16-row
   // workgroups with 4 waves across the columns when there are few rows
   if (Cres % 128 == 0) return launch_b_kc<4, 2, 4>(kc, feat, Wq, bias, nbr, order, n_rows, K, Cred, Cres, out, xcd, stream);
@@ -252,8 +254,8 @@ __global__ __launch_bounds__(256) void weights_to_bf16(const float* __restrict__
 }  // namespace
 
 int btc_apply_bf16w(const void* src, const void* Wq, const float* bias, const int32_t* nbr, const int32_t* order, int n_rows, int K, int Cred,
-                    int Cres, void* dst, hipStream_t stream) {
-  return apply_b(src, Wq, bias, nbr, order, n_rows, K, Cred, Cres, dst, stream);
+                    int Cres, void* dst, hipStream_t stream, int mirror) {
+  return apply_b(src, Wq, bias, nbr, order, n_rows, K, Cred, Cres, dst, stream, mirror);
 }
 
 extern "C" int btc_conv_bf16w_supported(int K, int Cred, int Cres) { return K >= 1 && K <= 64 && Cred >= 32 && Cred % 32 == 0 && Cres % 16 == 0; }

@@ -70,6 +70,10 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_apply_g(const void* __restr
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave / WC, wc = wave % WC;
+  // bit 1 of the flags: the map is a submanifold layer's FORWARD map read as its backward map -- column K-1-k of nbr is
+  // offset k of the transposed map (rulebook.hip: the two are mirror images, so nbr_in is never materialised)
+  const int mirror = (xcd_swizzle >> 1) & 1;
+  xcd_swizzle &= 1;
   int bx = blockIdx.x;
   if (xcd_swizzle) {  // workgroups are dealt round-robin to the 8 XCDs: give XCD x the contiguous tile range x
     const int nb = gridDim.x, per = nb >> 3, main = per << 3;
@@ -84,7 +88,7 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_apply_g(const void* __restr
   for (int e = tid; e < TM * K; e += THREADS) {
     const int rloc = e / K, kk = e - rloc * K;
     const int gr = s_row[rloc];
-    const int v = gr >= 0 ? nbr[(long long)gr * K + kk] : -1;
+    const int v = gr >= 0 ? nbr[(long long)gr * K + (mirror ? K - 1 - kk : kk)] : -1;
     s_nbr[e] = v;
     if (v >= 0) s_kact[kk] = 1;
   }

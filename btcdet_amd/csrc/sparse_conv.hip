@@ -34,7 +34,8 @@ __host__ __device__ constexpr int ldb_of(int nt) { return nt * 16 + (((nt * 16) 
 template <int NT, bool TRANS_W, bool VEC, int KB, int THREADS>
 __global__ __launch_bounds__(THREADS) void conv_apply(const float* __restrict__ feat, const float* __restrict__ W,
                                                   const float* __restrict__ bias, const int32_t* __restrict__ nbr,
-                                                  int n_rows, int K, int Cred, int Cres, float* __restrict__ out) {
+                                                  int n_rows, int K, int Cred, int Cres, float* __restrict__ out, int mirror) {
+  // mirror: `nbr` is a submanifold layer's forward map read as its backward map -- column K-1-k holds offset k (rulebook.hip)
   // KB > 1 (narrow layers, Cred <= 32: one chunk per offset): KB active offsets are staged per phase, which divides the
   // number of barrier-separated phases by KB and multiplies the loads in flight per workgroup by KB.
   // THREADS = 256 / 128 / 64 -> 64 / 32 / 16 output rows per workgroup (one 16-row MFMA slab per wave): small and
@@ -59,9 +60,10 @@ __global__ __launch_bounds__(THREADS) void conv_apply(const float* __restrict__ 
     const long long gbase = (long long)row0 * K;
     const long long gend = (long long)n_rows * K;
     for (int e = tid; e < TM * K; e += THREADS) {
-      int v = (gbase + e < gend) ? nbr[gbase + e] : -1;
+      const int kk = e % K;
+      int v = (gbase + e < gend) ? nbr[mirror ? gbase + e - kk + (K - 1 - kk) : gbase + e] : -1;
       s_nbr[e] = v;
-      if (v >= 0) s_kact[e % K] = 1;
+      if (v >= 0) s_kact[kk] = 1;
     }
   }
   __syncthreads();
@@ -214,7 +216,7 @@ __host__ __device__ inline size_t ws_lds_bytes(int K, int Cred, int nt) {
 template <int NT, bool TRANS_W>
 __global__ __launch_bounds__(WS_WAVES * 64) void conv_apply_ws(const float* __restrict__ feat, const float* __restrict__ W,
                                                               const float* __restrict__ bias, const int32_t* __restrict__ nbr,
-                                                              int n_rows, int K, int Cred, int Cres, float* __restrict__ out) {
+                                                              int n_rows, int K, int Cred, int Cres, float* __restrict__ out, int mirror) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int LDW = NT * 16;
   constexpr int QMAX = KC / 4;  // k-steps of a full 32-channel row
@@ -258,9 +260,10 @@ __global__ __launch_bounds__(WS_WAVES * 64) void conv_apply_ws(const float* __re
     {
       const long long gbase = (long long)row0 * K, gend = (long long)n_rows * K;
       for (int e = lane; e < 16 * K; e += 64) {
-        int v = (gbase + e < gend) ? nbr[gbase + e] : -1;
+        const int kk = e % K;
+        int v = (gbase + e < gend) ? nbr[mirror ? gbase + e - kk + (K - 1 - kk) : gbase + e] : -1;
         nb[e] = v;
-        if (v >= 0) kmask |= 1ull << (e % K);
+        if (v >= 0) kmask |= 1ull << kk;
       }
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) kmask |= __shfl_xor(kmask, o, 64);
@@ -988,14 +991,14 @@ __global__ __launch_bounds__(256) void dense_bwd_k(const float* __restrict__ dde
 
 template <int NT, bool TRANS_W, int THREADS>
 void launch_apply_t(dim3 grid, size_t lds, hipStream_t stream, bool vec, const float* feat, const float* W, const float* bias,
-                    const int32_t* nbr, int n_rows, int K, int Cred, int Cres, float* out) {
-  if (vec) conv_apply<NT, TRANS_W, true, 1, THREADS><<<grid, THREADS, lds, stream>>>(feat, W, bias, nbr, n_rows, K, Cred, Cres, out);
-  else conv_apply<NT, TRANS_W, false, 1, THREADS><<<grid, THREADS, lds, stream>>>(feat, W, bias, nbr, n_rows, K, Cred, Cres, out);
+                    const int32_t* nbr, int n_rows, int K, int Cred, int Cres, float* out, int mirror) {
+  if (vec) conv_apply<NT, TRANS_W, true, 1, THREADS><<<grid, THREADS, lds, stream>>>(feat, W, bias, nbr, n_rows, K, Cred, Cres, out, mirror);
+  else conv_apply<NT, TRANS_W, false, 1, THREADS><<<grid, THREADS, lds, stream>>>(feat, W, bias, nbr, n_rows, K, Cred, Cres, out, mirror);
 }
 
 template <bool TRANS_W>
 int launch_apply(const float* feat, const float* W, const float* bias, const int32_t* nbr, int n_rows, int K, int Cred,
-                 int Cres, float* out, hipStream_t stream, bool bf = false, const int32_t* order = nullptr) {
+                 int Cres, float* out, hipStream_t stream, bool bf = false, const int32_t* order = nullptr, int mirror = 0) {
   // order: optional row-order hint (row_order.hip); only the LDS-DMA kernel tiles by it, the others ignore it (same results)
   // bf: feat / out are bfloat16 (passed through the float* parameters); only the LDS-DMA kernel has that variant
   if (n_rows <= 0) return BTC_OK;
@@ -1042,7 +1045,7 @@ int launch_apply(const float* feat, const float* W, const float* bias, const int
     const int t_kc = btc_tune_get(BTC_TUNE_APPLY_KC);
     if (t_kc && Cred % t_kc == 0) kc = t_kc;
     while (kc > 16 && btc_apply_glds_lds_bytes(shape, kc, K, bf) > 160 * 1024) kc >>= 1;  // 3-stage ring + map tile
-    return btc_launch_apply_glds(TRANS_W, shape, kc, t_xcd == 2, bf, feat, W, bias, nbr, order, n_rows, K, Cred, Cres, out, stream);
+    return btc_launch_apply_glds(TRANS_W, shape, kc, (t_xcd == 2 ? 1 : 0) | (mirror ? 2 : 0), bf, feat, W, bias, nbr, order, n_rows, K, Cred, Cres, out, stream);
   }
   // weight-stationary persistent kernel (one 16-wave workgroup per CU).  Measured on MI355X: its dword-granular register
   // gather wins 2.5x for Cred <= 8 (the dgrad of the 2/3-channel occupancy heads, the 4/6-channel input layers) and loses
@@ -1057,8 +1060,8 @@ int launch_apply(const float* feat, const float* W, const float* bias, const int
       (void)hipFuncSetAttribute((const void*)conv_apply_ws<1, TRANS_W>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       (void)hipFuncSetAttribute((const void*)conv_apply_ws<2, TRANS_W>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     });
-    if (nt == 1) conv_apply_ws<1, TRANS_W><<<wgs, WS_WAVES * 64, lds, stream>>>(feat, W, bias, nbr, n_rows, K, Cred, Cres, out);
-    else conv_apply_ws<2, TRANS_W><<<wgs, WS_WAVES * 64, lds, stream>>>(feat, W, bias, nbr, n_rows, K, Cred, Cres, out);
+    if (nt == 1) conv_apply_ws<1, TRANS_W><<<wgs, WS_WAVES * 64, lds, stream>>>(feat, W, bias, nbr, n_rows, K, Cred, Cres, out, mirror);
+    else conv_apply_ws<2, TRANS_W><<<wgs, WS_WAVES * 64, lds, stream>>>(feat, W, bias, nbr, n_rows, K, Cred, Cres, out, mirror);
     BTC_LAUNCH_CHECK();
     return BTC_OK;
   }
@@ -1073,7 +1076,7 @@ int launch_apply(const float* feat, const float* W, const float* bias, const int
   dim3 grid(n_tiles, btc_cdiv(Cres, nt * 16));
   size_t lds = (size_t)(tm * LDA + KC * ldb_of(nt)) * sizeof(float) + (size_t)(tm * K + K + 1) * sizeof(int32_t);
   const bool vec = (Cred & 3) == 0;
-#define BTC_APPLY(NT_) launch_apply_t<NT_, TRANS_W, 256>(grid, lds, stream, vec, feat, W, bias, nbr, n_rows, K, Cred, Cres, out)
+#define BTC_APPLY(NT_) launch_apply_t<NT_, TRANS_W, 256>(grid, lds, stream, vec, feat, W, bias, nbr, n_rows, K, Cred, Cres, out, mirror)
   switch (nt) {
     case 1: BTC_APPLY(1); break;
     case 2: BTC_APPLY(2); break;
@@ -1219,20 +1222,24 @@ extern "C" int btc_conv_dgrad(const float* dout, const float* W, const int32_t* 
 
 extern "C" int btc_conv_apply_ordered(int pass, int operands, const void* src, const void* W, const float* bias, const int32_t* nbr,
                                       const int32_t* order, int n_rows, int K, int Cin, int Cout, void* dst, void* stream) {
-  BTC_CHECK_ARG((pass == BTC_PASS_FWD || pass == BTC_PASS_DGRAD) && operands >= BTC_OPERANDS_F32 && operands <= BTC_OPERANDS_BF16,
-                "btc_conv_apply_ordered: pass=%d operands=%d", pass, operands);
+  BTC_CHECK_ARG((pass == BTC_PASS_FWD || pass == BTC_PASS_DGRAD || pass == BTC_PASS_DGRAD_MIRROR) && operands >= BTC_OPERANDS_F32 &&
+                    operands <= BTC_OPERANDS_BF16, "btc_conv_apply_ordered: pass=%d operands=%d", pass, operands);
+  // BTC_PASS_DGRAD_MIRROR: dgrad of a submanifold layer through its FORWARD map -- nbr_in[j][k] == nbr_out[j][K-1-k] there, so the
+  // kernels read column K-1-k for offset k and the backward map never exists (same bits as the explicit map: tests)
+  const int mirror = pass == BTC_PASS_DGRAD_MIRROR;
+  if (mirror) pass = BTC_PASS_DGRAD;
   BTC_CHECK_ARG(K >= 1 && K <= 512 && Cin >= 1 && Cout >= 1 && n_rows >= 0, "btc_conv_apply_ordered: bad sizes");
   BTC_CHECK_ARG(pass == BTC_PASS_FWD || bias == nullptr, "btc_conv_apply_ordered: dgrad takes no bias");
   const int Cred = pass == BTC_PASS_FWD ? Cin : Cout, Cres = pass == BTC_PASS_FWD ? Cout : Cin;
   if (operands == BTC_OPERANDS_BF16) {
     BTC_CHECK_ARG(btc_conv_bf16w_supported(K, Cred, Cres), "btc_conv_apply_ordered: bf16 operands need K <= 64, Cred %% 32 == 0, Cres %% 16 == 0 (K=%d, %d -> %d)",
                   K, Cin, Cout);
-    return btc_apply_bf16w(src, W, bias, nbr, order, n_rows, K, Cred, Cres, dst, (hipStream_t)stream);
+    return btc_apply_bf16w(src, W, bias, nbr, order, n_rows, K, Cred, Cres, dst, (hipStream_t)stream, mirror);
   }
   const bool bf = operands == BTC_OPERANDS_BF16_ACT;
   if (pass == BTC_PASS_FWD)
     return launch_apply<false>((const float*)src, (const float*)W, bias, nbr, n_rows, K, Cred, Cres, (float*)dst, (hipStream_t)stream, bf, order);
-  return launch_apply<true>((const float*)src, (const float*)W, nullptr, nbr, n_rows, K, Cred, Cres, (float*)dst, (hipStream_t)stream, bf, order);
+  return launch_apply<true>((const float*)src, (const float*)W, nullptr, nbr, n_rows, K, Cred, Cres, (float*)dst, (hipStream_t)stream, bf, order, mirror);
 }
 
 extern "C" size_t btc_conv_wgrad_ws_bytes(int n_out, int K, int Cin, int Cout, int n_in) {

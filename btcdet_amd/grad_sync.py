@@ -13,9 +13,13 @@ plus per-parameter hooks), so the step uses this reducer instead -- same result,
   bucket's slices (``view_of``; ``assign_grads=True`` additionally points every ``param.grad`` at its slice);
 * ``finish()`` = launch whatever has not been launched + wait for everything (the one-call form after a single backward).
 
-Transports (``transport=`` / BTC_SYNC_TRANSPORT): ``rccl`` -- ncclAllReduce(ncclAvg) on a communicator of our own
-(btcdet_amd/rccl_direct.py; default when the process group's backend is nccl), ``torch`` -- ``dist.all_reduce`` of the process
-group, ``host`` -- reduce a host copy over gloo (ranks sharing one GPU in the functional tests; the way DDP treats gloo).
+Transports (``transport=`` / BTC_SYNC_TRANSPORT): ``torch`` -- ``dist.all_reduce`` of the process group (backend "nccl" = RCCL over
+xGMI; the default), ``rccl`` -- ncclAllReduce(ncclAvg) on a communicator of our own (btcdet_amd/rccl_direct.py), ``host`` -- reduce
+a host copy over gloo (ranks sharing one GPU in the functional tests; the way DDP treats gloo).  Measured at world size 1 on one
+MI355X (tools/ab_dist.sh, pipelined schedule, scenes/s): no process group 445, ``torch`` 422, ``rccl`` 162 -- the call itself is
+cheaper there (4 us of host time and an 11 us kernel per 10 MB bucket against 18 us / 46 us, tools/rccl_probe.py), but a SECOND RCCL
+communicator in the process takes hardware queues of its own and the step's streams end up sharing theirs (the same run with the
+collective switched off, BTC_SYNC_DRYRUN=1: 156), so it is opt-in, for a process whose control plane is not on RCCL.
 
 Rank consistency (the contract of DDP with find_unused_parameters=False): every rank must produce a gradient for the same
 parameters.  The optimizer treats EVERY parameter of a reduced bucket as present -- a rank that had no gradient for one
@@ -76,8 +80,7 @@ class BucketedGradSync(object):
         backend = dist.get_backend(process_group)
         self.buckets = [_Bucket(list(params), trig) for params, trig in buckets]
         dev = next((b.flat.device for b in self.buckets if b.params), torch.device("cpu"))
-        want = transport or os.environ.get("BTC_SYNC_TRANSPORT") or ("host" if backend == "gloo" and dev.type == "cuda" else
-                                                                      ("rccl" if backend == "nccl" else "torch"))
+        want = transport or os.environ.get("BTC_SYNC_TRANSPORT") or ("host" if backend == "gloo" and dev.type == "cuda" else "torch")
         self.comm = None
         if want == "rccl":
             try:

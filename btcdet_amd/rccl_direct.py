@@ -8,6 +8,11 @@ step is bound by its host threads.  Here the call is ``ncclAllReduce`` on the ca
 stream ordering, there is no work object, and the host cost is one library call.
 
 The library is the ``librccl.so`` PyTorch itself loads (``torch/lib``), so both communicators share one RCCL instance.
+
+Opt-in (BTC_SYNC_TRANSPORT=rccl), not the default: beside the process group's own RCCL communicator a second one takes further
+hardware queues and the step's streams end up sharing theirs -- measured at world size 1, the whole step 422 scenes/s through the
+process group, 162 with this communicator merely EXISTING (grad_sync.py docstring, tools/ab_dist.sh).  It pays where the control
+plane is not on RCCL (process group on gloo).
 """
 import ctypes
 import os

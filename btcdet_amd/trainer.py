@@ -268,6 +268,10 @@ class HotPathTrainer(object):
             self.grad_sync = BucketedGradSync([(gs[0], None), (gs[1], None)], process_group=process_group, assign_grads=False)
             self.grad_sync.bucket_of = {"occ": 0, "det": 1}
             self.grad_sync.split_backward = schedule == "split"
+            if schedule == "pipelined":
+                # each thread launches its bucket at the END of its own backward pass and awaits it at once: a communication stream
+                # would overlap nothing and costs two more event hops per bucket.  Pack and all-reduce go on the thread's own stream.
+                self.grad_sync.use_comm_stream = False
             if schedule == "split":    # the detection bucket goes first there (launch_ready between the two backward passes)
                 self.grad_sync.buckets.reverse()
                 self.grad_sync.bucket_of = {"occ": 1, "det": 0}
