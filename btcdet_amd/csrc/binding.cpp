@@ -233,6 +233,11 @@ std::tuple<OptTensor, OptTensor> conv_bwd(const Tensor& features, const Tensor& 
   need(grad_out.is_contiguous() && grad_out.scalar_type() == features.scalar_type(), "conv_bwd: grad must be contiguous and of the activation type");
   const bool bf = features.scalar_type() == at::kBFloat16;
   const int32_t* order = order_ptr(order_bwd, n_src, "conv_bwd: the row order does not match the map");
+  // a submanifold rulebook has ONE map: its backward map is the forward map with the offset index mirrored, and the caller hands
+  // in the same tensor for both (ops.Rulebook.map_bwd) -- the dgrad kernels then read column K-1-k for offset k
+  const bool mirror = map_fwd.numel() > 0 && map_bwd.data_ptr() == map_fwd.data_ptr();
+  const int pass_dgrad = mirror ? BTC_PASS_DGRAD_MIRROR : BTC_PASS_DGRAD;
+  const int32_t* wg_map_bwd = mirror ? nullptr : (const int32_t*)map_bwd.data_ptr();   // (weight gradient: the forward map alone)
   OptTensor din, dw;
   Tensor ws;
   hipStream_t main = (hipStream_t)st(stream);
@@ -259,10 +264,10 @@ std::tuple<OptTensor, OptTensor> conv_bwd(const Tensor& features, const Tensor& 
     Tensor d = at::empty({n_src, cin}, features.options());
     if (bf16_operands(grad_out, K, cout, cin)) {
       Tensor q = weights_bf16(w, K, cin, cout, stream);
-      chk(btc_conv_apply_ordered(BTC_PASS_DGRAD, BTC_OPERANDS_BF16, grad_out.data_ptr(), q.data_ptr(), nullptr, (const int32_t*)map_bwd.data_ptr(),
+      chk(btc_conv_apply_ordered(pass_dgrad, BTC_OPERANDS_BF16, grad_out.data_ptr(), q.data_ptr(), nullptr, (const int32_t*)map_bwd.data_ptr(),
                                  order, (int)n_src, (int)K, (int)cin, (int)cout, d.data_ptr(), st(stream)), "btc_conv_apply_ordered (dgrad, bf16 operands)");
     } else
-      chk(btc_conv_apply_ordered(BTC_PASS_DGRAD, bf ? BTC_OPERANDS_BF16_ACT : BTC_OPERANDS_F32, grad_out.data_ptr(), w.data_ptr(), nullptr,
+      chk(btc_conv_apply_ordered(pass_dgrad, bf ? BTC_OPERANDS_BF16_ACT : BTC_OPERANDS_F32, grad_out.data_ptr(), w.data_ptr(), nullptr,
                                  (const int32_t*)map_bwd.data_ptr(), order, (int)n_src, (int)K, (int)cin, (int)cout, d.data_ptr(), st(stream)),
           "btc_conv_apply_ordered (dgrad)");
     din = d;
@@ -275,11 +280,11 @@ std::tuple<OptTensor, OptTensor> conv_bwd(const Tensor& features, const Tensor& 
     ws = at::empty({(int64_t)(ws_bytes > 256 ? ws_bytes : 256)}, features.options().dtype(at::kByte));
     if (bf)
       chk(btc_conv_wgrad_bf16(features.data_ptr(), grad_out.data_ptr(), (const int32_t*)map_fwd.data_ptr(), (int)n_res,
-                              (const int32_t*)map_bwd.data_ptr(), (int)n_src, (int)K, (int)cin, (int)cout, (float*)g.data_ptr(), ws.data_ptr(),
+                              wg_map_bwd, (int)n_src, (int)K, (int)cin, (int)cout, (float*)g.data_ptr(), ws.data_ptr(),
                               ws_bytes, wstream), "btc_conv_wgrad_bf16");
     else
       chk(btc_conv_wgrad((const float*)features.data_ptr(), (const float*)grad_out.data_ptr(), (const int32_t*)map_fwd.data_ptr(), (int)n_res,
-                         (const int32_t*)map_bwd.data_ptr(), (int)n_src, (int)K, (int)cin, (int)cout, (float*)g.data_ptr(), ws.data_ptr(),
+                         wg_map_bwd, (int)n_src, (int)K, (int)cin, (int)cout, (float*)g.data_ptr(), ws.data_ptr(),
                          ws_bytes, wstream), "btc_conv_wgrad");
     dw = g;
   }
@@ -345,15 +350,15 @@ std::vector<Tensor> row_orders(const std::vector<Tensor>& maps, int64_t stream) 
   return out;
 }
 
-// submanifold rulebook: returns nbr (2, n, K) = nbr_out | nbr_in.  p_* are the addresses of int32[3] host arrays.
+// submanifold rulebook: returns nbr_out (n, K); nbr_in is its mirror image and is not built (BTC_PASS_DGRAD_MIRROR).  p_* are the
+// addresses of int32[3] host arrays.
 Tensor rulebook_subm(const Tensor& indices, int64_t batch, int64_t p_in, int64_t p_k, int64_t p_d, int64_t K, int64_t stream) {
   const int64_t n = indices.size(0);
-  Tensor nbr = at::empty({2, n, K}, indices.options());
+  Tensor nbr = at::empty({n, K}, indices.options());
   const size_t ws_bytes = btc_rulebook_subm_ws_bytes((int)n);
   Tensor ws = at::empty({(int64_t)(ws_bytes > 256 ? ws_bytes : 256)}, indices.options().dtype(at::kByte));
-  int32_t* out = (int32_t*)nbr.data_ptr();
-  chk(btc_rulebook_subm((const int32_t*)indices.data_ptr(), (int)n, (int)batch, ip(p_in), ip(p_k), ip(p_d), out, out + n * K, ws.data_ptr(),
-                        ws_bytes, st(stream)), "btc_rulebook_subm");
+  chk(btc_rulebook_subm((const int32_t*)indices.data_ptr(), (int)n, (int)batch, ip(p_in), ip(p_k), ip(p_d), (int32_t*)nbr.data_ptr(), nullptr,
+                        ws.data_ptr(), ws_bytes, st(stream)), "btc_rulebook_subm");
   return nbr;
 }
 
@@ -682,7 +687,7 @@ std::vector<std::vector<Tensor>> geometry_walk_finish(const std::shared_ptr<Pend
   for (size_t i = 0; i < n; ++i) {
     if (kind[i] == 0) {
       level_in[i] = level_out[i] = cur;
-      if (!skip[i]) other_elems += 2 * cur.size(0) * K[i];
+      if (!skip[i]) other_elems += cur.size(0) * K[i];   // one map: nbr_in is its mirror image (BTC_PASS_DGRAD_MIRROR)
     } else if (kind[i] == 1) {
       level_in[i] = cur;
       p_out_idx[i] = (int32_t*)p->out_idx[i].data_ptr();
@@ -713,10 +718,14 @@ std::vector<std::vector<Tensor>> geometry_walk_finish(const std::shared_ptr<Pend
       nbr_out = buf_o.narrow(0, off_o, rows_out * K[i]).view({rows_out, K[i]});
       off_o += rows_out * K[i];
     }
-    nbr_in = buf_o.narrow(0, off_o, rows_in * K[i]).view({rows_in, K[i]});
-    off_o += rows_in * K[i];
     p_nbr_out[i] = (int32_t*)nbr_out.data_ptr();
-    p_nbr_in[i] = (int32_t*)nbr_in.data_ptr();
+    if (kind[i] == 1) {
+      nbr_in = buf_o.narrow(0, off_o, rows_in * K[i]).view({rows_in, K[i]});
+      off_o += rows_in * K[i];
+      p_nbr_in[i] = (int32_t*)nbr_in.data_ptr();
+    } else {
+      nbr_in = nbr_out;   // the SAME tensor: conv_bwd recognises the submanifold rulebook by that and reads it mirrored
+    }
     out[i] = {level_in[i], level_out[i], nbr_out, nbr_in};
   }
   chk(btc_chain_maps((const int32_t*)indices.data_ptr(), p->n0, (int)p->batch, p->layers.data(), (int)n, hc, p_out_idx.data(), p_nbr_out.data(),

@@ -220,7 +220,7 @@ int launch_b_kc(int kc, const unsigned short* feat, const unsigned short* Wq, co
 }
 
 int apply_b(const void* feat_, const void* Wq_, const float* bias, const int32_t* nbr, const int32_t* order, int n_rows, int K, int Cred, int Cres,
-            void* out_, hipStream_t stream, int mirror) {
+            void* out_, hipStream_t stream, int mirror = 0) {
   if (n_rows <= 0) return BTC_OK;
   const unsigned short* feat = (const unsigned short*)feat_;
   const unsigned short* Wq = (const unsigned short*)Wq_;

@@ -32,7 +32,7 @@ namespace {
 constexpr int RB_T = 256;
 constexpr int RB_BLK = 8;           // words per rank block (one 32-byte sector)
 constexpr int RB_CHUNK = 256;       // blocks per chunk: one thread per block in rb_scan
-constexpr int RB_MAX_JOBS = 10;
+constexpr int RB_MAX_JOBS = 12;
 
 struct Level {
   unsigned* words;
@@ -286,17 +286,34 @@ __device__ __forceinline__ int rb_hash_find(unsigned long long key, unsigned lon
 }
 
 // ---- neighbour maps: every job of a chain in one launch
-enum { JOB_STRIDED = 0, JOB_SUBM_RANK = 1, JOB_SUBM_HASH = 2 };
+// A job walks the rows of one level and writes one (rows, K) map, coalesced:
+//   JOB_FWD   input rows  -> nbr_in [i][k] = rank, in the OUTPUT level, of the cell input i reaches at offset k
+//             (+ scatter, for an input level in arbitrary order that cannot be probed: nbr_out[row][k] = i into a map pre-filled with -1)
+//   JOB_BWD   output rows -> nbr_out[o][k] = rank, in the INPUT level, of the cell that reaches output o at offset k -- a gather: no
+//             -1 fill and no scattered 4-byte stores (the fill + scatter wrote every line of the map twice: profiles/r02h_pmc.json)
+//   JOB_SUBM  rows of a level -> nbr_out[i][k] = rank of the neighbour cell; nbr_in is its mirror image (nbr_in[i][K-1-k] ==
+//             nbr_out[i][k]) and is only written on request -- the apply kernels read the forward map mirrored instead
+//             (BTC_PASS_DGRAD_MIRROR), half of a submanifold rulebook's bytes
+// A workgroup takes RB_ROWS consecutive rows.  Levels built here are sorted by cell, so those rows are neighbours in space: when they
+// lie in one (batch, z) plane the workgroup STAGES the bitmap words of the <= 3 target planes x the y-range its rows can reach,
+// each with the rank of its first bit, in LDS, and the rows x K probes become LDS reads (one global 32-byte block + two prefix
+// words per staged WORD instead of per hit).  Windows that do not fit (sparse levels: 64 rows spread over many grid lines) and
+// hashed levels are probed directly.
+enum { JOB_FWD = 0, JOB_BWD = 1, JOB_SUBM = 2 };
+constexpr int RB_ROWS = 64;          // rows per workgroup of rb_fill
+constexpr int RB_WIN = 224;          // bitmap words per staged plane window
 
 struct Job {
   int type;
-  int n;                        // input rows
+  int n;                        // rows walked
+  int ranked;                   // the probed level is a ranked bitmap (else the hash of the chain's input level)
+  int sorted;                   // the walked rows are in ascending cell order (a level built here): staging is possible
   long long first_block;        // first workgroup of the job
   BtcGeom g;
-  Level lvl;                    // STRIDED: the OUTPUT level; SUBM_*: the level itself (SUBM_HASH uses only its shape)
-  const int4* in_idx;
-  int32_t* nbr_out;
-  int32_t* nbr_in;
+  Level lvl;                    // the PROBED level: FWD the output level, BWD the input level, SUBM the level itself (hash: shape only)
+  const int4* idx;              // the walked rows
+  int32_t* map;                 // (n, K), written coalesced: FWD nbr_in, BWD nbr_out, SUBM nbr_out
+  int32_t* map2;                // FWD: nbr_out to scatter into, or NULL; SUBM: nbr_in (mirror image), or NULL
   const unsigned long long* keys;
   const int32_t* vals;
   unsigned long long mask;
@@ -307,39 +324,134 @@ struct Jobs {
   Job j[RB_MAX_JOBS];
 };
 
+// one axis of a probe: coordinate c of the walked row + kernel offset kv -> coordinate in the probed level
+__device__ __forceinline__ bool probe_axis(const Job& J, int j, int c, int kv, int* o) {
+  const BtcGeom& g = J.g;
+  int q;
+  if (J.type == JOB_SUBM) {
+    q = c + (kv - g.k[j] / 2) * g.d[j];
+  } else if ((J.type == JOB_FWD) == (g.mode == BTC_MODE_CONV)) {   // FWD of a conv / BWD of a transposed conv: (c + p - kv d) / s
+    const int t = c + g.p[j] - kv * g.d[j];
+    if (t < 0 || !div_stride(t, g.s[j], &q)) return false;
+  } else {                                                         // FWD of a transposed conv / BWD of a conv: c s - p + kv d
+    q = c * g.s[j] - g.p[j] + kv * g.d[j];
+  }
+  *o = q;
+  return q >= 0 && q < J.lvl.shape[j];
+}
+
+// range of probed coordinates along axis j for walked coordinates c0 <= c1, clamped to the level (lo > hi: nothing)
+__device__ __forceinline__ void probe_range(const Job& J, int j, int c0, int c1, int* lo, int* hi) {
+  const BtcGeom& g = J.g;
+  int a, b;
+  if (J.type == JOB_SUBM) {
+    a = c0 - (g.k[j] / 2) * g.d[j];
+    b = c1 + (g.k[j] - 1 - g.k[j] / 2) * g.d[j];
+  } else if ((J.type == JOB_FWD) == (g.mode == BTC_MODE_CONV)) {
+    const int t0 = c0 + g.p[j] - (g.k[j] - 1) * g.d[j];
+    a = t0 <= 0 ? 0 : t0 / g.s[j];
+    b = (c1 + g.p[j]) / g.s[j];
+  } else {
+    a = c0 * g.s[j] - g.p[j];
+    b = c1 * g.s[j] - g.p[j] + (g.k[j] - 1) * g.d[j];
+  }
+  *lo = a < 0 ? 0 : a;
+  *hi = b >= J.lvl.shape[j] ? J.lvl.shape[j] - 1 : b;
+}
+
 __global__ __launch_bounds__(RB_T) void rb_fill(Jobs jobs) {
+  __shared__ unsigned s_word[3][RB_WIN];
+  __shared__ int32_t s_base[3][RB_WIN];
+  __shared__ long long s_w0[3];
+  __shared__ int s_cnt[3];
+  __shared__ int s_stage;
   int ji = 0;
 #pragma unroll
   for (int q = 1; q < RB_MAX_JOBS; ++q)
     if (q < jobs.count && (long long)blockIdx.x >= jobs.j[q].first_block) ji = q;
   const Job& J = jobs.j[ji];
-  const long long t = ((long long)blockIdx.x - J.first_block) * RB_T + threadIdx.x;
   const int K = J.g.K;
-  if (t >= (long long)J.n * K) return;
-  int i, kk;
-  split_item(t, K, &i, &kk);
-  const int4 c = J.in_idx[i];
-  if (J.type == JOB_STRIDED) {
-    int oz, oy, ox, row = -1;
-    if (fwd_cell(J.g, c.y, c.z, c.w, kk, &oz, &oy, &ox)) {
-      row = lvl_rank(J.lvl, lvl_cell(J.lvl, c.x, oz, oy, ox));   // always set: the level is the union of what is reachable
-      if (row >= 0) J.nbr_out[(size_t)row * K + kk] = i;
+  const int r0 = (int)((long long)blockIdx.x - J.first_block) * RB_ROWS;
+  if (r0 >= J.n) return;
+  const int rows = J.n - r0 < RB_ROWS ? J.n - r0 : RB_ROWS;
+  const Level& L = J.lvl;
+  const int tid = threadIdx.x;
+
+  // ---- staging decision (thread 0): one plane, <= 3 kernel planes, every window fits
+  if (tid == 0) {
+    int stage = 0;
+    if (J.ranked && J.sorted && J.g.k[0] <= 3 && rows >= 8) {
+      const int4 a = J.idx[r0], b = J.idx[r0 + rows - 1];
+      if (a.x == b.x && a.y == b.y) {
+        int ylo, yhi;
+        probe_range(J, 1, a.z, b.z, &ylo, &yhi);
+        stage = 1;
+        for (int kz = 0; kz < 3; ++kz) {
+          int nz;
+          s_cnt[kz] = 0;
+          s_w0[kz] = 0;
+          if (kz >= J.g.k[0] || ylo > yhi || !probe_axis(J, 0, a.y, kz, &nz)) continue;
+          const long long w_lo = lvl_cell(L, a.x, nz, ylo, 0) >> 5, w_hi = lvl_cell(L, a.x, nz, yhi, L.shape[2] - 1) >> 5;
+          if (w_hi - w_lo + 1 > RB_WIN) { stage = 0; break; }
+          s_w0[kz] = w_lo;
+          s_cnt[kz] = (int)(w_hi - w_lo + 1);
+        }
+      }
     }
-    J.nbr_in[t] = row;
-    return;
+    s_stage = stage;
   }
-  int kz, ky, kx;
-  split_offset(J.g, kk, &kz, &ky, &kx);
-  const int z = c.y + (kz - J.g.k[0] / 2) * J.g.d[0];
-  const int y = c.z + (ky - J.g.k[1] / 2) * J.g.d[1];
-  const int x = c.w + (kx - J.g.k[2] / 2) * J.g.d[2];
-  int j = -1;
-  if (z >= 0 && z < J.lvl.shape[0] && y >= 0 && y < J.lvl.shape[1] && x >= 0 && x < J.lvl.shape[2]) {
-    const long long cell = lvl_cell(J.lvl, c.x, z, y, x);
-    j = (J.type == JOB_SUBM_RANK) ? lvl_rank(J.lvl, cell) : rb_hash_find((unsigned long long)cell + 1ull, J.mask, J.keys, J.vals);
+  __syncthreads();
+  const bool staged = s_stage != 0;
+  if (staged) {
+    for (int e = tid; e < 3 * RB_WIN; e += RB_T) {
+      const int pz = e / RB_WIN, j = e - pz * RB_WIN;
+      if (j >= s_cnt[pz]) continue;
+      const long long w = s_w0[pz] + j;
+      const long long blk = w >> 3;
+      const int wi = (int)(w & 7);
+      const uint4* p = reinterpret_cast<const uint4*>(L.words + blk * RB_BLK);
+      const uint4 a = p[0], b = p[1];
+      const unsigned ws[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+      int r = L.cprefix[blk / RB_CHUNK] + L.bprefix[blk];
+      unsigned word = 0;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        r += (q < wi) ? __popc(ws[q]) : 0;
+        word = (q == wi) ? ws[q] : word;
+      }
+      s_word[pz][j] = word;
+      s_base[pz][j] = r;
+    }
+    __syncthreads();
   }
-  J.nbr_out[t] = j;
-  J.nbr_in[(size_t)i * K + (K - 1 - kk)] = j;   // input i feeds, at the mirrored offset, exactly the row that is its neighbour here
+
+  for (int e = tid; e < rows * K; e += RB_T) {
+    int il, kk;
+    split_item((long long)e, K, &il, &kk);
+    const int i = r0 + il;
+    const int4 c = J.idx[i];
+    int kz, ky, kx, z, y, x;
+    split_offset(J.g, kk, &kz, &ky, &kx);
+    int r = -1;
+    if (probe_axis(J, 0, c.y, kz, &z) && probe_axis(J, 1, c.z, ky, &y) && probe_axis(J, 2, c.w, kx, &x)) {
+      const long long cell = lvl_cell(L, c.x, z, y, x);
+      if (staged) {
+        const int j = (int)((cell >> 5) - s_w0[kz]);
+        const unsigned word = s_word[kz][j];
+        const unsigned bit = (unsigned)cell & 31u;
+        if ((word >> bit) & 1u) r = s_base[kz][j] + __popc(word & ((1u << bit) - 1u));
+      } else if (J.ranked) {
+        r = lvl_rank(L, cell);
+      } else {
+        r = rb_hash_find((unsigned long long)cell + 1ull, J.mask, J.keys, J.vals);
+      }
+    }
+    J.map[(size_t)i * K + kk] = r;
+    if (J.map2) {
+      if (J.type == JOB_SUBM) J.map2[(size_t)i * K + (K - 1 - kk)] = r;   // input i feeds, at the mirrored offset, exactly the row that is its neighbour here
+      else if (r >= 0) J.map2[(size_t)r * K + kk] = i;                     // JOB_FWD scatter (the output level is the union of what is reachable: r >= 0 whenever the cell is in range)
+    }
+  }
 }
 
 // ---- spconv-layout pair lists
@@ -479,9 +591,9 @@ extern "C" int btc_rulebook_subm(const int32_t* indices, int n, int batch, const
   Jobs jobs;
   jobs.count = 1;
   Job& J = jobs.j[0];
-  J.type = JOB_SUBM_HASH; J.n = n; J.first_block = 0; J.g = g; J.lvl = L; J.in_idx = (const int4*)indices;
-  J.nbr_out = nbr_out; J.nbr_in = nbr_in; J.keys = keys; J.vals = vals; J.mask = cap - 1;
-  rb_fill<<<btc_cdiv((long long)n * g.K, RB_T), RB_T, 0, stream>>>(jobs);
+  J.type = JOB_SUBM; J.n = n; J.ranked = 0; J.sorted = 0; J.first_block = 0; J.g = g; J.lvl = L; J.idx = (const int4*)indices;
+  J.map = nbr_out; J.map2 = nbr_in; J.keys = keys; J.vals = vals; J.mask = cap - 1;
+  rb_fill<<<btc_cdiv(n, RB_ROWS), RB_T, 0, stream>>>(jobs);
   BTC_LAUNCH_CHECK();
   return BTC_OK;
 }
@@ -555,9 +667,9 @@ extern "C" int btc_rulebook_conv_fill(const int32_t* indices, int n, int batch, 
     Jobs jobs;
     jobs.count = 1;
     Job& J = jobs.j[0];
-    J.type = JOB_STRIDED; J.n = n; J.first_block = 0; J.g = g; J.lvl = L; J.in_idx = (const int4*)indices;
-    J.nbr_out = nbr_out; J.nbr_in = nbr_in; J.keys = nullptr; J.vals = nullptr; J.mask = 0;
-    rb_fill<<<btc_cdiv((long long)n * g.K, RB_T), RB_T, 0, stream>>>(jobs);
+    J.type = JOB_FWD; J.n = n; J.ranked = 1; J.sorted = 0; J.first_block = 0; J.g = g; J.lvl = L; J.idx = (const int4*)indices;
+    J.map = nbr_in; J.map2 = nbr_out; J.keys = nullptr; J.vals = nullptr; J.mask = 0;
+    rb_fill<<<btc_cdiv(n, RB_ROWS), RB_T, 0, stream>>>(jobs);
     BTC_LAUNCH_CHECK();
   }
   return BTC_OK;
@@ -773,14 +885,15 @@ extern "C" int btc_chain_maps(const int32_t* indices, int n0, int batch, const B
     rows_of[lv] = h_counts[P.producer[lv]];
     idx_of[lv] = out_indices[P.producer[lv]];
   }
-  // nbr_out of the strided layers starts as -1; adjacent buffers are cleared by one memset
+  // nbr_out of a strided layer whose input is the chain's arbitrary-order level 0 is scattered into (it cannot be gathered: that
+  // level has no ranks) and starts as -1; adjacent buffers are cleared by one memset.  Every other strided nbr_out is gathered.
   {
     char* run_begin = nullptr;
     size_t run_bytes = 0;
     for (int i = 0; i <= n_layers; ++i) {
       char* p = nullptr;
       size_t bytes = 0;
-      if (i < n_layers && layers[i].kind == 1 && h_counts[i] > 0) {
+      if (i < n_layers && layers[i].kind == 1 && P.lvl_in[i] == 0 && h_counts[i] > 0) {
         p = (char*)nbr_out[i];
         bytes = (size_t)h_counts[i] * layers[i].k[0] * layers[i].k[1] * layers[i].k[2] * sizeof(int32_t);
       } else if (i < n_layers) {
@@ -806,35 +919,44 @@ extern "C" int btc_chain_maps(const int32_t* indices, int n0, int batch, const B
     blocks = 0;
     return BTC_OK;
   };
+  auto add = [&](int type, int n, const BtcGeom& g, const Level& lvl, int ranked, int sorted, const int32_t* idx, int32_t* map, int32_t* map2) -> int {
+    if (n <= 0) return BTC_OK;
+    const long long nb = btc_cdiv(n, RB_ROWS);
+    if (jobs.count == RB_MAX_JOBS || blocks + nb > 0x7fffffffLL) {
+      int rc2 = flush();
+      if (rc2) return rc2;
+    }
+    Job& J = jobs.j[jobs.count++];
+    J.type = type; J.n = n; J.ranked = ranked; J.sorted = sorted; J.first_block = blocks; J.g = g; J.lvl = lvl; J.idx = (const int4*)idx;
+    J.map = map; J.map2 = map2; J.keys = W.keys; J.vals = W.vals; J.mask = W.hash_cap ? W.hash_cap - 1 : 0;
+    blocks += nb;
+    return BTC_OK;
+  };
   for (int i = 0; i < n_layers; ++i) {
     if (layers[i].kind > 1) continue;
     if (layers[i].kind == 0 && !nbr_out[i] && !nbr_in[i]) continue;   // the caller has this submanifold layer's maps already
+    BTC_CHECK_ARG(nbr_out[i] && (layers[i].kind == 0 || nbr_in[i]), "btc_chain_maps: layer %d: nbr_out (and, for a strided layer, nbr_in) required", i);
     const int li = P.lvl_in[i];
-    const int n = rows_of[li];
-    if (n <= 0) continue;
     const BtcGeom g = geom_of(layers[i]);
-    const long long nb = btc_cdiv((long long)n * g.K, RB_T);
-    if (jobs.count == RB_MAX_JOBS || blocks + nb > 0x7fffffffLL) {
-      rc = flush();
-      if (rc) return rc;
-    }
-    Job& J = jobs.j[jobs.count++];
-    J.n = n; J.first_block = blocks; J.g = g; J.in_idx = (const int4*)idx_of[li];
-    J.nbr_out = nbr_out[i]; J.nbr_in = nbr_in[i]; J.keys = W.keys; J.vals = W.vals; J.mask = W.hash_cap ? W.hash_cap - 1 : 0;
     if (layers[i].kind == 1) {
-      J.type = JOB_STRIDED;
-      J.lvl = W.lv[P.lvl_out[i]];
+      const int lo = P.lvl_out[i];
+      // nbr_in: the input rows probe the output level; level-0 inputs also scatter nbr_out (see above)
+      rc = add(JOB_FWD, rows_of[li], g, W.lv[lo], 1, li != 0, idx_of[li], nbr_in[i], li == 0 ? nbr_out[i] : nullptr);
+      if (rc) return rc;
+      if (li != 0) {   // nbr_out: the output rows probe the (ranked) input level
+        rc = add(JOB_BWD, rows_of[lo], g, W.lv[li], 1, 1, idx_of[lo], nbr_out[i], nullptr);
+        if (rc) return rc;
+      }
     } else if (li == 0) {
-      J.type = JOB_SUBM_HASH;
       LevelLayout l0;
       rc = level_layout(batch, layers[i].in_shape, &l0);
       if (rc) return rc;
-      J.lvl = make_level(l0, layers[i].in_shape, nullptr, nullptr, nullptr);
+      rc = add(JOB_SUBM, rows_of[li], g, make_level(l0, layers[i].in_shape, nullptr, nullptr, nullptr), 0, 0, idx_of[li], nbr_out[i], nbr_in[i]);
+      if (rc) return rc;
     } else {
-      J.type = JOB_SUBM_RANK;
-      J.lvl = W.lv[li];
+      rc = add(JOB_SUBM, rows_of[li], g, W.lv[li], 1, 1, idx_of[li], nbr_out[i], nbr_in[i]);
+      if (rc) return rc;
     }
-    blocks += nb;
   }
   return flush();
 }

@@ -133,7 +133,7 @@ class SparseSequential(SparseModule):
         w, b, mf, mb, of, ob, ga, be, rms, rvs, nbts, ub, mom, eps, relus, need, ov, dfr = ([] for _ in range(18))
         ws = None
         for conv, bn, relu, rb, inverse in plan:
-            maps = (rb.nbr_in, rb.nbr_out) if inverse else (rb.nbr_out, rb.nbr_in)
+            maps = (rb.nbr_in, rb.nbr_out) if inverse else (rb.nbr_out, rb.map_bwd)
             ords = (rb.order_in, rb.order_out) if inverse else (rb.order_out, rb.order_in)
             of.append(ords[0]); ob.append(ords[1])
             training = bn.training or not bn.track_running_stats

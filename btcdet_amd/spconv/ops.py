@@ -109,18 +109,39 @@ def get_deconv_output_size(input_size, kernel_size, stride, padding, dilation, o
 
 
 class Rulebook(object):
-    """One cached rulebook (what spconv stores in ``indice_dict[indice_key]``)."""
+    """One cached rulebook (what spconv stores in ``indice_dict[indice_key]``).
 
-    __slots__ = ("out_indices", "in_indices", "nbr_out", "nbr_in", "in_shape", "out_shape", "K", "mode", "order_out", "order_in")
+    A SUBMANIFOLD rulebook holds ONE map: its backward map is the forward map with the offset index mirrored
+    (nbr_in[i][K-1-k] == nbr_out[i][k]), so ``map_bwd`` is the SAME tensor as ``nbr_out`` and the dgrad kernels read it mirrored
+    (BTC_PASS_DGRAD_MIRROR, include/btcdet_hip.h) -- the bindings recognise that case by the identity of the two tensors.
+    ``nbr_in`` still answers with the explicit (n, K) map (built on demand, cached), for tests and for spconv-style consumers."""
+
+    __slots__ = ("out_indices", "in_indices", "nbr_out", "map_bwd", "_nbr_in", "in_shape", "out_shape", "K", "mode", "order_out", "order_in")
 
     def __init__(self, out_indices, in_indices, nbr_out, nbr_in, in_shape, out_shape, K, mode, order_out=None, order_in=None):
         self.out_indices, self.in_indices = out_indices, in_indices
-        self.nbr_out, self.nbr_in = nbr_out, nbr_in
+        self.nbr_out = nbr_out
+        mirrored = nbr_in is None or nbr_in is nbr_out or (mode == MODE_SUBM and nbr_out.numel() > 0 and nbr_in.data_ptr() == nbr_out.data_ptr())
+        if mirrored and mode != MODE_SUBM:
+            raise _lib.BtcHipError("only a submanifold rulebook can do without its backward map")
+        self.map_bwd = nbr_out if mirrored else nbr_in      # what the kernels are handed
+        self._nbr_in = None if mirrored else nbr_in
         self.in_shape, self.out_shape = list(in_shape), list(out_shape)
         self.K, self.mode = K, mode
         # row-order hints of the two maps (csrc/row_order.hip): int32 permutations the apply kernels tile the rows by, or
         # None = map order.  Built for strided / transposed rulebooks (their 16-row tiles are 17-30 % full in map order).
         self.order_out, self.order_in = order_out, order_in
+
+    @property
+    def mirrored(self):
+        return self.map_bwd is self.nbr_out
+
+    @property
+    def nbr_in(self):
+        """the explicit backward map (n_in, K); for a submanifold rulebook the mirror image of nbr_out, materialised on first use"""
+        if self._nbr_in is None:
+            self._nbr_in = torch.flip(self.nbr_out, dims=[1]).contiguous()
+        return self._nbr_in
 
     @property
     def n_in(self):
@@ -172,7 +193,7 @@ def row_orders(maps):
 
 def _with_orders(rb):
     if ROW_ORDER and rb.K <= 64 and rb.order_out is None and (rb.mode != MODE_SUBM or ROW_ORDER >= 2):
-        rb.order_out, rb.order_in = row_orders([rb.nbr_out, rb.nbr_in])
+        rb.order_out, rb.order_in = row_orders([rb.nbr_out, rb.map_bwd])   # (a mirrored map groups the same rows: columns only swap places)
     return rb
 
 
@@ -268,20 +289,19 @@ def _build_rulebook(indices, batch_size, g):
     if F is not None:
         if g.subm:
             nbr = F.rulebook_subm(indices, int(batch_size), g.a_in, g.a_k, g.a_d, K, stream_ptr())
-            return Rulebook(indices, indices, nbr[0], nbr[1], g.in_list, g.out_list, K, g.mode)
+            return Rulebook(indices, indices, nbr, None, g.in_list, g.out_list, K, g.mode)
         out_indices, nbr_out, nbr_in, o_out, o_in = F.rulebook_conv(indices, int(batch_size), g.a_in, g.a_out, g.a_k, g.a_s, g.a_p, g.a_d, g.mode, K,
                                                                     _conv_ws_bytes(g, batch_size), stream_ptr())
         if not ROW_ORDER:
             o_out = o_in = None
         return Rulebook(out_indices, indices, nbr_out, nbr_in, g.in_list, g.out_list, K, g.mode, o_out, o_in)
     if g.subm:
-        nbr = torch.empty((2, n, K), dtype=torch.int32, device=dev)  # one allocation for nbr_out | nbr_in
-        nbr_out, nbr_in = nbr[0], nbr[1]
+        nbr_out = torch.empty((n, K), dtype=torch.int32, device=dev)   # nbr_in is its mirror image: not built (Rulebook docstring)
         ws_bytes = L.btc_rulebook_subm_ws_bytes(n)
         ws = workspace(ws_bytes, dev)
-        check(L.btc_rulebook_subm(ptr(indices), n, int(batch_size), g.p_in, g.p_k, g.p_d, ptr(nbr_out), ptr(nbr_in), ptr(ws), ws_bytes,
+        check(L.btc_rulebook_subm(ptr(indices), n, int(batch_size), g.p_in, g.p_k, g.p_d, ptr(nbr_out), None, ptr(ws), ws_bytes,
                                   stream_ptr()), "btc_rulebook_subm")
-        return Rulebook(indices, indices, nbr_out, nbr_in, g.in_list, g.out_list, K, g.mode)
+        return Rulebook(indices, indices, nbr_out, None, g.in_list, g.out_list, K, g.mode)
     if PROFILE is not None:
         return _start_conv_rulebook(indices, batch_size, g, None).finish()
     # synchronous build: count, one blocking 4-byte read-back (spconv syncs at the same point), fill
@@ -567,6 +587,9 @@ def _conv_backward(features, w, map_fwd, map_bwd, grad_out, wshape, need_din, ne
     din = dw = None
     dev = grad_out.device
     n_res, n_src = map_fwd.shape[0], map_bwd.shape[0]
+    mirror = map_bwd is map_fwd or (map_fwd.numel() > 0 and map_bwd.data_ptr() == map_fwd.data_ptr())   # a submanifold rulebook's single map (Rulebook docstring)
+    pass_dgrad = 2 if mirror else 1                                            # BTC_PASS_DGRAD_MIRROR / BTC_PASS_DGRAD
+    wg_bwd = None if mirror else map_bwd
     overlap = bool(need_din and need_dw and _overlap_ok(n_res))
     if PROFILE is None:
         F = fast()
@@ -581,7 +604,7 @@ def _conv_backward(features, w, map_fwd, map_bwd, grad_out, wshape, need_din, ne
             with torch.cuda.stream(side):
                 dw = torch.empty(wshape, dtype=torch.float32, device=dev)
                 ws = workspace(ws_bytes, dev)
-                check(wgrad(ptr(features), ptr(grad_out), ptr(map_fwd), n_res, ptr(map_bwd), n_src, K, cin, cout, ptr(dw), ptr(ws), ws_bytes,
+                check(wgrad(ptr(features), ptr(grad_out), ptr(map_fwd), n_res, ptr(wg_bwd), n_src, K, cin, cout, ptr(dw), ptr(ws), ws_bytes,
                             stream_ptr()), "btc_conv_wgrad")
             for t in (features, grad_out, map_fwd, map_bwd):
                 t.record_stream(side)
@@ -589,17 +612,17 @@ def _conv_backward(features, w, map_fwd, map_bwd, grad_out, wshape, need_din, ne
             dw = torch.empty(wshape, dtype=torch.float32, device=dev)
             ws = workspace(ws_bytes, dev)
             with _span("conv_wgrad", _wgrad_cost, (map_fwd, n_res, K, cin, cout, 2 if bf else 4)):
-                check(wgrad(ptr(features), ptr(grad_out), ptr(map_fwd), n_res, ptr(map_bwd), n_src, K, cin, cout, ptr(dw), ptr(ws), ws_bytes,
+                check(wgrad(ptr(features), ptr(grad_out), ptr(map_fwd), n_res, ptr(wg_bwd), n_src, K, cin, cout, ptr(dw), ptr(ws), ws_bytes,
                             stream_ptr()), "btc_conv_wgrad")
     if need_din:
         din = torch.empty((n_src, cin), dtype=features.dtype, device=dev)
         with _span("conv_apply", _conv_cost, (map_bwd, n_src, K, cout, cin, 2 if bf else 4)):
             if _bf16_operands(grad_out, K, cout, cin):
                 q = _weights_bf16(w, K, cin, cout)
-                check(L.btc_conv_apply_ordered(1, 2, ptr(grad_out), ptr(q[0]), None, ptr(map_bwd), ptr(ord_bwd), n_src, K, cin, cout, ptr(din),
+                check(L.btc_conv_apply_ordered(pass_dgrad, 2, ptr(grad_out), ptr(q[0]), None, ptr(map_bwd), ptr(ord_bwd), n_src, K, cin, cout, ptr(din),
                                                stream_ptr()), "btc_conv_apply_ordered")
             else:
-                check(L.btc_conv_apply_ordered(1, 1 if bf else 0, ptr(grad_out), ptr(w), None, ptr(map_bwd), ptr(ord_bwd), n_src, K, cin, cout,
+                check(L.btc_conv_apply_ordered(pass_dgrad, 1 if bf else 0, ptr(grad_out), ptr(w), None, ptr(map_bwd), ptr(ord_bwd), n_src, K, cin, cout,
                                                ptr(din), stream_ptr()), "btc_conv_apply_ordered")
     if side is not None:
         torch.cuda.current_stream().wait_stream(side)  # join: dW is consumed on the main stream from here on
@@ -763,9 +786,9 @@ def indice_conv(features, weight, bias, rulebook, inverse=False):
         # bf16 activations exist in the LDS-DMA kernel only (channel counts that are multiples of 16); the few other layers
         # (4 / 6 / 34 input channels, 2 / 3-channel heads) run in fp32 and round their result
         return indice_conv(features.float(), weight, bias, rulebook, inverse).to(torch.bfloat16)
-    if inverse:
+    if inverse:   # (inverse convs run on strided rulebooks: both maps exist)
         return SparseConvFunction.apply(features, weight, bias, rulebook.nbr_in, rulebook.nbr_out, rulebook.order_in, rulebook.order_out)
-    return SparseConvFunction.apply(features, weight, bias, rulebook.nbr_out, rulebook.nbr_in, rulebook.order_out, rulebook.order_in)
+    return SparseConvFunction.apply(features, weight, bias, rulebook.nbr_out, rulebook.map_bwd, rulebook.order_out, rulebook.order_in)
 
 
 def indice_conv_bn_relu(features, weight, bias, rulebook, bn, relu, inverse=False):
@@ -778,7 +801,7 @@ def indice_conv_bn_relu(features, weight, bias, rulebook, bn, relu, inverse=Fals
     nbt = bn.num_batches_tracked if (bn.training and bn.track_running_stats) else None
     rm = bn.running_mean if bn.track_running_stats else None
     rv = bn.running_var if bn.track_running_stats else None
-    maps = (rulebook.nbr_in, rulebook.nbr_out) if inverse else (rulebook.nbr_out, rulebook.nbr_in)
+    maps = (rulebook.nbr_in, rulebook.nbr_out) if inverse else (rulebook.nbr_out, rulebook.map_bwd)
     ords = (rulebook.order_in, rulebook.order_out) if inverse else (rulebook.order_out, rulebook.order_in)
     F = fast() if (PROFILE is None and CAPTURE is None and NATIVE_AUTOGRAD) else None
     if F is not None and features.is_cuda:

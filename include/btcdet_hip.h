@@ -134,7 +134,9 @@ int btc_out_shape(const int32_t* h_in_shape, const int32_t* h_k, const int32_t* 
                   const int32_t* h_d, const int32_t* h_outpad, int mode, int32_t* h_out_shape);
 
 /* SubM: outputs are the inputs in input order (any order: the cell -> row lookup is a hash with 64-bit cell keys).
- * Kernel sizes must be odd.  nbr_out, nbr_in: (n, K) int32, both fully written.  ws: btc_rulebook_subm_ws_bytes(n). */
+ * Kernel sizes must be odd.  nbr_out (n, K) int32, fully written.  nbr_in: (n, K), or NULL -- it is nbr_out's mirror image
+ * (nbr_in[i][K-1-k] == nbr_out[i][k]); the apply kernels read nbr_out mirrored instead (BTC_PASS_DGRAD_MIRROR below), so the hot
+ * path never materialises it.  ws: btc_rulebook_subm_ws_bytes(n). */
 size_t btc_rulebook_subm_ws_bytes(int n);
 int btc_rulebook_subm(const int32_t* indices, int n, int batch, const int32_t* h_shape, const int32_t* h_k,
                       const int32_t* h_d, int32_t* nbr_out, int32_t* nbr_in, void* ws, size_t ws_bytes,
@@ -167,8 +169,11 @@ int btc_rulebook_conv_fill(const int32_t* indices, int n, int batch, const int32
  *            count.  Nothing is read back; level l+1 is marked from level l's rows with their count taken from d_counts.
  *   -- the caller copies d_counts (n_layers int32) to the host and sizes the maps --
  *   phase B  btc_chain_maps   : nbr_out[i] (rows_out_i, K_i) and nbr_in[i] (rows_in_i, K_i) of every kind-0 / kind-1 layer in
- *            one multi-job launch (+ the -1 fill of the strided layers' nbr_out: hand in adjacent buffers to make it one).
- *            A kind-0 layer with nbr_out[i] == nbr_in[i] == NULL is skipped (the caller built that rulebook on its own).
+ *            one multi-job launch.  A strided layer's nbr_in is written by its input rows probing the output level, its nbr_out
+ *            by its OUTPUT rows probing the input level (a gather: no -1 fill, no scattered stores) -- except for a layer that
+ *            consumes the chain's arbitrary-order input level, whose nbr_out is filled with -1 and scattered into (hand in
+ *            adjacent buffers to make that one fill).  A kind-0 layer's nbr_in[i] may be NULL (mirror image of nbr_out, see
+ *            btc_rulebook_subm); with nbr_out[i] == nbr_in[i] == NULL the layer is skipped (the caller built that rulebook).
  * ws (btc_chain_ws_bytes) must be the same, untouched, for both phases; the phases may run on different streams as long
  * as phase B is ordered behind phase A (the detection backbone runs phase A on a side stream beside its first stage). */
 #define BTC_CHAIN_MAX_LAYERS 32
@@ -246,6 +251,8 @@ int btc_conv_dgrad_bf16w(const void* dout, const void* w_bf16, const int32_t* nb
  * order; the result is bit-identical either way.
  *   pass     : BTC_PASS_FWD   dst[i] = bias + sum_k src[nbr[i][k]] @ W[k]        (nbr = nbr_out, n_rows = n_out)
  *              BTC_PASS_DGRAD dst[j] = sum_k src[nbr[j][k]] @ W[k]^T             (nbr = nbr_in,  n_rows = n_in, bias NULL)
+ *              BTC_PASS_DGRAD_MIRROR  the same for a SUBMANIFOLD layer given its nbr_OUT: dst[j] = sum_k src[nbr[j][K-1-k]] @ W[k]^T
+ *                             (nbr_in[j][k] == nbr_out[j][K-1-k] there; same summation order, same bits as BTC_PASS_DGRAD on nbr_in)
  *   operands : BTC_OPERANDS_F32; BTC_OPERANDS_BF16_ACT (bf16 src / dst, fp32 W); BTC_OPERANDS_BF16 (bf16 src / dst and W =
  *              the bf16 copy btc_weights_to_bf16 made for that pass: wt_bf16 for FWD, w_bf16 for DGRAD)
  * btc_conv_wgrad_ordered: btc_conv_wgrad (bf16_act = 0) / btc_conv_wgrad_bf16 (1) walking the rows in the given order(s)
@@ -253,6 +260,7 @@ int btc_conv_dgrad_bf16w(const void* dout, const void* w_bf16, const int32_t* nb
 #define BTC_ROW_ORDER_MAX_MAPS 64
 #define BTC_PASS_FWD 0
 #define BTC_PASS_DGRAD 1
+#define BTC_PASS_DGRAD_MIRROR 2
 #define BTC_OPERANDS_F32 0
 #define BTC_OPERANDS_BF16_ACT 1
 #define BTC_OPERANDS_BF16 2
