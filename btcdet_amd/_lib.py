@@ -93,7 +93,7 @@ _SIGS = {
     "btc_chain_ws_bytes": (sz, [vp, ci, ci, ci]),
     "btc_chain_caps": (ci, [vp, ci, ci, ci, vp]),
     "btc_chain_levels": (ci, [vp, ci, ci, vp, ci, vp, vp, vp, vp, sz, vp]),
-    "btc_chain_maps": (ci, [vp, ci, ci, vp, ci, vp, vp, vp, vp, vp, sz, vp]),
+    "btc_chain_maps": (ci, [vp, ci, ci, vp, ci, vp, vp, vp, vp, vp, vp, vp, sz, vp]),
     "btc_conv_fwd": (ci, [vp, vp, vp, vp, ci, ci, ci, ci, vp, vp]),
     "btc_conv_dgrad": (ci, [vp, vp, vp, ci, ci, ci, ci, vp, vp]),
     "btc_conv_wgrad_ws_bytes": (sz, [ci, ci, ci, ci, ci]),
@@ -106,6 +106,7 @@ _SIGS = {
     "btc_conv_fwd_bf16w": (ci, [vp, vp, vp, vp, ci, ci, ci, ci, vp, vp]),
     "btc_conv_dgrad_bf16w": (ci, [vp, vp, vp, ci, ci, ci, ci, vp, vp]),
     "btc_row_orders": (ci, [vp, c_i32p, c_i32p, ci, vp, vp]),
+    "btc_row_orders_keyed": (ci, [vp, vp, c_i32p, c_i32p, ci, vp, vp]),
     "btc_conv_apply_ordered": (ci, [ci, ci, vp, vp, vp, vp, vp, ci, ci, ci, ci, vp, vp]),
     "btc_conv_wgrad_ordered": (ci, [ci, vp, vp, vp, ci, vp, ci, vp, vp, ci, ci, ci, vp, vp, sz, vp]),
     "btc_adam_group_ws_bytes": (sz, [ci]),

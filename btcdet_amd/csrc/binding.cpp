@@ -324,11 +324,16 @@ std::tuple<OptTensor, OptTensor> conv_bwd(const Tensor& features, const Tensor& 
 
 // row-order hints (csrc/row_order.hip) of several neighbour maps from ONE launch: order[j] is a slice of one buffer.  The apply
 // kernels tile the rows in that order (rows with the same offsets share a tile); results do not depend on it.
-std::vector<Tensor> row_orders(const std::vector<Tensor>& maps, int64_t stream) {
+std::vector<Tensor> row_orders_keyed(const std::vector<Tensor>& maps, const std::vector<Tensor>& keys, int64_t stream);
+std::vector<Tensor> row_orders(const std::vector<Tensor>& maps, int64_t stream) { return row_orders_keyed(maps, {}, stream); }
+
+// keys: nothing, or per map an undefined tensor / the (n) first-offset keys the rulebook fill wrote (btc_row_orders_keyed)
+std::vector<Tensor> row_orders_keyed(const std::vector<Tensor>& maps, const std::vector<Tensor>& keys, int64_t stream) {
   std::vector<Tensor> out(maps.size());
+  need(keys.empty() || keys.size() == maps.size(), "row_orders: one key tensor (or an undefined one) per map");
   for (size_t base = 0; base < maps.size(); base += BTC_ROW_ORDER_MAX_MAPS) {
     const size_t m = std::min(maps.size() - base, (size_t)BTC_ROW_ORDER_MAX_MAPS);
-    std::vector<const int32_t*> ptrs(m);
+    std::vector<const int32_t*> ptrs(m), kptrs(m, nullptr);
     std::vector<int32_t> ns(m), ks(m);
     int64_t total = 0;
     for (size_t j = 0; j < m; ++j) {
@@ -338,9 +343,14 @@ std::vector<Tensor> row_orders(const std::vector<Tensor>& maps, int64_t stream) 
       ns[j] = (int32_t)t.size(0);
       ks[j] = (int32_t)t.size(1);
       total += t.size(0);
+      if (!keys.empty() && keys[base + j].defined()) {
+        const Tensor& k = keys[base + j];
+        need(k.scalar_type() == at::kInt && k.is_contiguous() && k.numel() == t.size(0), "row_orders: keys must be (n) int32 contiguous");
+        kptrs[j] = (const int32_t*)k.data_ptr();
+      }
     }
     Tensor order = at::empty({total > 0 ? total : 1}, maps[base].options());
-    chk(btc_row_orders(ptrs.data(), ns.data(), ks.data(), (int)m, (int32_t*)order.data_ptr(), st(stream)), "btc_row_orders");
+    chk(btc_row_orders_keyed(ptrs.data(), kptrs.data(), ns.data(), ks.data(), (int)m, (int32_t*)order.data_ptr(), st(stream)), "btc_row_orders_keyed");
     int64_t off = 0;
     for (size_t j = 0; j < m; ++j) {
       out[base + j] = order.narrow(0, off, ns[j]);
@@ -622,7 +632,7 @@ std::shared_ptr<PendingWalk> geometry_walk_start(const Tensor& indices, int64_t 
   p->wsb = btc_chain_ws_bytes(p->layers.data(), (int)n, (int)batch, p->n0);
   need(p->wsb > 0, "geometry_walk: btc_chain_ws_bytes failed");
   p->ws = at::empty({(int64_t)p->wsb}, indices.options().dtype(at::kByte));
-  p->d_counts = at::zeros({(int64_t)n}, indices.options());
+  p->d_counts = at::empty({(int64_t)n}, indices.options());   // (every entry that is read -- the strided layers' -- is written by its level's scan)
   p->out_idx.resize(n);
   std::vector<int32_t*> p_out_idx(n, nullptr);
   for (size_t i = 0; i < n; ++i)
@@ -702,11 +712,26 @@ std::vector<std::vector<Tensor>> geometry_walk_finish(const std::shared_ptr<Pend
       level_out[i] = cur;
     }
   }
-  // the strided layers' nbr_out in ONE buffer (one -1 fill for the chain), everything else in another
+  // the strided layers' nbr_out in ONE buffer (one -1 fill for those that need it), everything else in another
   Tensor buf_s = at::empty({strided_elems > 0 ? strided_elems : 1}, indices.options());
   Tensor buf_o = at::empty({other_elems > 0 ? other_elems : 1}, indices.options());
   int64_t off_s = 0, off_o = 0;
   std::vector<std::vector<Tensor>> out(n);
+  // row-order hints of the strided / transposed layers' maps (both directions), one launch for the chain: these are the maps
+  // whose 16-row tiles are mostly empty in coordinate order (csrc/row_order.hip).  BTC_ROW_ORDER=2 orders the SubM maps too
+  // (measured: within noise at KITTI sizes), 0 none.  The sort keys (first present offset of every row) come out of the fill
+  // itself (btc_chain_maps first_out / first_in).
+  static const int order_mode = getenv("BTC_ROW_ORDER") ? atoi(getenv("BTC_ROW_ORDER")) : 1;
+  auto wants_order = [&](size_t i) {
+    return !skip[i] && K[i] <= 64 && ((kind[i] == 1 && order_mode >= 1) || (kind[i] == 0 && order_mode >= 2));
+  };
+  int64_t key_elems = 0;
+  for (size_t i = 0; i < n; ++i)
+    if (kind[i] == 1 && wants_order(i)) key_elems += level_in[i].size(0) + level_out[i].size(0);
+  Tensor buf_k = at::empty({key_elems > 0 ? key_elems : 1}, indices.options());
+  int64_t off_k = 0;
+  std::vector<int32_t*> p_first_out(n, nullptr), p_first_in(n, nullptr);
+  std::vector<Tensor> key_out(n), key_in(n);
   for (size_t i = 0; i < n; ++i) {
     if (kind[i] > 1 || skip[i]) continue;
     const int64_t rows_in = level_in[i].size(0), rows_out = level_out[i].size(0);
@@ -723,28 +748,36 @@ std::vector<std::vector<Tensor>> geometry_walk_finish(const std::shared_ptr<Pend
       nbr_in = buf_o.narrow(0, off_o, rows_in * K[i]).view({rows_in, K[i]});
       off_o += rows_in * K[i];
       p_nbr_in[i] = (int32_t*)nbr_in.data_ptr();
+      if (wants_order(i)) {
+        key_in[i] = buf_k.narrow(0, off_k, rows_in);
+        off_k += rows_in;
+        p_first_in[i] = (int32_t*)key_in[i].data_ptr();
+        key_out[i] = buf_k.narrow(0, off_k, rows_out);
+        off_k += rows_out;
+        p_first_out[i] = (int32_t*)key_out[i].data_ptr();
+      }
     } else {
       nbr_in = nbr_out;   // the SAME tensor: conv_bwd recognises the submanifold rulebook by that and reads it mirrored
     }
     out[i] = {level_in[i], level_out[i], nbr_out, nbr_in};
   }
   chk(btc_chain_maps((const int32_t*)indices.data_ptr(), p->n0, (int)p->batch, p->layers.data(), (int)n, hc, p_out_idx.data(), p_nbr_out.data(),
-                     p_nbr_in.data(), p->ws.data_ptr(), p->wsb, st(stream)), "btc_chain_maps");
-  // row-order hints of the strided / transposed layers' maps (both directions), one launch for the chain: these are the maps
-  // whose 16-row tiles are mostly empty in coordinate order (csrc/row_order.hip).  BTC_ROW_ORDER=2 orders the SubM maps too
-  // (measured: within noise at KITTI sizes), 0 none.
-  static const int order_mode = getenv("BTC_ROW_ORDER") ? atoi(getenv("BTC_ROW_ORDER")) : 1;
-  auto wants_order = [&](size_t i) {
-    return !skip[i] && K[i] <= 64 && ((kind[i] == 1 && order_mode >= 1) || (kind[i] == 0 && order_mode >= 2));
-  };
-  std::vector<Tensor> to_order;
+                     p_nbr_in.data(), p_first_out.data(), p_first_in.data(), p->ws.data_ptr(), p->wsb, st(stream)), "btc_chain_maps");
+  std::vector<Tensor> to_order, to_order_keys;
   for (size_t i = 0; i < n; ++i)
     if (wants_order(i)) {
       to_order.push_back(out[i][2]);
+      to_order_keys.push_back(key_out[i]);
       to_order.push_back(out[i][3]);
+      to_order_keys.push_back(key_in[i]);
     }
   if (!to_order.empty()) {
-    auto ord = row_orders(to_order, stream);
+    if (getenv("BTC_DEBUG_KEYS")) {
+      int nk = 0;
+      for (const Tensor& t : to_order_keys) nk += t.defined();
+      fprintf(stderr, "[btcfast] row orders: %zu maps, %d with keys\n", to_order.size(), nk);
+    }
+    auto ord = row_orders_keyed(to_order, to_order_keys, stream);
     size_t q = 0;
     for (size_t i = 0; i < n; ++i)
       if (wants_order(i)) {

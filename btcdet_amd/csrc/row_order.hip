@@ -30,6 +30,8 @@ constexpr int ORDER_BINS = 65;    // first offsets 0 .. 63, and "no neighbour"
 
 struct OrderJobs {
   const int32_t* nbr[MAX_MAPS];
+  const int32_t* first[MAX_MAPS];   // per map: the rows' first present offsets when the rulebook fill produced them (rulebook.hip), else NULL
+
   int n[MAX_MAPS];
   int K[MAX_MAPS];
   int off[MAX_MAPS];       // first element of the map's order in the output
@@ -50,7 +52,10 @@ __global__ __launch_bounds__(ORDER_T) void order_local(OrderJobs jobs, int32_t* 
   for (int r = tid; r < ORDER_BLK; r += ORDER_T) s_first[r] = K;
   for (int e = tid; e < ORDER_BINS * ORDER_W; e += ORDER_T) s_cnt[e] = 0;
   __syncthreads();
-  {
+  if (jobs.first[j]) {   // 4 bytes a row instead of 4 K: the keys came out of the rulebook fill
+    const int32_t* f = jobs.first[j] + row0;
+    for (int r = tid; r < rows; r += ORDER_T) s_first[r] = min(f[r], K);   // (a scattered map's untouched keys hold a large value)
+  } else {
     const int32_t* base = jobs.nbr[j] + (size_t)row0 * K;   // rows * K consecutive ints: coalesced
     const int total = rows * K;
     for (int e0 = tid; e0 < total; e0 += 8 * ORDER_T) {     // 8 loads in flight per thread (the walk is latency bound otherwise)
@@ -120,6 +125,11 @@ __global__ __launch_bounds__(ORDER_T) void order_local(OrderJobs jobs, int32_t* 
 }  // namespace
 
 extern "C" int btc_row_orders(const int32_t* const* nbrs, const int32_t* n_rows, const int32_t* Ks, int n_maps, int32_t* order, void* stream) {
+  return btc_row_orders_keyed(nbrs, nullptr, n_rows, Ks, n_maps, order, stream);
+}
+
+extern "C" int btc_row_orders_keyed(const int32_t* const* nbrs, const int32_t* const* firsts, const int32_t* n_rows, const int32_t* Ks, int n_maps,
+                                    int32_t* order, void* stream) {
   BTC_CHECK_ARG(n_maps >= 1 && n_maps <= MAX_MAPS, "btc_row_orders: 1..%d maps per call (got %d)", MAX_MAPS, n_maps);
   OrderJobs jobs;
   long long total = 0;
@@ -127,8 +137,9 @@ extern "C" int btc_row_orders(const int32_t* const* nbrs, const int32_t* n_rows,
   for (int j = 0; j < n_maps; ++j) {
     BTC_CHECK_ARG(n_rows[j] >= 0 && Ks[j] >= 1 && Ks[j] <= ORDER_BINS - 1, "btc_row_orders: map %d: n=%d K=%d (K <= %d)", j, n_rows[j], Ks[j],
                   ORDER_BINS - 1);
-    BTC_CHECK_ARG(n_rows[j] == 0 || nbrs[j] != nullptr, "btc_row_orders: map %d is NULL", j);
+    BTC_CHECK_ARG(n_rows[j] == 0 || nbrs[j] != nullptr || (firsts && firsts[j]), "btc_row_orders: map %d is NULL", j);
     jobs.nbr[j] = nbrs[j];
+    jobs.first[j] = firsts ? firsts[j] : nullptr;
     jobs.n[j] = n_rows[j];
     jobs.K[j] = Ks[j];
     jobs.off[j] = (int)total;

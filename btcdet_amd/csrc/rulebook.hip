@@ -137,19 +137,93 @@ __device__ __forceinline__ void mark_line(const BtcGeom& g, const Level& out, in
   if (cur_bits) or_word(out.words, cur_w, cur_bits);
 }
 
-// n rows: from d_n (device, the count of the producing level) when given, else n_host; one thread per (row, kz, ky)
-__global__ __launch_bounds__(RB_T) void rb_mark(const int4* __restrict__ idx, int n_host, const int32_t* __restrict__ d_n, BtcGeom g, Level out) {
+// n rows: from d_n (device, the count of the producing level) when given, else n_host.  A workgroup takes MARK_ROWS consecutive
+// rows.  Rows of a level built here are sorted by cell, i.e. neighbours in space, and under a stride-2 layer ~8 of them reach the
+// same output cell: marked straight into the global bitmap, the 9 x rows device-scope atomic ORs of such a workgroup pile up on a
+// few dozen words (the 40 K-row occupancy level: 53 us for this launch).  So when the workgroup's rows lie in one (batch, z) plane
+// it ORs into an LDS window of the <= 3 output planes x the y-range the rows can reach, and flushes the non-zero words with one
+// global atomic each.  `sorted` = 0 (the chain's arbitrary-order input level) and windows that do not fit mark directly.
+constexpr int MARK_ROWS = 32;    // x (kz, ky) lines = 288 items for 256 threads; small enough that a 3 K-row level still spreads over ~100 workgroups
+constexpr int MARK_WIN = 384;   // bitmap words per staged output plane
+
+__global__ __launch_bounds__(RB_T) void rb_mark(const int4* __restrict__ idx, int n_host, const int32_t* __restrict__ d_n, BtcGeom g, Level out,
+                                                int sorted) {
+  __shared__ unsigned s_win[3][MARK_WIN];
+  __shared__ long long s_w0[3];
+  __shared__ int s_cnt[3];
+  __shared__ int s_stage;
   const int n = d_n ? *d_n : n_host;
+  const int tid = threadIdx.x;
+  // (the grid is sized from a host-side BOUND on the level's rows, capped: the workgroups stride over the real row tiles)
+  for (int r0 = blockIdx.x * MARK_ROWS; r0 < n; r0 += gridDim.x * MARK_ROWS) {
+  const int rows = n - r0 < MARK_ROWS ? n - r0 : MARK_ROWS;
+  __syncthreads();   // the previous tile's flush has read the window
+  if (tid == 0) {
+    int stage = 0;
+    if (sorted && g.k[0] <= 3 && rows >= 8) {
+      const int4 a = idx[r0], b = idx[r0 + rows - 1];
+      if (a.x == b.x && a.y == b.y) {
+        // y-range of the output cells the rows can reach (fwd_axis over y in [a.z, b.z])
+        int ylo, yhi;
+        if (g.mode == BTC_MODE_CONV) {
+          const int t0 = a.z + g.p[1] - (g.k[1] - 1) * g.d[1];
+          ylo = t0 <= 0 ? 0 : t0 / g.s[1];
+          yhi = (b.z + g.p[1]) / g.s[1];
+        } else {
+          ylo = a.z * g.s[1] - g.p[1];
+          yhi = b.z * g.s[1] - g.p[1] + (g.k[1] - 1) * g.d[1];
+        }
+        ylo = ylo < 0 ? 0 : ylo;
+        yhi = yhi >= g.out_shape[1] ? g.out_shape[1] - 1 : yhi;
+        stage = 1;
+        for (int kz = 0; kz < 3; ++kz) {
+          int oz;
+          s_cnt[kz] = 0;
+          s_w0[kz] = 0;
+          if (kz >= g.k[0] || ylo > yhi || !fwd_axis(g, 0, a.y, kz, &oz)) continue;
+          const long long w_lo = lvl_cell(out, a.x, oz, ylo, 0) >> 5, w_hi = lvl_cell(out, a.x, oz, yhi, out.shape[2] - 1) >> 5;
+          if (w_hi - w_lo + 1 > MARK_WIN) { stage = 0; break; }
+          s_w0[kz] = w_lo;
+          s_cnt[kz] = (int)(w_hi - w_lo + 1);
+        }
+      }
+    }
+    s_stage = stage;
+  }
+  for (int e = tid; e < 3 * MARK_WIN; e += RB_T) (&s_win[0][0])[e] = 0u;
+  __syncthreads();
+  const bool staged = s_stage != 0;
   const int lines = g.k[0] * g.k[1];
-  const long long total = (long long)n * lines;
-  for (long long t = (long long)blockIdx.x * RB_T + threadIdx.x; t < total; t += (long long)gridDim.x * RB_T) {
-    int i, l;
-    if (lines == 9) { const long long q = t / 9; i = (int)q; l = (int)(t - q * 9); }
-    else { const long long q = t / lines; i = (int)q; l = (int)(t - q * lines); }
-    const int kz = (g.k[1] == 3) ? l / 3 : l / g.k[1];
-    const int ky = l - kz * g.k[1];
-    const int4 c = idx[i];
-    mark_line(g, out, c.x, c.y, c.z, c.w, kz, ky);
+  if (!staged) {
+    for (int e = tid; e < rows * lines; e += RB_T) {
+      const int il = e / lines, l = e - il * lines;
+      const int kz = l / g.k[1], ky = l - kz * g.k[1];
+      const int4 c = idx[r0 + il];
+      mark_line(g, out, c.x, c.y, c.z, c.w, kz, ky);
+    }
+    continue;
+  }
+  for (int e = tid; e < rows * lines; e += RB_T) {
+    const int il = e / lines, l = e - il * lines;
+    const int kz = l / g.k[1], ky = l - kz * g.k[1];
+    const int4 c = idx[r0 + il];
+    int oz, oy;
+    if (!fwd_axis(g, 0, c.y, kz, &oz) || !fwd_axis(g, 1, c.z, ky, &oy)) continue;
+    const long long line = lvl_cell(out, c.x, oz, oy, 0);
+    for (int kx = 0; kx < g.k[2]; ++kx) {
+      int ox;
+      if (!fwd_axis(g, 2, c.w, kx, &ox)) continue;
+      const long long cell = line + ox;
+      atomicOr(&s_win[kz][(int)((cell >> 5) - s_w0[kz])], 1u << ((unsigned)cell & 31u));
+    }
+  }
+  __syncthreads();
+  for (int e = tid; e < 3 * MARK_WIN; e += RB_T) {
+    const int pz = e / MARK_WIN, j = e - pz * MARK_WIN;
+    if (j >= s_cnt[pz]) continue;
+    const unsigned bits = s_win[pz][j];
+    if (bits) or_word(out.words, s_w0[pz] + j, bits);
+  }
   }
 }
 
@@ -223,9 +297,7 @@ __global__ __launch_bounds__(RB_T) void rb_scan(Level L, int32_t* __restrict__ c
 
 // rows of a scanned level in ascending cell order: one thread per bitmap word (its rank base = chunk prefix + block prefix +
 // the words in front of it inside the 32-byte block)
-__global__ __launch_bounds__(RB_T) void rb_emit(Level L, int4* __restrict__ out_idx, long long cap) {
-  const long long w = (long long)blockIdx.x * RB_T + threadIdx.x;
-  if (w >= L.nblk * RB_BLK) return;
+__device__ __forceinline__ void emit_word(const Level& L, long long w, int4* __restrict__ out_idx, long long cap) {
   unsigned bits = L.words[w];
   if (!bits) return;
   const long long blk = w >> 3;
@@ -249,6 +321,12 @@ __global__ __launch_bounds__(RB_T) void rb_emit(Level L, int4* __restrict__ out_
     if (row < cap) out_idx[row] = make_int4(bb, z, y, x);
     ++row;
   }
+}
+
+__global__ __launch_bounds__(RB_T) void rb_emit(Level L, int4* __restrict__ out_idx, long long cap) {
+  const long long w = (long long)blockIdx.x * RB_T + threadIdx.x;
+  if (w >= L.nblk * RB_BLK) return;
+  emit_word(L, w, out_idx, cap);
 }
 
 // ---- 64-bit-key hash of an arbitrary (unsorted) input level: key = cell + 1, 0 = empty (one memset clears bitmaps and hash)
@@ -300,7 +378,7 @@ __device__ __forceinline__ int rb_hash_find(unsigned long long key, unsigned lon
 // words per staged WORD instead of per hit).  Windows that do not fit (sparse levels: 64 rows spread over many grid lines) and
 // hashed levels are probed directly.
 enum { JOB_FWD = 0, JOB_BWD = 1, JOB_SUBM = 2 };
-constexpr int RB_ROWS = 64;          // rows per workgroup of rb_fill
+constexpr int RB_ROWS = 32;          // rows per workgroup of rb_fill (x 27 offsets = 864 probes for 256 threads)
 constexpr int RB_WIN = 224;          // bitmap words per staged plane window
 
 struct Job {
@@ -314,6 +392,10 @@ struct Job {
   const int4* idx;              // the walked rows
   int32_t* map;                 // (n, K), written coalesced: FWD nbr_in, BWD nbr_out, SUBM nbr_out
   int32_t* map2;                // FWD: nbr_out to scatter into, or NULL; SUBM: nbr_in (mirror image), or NULL
+  int32_t* first;               // (n) or NULL: lowest offset k with map[i][k] >= 0, K if none -- the sort key of the row-order hints
+                                // (row_order.hip), produced here so that order_local need not read the map again
+  int32_t* first2;              // FWD + scatter: the same keys for the scattered map (rows of the OUTPUT level), pre-filled with a
+                                // large value and lowered with atomicMin; or NULL
   const unsigned long long* keys;
   const int32_t* vals;
   unsigned long long mask;
@@ -365,6 +447,7 @@ __global__ __launch_bounds__(RB_T) void rb_fill(Jobs jobs) {
   __shared__ long long s_w0[3];
   __shared__ int s_cnt[3];
   __shared__ int s_stage;
+  __shared__ int s_first[RB_ROWS];
   int ji = 0;
 #pragma unroll
   for (int q = 1; q < RB_MAX_JOBS; ++q)
@@ -400,6 +483,7 @@ __global__ __launch_bounds__(RB_T) void rb_fill(Jobs jobs) {
     }
     s_stage = stage;
   }
+  if (tid < RB_ROWS) s_first[tid] = K;
   __syncthreads();
   const bool staged = s_stage != 0;
   if (staged) {
@@ -447,10 +531,18 @@ __global__ __launch_bounds__(RB_T) void rb_fill(Jobs jobs) {
       }
     }
     J.map[(size_t)i * K + kk] = r;
+    if (J.first && r >= 0) atomicMin(&s_first[il], kk);
     if (J.map2) {
       if (J.type == JOB_SUBM) J.map2[(size_t)i * K + (K - 1 - kk)] = r;   // input i feeds, at the mirrored offset, exactly the row that is its neighbour here
-      else if (r >= 0) J.map2[(size_t)r * K + kk] = i;                     // JOB_FWD scatter (the output level is the union of what is reachable: r >= 0 whenever the cell is in range)
+      else if (r >= 0) {                                                   // JOB_FWD scatter (the output level is the union of what is reachable: r >= 0 whenever the cell is in range)
+        J.map2[(size_t)r * K + kk] = i;
+        if (J.first2) atomicMin(&J.first2[r], kk);
+      }
     }
+  }
+  if (J.first) {
+    __syncthreads();
+    if (tid < rows) J.first[r0 + tid] = s_first[tid];
   }
 }
 
@@ -540,9 +632,9 @@ Level make_level(const LevelLayout& lo, const int32_t* shape, unsigned* words, i
   return L;
 }
 
-int mark_grid(long long n_lines) {
-  long long g = (n_lines + RB_T - 1) / RB_T;
-  return (int)(g > 4096 ? 4096 : (g < 1 ? 1 : g));
+int mark_grid(long long n_rows) {   // one workgroup per MARK_ROWS rows of the host-side bound, at most 4096 (they stride over the real tiles)
+  long long g = (n_rows + MARK_ROWS - 1) / MARK_ROWS;
+  return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
 }
 
 }  // namespace
@@ -592,7 +684,7 @@ extern "C" int btc_rulebook_subm(const int32_t* indices, int n, int batch, const
   jobs.count = 1;
   Job& J = jobs.j[0];
   J.type = JOB_SUBM; J.n = n; J.ranked = 0; J.sorted = 0; J.first_block = 0; J.g = g; J.lvl = L; J.idx = (const int4*)indices;
-  J.map = nbr_out; J.map2 = nbr_in; J.keys = keys; J.vals = vals; J.mask = cap - 1;
+  J.map = nbr_out; J.map2 = nbr_in; J.first = nullptr; J.first2 = nullptr; J.keys = keys; J.vals = vals; J.mask = cap - 1;
   rb_fill<<<btc_cdiv(n, RB_ROWS), RB_T, 0, stream>>>(jobs);
   BTC_LAUNCH_CHECK();
   return BTC_OK;
@@ -636,7 +728,7 @@ extern "C" int btc_rulebook_conv_count(const int32_t* indices, int n, int batch,
   if (rc) return rc;
   BTC_HIP(hipMemsetAsync(L.words, 0, lo.words_bytes + 256, stream));
   if (n > 0) {
-    rb_mark<<<mark_grid((long long)n * g.k[0] * g.k[1]), RB_T, 0, stream>>>((const int4*)indices, n, nullptr, g, L);
+    rb_mark<<<mark_grid(n), RB_T, 0, stream>>>((const int4*)indices, n, nullptr, g, L, 0);
     BTC_LAUNCH_CHECK();
   }
   rb_scan<<<lo.nchunks, RB_T, 0, stream>>>(L, chunk_sums, counter, lo.nchunks, d_n_out);
@@ -668,7 +760,7 @@ extern "C" int btc_rulebook_conv_fill(const int32_t* indices, int n, int batch, 
     jobs.count = 1;
     Job& J = jobs.j[0];
     J.type = JOB_FWD; J.n = n; J.ranked = 1; J.sorted = 0; J.first_block = 0; J.g = g; J.lvl = L; J.idx = (const int4*)indices;
-    J.map = nbr_in; J.map2 = nbr_out; J.keys = nullptr; J.vals = nullptr; J.mask = 0;
+    J.map = nbr_in; J.map2 = nbr_out; J.first = nullptr; J.first2 = nullptr; J.keys = nullptr; J.vals = nullptr; J.mask = 0;
     rb_fill<<<btc_cdiv(n, RB_ROWS), RB_T, 0, stream>>>(jobs);
     BTC_LAUNCH_CHECK();
   }
@@ -843,7 +935,7 @@ extern "C" int btc_chain_levels(const int32_t* indices, int n0, int batch, const
     const BtcGeom g = geom_of(layers[i]);
     if (li == 0) {
       if (n0 > 0) {
-        rb_mark<<<mark_grid((long long)n0 * g.k[0] * g.k[1]), RB_T, 0, stream>>>((const int4*)indices, n0, nullptr, g, W.lv[lo]);
+        rb_mark<<<mark_grid(n0), RB_T, 0, stream>>>((const int4*)indices, n0, nullptr, g, W.lv[lo], 0);
         BTC_LAUNCH_CHECK();
       }
     } else {
@@ -852,7 +944,7 @@ extern "C" int btc_chain_levels(const int32_t* indices, int n0, int batch, const
         if (rc) return rc;
       }
       const int prod = P.producer[li];   // row-parallel over the producing level's rows; their count stays on the device
-      rb_mark<<<mark_grid(h_cap[prod] * g.k[0] * g.k[1]), RB_T, 0, stream>>>((const int4*)out_indices[prod], 0, d_counts + prod, g, W.lv[lo]);
+      rb_mark<<<mark_grid(h_cap[prod]), RB_T, 0, stream>>>((const int4*)out_indices[prod], 0, d_counts + prod, g, W.lv[lo], 1);
       BTC_LAUNCH_CHECK();
     }
     rb_scan<<<W.lo[lo].nchunks, RB_T, 0, stream>>>(W.lv[lo], W.chunk_sums[lo], W.counters + lo, W.lo[lo].nchunks, d_counts + i);
@@ -867,8 +959,8 @@ extern "C" int btc_chain_levels(const int32_t* indices, int n0, int batch, const
 }
 
 extern "C" int btc_chain_maps(const int32_t* indices, int n0, int batch, const BtcChainLayer* layers, int n_layers, const int32_t* h_counts,
-                              int32_t* const* out_indices, int32_t* const* nbr_out, int32_t* const* nbr_in, void* ws, size_t ws_bytes,
-                              void* stream_) {
+                              int32_t* const* out_indices, int32_t* const* nbr_out, int32_t* const* nbr_in, int32_t* const* first_out,
+                              int32_t* const* first_in, void* ws, size_t ws_bytes, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   ChainPlan P;
   int rc = chain_plan(layers, n_layers, &P);
@@ -919,7 +1011,8 @@ extern "C" int btc_chain_maps(const int32_t* indices, int n0, int batch, const B
     blocks = 0;
     return BTC_OK;
   };
-  auto add = [&](int type, int n, const BtcGeom& g, const Level& lvl, int ranked, int sorted, const int32_t* idx, int32_t* map, int32_t* map2) -> int {
+  auto add = [&](int type, int n, const BtcGeom& g, const Level& lvl, int ranked, int sorted, const int32_t* idx, int32_t* map, int32_t* map2,
+                 int32_t* first, int32_t* first2 = nullptr) -> int {
     if (n <= 0) return BTC_OK;
     const long long nb = btc_cdiv(n, RB_ROWS);
     if (jobs.count == RB_MAX_JOBS || blocks + nb > 0x7fffffffLL) {
@@ -928,7 +1021,7 @@ extern "C" int btc_chain_maps(const int32_t* indices, int n0, int batch, const B
     }
     Job& J = jobs.j[jobs.count++];
     J.type = type; J.n = n; J.ranked = ranked; J.sorted = sorted; J.first_block = blocks; J.g = g; J.lvl = lvl; J.idx = (const int4*)idx;
-    J.map = map; J.map2 = map2; J.keys = W.keys; J.vals = W.vals; J.mask = W.hash_cap ? W.hash_cap - 1 : 0;
+    J.map = map; J.map2 = map2; J.first = first; J.first2 = first2; J.keys = W.keys; J.vals = W.vals; J.mask = W.hash_cap ? W.hash_cap - 1 : 0;
     blocks += nb;
     return BTC_OK;
   };
@@ -941,20 +1034,23 @@ extern "C" int btc_chain_maps(const int32_t* indices, int n0, int batch, const B
     if (layers[i].kind == 1) {
       const int lo = P.lvl_out[i];
       // nbr_in: the input rows probe the output level; level-0 inputs also scatter nbr_out (see above)
-      rc = add(JOB_FWD, rows_of[li], g, W.lv[lo], 1, li != 0, idx_of[li], nbr_in[i], li == 0 ? nbr_out[i] : nullptr);
+      int32_t* keys2 = (li == 0 && first_out) ? first_out[i] : nullptr;
+      if (keys2 && h_counts[i] > 0)   // scattered keys start large (0x7f7f7f7f) and are lowered with atomicMin; readers clamp to K
+        BTC_HIP(hipMemsetAsync(keys2, 0x7F, (size_t)h_counts[i] * sizeof(int32_t), stream));
+      rc = add(JOB_FWD, rows_of[li], g, W.lv[lo], 1, li != 0, idx_of[li], nbr_in[i], li == 0 ? nbr_out[i] : nullptr, first_in ? first_in[i] : nullptr, keys2);
       if (rc) return rc;
       if (li != 0) {   // nbr_out: the output rows probe the (ranked) input level
-        rc = add(JOB_BWD, rows_of[lo], g, W.lv[li], 1, 1, idx_of[lo], nbr_out[i], nullptr);
+        rc = add(JOB_BWD, rows_of[lo], g, W.lv[li], 1, 1, idx_of[lo], nbr_out[i], nullptr, first_out ? first_out[i] : nullptr);
         if (rc) return rc;
       }
     } else if (li == 0) {
       LevelLayout l0;
       rc = level_layout(batch, layers[i].in_shape, &l0);
       if (rc) return rc;
-      rc = add(JOB_SUBM, rows_of[li], g, make_level(l0, layers[i].in_shape, nullptr, nullptr, nullptr), 0, 0, idx_of[li], nbr_out[i], nbr_in[i]);
+      rc = add(JOB_SUBM, rows_of[li], g, make_level(l0, layers[i].in_shape, nullptr, nullptr, nullptr), 0, 0, idx_of[li], nbr_out[i], nbr_in[i], nullptr);
       if (rc) return rc;
     } else {
-      rc = add(JOB_SUBM, rows_of[li], g, W.lv[li], 1, 1, idx_of[li], nbr_out[i], nbr_in[i]);
+      rc = add(JOB_SUBM, rows_of[li], g, W.lv[li], 1, 1, idx_of[li], nbr_out[i], nbr_in[i], nullptr);
       if (rc) return rc;
     }
   }

@@ -186,8 +186,10 @@ int btc_chain_caps(const BtcChainLayer* h_layers, int n_layers, int batch, int n
 int btc_chain_levels(const int32_t* indices, int n0, int batch, const BtcChainLayer* h_layers, int n_layers,
                      int32_t* const* h_out_indices, const int64_t* h_cap, int32_t* d_counts, void* ws, size_t ws_bytes, void* stream);
 int btc_chain_maps(const int32_t* indices, int n0, int batch, const BtcChainLayer* h_layers, int n_layers, const int32_t* h_counts,
-                   int32_t* const* h_out_indices, int32_t* const* h_nbr_out, int32_t* const* h_nbr_in, void* ws, size_t ws_bytes,
-                   void* stream);
+                   int32_t* const* h_out_indices, int32_t* const* h_nbr_out, int32_t* const* h_nbr_in,
+                   int32_t* const* h_first_out /* NULL, or per layer NULL / (rows_out) keys of nbr_out for btc_row_orders_keyed (values
+                                                  above K mean K) */,
+                   int32_t* const* h_first_in /* the same for nbr_in (rows_in) */, void* ws, size_t ws_bytes, void* stream);
 
 /* spconv-layout view of a rulebook: pairs (2,K,n_in) int32 padded with -1, pair_num (K) int32,
  * pairs within an offset ordered by output row (the canonical order of SURVEY.md App. B.4).
@@ -266,6 +268,11 @@ int btc_conv_dgrad_bf16w(const void* dout, const void* w_bf16, const int32_t* nb
 #define BTC_OPERANDS_BF16 2
 int btc_row_orders(const int32_t* const* nbrs /* host array of device pointers */, const int32_t* n_rows /* host */,
                    const int32_t* Ks /* host */, int n_maps, int32_t* order /* device, sum n_rows */, void* stream);
+/* the same with the sort keys handed in where they exist: firsts[j] (n_rows[j]) = first present offset of every row of map j (K for a
+ * row without neighbours), as btc_chain_maps writes them while it fills the map -- order_local then reads 4 bytes a row instead of
+ * the whole map; firsts == NULL or firsts[j] == NULL: the keys are taken from nbrs[j] */
+int btc_row_orders_keyed(const int32_t* const* nbrs, const int32_t* const* firsts, const int32_t* n_rows, const int32_t* Ks, int n_maps,
+                         int32_t* order, void* stream);
 int btc_conv_apply_ordered(int pass, int operands, const void* src, const void* W, const float* bias, const int32_t* nbr,
                            const int32_t* order, int n_rows, int K, int Cin, int Cout, void* dst, void* stream);
 int btc_conv_wgrad_ordered(int bf16_act, const void* feat, const void* dout, const int32_t* nbr_out, int n_out,

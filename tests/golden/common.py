@@ -143,3 +143,27 @@ def make_gt_database(root, n_cars=40, n_peds=12, seed=5):
             infos[name].append({"name": name, "path": rel, "image_idx": "%06d" % (100 + i), "gt_idx": i % 4, "box3d_lidar": box,
                                 "num_points_in_gt": n, "difficulty": int(rng.integers(-1, 3)), "bbox": np.zeros(4, np.float32), "score": -1.0})
     return infos
+
+
+def variant_inputs(which):
+    """inputs of the backbone-variant goldens (gen_variants_golden.py / tests/test_hip_backbone_variants.py), regenerable on both
+    sides from numpy + the CPU oracle's voxelizer alone: two synthetic KITTI scenes voxelized on the occupancy grid ("occ": the
+    decoder variants, 4 mean features) or on the detection grid ("det": VoxelResBackBone8x, 4 mean features)
+    -> (voxel_features (N, 4) f32, voxel_coords (N, 4) int32 [b, z, y, x], grid_size [nx, ny, nz], batch size)"""
+    from oracle import oracle as orc
+    synth = _synth()
+    feats, coords = [], []
+    for b, seed in enumerate((41, 42)):
+        s = synth.make_scene(seed)
+        if which == "occ":
+            gen = orc.VoxelGeneratorV2(synth.KITTI_OCC_VOXEL, synth.KITTI_OCC_RANGE, 12, 20000)
+            r = gen.generate(orc.absxyz_2_cylinxyz_np(s["pre_rot_points"]))
+            grid = [209, 157, 9]
+        else:
+            gen = orc.VoxelGeneratorV2(synth.KITTI_DET_VOXEL, synth.KITTI_DET_RANGE, 5, 16000)
+            r = gen.generate(s["points"])
+            grid = [1408, 1600, 40]
+        n = np.maximum(r["num_points_per_voxel"], 1).astype(np.float32)[:, None]
+        feats.append((r["voxels"].sum(1, dtype=np.float32) / n).astype(np.float32))
+        coords.append(np.pad(r["coordinates"], ((0, 0), (1, 0)), constant_values=b).astype(np.int32))
+    return np.concatenate(feats), np.concatenate(coords), grid, 2

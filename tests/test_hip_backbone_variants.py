@@ -1,5 +1,6 @@
 """The backbone variants the reference reaches through BACKBONE_3D.NAME on the HIP operator set:
-residual blocks, lateral-merge decoders, SparseInverseConv3d decoders."""
+residual blocks, lateral-merge decoders, SparseInverseConv3d decoders -- pinned against the reference's own classes
+(tests/golden/variants.npz), plus the residual block against dense torch ops."""
 from functools import partial
 
 import numpy as np
@@ -19,37 +20,51 @@ def _batch(rng, n, B, shape, c):
     return {"voxel_features": torch.from_numpy(feats).to(dev()), "voxel_coords": torch.from_numpy(idx).to(dev()), "batch_size": B}
 
 
-@pytest.mark.parametrize("name", ["VoxelBackBoneDeconvRes", "VoxelBackBoneInverseRes"])
-def test_res_decoder_backbones_run(name):
-    from btcdet_amd import backbones_3d
-    from btcdet_amd.config import load_cfg
-    rng = np.random.default_rng(3)
-    grid = np.array([45, 37, 9])                       # 4m+1 per axis: stride-2 / transposed pairs round-trip
-    bd = _batch(rng, 1500, 2, (9, 37, 45), 4)
-    torch.manual_seed(0)
-    net = backbones_3d.__all__[name](model_cfg=load_cfg().MODEL.OCC.BACKBONE_3D, input_channels=4, grid_size=grid).to(dev()).train()
-    out = net(dict(bd))["encoded_spconv_tensor"]
-    assert out.features.shape[1] == net.num_point_features == 32 and list(out.spatial_shape) == [9, 37, 45]
-    if name == "VoxelBackBoneInverseRes":              # inverse convs restore the encoder's active set exactly
-        assert torch.equal(out.indices, bd["voxel_coords"])
-    else:                                              # conv1 is a dilating SparseConv3d: a superset of the input cells
-        assert out.features.shape[0] > bd["voxel_coords"].shape[0]
-    out.features.pow(2).mean().backward()
-    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in net.parameters())
+def _golden():
+    import os
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "variants.npz"))
 
 
-def test_res_backbone_8x_runs():
+@pytest.mark.parametrize("name,which", [("VoxelBackBoneDeconvRes", "occ"), ("VoxelBackBoneInverseRes", "occ"), ("VoxelResBackBone8x", "det")])
+def test_backbone_variants_vs_reference_modules(name, which):
+    """the three variants against the REFERENCE's own classes (spconv_backbone.py:226-627) executed over the oracle-backed spconv
+    (tests/golden/gen_variants_golden.py -> variants.npz): full-size synthetic KITTI input on the occupancy / detection grid,
+    name-keyed weights, train- and eval-mode BatchNorm -- output indices bit-exact (SHA-1), features within 2e-5 of the scale,
+    every multi-scale tensor of the residual 8x backbone included; then one backward pass (finite gradients everywhere)"""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import common
     from btcdet_amd import backbones_3d
     from btcdet_amd.config import load_cfg
-    rng = np.random.default_rng(4)
-    bd = _batch(rng, 4000, 2, (41, 96, 88), 4)
-    torch.manual_seed(0)
-    net = backbones_3d.VoxelResBackBone8x(model_cfg=load_cfg().MODEL.BACKBONE_3D, input_channels=4, grid_size=np.array([88, 96, 40])).to(dev())
+    g = _golden()
+    feats, coords, grid, B = common.variant_inputs(which)
+    assert np.array_equal(common.sha1(coords), g[name + "_in_coords_sha1"]) and np.array_equal(common.sha1(feats), g[name + "_in_feats_sha1"])
+    cfg = load_cfg()
+    model_cfg = cfg.MODEL.OCC.BACKBONE_3D if which == "occ" else cfg.MODEL.BACKBONE_3D
+    net = backbones_3d.__all__[name](model_cfg=model_cfg, input_channels=4, grid_size=np.array(grid))
+    common.init_by_name(net)
+    net = net.to(dev())
+    bd_in = {"voxel_features": torch.from_numpy(feats).to(dev()), "voxel_coords": torch.from_numpy(coords).to(dev()).float(), "batch_size": B}
+    for mode in ("train", "eval"):
+        net.train(mode == "train")
+        state = {k: v.clone() for k, v in net.state_dict().items()}
+        with torch.no_grad():
+            bd = net(dict(bd_in))
+        net.load_state_dict(state)
+        outs = {"out": bd["encoded_spconv_tensor"]}
+        outs.update(bd.get("multi_scale_3d_features") or {})
+        keys = [k[len(name) + len(mode) + 2:-len("_n")] for k in g.files if k.startswith("%s_%s_" % (name, mode)) and k.endswith("_n")]
+        assert sorted(keys) == sorted(outs), (keys, sorted(outs))
+        for key, x in outs.items():
+            p = "%s_%s_%s_" % (name, mode, key)
+            assert x.features.shape[0] == int(g[p + "n"]) and [int(v) for v in x.spatial_shape] == list(g[p + "shape"]), (p, x.features.shape)
+            assert np.array_equal(common.sha1(x.indices.cpu().numpy().astype(np.int32)), g[p + "indices_sha1"]), p
+            scale = float(np.abs(g[p + "features__sample"]).max())
+            err, _ = common.check_digest(g, p + "features", x.features.float().cpu().numpy(), rtol=0, atol=2e-5 * scale, what=p)
+            print("%s %s %s: max |diff| %.2e of scale %.2e" % (name, mode, key, err, scale))
     net.train()
-    ret = net(dict(bd))
-    out = ret["encoded_spconv_tensor"]
-    assert list(out.spatial_shape) == [2, 12, 11] and out.features.shape[1] == 128 and ret["encoded_spconv_tensor_stride"] == 8
-    assert [ret["multi_scale_3d_features"][k].features.shape[1] for k in ("x_conv1", "x_conv2", "x_conv3", "x_conv4")] == [16, 32, 64, 128]
+    out = net(dict(bd_in))["encoded_spconv_tensor"]
     out.features.pow(2).mean().backward()
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in net.parameters())
 
