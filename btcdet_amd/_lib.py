@@ -140,6 +140,8 @@ _SIGS = {
     "btc_three_nn": (ci, [vp, vp, vp, vp, ci, ci, vp, vp, vp]),
     "btc_three_interpolate": (ci, [vp, vp, vp, ci, ci, vp, vp]),
     "btc_three_interpolate_grad": (ci, [vp, vp, vp, ci, ci, ci, vp, vp]),
+    "btc_bn_fuse_ws_bytes": (sz, []),
+    "btc_conv_bn_relu_fwd": (ci, [ci, vp, vp, vp, vp, vp, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, ctypes.c_float, ctypes.c_float, ci, vp, vp, vp, vp, sz, vp, vp]),
     "btc_col_sum": (ci, [vp, ci, ci, vp, vp, sz, vp]),
     "btc_col_sum_bf16": (ci, [vp, ci, ci, vp, vp, sz, vp]),
     "btc_occ_targets_ws_bytes": (sz, [ctypes.POINTER(BtcOccConfig)]),

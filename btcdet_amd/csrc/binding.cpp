@@ -145,10 +145,43 @@ std::tuple<Tensor, Tensor> bn_fwd(const Tensor& x, const OptTensor& gamma, const
   return std::make_tuple(y, stats);
 }
 
+// zero-initialised slot buffer of the fused conv + BatchNorm statistics (csrc/bn_fuse.h), one per (device, stream): the kernels
+// leave it zeroed, and launches on one stream are serialised
+Tensor fuse_ws_of(const Tensor& like, int64_t stream) {
+  static std::mutex mu;
+  static std::unordered_map<uint64_t, Tensor> tab;
+  const uint64_t key = ((uint64_t)(uint8_t)like.get_device() << 56) ^ (uint64_t)stream;
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = tab.find(key);
+  if (it != tab.end()) return it->second;
+  Tensor t = at::zeros({(int64_t)btc_bn_fuse_ws_bytes()}, like.options().dtype(at::kByte));
+  tab.emplace(key, t);
+  return t;
+}
+
 std::tuple<Tensor, Tensor, Tensor> conv_bn_fwd(const Tensor& features, const Tensor& w, const OptTensor& bias, const Tensor& map_fwd,
                                                const OptTensor& order_fwd, const OptTensor& gamma, const OptTensor& beta, const OptTensor& rm, const OptTensor& rv,
                                                const OptTensor& nbt, bool use_batch, double momentum, double eps, bool relu, const Tensor& ws,
                                                int64_t ws_bytes, int64_t stream) {
+  const int64_t cin = w.size(-2), cout = w.size(-1), K = map_fwd.size(1), n_res = map_fwd.size(0);
+  if (use_batch && n_res >= 1 && !bf16_operands(features, K, cin, cout)) {
+    // training-mode BatchNorm: its batch statistics come out of the conv kernel's epilogue (btc_conv_bn_relu_fwd, csrc/bn_fuse.h)
+    need(features.is_contiguous() && w.is_contiguous() && map_fwd.is_contiguous(), "conv_bn_fwd: contiguous tensors expected");
+    need(w.numel() == K * cin * cout && features.size(1) == cin, "conv_bn_fwd: weight does not match the rulebook / features");
+    const int32_t* order = order_ptr(order_fwd, n_res, "conv_bn_fwd: the row order does not match the map");
+    Tensor x = at::empty({n_res, cout}, features.options());
+    Tensor y = at::empty_like(x);
+    Tensor stats = at::empty({2, cout}, features.options().dtype(at::kFloat));
+    Tensor fw = fuse_ws_of(features, stream);
+    float* mean = (float*)stats.data_ptr();
+    long long* nb = (nbt.has_value() && nbt->defined()) ? (long long*)nbt->data_ptr() : nullptr;
+    const int operands = features.scalar_type() == at::kBFloat16 ? BTC_OPERANDS_BF16_ACT : BTC_OPERANDS_F32;
+    chk(btc_conv_bn_relu_fwd(operands, features.data_ptr(), w.data_ptr(), fptr(bias), (const int32_t*)map_fwd.data_ptr(), order, (int)n_res, (int)K,
+                             (int)cin, (int)cout, x.data_ptr(), fptr(gamma), fptr(beta), (float*)vptr(rm), (float*)vptr(rv), nb, (float)momentum,
+                             (float)eps, (int)relu, y.data_ptr(), mean, mean + cout, ws.data_ptr(), (size_t)ws_bytes, fw.data_ptr(), st(stream)),
+        "btc_conv_bn_relu_fwd");
+    return std::make_tuple(x, y, stats);
+  }
   Tensor x = conv_fwd(features, w, bias, map_fwd, order_fwd, stream);
   auto ys = bn_fwd(x, gamma, beta, rm, rv, nbt, use_batch, momentum, eps, relu, ws, ws_bytes, stream);
   return std::make_tuple(x, std::get<0>(ys), std::get<1>(ys));

@@ -10,6 +10,7 @@
 //                             num_batches_tracked, and publishes mean / rstd (or dgamma / dbeta)
 //   bn_apply / bn_bwd_apply : elementwise, float4
 #include "btc_common.h"
+#include "bn_fuse.h"
 
 namespace {
 
@@ -459,7 +460,8 @@ extern "C" size_t btc_bn_ws_bytes(int C) { return 256 + btc_align((size_t)512 * 
 template <bool BF>
 static int bn_fwd_impl(const float* x, int N, int C, const float* gamma, const float* beta, float* running_mean,
                                float* running_var, long long* num_batches_tracked, float momentum, float eps, int training, int relu,
-                               float* y, float* save_mean, float* save_rstd, void* ws, size_t ws_bytes, void* stream_) {
+                               float* y, float* save_mean, float* save_rstd, void* ws, size_t ws_bytes, void* stream_, bool have_stats = false) {
+  // have_stats: save_mean / save_rstd (and the running statistics) were produced by the conv kernel's epilogue (bn_fuse.h): apply only
   hipStream_t stream = (hipStream_t)stream_;
   BTC_CHECK_ARG(N >= 1 && C >= 1, "btc_bn_relu_fwd: empty input");
   BTC_CHECK_ARG(ws_bytes >= btc_bn_ws_bytes(C), "btc_bn_relu_fwd: workspace too small");
@@ -467,7 +469,8 @@ static int bn_fwd_impl(const float* x, int N, int C, const float* gamma, const f
   int32_t* counter = (int32_t*)ws;  // first 256 bytes: arrival counter, zero on entry, zero on exit
   double* partial = (double*)((char*)ws + 256);
   BnShape S = bn_shape(N, C);
-  if (training) {
+  if (have_stats) {
+  } else if (training) {
     if ((C & 3) == 0) {
       const BnShape SV = bn_shape(N, C >> 2);
       const int g = bn_grid_bytes((long long)N * C * (BF ? 2 : 4), BTC_TUNE_BN_FWD_KB, 64);
@@ -563,4 +566,35 @@ extern "C" int btc_bn_relu_bwd_bf16(const void* x, const void* y, const void* dy
                                     size_t ws_bytes, void* stream) {
   return bn_bwd_impl<true>((const float*)x, (const float*)y, (const float*)dy, N, C, gamma, save_mean, save_rstd, training, relu, (float*)dx,
                            dgamma, dbeta, ws, ws_bytes, stream);
+}
+
+// ---- conv -> BatchNorm (training) -> ReLU with the statistics gathered in the conv's epilogue -------------------------------
+extern "C" size_t btc_bn_fuse_ws_bytes(void) { return btc_bn_fuse_bytes(); }
+
+extern "C" int btc_conv_bn_relu_fwd(int operands, const void* src, const void* W, const float* bias, const int32_t* nbr, const int32_t* order,
+                                    int n_rows, int K, int Cin, int Cout, void* x, const float* gamma, const float* beta, float* running_mean,
+                                    float* running_var, long long* num_batches_tracked, float momentum, float eps, int relu, void* y,
+                                    float* save_mean, float* save_rstd, void* ws, size_t ws_bytes, void* fuse_ws, void* stream) {
+  BTC_CHECK_ARG(n_rows >= 1, "btc_conv_bn_relu_fwd: empty input");
+  BTC_CHECK_ARG(operands >= BTC_OPERANDS_F32 && operands <= BTC_OPERANDS_BF16, "btc_conv_bn_relu_fwd: operands=%d", operands);
+  const bool bf = operands != BTC_OPERANDS_F32;
+  int fused = 0;
+  if (fuse_ws && operands != BTC_OPERANDS_BF16 && Cout <= BN_FUSE_CMAX && btc_tune_get(BTC_TUNE_BN_FUSE) != 1) {
+    BnFuse bn;
+    bn.counter = (int32_t*)fuse_ws;
+    bn.slots = (double*)((char*)fuse_ws + 256);
+    bn.mean_out = save_mean; bn.rstd_out = save_rstd;
+    bn.running_mean = running_mean; bn.running_var = running_var; bn.num_batches = num_batches_tracked;
+    bn.momentum = momentum; bn.eps = eps; bn.N = n_rows; bn.C = Cout;
+    int rc = btc_conv_fwd_stats(operands, src, (const float*)W, bias, nbr, order, n_rows, K, Cin, Cout, x, bn, (hipStream_t)stream, &fused);
+    if (rc) return rc;
+  } else {
+    int rc = btc_conv_apply_ordered(BTC_PASS_FWD, operands, src, W, bias, nbr, order, n_rows, K, Cin, Cout, x, stream);
+    if (rc) return rc;
+  }
+  if (bf)
+    return bn_fwd_impl<true>((const float*)x, n_rows, Cout, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, 1, relu,
+                             (float*)y, save_mean, save_rstd, ws, ws_bytes, stream, fused != 0);
+  return bn_fwd_impl<false>((const float*)x, n_rows, Cout, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, 1, relu,
+                            (float*)y, save_mean, save_rstd, ws, ws_bytes, stream, fused != 0);
 }

@@ -13,6 +13,7 @@
 //   B dgrad [c][KC] (= W^T)   :  slot p of column c holds reduction unit  p ^ (c & (KC/4 - 1))
 // Rows without a neighbour at the offset read a zeroed device row (the DMA has no per-lane predicated zero fill).
 #include "btc_common.h"
+#include "bn_fuse.h"
 
 #include <mutex>
 
@@ -45,7 +46,7 @@ template <int WR, int WC, int NTW, bool TRANS_W, int KC, bool BF>
 __global__ __launch_bounds__(64 * WR * WC) void conv_apply_g(const void* __restrict__ feat_, const float* __restrict__ W,
                                                              const float* __restrict__ bias, const int32_t* __restrict__ nbr,
                                                              const int32_t* __restrict__ order, int n_rows, int K, int Cred, int Cres,
-                                                             void* __restrict__ out_, int xcd_swizzle, int dbg) {
+                                                             void* __restrict__ out_, int xcd_swizzle, int dbg, const BnFuse bn) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NW = WR * WC, THREADS = 64 * NW;
   constexpr int TM = 16 * WR, TN = 16 * NTW * WC, NG = NTW * WC;  // NG: 16-column groups of the B image
@@ -216,6 +217,8 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_apply_g(const void* __restr
   }
 
   // ---- epilogue: C/D layout of 16x16: col = lane&15, row = (lane>>4)*4 + reg
+  float vals[NTW][4];
+  bool valid[4];
 #pragma unroll
   for (int nt = 0; nt < NTW; ++nt) {
     const int col = n0 + (wc * NTW + nt) * 16 + (lane & 15);
@@ -223,18 +226,27 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_apply_g(const void* __restr
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = s_row[wr * 16 + kq * 4 + r];
-      if (row >= 0) {
-        const float v = bias ? (acc[nt][r] + bv0) : acc[nt][r];
-        if (!BF) ((float*)out_)[(size_t)row * Cres + col] = v;
-        else ((unsigned short*)out_)[(size_t)row * Cres + col] = btc_f32_to_bf16(v);
+      valid[r] = row >= 0;
+      float v = bias ? (acc[nt][r] + bv0) : acc[nt][r];
+      if (BF) {
+        const unsigned short h = btc_f32_to_bf16(v);
+        if (row >= 0) ((unsigned short*)out_)[(size_t)row * Cres + col] = h;
+        v = btc_bf16_to_f32(h);   // the statistics below are those of the tensor as stored
+      } else if (row >= 0) {
+        ((float*)out_)[(size_t)row * Cres + col] = v;
       }
+      vals[nt][r] = v;
     }
+  }
+  if (bn.slots) {   // batch statistics for the BatchNorm behind this layer (bn_fuse.h)
+    bn_fuse_wave<NTW>(bn, vals, valid, n0 + wc * NTW * 16, (int)((bx * WR + wr) & (BN_FUSE_SLOTS - 1)));
+    bn_fuse_finish(bn, (int*)smem);
   }
 }
 
 template <int WR, int WC, int NTW, bool TRANS_W, int KC, bool BF>
 int launch_g(const void* feat, const float* W, const float* bias, const int32_t* nbr, const int32_t* order, int n_rows, int K, int Cred,
-             int Cres, void* out, int xcd, hipStream_t stream) {
+             int Cres, void* out, int xcd, hipStream_t stream, const BnFuse& bn) {
   constexpr int TM = 16 * WR, TN = 16 * NTW * WC;
   const size_t lds = btc_apply_glds_lds_bytes(WR * 100 + WC * 10 + NTW, KC, K, BF);
   BTC_CHECK_ARG(lds <= 160 * 1024, "conv_apply_g: tile does not fit the LDS");
@@ -245,15 +257,15 @@ int launch_g(const void* feat, const float* W, const float* bias, const int32_t*
   });
   dim3 grid(btc_cdiv(n_rows, TM), Cres / TN);
   conv_apply_g<WR, WC, NTW, TRANS_W, KC, BF><<<grid, 64 * WR * WC, lds, stream>>>(feat, W, bias, nbr, order, n_rows, K, Cred, Cres, out, xcd,
-                                                                                btc_tune_get(BTC_TUNE_APPLY_DEBUG));
+                                                                                btc_tune_get(BTC_TUNE_APPLY_DEBUG), bn);
   BTC_LAUNCH_CHECK();
   return BTC_OK;
 }
 
-#define G_ARGS feat, W, bias, nbr, order, n_rows, K, Cred, Cres, out, xcd, stream
+#define G_ARGS feat, W, bias, nbr, order, n_rows, K, Cred, Cres, out, xcd, stream, bn
 #define G_PARAMS                                                                                                             \
   const void *feat, const float *W, const float *bias, const int32_t *nbr, const int32_t *order, int n_rows, int K, int Cred, int Cres, \
-      void *out, int xcd, hipStream_t stream
+      void *out, int xcd, hipStream_t stream, const BnFuse &bn
 
 template <int WR, int WC, int NTW, bool TRANS_W, bool BF>
 int launch_g_kc(int kc, G_PARAMS) {
@@ -315,8 +327,10 @@ bool btc_apply_glds_supported(int K, int Cred, int Cres) { return K <= 64 && Cre
 // shape = WR*100 + WC*10 + NTW (waves: WR row groups x WC column groups of NTW 16-column tiles), kc = reduction chunk,
 // bf = activations (feat, out) are bfloat16
 int btc_launch_apply_glds(bool trans_w, int shape, int kc, int xcd, bool bf, const void* feat, const float* W, const float* bias,
-                          const int32_t* nbr, const int32_t* order, int n_rows, int K, int Cred, int Cres, void* out, hipStream_t stream) {
+                          const int32_t* nbr, const int32_t* order, int n_rows, int K, int Cred, int Cres, void* out, hipStream_t stream,
+                          const BnFuse* bn_) {
   if (n_rows <= 0) return BTC_OK;
+  const BnFuse bn = bn_ ? *bn_ : btc_bn_fuse_none();
   const int wr = shape / 100, wc = (shape / 10) % 10, ntw = shape % 10;
   BTC_CHECK_ARG(btc_apply_glds_supported(K, Cred, Cres) && wc * ntw > 0 && Cres % (16 * wc * ntw) == 0 && Cred % kc == 0 &&
                     (kc == 16 || kc == 32 || kc == 64),

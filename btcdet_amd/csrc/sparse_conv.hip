@@ -13,6 +13,7 @@
 #include <mutex>
 
 #include "btc_common.h"
+#include "bn_fuse.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -34,8 +35,9 @@ __host__ __device__ constexpr int ldb_of(int nt) { return nt * 16 + (((nt * 16) 
 template <int NT, bool TRANS_W, bool VEC, int KB, int THREADS>
 __global__ __launch_bounds__(THREADS) void conv_apply(const float* __restrict__ feat, const float* __restrict__ W,
                                                   const float* __restrict__ bias, const int32_t* __restrict__ nbr,
-                                                  int n_rows, int K, int Cred, int Cres, float* __restrict__ out, int mirror) {
+                                                  int n_rows, int K, int Cred, int Cres, float* __restrict__ out, int mirror, const BnFuse bn) {
   // mirror: `nbr` is a submanifold layer's forward map read as its backward map -- column K-1-k holds offset k (rulebook.hip)
+  // bn: batch statistics of the result for the BatchNorm behind this layer, gathered in the epilogue (bn_fuse.h)
   // KB > 1 (narrow layers, Cred <= 32: one chunk per offset): KB active offsets are staged per phase, which divides the
   // number of barrier-separated phases by KB and multiplies the loads in flight per workgroup by KB.
   // THREADS = 256 / 128 / 64 -> 64 / 32 / 16 output rows per workgroup (one 16-row MFMA slab per wave): small and
@@ -183,16 +185,24 @@ __global__ __launch_bounds__(THREADS) void conv_apply(const float* __restrict__ 
   }
 
   // ---- epilogue: C/D layout of 16x16: col = lane&15, row = (lane>>4)*4 + reg
+  float vals[NT][4];
+  bool valid[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) valid[r] = row0 + wave * 16 + kq * 4 + r < n_rows;
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     const int col = n0 + nt * 16 + (lane & 15);
-    if (col >= Cres) continue;
-    const float bv0 = bias ? bias[col] : 0.f;
+    const float bv0 = (bias && col < Cres) ? bias[col] : 0.f;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      int row = row0 + wave * 16 + kq * 4 + r;
-      if (row < n_rows) out[(size_t)row * Cres + col] = bias ? (acc[nt][r] + bv0) : acc[nt][r];
+      const int row = row0 + wave * 16 + kq * 4 + r;
+      vals[nt][r] = bias ? (acc[nt][r] + bv0) : acc[nt][r];
+      if (col < Cres && row < n_rows) out[(size_t)row * Cres + col] = vals[nt][r];
     }
+  }
+  if (bn.slots) {
+    bn_fuse_wave<NT>(bn, vals, valid, n0, (int)((blockIdx.x * (THREADS / 64) + wave) & (BN_FUSE_SLOTS - 1)));
+    bn_fuse_finish(bn, (int*)smem);
   }
 }
 
@@ -216,7 +226,8 @@ __host__ __device__ inline size_t ws_lds_bytes(int K, int Cred, int nt) {
 template <int NT, bool TRANS_W>
 __global__ __launch_bounds__(WS_WAVES * 64) void conv_apply_ws(const float* __restrict__ feat, const float* __restrict__ W,
                                                               const float* __restrict__ bias, const int32_t* __restrict__ nbr,
-                                                              int n_rows, int K, int Cred, int Cres, float* __restrict__ out, int mirror) {
+                                                              int n_rows, int K, int Cred, int Cres, float* __restrict__ out, int mirror,
+                                                              const BnFuse bn) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int LDW = NT * 16;
   constexpr int QMAX = KC / 4;  // k-steps of a full 32-channel row
@@ -310,19 +321,25 @@ __global__ __launch_bounds__(WS_WAVES * 64) void conv_apply_ws(const float* __re
     }
 #undef WS_FETCH
 #undef WS_MATH
+    float vals[NT][4];
+    bool valid[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) valid[r] = row0 + kq * 4 + r < n_rows;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       const int col = nt * 16 + lrow;
-      if (col >= Cres) continue;
-      const float bv0 = bias ? bias[col] : 0.f;
+      const float bv0 = (bias && col < Cres) ? bias[col] : 0.f;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        int row = row0 + kq * 4 + r;
-        if (row < n_rows) out[(size_t)row * Cres + col] = bias ? (acc[nt][r] + bv0) : acc[nt][r];
+        const int row = row0 + kq * 4 + r;
+        vals[nt][r] = bias ? (acc[nt][r] + bv0) : acc[nt][r];
+        if (col < Cres && row < n_rows) out[(size_t)row * Cres + col] = vals[nt][r];
       }
     }
+    if (bn.slots) bn_fuse_wave<NT>(bn, vals, valid, 0, (int)(tile & (BN_FUSE_SLOTS - 1)));
     __builtin_amdgcn_wave_barrier();
   }
+  if (bn.slots) bn_fuse_finish(bn, (int*)smem);
 }
 
 // dW partial: part[s][k][ci][co] = sum over the split's rows of feat[nbr[i][k]][ci] * dout[i][co]
@@ -991,14 +1008,16 @@ __global__ __launch_bounds__(256) void dense_bwd_k(const float* __restrict__ dde
 
 template <int NT, bool TRANS_W, int THREADS>
 void launch_apply_t(dim3 grid, size_t lds, hipStream_t stream, bool vec, const float* feat, const float* W, const float* bias,
-                    const int32_t* nbr, int n_rows, int K, int Cred, int Cres, float* out, int mirror) {
-  if (vec) conv_apply<NT, TRANS_W, true, 1, THREADS><<<grid, THREADS, lds, stream>>>(feat, W, bias, nbr, n_rows, K, Cred, Cres, out, mirror);
-  else conv_apply<NT, TRANS_W, false, 1, THREADS><<<grid, THREADS, lds, stream>>>(feat, W, bias, nbr, n_rows, K, Cred, Cres, out, mirror);
+                    const int32_t* nbr, int n_rows, int K, int Cred, int Cres, float* out, int mirror, const BnFuse& bn) {
+  if (vec) conv_apply<NT, TRANS_W, true, 1, THREADS><<<grid, THREADS, lds, stream>>>(feat, W, bias, nbr, n_rows, K, Cred, Cres, out, mirror, bn);
+  else conv_apply<NT, TRANS_W, false, 1, THREADS><<<grid, THREADS, lds, stream>>>(feat, W, bias, nbr, n_rows, K, Cred, Cres, out, mirror, bn);
 }
 
 template <bool TRANS_W>
 int launch_apply(const float* feat, const float* W, const float* bias, const int32_t* nbr, int n_rows, int K, int Cred,
-                 int Cres, float* out, hipStream_t stream, bool bf = false, const int32_t* order = nullptr, int mirror = 0) {
+                 int Cres, float* out, hipStream_t stream, bool bf = false, const int32_t* order = nullptr, int mirror = 0,
+                 const BnFuse* bn_ = nullptr) {
+  const BnFuse bn = bn_ ? *bn_ : btc_bn_fuse_none();   // batch statistics of the result in the epilogue (every kernel family below has it)
   // order: optional row-order hint (row_order.hip); only the LDS-DMA kernel tiles by it, the others ignore it (same results)
   // bf: feat / out are bfloat16 (passed through the float* parameters); only the LDS-DMA kernel has that variant
   if (n_rows <= 0) return BTC_OK;
@@ -1045,7 +1064,7 @@ int launch_apply(const float* feat, const float* W, const float* bias, const int
     const int t_kc = btc_tune_get(BTC_TUNE_APPLY_KC);
     if (t_kc && Cred % t_kc == 0) kc = t_kc;
     while (kc > 16 && btc_apply_glds_lds_bytes(shape, kc, K, bf) > 160 * 1024) kc >>= 1;  // 3-stage ring + map tile
-    return btc_launch_apply_glds(TRANS_W, shape, kc, (t_xcd == 2 ? 1 : 0) | (mirror ? 2 : 0), bf, feat, W, bias, nbr, order, n_rows, K, Cred, Cres, out, stream);
+    return btc_launch_apply_glds(TRANS_W, shape, kc, (t_xcd == 2 ? 1 : 0) | (mirror ? 2 : 0), bf, feat, W, bias, nbr, order, n_rows, K, Cred, Cres, out, stream, &bn);
   }
   // weight-stationary persistent kernel (one 16-wave workgroup per CU).  Measured on MI355X: its dword-granular register
   // gather wins 2.5x for Cred <= 8 (the dgrad of the 2/3-channel occupancy heads, the 4/6-channel input layers) and loses
@@ -1060,8 +1079,8 @@ int launch_apply(const float* feat, const float* W, const float* bias, const int
       (void)hipFuncSetAttribute((const void*)conv_apply_ws<1, TRANS_W>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       (void)hipFuncSetAttribute((const void*)conv_apply_ws<2, TRANS_W>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     });
-    if (nt == 1) conv_apply_ws<1, TRANS_W><<<wgs, WS_WAVES * 64, lds, stream>>>(feat, W, bias, nbr, n_rows, K, Cred, Cres, out, mirror);
-    else conv_apply_ws<2, TRANS_W><<<wgs, WS_WAVES * 64, lds, stream>>>(feat, W, bias, nbr, n_rows, K, Cred, Cres, out, mirror);
+    if (nt == 1) conv_apply_ws<1, TRANS_W><<<wgs, WS_WAVES * 64, lds, stream>>>(feat, W, bias, nbr, n_rows, K, Cred, Cres, out, mirror, bn);
+    else conv_apply_ws<2, TRANS_W><<<wgs, WS_WAVES * 64, lds, stream>>>(feat, W, bias, nbr, n_rows, K, Cred, Cres, out, mirror, bn);
     BTC_LAUNCH_CHECK();
     return BTC_OK;
   }
@@ -1076,7 +1095,7 @@ int launch_apply(const float* feat, const float* W, const float* bias, const int
   dim3 grid(n_tiles, btc_cdiv(Cres, nt * 16));
   size_t lds = (size_t)(tm * LDA + KC * ldb_of(nt)) * sizeof(float) + (size_t)(tm * K + K + 1) * sizeof(int32_t);
   const bool vec = (Cred & 3) == 0;
-#define BTC_APPLY(NT_) launch_apply_t<NT_, TRANS_W, 256>(grid, lds, stream, vec, feat, W, bias, nbr, n_rows, K, Cred, Cres, out, mirror)
+#define BTC_APPLY(NT_) launch_apply_t<NT_, TRANS_W, 256>(grid, lds, stream, vec, feat, W, bias, nbr, n_rows, K, Cred, Cres, out, mirror, bn)
   switch (nt) {
     case 1: BTC_APPLY(1); break;
     case 2: BTC_APPLY(2); break;
@@ -1240,6 +1259,20 @@ extern "C" int btc_conv_apply_ordered(int pass, int operands, const void* src, c
   if (pass == BTC_PASS_FWD)
     return launch_apply<false>((const float*)src, (const float*)W, bias, nbr, n_rows, K, Cred, Cres, (float*)dst, (hipStream_t)stream, bf, order);
   return launch_apply<true>((const float*)src, (const float*)W, nullptr, nbr, n_rows, K, Cred, Cres, (float*)dst, (hipStream_t)stream, bf, order, mirror);
+}
+
+// forward conv whose epilogue also gathers the batch statistics of its result (bn_fuse.h); operands F32 / BF16_ACT only.
+// -> BTC_OK, *fused = 1 when the statistics were taken (always, for these operand kinds and n_rows > 0)
+int btc_conv_fwd_stats(int operands, const void* src, const float* W, const float* bias, const int32_t* nbr, const int32_t* order, int n_rows, int K,
+                       int Cin, int Cout, void* dst, const BnFuse& bn, hipStream_t stream, int* fused) {
+  *fused = 0;
+  BTC_CHECK_ARG(K >= 1 && K <= 512 && Cin >= 1 && Cout >= 1 && n_rows >= 0, "btc_conv_fwd_stats: bad sizes");
+  BTC_CHECK_ARG(operands == BTC_OPERANDS_F32 || operands == BTC_OPERANDS_BF16_ACT, "btc_conv_fwd_stats: fp32 weights only");
+  BTC_CHECK_ARG(Cout <= BN_FUSE_CMAX, "btc_conv_fwd_stats: more than %d channels", BN_FUSE_CMAX);
+  if (n_rows <= 0) return BTC_OK;
+  const bool bf = operands == BTC_OPERANDS_BF16_ACT;
+  *fused = 1;
+  return launch_apply<false>((const float*)src, W, bias, nbr, n_rows, K, Cin, Cout, (float*)dst, stream, bf, order, 0, &bn);
 }
 
 extern "C" size_t btc_conv_wgrad_ws_bytes(int n_out, int K, int Cin, int Cout, int n_in) {

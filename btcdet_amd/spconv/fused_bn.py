@@ -21,6 +21,35 @@ def _ws(device, C):
     return buf, need
 
 
+_FUSE_WS = {}
+
+
+def fuse_ws(device):
+    """zero-initialised slot buffer of the fused conv + BatchNorm statistics (csrc/bn_fuse.h), one per (device, current stream): the
+    kernels leave it zeroed; launches on one stream are serialised, streams must not share it"""
+    key = (device.index, stream_ptr())
+    buf = _FUSE_WS.get(key)
+    if buf is None:
+        buf = _FUSE_WS[key] = torch.zeros(int(lib().btc_bn_fuse_ws_bytes()), dtype=torch.uint8, device=device)
+    return buf
+
+
+def conv_bn_forward(features, w, b, map_fwd, ord_fwd, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, relu):
+    """training-mode conv -> BatchNorm -> [ReLU] through btc_conv_bn_relu_fwd (statistics in the conv's epilogue); fp32 weights.
+    -> (x, y, stats (2, C) = mean | rstd)"""
+    n, K = map_fwd.shape
+    cin, cout = w.shape[-2], w.shape[-1]
+    x = torch.empty((n, cout), dtype=features.dtype, device=features.device)
+    y = torch.empty_like(x)
+    stats = torch.empty((2, cout), dtype=torch.float32, device=features.device)
+    ws, need = _ws(features.device, cout)
+    check(lib().btc_conv_bn_relu_fwd(1 if features.dtype == torch.bfloat16 else 0, ptr(features), ptr(w), ptr(b), ptr(map_fwd), ptr(ord_fwd), n, K, cin, cout,
+                                     ptr(x), ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), ptr(num_batches_tracked), float(momentum),
+                                     float(eps), int(relu), ptr(y), ptr(stats[0]), ptr(stats[1]), ptr(ws), need, ptr(fuse_ws(features.device)),
+                                     stream_ptr()), "btc_conv_bn_relu_fwd")
+    return x, y, stats
+
+
 def bn_forward(x, weight, bias, running_mean, running_var, num_batches_tracked, use_batch, momentum, eps, relu):
     """y = [relu](batchnorm(x)); returns (y, stats) with stats (2, C) = mean | rstd.  Running statistics / num_batches_tracked
     are updated in the kernel when given (training)."""

@@ -63,6 +63,7 @@ int btc_version(void);
 #define BTC_TUNE_BN_FWD_KB 9  /* bn_stats: KB of input per workgroup (0 = built-in 64) */
 #define BTC_TUNE_BN_BWD_KB 10 /* bn_bwd_stats: KB of input (x, y, dy) per workgroup (0 = built-in 128) */
 #define BTC_TUNE_WGRAD_PIPE 11 /* conv_wgrad_rows: 1 = the two-barrier kernel instead of the software-pipelined one */
+#define BTC_TUNE_BN_FUSE 12 /* btc_conv_bn_relu_fwd: 1 = statistics by the separate bn_stats launch instead of the conv epilogue */
 #define BTC_TUNE_APPLY_DEBUG 3 /* timing experiments only (WRONG results): 1 = no MFMA phase, 2 = no loads in the main loop */
 int btc_tune_set(int key, int value);
 int btc_tune_value(int key);   /* current value of a key (0 = built-in policy) */
@@ -403,6 +404,17 @@ int btc_bn_relu_bwd_bf16(const void* x, const void* y, const void* dy, int N, in
                          float* dbeta, void* ws, size_t ws_bytes, void* stream);
 /* out[c] = sum_r x[r][c] of an (N,C) matrix: the bias gradient of a sparse conv (grad_out.sum(0) in the reference's
  * autograd graph, spconv v1.2.1 SparseConvFunction.backward).  fp64 accumulation in a fixed order.  ws as above. */
+/* conv (forward, operands as btc_conv_apply_ordered) -> training-mode BatchNorm1d -> [ReLU] of the reference's post_act_block
+ * (spconv_backbone.py:33-43) in TWO launches: the conv kernel's epilogue gathers the batch statistics of its result (fp64 slot
+ * sums, last workgroup finalises mean / rstd / running statistics: csrc/bn_fuse.h), the second launch normalises.  x (n_rows, Cout)
+ * receives the conv result (saved for backward), y the BatchNorm output.  fuse_ws: btc_bn_fuse_ws_bytes() bytes, ZERO-initialised
+ * once and then owned by this entry point on ONE stream (it leaves them zeroed); NULL, or BTC_OPERANDS_BF16, or Cout > 1024: the
+ * statistics come from the separate pass of btc_bn_relu_fwd (ws / ws_bytes as there).  n_rows >= 1. */
+size_t btc_bn_fuse_ws_bytes(void);
+int btc_conv_bn_relu_fwd(int operands, const void* src, const void* W, const float* bias, const int32_t* nbr, const int32_t* order,
+                         int n_rows, int K, int Cin, int Cout, void* x, const float* gamma, const float* beta, float* running_mean,
+                         float* running_var, long long* num_batches_tracked, float momentum, float eps, int relu, void* y,
+                         float* save_mean, float* save_rstd, void* ws, size_t ws_bytes, void* fuse_ws, void* stream);
 int btc_col_sum(const float* x, int N, int C, float* out, void* ws, size_t ws_bytes, void* stream);
 int btc_col_sum_bf16(const void* x, int N, int C, float* out, void* ws, size_t ws_bytes, void* stream);
 

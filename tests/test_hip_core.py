@@ -447,3 +447,51 @@ def test_compiled_binding_and_ctypes_binding_agree(dtype):
     assert len(fast_res) == len(ct_res)
     for a, b in zip(fast_res, ct_res):
         assert a.dtype == b.dtype and torch.equal(a, b)
+
+
+@pytest.mark.parametrize("cin,cout,n,dtype", [(4, 16, 6000, "f32"), (16, 16, 3000, "f32"), (64, 128, 900, "f32"), (32, 32, 120000, "f32"), (20, 150, 700, "f32"),
+                                               (34, 32, 5000, "f32"), (64, 64, 5000, "bf16")])
+def test_conv_epilogue_batch_statistics_match_the_separate_pass(cin, cout, n, dtype):
+    """btc_conv_bn_relu_fwd gathers the BatchNorm batch statistics in the conv kernel's epilogue (csrc/bn_fuse.h) in every kernel
+    family the dispatch can pick (weight-stationary, LDS-DMA, register-staged; bf16 activations): conv result bit-identical to the
+    plain conv, mean / rstd / running statistics / output equal to the separate statistics pass (tuning key 12) within fp32
+    rounding of fp64 sums, and the slot buffer is left zeroed (two calls in a row, different channel counts, agree)"""
+    from btcdet_amd import _lib
+    from btcdet_amd.spconv import fused_bn, ops
+    L = _lib.lib()
+    rng = np.random.default_rng(cin + cout + n)
+    shape, B = ((12, 60, 90) if n > 50000 else (8, 30, 36)), 2
+    idx = rand_indices(rng, n, B, shape)
+    rb = ops.build_rulebook(torch.from_numpy(idx).to(dev()), B, shape, 3, 1, 1, 1, 0, True, False)
+    m = rb.nbr_out.shape[0]
+    tdt = torch.bfloat16 if dtype == "bf16" else torch.float32
+    feat = torch.from_numpy(rng.standard_normal((m, cin)).astype(np.float32)).to(dev()).to(tdt)
+    w = torch.from_numpy((rng.standard_normal((27, cin, cout)) / np.sqrt(cin)).astype(np.float32)).to(dev())
+    gamma = torch.from_numpy(rng.uniform(0.5, 1.5, cout).astype(np.float32)).to(dev())
+    beta = torch.from_numpy(rng.uniform(-0.3, 0.3, cout).astype(np.float32)).to(dev())
+    outs = []
+    for tune in (0, 1, 0):
+        rm, rv = torch.zeros(cout, device=dev()), torch.ones(cout, device=dev())
+        nbt = torch.zeros((), dtype=torch.long, device=dev())
+        assert L.btc_tune_set(12, tune) == 0
+        try:
+            x, y, stats = fused_bn.conv_bn_forward(feat, w, None, rb.nbr_out, None, gamma, beta, rm, rv, nbt, 0.01, 1e-3, True)
+            torch.cuda.synchronize()
+        finally:
+            L.btc_tune_set(12, 0)
+        outs.append((x.float(), y.float(), stats, rm, rv, int(nbt)))
+    plain = ops.indice_conv(feat, w, None, rb)
+    assert torch.equal(outs[0][0], outs[1][0])                                   # the conv result does not depend on where the statistics are taken
+    if dtype == "f32":                                                           # (bf16: the plain layer takes bf16 WEIGHT copies as well, another kernel)
+        assert torch.equal(outs[0][0], plain.float())
+    plain = outs[0][0]
+    assert bool((fused_bn.fuse_ws(feat.device) == 0).all())                       # slots and counter left zeroed
+    for a, b in ((outs[0], outs[1]), (outs[0], outs[2])):
+        assert a[5] == b[5] == 1
+        np.testing.assert_allclose(a[2].cpu().numpy(), b[2].cpu().numpy(), rtol=2e-6, atol=1e-7)       # mean | rstd
+        np.testing.assert_allclose(a[3].cpu().numpy(), b[3].cpu().numpy(), rtol=2e-6, atol=1e-8)       # running mean
+        np.testing.assert_allclose(a[4].cpu().numpy(), b[4].cpu().numpy(), rtol=2e-6, atol=1e-8)       # running var
+        tol = 1e-2 if dtype == "bf16" else 1e-5
+        np.testing.assert_allclose(a[1].cpu().numpy(), b[1].cpu().numpy(), rtol=tol, atol=tol)
+    ref = torch.nn.functional.batch_norm(plain.float(), None, None, gamma, beta, True, 0.0, 1e-3).relu()
+    np.testing.assert_allclose(outs[0][1].cpu().numpy(), ref.cpu().numpy(), rtol=(2e-2 if dtype == "bf16" else 2e-5), atol=(2e-2 if dtype == "bf16" else 2e-5))
