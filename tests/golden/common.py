@@ -167,3 +167,42 @@ def variant_inputs(which):
         feats.append((r["voxels"].sum(1, dtype=np.float32) / n).astype(np.float32))
         coords.append(np.pad(r["coordinates"], ((0, 0), (1, 0)), constant_values=b).astype(np.int32))
     return np.concatenate(feats), np.concatenate(coords), grid, 2
+
+
+def convhead_inputs(n_rois=24):
+    """inputs of the ROI-head pooling golden (gen_convhead_golden.py / tests/test_hip_conv_head.py), regenerable from numpy + the CPU
+    oracle's voxelizer: two synthetic scenes -> raw `points` (N, 5) [b, x, y, z, i], occupancy-completed points `occ_pnts` (M, 4) [x, y,
+    z, prob] + their batch index, an `x_combine`-like sparse volume on the stride-8 detection grid [5, 200, 176] (the scenes' detection
+    voxels down-sampled by 8, 128 hash-valued channels), and `rois` (2, n_rois, 7): the scenes' boxes jittered by hash values"""
+    from oracle import oracle as orc
+    synth = _synth()
+    pts, occ, occ_b, xc_idx, rois = [], [], [], [], []
+    for b, seed in enumerate((51, 52)):
+        s = synth.make_scene(seed)
+        p = s["points"]
+        pts.append(np.concatenate([np.full((p.shape[0], 1), b, np.float32), p], axis=1))
+        gen = orc.VoxelGeneratorV2(synth.KITTI_DET_VOXEL, synth.KITTI_DET_RANGE, 5, 16000)
+        c = gen.generate(p)["coordinates"]                       # (M, 3) z, y, x on [40, 1600, 1408]
+        cell = np.unique(c // 8, axis=0)
+        cell = cell[(cell[:, 0] < 5) & (cell[:, 1] < 200) & (cell[:, 2] < 176)]
+        xc_idx.append(np.concatenate([np.full((cell.shape[0], 1), b, np.int32), cell.astype(np.int32)], axis=1))
+        boxes = s["gt_boxes"][:, :7].astype(np.float32)
+        if boxes.shape[0] == 0:
+            boxes = np.array([[20, 0, -1, 3.9, 1.6, 1.56, 0.3]], np.float32)
+        u = _hash01(n_rois * 7, 100 + b).reshape(n_rois, 7)
+        r = boxes[np.arange(n_rois) % boxes.shape[0]].copy()
+        r[:, 0:3] += (u[:, 0:3] - np.float32(0.5)) * np.array([2.0, 2.0, 0.4], np.float32)
+        r[:, 3:6] *= (np.float32(0.9) + np.float32(0.2) * u[:, 3:6])
+        r[:, 6] += (u[:, 6] - np.float32(0.5)) * np.float32(0.6)
+        rois.append(r.astype(np.float32))
+        # occupancy-completed points: a hash-jittered subset of the box interiors (what PassOccVox adds), probability in the 4th column
+        k = 400
+        v = _hash01(k * 4, 200 + b).reshape(k, 4)
+        bx = boxes[np.arange(k) % boxes.shape[0]]
+        o = np.concatenate([bx[:, 0:3] + (v[:, 0:3] - np.float32(0.5)) * bx[:, 3:6], np.float32(0.3) + np.float32(0.7) * v[:, 3:4]], axis=1)
+        occ.append(o.astype(np.float32))
+        occ_b.append(np.full((k,), b, np.int64))
+    xc_idx = np.concatenate(xc_idx)
+    xc_feat = (_hash01(xc_idx.shape[0] * 128, 7) - np.float32(0.3)).clip(0).reshape(-1, 128).astype(np.float32)
+    return {"points": np.concatenate(pts).astype(np.float32), "occ_pnts": np.concatenate(occ), "added_occ_b_ind": np.concatenate(occ_b),
+            "xc_indices": xc_idx, "xc_features": xc_feat, "xc_shape": [5, 200, 176], "rois": np.stack(rois), "batch_size": 2}

@@ -38,9 +38,9 @@ class SparseConvTensor(object):
         idx = self.indices.numpy().astype(np.int32)
         if idx.shape[1] == 3:
             idx = np.concatenate([idx[:, :1], np.zeros_like(idx[:, :1]), idx[:, 1:]], axis=1)
-            out = orc.dense(self.features.detach().numpy(), idx, self.batch_size, [1] + shape)[:, :, 0]
+            out = orc.dense(self.features.detach().numpy(), idx, int(self.batch_size), [1] + shape)[:, :, 0]
         else:
-            out = orc.dense(self.features.detach().numpy(), idx, self.batch_size, shape)
+            out = orc.dense(self.features.detach().numpy(), idx, int(self.batch_size), shape)
         out = torch.from_numpy(out)
         if channels_first:
             return out

@@ -1,0 +1,92 @@
+"""The ROI head's pooling stage (btcdet_amd/conv_head.py: ConvHead.roi_conv_pool + helpers) on the GPU against
+the REFERENCE's own ConvHead executed on CPU (tests/golden/gen_convhead_golden.py -> convhead.npz: its sparse layers over the
+oracle-backed spconv, its CUDA-only pointnet2_stack primitives served by the C oracle): same name-keyed weights, same inputs
+(common.convhead_inputs), eval- and train-mode BatchNorm.  The three feature sources are compared separately (raw-point and
+occupancy-point set abstraction, the 6912-style micro-scene sparse convs over the trilinear read-out of x_combine) and together, then
+the head's cls / reg predictions; oracle parity of the primitives underneath is unpinned (CUDA-only in the reference)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+import common  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _head():
+    from btcdet_amd.config import load_cfg
+    from btcdet_amd.conv_head import ConvHead
+    cfg = load_cfg()
+    head = ConvHead(input_channels=128, model_cfg=cfg.MODEL.ROI_HEAD, num_class=1, det_voxel_size=[0.05, 0.05, 0.1],
+                    point_cloud_range=np.array(cfg.DATA_CONFIG.POINT_CLOUD_RANGE, dtype=np.float32), num_rawpoint_features=4)
+    common.init_by_name(head)
+    for m in head.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    return head.to(DEV)
+
+
+def _batch(inp):
+    from btcdet_amd import spconv
+    t = lambda a: torch.from_numpy(a.copy()).to(DEV)
+    xc = spconv.SparseConvTensor(t(inp["xc_features"]), t(inp["xc_indices"]), inp["xc_shape"], 2)
+    return {"batch_size": 2, "rois": t(inp["rois"]), "points": t(inp["points"]), "occ_pnts": t(inp["occ_pnts"]), "added_occ_b_ind": t(inp["added_occ_b_ind"]),
+            "multi_scale_3d_features": {"x_combine": xc}}
+
+
+def test_state_dict_keys_equal_the_reference_heads():
+    g = np.load(os.path.join(HERE, "golden", "convhead.npz"))
+    head = _head()
+    assert sorted(head.state_dict().keys()) == sorted(str(k) for k in g["state_keys"])
+
+
+@pytest.mark.parametrize("mode", ["eval", "train"])
+def test_roi_conv_pool_and_head_vs_reference(mode):
+    g = np.load(os.path.join(HERE, "golden", "convhead.npz"))
+    inp = common.convhead_inputs(int(g["n_rois"]))
+    for k in ("points", "occ_pnts", "xc_features", "rois", "xc_indices"):
+        assert np.array_equal(common.sha1(inp[k]), g["in_%s_sha1" % k]), k
+    head = _head()
+    head.train(mode == "train")
+    with torch.no_grad():
+        bd = _batch(inp)
+        pooled, _ = head.roi_conv_pool(bd)
+        shared = head.shared_fc_layer(pooled)
+        cls = head.cls_layers(shared).transpose(1, 2).contiguous().squeeze(dim=1)
+        reg = head.reg_layers(shared).transpose(1, 2).contiguous().squeeze(dim=1)
+    assert tuple(pooled.shape) == (2 * inp["rois"].shape[1], 27 * 240, 1)
+    v = pooled.view(pooled.shape[0], -1, 27)
+    for name, sl in (("raw", slice(0, 64)), ("occ", slice(64, 112)), ("xc", slice(112, 240))):
+        key = "%s_pooled_%s" % (mode, name)
+        scale = float(np.abs(g[key + "__sample"]).max())
+        err, _ = common.check_digest(g, key, v[:, sl].contiguous().cpu().numpy(), rtol=0, atol=5e-5 * scale, what=key, sum_rtol=1e-4)
+        print("%s %s: max |diff| %.2e of scale %.2e" % (mode, name, err, scale))
+    scale = float(np.abs(g[mode + "_pooled__sample"]).max())
+    common.check_digest(g, mode + "_pooled", pooled.cpu().numpy(), rtol=0, atol=5e-5 * scale, what="pooled", sum_rtol=1e-4)
+    np.testing.assert_allclose(cls.cpu().numpy(), g[mode + "_rcnn_cls"], rtol=2e-3, atol=2e-4)
+    np.testing.assert_allclose(reg.cpu().numpy(), g[mode + "_rcnn_reg"], rtol=2e-3, atol=2e-4)
+
+
+def test_forward_eval_produces_boxes_and_backward_reaches_every_parameter():
+    inp = common.convhead_inputs(24)
+    head = _head().eval()
+    with torch.no_grad():
+        out = head(_batch(inp))
+    assert tuple(out["batch_box_preds"].shape) == (2, 24, 7) and tuple(out["batch_cls_preds"].shape) == (2, 24, 1)
+    assert torch.isfinite(out["batch_box_preds"]).all()
+    head.train()
+    bd = _batch(inp)
+    bd["multi_scale_3d_features"]["x_combine"].features.requires_grad_(True)
+    head(bd)
+    f = head.forward_ret_dict
+    (f["rcnn_cls"].pow(2).mean() + f["rcnn_reg"].pow(2).mean()).backward()
+    missing = [n for n, p in head.named_parameters() if p.grad is None or not torch.isfinite(p.grad).all()]
+    assert not missing, missing
+    gx = bd["multi_scale_3d_features"]["x_combine"].features.grad
+    assert gx is not None and torch.isfinite(gx).all() and float(gx.abs().sum()) > 0      # gradients flow back into the backbone's x_combine
