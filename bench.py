@@ -302,6 +302,8 @@ def main():
         for i in range(n_warm):
             step_fn(batches[i % nb], batches[(i + 1) % nb])
         sync()
+        if getattr(step_fn, "timing", None):
+            step_fn.timing.clear()     # (BTC_TRAINER_TIMING=1: host phases of the timed steps only)
         marks = [torch.cuda.Event(enable_timing=True) for _ in range(n_steps + 1)]
         allocs0 = torch.cuda.memory_stats(device).get("num_device_alloc", 0)
         t0 = time.perf_counter()
@@ -320,6 +322,9 @@ def main():
     priming = max(0, 16 - args.warmup)
     dt, per_step_ms, device_allocs = timed_run(step, args.steps, priming + args.warmup, step.end_stream)
     dt = max_over_ranks(dt, dist, device)
+    if getattr(step, "timing", None) and rank == 0:   # BTC_TRAINER_TIMING=1: host milliseconds per phase and step of the timed region
+        n = max(step.timing.get("n", 1), 1)
+        print("trainer host ms per step:", {k: round(1e3 * v / n, 3) for k, v in step.timing.items() if k != "n"}, file=sys.stderr)
 
     # ---- secondary measurements (outside the timed region, N = 1 reporting only; --no-extras skips them)
     extras = {}

@@ -249,7 +249,21 @@ class VoxelBackBone8xOcc(nn.Module):
             stages.append(self.squeezeBev)
         self.__dict__['_first_strided'] = _chain_lookahead(stages)
 
-    def _walk_geometry(self, coords, bs, indice_dict):
+    def start_walk(self, batch_dict):
+        """the rulebook walk of forward(), STARTED ahead of it by whoever produced `voxel_coords` (BtcHotPath.forward_occ, right behind
+        PassOccVox): the level-0 submanifold rulebook on the current stream, the strided levels and the read-back of their row counts
+        forked onto the walk's side stream.  forward() -- on whatever stream, from whatever thread -- then only sizes and fills the maps:
+        the counts are long there, and the training thread does not sit in a blocking read-back in the middle of its forward pass
+        (0.6 of its 3 ms of host time in forward_det, BTC_TRAINER_TIMING=1)."""
+        coords = batch_dict['voxel_coords'].int()
+        if not coords.is_cuda:
+            return
+        indice_dict = {}
+        walk = self._walk_geometry(coords, batch_dict['batch_size'], indice_dict, force_async=True)
+        if isinstance(walk, tuple):
+            batch_dict['__det_walk__'] = (coords, indice_dict, walk)
+
+    def _walk_geometry(self, coords, bs, indice_dict, force_async=False):
         """all rulebooks of the main chain (subm1, spconv2, subm2, ... spconv_down2, subm_down2) in one call of the compiled
         binding before the first layer runs (spconv/geometry.py): every stage then finds its rulebooks ready and runs as one
         compiled call (SparseSequential._chain_plan) instead of ~100 us of Python per layer; the side-branch pools and the
@@ -266,7 +280,7 @@ class VoxelBackBone8xOcc(nn.Module):
             if getattr(self, "squeezeBev", None) is not None:
                 stages.append(self.squeezeBev)
             plan = plans[int(bs)] = GeometryPlan(flatten_convs(*stages), self.sparse_shape, bs)
-        if DET_WALK_ASYNC and sp_ops.PROFILE is None and plan.entries[0][0] == 0:
+        if (DET_WALK_ASYNC or force_async) and sp_ops.PROFILE is None and plan.entries[0][0] == 0:
             # The first stage (conv1, conv1_combine) only needs the level-0 submanifold rulebook, which needs no read-back: build it
             # alone, fork the rest of the walk (the strided levels and the read-back of their row counts) onto a side stream, and
             # let the caller run the first stage before it joins (forward -> _finish_walk).  The walk's ~0.3 ms of kernels and its
@@ -276,7 +290,7 @@ class VoxelBackBone8xOcc(nn.Module):
             if conv0.indice_key is not None:
                 indice_dict[conv0.indice_key] = rb0
             indice_dict.setdefault("__geometry_cache__", {})[conv0._gkey(coords, self.sparse_shape)] = (rb0, coords)
-            return (plan, plan.start(coords), {0: rb0}, coords)
+            return (plan, plan.start(coords, side_stream=not force_async or os.environ.get("BTC_WALK_AHEAD_SIDE", "0") == "1"), {0: rb0}, coords)
         plan.run(coords, indice_dict)
         return True
 
@@ -365,8 +379,15 @@ class VoxelBackBone8xOcc(nn.Module):
         if self.feature_dtype is not None:
             feats = feats.to(self.feature_dtype)
         bs = batch_dict['batch_size']
+        ahead = batch_dict.pop('__det_walk__', None)
+        if ahead is not None:   # start_walk(): same coordinates, the walk is under way (or done)
+            coords = ahead[0]
         x = spconv.SparseConvTensor(features=feats, indices=coords, spatial_shape=self.sparse_shape, batch_size=bs)
-        walk = self._walk_geometry(coords, bs, x.indice_dict)
+        if ahead is not None:
+            x.indice_dict = ahead[1]
+            walk = ahead[2]
+        else:
+            walk = self._walk_geometry(coords, bs, x.indice_dict)
         if not walk and self._first_strided is not None:
             # conv2's row count runs beside conv1 (rulebook lookahead, spconv/ops.py)
             self._first_strided.prefetch(coords, self.sparse_shape, bs, x.indice_dict)

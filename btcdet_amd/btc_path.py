@@ -9,12 +9,23 @@ btcdet_amd/trainer.py).  ``heads="rpn"`` appends the §8f row-1 glue -- BaseBEVB
 reference's module names (``det_modules.backbone_2d`` / ``det_modules.dense_head``) and its RPN loss (btcnet.py:108-114);
 the ROI head (ConvHead) is not built, ``x_combine`` keeps its stand-in.
 """
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
 
 from . import backbones_3d, bev_backbone, dense_head, height_compression, occ_head, occ_targets, pass_occ_vox, vfe
 from .processor import DataProcessor
+
+
+# BTC_DET_WALK_AHEAD=1: start the detection branch's rulebook walk behind PassOccVox, from the occupancy branch's thread
+# (backbones_3d.start_walk).  Off: measured on one MI355X, same box, 100 timed steps -- 431 scenes/s without, 304-314 with it (on a
+# side stream or on the occupancy branch's stream alike): the training thread's forward_det loses its 0.6 ms blocking read-back
+# (2.6 -> 1.5 ms of host time), but every kernel on the occupancy branch's stream and on the weight-gradient stream then runs 1.3-2x
+# longer (per-stream kernel totals 2.5 -> 4.8 ms and 2.4 -> 3.2 ms per step, tools/stream_timeline.py); round 2 had found the same
+# move neutral.  Kept for the record and for tests.
+DET_WALK_AHEAD = os.environ.get("BTC_DET_WALK_AHEAD", "0") == "1"
 
 
 class HotPathDataset(object):
@@ -198,14 +209,40 @@ class BtcHotPath(nn.Module):
         head = self.occ_modules.occ_dense_head
         if hasattr(head, "premerge"):
             head.premerge()  # the merged head weight is built before the backbone runs, so its CatBackward runs after it
+        prepared = {id(v) for v in batch_dict.values()} if gen is not None else None
         for mod in self.occ_module_list[n_done:]:
             batch_dict = mod(batch_dict)
+        if prepared is not None:
+            # what THIS call produced (on the current stream's pool): the only tensors a consumer on another stream has to register
+            # (hand_over) -- the prepared front is kept alive by its generation until the step has ended on every stream
+            batch_dict["__produced_here__"] = [v for v in batch_dict.values() if torch.is_tensor(v) and v.is_cuda and id(v) not in prepared]
         det_inputs_ready = None
         if torch.cuda.is_available() and batch_dict["voxels"].is_cuda:
+            dbb = self.det_modules.backbone_3d
+            if DET_WALK_AHEAD and hasattr(dbb, "start_walk"):
+                dbb.start_walk(batch_dict)   # the detection branch's rulebook walk starts here, behind PassOccVox (backbones_3d.start_walk)
             det_inputs_ready = torch.cuda.Event()
             det_inputs_ready.record()
         occ_loss, tb_dict = head.get_loss(batch_dict)
         return batch_dict, occ_loss, tb_dict, det_inputs_ready
+
+    @staticmethod
+    def hand_over(batch_dict, stream):
+        """register every device tensor of batch_dict (and of a rulebook walk started ahead) with `stream`, which will consume them:
+        they were allocated on the producer's stream, whose pool would otherwise hand their blocks out again while `stream` still
+        reads them.  ~40 calls of ~10 us: the pipelined step makes them from the producer's thread, off the training thread."""
+        def rec(t):
+            if torch.is_tensor(t) and t.is_cuda:
+                t.record_stream(stream)
+        for v in batch_dict.pop("__produced_here__", None) or batch_dict.values():
+            rec(v)
+        ahead = batch_dict.get("__det_walk__")
+        if ahead is not None:
+            rec(ahead[0])
+            for rb in ahead[2][2].values():
+                for t in (rb.nbr_out, rb.out_indices):
+                    rec(t)
+        batch_dict["__recorded_for__"] = stream.cuda_stream
 
     def forward_det(self, batch_dict, inputs_ready=None):
         """the detection branch up to the BEV map (btcnet.py:46-56) on the CURRENT stream; inputs_ready: the event of
@@ -213,9 +250,8 @@ class BtcHotPath(nn.Module):
         if inputs_ready is not None:
             cur = torch.cuda.current_stream()
             cur.wait_event(inputs_ready)
-            for v in batch_dict.values():
-                if torch.is_tensor(v) and v.is_cuda:
-                    v.record_stream(cur)
+            if batch_dict.pop("__recorded_for__", None) != cur.cuda_stream:   # (hand_over() did it from the producer's thread)
+                self.hand_over(batch_dict, cur)
         for mod in self.det_module_list:
             batch_dict = mod(batch_dict)
         # the two tensors the heads behind the hot path consume: the BEV map (BaseBEVBackbone) and x_combine (ConvHead)

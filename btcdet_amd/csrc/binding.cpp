@@ -636,7 +636,10 @@ std::shared_ptr<PendingWalk> geometry_walk_start(const Tensor& indices, int64_t 
                                                  const std::vector<int64_t>& a_k, const std::vector<int64_t>& a_s,
                                                  const std::vector<int64_t>& a_p, const std::vector<int64_t>& a_d,
                                                  const std::vector<int64_t>& mode, const std::vector<int64_t>& K,
-                                                 const std::vector<int64_t>& ws_bytes, const std::vector<int64_t>& ref, bool side) {
+                                                 const std::vector<int64_t>& ws_bytes, const std::vector<int64_t>& ref, int64_t side_mode) {
+  // side_mode: 0 = current stream, blocking read-back; 1 = forked onto the walk's side stream, counts copied to pinned memory
+  // asynchronously; 2 = current stream, counts copied asynchronously (no extra stream, no host wait here)
+  const bool side = side_mode != 0;
   const size_t n = kind.size();
   need(a_in.size() == n && a_out.size() == n && a_k.size() == n && a_s.size() == n && a_p.size() == n && a_d.size() == n && mode.size() == n &&
            K.size() == n && ws_bytes.size() == n && ref.size() == n, "geometry_walk: per-layer argument lists differ in length");
@@ -680,6 +683,8 @@ std::shared_ptr<PendingWalk> geometry_walk_start(const Tensor& indices, int64_t 
   if (side) {
     w = &walk_of(indices.get_device());
     slot = (int)(w->next.fetch_add(1) & 7u);
+  }
+  if (side_mode == 1) {
     run = w->side;
     // fork after the allocations and the zero fill of d_counts: the side stream is ordered behind them and behind `indices`
     if (hipEventRecord(w->fork[slot], main) != hipSuccess || hipStreamWaitEvent(run, w->fork[slot], 0) != hipSuccess)
@@ -713,6 +718,12 @@ std::vector<std::vector<Tensor>> geometry_walk_finish(const std::shared_ptr<Pend
   if (p->side) {
     if (hipEventSynchronize(p->done) != hipSuccess || hipStreamWaitEvent((hipStream_t)st(stream), p->done, 0) != hipSuccess)
       throw std::runtime_error("geometry walk: join failed");
+    // finish() may run on another stream than start() did (the walk of the detection branch is started from the occupancy branch's
+    // thread): the buffers start() allocated are used by the fill below on THIS stream
+    const c10::hip::HIPStream cur = c10::hip::getCurrentHIPStream();
+    for (const Tensor* t : {&p->ws, &p->d_counts, &p->indices}) c10::hip::HIPCachingAllocator::recordStream(t->storage().data_ptr(), cur);
+    for (const Tensor& t : p->out_idx)
+      if (t.defined()) c10::hip::HIPCachingAllocator::recordStream(t.storage().data_ptr(), cur);
   }
   int32_t hc_copy[BTC_CHAIN_MAX_LAYERS];
   for (size_t i = 0; i < n; ++i) hc_copy[i] = p->counts[i];   // the pinned slot is recycled 8 walks later
@@ -828,7 +839,7 @@ std::vector<std::vector<Tensor>> geometry_walk(const Tensor& indices, int64_t ba
                                                const std::vector<int64_t>& a_p, const std::vector<int64_t>& a_d,
                                                const std::vector<int64_t>& mode, const std::vector<int64_t>& K,
                                                const std::vector<int64_t>& ws_bytes, const std::vector<int64_t>& ref) {
-  return geometry_walk_finish(geometry_walk_start(indices, batch, kind, a_in, a_out, a_k, a_s, a_p, a_d, mode, K, ws_bytes, ref, false), {});
+  return geometry_walk_finish(geometry_walk_start(indices, batch, kind, a_in, a_out, a_k, a_s, a_p, a_d, mode, K, ws_bytes, ref, 0), {});
 }
 
 // a SparseSequential of conv -> BatchNorm -> ReLU layers whose rulebooks all exist already (the occupancy branch after

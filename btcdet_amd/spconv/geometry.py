@@ -70,10 +70,11 @@ class GeometryPlan(object):
                      [ops._conv_ws_bytes(x[2], self.batch_size) if (x[2] is not None and not x[2].subm) else 0 for x in e],
                      [x[1] for x in e])
 
-    def start(self, indices):
-        """phase A of the walk (the levels + the read-back of their row counts) forked onto a side stream; finish() joins it.
-        Whatever runs on the current stream in between overlaps with it."""
-        return ops.fast().geometry_walk_start(indices, self.batch_size, *self.args, True)
+    def start(self, indices, side_stream=True):
+        """phase A of the walk (the levels + the read-back of their row counts) forked onto a side stream (side_stream=False: on the
+        current stream, the counts still copied to pinned memory asynchronously); finish() joins it.  Whatever is launched in
+        between overlaps with it / runs behind it without a host wait."""
+        return ops.fast().geometry_walk_start(indices, self.batch_size, *self.args, 1 if side_stream else 2)
 
     def finish(self, handle, indices, indice_dict, have=None):
         """join start(): size and fill the maps on the current stream and file the rulebooks as run() does.  have: {layer

@@ -97,20 +97,32 @@ class SparseSequential(SparseModule):
         if not (FUSE_CONV_BN and FUSE_BN_RELU and CHAIN_LAYERS and f is not None and f.is_cuda and f.shape[0] > 0
                 and f.dtype in (nn_float32, _torch.bfloat16)):
             return None
-        mods = self._flat_modules()
-        plan, i = [], 0
+        # the container's structure is fixed: its (conv, bn, relu) triples are derived once (None: not a pure conv -> BatchNorm -> ReLU chain)
+        triples = self.__dict__.get("_chain_triples", False)
+        if triples is False:
+            mods = self._flat_modules()
+            triples, i = [], 0
+            while i < len(mods):
+                conv = mods[i]
+                bn = mods[i + 1] if i + 1 < len(mods) else None
+                if not (isinstance(conv, SparseConvolution) and not conv.conv1x1 and conv.ndim == 3 and bn is not None and fused_bn.fusable(bn)) \
+                        or ops.pads_in_channels(conv.in_channels):   # (padded per layer: ops._pad_in_channels)
+                    triples = None
+                    break
+                relu = i + 2 < len(mods) and type(mods[i + 2]) is nn.ReLU
+                triples.append((conv, bn, relu))
+                i += 2 + int(relu)
+            self.__dict__["_chain_triples"] = triples
+        if not triples:
+            return None
+        plan = []
         indices, shape = input.indices, input.spatial_shape
         geom = input.indice_dict.get("__geometry_cache__", None)
-        while i < len(mods):
-            conv = mods[i]
-            bn = mods[i + 1] if i + 1 < len(mods) else None
-            if not (isinstance(conv, SparseConvolution) and not conv.conv1x1 and conv.ndim == 3 and bn is not None and fused_bn.fusable(bn)):
+        for conv, bn, relu in triples:
+            if not fused_bn.fusable(bn):    # (a BatchNorm switched to eval without running statistics, ...)
                 return None
             if f.dtype == _torch.bfloat16 and (conv.in_channels % 16 or conv.out_channels % 16):
                 return None
-            if ops.pads_in_channels(conv.in_channels):   # padded per layer (ops._pad_in_channels)
-                return None
-            relu = i + 2 < len(mods) and type(mods[i + 2]) is nn.ReLU
             rb = input.indice_dict.get(conv.indice_key, None) if conv.indice_key is not None else None
             if conv.inverse:
                 if rb is None or rb.n_in == 0:
@@ -124,26 +136,35 @@ class SparseSequential(SparseModule):
                     return None
                 indices, shape = rb.out_indices, conv._out_shape(shape)
             plan.append((conv, bn, relu, rb, conv.inverse))
-            i += 2 + int(relu)
         return (plan, indices, shape) if plan else None
 
     def _run_chain(self, input, plan, indices, shape):
         from . import fused_bn, ops
         F = ops.fast()
-        w, b, mf, mb, of, ob, ga, be, rms, rvs, nbts, ub, mom, eps, relus, need, ov, dfr = ([] for _ in range(18))
-        ws = None
+        # what does not change from call to call (parameters, buffers, BatchNorm constants, workspace sizes) is gathered once per
+        # (training flags, weight tensors) of the chain; per call only the rulebook's maps / row orders and the row counts differ
+        key = tuple((bn.training, bn.track_running_stats, id(conv.weight)) for conv, bn, _, _, _ in plan)
+        st = self.__dict__.get("_chain_static")
+        if st is None or st[0] != key:
+            w, b, ga, be, rms, rvs, nbts, ub, mom, eps, relus, need, dfr = ([] for _ in range(13))
+            for conv, bn, relu, rb, inverse in plan:
+                training = bn.training or not bn.track_running_stats
+                rm = bn.running_mean if bn.track_running_stats else None
+                w.append(ops._f32c(conv.weight)); b.append(conv.bias)
+                ga.append(bn.weight); be.append(bn.bias); rms.append(rm); rvs.append(bn.running_var if bn.track_running_stats else None)
+                nbts.append(bn.num_batches_tracked if (bn.training and bn.track_running_stats) else None)
+                ub.append(bool(training or rm is None)); mom.append(float(bn.momentum)); eps.append(float(bn.eps)); relus.append(bool(relu))
+                need.append(int(fused_bn._ws(input.features.device, conv.weight.shape[-1])[1])); dfr.append(bool(conv.weight.is_leaf))
+            st = self.__dict__["_chain_static"] = (key, (w, b, ga, be, rms, rvs, nbts, ub, mom, eps, relus, need, dfr))
+        w, b, ga, be, rms, rvs, nbts, ub, mom, eps, relus, need, dfr = st[1]
+        mf, mb, of, ob, ov = [], [], [], [], []
         for conv, bn, relu, rb, inverse in plan:
-            maps = (rb.nbr_in, rb.nbr_out) if inverse else (rb.nbr_out, rb.map_bwd)
-            ords = (rb.order_in, rb.order_out) if inverse else (rb.order_out, rb.order_in)
-            of.append(ords[0]); ob.append(ords[1])
-            training = bn.training or not bn.track_running_stats
-            rm = bn.running_mean if bn.track_running_stats else None
-            ws, nb = fused_bn._ws(input.features.device, conv.weight.shape[-1])
-            w.append(ops._f32c(conv.weight)); b.append(conv.bias); mf.append(maps[0]); mb.append(maps[1])
-            ga.append(bn.weight); be.append(bn.bias); rms.append(rm); rvs.append(bn.running_var if bn.track_running_stats else None)
-            nbts.append(bn.num_batches_tracked if (bn.training and bn.track_running_stats) else None)
-            ub.append(bool(training or rm is None)); mom.append(float(bn.momentum)); eps.append(float(bn.eps)); relus.append(bool(relu))
-            need.append(int(nb)); ov.append(bool(ops._overlap_ok(maps[0].shape[0]))); dfr.append(bool(conv.weight.is_leaf))
+            if inverse:
+                mf.append(rb.nbr_in); mb.append(rb.nbr_out); of.append(rb.order_in); ob.append(rb.order_out)
+            else:
+                mf.append(rb.nbr_out); mb.append(rb.map_bwd); of.append(rb.order_out); ob.append(rb.order_in)
+            ov.append(bool(ops._overlap_ok(mf[-1].shape[0])))
+        ws = fused_bn._ws(input.features.device, max(wt.shape[-1] for wt in w))[0]
         out = F.conv_bn_relu_chain(ops._actc(input.features), w, b, mf, mb, of, ob, ga, be, rms, rvs, nbts, ub, mom, eps, relus, ws, need, ov, dfr)
         out_tensor = SparseConvTensor(out, indices, shape, input.batch_size)
         out_tensor.indice_dict = input.indice_dict

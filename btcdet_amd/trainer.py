@@ -101,9 +101,18 @@ def make_step(model, ddp, proc, opts, grad_sync=None, prefetch_stream=None, thre
     pipeline = bool(pipeline and det_stream is not None and ddp is model and (grad_sync is None or bucket_of is not None)
                     and prefetch_stream is not None and threaded and len(opts) == 1 and hasattr(opts[0], "groups") and len(opts[0].groups) == 2)
     ahead_occ = {}
+    # the NEXT batch's weight-independent front on a thread of its own: it shares nothing with the occupancy branch's backward /
+    # optimizer step / next forward but the worker thread they all used to queue on -- the step is bound by its host threads (measured,
+    # BTC_TRAINER_TIMING=1: training thread 4.1 ms and worker 4.45 ms of host time per 4.9 ms step, the front 1.7 ms of the worker's)
+    prep_pool = None
+    if pipeline and os.environ.get("BTC_PREP_THREAD", "1") != "0":
+        from concurrent.futures import ThreadPoolExecutor as _TPE
+        prep_pool = _TPE(max_workers=1)
 
-    def occ_tail(loss_occ, next_batch, occ_done):
+    def occ_tail(loss_occ, next_batch, occ_done, prep_future=None):
+        import time
         torch.cuda.set_device(device)
+        tw = time.perf_counter() if timing is not None else 0.0
         try:
             loss_occ.backward()
             _ops.join_wgrad()            # (no-op: the end-of-pass callback has joined the side stream into this thread's stream)
@@ -111,20 +120,44 @@ def make_step(model, ddp, proc, opts, grad_sync=None, prefetch_stream=None, thre
                 grad_sync.launch(bucket_of["occ"])
         finally:
             occ_done.set()
+        if timing is not None:
+            timing["w_occ_backward"] = timing.get("w_occ_backward", 0.0) + time.perf_counter() - tw
+            tw = time.perf_counter()
         if grad_sync is not None:
             grad_sync.wait(bucket_of["occ"])
         opts[0].step(groups=[0])         # occupancy group, on the main stream behind its backward (and its all-reduce)
         if next_batch is None:
             return None
-        return occ_forward(model.prepare(next_batch, stream=prefetch_stream))
+        bd_next = prep_future.result() if prep_future is not None else model.prepare(next_batch, stream=prefetch_stream)
+        if timing is not None:
+            timing["w_opt_prepare"] = timing.get("w_opt_prepare", 0.0) + time.perf_counter() - tw
+            tw = time.perf_counter()
+        out = occ_forward(bd_next)
+        if timing is not None:
+            timing["w_occ_forward"] = timing.get("w_occ_forward", 0.0) + time.perf_counter() - tw
+        return out
 
     def occ_forward(bd):
         out = model.forward_occ(bd)
+        if det_stream is not None and hasattr(model, "hand_over") and os.environ.get("BTC_HANDOVER_WORKER", "0") == "1":
+            model.hand_over(out[0], det_stream)   # (A/B knob: the record_stream calls from this thread instead of the training thread -- 407 vs 442 scenes/s)
         done = torch.cuda.Event()
         done.record()                    # the loss tensor is complete on this (the main) stream
         return out + (done,)
 
+    timing = {} if os.environ.get("BTC_TRAINER_TIMING") == "1" else None   # host seconds per phase of the pipelined step (tools)
+
+    def _mark(name, t0):
+        if timing is not None:
+            import time
+            t = time.perf_counter()
+            timing[name] = timing.get(name, 0.0) + t - t0
+            return t
+        return 0.0
+
     def step_pipelined(batch, next_batch):
+        import time
+        t = time.perf_counter() if timing is not None else 0.0
         opts[0].zero_grad(set_to_none=True)
         cur = ahead_occ.pop(id(batch), None)
         ahead_occ.clear()
@@ -134,14 +167,19 @@ def make_step(model, ddp, proc, opts, grad_sync=None, prefetch_stream=None, thre
         pending.clear()
         bd, loss_occ, tb, inputs_ready, occ_fwd_done = cur
         occ_done = threading.Event()
-        fut = pool.submit(occ_tail, loss_occ, next_batch, occ_done)
+        prep_future = prep_pool.submit(prep, next_batch) if (prep_pool is not None and next_batch is not None) else None
+        fut = pool.submit(occ_tail, loss_occ, next_batch, occ_done, prep_future)
+        t = _mark("head", t)
         with torch.cuda.stream(det_stream):
             ret, bd = model.forward_det(bd, inputs_ready)
             loss_det = det_loss(ret, bd)
+        t = _mark("det_forward", t)
         occ_done.wait()
+        t = _mark("wait_occ_backward", t)
         with torch.cuda.stream(det_stream):
             loss_det.backward()
             _ops.join_wgrad()
+            t = _mark("det_backward", t)
             if grad_sync is not None:
                 grad_sync.launch(bucket_of["det"])
                 grad_sync.wait(bucket_of["det"])
@@ -150,9 +188,13 @@ def make_step(model, ddp, proc, opts, grad_sync=None, prefetch_stream=None, thre
             loss_occ.record_stream(det_stream)
             loss = loss_occ.detach() + loss_det.detach()
             model.mark_step_end(stream=det_stream, upto=bd.get("__gen_id__", -1))
+        t = _mark("det_optimizer", t)
         nxt = fut.result()
         if nxt is not None:
             ahead_occ[id(next_batch)] = nxt
+        t = _mark("wait_worker", t)
+        if timing is not None:
+            timing["n"] = timing.get("n", 0) + 1
         return loss
 
     def step(batch, next_batch=None):
@@ -217,6 +259,7 @@ def make_step(model, ddp, proc, opts, grad_sync=None, prefetch_stream=None, thre
             pending[id(next_batch)] = model.prepare(next_batch, stream=prefetch_stream)
         model.mark_step_end()
         return loss
+    step.timing = timing
     step.end_stream = det_stream if pipeline else None   # where a step's last kernel runs (per-step timing marks)
     step.pipelined = pipeline
     return step
