@@ -192,6 +192,7 @@ class VoxelBackBoneDeconv(nn.Module):
 
 
 DET_GEOMETRY_WALK = os.environ.get("BTC_DET_GEOMETRY_WALK", "1") != "0"  # VoxelBackBone8xOcc._walk_geometry
+FAST_STAGES = os.environ.get("BTC_FAST_STAGES", "1") != "0"               # VoxelBackBone8xOcc._stage: stages straight into the compiled chain call
 DET_WALK_ASYNC = os.environ.get("BTC_DET_WALK_ASYNC", "1") != "0"        # ... with the strided levels built on a side stream beside conv1
 
 
@@ -276,10 +277,21 @@ class VoxelBackBone8xOcc(nn.Module):
         plans = self.__dict__.setdefault("_geometry_plans", {})
         plan = plans.get(int(bs))
         if plan is None:
-            stages = [self.conv1, self.conv2, self.conv2_combine, self.conv3, self.conv3_combine, self.conv4, self.conv4_combine, self.conv_out]
+            # every sparse conv of forward() in execution order: the main chain builds, the side layers (conv1_combine, down2, down3,
+            # down_combine) reuse by indice_key -- the plan then hands forward() one rulebook per layer (stage_rulebooks)
+            stages = [self.conv1, self.conv1_combine, self.conv2, self.conv2_combine, self.conv3, self.conv3_combine, self.conv4, self.conv4_combine,
+                      self.conv_out]
             if getattr(self, "squeezeBev", None) is not None:
                 stages.append(self.squeezeBev)
+            if getattr(self, "down3", None) is not None:
+                stages += [self.down2, self.down3, self.down_combine]
             plan = plans[int(bs)] = GeometryPlan(flatten_convs(*stages), self.sparse_shape, bs)
+            offs, pos = {}, 0
+            for st in stages:
+                n = len(flatten_convs(st))
+                offs[id(st)] = (pos, pos + n)
+                pos += n
+            plan.stage_slices = offs
         if (DET_WALK_ASYNC or force_async) and sp_ops.PROFILE is None and plan.entries[0][0] == 0:
             # The first stage (conv1, conv1_combine) only needs the level-0 submanifold rulebook, which needs no read-back: build it
             # alone, fork the rest of the walk (the strided levels and the read-back of their row counts) onto a side stream, and
@@ -291,14 +303,39 @@ class VoxelBackBone8xOcc(nn.Module):
                 indice_dict[conv0.indice_key] = rb0
             indice_dict.setdefault("__geometry_cache__", {})[conv0._gkey(coords, self.sparse_shape)] = (rb0, coords)
             return (plan, plan.start(coords, side_stream=not force_async or os.environ.get("BTC_WALK_AHEAD_SIDE", "0") == "1"), {0: rb0}, coords)
-        plan.run(coords, indice_dict)
-        return True
+        return ("done", plan, plan.run(coords, indice_dict))
 
     @staticmethod
     def _finish_walk(walk, indice_dict):
+        """-> (plan, one rulebook per sparse conv of the plan) once the walk is complete, else None"""
+        if isinstance(walk, tuple) and walk[0] == "done":
+            return walk[1], walk[2]
         if isinstance(walk, tuple):
             plan, handle, have, coords = walk
-            plan.finish(handle, coords, indice_dict, have)
+            return plan, plan.finish(handle, coords, indice_dict, have)
+        return None
+
+    def _stage(self, stage, x, ready):
+        """run a SparseSequential stage.  With the walk's rulebooks at hand (ready = (plan, rulebooks)) a pure conv -> BatchNorm -> ReLU
+        stage goes straight into ONE call of the compiled binding (SparseSequential._run_chain) -- no module call, no rulebook
+        look-ups, no per-layer Python: the training thread's forward pass is bound by exactly that"""
+        from .spconv import modules as sp_modules, ops as sp_ops
+        if ready is not None and sp_modules.CHAIN_LAYERS and sp_modules.FUSE_CONV_BN and sp_modules.FUSE_BN_RELU and sp_ops.PROFILE is None \
+                and sp_ops.CAPTURE is None and sp_ops.NATIVE_AUTOGRAD and sp_ops.fast() is not None:   # (the conditions of SparseSequential's own chain path)
+            plan, rbs = ready
+            sl = plan.stage_slices.get(id(stage))
+            triples = stage.__dict__.get("_chain_triples", False)
+            if triples is False:
+                stage._chain_plan(x)                      # derives and caches the stage's (conv, bn, relu) triples
+                triples = stage.__dict__.get("_chain_triples", None)
+            f = x.features
+            if sl is not None and triples and len(triples) == sl[1] - sl[0] and f.is_cuda and f.shape[0] > 0 and \
+                    (f.dtype == torch.float32 or all(c.in_channels % 16 == 0 and c.out_channels % 16 == 0 for c, _, _ in triples)):
+                mine = rbs[sl[0]:sl[1]]
+                if all(rb is not None and rb.n_out > 0 for rb in mine):
+                    steps = [(c, bn, relu, rb, False) for (c, bn, relu), rb in zip(triples, mine)]
+                    return stage._run_chain(x, steps, mine[-1].out_indices, plan.entries[sl[1] - 1][4])
+        return stage(x)
 
     def _build_occ_net(self, kind, i):
         """occupancy-code side branch at level i (1..3): maxpool / learned / fixed-mean / avg (spconv_backbone.py:793-866)"""
@@ -363,16 +400,17 @@ class VoxelBackBone8xOcc(nn.Module):
         N, C, D, H, W = d.shape
         return d.view(N, C * D, H, W)
 
-    def res_combine(self, x2, x3, x4, bev, out_feat_type="combine"):
+    def res_combine(self, x2, x3, x4, bev, out_feat_type="combine", ready=None):
         if getattr(self, "down3", None) is None:
             return None
-        x2, x3 = self.down2(x2), self.down3(x3)
-        x4.features = torch.cat((x2.features, x3.features, x4.features), dim=1)
+        x2, x3 = self._stage(self.down2, x2, ready), self._stage(self.down3, x3, ready)
         if out_feat_type == "big_bev_combine":
-            bev2d = self.compress_height(self.squeezeBev(bev))
-            x4.features = torch.cat((x4.features, _BevGather.apply(bev2d, x4.indices, tuple(x4.spatial_shape), x4.batch_size)
-                                     .to(x4.features.dtype)), dim=1)
-        return self.down_combine(x4)
+            bev2d = self.compress_height(self._stage(self.squeezeBev, bev, ready))
+            x4.features = torch.cat((x2.features, x3.features, x4.features,
+                                     _BevGather.apply(bev2d, x4.indices, tuple(x4.spatial_shape), x4.batch_size).to(x4.features.dtype)), dim=1)
+        else:
+            x4.features = torch.cat((x2.features, x3.features, x4.features), dim=1)
+        return self._stage(self.down_combine, x4, ready)
 
     def forward(self, batch_dict):
         feats, coords = batch_dict['voxel_features'], batch_dict['voxel_coords'].int()
@@ -392,7 +430,10 @@ class VoxelBackBone8xOcc(nn.Module):
             # conv2's row count runs beside conv1 (rulebook lookahead, spconv/ops.py)
             self._first_strided.prefetch(coords, self.sparse_shape, bs, x.indice_dict)
         n_occ = len(self.occ_conv_exec)
-        x1 = self.conv1(x)
+        ready = None
+        if FAST_STAGES and isinstance(walk, tuple) and walk[0] == "done":   # (the blocking walk: every rulebook is there already)
+            ready = self._finish_walk(walk, x.indice_dict)
+        x1 = self._stage(self.conv1, x, ready)
         occ = None
         if n_occ > 0:
             occ = spconv.SparseConvTensor(features=batch_dict["occ_voxel_features"], indices=coords,
@@ -403,29 +444,32 @@ class VoxelBackBone8xOcc(nn.Module):
                 x1 = self.sparse_cat([x1, occ])
                 if self.out_att[0]:
                     x1 = self.apply_att(x1, self.att_conv1)
-        x1 = self.conv1_combine(x1)
-        self._finish_walk(walk, x.indice_dict)   # the strided levels' rulebooks, built beside the first stage
+        x1 = self._stage(self.conv1_combine, x1, ready)
+        if ready is None:   # the strided levels' rulebooks, built beside the first stage
+            ready = self._finish_walk(walk, x.indice_dict)
+            if not FAST_STAGES:
+                ready = None
         levels = [x1]
         cur = x1
         for lvl in (1, 2, 3):
-            cur = getattr(self, 'conv%d' % (lvl + 1))(cur)
+            cur = self._stage(getattr(self, 'conv%d' % (lvl + 1)), cur, ready)
             if n_occ > lvl:
                 occ = getattr(self, 'occ_conv%d' % (lvl + 1))(occ)
                 if self.occ_conv_exec[lvl]:
                     cur = self.sparse_cat([cur, occ])
                     if self.out_att[lvl]:
                         cur = self.apply_att(cur, getattr(self, 'att_conv%d' % (lvl + 1)))
-            cur = getattr(self, 'conv%d_combine' % (lvl + 1))(cur)
+            cur = self._stage(getattr(self, 'conv%d_combine' % (lvl + 1)), cur, ready)
             levels.append(cur)
         x1, x2, x3, x4 = levels
-        out = self.conv_out(x4)
+        out = self._stage(self.conv_out, x4, ready)
         batch_dict.update({'encoded_spconv_tensor': out, 'encoded_spconv_tensor_stride': 8})
         batch_dict.update({'multi_scale_3d_features': {
             'x_conv1': self.suqeeze(x1, 1, self.out_feat_type[0]),
             'x_conv2': self.suqeeze(x2, 2, self.out_feat_type[1]),
             'x_conv3': self.suqeeze(x3, 3, self.out_feat_type[2]),
             'x_conv4': self.suqeeze(x4, 4, self.out_feat_type[3]),
-            'x_combine': self.res_combine(x2, x3, x4, out, out_feat_type=self.out_feat_type[4]),
+            'x_combine': self.res_combine(x2, x3, x4, out, out_feat_type=self.out_feat_type[4], ready=ready),
         }})
         return batch_dict
 

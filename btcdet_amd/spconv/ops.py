@@ -767,8 +767,11 @@ class ToDenseFunction(torch.autograd.Function):
         return dfeat, None, None, None
 
 
+PAD_CHANNELS = int(os.environ.get("BTC_PAD_CHANNELS", "32"))
+
+
 def pads_in_channels(cin):
-    """whether indice_conv zero-pads a layer's input channels (to the next multiple of 16)"""
+    """whether indice_conv zero-pads a layer's input channels (to the next multiple of PAD_CHANNELS)"""
     return cin > 16 and cin % 16 != 0
 
 
@@ -780,7 +783,9 @@ def _pad_in_channels(features, weight):
     the padding off the gradients."""
     cin = weight.shape[-2]
     if features.is_cuda and pads_in_channels(cin):
-        pad = 16 - cin % 16
+        # to the next multiple of PAD_CHANNELS: with 48 channels the LDS-DMA kernel walks 16-channel items (3 per offset, 81 per
+        # workgroup for a 3 x 3 x 3 kernel), with 64 one 64-channel item per offset
+        pad = (-cin) % PAD_CHANNELS
         return torch.nn.functional.pad(features, (0, pad)), torch.nn.functional.pad(weight, (0, 0, 0, pad))
     return features, weight
 
