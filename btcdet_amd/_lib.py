@@ -103,6 +103,9 @@ _SIGS = {
     "btc_conv_wgrad_bf16": (ci, [vp, vp, vp, ci, vp, ci, ci, ci, ci, vp, vp, sz, vp]),
     "btc_conv_bf16w_supported": (ci, [ci, ci, ci]),
     "btc_weights_to_bf16": (ci, [vp, ci, ci, ci, vp, vp, vp]),
+    "btc_conv_split_supported": (ci, [ci, ci, ci]),
+    "btc_conv_split_wanted": (ci, [ci, ci, ci, ci]),
+    "btc_weights_split3": (ci, [vp, ci, ci, ci, vp, vp, vp]),
     "btc_conv_fwd_bf16w": (ci, [vp, vp, vp, vp, ci, ci, ci, ci, vp, vp]),
     "btc_conv_dgrad_bf16w": (ci, [vp, vp, vp, ci, ci, ci, ci, vp, vp]),
     "btc_row_orders": (ci, [vp, c_i32p, c_i32p, ci, vp, vp]),

@@ -73,28 +73,45 @@ bool bf16_operands(const Tensor& features, int64_t K, int64_t cred, int64_t cres
          btc_tune_value(BTC_TUNE_BF16_OPERANDS) != 1;
 }
 
-Tensor weights_bf16(const Tensor& w, int64_t K, int64_t cin, int64_t cout, int64_t stream) {
+// planes = 1: the bf16 copies; planes = 3: the hi / mid / lo planes of the split-operand kernel (btc_weights_split3) -- same rows
+std::unordered_map<const void*, WqEntry> g_ws;
+
+void convert_weights(const Tensor& w, int64_t K, int64_t cin, int64_t cout, int planes, Tensor& q, int64_t stream) {
+  char* row1 = (char*)q.data_ptr() + 2 * planes * w.numel();
+  if (planes == 1)
+    chk(btc_weights_to_bf16((const float*)w.data_ptr(), (int)K, (int)cin, (int)cout, q.data_ptr(), row1, st(stream)), "btc_weights_to_bf16");
+  else
+    chk(btc_weights_split3((const float*)w.data_ptr(), (int)K, (int)cin, (int)cout, q.data_ptr(), row1, st(stream)), "btc_weights_split3");
+}
+
+Tensor weights_q(const Tensor& w, int64_t K, int64_t cin, int64_t cout, int64_t stream, int planes) {
   const void* key = w.unsafeGetTensorImpl();
   const uint32_t version = (uint32_t)w._version();
   if (!w.is_leaf()) {   // a temporary (the zero-padded 34 -> 48 channel weight is a fresh tensor every step): convert, do not cache
-    Tensor q = at::empty({2, w.numel()}, w.options().dtype(at::kBFloat16));
-    chk(btc_weights_to_bf16((const float*)w.data_ptr(), (int)K, (int)cin, (int)cout, q.data_ptr(), (char*)q.data_ptr() + 2 * w.numel(), st(stream)),
-        "btc_weights_to_bf16");
+    Tensor q = at::empty({2, planes * w.numel()}, w.options().dtype(at::kBFloat16));
+    convert_weights(w, K, cin, cout, planes, q, stream);
     return q;
   }
   std::lock_guard<std::mutex> lock(g_wq_mu);
-  auto it = g_wq.find(key);
-  if (it != g_wq.end() && !it->second.weak.expired() && it->second.version == version && it->second.q.get_device() == w.get_device())
+  auto& tab = planes == 1 ? g_wq : g_ws;
+  auto it = tab.find(key);
+  if (it != tab.end() && !it->second.weak.expired() && it->second.version == version && it->second.q.get_device() == w.get_device())
     return it->second.q;
-  Tensor q = (it != g_wq.end() && !it->second.weak.expired() && it->second.q.numel() == 2 * w.numel() && it->second.q.get_device() == w.get_device())
-                 ? it->second.q : at::empty({2, w.numel()}, w.options().dtype(at::kBFloat16));
-  chk(btc_weights_to_bf16((const float*)w.data_ptr(), (int)K, (int)cin, (int)cout, q.data_ptr(), (char*)q.data_ptr() + 2 * w.numel(), st(stream)),
-      "btc_weights_to_bf16");
-  if (it != g_wq.end()) g_wq.erase(it);
-  g_wq.emplace(key, WqEntry(c10::weak_intrusive_ptr<c10::TensorImpl>(w.getIntrusivePtr()), version, q));
+  Tensor q = (it != tab.end() && !it->second.weak.expired() && it->second.q.numel() == 2 * planes * w.numel() && it->second.q.get_device() == w.get_device())
+                 ? it->second.q : at::empty({2, planes * w.numel()}, w.options().dtype(at::kBFloat16));
+  convert_weights(w, K, cin, cout, planes, q, stream);
+  if (it != tab.end()) tab.erase(it);
+  tab.emplace(key, WqEntry(c10::weak_intrusive_ptr<c10::TensorImpl>(w.getIntrusivePtr()), version, q));
   // models come and go in a long-lived process (tests): every miss drops the entries of freed parameters (a few dozen entries)
-  for (auto e = g_wq.begin(); e != g_wq.end();) e = e->second.weak.expired() ? g_wq.erase(e) : std::next(e);
+  for (auto e = tab.begin(); e != tab.end();) e = e->second.weak.expired() ? tab.erase(e) : std::next(e);
   return q;
+}
+
+Tensor weights_bf16(const Tensor& w, int64_t K, int64_t cin, int64_t cout, int64_t stream) { return weights_q(w, K, cin, cout, stream, 1); }
+
+// fp32 launch of n_rows rows on the split-operand kernel (csrc/conv_apply_split.hip)?  The library's policy; BTC_TUNE_SPLIT = 1: never
+bool split_operands(const Tensor& src, int64_t K, int64_t cred, int64_t cres, int64_t n_rows) {
+  return src.scalar_type() == at::kFloat && btc_conv_split_wanted((int)K, (int)cred, (int)cres, (int)n_rows);
 }
 
 // out = conv(features) ; features (n_src, Cin) fp32 | bf16 contiguous, w [K.., Cin, Cout] fp32, map_fwd (n_res, K) int32
@@ -116,6 +133,11 @@ Tensor conv_fwd(const Tensor& features, const Tensor& w, const OptTensor& bias, 
     chk(btc_conv_apply_ordered(BTC_PASS_FWD, BTC_OPERANDS_BF16, features.data_ptr(), (const char*)q.data_ptr() + 2 * w.numel(), fptr(bias),
                                (const int32_t*)map_fwd.data_ptr(), order, (int)n_res, (int)K, (int)cin, (int)cout, out.data_ptr(), st(stream)),
         "btc_conv_apply_ordered (fwd, bf16 operands)");
+  } else if (split_operands(features, K, cin, cout, n_res)) {
+    Tensor q = weights_q(w, K, cin, cout, stream, 3);
+    chk(btc_conv_apply_ordered(BTC_PASS_FWD, BTC_OPERANDS_F32_SPLIT, features.data_ptr(), (const char*)q.data_ptr() + 6 * w.numel(), fptr(bias),
+                               (const int32_t*)map_fwd.data_ptr(), order, (int)n_res, (int)K, (int)cin, (int)cout, out.data_ptr(), st(stream)),
+        "btc_conv_apply_ordered (fwd, split operands)");
   } else {
     const int operands = features.scalar_type() == at::kBFloat16 ? BTC_OPERANDS_BF16_ACT : BTC_OPERANDS_F32;
     chk(btc_conv_apply_ordered(BTC_PASS_FWD, operands, features.data_ptr(), w.data_ptr(), fptr(bias), (const int32_t*)map_fwd.data_ptr(), order,
@@ -175,8 +197,15 @@ std::tuple<Tensor, Tensor, Tensor> conv_bn_fwd(const Tensor& features, const Ten
     Tensor fw = fuse_ws_of(features, stream);
     float* mean = (float*)stats.data_ptr();
     long long* nb = (nbt.has_value() && nbt->defined()) ? (long long*)nbt->data_ptr() : nullptr;
-    const int operands = features.scalar_type() == at::kBFloat16 ? BTC_OPERANDS_BF16_ACT : BTC_OPERANDS_F32;
-    chk(btc_conv_bn_relu_fwd(operands, features.data_ptr(), w.data_ptr(), fptr(bias), (const int32_t*)map_fwd.data_ptr(), order, (int)n_res, (int)K,
+    int operands = features.scalar_type() == at::kBFloat16 ? BTC_OPERANDS_BF16_ACT : BTC_OPERANDS_F32;
+    const void* wp = w.data_ptr();
+    Tensor q;
+    if (split_operands(features, K, cin, cout, n_res)) {
+      q = weights_q(w, K, cin, cout, stream, 3);
+      operands = BTC_OPERANDS_F32_SPLIT;
+      wp = (const char*)q.data_ptr() + 6 * w.numel();
+    }
+    chk(btc_conv_bn_relu_fwd(operands, features.data_ptr(), wp, fptr(bias), (const int32_t*)map_fwd.data_ptr(), order, (int)n_res, (int)K,
                              (int)cin, (int)cout, x.data_ptr(), fptr(gamma), fptr(beta), (float*)vptr(rm), (float*)vptr(rv), nb, (float)momentum,
                              (float)eps, (int)relu, y.data_ptr(), mean, mean + cout, ws.data_ptr(), (size_t)ws_bytes, fw.data_ptr(), st(stream)),
         "btc_conv_bn_relu_fwd");
@@ -299,6 +328,10 @@ std::tuple<OptTensor, OptTensor> conv_bwd(const Tensor& features, const Tensor& 
       Tensor q = weights_bf16(w, K, cin, cout, stream);
       chk(btc_conv_apply_ordered(pass_dgrad, BTC_OPERANDS_BF16, grad_out.data_ptr(), q.data_ptr(), nullptr, (const int32_t*)map_bwd.data_ptr(),
                                  order, (int)n_src, (int)K, (int)cin, (int)cout, d.data_ptr(), st(stream)), "btc_conv_apply_ordered (dgrad, bf16 operands)");
+    } else if (split_operands(grad_out, K, cout, cin, n_src)) {
+      Tensor q = weights_q(w, K, cin, cout, stream, 3);
+      chk(btc_conv_apply_ordered(pass_dgrad, BTC_OPERANDS_F32_SPLIT, grad_out.data_ptr(), q.data_ptr(), nullptr, (const int32_t*)map_bwd.data_ptr(),
+                                 order, (int)n_src, (int)K, (int)cin, (int)cout, d.data_ptr(), st(stream)), "btc_conv_apply_ordered (dgrad, split operands)");
     } else
       chk(btc_conv_apply_ordered(pass_dgrad, bf ? BTC_OPERANDS_BF16_ACT : BTC_OPERANDS_F32, grad_out.data_ptr(), w.data_ptr(), nullptr,
                                  (const int32_t*)map_bwd.data_ptr(), order, (int)n_src, (int)K, (int)cin, (int)cout, d.data_ptr(), st(stream)),

@@ -576,8 +576,8 @@ extern "C" int btc_conv_bn_relu_fwd(int operands, const void* src, const void* W
                                     float* running_var, long long* num_batches_tracked, float momentum, float eps, int relu, void* y,
                                     float* save_mean, float* save_rstd, void* ws, size_t ws_bytes, void* fuse_ws, void* stream) {
   BTC_CHECK_ARG(n_rows >= 1, "btc_conv_bn_relu_fwd: empty input");
-  BTC_CHECK_ARG(operands >= BTC_OPERANDS_F32 && operands <= BTC_OPERANDS_BF16, "btc_conv_bn_relu_fwd: operands=%d", operands);
-  const bool bf = operands != BTC_OPERANDS_F32;
+  BTC_CHECK_ARG(operands >= BTC_OPERANDS_F32 && operands <= BTC_OPERANDS_F32_SPLIT, "btc_conv_bn_relu_fwd: operands=%d", operands);
+  const bool bf = operands == BTC_OPERANDS_BF16_ACT || operands == BTC_OPERANDS_BF16;
   int fused = 0;
   if (fuse_ws && operands != BTC_OPERANDS_BF16 && Cout <= BN_FUSE_CMAX && btc_tune_get(BTC_TUNE_BN_FUSE) != 1) {
     BnFuse bn;

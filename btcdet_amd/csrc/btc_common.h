@@ -44,7 +44,8 @@ int btc_tune_get(int key);
 // conv_apply_glds.hip: LDS-DMA pipelined sparse-conv apply (same results as conv_apply)
 bool btc_apply_glds_supported(int K, int Cred, int Cres);
 bool btc_apply_glds_has_shape(int shape, bool bf = false);
-size_t btc_apply_glds_lds_bytes(int shape, int kc, int K, bool bf);
+size_t btc_apply_glds_lds_bytes(int shape, int kc, int K, bool bf, int stages = 3);
+int btc_apply_glds_stages(int shape, int kc, int K, bool bf, int asked);
 // xcd: kernel flags -- bit 0 = XCD-contiguous tile mapping, bit 1 = `nbr` is a submanifold layer's forward map read as its backward
 // map (column K-1-k holds offset k: the two maps are mirror images, rulebook.hip)
 int btc_launch_apply_glds(bool trans_w, int shape, int kc, int xcd, bool bf, const void* feat, const float* W, const float* bias,
@@ -58,6 +59,9 @@ int btc_conv_fwd_stats(int operands, const void* src, const float* W, const floa
 // conv_apply_bf16.hip: bf16 operands on the bf16 matrix pipe; Wq[k][Cres][Cred] bf16
 int btc_apply_bf16w(const void* src, const void* Wq, const float* bias, const int32_t* nbr, const int32_t* order, int n_rows, int K, int Cred,
                     int Cres, void* dst, hipStream_t stream, int mirror = 0);
+struct BnFuse;
+int btc_apply_split(const float* src, const void* Ws, const float* bias, const int32_t* nbr, const int32_t* order, int n_rows, int K, int Cred,
+                    int Cres, float* dst, hipStream_t stream, int mirror, const BnFuse* bn);
 
 // bfloat16 <-> fp32 (round to nearest even; NaN stays NaN)
 __host__ __device__ __forceinline__ unsigned short btc_f32_to_bf16(float f) {

@@ -23,11 +23,30 @@ namespace {
 
 __device__ float g_zero_row[64];  // zero-initialised; the source of gathers for absent neighbours
 
-constexpr int G_STAGES = 3;
+constexpr int G_STAGES_DEFAULT = 3;   // ring depth when the launcher does not say (flags bits 4..7)
+constexpr int G_STAGES_MAX = 8;
 
 __device__ __forceinline__ void glds16(const float* g, float* l) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16,
                                    0, 0);
+}
+
+// 4 x 4 transpose across the four 16-lane rows of a wave: on entry lane (r, i) -- row r = lane >> 4 -- holds x[e] = M[r][e],
+// on exit y[e] = M[e][r].  Lane (i, kq) of an MFMA operand needs channel 4 q + kq for reduction step q: it reads the 16-byte
+// unit kq of a 16-channel block with ONE ds_read_b128 (conflict-free for the swizzled images above) and the transpose hands
+// every lane its four steps -- the same values in the same MFMA slots as four ds_read_b32, which for the row-major A / B^T
+// images are 2-way bank conflicts each (16 rows x 2 slots of a 32-lane group fall on 16 of the 32 banks).
+__device__ __forceinline__ void transpose4(const f32x4 v, float& y0, float& y1, float& y2, float& y3) {
+  unsigned x0 = __float_as_uint(v[0]), x1 = __float_as_uint(v[1]), x2 = __float_as_uint(v[2]), x3 = __float_as_uint(v[3]);
+  auto a = __builtin_amdgcn_permlane32_swap(x0, x2, false, false);   // rows 2, 3 of x0 <-> rows 0, 1 of x2
+  x0 = a[0]; x2 = a[1];
+  auto b = __builtin_amdgcn_permlane32_swap(x1, x3, false, false);
+  x1 = b[0]; x3 = b[1];
+  auto c = __builtin_amdgcn_permlane16_swap(x0, x1, false, false);   // odd rows of x0 <-> even rows of x1
+  x0 = c[0]; x1 = c[1];
+  auto d = __builtin_amdgcn_permlane16_swap(x2, x3, false, false);
+  x2 = d[0]; x3 = d[1];
+  y0 = __uint_as_float(x0); y1 = __uint_as_float(x1); y2 = __uint_as_float(x2); y3 = __uint_as_float(x3);
 }
 
 template <int N>
@@ -48,6 +67,8 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_apply_g(const void* __restr
                                                              const int32_t* __restrict__ order, int n_rows, int K, int Cred, int Cres,
                                                              void* __restrict__ out_, int xcd_swizzle, int dbg, const BnFuse bn) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  // ring depth (flags bits 4..7, set by the launcher which sized the LDS for it): S - 1 items are in flight while one is multiplied
+  const int S = ((xcd_swizzle >> 4) & 15) ? ((xcd_swizzle >> 4) & 15) : G_STAGES_DEFAULT;
   constexpr int NW = WR * WC, THREADS = 64 * NW;
   constexpr int TM = 16 * WR, TN = 16 * NTW * WC, NG = NTW * WC;  // NG: 16-column groups of the B image
   constexpr int ES = BF ? 2 : 4;                   // bytes per activation element
@@ -63,7 +84,7 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_apply_g(const void* __restr
   constexpr int A_BYTES = (TM * KC * ES + 1023) / 1024 * 1024;
   constexpr int STAGE = A_BYTES + KC * TN * 4;     // bytes
   char* ring = smem;                               // [G_STAGES][ A: TM x KC activations | B: KC x TN fp32 ]
-  int32_t* s_nbr = (int32_t*)(ring + G_STAGES * STAGE);  // [TM][K]
+  int32_t* s_nbr = (int32_t*)(ring + S * STAGE);  // [TM][K]
   int32_t* s_kact = s_nbr + TM * K;                // [K] flags, then the compact list of active offsets
   int32_t* s_nact = s_kact + K;                    // [1]
   int32_t* s_row = s_nact + 1;                     // [TM] the row each tile slot works on (order[] or identity), -1 past the end
@@ -125,6 +146,7 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_apply_g(const void* __restr
     float* Bs = (float*)(As + A_BYTES);
 #pragma unroll
     for (int t = 0; t < NAI; ++t) {
+      if (dbg & 8) break;   // timing experiments: no A gathers
       const int ai = (wave + NW * t) % NAI_TOTAL;  // instruction ai covers units [64 ai, 64 ai + 64) of the A image
       const int U = ai * 64 + lane;
       if (A_UNITS % 64 == 0 || U < A_UNITS) {      // a partial last instruction is exec-masked (inactive lanes write nothing)
@@ -138,6 +160,7 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_apply_g(const void* __restr
     const float* Wk = W + (size_t)k * Cred * Cres;
 #pragma unroll
     for (int t = 0; t < NBI; ++t) {
+      if (dbg & 4) break;   // timing experiments: no weight panels
       const int ii = (wave + NW * t) % NBI_TOTAL;
       const int U = ii * 64 + lane;
       const float* src;
@@ -155,15 +178,26 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_apply_g(const void* __restr
   };
 
   const int arow = lane & 15, kq = lane >> 4;
-  if (n_items > 0) issue(0, 0);
-  if (n_items > 1) issue(1, 1);
+  // vmcnt is a 6-bit counter: the launcher keeps (S - 2) * NPI <= 63 (btc_apply_glds_stages), the clamped cases below are never taken
+#define WAIT_ITEMS(n) wait_vm<((n) * NPI > 63 ? 63 : (n) * NPI)>()
+  for (int i = 0; i < S - 1 && i < n_items; ++i) issue(i, i);
   int st = 0;
   for (int item = 0; item < n_items; ++item) {
-    if (item + 1 < n_items) wait_vm<NPI>();  // this item has landed; the next one stays in flight
-    else wait_vm<0>();
+    // this item has landed; the min(S - 2, items left) issued behind it stay in flight
+    const int left = n_items - 1 - item, fl = left < S - 2 ? left : S - 2;
+    switch (fl) {
+      case 0: wait_vm<0>(); break;
+      case 1: WAIT_ITEMS(1); break;
+      case 2: WAIT_ITEMS(2); break;
+      case 3: WAIT_ITEMS(3); break;
+      case 4: WAIT_ITEMS(4); break;
+      case 5: WAIT_ITEMS(5); break;
+      default: WAIT_ITEMS(6); break;
+    }
+#undef WAIT_ITEMS
     __builtin_amdgcn_s_barrier();  // everyone's share of this item is in LDS, and everyone is done reading item - 1
     asm volatile("" ::: "memory");
-    if (item + 2 < n_items && !(dbg & 2)) issue(item + 2, st == 0 ? 2 : st - 1);  // into the stage item - 1 occupied
+    if (item + S - 1 < n_items && !(dbg & 2)) issue(item + S - 1, st == 0 ? S - 1 : st - 1);  // into the stage item - 1 occupied
     const int k = s_kact[item / n_chunks];
     if (((wave_act >> k) & 1ull) && !(dbg & 1)) {
       // fragment reads are software-pipelined by hand in groups of G reduction steps: the reads of group g + 1 are issued
@@ -176,11 +210,34 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_apply_g(const void* __restr
       constexpr int G = (16 / NTW) < 1 ? 1 : ((16 / NTW) > Q ? Q : (16 / NTW));
       constexpr int NGRP = Q / G;
       float a[2][G], b[2][G][NTW];
+      constexpr bool A128 = !BF && (G % 4 == 0);               // fp32 A fragments: one b128 read + a lane transpose per 4 steps
+      constexpr bool B128 = TRANS_W && (G % 4 == 0) && UPB >= 8;  // the same for the B^T image of dgrad
       auto load_group = [&](int g, int buf) {
+        if (A128) {
+#pragma unroll
+          for (int jb = 0; jb < G / 4; ++jb) {
+            const int u = (g * (G / 4) + jb) * 4 + kq;
+            const f32x4 v = *(const f32x4*)(A + ((u ^ aswz) * 16));
+            transpose4(v, a[buf][4 * jb], a[buf][4 * jb + 1], a[buf][4 * jb + 2], a[buf][4 * jb + 3]);
+          }
+        }
+        if (B128) {
+#pragma unroll
+          for (int nt = 0; nt < NTW; ++nt) {
+            const float* colp = B + ((wc * NTW + nt) * 16 + arow) * KC;
+#pragma unroll
+            for (int jb = 0; jb < G / 4; ++jb) {
+              const int u = (g * (G / 4) + jb) * 4 + kq;
+              const f32x4 v = *(const f32x4*)(colp + ((u ^ (arow & (UPB - 1))) * 4));
+              transpose4(v, b[buf][4 * jb][nt], b[buf][4 * jb + 1][nt], b[buf][4 * jb + 2][nt], b[buf][4 * jb + 3][nt]);
+            }
+          }
+        }
 #pragma unroll
         for (int i = 0; i < G; ++i) {
           const int q = g * G + i;
-          if (!BF) {  // channel q*4 + kq: unit q, element kq
+          if (A128) {
+          } else if (!BF) {  // channel q*4 + kq: unit q, element kq
             a[buf][i] = *(const float*)(A + ((q ^ aswz) * 16) + kq * 4);
           } else {    // unit q/2, element (q&1)*4 + kq; bf16 -> fp32 is a 16-bit shift
             const unsigned short h = *(const unsigned short*)(A + (((q >> 1) ^ aswz) * 16) + (((q & 1) * 4 + kq) * 2));
@@ -193,7 +250,7 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_apply_g(const void* __restr
               const int cg = wc * NTW + nt;
               b[buf][i][nt] = bp[((NG >= 2) ? (cg ^ (kq & 1)) : cg) * 16];
             }
-          } else {
+          } else if (!B128) {
             const float* bp = B + (wc * NTW * 16 + arow) * KC + (q ^ (arow & (UPB - 1))) * 4 + kq;
 #pragma unroll
             for (int nt = 0; nt < NTW; ++nt) b[buf][i][nt] = bp[nt * 16 * KC];
@@ -213,7 +270,7 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_apply_g(const void* __restr
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-    st = (st == G_STAGES - 1) ? 0 : st + 1;
+    st = (st == S - 1) ? 0 : st + 1;
   }
 
   // ---- epilogue: C/D layout of 16x16: col = lane&15, row = (lane>>4)*4 + reg
@@ -248,7 +305,9 @@ template <int WR, int WC, int NTW, bool TRANS_W, int KC, bool BF>
 int launch_g(const void* feat, const float* W, const float* bias, const int32_t* nbr, const int32_t* order, int n_rows, int K, int Cred,
              int Cres, void* out, int xcd, hipStream_t stream, const BnFuse& bn) {
   constexpr int TM = 16 * WR, TN = 16 * NTW * WC;
-  const size_t lds = btc_apply_glds_lds_bytes(WR * 100 + WC * 10 + NTW, KC, K, BF);
+  const int stages = btc_apply_glds_stages(WR * 100 + WC * 10 + NTW, KC, K, BF, (xcd >> 4) & 15);
+  xcd = (xcd & 15) | (stages << 4);
+  const size_t lds = btc_apply_glds_lds_bytes(WR * 100 + WC * 10 + NTW, KC, K, BF, stages);
   BTC_CHECK_ARG(lds <= 160 * 1024, "conv_apply_g: tile does not fit the LDS");
   static std::once_flag once;   // launches come from the training thread, the autograd thread and the prefetch thread
   std::call_once(once, [] {
@@ -316,10 +375,28 @@ bool btc_apply_glds_has_shape(int shape, bool bf) {
   return false;
 }
 
-size_t btc_apply_glds_lds_bytes(int shape, int kc, int K, bool bf) {
+size_t btc_apply_glds_lds_bytes(int shape, int kc, int K, bool bf, int stages) {
   const int tm = 16 * (shape / 100), tn = 16 * ((shape / 10) % 10) * (shape % 10);
   const size_t a_bytes = ((size_t)tm * kc * (bf ? 2 : 4) + 1023) / 1024 * 1024;
-  return (size_t)G_STAGES * (a_bytes + (size_t)kc * tn * 4) + (size_t)(tm * K + K + 1 + tm) * sizeof(int32_t);
+  return (size_t)(stages > 0 ? stages : G_STAGES_DEFAULT) * (a_bytes + (size_t)kc * tn * 4) + (size_t)(tm * K + K + 1 + tm) * sizeof(int32_t);
+}
+
+// Ring depth of a launch.  An item of a narrow layer is 8-16 MFMAs a wave (0.1-0.25 us) against a DMA round trip of 1-2 us,
+// so with two items in flight a workgroup's walk over its (offset, chunk) items is a chain of exposed latencies; the depth
+// is therefore as large as the LDS allows while `want_wgs` workgroups still share a CU (64 KB for the ring at most).
+int btc_apply_glds_stages(int shape, int kc, int K, bool bf, int asked) {
+  const int tm = 16 * (shape / 100), tn = 16 * ((shape / 10) % 10) * (shape % 10), nw = (shape / 100) * ((shape / 10) % 10);
+  const size_t a_bytes = ((size_t)tm * kc * (bf ? 2 : 4) + 1023) / 1024 * 1024, stage = a_bytes + (size_t)kc * tn * 4;
+  const int npi = (int)(((a_bytes / 1024) + nw - 1) / nw + ((size_t)kc * tn / 256 + nw - 1) / nw);   // DMA instructions per wave and item
+  int s = asked ? asked : btc_tune_get(BTC_TUNE_APPLY_STAGES);
+  if (!s) {
+    s = (int)((size_t)48 * 1024 / stage);
+    if (s > 6) s = 6;
+  }
+  if (s < 3) s = 3;
+  if (s > G_STAGES_MAX) s = G_STAGES_MAX;
+  while (s > 3 && ((s - 2) * npi > 63 || btc_apply_glds_lds_bytes(shape, kc, K, bf, s) > 160 * 1024)) --s;
+  return s;
 }
 
 bool btc_apply_glds_supported(int K, int Cred, int Cres) { return K <= 64 && Cred % 16 == 0 && Cres % 16 == 0 && Cred >= 16; }

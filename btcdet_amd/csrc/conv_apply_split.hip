@@ -1,0 +1,336 @@
+// Sparse convolution apply, fp32 in / fp32 out, with the products on the bf16 matrix pipe: every fp32 operand is split into
+// three bfloat16 pieces  x = hi + mid + lo  (8 + 8 + 8 significant bits, by truncation: the split is EXACT), and
+//     a * b  ~=  hi*hi + hi*mid + mid*hi + mid*mid + hi*lo + lo*hi          (the three dropped terms are <= 2^-24 |a b| each)
+// is six `v_mfma_f32_16x16x32_bf16` (fp32 accumulate) instead of eight `v_mfma_f32_16x16x4_f32` per 32 reduction channels of a
+// 16 x 16 tile: 6 x 16 cycles of the matrix pipe against 8 x 32.  Products of bf16 pairs are exact in fp32, so what differs from
+// the fp32 fmaf chain of conv_apply_g is (a) the dropped terms, ~1e-7 of |a b|, and (b) the fp32 accumulation order inside
+// the MFMA -- both of the order of the fp32 rounding the exact chain itself carries.  tests/test_hip_split.py states the bound
+// (<= 2e-6 of the result's scale against the exact kernel and against the fp64 product) and checks run-to-run bit-identity.
+// conv_apply_g stays the parity reference (BTC_TUNE_SPLIT = 1 selects it everywhere); this kernel takes the layers whose matrix
+// phase is the long pole (on the >= 64-channel layers conv_apply_g spends 75-85 % of its time there).
+//
+// Operands: activations fp32 as stored (gathered rows through the LDS-DMA ring, split in registers after the fragment read:
+// 8 consecutive channels = two ds_read_b128, 11 VALU operations per pair of values); weights as three bf16 planes made once per
+// optimizer step (btc_weights_split3), read as B^T rows contiguous along the reduction axis like conv_apply_b's:
+//     forward : Ws = planes of W^T  [3][K][Cout][Cin]   (Cred = Cin,  Cres = Cout)
+//     dgrad   : Ws = planes of W    [3][K][Cin][Cout]   (Cred = Cout, Cres = Cin)
+// LDS images per pipeline stage (bank swizzles on the per-lane SOURCE address; checked conflict-free for ds_read_b128's four
+// 16-lane groups by brute force):
+//     A    : TM rows x KC fp32          16-byte unit p of row r holds source unit  p ^ ((r ^ (r >> 3)) & (KC/4 - 1))
+//     B^T  : 3 planes x TN rows x KC bf16   unit p of row c holds source unit  p ^ ((c >> 1) & (KC/8 - 1))
+#include <mutex>
+
+#include "btc_common.h"
+#include "bn_fuse.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+namespace {
+
+__device__ float g_zero_row_s[64];  // zero-initialised source of gathers for absent neighbours (>= KC fp32)
+
+
+__device__ __forceinline__ void glds16s(const void* g, void* l) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vm_s() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// two fp32 values -> one dword of each plane (low half = a's piece, high half = b's piece)
+__device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned& mid, unsigned& lo) {
+  const unsigned ab = __float_as_uint(a), bb = __float_as_uint(b);
+  hi = __builtin_amdgcn_perm(bb, ab, 0x07060302u);
+  const float a1 = a - __uint_as_float(ab & 0xFFFF0000u), b1 = b - __uint_as_float(bb & 0xFFFF0000u);   // exact
+  const unsigned a1b = __float_as_uint(a1), b1b = __float_as_uint(b1);
+  mid = __builtin_amdgcn_perm(b1b, a1b, 0x07060302u);
+  const float a2 = a1 - __uint_as_float(a1b & 0xFFFF0000u), b2 = b1 - __uint_as_float(b1b & 0xFFFF0000u);   // exact
+  lo = __builtin_amdgcn_perm(__float_as_uint(b2), __float_as_uint(a2), 0x07060302u);
+}
+
+template <int WR, int WC, int NTW, int KC, int S_STAGES>
+__global__ __launch_bounds__(64 * WR * WC) void conv_apply_s(const float* __restrict__ feat, const unsigned short* __restrict__ Ws,
+                                                             const float* __restrict__ bias, const int32_t* __restrict__ nbr,
+                                                             const int32_t* __restrict__ order, int n_rows, int K, int Cred, int Cres,
+                                                             float* __restrict__ out, int flags, const BnFuse bn) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NW = WR * WC, THREADS = 64 * NW;
+  constexpr int TM = 16 * WR, TN = 16 * NTW * WC;
+  constexpr int UPA = KC / 4, UPB = KC / 8;          // 16-byte units per A row (fp32) / per B^T row of one plane (bf16)
+  constexpr int A_UNITS = TM * UPA, B_UNITS = 3 * TN * UPB;
+  static_assert(A_UNITS % 64 == 0 && B_UNITS % 64 == 0, "whole DMA instructions");
+  constexpr int NAI_TOTAL = A_UNITS / 64, NAI = (NAI_TOTAL + NW - 1) / NW;
+  constexpr int NBI_TOTAL = B_UNITS / 64, NBI = (NBI_TOTAL + NW - 1) / NW;
+  constexpr int NPI = NAI + NBI;
+  constexpr int A_BYTES = TM * KC * 4, P_BYTES = TN * KC * 2;   // one plane of the weight panel
+  constexpr int STAGE = A_BYTES + 3 * P_BYTES;
+  char* ring = smem;
+  int32_t* s_nbr = (int32_t*)(ring + S_STAGES * STAGE);  // [TM][K]
+  int32_t* s_kact = s_nbr + TM * K;
+  int32_t* s_nact = s_kact + K;
+  int32_t* s_row = s_nact + 1;                           // [TM] row of each tile slot (order[] or identity), -1 past the end
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave / WC, wc = wave % WC;
+  const int mirror = (flags >> 1) & 1;   // a submanifold FORWARD map read as the backward map (column K-1-k), see conv_apply_g
+  int bx = blockIdx.x;
+  if (flags & 1) {
+    const int nb = gridDim.x, per = nb >> 3, main = per << 3;
+    if (bx < main) bx = (bx & 7) * per + (bx >> 3);
+  }
+  const int row0 = bx * TM;
+  const int n0 = blockIdx.y * TN;
+  const size_t plane = (size_t)K * Cred * Cres;   // elements between two planes of Ws
+
+  for (int e = tid; e < K; e += THREADS) s_kact[e] = 0;
+  for (int e = tid; e < TM; e += THREADS) s_row[e] = (row0 + e < n_rows) ? (order ? order[row0 + e] : row0 + e) : -1;
+  __syncthreads();
+  for (int e = tid; e < TM * K; e += THREADS) {
+    const int rloc = e / K, kk = e - rloc * K;
+    const int gr = s_row[rloc];
+    const int v = gr >= 0 ? nbr[(long long)gr * K + (mirror ? K - 1 - kk : kk)] : -1;
+    s_nbr[e] = v;
+    if (v >= 0) s_kact[kk] = 1;
+  }
+  __syncthreads();
+  unsigned long long wave_act;
+  {
+    bool any = false;
+    if (lane < K)
+      for (int r = 0; r < 16; ++r) any |= s_nbr[(wr * 16 + r) * K + lane] >= 0;
+    wave_act = __ballot(any);
+  }
+  const int kflag = (lane < K) ? s_kact[lane] : 0;
+  __syncthreads();
+  if (wave == 0) {
+    const unsigned long long m = __ballot(kflag != 0);
+    if (kflag) s_kact[__popcll(m & ((1ull << lane) - 1ull))] = lane;
+    if (lane == 0) *s_nact = __popcll(m);
+  }
+  __syncthreads();
+  const int n_act = *s_nact;
+  const int n_chunks = Cred / KC;
+  const int n_items = n_act * n_chunks;
+
+  // three accumulators per tile, one per magnitude class of the piece products (1, 2^-8, 2^-16 of |a b|): the matrix pipe aligns
+  // the 32 products of an instruction to the accumulator it adds them to, so small products added to a large running sum lose
+  // their low bits one by one (measured: 9x the exact chain's error on the 6912-term sums of the 256 -> 128 layer); summed among
+  // themselves they keep them, and the classes meet once, in the epilogue
+  f32x4 acc[NTW], accm[NTW], accs[NTW];
+#pragma unroll
+  for (int nt = 0; nt < NTW; ++nt) acc[nt] = accm[nt] = accs[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  auto issue = [&](int item, int st) {
+    const int k = s_kact[item / n_chunks];
+    const int cc = (item % n_chunks) * KC;
+    char* As = ring + st * STAGE;
+    char* Bs = As + A_BYTES;
+#pragma unroll
+    for (int t = 0; t < NAI; ++t) {
+      const int ai = (wave + NW * t) % NAI_TOTAL;
+      const int U = ai * 64 + lane;
+      const int rloc = U / UPA;
+      const int u = (U % UPA) ^ ((rloc ^ (rloc >> 3)) & (UPA - 1));
+      const int nb = s_nbr[rloc * K + k];
+      const float* src = nb >= 0 ? feat + (size_t)nb * Cred + cc + u * 4 : g_zero_row_s;
+      glds16s(src, As + ai * 1024);
+    }
+    const unsigned short* Wk = Ws + ((size_t)k * Cres + n0) * Cred + cc;
+#pragma unroll
+    for (int t = 0; t < NBI; ++t) {
+      const int bi = (wave + NW * t) % NBI_TOTAL;
+      const int U = bi * 64 + lane;
+      const int pl = U / (TN * UPB), rem = U % (TN * UPB);
+      const int c = rem / UPB;
+      const int u = (rem % UPB) ^ ((c >> 1) & (UPB - 1));
+      glds16s(Wk + pl * plane + (size_t)c * Cred + u * 8, Bs + bi * 1024);
+    }
+  };
+
+  const int arow = lane & 15, kg = lane >> 4;
+  static_assert((S_STAGES - 2) * NPI <= 63, "vmcnt is a 6-bit counter");
+#pragma unroll
+  for (int i = 0; i < S_STAGES - 1; ++i)
+    if (i < n_items) issue(i, i);
+  int st = 0;
+  for (int item = 0; item < n_items; ++item) {
+    // this item has landed; the min(S_STAGES - 2, items left) issued behind it stay in flight
+    const int left = n_items - 1 - item;
+    if (S_STAGES >= 4 && left >= 2) wait_vm_s<(S_STAGES >= 4 ? 2 : 0) * NPI>();
+    else if (S_STAGES >= 3 && left >= 1) wait_vm_s<(S_STAGES >= 3 ? 1 : 0) * NPI>();
+    else wait_vm_s<0>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (item + S_STAGES - 1 < n_items) issue(item + S_STAGES - 1, st == 0 ? S_STAGES - 1 : st - 1);
+    const int k = s_kact[item / n_chunks];
+    if ((wave_act >> k) & 1ull) {
+      const int r = wr * 16 + arow;
+      const char* A = ring + st * STAGE + r * (KC * 4);
+      const char* B = ring + st * STAGE + A_BYTES;
+      const int aswz = (r ^ (r >> 3)) & (UPA - 1);
+      constexpr int STEPS = KC / 32;
+#pragma unroll
+      for (int s = 0; s < STEPS; ++s) {
+        const int u0 = 8 * s + 2 * kg;   // channels 32 s + 8 kg .. + 7 of the lane's row
+        const f32x4 v0 = *(const f32x4*)(A + ((u0 ^ aswz) * 16));
+        const f32x4 v1 = *(const f32x4*)(A + (((u0 + 1) ^ aswz) * 16));
+        uint4 bh[NTW], bm[NTW], bl[NTW];
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) {
+          const int col = (wc * NTW + nt) * 16 + arow;
+          const char* bp = B + col * (KC * 2) + (((4 * s + kg) ^ ((col >> 1) & (UPB - 1))) * 16);
+          bh[nt] = *(const uint4*)bp;
+          bm[nt] = *(const uint4*)(bp + P_BYTES);
+          bl[nt] = *(const uint4*)(bp + 2 * P_BYTES);
+        }
+        uint4 ah, am, al;
+        split2(v0[0], v0[1], ah.x, am.x, al.x);
+        split2(v0[2], v0[3], ah.y, am.y, al.y);
+        split2(v1[0], v1[1], ah.z, am.z, al.z);
+        split2(v1[2], v1[3], ah.w, am.w, al.w);
+        const bf16x8 Ah = __builtin_bit_cast(bf16x8, ah), Am = __builtin_bit_cast(bf16x8, am), Al = __builtin_bit_cast(bf16x8, al);
+#define S_MFMA(ACC, X, Y)                 \
+  _Pragma("unroll") for (int nt = 0; nt < NTW; ++nt) ACC[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(X, __builtin_bit_cast(bf16x8, Y[nt]), ACC[nt], 0, 0, 0)
+        S_MFMA(accs, Al, bh);
+        S_MFMA(accs, Ah, bl);
+        S_MFMA(accs, Am, bm);
+        S_MFMA(accm, Am, bh);
+        S_MFMA(accm, Ah, bm);
+        S_MFMA(acc, Ah, bh);
+#undef S_MFMA
+      }
+    }
+    st = (st == S_STAGES - 1) ? 0 : st + 1;
+  }
+
+  // epilogue as conv_apply_g's: C/D layout of 16x16: col = lane & 15, row = (lane >> 4) * 4 + reg
+  float vals[NTW][4];
+  bool valid[4];
+#pragma unroll
+  for (int nt = 0; nt < NTW; ++nt) {
+    const int col = n0 + (wc * NTW + nt) * 16 + (lane & 15);
+    const float bv0 = bias ? bias[col] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = s_row[wr * 16 + kg * 4 + r];
+      valid[r] = row >= 0;
+      const float sum = acc[nt][r] + (accm[nt][r] + accs[nt][r]);
+      const float v = bias ? (sum + bv0) : sum;
+      if (row >= 0) out[(size_t)row * Cres + col] = v;
+      vals[nt][r] = v;
+    }
+  }
+  if (bn.slots) {   // batch statistics for the BatchNorm behind this layer (bn_fuse.h)
+    bn_fuse_wave<NTW>(bn, vals, valid, n0 + wc * NTW * 16, (int)((bx * WR + wr) & (BN_FUSE_SLOTS - 1)));
+    bn_fuse_finish(bn, (int*)smem);
+  }
+}
+
+size_t lds_bytes_s(int tm, int tn, int kc, int K, int stages) {
+  return (size_t)stages * ((size_t)tm * kc * 4 + (size_t)3 * tn * kc * 2) + (size_t)(tm * K + K + 1 + tm) * sizeof(int32_t);
+}
+
+template <int WR, int WC, int NTW, int KC, int S_STAGES>
+int launch_s(const float* feat, const unsigned short* Ws, const float* bias, const int32_t* nbr, const int32_t* order, int n_rows, int K, int Cred,
+             int Cres, float* out, int flags, hipStream_t stream, const BnFuse& bn) {
+  constexpr int TM = 16 * WR, TN = 16 * NTW * WC;
+  const size_t lds = lds_bytes_s(TM, TN, KC, K, S_STAGES);
+  BTC_CHECK_ARG(lds <= 160 * 1024, "conv_apply_s: tile does not fit the LDS");
+  static std::once_flag once;   // launches come from the training thread, the autograd thread and the prefetch thread
+  std::call_once(once, [] {
+    (void)hipFuncSetAttribute((const void*)conv_apply_s<WR, WC, NTW, KC, S_STAGES>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  });
+  dim3 grid(btc_cdiv(n_rows, TM), Cres / TN);
+  conv_apply_s<WR, WC, NTW, KC, S_STAGES><<<grid, 64 * WR * WC, lds, stream>>>(feat, Ws, bias, nbr, order, n_rows, K, Cred, Cres, out, flags, bn);
+  BTC_LAUNCH_CHECK();
+  return BTC_OK;
+}
+
+__global__ __launch_bounds__(256) void weights_split3(const float* __restrict__ W, int K, int Cin, int Cout, unsigned short* __restrict__ w_s,
+                                                      unsigned short* __restrict__ wt_s) {
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long per = (long long)Cin * Cout, n = (long long)K * per;
+  if (e >= n) return;
+  const float x = W[e];
+  const unsigned xb = __float_as_uint(x);
+  const float x1 = x - __uint_as_float(xb & 0xFFFF0000u);
+  const unsigned x1b = __float_as_uint(x1);
+  const float x2 = x1 - __uint_as_float(x1b & 0xFFFF0000u);
+  const unsigned short p[3] = {(unsigned short)(xb >> 16), (unsigned short)(x1b >> 16), (unsigned short)(__float_as_uint(x2) >> 16)};
+  const int k = (int)(e / per);
+  const int rem = (int)(e - (long long)k * per);
+  const int ci = rem / Cout, co = rem - ci * Cout;
+  const long long et = (long long)k * per + (long long)co * Cin + ci;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    w_s[j * n + e] = p[j];
+    wt_s[j * n + et] = p[j];
+  }
+}
+
+}  // namespace
+
+extern "C" int btc_conv_split_supported(int K, int Cred, int Cres) {
+  return K >= 1 && K <= 64 && Cred >= 32 && Cred % 32 == 0 && Cres >= 64 && Cres % 64 == 0;
+}
+
+// the built-in policy of the host bindings: take this kernel for an fp32 launch of n_rows rows?  (below ~6 K rows the exact kernel's
+// 16-row workgroups fill the GPU better: 64 -> 64 at 3 K rows 31 us against 32-41)
+extern "C" int btc_conv_split_wanted(int K, int Cred, int Cres, int n_rows) {
+  return btc_tune_get(BTC_TUNE_SPLIT) != 1 && btc_conv_split_supported(K, Cred, Cres) && n_rows >= 6000;
+}
+
+// Ws: the planes btc_weights_split3 made for this pass (wt_split for forward, w_split for dgrad)
+int btc_apply_split(const float* src, const void* Ws_, const float* bias, const int32_t* nbr, const int32_t* order, int n_rows, int K, int Cred,
+                    int Cres, float* dst, hipStream_t stream, int mirror, const BnFuse* bn_) {
+  if (n_rows <= 0) return BTC_OK;
+  BTC_CHECK_ARG(btc_conv_split_supported(K, Cred, Cres), "conv_apply_s: needs K <= 64, Cred %% 32 == 0, Cres %% 64 == 0 (K=%d, %d -> %d)", K, Cred, Cres);
+  const BnFuse bn = bn_ ? *bn_ : btc_bn_fuse_none();
+  const unsigned short* Ws = (const unsigned short*)Ws_;
+  const int flags = (btc_tune_get(BTC_TUNE_APPLY_XCD) == 2 ? 1 : 0) | (mirror ? 2 : 0);
+  const int t_nt = btc_tune_get(BTC_TUNE_APPLY_NT);
+  // shapes / chunk from tools/conv_bench.py on MI355X (us per launch, exact fp32 chain -> this kernel): 256 -> 128 at 14 K rows 333 -> 200
+  // (64 x 128 tile, 64-channel items, double buffer; 32-channel items with three stages 241), 128 -> 128 164 -> 102, 64 -> 64 at 14 K rows
+  // 57 -> 37.5 (64-channel items; 32-channel items 46.7), at 30 K rows 110 -> 68 (32-channel items, three stages; 64-channel items 75),
+  // 32 -> 64 at 30 K rows 65 -> 36.  A launch is bound by the issue of its LDS-DMA pieces (the three weight planes are 6 bytes a
+  // weight), so the fewer, larger items win until the second workgroup per CU is lost.
+  int shape = (Cres % 128 == 0) ? 424 : 422;
+  if ((t_nt == 224 || t_nt == 424) && Cres % 128 == 0) shape = t_nt;   // tuning runs
+  if (t_nt == 222 || t_nt == 422) shape = t_nt;
+  const int t_kc = btc_tune_get(BTC_TUNE_APPLY_KC), t_st = btc_tune_get(BTC_TUNE_APPLY_STAGES);
+  int kc = (Cred % 64 == 0 && (shape % 10 == 4 || n_rows < 22000)) ? 64 : 32;
+  if (t_kc == 32 || (t_kc == 64 && Cred % 64 == 0)) kc = t_kc;
+  int stages = t_st ? t_st : 3;
+  if (kc == 64) stages = (t_st == 3 && shape == 422) ? 3 : 2;
+#define S_ARGS src, Ws, bias, nbr, order, n_rows, K, Cred, Cres, dst, flags, stream, bn
+  switch (shape * 10 + stages + (kc == 64 ? 5 : 0)) {   // ...7 / ...8: KC = 64 with 2 / 3 stages
+    case 4243: return launch_s<4, 2, 4, 32, 3>(S_ARGS);
+    case 4244: return launch_s<4, 2, 4, 32, 4>(S_ARGS);
+    case 4247: return launch_s<4, 2, 4, 64, 2>(S_ARGS);
+    case 2243: return launch_s<2, 2, 4, 32, 3>(S_ARGS);
+    case 2247: return launch_s<2, 2, 4, 64, 2>(S_ARGS);
+    case 2227: return launch_s<2, 2, 2, 64, 2>(S_ARGS);
+    case 4228: return launch_s<4, 2, 2, 64, 3>(S_ARGS);
+    case 2244: return launch_s<2, 2, 4, 32, 4>(S_ARGS);
+    case 4223: return launch_s<4, 2, 2, 32, 3>(S_ARGS);
+    case 4224: return launch_s<4, 2, 2, 32, 4>(S_ARGS);
+    case 4227: return launch_s<4, 2, 2, 64, 2>(S_ARGS);
+    case 2223: return launch_s<2, 2, 2, 32, 3>(S_ARGS);
+    case 2224: return launch_s<2, 2, 2, 32, 4>(S_ARGS);
+    default: break;
+  }
+  btc_set_error("conv_apply_s: no instance for shape %d, %d stages, kc %d", shape, stages, kc);
+  return BTC_EINVAL;
+#undef S_ARGS
+}
+
+extern "C" int btc_weights_split3(const float* W, int K, int Cin, int Cout, void* w_split, void* wt_split, void* stream) {
+  BTC_CHECK_ARG(K >= 1 && Cin >= 1 && Cout >= 1, "btc_weights_split3: bad sizes");
+  const long long n = (long long)K * Cin * Cout;
+  weights_split3<<<btc_cdiv(n, 256), 256, 0, (hipStream_t)stream>>>(W, K, Cin, Cout, (unsigned short*)w_split, (unsigned short*)wt_split);
+  BTC_LAUNCH_CHECK();
+  return BTC_OK;
+}

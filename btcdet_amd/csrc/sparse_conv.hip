@@ -1242,7 +1242,7 @@ extern "C" int btc_conv_dgrad(const float* dout, const float* W, const int32_t* 
 extern "C" int btc_conv_apply_ordered(int pass, int operands, const void* src, const void* W, const float* bias, const int32_t* nbr,
                                       const int32_t* order, int n_rows, int K, int Cin, int Cout, void* dst, void* stream) {
   BTC_CHECK_ARG((pass == BTC_PASS_FWD || pass == BTC_PASS_DGRAD || pass == BTC_PASS_DGRAD_MIRROR) && operands >= BTC_OPERANDS_F32 &&
-                    operands <= BTC_OPERANDS_BF16, "btc_conv_apply_ordered: pass=%d operands=%d", pass, operands);
+                    operands <= BTC_OPERANDS_F32_SPLIT, "btc_conv_apply_ordered: pass=%d operands=%d", pass, operands);
   // BTC_PASS_DGRAD_MIRROR: dgrad of a submanifold layer through its FORWARD map -- nbr_in[j][k] == nbr_out[j][K-1-k] there, so the
   // kernels read column K-1-k for offset k and the backward map never exists (same bits as the explicit map: tests)
   const int mirror = pass == BTC_PASS_DGRAD_MIRROR;
@@ -1255,6 +1255,8 @@ extern "C" int btc_conv_apply_ordered(int pass, int operands, const void* src, c
                   K, Cin, Cout);
     return btc_apply_bf16w(src, W, bias, nbr, order, n_rows, K, Cred, Cres, dst, (hipStream_t)stream, mirror);
   }
+  if (operands == BTC_OPERANDS_F32_SPLIT)
+    return btc_apply_split((const float*)src, W, bias, nbr, order, n_rows, K, Cred, Cres, (float*)dst, (hipStream_t)stream, mirror, nullptr);
   const bool bf = operands == BTC_OPERANDS_BF16_ACT;
   if (pass == BTC_PASS_FWD)
     return launch_apply<false>((const float*)src, (const float*)W, bias, nbr, n_rows, K, Cred, Cres, (float*)dst, (hipStream_t)stream, bf, order);
@@ -1267,9 +1269,14 @@ int btc_conv_fwd_stats(int operands, const void* src, const float* W, const floa
                        int Cin, int Cout, void* dst, const BnFuse& bn, hipStream_t stream, int* fused) {
   *fused = 0;
   BTC_CHECK_ARG(K >= 1 && K <= 512 && Cin >= 1 && Cout >= 1 && n_rows >= 0, "btc_conv_fwd_stats: bad sizes");
-  BTC_CHECK_ARG(operands == BTC_OPERANDS_F32 || operands == BTC_OPERANDS_BF16_ACT, "btc_conv_fwd_stats: fp32 weights only");
+  BTC_CHECK_ARG(operands == BTC_OPERANDS_F32 || operands == BTC_OPERANDS_BF16_ACT || operands == BTC_OPERANDS_F32_SPLIT,
+                "btc_conv_fwd_stats: fp32 weights (or their split planes) only");
   BTC_CHECK_ARG(Cout <= BN_FUSE_CMAX, "btc_conv_fwd_stats: more than %d channels", BN_FUSE_CMAX);
   if (n_rows <= 0) return BTC_OK;
+  if (operands == BTC_OPERANDS_F32_SPLIT) {
+    *fused = 1;
+    return btc_apply_split((const float*)src, W, bias, nbr, order, n_rows, K, Cin, Cout, (float*)dst, stream, 0, &bn);
+  }
   const bool bf = operands == BTC_OPERANDS_BF16_ACT;
   *fused = 1;
   return launch_apply<false>((const float*)src, W, bias, nbr, n_rows, K, Cin, Cout, (float*)dst, stream, bf, order, 0, &bn);

@@ -35,7 +35,8 @@ def fuse_ws(device):
 
 
 def conv_bn_forward(features, w, b, map_fwd, ord_fwd, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, relu):
-    """training-mode conv -> BatchNorm -> [ReLU] through btc_conv_bn_relu_fwd (statistics in the conv's epilogue); fp32 weights.
+    """training-mode conv -> BatchNorm -> [ReLU] through btc_conv_bn_relu_fwd (statistics in the conv's epilogue); fp32 weights
+    or their split planes.
     -> (x, y, stats (2, C) = mean | rstd)"""
     n, K = map_fwd.shape
     cin, cout = w.shape[-2], w.shape[-1]
@@ -43,7 +44,11 @@ def conv_bn_forward(features, w, b, map_fwd, ord_fwd, gamma, beta, running_mean,
     y = torch.empty_like(x)
     stats = torch.empty((2, cout), dtype=torch.float32, device=features.device)
     ws, need = _ws(features.device, cout)
-    check(lib().btc_conv_bn_relu_fwd(1 if features.dtype == torch.bfloat16 else 0, ptr(features), ptr(w), ptr(b), ptr(map_fwd), ptr(ord_fwd), n, K, cin, cout,
+    operands = 1 if features.dtype == torch.bfloat16 else 0
+    from . import ops
+    if ops._split_operands(features, K, cin, cout, n):   # split-operand kernel: W = the forward planes
+        operands, w = 3, ops._weights_split(w, K, cin, cout)[1]
+    check(lib().btc_conv_bn_relu_fwd(operands, ptr(features), ptr(w), ptr(b), ptr(map_fwd), ptr(ord_fwd), n, K, cin, cout,
                                      ptr(x), ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), ptr(num_batches_tracked), float(momentum),
                                      float(eps), int(relu), ptr(y), ptr(stats[0]), ptr(stats[1]), ptr(ws), need, ptr(fuse_ws(features.device)),
                                      stream_ptr()), "btc_conv_bn_relu_fwd")

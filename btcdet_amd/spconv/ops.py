@@ -554,6 +554,32 @@ def _weights_bf16(w, K, cin, cout):
     return q
 
 
+_WS3 = {}
+
+
+def _split_operands(src, K, cred, cres, n_rows):
+    """fp32 launch on the split-operand kernel (csrc/conv_apply_split.hip: three bf16 pieces per operand, six bf16 MFMAs per
+    product block)?  The library's policy (btc_conv_split_wanted; never under BTC_TUNE_SPLIT = 1) -- same as binding.cpp"""
+    return src.dtype == torch.float32 and lib().btc_conv_split_wanted(int(K), int(cred), int(cres), int(n_rows)) == 1
+
+
+def _weights_split(w, K, cin, cout):
+    """(2, 3 * numel) bf16: row 0 = the hi | mid | lo planes of W [K][Cin][Cout] (dgrad operand), row 1 = those of W^T (forward
+    operand); rebuilt when the parameter's version counter moved"""
+    import weakref
+    hit = _WS3.get(id(w)) if w.is_leaf else None
+    if hit is not None and hit[0]() is w and hit[1] == w._version:
+        return hit[2]
+    q = torch.empty((2, 3 * w.numel()), dtype=torch.bfloat16, device=w.device)
+    check(lib().btc_weights_split3(ptr(w), int(K), int(cin), int(cout), ptr(q[0]), ptr(q[1]), stream_ptr()), "btc_weights_split3")
+    if not w.is_leaf:
+        return q
+    for k in [k for k, v in _WS3.items() if v[0]() is None]:
+        del _WS3[k]
+    _WS3[id(w)] = (weakref.ref(w), w._version, q)
+    return q
+
+
 def _conv_forward(features, w, b, map_fwd, ord_fwd=None):
     if PROFILE is None:
         F = fast()
@@ -570,6 +596,12 @@ def _conv_forward(features, w, b, map_fwd, ord_fwd=None):
         q = _weights_bf16(w, K, cin, cout)
         with _span("conv_apply", _conv_cost, (map_fwd, n_res, K, cin, cout, 2)):
             check(lib().btc_conv_apply_ordered(0, 2, ptr(features), ptr(q[1]), ptr(b), ptr(map_fwd), ptr(ord_fwd), n_res, K, cin, cout, ptr(out),
+                                               stream_ptr()), "btc_conv_apply_ordered")
+        return out
+    if _split_operands(features, K, cin, cout, n_res):
+        q = _weights_split(w, K, cin, cout)
+        with _span("conv_apply", _conv_cost, (map_fwd, n_res, K, cin, cout, 4)):
+            check(lib().btc_conv_apply_ordered(0, 3, ptr(features), ptr(q[1]), ptr(b), ptr(map_fwd), ptr(ord_fwd), n_res, K, cin, cout, ptr(out),
                                                stream_ptr()), "btc_conv_apply_ordered")
         return out
     with _span("conv_apply", _conv_cost, (map_fwd, n_res, K, cin, cout, 2 if bf else 4)):
@@ -620,6 +652,10 @@ def _conv_backward(features, w, map_fwd, map_bwd, grad_out, wshape, need_din, ne
             if _bf16_operands(grad_out, K, cout, cin):
                 q = _weights_bf16(w, K, cin, cout)
                 check(L.btc_conv_apply_ordered(pass_dgrad, 2, ptr(grad_out), ptr(q[0]), None, ptr(map_bwd), ptr(ord_bwd), n_src, K, cin, cout, ptr(din),
+                                               stream_ptr()), "btc_conv_apply_ordered")
+            elif _split_operands(grad_out, K, cout, cin, n_src):
+                q = _weights_split(w, K, cin, cout)
+                check(L.btc_conv_apply_ordered(pass_dgrad, 3, ptr(grad_out), ptr(q[0]), None, ptr(map_bwd), ptr(ord_bwd), n_src, K, cin, cout, ptr(din),
                                                stream_ptr()), "btc_conv_apply_ordered")
             else:
                 check(L.btc_conv_apply_ordered(pass_dgrad, 1 if bf else 0, ptr(grad_out), ptr(w), None, ptr(map_bwd), ptr(ord_bwd), n_src, K, cin, cout,
@@ -767,7 +803,7 @@ class ToDenseFunction(torch.autograd.Function):
         return dfeat, None, None, None
 
 
-PAD_CHANNELS = int(os.environ.get("BTC_PAD_CHANNELS", "32"))
+PAD_CHANNELS = int(os.environ.get("BTC_PAD_CHANNELS", "16"))   # 34 -> 48; 64 measured the same speed (and would move the bf16 run onto bf16 weights)
 
 
 def pads_in_channels(cin):

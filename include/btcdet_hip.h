@@ -64,6 +64,8 @@ int btc_version(void);
 #define BTC_TUNE_BN_BWD_KB 10 /* bn_bwd_stats: KB of input (x, y, dy) per workgroup (0 = built-in 128) */
 #define BTC_TUNE_WGRAD_PIPE 11 /* conv_wgrad_rows: 1 = the two-barrier kernel instead of the software-pipelined one */
 #define BTC_TUNE_BN_FUSE 12 /* btc_conv_bn_relu_fwd: 1 = statistics by the separate bn_stats launch instead of the conv epilogue */
+#define BTC_TUNE_SPLIT 14 /* host bindings: 1 = never take the split-operand kernel (conv_apply_g's exact fmaf chain everywhere) */
+#define BTC_TUNE_APPLY_STAGES 13 /* conv_apply_g: depth of the LDS ring (3..8; 0 = built-in policy) */
 #define BTC_TUNE_APPLY_DEBUG 3 /* timing experiments only (WRONG results): 1 = no MFMA phase, 2 = no loads in the main loop */
 int btc_tune_set(int key, int value);
 int btc_tune_value(int key);   /* current value of a key (0 = built-in policy) */
@@ -244,6 +246,19 @@ int btc_conv_fwd_bf16w(const void* feat, const void* wt_bf16, const float* bias,
 int btc_conv_dgrad_bf16w(const void* dout, const void* w_bf16, const int32_t* nbr_in, int n_in, int K, int Cin, int Cout, void* din,
                          void* stream);
 
+/* fp32 activations, fp32 results, products on the bf16 matrix pipe (csrc/conv_apply_split.hip): every operand is split exactly into
+ * three bfloat16 pieces (hi + mid + lo) and a * b is taken as the six largest of the nine piece products, fp32 accumulate --
+ * 6 bf16 MFMAs instead of 8 fp32 MFMAs per 32 reduction channels at 16x the rate.  Not the bit pattern of the exact fmaf chain
+ * (btc_conv_fwd / btc_conv_dgrad stay the parity reference): within 2e-6 of the result's scale of it, deterministic
+ * (tests/test_hip_split.py).  For the layers whose matrix phase is the long pole: Cred % 32 == 0, Cres % 64 == 0.
+ *   btc_weights_split3 : W fp32 [K][Cin][Cout] -> w_split [3][K][Cin][Cout] bf16 (dgrad operand), wt_split [3][K][Cout][Cin]
+ *                        (forward operand); once per optimizer step and layer (3*K*Cin*Cout*2 bytes each)
+ * used through btc_conv_apply_ordered / btc_conv_bn_relu_fwd with operands = BTC_OPERANDS_F32_SPLIT and W = the planes of that pass */
+int btc_conv_split_supported(int K, int Cred, int Cres);
+/* the host bindings' policy: 1 = an fp32 launch of n_rows rows should take the split-operand kernel (0 always under BTC_TUNE_SPLIT = 1) */
+int btc_conv_split_wanted(int K, int Cred, int Cres, int n_rows);
+int btc_weights_split3(const float* W, int K, int Cin, int Cout, void* w_split, void* wt_split, void* stream);
+
 /* Row-order hints (csrc/row_order.hip).  The apply kernels work on tiles of 16 consecutive map rows and pay for every
  * offset ANY row of the tile has; which rows share a tile changes no result.  btc_row_orders sorts the rows of up to
  * BTC_ROW_ORDER_MAX_MAPS neighbour maps by their FIRST PRESENT OFFSET (lowest k with nbr[row][k] >= 0; K if none) -- a
@@ -257,7 +272,8 @@ int btc_conv_dgrad_bf16w(const void* dout, const void* w_bf16, const int32_t* nb
  *              BTC_PASS_DGRAD_MIRROR  the same for a SUBMANIFOLD layer given its nbr_OUT: dst[j] = sum_k src[nbr[j][K-1-k]] @ W[k]^T
  *                             (nbr_in[j][k] == nbr_out[j][K-1-k] there; same summation order, same bits as BTC_PASS_DGRAD on nbr_in)
  *   operands : BTC_OPERANDS_F32; BTC_OPERANDS_BF16_ACT (bf16 src / dst, fp32 W); BTC_OPERANDS_BF16 (bf16 src / dst and W =
- *              the bf16 copy btc_weights_to_bf16 made for that pass: wt_bf16 for FWD, w_bf16 for DGRAD)
+ *              the bf16 copy btc_weights_to_bf16 made for that pass: wt_bf16 for FWD, w_bf16 for DGRAD); BTC_OPERANDS_F32_SPLIT
+ *              (fp32 src / dst, W = the planes btc_weights_split3 made for that pass: wt_split for FWD, w_split for DGRAD)
  * btc_conv_wgrad_ordered: btc_conv_wgrad (bf16_act = 0) / btc_conv_wgrad_bf16 (1) walking the rows in the given order(s)
  * (either may be NULL); dW is then the fp32 sum in THAT row order -- deterministic for a given order. */
 #define BTC_ROW_ORDER_MAX_MAPS 64
@@ -267,6 +283,7 @@ int btc_conv_dgrad_bf16w(const void* dout, const void* w_bf16, const int32_t* nb
 #define BTC_OPERANDS_F32 0
 #define BTC_OPERANDS_BF16_ACT 1
 #define BTC_OPERANDS_BF16 2
+#define BTC_OPERANDS_F32_SPLIT 3
 int btc_row_orders(const int32_t* const* nbrs /* host array of device pointers */, const int32_t* n_rows /* host */,
                    const int32_t* Ks /* host */, int n_maps, int32_t* order /* device, sum n_rows */, void* stream);
 /* the same with the sort keys handed in where they exist: firsts[j] (n_rows[j]) = first present offset of every row of map j (K for a

@@ -21,3 +21,13 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+@pytest.fixture
+def exact_conv():
+    """bit-exact comparisons with the oracle's fmaf chain: keep the fp32 launches off the split-operand kernel
+    (csrc/conv_apply_split.hip, fp32-accurate but a different summation; its own bounds: tests/test_hip_split.py)"""
+    from btcdet_amd._lib import check, lib
+    check(lib().btc_tune_set(14, 1), "btc_tune_set")
+    yield
+    check(lib().btc_tune_set(14, 0), "btc_tune_set")

@@ -29,7 +29,8 @@ def test_bench_json_line_contract():
     cfg = d["config"]
     assert "workload" in cfg and "model" not in cfg and cfg["global_batch"] == 2 and cfg["parallelism"] == "dp1"
     r = d["roofline"]
-    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    # "latency": neither roof within a factor 5 (frac_hbm_measured and frac_mfma < 0.2); the fraction is still quoted against the HBM roof
+    assert r["bound"] in ("hbm", "mfma", "latency") and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4 and 0.05 < r["frac"] < 1.0
     assert r["traffic"] is None or r["traffic"] > 1e6
     assert r["launches_per_step"] == 54.0 and 10 < r["avg_launch_us"] < 500
@@ -45,4 +46,4 @@ def test_bench_in_order_schedule_still_runs():
                        cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, text=True)
     assert p.returncode == 0, p.stderr[-2000:]
     d = json.loads([l for l in p.stdout.splitlines() if l.strip()][-1])
-    assert d["value"] > 50 and d["config"]["schedule"] == "in order, one stream"
+    assert d["value"] > 50 and d["config"]["schedule"].startswith("in order, one stream")

@@ -64,7 +64,7 @@ def test_conv_bf16_features_bit_exact(fp32_weights, cin, cout, n, kind):
 
 
 @pytest.mark.parametrize("cin,cout", [(6, 16), (34, 32), (32, 3)])
-def test_conv_bf16_features_odd_channels_fall_back_to_fp32_compute(cin, cout):
+def test_conv_bf16_features_odd_channels_fall_back_to_fp32_compute(cin, cout, exact_conv):
     """channel counts that are not multiples of 16 compute in fp32 on the widened activations and round the result"""
     from btcdet_amd.spconv import ops
     rng = np.random.default_rng(cin + cout)

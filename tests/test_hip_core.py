@@ -245,7 +245,7 @@ def test_conv_apply_lds_dma_instances_bit_exact(shape_code, kc):
 
 @pytest.mark.parametrize("cin,cout", [(4, 16), (6, 16), (16, 16), (32, 2), (32, 3), (16, 32), (32, 16), (32, 32), (34, 32), (32, 64), (64, 32), (64, 64), (2, 2)])
 @pytest.mark.parametrize("kind", ["subm", "conv"])
-def test_wgrad_row_stationary_kernel(cin, cout, kind):
+def test_wgrad_row_stationary_kernel(cin, cout, kind, exact_conv):
     """>= 4096 output rows selects conv_wgrad_rows (persistent, row-stationary); fp32 tolerance as above"""
     from btcdet_amd.spconv import ops
     rng = np.random.default_rng(cin * 100 + cout)

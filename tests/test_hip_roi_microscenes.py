@@ -43,7 +43,7 @@ def test_rulebooks_at_full_micro_scene_count():
     assert np.all(np.diff(idx[:, 0]) > 0)                       # one output row per non-empty micro-scene, ascending
 
 
-def test_configured_128_channel_layers_vs_oracle():
+def test_configured_128_channel_layers_vs_oracle(exact_conv):
     from btcdet_amd.spconv import ops
     rng = np.random.default_rng(1)
     B, C = 640, 128

@@ -1,0 +1,131 @@
+"""The split-operand sparse-conv kernel (csrc/conv_apply_split.hip): fp32 in / fp32 out, every operand split exactly into three
+bfloat16 pieces, the six largest piece products on the bf16 matrix pipe, one fp32 accumulator per magnitude class.  It is NOT the
+bit pattern of the oracle's fmaf chain (the exact kernels stay the parity reference: `exact_conv` fixture, BTC_TUNE_SPLIT = 1), so
+its bound is stated here: against the float64 product it is at least as close as the exact fp32 chain, it differs from that chain
+by <= 4e-6 of the result's scale, and it is deterministic (run to run, and under any row order)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as orc
+from test_hip_core import dev, rand_indices, _rb_both
+
+pytestmark = pytest.mark.gpu
+
+
+def _f64_conv(src, W, nbr, transpose):
+    """float64 reference: dst[i] = sum_k src[nbr[i][k]] @ W[k] (or W[k]^T)"""
+    K = nbr.shape[1]
+    W = W.reshape(K, W.shape[-2], W.shape[-1]).astype(np.float64)
+    s64 = src.astype(np.float64)
+    out = np.zeros((nbr.shape[0], W.shape[1] if transpose else W.shape[2]))
+    for k in range(K):
+        rows = np.nonzero(nbr[:, k] >= 0)[0]
+        if rows.size:
+            out[rows] += s64[nbr[rows, k]] @ (W[k].T if transpose else W[k])
+    return out
+
+
+def _err(a, ref):
+    d = a.astype(np.float64) - ref
+    return float(np.abs(d).max() / np.abs(ref).max()), float(np.sqrt((d ** 2).mean()) / np.sqrt((ref ** 2).mean()))
+
+
+@pytest.mark.parametrize("cin,cout,kind", [(64, 64, "subm"), (32, 64, "conv"), (64, 128, "subm"), (128, 128, "subm"), (256, 128, "subm"), (128, 64, "conv")])
+def test_split_kernel_vs_fp64_and_exact_chain(cin, cout, kind):
+    from btcdet_amd import _lib
+    from btcdet_amd.spconv import ops
+    L = _lib.lib()
+    rng = np.random.default_rng(cin * 7 + cout)
+    B = 2
+    shape, n_pts = ((12, 48, 44), 9000) if kind == "subm" else ((16, 64, 64), 40000)
+    idx = rand_indices(rng, n_pts, B, shape)
+    s = (1, 1, 1) if kind == "subm" else (2, 2, 2)
+    (o_idx, o_out, o_in, o_sh), rb = _rb_both(idx, B, shape, (3, 3, 3), s, (1, 1, 1), (1, 1, 1), kind)
+    n_out, n_in = o_out.shape[0], o_in.shape[0]
+    feat = rng.standard_normal((n_in, cin)).astype(np.float32)
+    W = (rng.standard_normal((3, 3, 3, cin, cout)) / np.sqrt(cin)).astype(np.float32)
+    bias = rng.standard_normal(cout).astype(np.float32)
+    dout = rng.standard_normal((n_out, cout)).astype(np.float32)
+    took_fwd = L.btc_conv_split_wanted(27, cin, cout, n_out) == 1
+    took_bwd = L.btc_conv_split_wanted(27, cout, cin, n_in) == 1
+    assert took_fwd or took_bwd, "this case is meant to reach the split-operand kernel"
+
+    def run():
+        f = torch.from_numpy(feat).to(dev()).requires_grad_(True)
+        w = torch.from_numpy(W).to(dev())
+        out = ops.indice_conv(f, w, torch.from_numpy(bias).to(dev()), rb)
+        out.backward(torch.from_numpy(dout).to(dev()))
+        return out.detach().cpu().numpy(), f.grad.cpu().numpy()
+
+    out, din = run()
+    out2, din2 = run()
+    assert np.array_equal(out, out2) and np.array_equal(din, din2)                     # deterministic
+    for name, got, exact, ref64, took in (
+            ("fwd", out, orc.conv_fwd(feat, W, bias, o_out), _f64_conv(feat, W, o_out, False) + bias.astype(np.float64), took_fwd),
+            ("dgrad", din, orc.conv_dgrad(dout, W, o_in), _f64_conv(dout, W, o_in, True), took_bwd)):
+        if not took:
+            assert np.array_equal(got, exact), name                                  # the exact kernel: the oracle's bits
+            continue
+        assert not np.array_equal(got, exact)                                          # (it really is the other kernel)
+        (mx, rms), (mx_e, rms_e) = _err(got, ref64), _err(exact, ref64)
+        dmax = float(np.abs(got - exact).max() / np.abs(exact).max())
+        print("%s %d -> %d %s: split vs fp64 max %.2e rms %.2e | exact chain vs fp64 max %.2e rms %.2e | split vs exact max %.2e" % (
+            name, cin, cout, kind, mx, rms, mx_e, rms_e, dmax))
+        assert rms <= 1.1 * rms_e and mx <= 1.5 * mx_e + 2e-7, name                    # at least as close to the true product as the fp32 chain
+        assert dmax <= 4e-6, name
+
+
+def test_split_kernel_row_order_and_mirror_do_not_change_bits():
+    """any row permutation (btc_conv_apply_ordered's hint) and the mirrored read of a submanifold map give the same bits as the
+    map order / the explicit backward map: a row's sums never depend on which rows share its tile"""
+    from btcdet_amd import _lib
+    from btcdet_amd._lib import check, ptr, stream_ptr
+    from btcdet_amd.spconv import ops
+    L = _lib.lib()
+    rng = np.random.default_rng(3)
+    shape, B, cin, cout = (12, 48, 44), 2, 64, 64
+    idx = rand_indices(rng, 9000, B, shape)
+    rb = ops.build_rulebook(torch.from_numpy(idx).to(dev()), B, shape, 3, 1, 1, 1, 0, True, False)
+    n = rb.nbr_out.shape[0]
+    feat = torch.from_numpy(rng.standard_normal((n, cin)).astype(np.float32)).to(dev())
+    w = torch.from_numpy((rng.standard_normal((27, cin, cout)) / 8).astype(np.float32)).to(dev())
+    q = torch.empty((2, 3 * w.numel()), dtype=torch.bfloat16, device=dev())
+    check(L.btc_weights_split3(ptr(w), 27, cin, cout, ptr(q[0]), ptr(q[1]), stream_ptr()), "btc_weights_split3")
+    order = torch.from_numpy(rng.permutation(n).astype(np.int32)).to(dev())
+    outs = []
+    for o in (None, order):
+        out = torch.empty((n, cout), device=dev())
+        check(L.btc_conv_apply_ordered(0, 3, ptr(feat), ptr(q[1]), None, ptr(rb.nbr_out), ptr(o), n, 27, cin, cout, ptr(out), stream_ptr()), "fwd")
+        outs.append(out)
+    assert torch.equal(outs[0], outs[1])
+    nbr_in = rb.nbr_in.contiguous()           # materialised mirror image
+    dins = []
+    for pass_, m in ((1, nbr_in), (2, rb.nbr_out)):
+        din = torch.empty((n, cin), device=dev())
+        check(L.btc_conv_apply_ordered(pass_, 3, ptr(outs[0]), ptr(q[0]), None, ptr(m), None, n, 27, cin, cout, ptr(din), stream_ptr()), "dgrad")
+        dins.append(din)
+    assert torch.equal(dins[0], dins[1])
+
+
+def test_split_planes_are_an_exact_decomposition():
+    """hi + mid + lo == the fp32 weight, bit for bit, and the two layouts hold the same pieces"""
+    from btcdet_amd import _lib
+    from btcdet_amd._lib import check, ptr, stream_ptr
+    L = _lib.lib()
+    rng = np.random.default_rng(0)
+    K, cin, cout = 27, 32, 64
+    w = (rng.standard_normal((K, cin, cout)) * np.exp(rng.uniform(-20, 20, (K, cin, cout)))).astype(np.float32)
+    w[0, 0, :4] = [0.0, -0.0, 1.0, -3.0]
+    wt = torch.from_numpy(w).to(dev())
+    q = torch.empty((2, 3, K, cin, cout), dtype=torch.bfloat16, device=dev())
+    check(L.btc_weights_split3(ptr(wt), K, cin, cout, ptr(q[0]), ptr(q[1]), stream_ptr()), "btc_weights_split3")
+    planes = q[0].float().cpu().numpy().astype(np.float64)
+    assert np.array_equal((planes[0] + planes[1] + planes[2]).astype(np.float32), w)
+    t = q[1].view(3, K, cout, cin).float().cpu().numpy()
+    assert np.array_equal(np.swapaxes(t, 2, 3), q[0].float().cpu().numpy())
+
+
+def test_exact_kernel_selected_by_tune_key(exact_conv):
+    from btcdet_amd import _lib
+    assert _lib.lib().btc_conv_split_wanted(27, 64, 64, 20000) == 0

@@ -108,7 +108,7 @@ def test_waymo_rulebooks_bit_exact_and_properties(det_voxels):
 
 
 @pytest.mark.parametrize("cin,cout", [(6, 16), (16, 32), (64, 64)])
-def test_waymo_conv_full_size(det_voxels, cin, cout):
+def test_waymo_conv_full_size(det_voxels, cin, cout, exact_conv):
     """forward / dgrad bit-exact and wgrad within 1e-4 of the scale on the full-size stride-2 rulebook"""
     from btcdet_amd.spconv import ops
     _, idx = det_voxels

@@ -13,7 +13,23 @@ from btcdet_amd.btc_path import BtcHotPath
 from btcdet_amd.config import load_cfg
 from btcdet_amd.spconv import ops
 
-variants = [tuple(int(x) for x in v.split(":")) for v in sys.argv[1:]] or [(0, 0, 0), (2, 0, 0)]
+def parse_variant(v):
+    """kernel:nt:xcd positional btc_tune_set values, or key=value items (13=5: ring depth 5), mixed"""
+    vals = [0] * 16
+    if v.startswith("split"):     # split[:tune...]: the split-operand kernel where it applies (operands = 3), tune values after the colon
+        vals.append(1)
+        v = v[6:] or "0"
+    for i, part in enumerate(v.split(":")):
+        if "=" in part:
+            k, x = part.split("=")
+            vals[int(k)] = int(x)
+        else:
+            vals[i] = int(part)
+    return tuple(vals)
+
+
+variants = [parse_variant(v) for v in sys.argv[1:]] or [parse_variant("0"), parse_variant("2")]
+names = sys.argv[1:] or ["0", "2"]
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
 model = BtcHotPath(load_cfg(), device=dev).to(dev).train()
@@ -29,7 +45,7 @@ L = _lib.lib()
 
 
 def tune(v):
-    v = tuple(v) + (0,) * (7 - len(v))
+    v = tuple(v[:16]) + (0,) * (16 - len(v[:16]))
     for key, val in enumerate(v):
         check(L.btc_tune_set(key, val), "btc_tune_set")
 
@@ -48,7 +64,7 @@ def timed(fn, reps=10):
 
 seen = set()
 print("%-5s %7s %7s %2s %4s %4s %8s | " % ("dir", "n_res", "n_src", "K", "cred", "cres", "pairs") +
-      " ".join("%12s" % (":".join(map(str, v))) for v in variants))
+      " ".join("%12s" % n for n in names))
 tot = np.zeros(len(variants))
 ONLY = os.environ.get("CB_ONLY")  # e.g. "256,128" = only layers with these (cin, cout)
 for feats, w, b, mf, mb in cap:
@@ -72,7 +88,20 @@ for feats, w, b, mf, mb in cap:
         us, ref = [], None
         for v in variants:
             tune(v)
-            if direction == "fwd":
+            split = len(v) > 16 and direction != "wgrad" and L.btc_conv_split_supported(K, cin if direction == "fwd" else cout, cout if direction == "fwd" else cin) == 1
+            if split:
+                if "planes" not in ws_cache:
+                    q = torch.empty((2, 3) + tuple(w.shape), dtype=torch.bfloat16, device=dev)
+                    check(L.btc_weights_split3(ptr(w), K, cin, cout, ptr(q[0]), ptr(q[1]), stream_ptr()), "split3")
+                    ws_cache["planes"] = q
+                q = ws_cache["planes"]
+                if direction == "fwd":
+                    fn = lambda: check(L.btc_conv_apply_ordered(0, 3, ptr(feats), ptr(q[1]), ptr(b), ptr(mf), None, n_res, K, cin, cout, ptr(out), stream_ptr()), "fwd split")
+                    res = out
+                else:
+                    fn = lambda: check(L.btc_conv_apply_ordered(1, 3, ptr(dout), ptr(q[0]), None, ptr(mb), None, n_src, K, cin, cout, ptr(din), stream_ptr()), "dgrad split")
+                    res = din
+            elif direction == "fwd":
                 fn = lambda: check(L.btc_conv_fwd(ptr(feats), ptr(w), ptr(b), ptr(mf), n_res, K, cin, cout, ptr(out), stream_ptr()), "fwd")
                 res = out
             elif direction == "wgrad":
@@ -89,7 +118,22 @@ for feats, w, b, mf, mb in cap:
             cur = res.clone()
             if ref is None:
                 ref = cur
-            if direction == "wgrad":
+            if os.environ.get("CB_F64") and direction == "fwd" and n_res <= 50000 and (split or v is variants[0]):
+                f64, w64 = feats.double(), w.double().reshape(K, cin, cout)
+                r64 = torch.zeros((n_res, cout), dtype=torch.float64, device=dev)
+                for kk in range(K):
+                    idx = mf[:, kk].long()
+                    r64 += (f64[idx.clamp(min=0)] * (idx >= 0).unsqueeze(1)) @ w64[kk]
+                if b is not None:
+                    r64 += b.double()
+                print("      vs fp64: %-12s max |err| / scale %.2e   rms err / rms %.2e" % (
+                    "split" if split else "exact chain", float((cur.double() - r64).abs().max() / r64.abs().max()),
+                    float((cur.double() - r64).pow(2).mean().sqrt() / r64.pow(2).mean().sqrt())))
+            if split:
+                err = float((ref - cur).abs().max() / ref.abs().max())
+                ok = err <= 2e-6
+                worst_split = max(globals().get("worst_split", 0.0), err)
+            elif direction == "wgrad":
                 ok = bool((ref - cur).abs().max() <= 1e-4 * ref.abs().max())
             else:
                 ok = torch.equal(ref.view(torch.int32), cur.view(torch.int32)) or (len(v) > 3 and v[3])
@@ -99,4 +143,5 @@ for feats, w, b, mf, mb in cap:
         print("%-5s %7d %7d %2d %4d %4d %8d | " % (direction, n_res, n_src, K, cred, cres, pairs) +
               " ".join("%9.1f%s" % (t, "   " if ok else " !!") for t, ok in us) + "  x%d" % mult)
 tune(())
+print("worst split-operand error relative to the scale: %.2e" % globals().get("worst_split", 0.0))
 print("sum over the step's layers (us): " + " ".join("%12.0f" % t for t in tot))
