@@ -211,7 +211,7 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_apply_g(const void* __restr
       constexpr int NGRP = Q / G;
       float a[2][G], b[2][G][NTW];
       constexpr bool A128 = !BF && (G % 4 == 0);               // fp32 A fragments: one b128 read + a lane transpose per 4 steps
-      constexpr bool B128 = TRANS_W && (G % 4 == 0) && UPB >= 8;  // the same for the B^T image of dgrad
+      constexpr bool B128 = TRANS_W && (G % 4 == 0) && UPB >= 8 && NTW == 1;  // the same for the B^T image of dgrad (NTW x the swaps: measured +7 % at NTW = 4)
       auto load_group = [&](int g, int buf) {
         if (A128) {
 #pragma unroll

@@ -278,9 +278,9 @@ extern "C" int btc_conv_split_supported(int K, int Cred, int Cres) {
 }
 
 // the built-in policy of the host bindings: take this kernel for an fp32 launch of n_rows rows?  (below ~6 K rows the exact kernel's
-// 16-row workgroups fill the GPU better: 64 -> 64 at 3 K rows 31 us against 32-41)
+// 16-row workgroups fill the GPU better: 64 -> 64 at 3 K rows 31 us against 32-41; wide layers pay off from ~4 K rows)
 extern "C" int btc_conv_split_wanted(int K, int Cred, int Cres, int n_rows) {
-  return btc_tune_get(BTC_TUNE_SPLIT) != 1 && btc_conv_split_supported(K, Cred, Cres) && n_rows >= 6000;
+  return btc_tune_get(BTC_TUNE_SPLIT) != 1 && btc_conv_split_supported(K, Cred, Cres) && n_rows >= ((Cred >= 128 || Cres >= 128) ? 4000 : 6000);
 }
 
 // Ws: the planes btc_weights_split3 made for this pass (wt_split for forward, w_split for dgrad)
@@ -297,7 +297,9 @@ int btc_apply_split(const float* src, const void* Ws_, const float* bias, const 
   // 57 -> 37.5 (64-channel items; 32-channel items 46.7), at 30 K rows 110 -> 68 (32-channel items, three stages; 64-channel items 75),
   // 32 -> 64 at 30 K rows 65 -> 36.  A launch is bound by the issue of its LDS-DMA pieces (the three weight planes are 6 bytes a
   // weight), so the fewer, larger items win until the second workgroup per CU is lost.
-  int shape = (Cres % 128 == 0) ? 424 : 422;
+  // few rows: the 64-row tiles leave CUs idle (6.4 K rows x 128 columns = 100 workgroups): 256 -> 128 at 6.4 K rows 200 us with the
+  // 64 x 128 tile, 148 with 32 x 64 (exact chain 193); 128 -> 256 (two column blocks) 105 with 64 x 128, 127 with 32 x 64 (exact 178)
+  int shape = (Cres % 128 == 0) ? ((n_rows >= 10000 || Cres >= 256) ? 424 : 222) : (n_rows >= 10000 ? 422 : 222);
   if ((t_nt == 224 || t_nt == 424) && Cres % 128 == 0) shape = t_nt;   // tuning runs
   if (t_nt == 222 || t_nt == 422) shape = t_nt;
   const int t_kc = btc_tune_get(BTC_TUNE_APPLY_KC), t_st = btc_tune_get(BTC_TUNE_APPLY_STAGES);

@@ -36,7 +36,8 @@ model = BtcHotPath(load_cfg(), device=dev).to(dev).train()
 opts = [torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=1e-3)]
 batches = bench.build_batches(2, 0, dev)
 step = bench.make_step(model, model, model.dataset.data_processor, opts)
-step(batches[0])
+for _ in range(int(os.environ.get("CB_WARM", "1"))):   # the occupancy head's predictions (hence the detection levels' sizes) settle over the first ~10 steps
+    step(batches[0])
 ops.CAPTURE = []
 step(batches[0])
 cap, ops.CAPTURE = ops.CAPTURE, None
