@@ -82,7 +82,14 @@ def make_step(model, ddp, proc, opts, grad_sync=None, prefetch_stream=None, thre
 
     def prep(next_batch):
         torch.cuda.set_device(device)
-        return model.prepare(next_batch, stream=prefetch_stream)
+        if timing is None:
+            return model.prepare(next_batch, stream=prefetch_stream)
+        import time
+        t0, c0 = time.perf_counter(), time.thread_time()
+        out = model.prepare(next_batch, stream=prefetch_stream)
+        timing["p_prepare"] = timing.get("p_prepare", 0.0) + time.perf_counter() - t0
+        timing["cpu_prep"] = timing.get("cpu_prep", 0.0) + time.thread_time() - c0
+        return out
 
     def occ_backward(loss):
         torch.cuda.set_device(device)
@@ -113,6 +120,7 @@ def make_step(model, ddp, proc, opts, grad_sync=None, prefetch_stream=None, thre
         import time
         torch.cuda.set_device(device)
         tw = time.perf_counter() if timing is not None else 0.0
+        cw = time.thread_time() if timing is not None else 0.0
         try:
             loss_occ.backward()
             _ops.join_wgrad()            # (no-op: the end-of-pass callback has joined the side stream into this thread's stream)
@@ -135,6 +143,7 @@ def make_step(model, ddp, proc, opts, grad_sync=None, prefetch_stream=None, thre
         out = occ_forward(bd_next)
         if timing is not None:
             timing["w_occ_forward"] = timing.get("w_occ_forward", 0.0) + time.perf_counter() - tw
+            timing["cpu_worker"] = timing.get("cpu_worker", 0.0) + time.thread_time() - cw   # CPU seconds of this thread (a phase much longer than its CPU time was waiting: GIL, GPU, another thread)
         return out
 
     def occ_forward(bd):
@@ -158,6 +167,7 @@ def make_step(model, ddp, proc, opts, grad_sync=None, prefetch_stream=None, thre
     def step_pipelined(batch, next_batch):
         import time
         t = time.perf_counter() if timing is not None else 0.0
+        c0 = time.thread_time() if timing is not None else 0.0
         opts[0].zero_grad(set_to_none=True)
         cur = ahead_occ.pop(id(batch), None)
         ahead_occ.clear()
@@ -195,6 +205,7 @@ def make_step(model, ddp, proc, opts, grad_sync=None, prefetch_stream=None, thre
         t = _mark("wait_worker", t)
         if timing is not None:
             timing["n"] = timing.get("n", 0) + 1
+            timing["cpu_main"] = timing.get("cpu_main", 0.0) + time.thread_time() - c0
         return loss
 
     def step(batch, next_batch=None):
@@ -281,12 +292,19 @@ class HotPathTrainer(object):
     when a process group exists, the streams and the worker thread of the chosen schedule."""
 
     def __init__(self, model, groups=None, total_steps=None, schedule=None, distributed=None, det_loss=None, process_group=None,
-                 optimizer=None):
+                 optimizer=None, reserve_bytes=None):
         import torch.distributed as dist
         from .spconv import ops
         from .train_step import GroupOptimizer
         self.model = model
         self.device = next(model.parameters()).device
+        # The step's buffers follow the scene (row counts per level move with every batch, and with what the occupancy head currently
+        # predicts), so the caching allocator keeps meeting new maxima and calls hipMalloc -- a device-wide stall -- in the middle of
+        # steady-state steps.  One large block, allocated and released here, leaves the allocator a pool it can carve those from.
+        # (The allocator's pools are per stream: the block is taken on each stream the schedule allocates on.)
+        if reserve_bytes is None:
+            reserve_bytes = int(os.environ.get("BTC_RESERVE_MB", "512")) << 20
+        self._reserve_bytes = reserve_bytes if self.device.type == "cuda" else 0
         if distributed is None:
             distributed = dist.is_available() and dist.is_initialized()
         self.world = dist.get_world_size(process_group) if distributed else 1
@@ -326,6 +344,12 @@ class HotPathTrainer(object):
         self._step = make_step(model, model, model.dataset.data_processor, [optimizer], self.grad_sync, self.prefetch_stream,
                                threaded=True, det_stream=self.det_stream, det_loss=det_loss, pipeline=schedule == "pipelined")
         self.end_stream = self._step.end_stream
+        if self._reserve_bytes > 0:
+            for stream in (torch.cuda.current_stream(self.device), self.det_stream, self.prefetch_stream):
+                if stream is not None:
+                    with torch.cuda.stream(stream):
+                        block = torch.empty(self._reserve_bytes, dtype=torch.uint8, device=self.device)
+                        del block
 
     def step(self, batch, next_batch=None):
         """one optimizer step on `batch`; next_batch (optional) lets the schedule prepare / start it ahead"""

@@ -1,0 +1,26 @@
+#!/bin/bash
+# the measurement set of a round: bench lines (default / bf16 / Waymo shape / Waymo bf16), kernel statistics of the default and the
+# in-order schedule, the two PMC passes, the straggler estimate -> gpurun_out/<tag>/ (copy what is to be judged into profiles/)
+tag=${1:-r03g}
+mkdir -p gpurun_out/$tag
+cd /root/repo
+timeout 400 python bench.py > gpurun_out/$tag/bench.json 2> gpurun_out/$tag/bench.err
+timeout 300 python bench.py --features bf16 --no-cpu-baseline --no-extras > gpurun_out/$tag/bench_bf16.json 2> gpurun_out/$tag/bench_bf16.err
+timeout 300 python bench.py --workload waymo --steps 40 --warmup 5 --no-cpu-baseline --no-extras > gpurun_out/$tag/bench_waymo.json 2> gpurun_out/$tag/bench_waymo.err
+timeout 300 python bench.py --workload waymo --features bf16 --steps 40 --warmup 5 --no-cpu-baseline --no-extras > gpurun_out/$tag/bench_waymo_bf16.json 2> gpurun_out/$tag/bench_waymo_bf16.err
+SKIP_BENCH=1 bash tools/gpu_prof.sh $tag > gpurun_out/$tag/prof.log 2>&1
+bash tools/gpu_pmc.sh $tag > gpurun_out/$tag/pmc.log 2>&1
+timeout 300 python tools/straggler.py 64 gpurun_out/$tag/straggler.json > gpurun_out/$tag/straggler.log 2>&1
+for f in bench bench_bf16 bench_waymo bench_waymo_bf16; do
+  python - <<PY
+import json
+try:
+    d = json.loads([l for l in open("gpurun_out/$tag/$f.json") if l.startswith("{")][-1])
+    r = d.get("roofline") or {}
+    print("$f", d["value"], d["ms_per_step"], "rulebook GB/s", d.get("rulebook_hbm_GBps"), "conv ms", r.get("kernel_ms_per_step"), "frac", r.get("frac"), r.get("bound"), (d.get("config") or {}).get("in_order_scenes_per_s"), (d.get("config") or {}).get("with_rpn_heads"))
+except Exception as e:
+    print("$f failed", e)
+PY
+done
+tail -3 gpurun_out/$tag/pmc.log
+tail -3 gpurun_out/$tag/straggler.log
