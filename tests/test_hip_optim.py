@@ -88,3 +88,35 @@ def test_missing_gradient_takes_the_list_path():
         np.testing.assert_allclose(p1.detach().cpu().numpy(), p0.detach().cpu().numpy(), rtol=2e-5, atol=2e-7)
     s0, s1 = o0.state_dict_lst()[1], o1.state_dict_lst()[1]
     assert [float(s0["state"][k]["step"]) for k in sorted(s0["state"])] == [float(s1["state"][k]["step"]) for k in sorted(s1["state"])]
+
+
+@pytest.mark.parametrize("tag,lr,wd", [("det", 0.01, 0.01), ("occ", 0.003, 0.001)])
+def test_flat_path_on_the_gpu_vs_the_reference_loop(tag, lr, wd):
+    """the three-launch flat optimizer step ON THE GPU against the vectors the reference's own OptimWrapper / OneCycle /
+    clip_grad_norm_ loop body wrote (tests/golden/gen_optim_golden.py -> optim.npz; tests/test_train_step_cpu.py checks the list path
+    on the CPU against the same file): lr / beta1 sequence exactly, parameters after 1, 2, 3, 16-18, 40 and 43 steps, norm clip biting on
+    every third step"""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import common
+    from test_train_step_cpu import tiny
+    from btcdet_amd.train_step import GroupOptimizer
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "optim.npz"))
+    per_epoch, epochs = [int(v) for v in g["meta"]]
+    m = tiny().cuda()
+    opt = GroupOptimizer([dict(params=list(m.parameters()), lr=lr, weight_decay=wd, grad_norm_clip=10.0, moms=(0.95, 0.85), div_factor=10,
+                               pct_start=0.4, lr_clip=1e-7)], total_steps=per_epoch * epochs, flat=True)
+    assert "flat" in opt.groups[0]
+    snaps = {int(i): k for k, i in enumerate(g["snap_iters"])}
+    for it in range(per_epoch * epochs + 3):
+        assert opt.groups[0]["lr"] == pytest.approx(float(g[tag + "_lr"][it]), rel=1e-12, abs=0)
+        assert opt.groups[0]["mom"] == pytest.approx(float(g[tag + "_mom"][it]), rel=1e-12, abs=0)
+        opt.zero_grad()
+        for j, (n, p) in enumerate(m.named_parameters()):
+            u = torch.from_numpy(common._hash01(p.numel(), 100 * it + j)).reshape(p.shape)
+            p.grad = ((u - 0.5) * (40.0 if it % 3 == 0 else 0.5)).cuda()
+        opt.step()
+        if it in snaps:
+            got = np.concatenate([p.detach().cpu().numpy().reshape(-1) for p in m.parameters()])
+            np.testing.assert_allclose(got, g[tag + "_params"][snaps[it]], rtol=2e-5, atol=2e-7, err_msg="after step %d" % it)
