@@ -24,6 +24,7 @@ Prints ONE JSON line on rank 0 (contract in the task statement), including
   cpu_baseline  the CPU oracle timed on the host cores for a bounded sample of the same workload (N = 1 only)
   config.in_order_scenes_per_s   the same modules driven in order on one stream (what the reference's own loop gets)
   config.with_rpn_heads          the step with BaseBEVBackbone + AnchorHeadSingle behind the BEV map (second, shorter run).
+  config.with_all_heads          ... and the ROI head (proposals, targets, ConvHead, rcnn loss) behind that: the reference's whole loss.
 """
 import argparse
 import json
@@ -198,7 +199,7 @@ def main():
     ap.add_argument("--features", choices=["fp32", "bf16"], default="fp32",
                     help="fp32: the reference's precision (default, the headline number); bf16: BASELINE.json configs[2] -- bfloat16 "
                          "activations between sparse layers, fp32 weights / accumulation / statistics")
-    ap.add_argument("--heads", choices=["standin", "rpn"], default="standin",
+    ap.add_argument("--heads", choices=["standin", "rpn", "full"], default="standin",
                     help="standin (headline): L2 stand-ins on the two tensors the heads behind the hot path consume; rpn: BaseBEVBackbone + "
                          "AnchorHeadSingle with the reference's RPN loss (btcnet.py:108-114) behind the BEV map, the ROI head's tensor keeps "
                          "its stand-in (ConvHead is not built)")
@@ -275,7 +276,7 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    model = build_model("rpn" if args.heads == "rpn" else None)
+    model = build_model(args.heads if args.heads in ("rpn", "full") else None)
     batches = build_batches(4, rank, device, bs, args.workload)
     nb = len(batches)
     # Schedule: HotPathTrainer's default ("pipelined": detection branch on its own stream, occupancy branch one step ahead, each
@@ -353,7 +354,7 @@ def main():
         from btcdet_amd import grad_sync as _gs
         n = max(_gs._TIMING.get("n", 1), 1)
         print("grad_sync host ms per step:", {k: round(v / n * 1e3, 3) for k, v in _gs._TIMING.items() if k != "n"}, file=sys.stderr)
-    if want_extras and args.heads != "rpn" and os.environ.get("BTC_BENCH_RPN", "1") != "0":
+    if want_extras and args.heads == "standin" and os.environ.get("BTC_BENCH_RPN", "1") != "0":
         # the same step with the §8f row-1 heads behind the BEV map (BaseBEVBackbone + AnchorHeadSingle, RPN loss of btcnet.py:108-114;
         # dense 2-D convs = vendor library): a second model, trainer and optimizer, run after the headline measurement
         del plain_step
@@ -365,13 +366,26 @@ def main():
         dt_r = max_over_ranks(dt_r, dist, device)
         extras["with_rpn_heads"] = {"scenes_per_s": round(bs * world * k_r / dt_r, 2), "ms_per_step": round(1e3 * dt_r / k_r, 3), "steps": k_r,
                                     "what": "BaseBEVBackbone + AnchorHeadSingle (RPN cls / loc / dir loss, targets assigned in the prepared front) "
-                                            "behind HeightCompression; x_combine keeps its L2 stand-in (ConvHead not built)"}
+                                            "behind HeightCompression; x_combine keeps its L2 stand-in"}
+        # ... and with the ROI head behind the proposals too: get_training_loss = loss_rpn + loss_rcnn + occupancy loss (btcnet.py:58-129)
+        del tr_r, model_r
+        model_f = build_model("full")
+        with _StdoutToStderr():
+            tr_f = HotPathTrainer(model_f, schedule=schedule, distributed=with_reducer, det_loss=model_f.det_loss)
+        k_f = min(args.steps, 10)
+        dt_f, ms_f, _ = timed_run(tr_f._step, k_f, 12, tr_f._step.end_stream)
+        dt_f = max_over_ranks(dt_f, dist, device)
+        extras["with_all_heads"] = {"scenes_per_s": round(bs * world * k_f / dt_f, 2), "ms_per_step": round(1e3 * dt_f / k_f, 3), "steps": k_f,
+                                    "what": "the reference's whole training loss: RPN (BaseBEVBackbone + AnchorHeadSingle) -> proposals (rotated NMS, 9000 -> 512) "
+                                            "-> ROI targets (128 sampled rois per scene) -> ConvHead (roi_conv_pool over raw points, occupancy points and "
+                                            "x_combine, 6912-cell micro-scene sparse pyramid) -> rcnn cls / reg / corner loss, + occupancy loss"}
 
     result = None
     if rank == 0:
         scenes = bs * world * args.steps
-        heads_txt = ("(+L2 stand-in for the BEV heads and the ROI head)" if args.heads == "standin" else
-                     "-> BaseBEVBackbone -> AnchorHeadSingle + RPN loss (+L2 stand-in for the ROI head)")
+        heads_txt = {"standin": "(+L2 stand-in for the BEV heads and the ROI head)",
+                     "rpn": "-> BaseBEVBackbone -> AnchorHeadSingle + RPN loss (+L2 stand-in for the ROI head)",
+                     "full": "-> BaseBEVBackbone -> AnchorHeadSingle + RPN loss -> proposals -> ROI targets -> ConvHead + rcnn loss"}[args.heads]
         result = {
             "metric": "scenes/s fwd+bwd %s bs=2/GPU (BtcDet hot path)" % ("Waymo-shaped synthetic" if waymo else "KITTI-Car"), "value": round(scenes / dt, 3), "unit": "scenes/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),

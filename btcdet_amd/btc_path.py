@@ -50,7 +50,7 @@ class HotPathDataset(object):
 class BtcHotPath(nn.Module):
     def __init__(self, cfg, dataset=None, device="cuda", heads=None):
         super().__init__()
-        assert heads in (None, "rpn"), heads
+        assert heads in (None, "rpn", "full"), heads
         self.cfg = cfg
         self.heads = heads
         self.dataset = dataset if dataset is not None else HotPathDataset(cfg)
@@ -92,15 +92,23 @@ class BtcHotPath(nn.Module):
         for name, mod in [("vfe", dvfe), ("backbone_3d", dbb), ("map_to_bev_module", bev)]:
             self.det_modules.add_module(name, mod)
         self.det_module_list = [dvfe, dbb, bev]
-        if heads == "rpn":   # module_topology continues: backbone_2d, dense_head (detector3d_template.py:28-30,252-289)
+        if heads in ("rpn", "full"):   # module_topology continues: backbone_2d, dense_head [, roi_head] (detector3d_template.py:28-30,252-330)
             b2d = bev_backbone.__all__[m.BACKBONE_2D.NAME](model_cfg=m.BACKBONE_2D, input_channels=m.MAP_TO_BEV.NUM_BEV_FEATURES)
             dh = dense_head.__all__[m.DENSE_HEAD.NAME](model_cfg=m.DENSE_HEAD, input_channels=b2d.num_bev_features,
                                                        num_class=len(cfg.CLASS_NAMES) if not m.DENSE_HEAD.CLASS_AGNOSTIC else 1,
                                                        class_names=cfg.CLASS_NAMES, grid_size=ds.det_grid_size,
-                                                       point_cloud_range=ds.point_cloud_range, predict_boxes_when_training=False)
+                                                       point_cloud_range=ds.point_cloud_range, predict_boxes_when_training=heads == "full")
             self.det_modules.add_module("backbone_2d", b2d)
             self.det_modules.add_module("dense_head", dh)
             self.det_module_list += [b2d, dh]
+            if heads == "full":   # the ROI head behind the proposals (btcnet.py:116-121; conv_head.py) -- training targets: roi_targets.py
+                from . import conv_head
+                rh = conv_head.__all__[m.ROI_HEAD.NAME](input_channels=dbb.num_point_features, model_cfg=m.ROI_HEAD,
+                                                        num_class=len(cfg.CLASS_NAMES) if not m.ROI_HEAD.CLASS_AGNOSTIC else 1,
+                                                        det_voxel_size=ds.det_voxel_size, point_cloud_range=ds.point_cloud_range,
+                                                        num_rawpoint_features=nraw)
+                self.det_modules.add_module("roi_head", rh)
+                self.det_module_list.append(rh)
         self.percentage = d.OCC.get("USEOCC_PERCENTAGE", 1.0)
 
     # ------------------------------------------------------------------------------------------------------------------
@@ -132,7 +140,7 @@ class BtcHotPath(nn.Module):
         bb = self.occ_modules.backbone_3d
         if n_done == 2 and hasattr(bb, "prefetch_geometry"):
             bd = bb.prefetch_geometry(bd, self.occ_modules.occ_dense_head)
-        if self.heads == "rpn" and bd["is_train"]:
+        if self.heads in ("rpn", "full") and bd["is_train"]:
             # anchor targets are a function of the boxes alone (dense_head.AxisAlignedTargetAssigner: nonzero / argmax with host
             # read-backs, as in the reference): part of the weight-independent front, off the training thread's stream
             dh = self.det_modules.dense_head
@@ -262,9 +270,12 @@ class BtcHotPath(nn.Module):
         """the detection branch's training loss (btcnet.py:108-129): with heads="rpn" the anchor head's RPN loss + the L2
         stand-in for the ROI head's consumer tensor; without heads the two stand-ins of trainer.stand_in_det_loss"""
         from .trainer import MeanSquare, stand_in_det_loss
-        if self.heads != "rpn":
+        if self.heads not in ("rpn", "full"):
             return stand_in_det_loss(ret, batch_dict)
         loss_rpn, tb = self.det_modules.dense_head.get_loss()
+        if self.heads == "full":    # get_training_loss: loss_rpn + loss_rcnn (btcnet.py:108-121)
+            loss_rcnn, tb = self.det_modules.roi_head.get_loss(tb)
+            return loss_rpn + loss_rcnn
         return loss_rpn + MeanSquare.apply(ret["x_combine"], 1e-3)
 
     def forward(self, batch_dict):

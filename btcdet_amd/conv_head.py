@@ -254,16 +254,43 @@ class ConvHead(nn.Module):
         boxes = torch.cat([xyz + rois[:, :, 0:3].reshape(-1, 3), boxes[:, 3:]], dim=-1)
         return cls_preds.view(batch_size, -1, cls_preds.shape[-1]), boxes.view(batch_size, -1, code)
 
+    def assign_targets(self, batch_dict, sampled_inds=None):
+        """RoIHeadTemplate.assign_targets (roi_head_template.py:102-134): ROI_PER_IMAGE sampled rois per scene with their matched boxes
+        in the roi's frame (btcdet_amd/roi_targets.py: resident, no read-back)"""
+        from .roi_targets import ProposalTargetLayer, canonical_targets
+        if getattr(self, "proposal_target_layer", None) is None:
+            self.proposal_target_layer = ProposalTargetLayer(self.model_cfg.TARGET_CONFIG)
+        return canonical_targets(self.proposal_target_layer(batch_dict, sampled_inds))
+
+    def get_loss(self, tb_dict=None):
+        """RoIHeadTemplate.get_loss (roi_head_template.py:222-232): rcnn_loss = cls + reg (+ corner); the logged scalars are copied to
+        pinned memory asynchronously (LazyScalar, as OccHead3D's) instead of five `.item()` stalls"""
+        from .occ_head import _lazy_scalars
+        from .roi_targets import rcnn_cls_loss, rcnn_reg_loss
+        tb_dict = {} if tb_dict is None else tb_dict
+        ret, cfg = self.forward_ret_dict, self.model_cfg.LOSS_CONFIG
+        loss_cls = rcnn_cls_loss(ret["rcnn_cls"], ret["rcnn_cls_labels"], cfg)
+        loss_reg, corner = rcnn_reg_loss(ret, self.box_coder, cfg)
+        loss = loss_cls + loss_reg
+        names = ["rcnn_loss_cls", "rcnn_loss_reg", "rcnn_loss"] + (["rcnn_loss_corner"] if corner is not None else [])
+        vals = [loss_cls, loss_reg, loss] + ([corner] if corner is not None else [])
+        tb_dict.update(zip(names, _lazy_scalars(torch.stack([v.detach().float() for v in vals]), len(vals))))
+        return loss, tb_dict
+
     def forward(self, batch_dict):
-        if "rois" not in batch_dict:
+        targets = None
+        if "batch_box_preds" in batch_dict:     # behind a dense head: its proposals (a caller may hand `rois` over instead)
             proposal_layer(batch_dict, self.model_cfg.NMS_CONFIG["TRAIN" if self.training else "TEST"])
+        if self.training and "gt_boxes" in batch_dict:
+            targets = self.assign_targets(batch_dict)
+            batch_dict["rois"], batch_dict["roi_labels"] = targets["rois"], targets["roi_labels"]
         pooled, _ = self.roi_conv_pool(batch_dict)
         batch_dict["pooled_features"] = pooled
         shared = self.shared_fc_layer(pooled) if getattr(self, "shared_fc_layer", None) is not None else pooled
         rcnn_cls = self.cls_layers(shared).transpose(1, 2).contiguous().squeeze(dim=1)
         rcnn_reg = self.reg_layers(shared).transpose(1, 2).contiguous().squeeze(dim=1)
         if self.training:
-            self.forward_ret_dict = {"rois": batch_dict["rois"], "rcnn_cls": rcnn_cls, "rcnn_reg": rcnn_reg}
+            self.forward_ret_dict = dict(targets or {"rois": batch_dict["rois"]}, rcnn_cls=rcnn_cls, rcnn_reg=rcnn_reg)
         else:
             batch_dict["batch_cls_preds"], batch_dict["batch_box_preds"] = self.generate_predicted_boxes(batch_dict["batch_size"], batch_dict["rois"],
                                                                                                          rcnn_cls, rcnn_reg)

@@ -309,7 +309,9 @@ class StackSAModuleMSG(nn.Module):
         for grouper, mlp in zip(self.groupers, self.mlps):
             res = grouper(xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, features, rotateMatrix=rotateMatrix, xyscales=xyscales, zscales=zscales)
             grouped = res[0]                                              # (rows, C, nsample)
-            image = grouped.permute(1, 0, 2).unsqueeze(0)                 # (1, C, rows, nsample)
+            # packed: MIOpen has no tuned solver for a strided view and falls back to its naive kernels (22 / 17 / 10 ms per weight-
+            # gradient / data-gradient / forward call of these 1 x 1 convolutions at the ROI head's 6912 x 64 samples)
+            image = grouped.permute(1, 0, 2).unsqueeze(0).contiguous()    # (1, C, rows, nsample)
             if vis:
                 seen.append(torch.split(image[0].permute(1, 2, 0)[..., :3], first_scene)[0])
                 if rotateMatrix is not None:

@@ -803,7 +803,10 @@ class ToDenseFunction(torch.autograd.Function):
         return dfeat, None, None, None
 
 
-PAD_CHANNELS = int(os.environ.get("BTC_PAD_CHANNELS", "16"))   # 34 -> 48; 64 measured the same speed (and would move the bf16 run onto bf16 weights)
+# fp32 features: 34 -> 64 channels (one 64-channel item per offset instead of three 16-channel ones: 83 -> 60 us forward, 68 -> 55 us dgrad
+# at 29 K rows, and the dgrad becomes a 32 -> 64 layer the split-operand kernel takes); bf16 features: 34 -> 48, which keeps that layer on
+# fp32 weights (48 is not a multiple of 32: no bf16 weight copy), i.e. bit-equal to the oracle's chain on the widened activations
+PAD_CHANNELS = int(os.environ.get("BTC_PAD_CHANNELS", "0"))   # 0 = by dtype as above
 
 
 def pads_in_channels(cin):
@@ -821,7 +824,7 @@ def _pad_in_channels(features, weight):
     if features.is_cuda and pads_in_channels(cin):
         # to the next multiple of PAD_CHANNELS: with 48 channels the LDS-DMA kernel walks 16-channel items (3 per offset, 81 per
         # workgroup for a 3 x 3 x 3 kernel), with 64 one 64-channel item per offset
-        pad = (-cin) % PAD_CHANNELS
+        pad = (-cin) % (PAD_CHANNELS or (32 if features.dtype == torch.float32 else 16))
         return torch.nn.functional.pad(features, (0, pad)), torch.nn.functional.pad(weight, (0, 0, 0, pad))
     return features, weight
 

@@ -273,6 +273,7 @@ def make_step(model, ddp, proc, opts, grad_sync=None, prefetch_stream=None, thre
     step.timing = timing
     step.end_stream = det_stream if pipeline else None   # where a step's last kernel runs (per-step timing marks)
     step.pipelined = pipeline
+    step.pools = [p_ for p_ in (locals().get("pool"), prep_pool) if p_ is not None]
     return step
 
 
@@ -354,3 +355,10 @@ class HotPathTrainer(object):
     def step(self, batch, next_batch=None):
         """one optimizer step on `batch`; next_batch (optional) lets the schedule prepare / start it ahead"""
         return self._step(batch, next_batch)
+
+    def finish(self):
+        """end of training: drain the streams and stop the schedule's host threads (the trainer is not usable afterwards)"""
+        if self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)
+        for pool in getattr(self._step, "pools", ()):
+            pool.shutdown(wait=True)

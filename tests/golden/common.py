@@ -206,3 +206,34 @@ def convhead_inputs(n_rois=24):
     xc_feat = (_hash01(xc_idx.shape[0] * 128, 7) - np.float32(0.3)).clip(0).reshape(-1, 128).astype(np.float32)
     return {"points": np.concatenate(pts).astype(np.float32), "occ_pnts": np.concatenate(occ), "added_occ_b_ind": np.concatenate(occ_b),
             "xc_indices": xc_idx, "xc_features": xc_feat, "xc_shape": [5, 200, 176], "rois": np.stack(rois), "batch_size": 2}
+
+
+def roi_target_inputs(n_rois=512):
+    """inputs of the ROI-head target golden (gen_roi_targets_golden.py / tests/test_hip_roi_targets.py): per scene the synthetic scene's
+    boxes (B, G + 1, 8) zero-padded with class 1 in the last column, and `n_rois` proposals: a third jittered lightly around the boxes
+    (foreground), a third jittered more (hard background), the rest anywhere in the range (easy background); scene 2 has NO boxes
+    (the reference's empty-ground-truth path); scores hash-valued, labels 1"""
+    synth = _synth()
+    boxes = [synth.make_scene(61)["gt_boxes"].astype(np.float32), synth.make_scene(62)["gt_boxes"].astype(np.float32),
+             np.zeros((0, 8), np.float32)]
+    g = max(len(b) for b in boxes)
+    B = len(boxes)
+    gt = np.zeros((B, g + 1, 8), np.float32)
+    rois = np.zeros((B, n_rois, 7), np.float32)
+    for i, bx in enumerate(boxes):
+        gt[i, :len(bx)] = bx
+        u = _hash01(n_rois * 7, 300 + i).reshape(n_rois, 7)
+        base = bx[:, :7] if len(bx) else np.array([[20, 0, -1, 3.9, 1.6, 1.56, 0.3]], np.float32)
+        r = base[np.arange(n_rois) % base.shape[0]].copy()
+        k = np.arange(n_rois)
+        scale = np.where(k % 3 == 0, 0.15, np.where(k % 3 == 1, 1.0, 0.0)).astype(np.float32)[:, None]
+        r[:, 0:3] += (u[:, 0:3] - np.float32(0.5)) * np.array([2.0, 2.0, 0.5], np.float32) * scale
+        r[:, 3:6] *= (np.float32(1.0) + (u[:, 3:6] - np.float32(0.5)) * np.float32(0.3) * scale)
+        r[:, 6] += (u[:, 6] - np.float32(0.5)) * np.float32(0.8) * scale[:, 0]
+        far = k % 3 == 2
+        r[far, 0] = np.float32(5.0) + u[far, 0] * np.float32(60.0)
+        r[far, 1] = (u[far, 1] - np.float32(0.5)) * np.float32(70.0)
+        r[far, 6] = (u[far, 6] - np.float32(0.5)) * np.float32(6.0)
+        rois[i] = r
+    scores = _hash01(B * n_rois, 310).reshape(B, n_rois).astype(np.float32)
+    return {"batch_size": B, "rois": rois, "roi_scores": scores, "roi_labels": np.ones((B, n_rois), np.int64), "gt_boxes": gt}
