@@ -368,13 +368,16 @@ def main():
                                     "what": "BaseBEVBackbone + AnchorHeadSingle (RPN cls / loc / dir loss, targets assigned in the prepared front) "
                                             "behind HeightCompression; x_combine keeps its L2 stand-in"}
         # ... and with the ROI head behind the proposals too: get_training_loss = loss_rpn + loss_rcnn + occupancy loss (btcnet.py:58-129)
+        tr_r.finish()    # (its host threads and their queued work are gone before the next model runs)
         del tr_r, model_r
+        torch.cuda.empty_cache()
         model_f = build_model("full")
         with _StdoutToStderr():
             tr_f = HotPathTrainer(model_f, schedule=schedule, distributed=with_reducer, det_loss=model_f.det_loss)
         k_f = min(args.steps, 10)
         dt_f, ms_f, _ = timed_run(tr_f._step, k_f, 12, tr_f._step.end_stream)
         dt_f = max_over_ranks(dt_f, dist, device)
+        tr_f.finish()
         extras["with_all_heads"] = {"scenes_per_s": round(bs * world * k_f / dt_f, 2), "ms_per_step": round(1e3 * dt_f / k_f, 3), "steps": k_f,
                                     "what": "the reference's whole training loss: RPN (BaseBEVBackbone + AnchorHeadSingle) -> proposals (rotated NMS, 9000 -> 512) "
                                             "-> ROI targets (128 sampled rois per scene) -> ConvHead (roi_conv_pool over raw points, occupancy points and "
@@ -443,7 +446,8 @@ def main():
                     bound = "latency"
                 else:
                     bound = "hbm" if f_hbm >= f_mfma else "mfma"
-                result["roofline"] = {"kernel": "conv_apply (fused sparse conv fwd + dgrad, output-stationary MFMA %s)" % ("bf16 x bf16 -> f32" if bf else "f32"),
+                result["roofline"] = {"kernel": "conv_apply (fused sparse conv fwd + dgrad, output-stationary MFMA: %s)" % (
+                                          "bf16 x bf16 -> f32" if bf else "exact f32 chain, or f32 operands split over the bf16 pipe on the wide layers"),
                                       "bound": bound, "nearer_roof": "hbm" if f_hbm >= f_mfma else "mfma",
                                       "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(f_hbm, 5),
                                       "traffic": traffic, "launches_per_step": k["launches"] / prof_steps,
