@@ -274,13 +274,14 @@ __global__ __launch_bounds__(256) void weights_split3(const float* __restrict__ 
 }  // namespace
 
 extern "C" int btc_conv_split_supported(int K, int Cred, int Cres) {
-  return K >= 1 && K <= 64 && Cred >= 32 && Cred % 32 == 0 && Cres >= 64 && Cres % 64 == 0;
+  return K >= 1 && K <= 64 && Cred >= 32 && Cred % 32 == 0 && Cres >= 32 && Cres % 32 == 0;
 }
 
 // the built-in policy of the host bindings: take this kernel for an fp32 launch of n_rows rows?  (below ~6 K rows the exact kernel's
 // 16-row workgroups fill the GPU better: 64 -> 64 at 3 K rows 31 us against 32-41; wide layers pay off from ~4 K rows)
 extern "C" int btc_conv_split_wanted(int K, int Cred, int Cres, int n_rows) {
-  return btc_tune_get(BTC_TUNE_SPLIT) != 1 && btc_conv_split_supported(K, Cred, Cres) && n_rows >= ((Cred >= 128 || Cres >= 128) ? 4000 : 6000);
+  return btc_tune_get(BTC_TUNE_SPLIT) != 1 && btc_conv_split_supported(K, Cred, Cres) &&
+         n_rows >= ((Cred >= 128 || Cres >= 128) ? 4000 : (Cres % 64 == 0 ? 6000 : 20000));
 }
 
 // Ws: the planes btc_weights_split3 made for this pass (wt_split for forward, w_split for dgrad)
@@ -300,11 +301,16 @@ int btc_apply_split(const float* src, const void* Ws_, const float* bias, const 
   // few rows: the 64-row tiles leave CUs idle (6.4 K rows x 128 columns = 100 workgroups): 256 -> 128 at 6.4 K rows 200 us with the
   // 64 x 128 tile, 148 with 32 x 64 (exact chain 193); 128 -> 256 (two column blocks) 105 with 64 x 128, 127 with 32 x 64 (exact 178)
   int shape = (Cres % 128 == 0) ? ((n_rows >= 10000 || Cres >= 256) ? 424 : 222) : (n_rows >= 10000 ? 422 : 222);
+  // 32 result columns: 128 x 32 / 64 x 32 tiles, the waves split the rows.  32 -> 32 at 26-29 K rows 46 / 40 us (exact chain) -> 29 / 28
+  // (128-row tiles; 64-row tiles 32 / 31), at 210 K rows 165 / 196 (forward / dgrad) -> 147 / 146 with 64-row tiles (128-row tiles 183)
+  if (Cres % 64 != 0) shape = n_rows >= 100000 ? 412 : 812;
+  if ((t_nt == 812 || t_nt == 412) && Cres % 32 == 0) shape = t_nt;
   if ((t_nt == 224 || t_nt == 424) && Cres % 128 == 0) shape = t_nt;   // tuning runs
-  if (t_nt == 222 || t_nt == 422) shape = t_nt;
+  if ((t_nt == 222 || t_nt == 422) && Cres % 64 == 0) shape = t_nt;
   const int t_kc = btc_tune_get(BTC_TUNE_APPLY_KC), t_st = btc_tune_get(BTC_TUNE_APPLY_STAGES);
-  int kc = (Cred % 64 == 0 && (shape % 10 == 4 || n_rows < 22000)) ? 64 : 32;
+  int kc = (Cred % 64 == 0 && (shape % 10 == 4 || n_rows < 22000) && shape % 100 != 12) ? 64 : 32;
   if (t_kc == 32 || (t_kc == 64 && Cred % 64 == 0)) kc = t_kc;
+  if (shape % 100 == 12) kc = 32;   // (the 32-column tiles exist with 32-channel items only)
   int stages = t_st ? t_st : 3;
   if (kc == 64) stages = (t_st == 3 && shape == 422) ? 3 : 2;
 #define S_ARGS src, Ws, bias, nbr, order, n_rows, K, Cred, Cres, dst, flags, stream, bn
@@ -320,6 +326,10 @@ int btc_apply_split(const float* src, const void* Ws_, const float* bias, const 
     case 4223: return launch_s<4, 2, 2, 32, 3>(S_ARGS);
     case 4224: return launch_s<4, 2, 2, 32, 4>(S_ARGS);
     case 4227: return launch_s<4, 2, 2, 64, 2>(S_ARGS);
+    case 4123: return launch_s<4, 1, 2, 32, 3>(S_ARGS);
+    case 4124: return launch_s<4, 1, 2, 32, 4>(S_ARGS);
+    case 8123: return launch_s<8, 1, 2, 32, 3>(S_ARGS);
+    case 8124: return launch_s<8, 1, 2, 32, 4>(S_ARGS);
     case 2223: return launch_s<2, 2, 2, 32, 3>(S_ARGS);
     case 2224: return launch_s<2, 2, 2, 32, 4>(S_ARGS);
     default: break;

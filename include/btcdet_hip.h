@@ -250,7 +250,7 @@ int btc_conv_dgrad_bf16w(const void* dout, const void* w_bf16, const int32_t* nb
  * three bfloat16 pieces (hi + mid + lo) and a * b is taken as the six largest of the nine piece products, fp32 accumulate --
  * 6 bf16 MFMAs instead of 8 fp32 MFMAs per 32 reduction channels at 16x the rate.  Not the bit pattern of the exact fmaf chain
  * (btc_conv_fwd / btc_conv_dgrad stay the parity reference): within 2e-6 of the result's scale of it, deterministic
- * (tests/test_hip_split.py).  For the layers whose matrix phase is the long pole: Cred % 32 == 0, Cres % 64 == 0.
+ * (tests/test_hip_split.py).  For the layers whose matrix phase is the long pole: Cred % 32 == 0, Cres % 32 == 0.
  *   btc_weights_split3 : W fp32 [K][Cin][Cout] -> w_split [3][K][Cin][Cout] bf16 (dgrad operand), wt_split [3][K][Cout][Cin]
  *                        (forward operand); once per optimizer step and layer (3*K*Cin*Cout*2 bytes each)
  * used through btc_conv_apply_ordered / btc_conv_bn_relu_fwd with operands = BTC_OPERANDS_F32_SPLIT and W = the planes of that pass */

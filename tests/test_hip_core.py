@@ -297,7 +297,7 @@ def test_wgrad_pipelined_kernel_both_phase_counts(cin, cout, full_ph):
 
 
 @pytest.mark.parametrize("cin,cout", [(32, 32), (64, 32), (16, 32), (32, 3)])
-def test_wgrad_walks_smaller_side_for_transposed_conv(cin, cout):
+def test_wgrad_walks_smaller_side_for_transposed_conv(cin, cout, exact_conv):
     """transposed conv with n_out > 2 n_in: btc_conv_wgrad walks nbr_in (swap path of conv_wgrad_rows)"""
     from btcdet_amd.spconv import ops
     rng = np.random.default_rng(cin + cout)

@@ -31,16 +31,18 @@ def _err(a, ref):
     return float(np.abs(d).max() / np.abs(ref).max()), float(np.sqrt((d ** 2).mean()) / np.sqrt((ref ** 2).mean()))
 
 
-@pytest.mark.parametrize("cin,cout,kind", [(64, 64, "subm"), (32, 64, "conv"), (64, 128, "subm"), (128, 128, "subm"), (256, 128, "subm"), (128, 64, "conv")])
+@pytest.mark.parametrize("cin,cout,kind", [(64, 64, "subm"), (32, 64, "conv"), (64, 128, "subm"), (128, 128, "subm"), (256, 128, "subm"), (128, 64, "conv"),
+                                           (32, 32, "big"), (64, 32, "big")])
 def test_split_kernel_vs_fp64_and_exact_chain(cin, cout, kind):
     from btcdet_amd import _lib
     from btcdet_amd.spconv import ops
     L = _lib.lib()
     rng = np.random.default_rng(cin * 7 + cout)
     B = 2
-    shape, n_pts = ((12, 48, 44), 9000) if kind == "subm" else ((16, 64, 64), 40000)
+    shape, n_pts = {"subm": ((12, 48, 44), 9000), "conv": ((16, 64, 64), 40000), "big": ((12, 64, 64), 26000)}[kind]   # big: > 20 K rows (32-column tiles)
     idx = rand_indices(rng, n_pts, B, shape)
-    s = (1, 1, 1) if kind == "subm" else (2, 2, 2)
+    s = (2, 2, 2) if kind == "conv" else (1, 1, 1)
+    kind = "subm" if kind == "big" else kind
     (o_idx, o_out, o_in, o_sh), rb = _rb_both(idx, B, shape, (3, 3, 3), s, (1, 1, 1), (1, 1, 1), kind)
     n_out, n_in = o_out.shape[0], o_in.shape[0]
     feat = rng.standard_normal((n_in, cin)).astype(np.float32)
