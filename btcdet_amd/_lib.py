@@ -104,6 +104,7 @@ _SIGS = {
     "btc_conv_bf16w_supported": (ci, [ci, ci, ci]),
     "btc_weights_to_bf16": (ci, [vp, ci, ci, ci, vp, vp, vp]),
     "btc_conv_split_supported": (ci, [ci, ci, ci]),
+    "btc_set_scratch": (ci, [vp, vp, sz]),
     "btc_conv_split_wanted": (ci, [ci, ci, ci, ci]),
     "btc_weights_split3": (ci, [vp, ci, ci, ci, vp, vp, vp]),
     "btc_conv_fwd_bf16w": (ci, [vp, vp, vp, vp, ci, ci, ci, ci, vp, vp]),

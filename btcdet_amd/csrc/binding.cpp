@@ -109,9 +109,24 @@ Tensor weights_q(const Tensor& w, int64_t K, int64_t cin, int64_t cout, int64_t 
 
 Tensor weights_bf16(const Tensor& w, int64_t K, int64_t cin, int64_t cout, int64_t stream) { return weights_q(w, K, cin, cout, stream, 1); }
 
+// the stream's scratch buffer for z-split launches of the split-operand kernel (btc_set_scratch): 48 MB, allocated on first use
+// from the stream's own pool and kept for the life of the process
+void ensure_scratch(const Tensor& like, int64_t stream) {
+  static std::mutex mu;
+  static std::unordered_map<uint64_t, Tensor> tab;
+  const uint64_t key = ((uint64_t)(uint8_t)like.get_device() << 56) ^ (uint64_t)stream;
+  std::lock_guard<std::mutex> lock(mu);
+  if (tab.find(key) != tab.end()) return;
+  Tensor t = at::empty({(int64_t)48 << 20}, like.options().dtype(at::kByte));
+  chk(btc_set_scratch(st(stream), t.data_ptr(), (size_t)t.numel()), "btc_set_scratch");
+  tab.emplace(key, t);
+}
+
 // fp32 launch of n_rows rows on the split-operand kernel (csrc/conv_apply_split.hip)?  The library's policy; BTC_TUNE_SPLIT = 1: never
-bool split_operands(const Tensor& src, int64_t K, int64_t cred, int64_t cres, int64_t n_rows) {
-  return src.scalar_type() == at::kFloat && btc_conv_split_wanted((int)K, (int)cred, (int)cres, (int)n_rows);
+bool split_operands(const Tensor& src, int64_t K, int64_t cred, int64_t cres, int64_t n_rows, int64_t stream) {
+  if (!(src.scalar_type() == at::kFloat && btc_conv_split_wanted((int)K, (int)cred, (int)cres, (int)n_rows))) return false;
+  ensure_scratch(src, stream);
+  return true;
 }
 
 // out = conv(features) ; features (n_src, Cin) fp32 | bf16 contiguous, w [K.., Cin, Cout] fp32, map_fwd (n_res, K) int32
@@ -133,7 +148,7 @@ Tensor conv_fwd(const Tensor& features, const Tensor& w, const OptTensor& bias, 
     chk(btc_conv_apply_ordered(BTC_PASS_FWD, BTC_OPERANDS_BF16, features.data_ptr(), (const char*)q.data_ptr() + 2 * w.numel(), fptr(bias),
                                (const int32_t*)map_fwd.data_ptr(), order, (int)n_res, (int)K, (int)cin, (int)cout, out.data_ptr(), st(stream)),
         "btc_conv_apply_ordered (fwd, bf16 operands)");
-  } else if (split_operands(features, K, cin, cout, n_res)) {
+  } else if (split_operands(features, K, cin, cout, n_res, stream)) {
     Tensor q = weights_q(w, K, cin, cout, stream, 3);
     chk(btc_conv_apply_ordered(BTC_PASS_FWD, BTC_OPERANDS_F32_SPLIT, features.data_ptr(), (const char*)q.data_ptr() + 6 * w.numel(), fptr(bias),
                                (const int32_t*)map_fwd.data_ptr(), order, (int)n_res, (int)K, (int)cin, (int)cout, out.data_ptr(), st(stream)),
@@ -200,7 +215,7 @@ std::tuple<Tensor, Tensor, Tensor> conv_bn_fwd(const Tensor& features, const Ten
     int operands = features.scalar_type() == at::kBFloat16 ? BTC_OPERANDS_BF16_ACT : BTC_OPERANDS_F32;
     const void* wp = w.data_ptr();
     Tensor q;
-    if (split_operands(features, K, cin, cout, n_res)) {
+    if (split_operands(features, K, cin, cout, n_res, stream)) {
       q = weights_q(w, K, cin, cout, stream, 3);
       operands = BTC_OPERANDS_F32_SPLIT;
       wp = (const char*)q.data_ptr() + 6 * w.numel();
@@ -321,15 +336,21 @@ std::tuple<OptTensor, OptTensor> conv_bwd(const Tensor& features, const Tensor& 
   // it leaves an exposed tail at the join (7.4 ms per step dgrad-first, 6.1 wgrad-first).  BTC_WGRAD_FIRST=0/1 overrides.
   static const int order_env = getenv("BTC_WGRAD_FIRST") ? atoi(getenv("BTC_WGRAD_FIRST")) : -1;
   const bool wgrad_first = order_env >= 0 ? order_env != 0 : bf;
+  // The operand copy of a NON-leaf weight (the zero-padded 34 -> 64-channel one) is a temporary of this call.  It must outlive the
+  // allocations of run_wgrad: this layer's weight gradient runs on the side stream BESIDE the dgrad (its fork was recorded before
+  // either launch), so a dW / workspace block carved out of the just-released planes would be written while the dgrad still
+  // reads them -- non-finite dX now and then, found by the two-ranks-on-one-GPU test.  Released when the function returns: what is
+  // allocated after that is used behind this dgrad on its own stream, or behind a later fork on the side stream.
+  Tensor q_hold;
   auto run_dgrad = [&]() {
   if (need_din) {
     Tensor d = at::empty({n_src, cin}, features.options());
     if (bf16_operands(grad_out, K, cout, cin)) {
-      Tensor q = weights_bf16(w, K, cin, cout, stream);
+      Tensor q = q_hold = weights_bf16(w, K, cin, cout, stream);
       chk(btc_conv_apply_ordered(pass_dgrad, BTC_OPERANDS_BF16, grad_out.data_ptr(), q.data_ptr(), nullptr, (const int32_t*)map_bwd.data_ptr(),
                                  order, (int)n_src, (int)K, (int)cin, (int)cout, d.data_ptr(), st(stream)), "btc_conv_apply_ordered (dgrad, bf16 operands)");
-    } else if (split_operands(grad_out, K, cout, cin, n_src)) {
-      Tensor q = weights_q(w, K, cin, cout, stream, 3);
+    } else if (split_operands(grad_out, K, cout, cin, n_src, stream)) {
+      Tensor q = q_hold = weights_q(w, K, cin, cout, stream, 3);
       chk(btc_conv_apply_ordered(pass_dgrad, BTC_OPERANDS_F32_SPLIT, grad_out.data_ptr(), q.data_ptr(), nullptr, (const int32_t*)map_bwd.data_ptr(),
                                  order, (int)n_src, (int)K, (int)cin, (int)cout, d.data_ptr(), st(stream)), "btc_conv_apply_ordered (dgrad, split operands)");
     } else

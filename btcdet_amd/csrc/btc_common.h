@@ -59,6 +59,7 @@ int btc_conv_fwd_stats(int operands, const void* src, const float* W, const floa
 // conv_apply_bf16.hip: bf16 operands on the bf16 matrix pipe; Wq[k][Cres][Cred] bf16
 int btc_apply_bf16w(const void* src, const void* Wq, const float* bias, const int32_t* nbr, const int32_t* order, int n_rows, int K, int Cred,
                     int Cres, void* dst, hipStream_t stream, int mirror = 0);
+void* btc_scratch(hipStream_t stream, size_t* bytes);   // the stream's registered scratch buffer (btc_set_scratch) or NULL
 struct BnFuse;
 int btc_apply_split(const float* src, const void* Ws, const float* bias, const int32_t* nbr, const int32_t* order, int n_rows, int K, int Cred,
                     int Cres, float* dst, hipStream_t stream, int mirror, const BnFuse* bn);

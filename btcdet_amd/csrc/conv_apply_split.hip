@@ -113,7 +113,12 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_apply_s(const float* __rest
   __syncthreads();
   const int n_act = *s_nact;
   const int n_chunks = Cred / KC;
-  const int n_items = n_act * n_chunks;
+  // gridDim.z > 1: the workgroups z = 0 .. Z-1 of a tile share its (offset, chunk) items -- contiguous ranges, in order -- and each
+  // writes its partial sums to slab z of `out` (n_rows x Cres floats each; split_reduce adds them up in z order).  For levels
+  // of a few thousand rows: one workgroup per tile walks 54-108 items one after the other while most CUs have nothing to do.
+  const int n_all = n_act * n_chunks;
+  const int i0 = (int)((long long)blockIdx.z * n_all / gridDim.z), n_items = (int)((long long)(blockIdx.z + 1) * n_all / gridDim.z);
+  out += (size_t)blockIdx.z * n_rows * Cres;
 
   // three accumulators per tile, one per magnitude class of the piece products (1, 2^-8, 2^-16 of |a b|): the matrix pipe aligns
   // the 32 products of an instruction to the accumulator it adds them to, so small products added to a large running sum lose
@@ -154,9 +159,9 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_apply_s(const float* __rest
   static_assert((S_STAGES - 2) * NPI <= 63, "vmcnt is a 6-bit counter");
 #pragma unroll
   for (int i = 0; i < S_STAGES - 1; ++i)
-    if (i < n_items) issue(i, i);
+    if (i0 + i < n_items) issue(i0 + i, i);
   int st = 0;
-  for (int item = 0; item < n_items; ++item) {
+  for (int item = i0; item < n_items; ++item) {
     // this item has landed; the min(S_STAGES - 2, items left) issued behind it stay in flight
     const int left = n_items - 1 - item;
     if (S_STAGES >= 4 && left >= 2) wait_vm_s<(S_STAGES >= 4 ? 2 : 0) * NPI>();
@@ -235,7 +240,7 @@ size_t lds_bytes_s(int tm, int tn, int kc, int K, int stages) {
 
 template <int WR, int WC, int NTW, int KC, int S_STAGES>
 int launch_s(const float* feat, const unsigned short* Ws, const float* bias, const int32_t* nbr, const int32_t* order, int n_rows, int K, int Cred,
-             int Cres, float* out, int flags, hipStream_t stream, const BnFuse& bn) {
+             int Cres, float* out, int flags, hipStream_t stream, const BnFuse& bn, int zsplit) {
   constexpr int TM = 16 * WR, TN = 16 * NTW * WC;
   const size_t lds = lds_bytes_s(TM, TN, KC, K, S_STAGES);
   BTC_CHECK_ARG(lds <= 160 * 1024, "conv_apply_s: tile does not fit the LDS");
@@ -243,10 +248,45 @@ int launch_s(const float* feat, const unsigned short* Ws, const float* bias, con
   std::call_once(once, [] {
     (void)hipFuncSetAttribute((const void*)conv_apply_s<WR, WC, NTW, KC, S_STAGES>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   });
-  dim3 grid(btc_cdiv(n_rows, TM), Cres / TN);
+  dim3 grid(btc_cdiv(n_rows, TM), Cres / TN, zsplit);
   conv_apply_s<WR, WC, NTW, KC, S_STAGES><<<grid, 64 * WR * WC, lds, stream>>>(feat, Ws, bias, nbr, order, n_rows, K, Cred, Cres, out, flags, bn);
   BTC_LAUNCH_CHECK();
   return BTC_OK;
+}
+
+// out[r][c] = bias[c] + slab_0[r][c] + slab_1[r][c] + ... (in that order: deterministic) of a z-split launch, with the BatchNorm
+// statistics epilogue of the conv kernels; a wave owns 16 rows x 32 columns in the MFMA C/D layout bn_fuse_wave expects
+__global__ __launch_bounds__(256) void split_reduce(const float* __restrict__ slabs, int Z, const float* __restrict__ bias, int n_rows, int Cres,
+                                                    float* __restrict__ out, const BnFuse bn) {
+  __shared__ int s_flag;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row0 = (blockIdx.x * 4 + wave) * 16, c0 = blockIdx.y * 32;
+  const size_t slab = (size_t)n_rows * Cres;
+  float vals[2][4];
+  bool valid[4];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    const int col = c0 + nt * 16 + (lane & 15);
+    const float b = bias ? bias[col] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = row0 + (lane >> 4) * 4 + r;
+      valid[r] = row < n_rows;
+      float v = 0.f;
+      if (row < n_rows) {
+        const float* p = slabs + (size_t)row * Cres + col;
+        v = p[0];
+        for (int z = 1; z < Z; ++z) v += p[z * slab];
+        if (bias) v += b;
+        out[(size_t)row * Cres + col] = v;
+      }
+      vals[nt][r] = v;
+    }
+  }
+  if (bn.slots) {
+    bn_fuse_wave<2>(bn, vals, valid, c0, (int)((blockIdx.x * 4 + wave) & (BN_FUSE_SLOTS - 1)));
+    bn_fuse_finish(bn, &s_flag);
+  }
 }
 
 __global__ __launch_bounds__(256) void weights_split3(const float* __restrict__ W, int K, int Cin, int Cout, unsigned short* __restrict__ w_s,
@@ -277,17 +317,19 @@ extern "C" int btc_conv_split_supported(int K, int Cred, int Cres) {
   return K >= 1 && K <= 64 && Cred >= 32 && Cred % 32 == 0 && Cres >= 32 && Cres % 32 == 0;
 }
 
-// the built-in policy of the host bindings: take this kernel for an fp32 launch of n_rows rows?  (below ~6 K rows the exact kernel's
-// 16-row workgroups fill the GPU better: 64 -> 64 at 3 K rows 31 us against 32-41; wide layers pay off from ~4 K rows)
+// the built-in policy of the host bindings (which register a scratch buffer per stream, so small levels run z-split): take this
+// kernel for an fp32 launch of n_rows rows?
 extern "C" int btc_conv_split_wanted(int K, int Cred, int Cres, int n_rows) {
   return btc_tune_get(BTC_TUNE_SPLIT) != 1 && btc_conv_split_supported(K, Cred, Cres) &&
-         n_rows >= ((Cred >= 128 || Cres >= 128) ? 4000 : (Cres % 64 == 0 ? 6000 : 20000));
+         n_rows >= ((Cred >= 128 || Cres >= 128) ? 2500 : (Cres % 64 == 0 ? (Cred >= 64 ? 2500 : 6000) : 20000));
 }
 
 // Ws: the planes btc_weights_split3 made for this pass (wt_split for forward, w_split for dgrad)
-int btc_apply_split(const float* src, const void* Ws_, const float* bias, const int32_t* nbr, const int32_t* order, int n_rows, int K, int Cred,
-                    int Cres, float* dst, hipStream_t stream, int mirror, const BnFuse* bn_) {
+int btc_apply_split(const float* src, const void* Ws_, const float* bias_, const int32_t* nbr, const int32_t* order, int n_rows, int K, int Cred,
+                    int Cres, float* dst_, hipStream_t stream, int mirror, const BnFuse* bn_) {
   if (n_rows <= 0) return BTC_OK;
+  const float* bias = bias_;
+  float* dst = dst_;
   BTC_CHECK_ARG(btc_conv_split_supported(K, Cred, Cres), "conv_apply_s: needs K <= 64, Cred %% 32 == 0, Cres %% 64 == 0 (K=%d, %d -> %d)", K, Cred, Cres);
   const BnFuse bn = bn_ ? *bn_ : btc_bn_fuse_none();
   const unsigned short* Ws = (const unsigned short*)Ws_;
@@ -298,9 +340,16 @@ int btc_apply_split(const float* src, const void* Ws_, const float* bias, const 
   // 57 -> 37.5 (64-channel items; 32-channel items 46.7), at 30 K rows 110 -> 68 (32-channel items, three stages; 64-channel items 75),
   // 32 -> 64 at 30 K rows 65 -> 36.  A launch is bound by the issue of its LDS-DMA pieces (the three weight planes are 6 bytes a
   // weight), so the fewer, larger items win until the second workgroup per CU is lost.
-  // few rows: the 64-row tiles leave CUs idle (6.4 K rows x 128 columns = 100 workgroups): 256 -> 128 at 6.4 K rows 200 us with the
-  // 64 x 128 tile, 148 with 32 x 64 (exact chain 193); 128 -> 256 (two column blocks) 105 with 64 x 128, 127 with 32 x 64 (exact 178)
-  int shape = (Cres % 128 == 0) ? ((n_rows >= 10000 || Cres >= 256) ? 424 : 222) : (n_rows >= 10000 ? 422 : 222);
+  // few rows (under 10 K): with the stream's scratch buffer the 64-row tiles stay and up to four workgroups share a tile's items
+  // (z-split, below): 256 -> 128 at 6.4 K rows 192 us (exact chain) -> 146 (32 x 64 tiles, unsplit) -> 99 (64 x 128 tiles, Z = 4);
+  // 128 -> 128 96 -> 72 -> 59; 64 -> 64 at 6.4 K rows 37 -> 34 -> 26 (64 x 64, Z = 2), at 3 K rows 31 -> 34 -> 21 (Z = 4).
+  // Without scratch: 32 x 64 tiles, so that there are workgroups enough.
+  size_t scratch_bytes = 0;
+  float* scratch = (float*)btc_scratch(stream, &scratch_bytes);
+  const int t_z = btc_tune_get(BTC_TUNE_SPLIT_Z);
+  const bool few = n_rows < 10000;
+  const bool can_z = few && t_z != 1 && scratch_bytes >= (size_t)2 * n_rows * Cres * sizeof(float);
+  int shape = (Cres % 128 == 0) ? ((!few || can_z || Cres >= 256) ? 424 : 222) : ((!few || can_z) ? 422 : 222);
   // 32 result columns: 128 x 32 / 64 x 32 tiles, the waves split the rows.  32 -> 32 at 26-29 K rows 46 / 40 us (exact chain) -> 29 / 28
   // (128-row tiles; 64-row tiles 32 / 31), at 210 K rows 165 / 196 (forward / dgrad) -> 147 / 146 with 64-row tiles (128-row tiles 183)
   if (Cres % 64 != 0) shape = n_rows >= 100000 ? 412 : 812;
@@ -313,30 +362,47 @@ int btc_apply_split(const float* src, const void* Ws_, const float* bias, const 
   if (shape % 100 == 12) kc = 32;   // (the 32-column tiles exist with 32-channel items only)
   int stages = t_st ? t_st : 3;
   if (kc == 64) stages = (t_st == 3 && shape == 422) ? 3 : 2;
-#define S_ARGS src, Ws, bias, nbr, order, n_rows, K, Cred, Cres, dst, flags, stream, bn
-  switch (shape * 10 + stages + (kc == 64 ? 5 : 0)) {   // ...7 / ...8: KC = 64 with 2 / 3 stages
-    case 4243: return launch_s<4, 2, 4, 32, 3>(S_ARGS);
-    case 4244: return launch_s<4, 2, 4, 32, 4>(S_ARGS);
-    case 4247: return launch_s<4, 2, 4, 64, 2>(S_ARGS);
-    case 2243: return launch_s<2, 2, 4, 32, 3>(S_ARGS);
-    case 2247: return launch_s<2, 2, 4, 64, 2>(S_ARGS);
-    case 2227: return launch_s<2, 2, 2, 64, 2>(S_ARGS);
-    case 4228: return launch_s<4, 2, 2, 64, 3>(S_ARGS);
-    case 2244: return launch_s<2, 2, 4, 32, 4>(S_ARGS);
-    case 4223: return launch_s<4, 2, 2, 32, 3>(S_ARGS);
-    case 4224: return launch_s<4, 2, 2, 32, 4>(S_ARGS);
-    case 4227: return launch_s<4, 2, 2, 64, 2>(S_ARGS);
-    case 4123: return launch_s<4, 1, 2, 32, 3>(S_ARGS);
-    case 4124: return launch_s<4, 1, 2, 32, 4>(S_ARGS);
-    case 8123: return launch_s<8, 1, 2, 32, 3>(S_ARGS);
-    case 8124: return launch_s<8, 1, 2, 32, 4>(S_ARGS);
-    case 2223: return launch_s<2, 2, 2, 32, 3>(S_ARGS);
-    case 2224: return launch_s<2, 2, 2, 32, 4>(S_ARGS);
-    default: break;
+  // z-split (conv_apply_s header): few rows -> few tiles -> most CUs idle while each workgroup walks its tile's 27-108 items alone.
+  // The partial slabs live in the stream's scratch buffer (btc_set_scratch); without one, or when it is too small, no split.
+  const int items = K * (Cred / kc);
+  int Z = 1;
+  if (can_z && shape % 100 != 12 && items >= 12) {
+    Z = t_z > 1 ? t_z : ((Cres % 128 == 0 || n_rows < 4000) ? 4 : 2);
+    if (Z > items / 6) Z = items / 6;
+    while (Z > 1 && (size_t)Z * n_rows * Cres * sizeof(float) > scratch_bytes) --Z;
+    if (Z > 1) dst = scratch;
   }
-  btc_set_error("conv_apply_s: no instance for shape %d, %d stages, kc %d", shape, stages, kc);
-  return BTC_EINVAL;
+  const BnFuse bn_kernel = Z > 1 ? btc_bn_fuse_none() : bn;
+  if (Z > 1) bias = nullptr;
+#define S_ARGS src, Ws, bias, nbr, order, n_rows, K, Cred, Cres, dst, flags, stream, bn_kernel, Z
+  int rc = BTC_EINVAL;
+  switch (shape * 10 + stages + (kc == 64 ? 5 : 0)) {   // ...7 / ...8: KC = 64 with 2 / 3 stages
+    case 4243: rc = launch_s<4, 2, 4, 32, 3>(S_ARGS); break;
+    case 4244: rc = launch_s<4, 2, 4, 32, 4>(S_ARGS); break;
+    case 4247: rc = launch_s<4, 2, 4, 64, 2>(S_ARGS); break;
+    case 2243: rc = launch_s<2, 2, 4, 32, 3>(S_ARGS); break;
+    case 2247: rc = launch_s<2, 2, 4, 64, 2>(S_ARGS); break;
+    case 2227: rc = launch_s<2, 2, 2, 64, 2>(S_ARGS); break;
+    case 4228: rc = launch_s<4, 2, 2, 64, 3>(S_ARGS); break;
+    case 2244: rc = launch_s<2, 2, 4, 32, 4>(S_ARGS); break;
+    case 4223: rc = launch_s<4, 2, 2, 32, 3>(S_ARGS); break;
+    case 4224: rc = launch_s<4, 2, 2, 32, 4>(S_ARGS); break;
+    case 4227: rc = launch_s<4, 2, 2, 64, 2>(S_ARGS); break;
+    case 4123: rc = launch_s<4, 1, 2, 32, 3>(S_ARGS); break;
+    case 4124: rc = launch_s<4, 1, 2, 32, 4>(S_ARGS); break;
+    case 8123: rc = launch_s<8, 1, 2, 32, 3>(S_ARGS); break;
+    case 8124: rc = launch_s<8, 1, 2, 32, 4>(S_ARGS); break;
+    case 2223: rc = launch_s<2, 2, 2, 32, 3>(S_ARGS); break;
+    case 2224: rc = launch_s<2, 2, 2, 32, 4>(S_ARGS); break;
+    default:
+      btc_set_error("conv_apply_s: no instance for shape %d, %d stages, kc %d", shape, stages, kc);
+      return BTC_EINVAL;
+  }
 #undef S_ARGS
+  if (rc != BTC_OK || Z == 1) return rc;
+  split_reduce<<<dim3(btc_cdiv(n_rows, 64), Cres / 32), 256, 0, stream>>>(dst, Z, bias_, n_rows, Cres, dst_, bn);
+  BTC_LAUNCH_CHECK();
+  return BTC_OK;
 }
 
 extern "C" int btc_weights_split3(const float* W, int K, int Cin, int Cout, void* w_split, void* wt_split, void* stream) {

@@ -32,6 +32,27 @@ extern "C" int btc_tune_set(int key, int value) {
   return BTC_OK;
 }
 
+// per-stream scratch buffers (btc_set_scratch): caller-allocated device memory the library may use for the lifetime of a launch on
+// that stream -- today the partial slabs of z-split sparse-conv launches (conv_apply_split.hip).  Launches on one stream are
+// serialised, so one buffer per stream is enough; the caller keeps it alive until it registers another (or NULL) for the stream.
+#include <mutex>
+#include <unordered_map>
+static std::mutex g_scratch_mu;
+static std::unordered_map<void*, std::pair<void*, size_t>> g_scratch;
+extern "C" int btc_set_scratch(void* stream, void* ptr, size_t bytes) {
+  std::lock_guard<std::mutex> lock(g_scratch_mu);
+  if (!ptr || !bytes) g_scratch.erase(stream);
+  else g_scratch[stream] = std::make_pair(ptr, bytes);
+  return BTC_OK;
+}
+void* btc_scratch(hipStream_t stream, size_t* bytes) {
+  std::lock_guard<std::mutex> lock(g_scratch_mu);
+  auto it = g_scratch.find((void*)stream);
+  if (it == g_scratch.end()) { *bytes = 0; return nullptr; }
+  *bytes = it->second.second;
+  return it->second.first;
+}
+
 namespace {
 
 constexpr int SCAN_THREADS = 256;

@@ -560,12 +560,19 @@ def _weights_bf16(w, K, cin, cout):
 
 
 _WS3 = {}
+_SCRATCH = {}
 
 
 def _split_operands(src, K, cred, cres, n_rows):
     """fp32 launch on the split-operand kernel (csrc/conv_apply_split.hip: three bf16 pieces per operand, six bf16 MFMAs per
     product block)?  The library's policy (btc_conv_split_wanted; never under BTC_TUNE_SPLIT = 1) -- same as binding.cpp"""
-    return src.dtype == torch.float32 and lib().btc_conv_split_wanted(int(K), int(cred), int(cres), int(n_rows)) == 1
+    if not (src.dtype == torch.float32 and lib().btc_conv_split_wanted(int(K), int(cred), int(cres), int(n_rows)) == 1):
+        return False
+    key = (src.device.index, stream_ptr())
+    if key not in _SCRATCH:    # the stream's scratch buffer for z-split launches (btc_set_scratch), as binding.cpp ensure_scratch
+        buf = _SCRATCH[key] = torch.empty(48 << 20, dtype=torch.uint8, device=src.device)
+        check(lib().btc_set_scratch(stream_ptr(), ptr(buf), buf.numel()), "btc_set_scratch")
+    return True
 
 
 def _weights_split(w, K, cin, cout):

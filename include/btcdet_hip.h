@@ -64,6 +64,7 @@ int btc_version(void);
 #define BTC_TUNE_BN_BWD_KB 10 /* bn_bwd_stats: KB of input (x, y, dy) per workgroup (0 = built-in 128) */
 #define BTC_TUNE_WGRAD_PIPE 11 /* conv_wgrad_rows: 1 = the two-barrier kernel instead of the software-pipelined one */
 #define BTC_TUNE_BN_FUSE 12 /* btc_conv_bn_relu_fwd: 1 = statistics by the separate bn_stats launch instead of the conv epilogue */
+#define BTC_TUNE_SPLIT_Z 15 /* split-operand kernel: workgroups sharing a tile's items (0 = built-in policy, 1 = never, 2..4 = always that many) */
 #define BTC_TUNE_SPLIT 14 /* host bindings: 1 = never take the split-operand kernel (conv_apply_g's exact fmaf chain everywhere) */
 #define BTC_TUNE_APPLY_STAGES 13 /* conv_apply_g: depth of the LDS ring (3..8; 0 = built-in policy) */
 #define BTC_TUNE_APPLY_DEBUG 3 /* timing experiments only (WRONG results): 1 = no MFMA phase, 2 = no loads in the main loop */
@@ -255,6 +256,12 @@ int btc_conv_dgrad_bf16w(const void* dout, const void* w_bf16, const int32_t* nb
  *                        (forward operand); once per optimizer step and layer (3*K*Cin*Cout*2 bytes each)
  * used through btc_conv_apply_ordered / btc_conv_bn_relu_fwd with operands = BTC_OPERANDS_F32_SPLIT and W = the planes of that pass */
 int btc_conv_split_supported(int K, int Cred, int Cres);
+/* Scratch memory for a stream: `bytes` of device memory the library may use during any launch on `stream` (the caller owns it and
+ * keeps it alive until it registers another buffer, or NULL, for that stream).  Used by the split-operand kernel on levels of a few
+ * thousand rows: up to four workgroups share a tile's (offset, chunk) items, write partial sums to slabs of n_rows x Cout floats in
+ * the scratch and a second launch adds the slabs in order (deterministic; bias and the BatchNorm statistics move to that launch).
+ * Without a buffer (or with one too small for two slabs) such launches run unsplit. */
+int btc_set_scratch(void* stream, void* ptr, size_t bytes);
 /* the host bindings' policy: 1 = an fp32 launch of n_rows rows should take the split-operand kernel (0 always under BTC_TUNE_SPLIT = 1) */
 int btc_conv_split_wanted(int K, int Cred, int Cres, int n_rows);
 int btc_weights_split3(const float* W, int K, int Cin, int Cout, void* w_split, void* wt_split, void* stream);

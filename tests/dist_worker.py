@@ -55,6 +55,14 @@ def run(rank, world, port, out, backend, schedule, transport=None, steps=3, shar
             tr.step(batches[i], batches[i + 1])
             torch.cuda.synchronize()
             local = [p.grad.detach().clone() for p in params]              # assign_grads=False: param.grad is the LOCAL gradient
+            bad = [n for n, p in model.named_parameters() if p.grad is not None and not torch.isfinite(p.grad).all()]
+            if bad:
+                good = [n for n, p in model.named_parameters() if p.grad is not None and n.startswith("det_") and torch.isfinite(p.grad).all()]
+                out["bad_%d_%d" % (rank, i)] = {"bad": bad, "finite_det": good}
+                if os.environ.get("BTC_NAN_DUMP"):
+                    import json
+                    with open(os.environ["BTC_NAN_DUMP"], "a") as fh:
+                        fh.write(json.dumps({"rank": rank, "step": i, "bad": bad, "finite_det": good}) + "\n")
             reduced = [sync.view_of(p).detach().clone() for p in params]
             mean = []
             for g in local:                                                # the mean over ranks, independently of the reducer

@@ -22,6 +22,8 @@ def test_two_ranks_on_one_gpu_real_hot_path_clip_biting(schedule):
     mgr = mp.Manager()
     out = mgr.dict()
     mp.spawn(dist_worker.run, args=(world, 29781 + (schedule == "pipelined"), out, "gloo", schedule, None, 3, True), nprocs=world, join=True)
+    bad = {k: v for k, v in out.items() if str(k).startswith("bad_")}
+    assert not bad, bad     # parameters with a non-finite local gradient (rank, step)
     for r in range(world):
         o = out[r]
         assert o["backend"] == "gloo" and o["world"] == 2 and o["transport"] == "host" and o["it"] == 3

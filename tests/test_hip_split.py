@@ -131,3 +131,55 @@ def test_split_planes_are_an_exact_decomposition():
 def test_exact_kernel_selected_by_tune_key(exact_conv):
     from btcdet_amd import _lib
     assert _lib.lib().btc_conv_split_wanted(27, 64, 64, 20000) == 0
+
+
+@pytest.mark.parametrize("cin,cout,n_pts", [(64, 64, 3500), (64, 64, 7000), (256, 128, 6000), (128, 256, 6000)])
+def test_z_split_small_levels(cin, cout, n_pts):
+    """levels of a few thousand rows: up to four workgroups share a tile's items, partial slabs in the stream's scratch buffer, a second
+    launch adds them in order (+ bias, + the BatchNorm statistics).  Same bounds as the unsplit kernel, bit-identical run to run, and the
+    fused BatchNorm statistics equal the separate pass"""
+    from btcdet_amd import _lib
+    from btcdet_amd.spconv import fused_bn, ops
+    L = _lib.lib()
+    rng = np.random.default_rng(cin + cout + n_pts)
+    shape, B = (10, 40, 40), 2
+    idx = rand_indices(rng, n_pts, B, shape)
+    (o_idx, o_out, o_in, o_sh), rb = _rb_both(idx, B, shape, (3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 1, 1), "subm")
+    n = o_out.shape[0]
+    assert 2500 <= n < 10000 and L.btc_conv_split_wanted(27, cin, cout, n) == 1
+    feat = rng.standard_normal((n, cin)).astype(np.float32)
+    W = (rng.standard_normal((3, 3, 3, cin, cout)) / np.sqrt(cin)).astype(np.float32)
+    bias = rng.standard_normal(cout).astype(np.float32)
+    f, w, b = (torch.from_numpy(a).to(dev()) for a in (feat, W, bias))
+    outs = {}
+    for z in (0, 1):                       # 0: the policy (z-split here), 1: never
+        assert L.btc_tune_set(15, z) == 0
+        try:
+            outs[z] = [ops.indice_conv(f, w, b, rb).cpu().numpy() for _ in range(2)]
+        finally:
+            L.btc_tune_set(15, 0)
+        assert np.array_equal(outs[z][0], outs[z][1])
+    assert not np.array_equal(outs[0][0], outs[1][0])          # (the split really ran: another summation order)
+    ref64 = _f64_conv(feat, W, o_out, False) + bias.astype(np.float64)
+    exact = orc.conv_fwd(feat, W, bias, o_out)
+    (mx, rms), (mx_e, rms_e) = _err(outs[0][0], ref64), _err(exact, ref64)
+    print("%d -> %d at %d rows, z-split: vs fp64 max %.2e rms %.2e | exact chain max %.2e rms %.2e" % (cin, cout, n, mx, rms, mx_e, rms_e))
+    assert rms <= 1.1 * rms_e and mx <= 1.5 * mx_e + 2e-7
+    # conv -> BatchNorm with the statistics taken in the reduce launch
+    gamma = torch.from_numpy(rng.uniform(0.5, 1.5, cout).astype(np.float32)).to(dev())
+    beta = torch.from_numpy(rng.uniform(-0.3, 0.3, cout).astype(np.float32)).to(dev())
+    res = []
+    for tune in (0, 1):
+        rm, rv, nbt = torch.zeros(cout, device=dev()), torch.ones(cout, device=dev()), torch.zeros((), dtype=torch.long, device=dev())
+        assert L.btc_tune_set(12, tune) == 0
+        try:
+            x, y, stats = fused_bn.conv_bn_forward(f, w.view(27, cin, cout), None, rb.nbr_out, None, gamma, beta, rm, rv, nbt, 0.01, 1e-3, True)
+            torch.cuda.synchronize()
+        finally:
+            L.btc_tune_set(12, 0)
+        res.append((x, y, stats, rm, rv))
+    assert torch.equal(res[0][0], res[1][0])
+    for a, c in zip(res[0][2:], res[1][2:]):
+        np.testing.assert_allclose(a.cpu().numpy(), c.cpu().numpy(), rtol=2e-6, atol=1e-7)
+    np.testing.assert_allclose(res[0][1].cpu().numpy(), res[1][1].cpu().numpy(), rtol=0, atol=1e-5)
+    assert bool((fused_bn.fuse_ws(f.device) == 0).all())

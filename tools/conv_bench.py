@@ -43,6 +43,8 @@ step(batches[0])
 cap, ops.CAPTURE = ops.CAPTURE, None
 torch.cuda.synchronize()
 L = _lib.lib()
+_scratch = torch.empty(48 << 20, dtype=torch.uint8, device=dev)      # z-split launches of the split-operand kernel
+check(L.btc_set_scratch(stream_ptr(), ptr(_scratch), _scratch.numel()), "btc_set_scratch")
 
 
 def tune(v):
