@@ -870,11 +870,6 @@ std::vector<std::vector<Tensor>> geometry_walk_finish(const std::shared_ptr<Pend
       to_order_keys.push_back(key_in[i]);
     }
   if (!to_order.empty()) {
-    if (getenv("BTC_DEBUG_KEYS")) {
-      int nk = 0;
-      for (const Tensor& t : to_order_keys) nk += t.defined();
-      fprintf(stderr, "[btcfast] row orders: %zu maps, %d with keys\n", to_order.size(), nk);
-    }
     auto ord = row_orders_keyed(to_order, to_order_keys, stream);
     size_t q = 0;
     for (size_t i = 0; i < n; ++i)
