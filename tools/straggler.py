@@ -2,8 +2,8 @@
 
 At N > 1 every step ends at the gradient all-reduce -- a barrier -- so a step takes as long as the slowest rank's batch.  Scenes
 differ (point counts, active voxels per level), hence so do step times.  This tool runs the bench's step (HotPathTrainer, default
-schedule) over >= 64 DISTINCT seeded batches, twice (the first pass brings the caching allocator and the per-size plans to their
-steady state), takes the second pass's per-step times (HIP events at the end of every step on the stream its last kernel runs on)
+schedule) over >= 64 DISTINCT seeded batches, three times (the first two passes bring the caching allocator and the per-size plans to their
+steady state), takes the third pass's per-step times (HIP events at the end of every step on the stream its last kernel runs on)
 and reports   predicted_eff_world8 = mean(step) / E[max of 8 independent draws]   (bootstrap over the measured distribution).
 No collective is involved: this is the efficiency loss from batch-to-batch variance alone.
 
@@ -51,6 +51,7 @@ def one_pass(record):
 
 
 one_pass(False)
+one_pass(False)   # two warm passes: every batch size has been seen twice, the allocator has its blocks
 a0 = torch.cuda.memory_stats(dev).get("num_device_alloc", 0)
 ms = one_pass(True)
 allocs = torch.cuda.memory_stats(dev).get("num_device_alloc", 0) - a0
@@ -63,7 +64,7 @@ res = {"n_batches": n, "points_per_batch": [b["n_points"] for b in batches], "st
        "e_max_ms": {str(w): round(v, 4) for w, v in emax.items()},
        "predicted_eff": {str(w): round(float(ms.mean()) / v, 4) for w, v in emax.items()},
        "predicted_eff_world8": round(float(ms.mean()) / emax8, 4), "device_allocs_in_measured_pass": int(allocs),
-       "how": "HotPathTrainer (default schedule) over %d distinct seeded batches, second pass; per-step HIP-event intervals; "
+       "how": "HotPathTrainer (default schedule) over %d distinct seeded batches, third pass; per-step HIP-event intervals; "
               "E[max of w] by bootstrap (20000 draws)" % n}
 os.makedirs(os.path.dirname(out), exist_ok=True)
 with open(out, "w") as f:
