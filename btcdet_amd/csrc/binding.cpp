@@ -109,6 +109,33 @@ Tensor weights_q(const Tensor& w, int64_t K, int64_t cin, int64_t cout, int64_t 
 
 Tensor weights_bf16(const Tensor& w, int64_t K, int64_t cin, int64_t cout, int64_t stream) { return weights_q(w, K, cin, cout, stream, 1); }
 
+// the split planes of MANY leaf weights in one launch (a parameter group's eligible layers right after its optimizer step, on the
+// stream its next forward runs on): every cache entry is brought to the weight's current version, later weights_q calls hit
+void split_weights(const std::vector<Tensor>& weights, int64_t stream) {
+  const size_t n = weights.size();
+  if (n == 0) return;
+  std::vector<const float*> W(n);
+  std::vector<void*> ws(n), wts(n);
+  std::vector<int32_t> K(n), Cin(n), Cout(n);
+  std::lock_guard<std::mutex> lock(g_wq_mu);
+  for (size_t i = 0; i < n; ++i) {
+    const Tensor& w = weights[i];
+    need(w.is_leaf() && w.is_contiguous() && w.scalar_type() == at::kFloat && w.dim() >= 3, "split_weights: contiguous fp32 leaf weights [.., Cin, Cout] expected");
+    const int64_t cin = w.size(-2), cout = w.size(-1);
+    const void* key = w.unsafeGetTensorImpl();
+    auto it = g_ws.find(key);
+    Tensor q = (it != g_ws.end() && !it->second.weak.expired() && it->second.q.numel() == 6 * w.numel() && it->second.q.get_device() == w.get_device())
+                   ? it->second.q : at::empty({2, 3 * w.numel()}, w.options().dtype(at::kBFloat16));
+    if (it != g_ws.end()) g_ws.erase(it);
+    g_ws.emplace(key, WqEntry(c10::weak_intrusive_ptr<c10::TensorImpl>(w.getIntrusivePtr()), (uint32_t)w._version(), q));
+    W[i] = (const float*)w.data_ptr();
+    ws[i] = q.data_ptr();
+    wts[i] = (char*)q.data_ptr() + 6 * w.numel();
+    K[i] = (int32_t)(w.numel() / (cin * cout)); Cin[i] = (int32_t)cin; Cout[i] = (int32_t)cout;
+  }
+  chk(btc_weights_split3_multi(W.data(), ws.data(), wts.data(), K.data(), Cin.data(), Cout.data(), (int)n, st(stream)), "btc_weights_split3_multi");
+}
+
 // the stream's scratch buffer for z-split launches of the split-operand kernel (btc_set_scratch): 48 MB, allocated on first use
 // from the stream's own pool and kept for the life of the process
 void ensure_scratch(const Tensor& like, int64_t stream) {
@@ -963,6 +990,7 @@ void pack_grads(const std::vector<Tensor>& grads, const Tensor& chunk_seg, const
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.doc() = "compiled PyTorch binding of libbtcdet_hip.so's hot entry points";
+  m.def("split_weights", &split_weights, py::call_guard<py::gil_scoped_release>());
   m.def("conv_fwd", &conv_fwd, py::call_guard<py::gil_scoped_release>());
   m.def("bn_fwd", &bn_fwd, py::call_guard<py::gil_scoped_release>());
   m.def("conv_bn_fwd", &conv_bn_fwd, py::call_guard<py::gil_scoped_release>());

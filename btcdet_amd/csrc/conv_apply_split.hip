@@ -311,7 +311,65 @@ __global__ __launch_bounds__(256) void weights_split3(const float* __restrict__ 
   }
 }
 
+// the same for up to SPLIT_MULTI_MAX weights in ONE launch: the table travels in the kernel arguments, a block finds its weight by
+// its first-block entry (one optimizer group's eligible layers after its step: ~10 launches of 6 us become one)
+constexpr int SPLIT_MULTI_MAX = 32;
+struct SplitTable {
+  const float* W[SPLIT_MULTI_MAX];
+  unsigned short* w_s[SPLIT_MULTI_MAX];
+  unsigned short* wt_s[SPLIT_MULTI_MAX];
+  int K[SPLIT_MULTI_MAX], Cin[SPLIT_MULTI_MAX], Cout[SPLIT_MULTI_MAX], first_block[SPLIT_MULTI_MAX + 1];
+  int n;
+};
+
+__global__ __launch_bounds__(256) void weights_split3_multi(const SplitTable t) {
+  int s = 0;
+  while (s + 1 < t.n && (int)blockIdx.x >= t.first_block[s + 1]) ++s;
+  const long long e = (long long)((int)blockIdx.x - t.first_block[s]) * 256 + threadIdx.x;
+  const int Cin = t.Cin[s], Cout = t.Cout[s];
+  const long long per = (long long)Cin * Cout, n = (long long)t.K[s] * per;
+  if (e >= n) return;
+  const float x = t.W[s][e];
+  const unsigned xb = __float_as_uint(x);
+  const float x1 = x - __uint_as_float(xb & 0xFFFF0000u);
+  const unsigned x1b = __float_as_uint(x1);
+  const float x2 = x1 - __uint_as_float(x1b & 0xFFFF0000u);
+  const unsigned short p[3] = {(unsigned short)(xb >> 16), (unsigned short)(x1b >> 16), (unsigned short)(__float_as_uint(x2) >> 16)};
+  const int k = (int)(e / per);
+  const int rem = (int)(e - (long long)k * per);
+  const int ci = rem / Cout, co = rem - ci * Cout;
+  const long long et = (long long)k * per + (long long)co * Cin + ci;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    t.w_s[s][j * n + e] = p[j];
+    t.wt_s[s][j * n + et] = p[j];
+  }
+}
+
 }  // namespace
+
+extern "C" int btc_weights_split3_multi(const float* const* W, void* const* w_split, void* const* wt_split, const int32_t* K, const int32_t* Cin,
+                                        const int32_t* Cout, int n, void* stream) {
+  BTC_CHECK_ARG(n >= 0, "btc_weights_split3_multi: bad count");
+  for (int base = 0; base < n; base += SPLIT_MULTI_MAX) {
+    SplitTable t;
+    t.n = n - base < SPLIT_MULTI_MAX ? n - base : SPLIT_MULTI_MAX;
+    int blocks = 0;
+    for (int i = 0; i < t.n; ++i) {
+      BTC_CHECK_ARG(K[base + i] >= 1 && Cin[base + i] >= 1 && Cout[base + i] >= 1, "btc_weights_split3_multi: bad sizes");
+      t.W[i] = W[base + i];
+      t.w_s[i] = (unsigned short*)w_split[base + i];
+      t.wt_s[i] = (unsigned short*)wt_split[base + i];
+      t.K[i] = K[base + i]; t.Cin[i] = Cin[base + i]; t.Cout[i] = Cout[base + i];
+      t.first_block[i] = blocks;
+      blocks += (int)btc_cdiv((long long)K[base + i] * Cin[base + i] * Cout[base + i], 256);
+    }
+    t.first_block[t.n] = blocks;
+    if (blocks > 0) weights_split3_multi<<<blocks, 256, 0, (hipStream_t)stream>>>(t);
+    BTC_LAUNCH_CHECK();
+  }
+  return BTC_OK;
+}
 
 extern "C" int btc_conv_split_supported(int K, int Cred, int Cres) {
   return K >= 1 && K <= 64 && Cred >= 32 && Cred % 32 == 0 && Cres >= 32 && Cres % 32 == 0;

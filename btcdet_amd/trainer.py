@@ -80,6 +80,18 @@ def make_step(model, ddp, proc, opts, grad_sync=None, prefetch_stream=None, thre
     split_backward = grad_sync is not None and ddp is model and len(grad_sync.buckets) > 1 and getattr(grad_sync, "split_backward", False)
     bucket_of = getattr(grad_sync, "bucket_of", None) if grad_sync is not None else None
 
+    # bf16 planes of the split-operand kernel's weights: one launch per parameter group right behind its optimizer step
+    _split = {}
+
+    def refresh_planes(group):
+        if "lists" not in _split:
+            _split["lists"] = split_weight_lists(model) if hasattr(model, "occ_modules") else ((), ())
+        ws = _split["lists"][group]
+        if ws:
+            from .spconv import ops as _o
+            from ._lib import stream_ptr
+            _o.fast().split_weights(ws, stream_ptr())
+
     def prep(next_batch):
         torch.cuda.set_device(device)
         if timing is None:
@@ -134,6 +146,7 @@ def make_step(model, ddp, proc, opts, grad_sync=None, prefetch_stream=None, thre
         if grad_sync is not None:
             grad_sync.wait(bucket_of["occ"])
         opts[0].step(groups=[0])         # occupancy group, on the main stream behind its backward (and its all-reduce)
+        refresh_planes(0)
         if next_batch is None:
             return None
         bd_next = prep_future.result() if prep_future is not None else model.prepare(next_batch, stream=prefetch_stream)
@@ -194,6 +207,7 @@ def make_step(model, ddp, proc, opts, grad_sync=None, prefetch_stream=None, thre
                 grad_sync.launch(bucket_of["det"])
                 grad_sync.wait(bucket_of["det"])
             opts[0].step(groups=[1])     # detection group, on det_stream behind its backward (and its all-reduce)
+            refresh_planes(1)
             det_stream.wait_event(occ_fwd_done)
             loss_occ.record_stream(det_stream)
             loss = loss_occ.detach() + loss_det.detach()
@@ -266,6 +280,9 @@ def make_step(model, ddp, proc, opts, grad_sync=None, prefetch_stream=None, thre
         else:
             for o in opts:
                 o.step()
+            if len(opts) == 1 and hasattr(opts[0], "groups") and len(opts[0].groups) == 2:
+                refresh_planes(0)
+                refresh_planes(1)
         if ahead and not threaded:
             pending[id(next_batch)] = model.prepare(next_batch, stream=prefetch_stream)
         model.mark_step_end()
@@ -275,6 +292,22 @@ def make_step(model, ddp, proc, opts, grad_sync=None, prefetch_stream=None, thre
     step.pipelined = pipeline
     step.pools = [p_ for p_ in (locals().get("pool"), prep_pool) if p_ is not None]
     return step
+
+
+def split_weight_lists(model):
+    """per parameter group (occupancy, detection): the sparse-conv weights the split-operand kernel can take (both channel counts
+    multiples of 32, fp32, on the GPU) -- their bf16 planes are refreshed by ONE launch right after the group's optimizer step
+    (binding.cpp split_weights) instead of one launch per layer at the layer's next forward; () when that kernel is switched off"""
+    from . import _lib
+    from .spconv import ops
+    from .spconv.conv import SparseConvolution
+    F = ops.fast()
+    if F is None or not hasattr(F, "split_weights") or _lib.lib().btc_tune_value(14) == 1:
+        return (), ()
+    def pick(root):
+        return [m.weight for m in root.modules() if isinstance(m, SparseConvolution) and m.in_channels % 32 == 0 and m.out_channels % 32 == 0
+                and m.weight.is_cuda and m.weight.dtype == torch.float32 and m.weight.requires_grad]
+    return pick(model.occ_modules), pick(model.det_modules)
 
 
 def reference_groups(model, world=1, epochs=40, frames=3712, batch_size=2):

@@ -265,6 +265,9 @@ int btc_set_scratch(void* stream, void* ptr, size_t bytes);
 /* the host bindings' policy: 1 = an fp32 launch of n_rows rows should take the split-operand kernel (0 always under BTC_TUNE_SPLIT = 1) */
 int btc_conv_split_wanted(int K, int Cred, int Cres, int n_rows);
 int btc_weights_split3(const float* W, int K, int Cin, int Cout, void* w_split, void* wt_split, void* stream);
+/* the same for n weights in one launch (host arrays of device pointers / sizes): a parameter group's layers right after its optimizer step */
+int btc_weights_split3_multi(const float* const* W, void* const* w_split, void* const* wt_split, const int32_t* K, const int32_t* Cin,
+                             const int32_t* Cout, int n, void* stream);
 
 /* Row-order hints (csrc/row_order.hip).  The apply kernels work on tiles of 16 consecutive map rows and pay for every
  * offset ANY row of the tile has; which rows share a tile changes no result.  btc_row_orders sorts the rows of up to

@@ -183,3 +183,28 @@ def test_z_split_small_levels(cin, cout, n_pts):
         np.testing.assert_allclose(a.cpu().numpy(), c.cpu().numpy(), rtol=2e-6, atol=1e-7)
     np.testing.assert_allclose(res[0][1].cpu().numpy(), res[1][1].cpu().numpy(), rtol=0, atol=1e-5)
     assert bool((fused_bn.fuse_ws(f.device) == 0).all())
+
+
+def test_multi_weight_split_equals_single():
+    """btc_weights_split3_multi (one launch for a group's layers) writes the planes btc_weights_split3 writes, for 40 weights of mixed
+    shapes (more than one table's worth)"""
+    import ctypes
+    from btcdet_amd import _lib
+    from btcdet_amd._lib import check, ptr, stream_ptr
+    L = _lib.lib()
+    rng = np.random.default_rng(11)
+    shapes = [(27, 32, 32), (27, 64, 64), (3, 64, 128), (27, 32, 64), (2, 128, 64), (27, 128, 32), (8, 96, 32), (1, 32, 160)] * 5
+    ws = [torch.from_numpy(rng.standard_normal(s).astype(np.float32)).to(dev()) for s in shapes]
+    single = []
+    for w, (K, cin, cout) in zip(ws, shapes):
+        q = torch.empty((2, 3 * w.numel()), dtype=torch.bfloat16, device=dev())
+        check(L.btc_weights_split3(ptr(w), K, cin, cout, ptr(q[0]), ptr(q[1]), stream_ptr()), "single")
+        single.append(q)
+    multi = [torch.zeros_like(q) for q in single]
+    n = len(ws)
+    arr = lambda vals: (ctypes.c_void_p * n)(*vals)
+    i32 = lambda vals: (ctypes.c_int32 * n)(*vals)
+    check(L.btc_weights_split3_multi(arr([ptr(w) for w in ws]), arr([ptr(q[0]) for q in multi]), arr([ptr(q[1]) for q in multi]),
+                                     i32([s[0] for s in shapes]), i32([s[1] for s in shapes]), i32([s[2] for s in shapes]), n, stream_ptr()), "multi")
+    for a, b in zip(single, multi):
+        assert torch.equal(a.view(torch.int16), b.view(torch.int16))
