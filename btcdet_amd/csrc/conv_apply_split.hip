@@ -255,36 +255,49 @@ int launch_s(const float* feat, const unsigned short* Ws, const float* bias, con
 }
 
 // out[r][c] = bias[c] + slab_0[r][c] + slab_1[r][c] + ... (in that order: deterministic) of a z-split launch, with the BatchNorm
-// statistics epilogue of the conv kernels; a wave owns 16 rows x 32 columns in the MFMA C/D layout bn_fuse_wave expects
+// statistics the conv kernels' epilogues gather (bn_fuse.h slots, the same last-arriver finish).  A workgroup owns 64 rows x 64
+// columns: a lane reads float4s (16 lanes = one 256-byte row segment), walks 4 of its wave's 16 rows and keeps the column sums of
+// its 4 columns; the four lanes of a column group meet through two shuffles.  (Cres % 64 == 0 for every shape that splits.)
 __global__ __launch_bounds__(256) void split_reduce(const float* __restrict__ slabs, int Z, const float* __restrict__ bias, int n_rows, int Cres,
                                                     float* __restrict__ out, const BnFuse bn) {
   __shared__ int s_flag;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int row0 = (blockIdx.x * 4 + wave) * 16, c0 = blockIdx.y * 32;
+  const int cq = lane & 15, rq = lane >> 4;
+  const int col = blockIdx.y * 64 + cq * 4;
+  const int row0 = (blockIdx.x * 4 + wave) * 16;
   const size_t slab = (size_t)n_rows * Cres;
-  float vals[2][4];
-  bool valid[4];
+  const f32x4 b = bias ? *(const f32x4*)(bias + col) : (f32x4){0.f, 0.f, 0.f, 0.f};
+  double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-  for (int nt = 0; nt < 2; ++nt) {
-    const int col = c0 + nt * 16 + (lane & 15);
-    const float b = bias ? bias[col] : 0.f;
+  for (int i = 0; i < 4; ++i) {
+    const int row = row0 + i * 4 + rq;
+    if (row < n_rows) {
+      const float* p = slabs + (size_t)row * Cres + col;
+      f32x4 v = *(const f32x4*)p;
+      for (int z = 1; z < Z; ++z) v += *(const f32x4*)(p + z * slab);
+      if (bias) v += b;
+      *(f32x4*)(out + (size_t)row * Cres + col) = v;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = row0 + (lane >> 4) * 4 + r;
-      valid[r] = row < n_rows;
-      float v = 0.f;
-      if (row < n_rows) {
-        const float* p = slabs + (size_t)row * Cres + col;
-        v = p[0];
-        for (int z = 1; z < Z; ++z) v += p[z * slab];
-        if (bias) v += b;
-        out[(size_t)row * Cres + col] = v;
+      for (int e = 0; e < 4; ++e) {
+        s1[e] += (double)v[e];
+        s2[e] += (double)v[e] * (double)v[e];
       }
-      vals[nt][r] = v;
     }
   }
   if (bn.slots) {
-    bn_fuse_wave<2>(bn, vals, valid, c0, (int)((blockIdx.x * 4 + wave) & (BN_FUSE_SLOTS - 1)));
+    const int slot = (int)((blockIdx.x * 4 + wave) & (BN_FUSE_SLOTS - 1));
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      s1[e] += __shfl_xor(s1[e], 16, 64);
+      s2[e] += __shfl_xor(s2[e], 16, 64);
+      s1[e] += __shfl_xor(s1[e], 32, 64);
+      s2[e] += __shfl_xor(s2[e], 32, 64);
+      if (lane < 16 && col + e < bn.C) {
+        double* p = bn.slots + ((size_t)slot * 2) * BN_FUSE_CMAX + col + e;
+        unsafeAtomicAdd(p, s1[e]);
+        unsafeAtomicAdd(p + BN_FUSE_CMAX, s2[e]);
+      }
+    }
     bn_fuse_finish(bn, &s_flag);
   }
 }
@@ -458,7 +471,7 @@ int btc_apply_split(const float* src, const void* Ws_, const float* bias_, const
   }
 #undef S_ARGS
   if (rc != BTC_OK || Z == 1) return rc;
-  split_reduce<<<dim3(btc_cdiv(n_rows, 64), Cres / 32), 256, 0, stream>>>(dst, Z, bias_, n_rows, Cres, dst_, bn);
+  split_reduce<<<dim3(btc_cdiv(n_rows, 64), Cres / 64), 256, 0, stream>>>(dst, Z, bias_, n_rows, Cres, dst_, bn);
   BTC_LAUNCH_CHECK();
   return BTC_OK;
 }
