@@ -55,7 +55,7 @@ def pmc_traffic_per_launch():
     --pmc WRITE_SIZE in separate runs, FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md); PMC counters cannot be read
     inside the timed process, so this is null when the file is absent"""
     try:
-        name = next(n for n in ("r03i_pmc.json", "r03_pmc.json", "r02h_pmc.json") if os.path.exists(os.path.join(ROOT, "profiles", n)))
+        name = next(n for n in ("r03j_pmc.json", "r03_pmc.json", "r02h_pmc.json") if os.path.exists(os.path.join(ROOT, "profiles", n)))
         with open(os.path.join(ROOT, "profiles", name)) as f:
             return json.load(f)["conv_apply"]["hbm_bytes_per_launch"]
     except (OSError, KeyError, ValueError):
@@ -480,9 +480,9 @@ def straggler_estimate():
     (tools/straggler.py -> profiles/*_straggler.json): the gradient all-reduce is a barrier, so a step takes as long as the
     slowest of the 8 ranks' batches; E[mean] / E[max of 8 independent draws].  None when the file is absent."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r03i_straggler.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r03j_straggler.json")) as f:
             d = json.load(f)
-        return {"world": 8, "efficiency": d["predicted_eff_world8"], "from": "profiles/r03i_straggler.json: %d distinct seeded batches, step time "
+        return {"world": 8, "efficiency": d["predicted_eff_world8"], "from": "profiles/r03j_straggler.json: %d distinct seeded batches, step time "
                 "mean %.3f ms, sd %.3f ms" % (d["n_batches"], d["mean_ms"], d["sd_ms"])}
     except (OSError, KeyError, ValueError):
         return None
