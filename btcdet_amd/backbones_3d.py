@@ -464,6 +464,10 @@ class VoxelBackBone8xOcc(nn.Module):
         x1, x2, x3, x4 = levels
         out = self._stage(self.conv_out, x4, ready)
         batch_dict.update({'encoded_spconv_tensor': out, 'encoded_spconv_tensor_stride': 8})
+        # active rows per level of this batch (host integers the rulebook walk has read back already; bench.py reports them)
+        batch_dict['__level_rows__'] = {'det_L0': int(x1.features.shape[0]), 'det_L1': int(x2.features.shape[0]),
+                                        'det_L2': int(x3.features.shape[0]), 'det_L3': int(x4.features.shape[0]),
+                                        'det_out': int(out.features.shape[0])}
         batch_dict.update({'multi_scale_3d_features': {
             'x_conv1': self.suqeeze(x1, 1, self.out_feat_type[0]),
             'x_conv2': self.suqeeze(x2, 2, self.out_feat_type[1]),

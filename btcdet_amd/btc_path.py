@@ -260,8 +260,17 @@ class BtcHotPath(nn.Module):
             cur.wait_event(inputs_ready)
             if batch_dict.pop("__recorded_for__", None) != cur.cuda_stream:   # (hand_over() did it from the producer's thread)
                 self.hand_over(batch_dict, cur)
+        rows = {}   # active rows per level of this batch -- tensor shapes, host integers, no read-back (bench.py reports them per timed step)
+        enc = batch_dict.get("encoded_spconv_tensor")
+        if enc is not None and hasattr(enc, "features"):
+            rows["occ_out"] = int(enc.features.shape[0])          # the occupancy decoder's output level (the head runs on it)
+        if "det_voxel_coords" in batch_dict:
+            rows["det_voxels"] = int(batch_dict["det_voxel_coords"].shape[0])
+        rows["det_voxels_after_pass_occ"] = int(batch_dict["voxel_coords"].shape[0])   # M'': detection voxels + PassOccVox's added ones
         for mod in self.det_module_list:
             batch_dict = mod(batch_dict)
+        rows.update(batch_dict.get("__level_rows__", {}))
+        self.last_level_rows = rows
         # the two tensors the heads behind the hot path consume: the BEV map (BaseBEVBackbone) and x_combine (ConvHead)
         return {"spatial_features": batch_dict["spatial_features"],
                 "x_combine": batch_dict["multi_scale_3d_features"]["x_combine"].features}, batch_dict

@@ -28,7 +28,14 @@ def test_bench_json_line_contract():
     assert d["value"] > 50 and abs(d["value"] - 2 * 1000.0 / d["ms_per_step"]) < 0.01 * d["value"]      # bs = 2 scenes per step
     cfg = d["config"]
     assert "workload" in cfg and "model" not in cfg and cfg["global_batch"] == 2 and cfg["parallelism"] == "dp1"
+    # the workload is fixed: every step draws unseen scenes (no recycled batches for the optimizer to memorise); level rows are reported
+    assert cfg["distinct_batches"] >= 64 + 4 + 1 and cfg["priming_steps"] == 62
+    lv = cfg["level_rows"]
+    assert lv["det_L0"]["median"] >= lv["det_voxels"]["median"] > 5000 and lv["det_L1"]["min"] > 1000 and lv["occ_out"]["median"] > 50000
+    assert lv["det_voxels_after_pass_occ"]["median"] >= lv["det_voxels"]["median"]
+    assert cfg["recurring_batches_scenes_per_s"]["scenes_per_s"] > 50
     r = d["roofline"]
+    assert (r["traffic"] is None) == (r["traffic_source"] is None)
     # "latency": neither roof within a factor 5 (frac_hbm_measured and frac_mfma < 0.2); the fraction is still quoted against the HBM roof
     assert r["bound"] in ("hbm", "mfma", "latency") and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4 and 0.05 < r["frac"] < 1.0

@@ -23,7 +23,7 @@ from btcdet_amd.config import load_cfg  # noqa: E402
 from btcdet_amd.trainer import HotPathTrainer  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 64
-out = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "gpurun_out", "r03_straggler.json")
+out = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "gpurun_out", "straggler.json")
 dev = torch.device("cuda", 0)
 torch.cuda.set_device(0)
 from btcdet_amd.affinity import pin_to_gpu  # noqa: E402
