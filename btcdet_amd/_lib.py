@@ -36,7 +36,7 @@ class BtcOccConfig(ctypes.Structure):
                 ("det_zmin", ctypes.c_float), ("det_zmax", ctypes.c_float),
                 ("w_fore_cls", ctypes.c_float), ("w_mirr_cls", ctypes.c_float), ("w_bm_cls", ctypes.c_float),
                 ("w_neg_cls", ctypes.c_float), ("w_fore_res", ctypes.c_float), ("w_mirr_res", ctypes.c_float),
-                ("w_bm_res", ctypes.c_float), ("box_weight", ctypes.c_float)]
+                ("w_bm_res", ctypes.c_float), ("box_weight", ctypes.c_float), ("backproject_lut", ctypes.c_void_p)]
 
 
 OCC_BUFFER_FIELDS = ["vcc_mask", "voxelwise_mask", "bm_voxelwise_mask", "occ_voxelwise_mask", "fore_voxelwise_mask",
@@ -150,6 +150,7 @@ _SIGS = {
     "btc_col_sum": (ci, [vp, ci, ci, vp, vp, sz, vp]),
     "btc_col_sum_bf16": (ci, [vp, ci, ci, vp, vp, sz, vp]),
     "btc_occ_targets_ws_bytes": (sz, [ctypes.POINTER(BtcOccConfig)]),
+    "btc_occ_backproject_lut": (ci, [ctypes.POINTER(BtcOccConfig), vp, vp]),
     "btc_occ_targets": (ci, [ctypes.POINTER(BtcOccConfig), vp, vp, vp, ci, ci, ci, vp, vp, vp, vp, ci, vp, vp,
                              ctypes.POINTER(BtcOccBuffers), vp, sz, vp]),
 }

@@ -192,8 +192,38 @@ __global__ __launch_bounds__(256) void occ_ray_count(const uint8_t* __restrict__
 
 // per ray: empty-ray fix (occ_targets_template.py:128-130,186-191), prefix OR along range
 // (cumsum > 0.9, :133-134), back-projection of the occluded cell corners (:145-154)
+// back-projection of ONE sphere cell corner (sz, sy, x) into the cylinder grid -> linear cell z*ny*nx + y*nx + x, or -1 out of range
+// (occ_targets_template.py:146-152: idx * voxel + origin, sphere_uvd2absxyz, cartesian_cylinder_coords, point2coords_inrange);
+// (ce, se, ca, sa) = cos / sin of the corner's elevation and azimuth
+__device__ __forceinline__ int backproject_cell(const OccParams& P, int x, float ce, float se, float ca, float sa) {
+  const float rr = __fadd_rn(__fmul_rn((float)x, P.s_vs[0]), P.s_origin[0]);
+  const float xyd = __fmul_rn(rr, ce);
+  const float px = __fmul_rn(xyd, ca), py = __fmul_rn(-xyd, sa), pz = __fmul_rn(rr, se);
+  float cyl[3];
+  cart_to_cyl(px, py, pz, cyl);
+  int cc[3];
+  const int n3[3] = {P.nx, P.ny, P.nz};
+  if (!cell_inrange(cyl, P.origin, P.pmax, P.vs, n3, cc)) return -1;
+  return (cc[2] * P.ny + cc[1]) * P.nx + cc[0];
+}
+
+// The back-projection is a function of the two grids alone -- the corner lattice of the sphere grid does not move with the batch
+// (rot_z only enters the FORWARD projection of the points) -- so it is a static table: lut[sz][sy][x] = cylinder cell or -1.
+// This kernel fills it with the device's correctly-rounded transcendentals (the same arithmetic occ_ray_project evaluates inline
+// when no table is given); the host side may instead supply a table evaluated with the arithmetic of whatever platform the
+// reference is to be reproduced on (btcdet_amd/occ_targets.py: torch's own CPU kernels).
+__global__ __launch_bounds__(256) void occ_backproject_lut(OccParams P, int32_t* __restrict__ lut) {
+  const int ray = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (ray >= P.snz * P.sny) return;
+  const int sy = ray % P.sny, sz = ray / P.sny;
+  const float el = __fadd_rn(__fmul_rn((float)sz, P.s_vs[2]), P.s_origin[2]);
+  const float az = __fadd_rn(__fmul_rn((float)sy, P.s_vs[1]), P.s_origin[1]);
+  const float ce = cr_cos(deg2rad(el)), se = cr_sin(deg2rad(el)), ca = cr_cos(deg2rad(az)), sa = cr_sin(deg2rad(az));
+  for (int x = lane; x < P.snx; x += 64) lut[(size_t)ray * P.snx + x] = backproject_cell(P, x, ce, se, ca, sa);
+}
+
 __global__ __launch_bounds__(256) void occ_ray_project(const uint8_t* __restrict__ smap, const int32_t* __restrict__ ray_cnt,
-                                                       OccParams P, uint8_t* __restrict__ occ_raw) {
+                                                       OccParams P, const int32_t* __restrict__ lut, uint8_t* __restrict__ occ_raw) {
   int ray = blockIdx.x * 4 + (threadIdx.x >> 6);
   int lane = threadIdx.x & 63;
   int nrays = P.B * P.snz * P.sny;
@@ -226,19 +256,22 @@ __global__ __launch_bounds__(256) void occ_ray_project(const uint8_t* __restrict
     }
   }
   if (first >= P.snx) return;
+  uint8_t* occ_b = occ_raw + (size_t)b * P.nz * P.ny * P.nx;
+  if (lut) {   // static table of the corner lattice (coalesced 4-byte reads, no transcendental in the step)
+    const int32_t* l = lut + ((size_t)sz * P.sny + sy) * P.snx;
+    for (int x = first + lane; x < P.snx; x += 64) {
+      const int c = l[x];
+      if (c >= 0) occ_b[c] = 1;
+    }
+    return;
+  }
   // corner (no +0.5) of the sphere cell: idx * voxel + origin (occ_targets_template.py:147)
   float el = __fadd_rn(__fmul_rn((float)sz, P.s_vs[2]), P.s_origin[2]);
   float az = __fadd_rn(__fmul_rn((float)sy, P.s_vs[1]), P.s_origin[1]);
   float ce = cr_cos(deg2rad(el)), se = cr_sin(deg2rad(el)), ca = cr_cos(deg2rad(az)), sa = cr_sin(deg2rad(az));
-  const int n3[3] = {P.nx, P.ny, P.nz};
   for (int x = first + lane; x < P.snx; x += 64) {
-    float rr = __fadd_rn(__fmul_rn((float)x, P.s_vs[0]), P.s_origin[0]);
-    float xyd = __fmul_rn(rr, ce);
-    float px = __fmul_rn(xyd, ca), py = __fmul_rn(-xyd, sa), pz = __fmul_rn(rr, se);
-    float cyl[3];
-    cart_to_cyl(px, py, pz, cyl);
-    int cc[3];
-    if (cell_inrange(cyl, P.origin, P.pmax, P.vs, n3, cc)) occ_raw[cell_index(P, b, cc[2], cc[1], cc[0])] = 1;
+    const int c = backproject_cell(P, x, ce, se, ca, sa);
+    if (c >= 0) occ_b[c] = 1;
   }
 }
 
@@ -435,15 +468,7 @@ extern "C" size_t btc_occ_targets_ws_bytes(const BtcOccConfig* cfg) {
   return occ_ws_layout(cfg, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
 }
 
-extern "C" int btc_occ_targets(const BtcOccConfig* cfg, float* voxels, const int32_t* voxel_coords, const int32_t* voxel_num,
-                               int M, int max_points, int C, const float* gt_boxes, const int32_t* gt_num,
-                               const float* mirr_flag, const float* bm_points, int n_bm, const float* rot_z,
-                               const float* centers, const BtcOccBuffers* out, void* ws, size_t ws_bytes, void* stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
-  BTC_CHECK_ARG(cfg && out, "btc_occ_targets: null config / buffers");
-  BTC_CHECK_ARG(C >= 3 && M >= 0 && max_points >= 1, "btc_occ_targets: bad voxel layout");
-  BTC_CHECK_ARG(ws_bytes >= btc_occ_targets_ws_bytes(cfg), "btc_occ_targets: workspace too small");
-  OccParams P;
+static void occ_params_from(const BtcOccConfig* cfg, OccParams& P) {
   P.B = cfg->batch;
   P.nx = cfg->grid[0]; P.ny = cfg->grid[1]; P.nz = cfg->grid[2];
   P.snx = cfg->sphere_grid[0]; P.sny = cfg->sphere_grid[1]; P.snz = cfg->sphere_grid[2];
@@ -459,6 +484,28 @@ extern "C" int btc_occ_targets(const BtcOccConfig* cfg, float* voxels, const int
   P.w_fore_cls = cfg->w_fore_cls; P.w_mirr_cls = cfg->w_mirr_cls; P.w_bm_cls = cfg->w_bm_cls; P.w_neg_cls = cfg->w_neg_cls;
   P.w_fore_res = cfg->w_fore_res; P.w_mirr_res = cfg->w_mirr_res; P.w_bm_res = cfg->w_bm_res; P.box_weight = cfg->box_weight;
   P.use_box_weight = cfg->use_box_weight;
+}
+
+extern "C" int btc_occ_backproject_lut(const BtcOccConfig* cfg, int32_t* lut, void* stream_) {
+  BTC_CHECK_ARG(cfg && lut, "btc_occ_backproject_lut: null config / table");
+  OccParams P;
+  occ_params_from(cfg, P);
+  BTC_CHECK_ARG(P.snx > 0 && P.sny > 0 && P.snz > 0, "btc_occ_backproject_lut: empty sphere grid");
+  occ_backproject_lut<<<btc_cdiv(P.snz * P.sny, 4), 256, 0, (hipStream_t)stream_>>>(P, lut);
+  BTC_LAUNCH_CHECK();
+  return BTC_OK;
+}
+
+extern "C" int btc_occ_targets(const BtcOccConfig* cfg, float* voxels, const int32_t* voxel_coords, const int32_t* voxel_num,
+                               int M, int max_points, int C, const float* gt_boxes, const int32_t* gt_num,
+                               const float* mirr_flag, const float* bm_points, int n_bm, const float* rot_z,
+                               const float* centers, const BtcOccBuffers* out, void* ws, size_t ws_bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  BTC_CHECK_ARG(cfg && out, "btc_occ_targets: null config / buffers");
+  BTC_CHECK_ARG(C >= 3 && M >= 0 && max_points >= 1, "btc_occ_targets: bad voxel layout");
+  BTC_CHECK_ARG(ws_bytes >= btc_occ_targets_ws_bytes(cfg), "btc_occ_targets: workspace too small");
+  OccParams P;
+  occ_params_from(cfg, P);
 
   const size_t vol = (size_t)P.nx * P.ny * P.nz * P.B;
   uint8_t *smap, *occ_raw, *mirr_raw;
@@ -495,7 +542,7 @@ extern "C" int btc_occ_targets(const BtcOccConfig* cfg, float* voxels, const int
   const int nrays = P.B * P.snz * P.sny;
   occ_ray_count<<<btc_cdiv(nrays, 4), T, 0, stream>>>(smap, P, ray_cnt);
   BTC_LAUNCH_CHECK();
-  occ_ray_project<<<btc_cdiv(nrays, 4), T, 0, stream>>>(smap, ray_cnt, P, occ_raw);
+  occ_ray_project<<<btc_cdiv(nrays, 4), T, 0, stream>>>(smap, ray_cnt, P, cfg->backproject_lut, occ_raw);
   BTC_LAUNCH_CHECK();
   if (n_bm > 0) {
     occ_bm_pass<<<btc_cdiv(n_bm, T), T, 0, stream>>>(bm_points, n_bm, gt_boxes, gt_num, rot_z, P, out->bm_voxelwise_mask, bm_sum, bm_cnt);

@@ -29,6 +29,40 @@ def cylinder_voxel_centers(grid_size, occ_range, voxel_size, device):
             "all_voxel_centers_2d": torch.mean(ctr[:, :, :, :2], dim=0).view(-1, 2).to(device)}
 
 
+def backproject_table_host(sphere_grid, sphere_range, sphere_voxel, grid, occ_range, occ_voxel, sphere_offset=(0.0, 0.0, 0.0)):
+    """(snz, sny, snx) int32 on the HOST: the cylinder cell z*ny*nx + y*nx + x that the corner of sphere cell [sz][sy][sx]
+    back-projects into, -1 when it leaves the cylinder range -- occ_from_cylin_ocp's second half
+    (/root/reference/btcdet/models/occ_pnt/occ_training_targets/occ_targets_template.py:146-152: index * reverse_sphere_voxel_size +
+    rever_sphere_origin_tensor -> coords_utils.sphere_uvd2absxyz (:180-186) -> cartesian_cylinder_coords (:229-239) ->
+    point2coords_inrange (:82-90)) evaluated ONCE for the whole corner lattice instead of per batch for the occluded cells: the
+    lattice does not move with the batch.  Same torch ops in the same order and dtypes as the reference, on the host, so the table
+    carries the host platform's float32 cos / sin / sqrt / atan2 -- the arithmetic a CPU run of the reference quantises on (every
+    corner lies exactly ON an azimuth cell boundary, so the cell index is decided by the last ulp: torch-CPU = MKL VML for cos /
+    sin / sqrt and Sleef_atan2f_u10, none of them correctly rounded; a CUDA run of the reference differs from both).  The kernels
+    then look cells up instead of evaluating transcendentals (csrc/occupancy.hip occ_ray_project)."""
+    snx, sny, snz = [int(v) for v in sphere_grid]
+    nx, ny, nz = [int(v) for v in grid]
+    rev_vs = torch.as_tensor([sphere_voxel[2], sphere_voxel[1], sphere_voxel[0]], dtype=torch.float32)
+    rev_origin = torch.as_tensor([[sphere_range[2], sphere_range[1], sphere_range[0]]], dtype=torch.float32)
+    z, y, x = torch.meshgrid(torch.arange(snz), torch.arange(sny), torch.arange(snx), indexing="ij")
+    ind = torch.stack([z, y, x], dim=-1).view(-1, 3)                          # what torch.nonzero yields for a full mask
+    sp = ind * rev_vs + rev_origin                                             # (el, az, r) of every corner, float32
+    sx, sy, sz = sp[..., 2], sp[..., 1], sp[..., 0]
+    xyd = sx * torch.cos(sz * np.pi / 180.)
+    carte = torch.stack([xyd * torch.cos(sy * np.pi / 180.), -xyd * torch.sin(sy * np.pi / 180.), sx * torch.sin(sz * np.pi / 180.)], dim=-1)
+    carte = carte - torch.as_tensor([list(sphere_offset)], dtype=torch.float32)
+    sq = torch.square(carte)
+    cyl = torch.stack([torch.sqrt(torch.sum(sq[..., 0:2], dim=-1)), torch.atan2(-carte[..., 1], carte[..., 0]) * (180. / np.pi), carte[..., 2]], dim=-1)
+    origin = torch.as_tensor([list(occ_range[:3])], dtype=torch.float32)
+    pmax = torch.as_tensor([list(occ_range[3:6])], dtype=torch.float32)
+    vs = torch.as_tensor([list(occ_voxel)], dtype=torch.float32)
+    ok = torch.cat([cyl >= origin, cyl <= pmax], dim=-1).all(-1)
+    c = ((cyl - origin) / vs).to(torch.int64)
+    c = torch.maximum(torch.minimum(c, torch.as_tensor([[nx - 1, ny - 1, nz - 1]], dtype=torch.int64)), torch.zeros((1, 3), dtype=torch.int64))
+    lut = torch.where(ok, (c[..., 2] * ny + c[..., 1]) * nx + c[..., 0], torch.full_like(c[..., 0], -1))
+    return lut.to(torch.int32).view(snz, sny, snx).contiguous()
+
+
 class OccTargets3D(nn.Module):
     def __init__(self, model_cfg, voxel_size, point_cloud_range, data_cfg, grid_size, num_class, voxel_centers):
         super().__init__()
@@ -78,6 +112,34 @@ class OccTargets3D(nn.Module):
         c.w_fore_res, c.w_mirr_res = lw.get("occ_fore_res_weight", 0.1), lw.get("occ_mirr_res_weight", 0.1)
         c.w_bm_res, c.box_weight = lw.get("occ_bm_res_weight", 0.1), occ.BOX_WEIGHT
         self._cfg = c
+        # back-projection of the occluded sphere cells (a10): "torch" (default) -- a static table made once with torch's own CPU
+        # kernels, i.e. the arithmetic a CPU run of the reference quantises on (backproject_table_host: 0 cells differ from the
+        # reference-pinned oracle); "device" -- the same table filled by the device's correctly-rounded transcendentals
+        # (btc_occ_backproject_lut); "inline" -- no table, the kernel evaluates them per occluded cell (rounds 1-3).
+        # OCC.TARGETS.BACKPROJECT in the model config, BTC_OCC_BACKPROJECT in the environment.
+        import os
+        self.backproject = os.environ.get("BTC_OCC_BACKPROJECT") or model_cfg.TARGETS.get("BACKPROJECT", "torch")
+        assert self.backproject in ("torch", "device", "inline"), self.backproject
+        self.sphere_offset = [float(v) for v in occ.get("SPHERE_OFFSET", [0.0, 0.0, 0.0])]
+        assert self.backproject == "torch" or not any(self.sphere_offset), "SPHERE_OFFSET needs the host-made table (BACKPROJECT: torch)"
+        self._lut = {}   # device -> table (plain attribute: not a buffer, so state_dict keys stay the reference's)
+
+    def backproject_table(self, dev):
+        """the static back-projection table on `dev` (None for BACKPROJECT: inline)"""
+        if self.backproject == "inline":
+            return None
+        key = str(dev)
+        lut = self._lut.get(key)
+        if lut is None:
+            c = self._cfg
+            if self.backproject == "torch":
+                lut = backproject_table_host(list(c.sphere_grid), list(c.sphere_range), list(c.sphere_voxel), list(c.grid), list(c.occ_range),
+                                             list(c.occ_voxel), self.sphere_offset).to(dev)
+            else:
+                lut = torch.empty((self.sphere_nz, self.sphere_ny, self.sphere_nx), dtype=torch.int32, device=dev)
+                check(lib().btc_occ_backproject_lut(ctypes.byref(c), ptr(lut), stream_ptr()), "btc_occ_backproject_lut")
+            self._lut[key] = lut
+        return lut
 
     def get_paddings_indicator(self, actual_num, max_num, axis=0):
         return actual_num.int().unsqueeze(1) > torch.arange(max_num, dtype=torch.int, device=actual_num.device).view(1, -1)
@@ -120,6 +182,8 @@ class OccTargets3D(nn.Module):
         bufs = BtcOccBuffers(**{k: out[k].data_ptr() for k in OCC_BUFFER_FIELDS})
         cfg = self._cfg
         cfg.batch, cfg.max_boxes = bs, G
+        lut = self.backproject_table(dev)
+        cfg.backproject_lut = lut.data_ptr() if lut is not None else None
         L = lib()
         ws_bytes = L.btc_occ_targets_ws_bytes(ctypes.byref(cfg))
         ws = workspace(ws_bytes, dev)

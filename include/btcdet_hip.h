@@ -391,6 +391,13 @@ typedef struct BtcOccConfig {
   float sphere_range[6], sphere_voxel[3];
   float det_zmin, det_zmax; /* DATA_CONFIG.POINT_CLOUD_RANGE[2], [5] */
   float w_fore_cls, w_mirr_cls, w_bm_cls, w_neg_cls, w_fore_res, w_mirr_res, w_bm_res, box_weight;
+  /* optional DEVICE table (snz, sny, snx) i32: the cylinder cell (z*ny*nx + y*nx + x) the corner of sphere cell [sz][sy][sx]
+   * back-projects into, -1 = out of range (occ_targets_template.py:146-152 -- a function of the two grids alone, so it is
+   * static).  NULL: the kernel evaluates the back-projection inline with correctly-rounded transcendentals.  The reference
+   * quantises these values exactly ON azimuth cell boundaries, so its result depends on the last ulp of the platform's
+   * cos / sin / atan2 / sqrt; a table evaluated with that platform's arithmetic reproduces its cells exactly
+   * (btc_occ_backproject_lut fills one with the device's own arithmetic). */
+  const int32_t* backproject_lut;
 } BtcOccConfig;
 
 typedef struct BtcOccBuffers {
@@ -402,6 +409,8 @@ typedef struct BtcOccBuffers {
 } BtcOccBuffers;
 
 size_t btc_occ_targets_ws_bytes(const BtcOccConfig* cfg);
+/* lut (snz, sny, snx) i32 <- the back-projection table above in the device's correctly-rounded arithmetic (cfg->batch unused) */
+int btc_occ_backproject_lut(const BtcOccConfig* cfg, int32_t* lut, void* stream);
 int btc_occ_targets(const BtcOccConfig* cfg, float* voxels, const int32_t* voxel_coords, const int32_t* voxel_num,
                     int M, int max_points, int C, const float* gt_boxes, const int32_t* gt_num, const float* mirr_flag,
                     const float* bm_points, int n_bm, const float* rot_z, const float* centers,

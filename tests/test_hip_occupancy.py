@@ -1,6 +1,11 @@
 """GPU parity of the occupancy / occlusion target generator (btc_occ_targets) against the CPU oracle
 (which is itself pinned bit-for-bit to the real reference, tests/test_oracle_golden.py).
 
+Round 4: the back-projection of the occluded sphere cells is a static table (OccTargets3D.backproject).  With the default table --
+made once by torch's own CPU kernels, the arithmetic a CPU run of the reference quantises on -- the occlusion mask and every mask
+derived from it are BIT-EXACT against the reference-pinned oracle on all six batches (test_occ_targets_exact_vs_reference_oracle).
+The text below describes the "inline" / "device" modes (correctly-rounded transcendentals on the GPU), kept and tested as before.
+
 Integer-only stages (voxel mask, vcc dilation, everything derived by pure logic) must match exactly.
 Stages that quantise an fp32 transcendental result (atan2f / sinf / cosf differ from the CPU libm by an
 ulp) are compared with a stated tolerance: the back-projected occlusion mask places every sphere-cell
@@ -22,8 +27,11 @@ from btcdet_amd.config import load_cfg
 pytestmark = pytest.mark.gpu
 
 
-def run_gpu(bd, cfg, dev):
+def run_gpu(bd, cfg, dev, backproject="inline"):
     from btcdet_amd.occ_targets import OccTargets3D, cylinder_voxel_centers
+    import copy
+    cfg = copy.deepcopy(cfg)
+    cfg.MODEL.OCC.TARGETS["BACKPROJECT"] = backproject
     d = cfg.DATA_CONFIG
     occ_range = np.array(d.OCC.POINT_CLOUD_RANGE, dtype=np.float32)
     grid = np.round((occ_range[3:6] - occ_range[0:3]) / np.array(d.OCC.VOXEL_SIZE)).astype(np.int64)
@@ -65,17 +73,59 @@ def compare(out, ref, exact_keys, fuzzy_keys):
         assert stray <= STRAY_TOL * tot + 2, (k, stray, tot)       # ... except where the height index flips as well
 
 
+def _batch(which):
+    if which == "golden":
+        return golden_batch()[2]
+    if which == "kitti":
+        return kitti_batch()
+    from golden_batch import golden_batch_full   # full-size / edge-case batches of the reference (empty scene, 0 boxes, no bm_points key, 40-point scene)
+    return golden_batch_full(which)[2]
+
+
+EXACT_MASKS = ["voxelwise_mask", "vcc_mask", "voxel_point_mask", "final_point_mask", "occ_voxelwise_mask", "general_cls_loss_mask"]
+
+
+@pytest.mark.parametrize("which", ["golden", "kitti", "full_a", "full_b", "full_c", "full_d"])
+def test_occ_targets_exact_vs_reference_oracle(which):
+    """the DEFAULT path (BACKPROJECT: torch): 0 cells of the occlusion mask differ from the reference-pinned oracle, hence every
+    mask that is (geometry) & (occlusion) is exact wherever the geometry masks are (they are, on these batches)"""
+    dev = torch.device("cuda:0")
+    cfg = load_cfg()
+    assert cfg.MODEL.OCC.TARGETS.get("BACKPROJECT", "torch") == "torch"
+    bd = _batch(which)
+    ref = occ_oracle.OccOracle(cfg).targets(bd)
+    out, _ = run_gpu(bd, cfg, dev, backproject="torch")
+    for k in EXACT_MASKS:
+        a, b = out[k].cpu(), ref[k]
+        nd = int((a.to(b.dtype) != b).sum())
+        print("%s vs the reference-pinned oracle: %d cells differ of %d set" % (k, nd, int(b.bool().sum())))
+        assert nd == 0, (k, nd)
+    geo_ok = all(torch.equal(out[k].cpu() > 0, ref[k] > 0) for k in ["fore_voxelwise_mask", "bm_voxelwise_mask"])
+    assert geo_ok
+    for k in ["pos_mask", "occ_fore_cls_mask", "occ_mirr_cls_mask", "occ_bm_cls_mask", "general_reg_loss_mask", "forebox_label"]:
+        assert torch.equal(out[k].cpu() > 0, ref[k] > 0), k
+    assert int(out["pos_all_num"]) == int(ref["pos_all_num"])
+    assert torch.equal(out["general_cls_loss_mask_float"].cpu(), ref["general_cls_loss_mask_float"])
+    assert torch.equal(out["general_reg_loss_mask_float"].cpu(), ref["general_reg_loss_mask_float"])
+    assert float((out["res_mtrx"].cpu() - ref["res_mtrx"]).abs().max()) <= 1e-3      # float atomics: order of the per-cell sums
+
+
+def test_device_table_equals_inline_back_projection():
+    """BACKPROJECT: device (table filled by btc_occ_backproject_lut) == inline evaluation, bit for bit"""
+    dev = torch.device("cuda:0")
+    cfg = load_cfg()
+    bd = _batch("full_a")
+    a, _ = run_gpu(bd, cfg, dev, backproject="inline")
+    b, _ = run_gpu(bd, cfg, dev, backproject="device")
+    for k in EXACT_MASKS + ["pos_mask", "general_reg_loss_mask"]:
+        assert torch.equal(a[k], b[k]), k
+
+
 @pytest.mark.parametrize("which", ["golden", "kitti", "full_a", "full_b", "full_c", "full_d"])
 def test_occ_targets_vs_oracle(which):
     dev = torch.device("cuda:0")
     cfg = load_cfg()
-    if which == "golden":
-        _, _, bd = golden_batch()
-    elif which == "kitti":
-        bd = kitti_batch()
-    else:   # full-size / edge-case batches of the reference (empty scene, 0 boxes, no bm_points key, 40-point scene)
-        from golden_batch import golden_batch_full
-        _, _, bd, _ = golden_batch_full(which)
+    bd = _batch(which)
     O = occ_oracle.OccOracle(cfg)
     ref = O.targets(bd)
     with occ_oracle.trig_mode(True):
