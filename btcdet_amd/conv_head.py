@@ -11,8 +11,9 @@ What runs where: every ROI (B x 128 in training) is cut into a GRID_SIZE (3 x 3 
    B x 128 x 27 = 6912 micro-scenes in one sparse tensor (csrc/rulebook.hip / conv kernels, tests/test_hip_roi_microscenes.py);
 the three sources are concatenated per lattice point and handed to the shared FC / cls / reg layers.
 
-Not built: target assignment (ProposalTargetLayer) and the RCNN losses of RoIHeadTemplate -- `forward` therefore takes the ROIs
-from `batch_dict['rois']` or from the proposal step (dense_head.proposal_layer) and stops at the predictions."""
+Training side: target assignment (ProposalTargetLayer) and the RCNN cls / reg / corner losses of RoIHeadTemplate live in
+btcdet_amd/roi_targets.py (`assign_targets`, `get_loss`); `forward` takes the ROIs from `batch_dict['rois']` or from the proposal
+step (dense_head.proposal_layer)."""
 from functools import partial
 
 import numpy as np

@@ -109,6 +109,22 @@ __device__ __forceinline__ void btc_st1(float* base, size_t i, float a) {
   else reinterpret_cast<unsigned short*>(base)[i] = btc_f32_to_bf16(a);
 }
 
+// hipFuncSetAttribute (dynamic LDS size) is a per-DEVICE attribute: one flag per device the process touches, not one per process
+// (a process that drives two GPUs would otherwise launch with the default 64 KB limit on the second one)
+#ifdef __cplusplus
+#include <mutex>
+constexpr int BTC_MAX_DEVICES = 16;
+struct BtcPerDeviceOnce {
+  std::once_flag flag[BTC_MAX_DEVICES];
+};
+template <class F>
+static inline void btc_once_per_device(BtcPerDeviceOnce& o, F&& fn) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::call_once(o.flag[dev >= 0 && dev < BTC_MAX_DEVICES ? dev : 0], fn);
+}
+#endif
+
 static inline int btc_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 static inline size_t btc_align(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 static inline unsigned btc_pow2_ge(unsigned long long v) {

@@ -202,8 +202,8 @@ int launch_b(const unsigned short* feat, const unsigned short* Wq, const float* 
   constexpr int TM = 16 * WR, TN = 16 * NTW * WC;
   const size_t lds = lds_bytes_b(TM, TN, KC, K);
   BTC_CHECK_ARG(lds <= 160 * 1024, "conv_apply_b: tile does not fit the LDS");
-  static std::once_flag once;   // launches come from the training thread, the autograd thread and the prefetch thread
-  std::call_once(once, [] {
+  static BtcPerDeviceOnce once;   // launches come from the training thread, the autograd thread and the prefetch thread
+  btc_once_per_device(once, [] {
     (void)hipFuncSetAttribute((const void*)conv_apply_b<WR, WC, NTW, KC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   });
   dim3 grid(btc_cdiv(n_rows, TM), Cres / TN);

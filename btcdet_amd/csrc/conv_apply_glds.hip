@@ -309,8 +309,8 @@ int launch_g(const void* feat, const float* W, const float* bias, const int32_t*
   xcd = (xcd & 15) | (stages << 4);
   const size_t lds = btc_apply_glds_lds_bytes(WR * 100 + WC * 10 + NTW, KC, K, BF, stages);
   BTC_CHECK_ARG(lds <= 160 * 1024, "conv_apply_g: tile does not fit the LDS");
-  static std::once_flag once;   // launches come from the training thread, the autograd thread and the prefetch thread
-  std::call_once(once, [] {
+  static BtcPerDeviceOnce once;   // launches come from the training thread, the autograd thread and the prefetch thread
+  btc_once_per_device(once, [] {
     (void)hipFuncSetAttribute((const void*)conv_apply_g<WR, WC, NTW, TRANS_W, KC, BF>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               160 * 1024);
   });

@@ -244,8 +244,8 @@ int launch_s(const float* feat, const unsigned short* Ws, const float* bias, con
   constexpr int TM = 16 * WR, TN = 16 * NTW * WC;
   const size_t lds = lds_bytes_s(TM, TN, KC, K, S_STAGES);
   BTC_CHECK_ARG(lds <= 160 * 1024, "conv_apply_s: tile does not fit the LDS");
-  static std::once_flag once;   // launches come from the training thread, the autograd thread and the prefetch thread
-  std::call_once(once, [] {
+  static BtcPerDeviceOnce once;   // launches come from the training thread, the autograd thread and the prefetch thread
+  btc_once_per_device(once, [] {
     (void)hipFuncSetAttribute((const void*)conv_apply_s<WR, WC, NTW, KC, S_STAGES>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   });
   dim3 grid(btc_cdiv(n_rows, TM), Cres / TN, zsplit);

@@ -37,17 +37,30 @@ extern "C" int btc_tune_set(int key, int value) {
 // serialised, so one buffer per stream is enough; the caller keeps it alive until it registers another (or NULL) for the stream.
 #include <mutex>
 #include <unordered_map>
+// Keyed by (current device, stream handle): the default stream's handle is 0 on EVERY device, so a process that drives two GPUs
+// must not find device 1's buffer when it launches on device 0.
+#include <map>
 static std::mutex g_scratch_mu;
-static std::unordered_map<void*, std::pair<void*, size_t>> g_scratch;
+static std::map<std::pair<int, void*>, std::pair<void*, size_t>> g_scratch;
+static std::pair<int, void*> scratch_key(void* stream) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  return std::make_pair(dev, stream);
+}
 extern "C" int btc_set_scratch(void* stream, void* ptr, size_t bytes) {
+  auto key = scratch_key(stream);
+  hipPointerAttribute_t attr;
+  if (ptr && hipPointerGetAttributes(&attr, ptr) == hipSuccess) key.first = attr.device;   // the buffer's device, whatever is current
+  else (void)hipGetLastError();
   std::lock_guard<std::mutex> lock(g_scratch_mu);
-  if (!ptr || !bytes) g_scratch.erase(stream);
-  else g_scratch[stream] = std::make_pair(ptr, bytes);
+  if (!ptr || !bytes) g_scratch.erase(key);
+  else g_scratch[key] = std::make_pair(ptr, bytes);
   return BTC_OK;
 }
 void* btc_scratch(hipStream_t stream, size_t* bytes) {
+  const auto key = scratch_key((void*)stream);
   std::lock_guard<std::mutex> lock(g_scratch_mu);
-  auto it = g_scratch.find((void*)stream);
+  auto it = g_scratch.find(key);
   if (it == g_scratch.end()) { *bytes = 0; return nullptr; }
   *bytes = it->second.second;
   return it->second.first;

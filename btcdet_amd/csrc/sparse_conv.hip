@@ -1074,8 +1074,8 @@ int launch_apply(const float* feat, const float* W, const float* bias, const int
     int wgs = btc_cdiv(n_tiles16, WS_WAVES);
     if (wgs > 256) wgs = 256;
     size_t lds = ws_lds_bytes(K, Cred, nt);
-    static std::once_flag once;
-    std::call_once(once, [] {
+    static BtcPerDeviceOnce once;
+    btc_once_per_device(once, [] {
       (void)hipFuncSetAttribute((const void*)conv_apply_ws<1, TRANS_W>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       (void)hipFuncSetAttribute((const void*)conv_apply_ws<2, TRANS_W>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     });
@@ -1110,8 +1110,8 @@ int launch_apply(const float* feat, const float* W, const float* bias, const int
 template <int MT, int NT, int KB, int PH, bool BF>
 void launch_wgrad_rows_p(dim3 grid, size_t lds, hipStream_t stream, const float* g, const float* c, const int32_t* map, const int32_t* ord, int rows,
                          int K, int Cg, int Cc, float* part, int swap) {
-  static std::once_flag once;   // launches come from the training thread, the autograd thread and the prefetch thread
-  std::call_once(once, [] {
+  static BtcPerDeviceOnce once;   // launches come from the training thread, the autograd thread and the prefetch thread
+  btc_once_per_device(once, [] {
     (void)hipFuncSetAttribute((const void*)conv_wgrad_rows_p<MT, NT, KB, PH, BF>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   });
   conv_wgrad_rows_p<MT, NT, KB, PH, BF><<<grid, 256, lds, stream>>>(g, c, map, ord, rows, K, Cg, Cc, part, swap);

@@ -205,6 +205,10 @@ class BucketedGradSync(object):
         if ev is not None:
             ev.synchronize()   # recorded a whole step ago
         m1, m2 = float(host[0]), float(host[1])
+        if m1 != 0.0 or m2 != 0.0:
+            # some rank had gaps in that step: the REDUCED tail in this rank's flat buffer is non-zero whether or not this rank wrote
+            # one locally -- it must not travel into the next all-reduce (matters when the error below is caught by the caller)
+            b.dirty_tail = True
         if self.reduce_op != dist.ReduceOp.AVG and not self.stage_on_host and self.comm is None:
             m1, m2 = m1 / self.world, m2 / self.world    # (sum transport: scaled in wait(), after these values were read)
         if m2 - m1 * m1 > 1e-3 * max(1.0, m2):   # variance over the ranks of the number of missing gradients: the same number on every rank
@@ -220,7 +224,9 @@ class BucketedGradSync(object):
             b.flat.zero_()
             b.flat[-2:].copy_(torch.tensor([float(n_missing), float(n_missing) ** 2], dtype=torch.float32), non_blocking=False)
             b.dirty_tail = True
-        elif b.dirty_tail:
+        elif b.dirty_tail or not self.check_consistency:
+            # (BTC_SYNC_CHECK=0: nobody reads the reduced tail back, so nobody learns that another rank made it non-zero -- zero it
+            # every step, 8 bytes)
             b.flat[-2:].zero_()
             b.dirty_tail = False
         if not have:
@@ -292,7 +298,15 @@ class BucketedGradSync(object):
     # ------------------------------------------------------------------------------------------------ optimizer interface
     def has_grad(self, param):
         """every parameter of a reduced bucket counts as present on every rank (a rank without a local gradient contributed
-        zeros to the mean): the decision is the same everywhere by construction"""
+        zeros to the mean): the decision is the same everywhere by construction.
+
+        Known divergence from a single-process run (documented): a parameter that is unused on ALL ranks in a step
+        -- the one legal case of a missing gradient -- gets a zero-gradient Adam step here (its moments decay, its step counter
+        advances, decoupled weight decay applies), while torch.optim.Adam / the reference / this optimizer at N = 1 skip a
+        grad-is-None parameter.  Skipping it here too would need the REDUCED count of gaps at optimizer time, i.e. a read-back
+        between the all-reduce and the optimizer step of every step; the configured models use every parameter in every step
+        (DistributedDataParallel(find_unused_parameters=False) in the reference, tools/train.py:166-168), so the step is not
+        paid for.  local_missing() tells a caller that wants the skip which parameters this rank had no gradient for."""
         return True
 
     def missing(self):

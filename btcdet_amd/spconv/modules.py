@@ -105,7 +105,9 @@ class SparseSequential(SparseModule):
             while i < len(mods):
                 conv = mods[i]
                 bn = mods[i + 1] if i + 1 < len(mods) else None
-                if not (isinstance(conv, SparseConvolution) and not conv.conv1x1 and conv.ndim == 3 and bn is not None and fused_bn.fusable(bn)) \
+                # structure only (a BatchNorm1d behind a 3-D sparse conv): whether the BatchNorm is fusable IN ITS CURRENT STATE is asked per
+                # call below -- an eval sanity pass before training must not switch the fast path off for good
+                if not (isinstance(conv, SparseConvolution) and not conv.conv1x1 and conv.ndim == 3 and isinstance(bn, nn.BatchNorm1d)) \
                         or ops.pads_in_channels(conv.in_channels):   # (padded per layer: ops._pad_in_channels)
                     triples = None
                     break
@@ -143,7 +145,11 @@ class SparseSequential(SparseModule):
         F = ops.fast()
         # what does not change from call to call (parameters, buffers, BatchNorm constants, workspace sizes) is gathered once per
         # (training flags, weight tensors) of the chain; per call only the rulebook's maps / row orders and the row counts differ
-        key = tuple((bn.training, bn.track_running_stats, id(conv.weight)) for conv, bn, _, _, _ in plan)
+        # (nn.Module._apply -- .to(device), .float() -- and load_state_dict(assign=True) REPLACE buffer tensors and keep Parameter
+        # identity: the buffers' and the affine parameters' identities are part of the key, or the chain would go on reading and
+        # updating tensors the module no longer owns)
+        key = tuple((bn.training, bn.track_running_stats, id(conv.weight), id(conv.bias), id(bn.weight), id(bn.bias), id(bn.running_mean),
+                     id(bn.running_var), id(bn.num_batches_tracked), conv.weight.device) for conv, bn, _, _, _ in plan)
         st = self.__dict__.get("_chain_static")
         if st is None or st[0] != key:
             w, b, ga, be, rms, rvs, nbts, ub, mom, eps, relus, need, dfr = ([] for _ in range(13))

@@ -128,6 +128,8 @@ def make_step(model, ddp, proc, opts, grad_sync=None, prefetch_stream=None, thre
         from concurrent.futures import ThreadPoolExecutor as _TPE
         prep_pool = _TPE(max_workers=1)
 
+    occ_failed = []   # the worker's exception, if its backward / bucket launch raised (looked at by the training thread, below)
+
     def occ_tail(loss_occ, next_batch, occ_done, prep_future=None):
         import time
         torch.cuda.set_device(device)
@@ -138,6 +140,9 @@ def make_step(model, ddp, proc, opts, grad_sync=None, prefetch_stream=None, thre
             _ops.join_wgrad()            # (no-op: the end-of-pass callback has joined the side stream into this thread's stream)
             if grad_sync is not None:    # issued BEFORE the hand-over: every rank's order is occupancy bucket, then detection bucket
                 grad_sync.launch(bucket_of["occ"])
+        except BaseException as e:       # recorded BEFORE the hand-over: the training thread must not issue the detection bucket's
+            occ_failed.append(e)         # collective when this rank never issued the occupancy bucket's (fixed per-rank order)
+            raise
         finally:
             occ_done.set()
         if timing is not None:
@@ -198,6 +203,13 @@ def make_step(model, ddp, proc, opts, grad_sync=None, prefetch_stream=None, thre
             loss_det = det_loss(ret, bd)
         t = _mark("det_forward", t)
         occ_done.wait()
+        if occ_failed:
+            # the occupancy bucket was not launched on this rank: launching the detection bucket now would pair it with the other
+            # ranks' occupancy bucket (different size) -- an RCCL hang or silently mis-reduced buffers.  Fail here, cleanly.
+            err = occ_failed.pop()
+            occ_failed.clear()
+            raise RuntimeError("the occupancy branch's backward / bucket launch failed on this rank; the detection bucket's all-reduce "
+                               "is NOT issued (collective order)") from err
         t = _mark("wait_occ_backward", t)
         with torch.cuda.stream(det_stream):
             loss_det.backward()
@@ -318,7 +330,10 @@ def reference_groups(model, world=1, epochs=40, frames=3712, batch_size=2):
     det = [p for p in model.det_modules.parameters() if p.requires_grad]
     sched = dict(grad_norm_clip=10.0, moms=(0.95, 0.85), div_factor=10.0, pct_start=0.4, lr_clip=1e-7)
     groups = [dict(params=occ, lr=0.003, weight_decay=0.001, **sched), dict(params=det, lr=0.01, weight_decay=0.01, **sched)]
-    return groups, epochs * (frames // (batch_size * world))
+    # len(train_loader) of the reference: DistributedSampler pads every rank to ceil(frames / world) samples, the DataLoader
+    # (drop_last False) then yields ceil(that / batch_size) batches (tools/train.py:111-123, build_dataloader)
+    per_rank = -(-frames // world)
+    return groups, epochs * (-(-per_rank // batch_size))
 
 
 class HotPathTrainer(object):
@@ -355,10 +370,12 @@ class HotPathTrainer(object):
         self.grad_sync = None
         if distributed:
             from .grad_sync import BucketedGradSync
+            # `src` of dist.broadcast is a GLOBAL rank: member 0 of a sub-group is not global rank 0
+            src = dist.get_global_rank(process_group, 0) if process_group is not None else 0
             for p in model.parameters():   # same start on every rank (DistributedDataParallel does this broadcast in its constructor)
-                dist.broadcast(p.data, src=0, group=process_group)
+                dist.broadcast(p.data, src=src, group=process_group)
             for b in model.buffers():
-                dist.broadcast(b.data, src=0, group=process_group)
+                dist.broadcast(b.data, src=src, group=process_group)
             gs = [g["params"] for g in optimizer.groups]
             self.grad_sync = BucketedGradSync([(gs[0], None), (gs[1], None)], process_group=process_group, assign_grads=False)
             self.grad_sync.bucket_of = {"occ": 0, "det": 1}

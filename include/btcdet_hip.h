@@ -260,7 +260,8 @@ int btc_conv_split_supported(int K, int Cred, int Cres);
  * keeps it alive until it registers another buffer, or NULL, for that stream).  Used by the split-operand kernel on levels of a few
  * thousand rows: up to four workgroups share a tile's (offset, chunk) items, write partial sums to slabs of n_rows x Cout floats in
  * the scratch and a second launch adds the slabs in order (deterministic; bias and the BatchNorm statistics move to that launch).
- * Without a buffer (or with one too small for two slabs) such launches run unsplit. */
+ * Without a buffer (or with one too small for two slabs) such launches run unsplit.  The registry is keyed by (device of `ptr`,
+ * stream handle) -- the default stream's handle is 0 on every device --; with ptr == NULL the current device's entry is removed. */
 int btc_set_scratch(void* stream, void* ptr, size_t bytes);
 /* the host bindings' policy: 1 = an fp32 launch of n_rows rows should take the split-operand kernel (0 always under BTC_TUNE_SPLIT = 1) */
 int btc_conv_split_wanted(int K, int Cred, int Cres, int n_rows);
