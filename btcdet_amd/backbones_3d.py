@@ -319,7 +319,7 @@ class VoxelBackBone8xOcc(nn.Module):
         """run a SparseSequential stage.  With the walk's rulebooks at hand (ready = (plan, rulebooks)) a pure conv -> BatchNorm -> ReLU
         stage goes straight into ONE call of the compiled binding (SparseSequential._run_chain) -- no module call, no rulebook
         look-ups, no per-layer Python: the training thread's forward pass is bound by exactly that"""
-        from .spconv import modules as sp_modules, ops as sp_ops
+        from .spconv import fused_bn as sp_fused_bn, modules as sp_modules, ops as sp_ops
         if ready is not None and sp_modules.CHAIN_LAYERS and sp_modules.FUSE_CONV_BN and sp_modules.FUSE_BN_RELU and sp_ops.PROFILE is None \
                 and sp_ops.CAPTURE is None and sp_ops.NATIVE_AUTOGRAD and sp_ops.fast() is not None:   # (the conditions of SparseSequential's own chain path)
             plan, rbs = ready
@@ -330,6 +330,7 @@ class VoxelBackBone8xOcc(nn.Module):
                 triples = stage.__dict__.get("_chain_triples", None)
             f = x.features
             if sl is not None and triples and len(triples) == sl[1] - sl[0] and f.is_cuda and f.shape[0] > 0 and \
+                    all(sp_fused_bn.fusable(bn) for _, bn, _ in triples) and \
                     (f.dtype == torch.float32 or all(c.in_channels % 16 == 0 and c.out_channels % 16 == 0 for c, _, _ in triples)):
                 mine = rbs[sl[0]:sl[1]]
                 if all(rb is not None and rb.n_out > 0 for rb in mine):
@@ -531,6 +532,8 @@ class SparseBasicBlock(spconv.SparseModule):
 def _bn_act(bn, feats, relu):
     """BatchNorm1d (+ ReLU) over sparse features through the fused HIP kernels when they apply"""
     from .spconv import fused_bn
+    if feats.is_cuda and feats.dim() == 2 and fused_bn.is_sync(bn):     # --sync_bn: statistics over all ranks' rows
+        return fused_bn.sync_batch_norm_relu(bn, feats, relu)
     if feats.is_cuda and feats.dim() == 2 and feats.shape[0] > 0 and fused_bn.fusable(bn):
         return fused_bn.batch_norm_relu(bn, feats, relu)
     y = bn(feats)

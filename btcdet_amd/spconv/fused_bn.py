@@ -120,8 +120,124 @@ class BatchNormReLUFunction(torch.autograd.Function):
 
 
 def fusable(bn):
+    """this BatchNorm1d, in its current state, through the rank-local fused kernels?  (Not when it synchronises its batch statistics
+    over a process group: is_sync)"""
     return isinstance(bn, torch.nn.BatchNorm1d) and bn.affine == (bn.weight is not None) and \
-        (bn.momentum is not None) and (bn.track_running_stats or bn.training)
+        (bn.momentum is not None) and (bn.track_running_stats or bn.training) and not is_sync(bn)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# --sync_bn (/root/reference/tools/train.py:32,130-131: torch.nn.SyncBatchNorm.convert_sync_batchnorm): the batch statistics of a
+# BatchNorm1d over sparse features taken over ALL ranks' rows.  convert_sync_batchnorm() below marks the modules (same objects, same
+# parameters, buffers and state_dict keys); SparseSequential then routes them here.  Per layer and step, as torch's SyncBatchNorm:
+# one all_gather of (mean, biased var, count) forward, one all_reduce of (sum dy x^, sum dy) backward -- the normalisation and its
+# backward are the fused HIP kernels in their given-statistics mode (btc_bn_relu_fwd / _bwd, training = 0) plus one elementwise
+# correction for the two mean terms.
+# ----------------------------------------------------------------------------------------------------------------------
+def is_sync(bn):
+    return getattr(bn, "sync_group", None) is not None and bn.training
+
+
+def convert_sync_batchnorm(module, process_group=None):
+    """mark every nn.BatchNorm1d under `module` to synchronise its batch statistics over process_group (default: the world) while in
+    training mode; a world of one rank leaves the module alone.  -> number of modules marked"""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(process_group) == 1:
+        return 0
+    n = 0
+    for m in module.modules():
+        if isinstance(m, torch.nn.BatchNorm1d) and m.affine and m.momentum is not None:
+            m.sync_group = process_group if process_group is not None else dist.group.WORLD
+            n += 1
+    return n
+
+
+def combine_stats(gathered, C):
+    """gathered (W, 2C + 1): per rank (mean | biased var | row count) -> (mean, biased var, total count) of the concatenated batch
+    (Chan et al.'s pairwise update, all ranks at once; ranks without rows carry count 0)"""
+    cnt = gathered[:, 2 * C:2 * C + 1]
+    n = cnt.sum()
+    mean = (gathered[:, :C] * cnt).sum(0) / n
+    var = ((gathered[:, C:2 * C] + (gathered[:, :C] - mean) ** 2) * cnt).sum(0) / n
+    return mean, var, n
+
+
+def _via_host(group):
+    import torch.distributed as dist
+    return dist.get_backend(group) == "gloo"   # (2 ranks on ONE GPU in the tests: device tensors staged through the host)
+
+
+def _all_gather_rows(t, group):
+    import torch.distributed as dist
+    W = dist.get_world_size(group)
+    src = t.cpu() if _via_host(group) else t
+    out = torch.empty((W,) + tuple(src.shape), dtype=src.dtype, device=src.device)
+    dist.all_gather_into_tensor(out, src.contiguous(), group=group) if not _via_host(group) else \
+        dist.all_gather(list(out.unbind(0)), src.contiguous(), group=group)
+    return out.to(t.device)
+
+
+def _all_reduce_sum(t, group):
+    import torch.distributed as dist
+    if _via_host(group):
+        h = t.cpu()
+        dist.all_reduce(h, group=group)
+        return h.to(t.device)
+    dist.all_reduce(t, group=group)
+    return t
+
+
+class SyncBatchNormReLUFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, num_batches_tracked, momentum, eps, relu, group):
+        x = x.contiguous()
+        N, C = x.shape
+        xf = x if x.dtype == torch.float32 else x.float()
+        if N > 0:
+            var_l, mean_l = torch.var_mean(xf, dim=0, unbiased=False)
+        else:
+            var_l = mean_l = torch.zeros((C,), dtype=torch.float32, device=x.device)
+        mine = torch.cat([mean_l, var_l, torch.full((1,), float(N), dtype=torch.float32, device=x.device)])
+        mean, var, n = combine_stats(_all_gather_rows(mine, group), C)
+        if running_mean is not None:   # torch's update: unbiased variance of the WHOLE batch
+            with torch.no_grad():
+                running_mean.mul_(1.0 - momentum).add_(mean, alpha=momentum)
+                running_var.mul_(1.0 - momentum).add_(var * (n / (n - 1.0).clamp_(min=1.0)), alpha=momentum)
+                if num_batches_tracked is not None:
+                    num_batches_tracked.add_(1)
+        # normalisation (+ ReLU) with GIVEN statistics: the fused kernel's eval path
+        y, stats = bn_forward(x, weight, bias, mean.contiguous(), var.contiguous(), None, False, momentum, eps, relu) if N > 0 else \
+            (torch.empty_like(x), torch.stack([mean, torch.rsqrt(var + eps)]))
+        ctx.save_for_backward(x, y, weight, stats, n)
+        ctx.meta = (bool(relu), group)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, weight, stats, n = ctx.saved_tensors
+        relu, group = ctx.meta
+        N, C = x.shape
+        if N > 0:
+            dy = (dy if dy.dtype == x.dtype else dy.to(x.dtype)).contiguous()
+            dx_e, dgamma, dbeta = bn_backward(x, y, dy, weight, stats, False, relu)     # dx_e = gamma rstd dy', dgamma = sum dy' x^, dbeta = sum dy'
+        else:
+            dx_e, dgamma, dbeta = torch.empty_like(x), torch.zeros_like(weight), torch.zeros_like(weight)
+        tot = _all_reduce_sum(torch.stack([dgamma, dbeta]), group)
+        if N > 0:
+            mean, rstd = stats[0], stats[1]
+            a = weight * rstd * rstd * tot[0] / n
+            b = weight * rstd * tot[1] / n - mean * a
+            dx = torch.addcmul(dx_e.float() - b, x.float(), a, value=-1.0).to(x.dtype)   # - gamma rstd (mean(dy') + x^ mean(dy' x^)) over ALL ranks' rows
+        else:
+            dx = dx_e
+        return dx, dgamma, dbeta, None, None, None, None, None, None, None
+
+
+def sync_batch_norm_relu(bn, x, relu):
+    """training-mode bn(x) [+ ReLU] with the statistics of all ranks' rows (is_sync(bn)); (N, C) float32 / bfloat16 GPU tensor"""
+    tr = bn.track_running_stats
+    return SyncBatchNormReLUFunction.apply(x, bn.weight, bn.bias, bn.running_mean if tr else None, bn.running_var if tr else None,
+                                           bn.num_batches_tracked if tr else None, bn.momentum, bn.eps, relu, bn.sync_group)
 
 
 def batch_norm_relu(bn, x, relu):

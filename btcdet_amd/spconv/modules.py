@@ -205,7 +205,12 @@ class SparseSequential(SparseModule):
                 if isinstance(input, SparseConvTensor):
                     if input.indices.shape[0] != 0:
                         f = input.features
-                        if FUSE_BN_RELU and fused_bn.fusable(module) and f.is_cuda and f.dtype in (nn_float32, _torch.bfloat16) and f.dim() == 2:
+                        if fused_bn.is_sync(module) and f.is_cuda and f.dtype in (nn_float32, _torch.bfloat16) and f.dim() == 2:
+                            # --sync_bn: batch statistics over all ranks' rows (fused_bn.SyncBatchNormReLUFunction)
+                            relu = i < len(mods) and type(mods[i]) is nn.ReLU
+                            input.features = fused_bn.sync_batch_norm_relu(module, f, relu)
+                            i += int(relu)
+                        elif FUSE_BN_RELU and fused_bn.fusable(module) and f.is_cuda and f.dtype in (nn_float32, _torch.bfloat16) and f.dim() == 2:
                             # BatchNorm1d (+ the ReLU that follows it): one fused HIP call, same parameters / buffers
                             relu = i < len(mods) and type(mods[i]) is nn.ReLU
                             input.features = fused_bn.batch_norm_relu(module, f, relu)

@@ -341,7 +341,7 @@ class HotPathTrainer(object):
     when a process group exists, the streams and the worker thread of the chosen schedule."""
 
     def __init__(self, model, groups=None, total_steps=None, schedule=None, distributed=None, det_loss=None, process_group=None,
-                 optimizer=None, reserve_bytes=None):
+                 optimizer=None, reserve_bytes=None, sync_bn=False):
         import torch.distributed as dist
         from .spconv import ops
         from .train_step import GroupOptimizer
@@ -368,6 +368,16 @@ class HotPathTrainer(object):
             optimizer = GroupOptimizer(groups, total_steps)
         self.optimizer = optimizer
         self.grad_sync = None
+        self.sync_bn = 0
+        if distributed and sync_bn:
+            # --sync_bn of the reference (tools/train.py:32,130-131): every BatchNorm1d over sparse features takes its batch statistics
+            # over all ranks' rows (spconv/fused_bn.py); the conv -> BatchNorm fusion and the compiled layer chains step aside for
+            # these modules (one all_gather forward and one all_reduce backward per layer, as torch.nn.SyncBatchNorm).  Both
+            # branches issue collectives from their own threads under the pipelined schedule, so sync_bn runs in order.
+            from .spconv import fused_bn
+            self.sync_bn = fused_bn.convert_sync_batchnorm(model, process_group)
+            if self.sync_bn and schedule == "pipelined":
+                schedule = self.schedule = "split"
         if distributed:
             from .grad_sync import BucketedGradSync
             # `src` of dist.broadcast is a GLOBAL rank: member 0 of a sub-group is not global rank 0
@@ -412,6 +422,38 @@ class HotPathTrainer(object):
     def step(self, batch, next_batch=None):
         """one optimizer step on `batch`; next_batch (optional) lets the schedule prepare / start it ahead"""
         return self._step(batch, next_batch)
+
+    def broadcast_buffers(self, src_member=0):
+        """BatchNorm running statistics (every module buffer) of group member `src_member` -> all ranks.  The reference trains under
+        DistributedDataParallel with the default broadcast_buffers=True (tools/train.py:166-168): rank 0's buffers are re-broadcast at
+        every forward, so any rank's checkpoint holds rank 0's running statistics.  Here the buffers stay rank-local during training
+        (training-mode BatchNorm does not read them; with sync_bn they are identical anyway) and are aligned when somebody is about
+        to read them: call this before checkpoint_state_mult_opt / an evaluation pass.  No-op without a process group."""
+        import torch.distributed as dist
+        if self.world == 1 or not (dist.is_available() and dist.is_initialized()):
+            return 0
+        group = self.grad_sync.group if self.grad_sync is not None else None
+        src = dist.get_global_rank(group, src_member) if group is not None else src_member
+        if self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)
+        via_host = dist.get_backend(group) == "gloo" and self.device.type == "cuda"
+        n = 0
+        for b in self.model.buffers():
+            if via_host:
+                h = b.detach().cpu()
+                dist.broadcast(h, src=src, group=group)
+                b.data.copy_(h)
+            else:
+                dist.broadcast(b.data, src=src, group=group)
+            n += 1
+        return n
+
+    def checkpoint_state(self, epoch=None, it=None):
+        """the reference's checkpoint dictionary (tools/train_utils/train_utils.py:272-317) of this trainer's model and optimizer, with
+        rank 0's BatchNorm buffers on every rank (broadcast_buffers)"""
+        from .checkpoint import checkpoint_state_mult_opt
+        self.broadcast_buffers()
+        return checkpoint_state_mult_opt(self.model, [self.optimizer], epoch=epoch, it=it if it is not None else self.optimizer.iteration)
 
     def finish(self):
         """end of training: drain the streams and stop the schedule's host threads (the trainer is not usable afterwards)"""
