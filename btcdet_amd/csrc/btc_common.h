@@ -38,7 +38,7 @@ void btc_set_error(const char* fmt, ...);
   } while (0)
 
 // tuning overrides (btc_tune_set): 0 = built-in policy
-#define BTC_TUNE_KEYS 16
+#define BTC_TUNE_KEYS 24
 int btc_tune_get(int key);
 
 // conv_apply_glds.hip: LDS-DMA pipelined sparse-conv apply (same results as conv_apply)
@@ -59,6 +59,8 @@ int btc_conv_fwd_stats(int operands, const void* src, const float* W, const floa
 // conv_apply_bf16.hip: bf16 operands on the bf16 matrix pipe; Wq[k][Cres][Cred] bf16
 int btc_apply_bf16w(const void* src, const void* Wq, const float* bias, const int32_t* nbr, const int32_t* order, int n_rows, int K, int Cred,
                     int Cres, void* dst, hipStream_t stream, int mirror = 0);
+constexpr size_t BTC_SCRATCH_HEAD = 64 * 1024;              // head of a registered scratch buffer: zeroed at registration, zero between launches
+constexpr long long BTC_SCRATCH_TICKETS = BTC_SCRATCH_HEAD / 4;   // (the z-split launches' per-tile tickets live there)
 void* btc_scratch(hipStream_t stream, size_t* bytes);   // the stream's registered scratch buffer (btc_set_scratch) or NULL
 struct BnFuse;
 int btc_apply_split(const float* src, const void* Ws, const float* bias, const int32_t* nbr, const int32_t* order, int n_rows, int K, int Cred,

@@ -55,7 +55,8 @@ template <int WR, int WC, int NTW, int KC, int S_STAGES>
 __global__ __launch_bounds__(64 * WR * WC) void conv_apply_s(const float* __restrict__ feat, const unsigned short* __restrict__ Ws,
                                                              const float* __restrict__ bias, const int32_t* __restrict__ nbr,
                                                              const int32_t* __restrict__ order, int n_rows, int K, int Cred, int Cres,
-                                                             float* __restrict__ out, int flags, const BnFuse bn) {
+                                                             float* __restrict__ out, int flags, const BnFuse bn, float* __restrict__ out_final,
+                                                             int32_t* __restrict__ ztickets) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NW = WR * WC, THREADS = 64 * NW;
   constexpr int TM = 16 * WR, TN = 16 * NTW * WC;
@@ -118,6 +119,7 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_apply_s(const float* __rest
   // of a few thousand rows: one workgroup per tile walks 54-108 items one after the other while most CUs have nothing to do.
   const int n_all = n_act * n_chunks;
   const int i0 = (int)((long long)blockIdx.z * n_all / gridDim.z), n_items = (int)((long long)(blockIdx.z + 1) * n_all / gridDim.z);
+  float* const slab0 = out;
   out += (size_t)blockIdx.z * n_rows * Cres;
 
   // three accumulators per tile, one per magnitude class of the piece products (1, 2^-8, 2^-16 of |a b|): the matrix pipe aligns
@@ -214,22 +216,66 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_apply_s(const float* __rest
   // epilogue as conv_apply_g's: C/D layout of 16x16: col = lane & 15, row = (lane >> 4) * 4 + reg
   float vals[NTW][4];
   bool valid[4];
+  const bool zred = ztickets != nullptr;   // z-split with the reduction in this launch: partial sums first, bias / statistics by the tile's last workgroup
 #pragma unroll
   for (int nt = 0; nt < NTW; ++nt) {
     const int col = n0 + (wc * NTW + nt) * 16 + (lane & 15);
-    const float bv0 = bias ? bias[col] : 0.f;
+    const float bv0 = (bias && !zred) ? bias[col] : 0.f;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = s_row[wr * 16 + kg * 4 + r];
       valid[r] = row >= 0;
       const float sum = acc[nt][r] + (accm[nt][r] + accs[nt][r]);
-      const float v = bias ? (sum + bv0) : sum;
+      const float v = (bias && !zred) ? (sum + bv0) : sum;
       if (row >= 0) out[(size_t)row * Cres + col] = v;
       vals[nt][r] = v;
     }
   }
+  bool contribute = true;
+  if (zred) {
+    // The Z workgroups of a tile meet at a ticket (release -> fetch_add -> acquire at agent scope, as bn_fuse_finish); the LAST one
+    // adds the Z partial slabs of the tile in z order -- deterministic, the sums split_reduce made -- with the bias, writes the result
+    // and contributes the BatchNorm statistics: no second launch (11 per training step at ~14 us each), the slabs are read from L2.
+    int* s_flag = (int*)smem;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      const int t = __hip_atomic_fetch_add(ztickets + blockIdx.y * gridDim.x + blockIdx.x, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      *s_flag = (t == (int)gridDim.z - 1);
+    }
+    __syncthreads();
+    contribute = *s_flag != 0;
+    if (contribute) {
+      if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        __hip_atomic_store(ztickets + blockIdx.y * gridDim.x + blockIdx.x, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // zero on exit
+      }
+      __syncthreads();
+      const size_t slab = (size_t)n_rows * Cres;
+      const int Z = (int)gridDim.z;
+#pragma unroll
+      for (int nt = 0; nt < NTW; ++nt) {
+        const int col = n0 + (wc * NTW + nt) * 16 + (lane & 15);
+        const float bv0 = bias ? bias[col] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = s_row[wr * 16 + kg * 4 + r];
+          float v = 0.f;
+          if (row >= 0) {
+            const float* p = slab0 + (size_t)row * Cres + col;
+            v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int z = 1; z < Z; ++z) v += __hip_atomic_load(p + z * slab, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (bias) v += bv0;
+            out_final[(size_t)row * Cres + col] = v;
+          }
+          vals[nt][r] = v;
+        }
+      }
+    }
+  }
   if (bn.slots) {   // batch statistics for the BatchNorm behind this layer (bn_fuse.h)
-    bn_fuse_wave<NTW>(bn, vals, valid, n0 + wc * NTW * 16, (int)((bx * WR + wr) & (BN_FUSE_SLOTS - 1)));
+    if (contribute) bn_fuse_wave<NTW>(bn, vals, valid, n0 + wc * NTW * 16, (int)((bx * WR + wr) & (BN_FUSE_SLOTS - 1)));
     bn_fuse_finish(bn, (int*)smem);
   }
 }
@@ -240,7 +286,7 @@ size_t lds_bytes_s(int tm, int tn, int kc, int K, int stages) {
 
 template <int WR, int WC, int NTW, int KC, int S_STAGES>
 int launch_s(const float* feat, const unsigned short* Ws, const float* bias, const int32_t* nbr, const int32_t* order, int n_rows, int K, int Cred,
-             int Cres, float* out, int flags, hipStream_t stream, const BnFuse& bn, int zsplit) {
+             int Cres, float* out, int flags, hipStream_t stream, const BnFuse& bn, int zsplit, float* out_final, int32_t* ztickets) {
   constexpr int TM = 16 * WR, TN = 16 * NTW * WC;
   const size_t lds = lds_bytes_s(TM, TN, KC, K, S_STAGES);
   BTC_CHECK_ARG(lds <= 160 * 1024, "conv_apply_s: tile does not fit the LDS");
@@ -249,7 +295,9 @@ int launch_s(const float* feat, const unsigned short* Ws, const float* bias, con
     (void)hipFuncSetAttribute((const void*)conv_apply_s<WR, WC, NTW, KC, S_STAGES>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   });
   dim3 grid(btc_cdiv(n_rows, TM), Cres / TN, zsplit);
-  conv_apply_s<WR, WC, NTW, KC, S_STAGES><<<grid, 64 * WR * WC, lds, stream>>>(feat, Ws, bias, nbr, order, n_rows, K, Cred, Cres, out, flags, bn);
+  BTC_CHECK_ARG(!ztickets || (long long)grid.x * grid.y <= BTC_SCRATCH_TICKETS, "conv_apply_s: more tiles than z-split tickets");
+  conv_apply_s<WR, WC, NTW, KC, S_STAGES><<<grid, 64 * WR * WC, lds, stream>>>(feat, Ws, bias, nbr, order, n_rows, K, Cred, Cres, out, flags, bn, out_final,
+                                                                               ztickets);
   BTC_LAUNCH_CHECK();
   return BTC_OK;
 }
@@ -419,6 +467,15 @@ int btc_apply_split(const float* src, const void* Ws_, const float* bias_, const
   float* scratch = (float*)btc_scratch(stream, &scratch_bytes);
   const int t_z = btc_tune_get(BTC_TUNE_SPLIT_Z);
   const bool few = n_rows < 10000;
+  // the scratch buffer's head (BTC_SCRATCH_HEAD bytes, zeroed by btc_set_scratch and left zeroed by every launch) holds the tiles' tickets
+  int32_t* const tickets = (int32_t*)scratch;
+  if (scratch_bytes > BTC_SCRATCH_HEAD) {
+    scratch = (float*)((char*)scratch + BTC_SCRATCH_HEAD);
+    scratch_bytes -= BTC_SCRATCH_HEAD;
+  } else {
+    scratch = nullptr;
+    scratch_bytes = 0;
+  }
   const bool can_z = few && t_z != 1 && scratch_bytes >= (size_t)2 * n_rows * Cres * sizeof(float);
   int shape = (Cres % 128 == 0) ? ((!few || can_z || Cres >= 256) ? 424 : 222) : ((!few || can_z) ? 422 : 222);
   // 32 result columns: 128 x 32 / 64 x 32 tiles, the waves split the rows.  32 -> 32 at 26-29 K rows 46 / 40 us (exact chain) -> 29 / 28
@@ -443,9 +500,14 @@ int btc_apply_split(const float* src, const void* Ws_, const float* bias_, const
     while (Z > 1 && (size_t)Z * n_rows * Cres * sizeof(float) > scratch_bytes) --Z;
     if (Z > 1) dst = scratch;
   }
-  const BnFuse bn_kernel = Z > 1 ? btc_bn_fuse_none() : bn;
-  if (Z > 1) bias = nullptr;
-#define S_ARGS src, Ws, bias, nbr, order, n_rows, K, Cred, Cres, dst, flags, stream, bn_kernel, Z
+  // BTC_TUNE_SPLIT_REDUCE = 1: the tile's last workgroup adds the slabs inside the launch (no second launch).  Measured on MI355X
+  // (tools/conv_bench.py, round 4) and NOT the default: the serial tail of the last arriver (ticket, then Z dependent uncached reads of
+  // its 64 x 128 block) costs more than the launch it saves -- 256 -> 128 at 6.4 K rows 112.8 us against 101.8 with split_reduce,
+  // 128 -> 128 70.5 / 58.8, 64 -> 64 26.4 / 25.1; the step's conv launches 2296 us against 2219.
+  const bool in_kernel = Z > 1 && btc_tune_get(BTC_TUNE_SPLIT_REDUCE) == 1;
+  const BnFuse bn_kernel = (Z > 1 && !in_kernel) ? btc_bn_fuse_none() : bn;
+  if (Z > 1 && !in_kernel) bias = nullptr;
+#define S_ARGS src, Ws, bias, nbr, order, n_rows, K, Cred, Cres, dst, flags, stream, bn_kernel, Z, dst_, (in_kernel ? tickets : nullptr)
   int rc = BTC_EINVAL;
   switch (shape * 10 + stages + (kc == 64 ? 5 : 0)) {   // ...7 / ...8: KC = 64 with 2 / 3 stages
     case 4243: rc = launch_s<4, 2, 4, 32, 3>(S_ARGS); break;
@@ -470,7 +532,7 @@ int btc_apply_split(const float* src, const void* Ws_, const float* bias_, const
       return BTC_EINVAL;
   }
 #undef S_ARGS
-  if (rc != BTC_OK || Z == 1) return rc;
+  if (rc != BTC_OK || Z == 1 || in_kernel) return rc;
   split_reduce<<<dim3(btc_cdiv(n_rows, 64), Cres / 64), 256, 0, stream>>>(dst, Z, bias_, n_rows, Cres, dst_, bn);
   BTC_LAUNCH_CHECK();
   return BTC_OK;

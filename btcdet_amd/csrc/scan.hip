@@ -52,6 +52,8 @@ extern "C" int btc_set_scratch(void* stream, void* ptr, size_t bytes) {
   hipPointerAttribute_t attr;
   if (ptr && hipPointerGetAttributes(&attr, ptr) == hipSuccess) key.first = attr.device;   // the buffer's device, whatever is current
   else (void)hipGetLastError();
+  if (ptr && bytes >= BTC_SCRATCH_HEAD)   // the head holds counters the kernels expect zero (and leave zero): cleared once, on the buffer's stream
+    BTC_HIP(hipMemsetAsync(ptr, 0, BTC_SCRATCH_HEAD, (hipStream_t)stream));
   std::lock_guard<std::mutex> lock(g_scratch_mu);
   if (!ptr || !bytes) g_scratch.erase(key);
   else g_scratch[key] = std::make_pair(ptr, bytes);

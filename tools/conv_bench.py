@@ -15,7 +15,7 @@ from btcdet_amd.spconv import ops
 
 def parse_variant(v):
     """kernel:nt:xcd positional btc_tune_set values, or key=value items (13=5: ring depth 5), mixed"""
-    vals = [0] * 16
+    vals = [0] * 24
     if v.startswith("split"):     # split[:tune...]: the split-operand kernel where it applies (operands = 3), tune values after the colon
         vals.append(1)
         v = v[6:] or "0"
@@ -48,7 +48,7 @@ check(L.btc_set_scratch(stream_ptr(), ptr(_scratch), _scratch.numel()), "btc_set
 
 
 def tune(v):
-    v = tuple(v[:16]) + (0,) * (16 - len(v[:16]))
+    v = tuple(v[:24]) + (0,) * (24 - len(v[:24]))
     for key, val in enumerate(v):
         check(L.btc_tune_set(key, val), "btc_tune_set")
 
@@ -91,7 +91,7 @@ for feats, w, b, mf, mb in cap:
         us, ref = [], None
         for v in variants:
             tune(v)
-            split = len(v) > 16 and direction != "wgrad" and L.btc_conv_split_supported(K, cin if direction == "fwd" else cout, cout if direction == "fwd" else cin) == 1
+            split = len(v) > 24 and direction != "wgrad" and L.btc_conv_split_supported(K, cin if direction == "fwd" else cout, cout if direction == "fwd" else cin) == 1
             if split:
                 if "planes" not in ws_cache:
                     q = torch.empty((2, 3) + tuple(w.shape), dtype=torch.bfloat16, device=dev)
