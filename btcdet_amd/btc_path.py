@@ -288,8 +288,40 @@ class BtcHotPath(nn.Module):
         return loss_rpn + MeanSquare.apply(ret["x_combine"], 1e-3)
 
     def forward(self, batch_dict):
-        """BtcNet.forward up to the BEV map (btcnet.py:32-56) + the occupancy loss (btcnet.py:91-101)"""
-        batch_dict, occ_loss, tb_dict, _ = self.forward_occ(batch_dict)
-        out, batch_dict = self.forward_det(batch_dict)
+        """BtcNet.forward up to the BEV map (btcnet.py:32-56) + the occupancy loss (btcnet.py:91-101).
+
+        BTC_FORWARD_DET_STREAM=1 (off by default): the detection branch on a stream of its own inside this call, for a caller of the
+        plain module protocol (the reference's own train_one_epoch_multi_opt: model(batch) -> loss.backward() -> optimizer steps, no
+        trainer of this package).  Autograd runs every backward node on the stream its forward ran on, so ONE loss.backward() from ONE
+        thread then has the occupancy branch's backward, the detection branch's and the weight gradients on three streams.  Measured
+        (round 4, same box, bench.py's in-order leg): 283.7 scenes/s with it against 325.5 without -- one more ACTIVE stream costs
+        more than the overlap buys when one host thread feeds them all (the pipelined schedule pays off because each of its streams has
+        a thread of its own).  Kept for the record and for experiments."""
+        batch_dict, occ_loss, tb_dict, ready = self.forward_occ(batch_dict)
+        side = self._forward_det_stream(batch_dict) if ready is not None else None
+        if side is None:
+            out, batch_dict = self.forward_det(batch_dict)
+        else:
+            cur = torch.cuda.current_stream()
+            with torch.cuda.stream(side):
+                out, batch_dict = self.forward_det(batch_dict, ready)
+            cur.wait_stream(side)
+            for t in out.values():       # produced on the side stream's pool, consumed (loss) on the caller's stream
+                if torch.is_tensor(t) and t.is_cuda:
+                    t.record_stream(cur)
         out["loss_occ"] = occ_loss
         return out, tb_dict, batch_dict
+
+    def _forward_det_stream(self, batch_dict):
+        """the detection branch's own stream for forward(), or None (evaluation, CPU tensors, attached branches, a per-launch profile
+        in progress, switched off)"""
+        from .spconv import ops as sp_ops
+        if not (self.training and batch_dict.get("is_train", True) and batch_dict["voxels"].is_cuda and sp_ops.PROFILE is None
+                and sp_ops.CAPTURE is None and os.environ.get("BTC_FORWARD_DET_STREAM", "0") == "1"):
+            return None
+        if getattr(self.occ_modules.occ_pnt_update, "pass_gradient", False):   # (PASS_GRAD: the occupancy branch's backward would depend on the detection branch's)
+            return None
+        st = self.__dict__.get("_det_side_stream")
+        if st is None or st.device != batch_dict["voxels"].device:
+            st = self.__dict__["_det_side_stream"] = torch.cuda.Stream(device=batch_dict["voxels"].device)
+        return st
