@@ -193,7 +193,9 @@ class VoxelBackBoneDeconv(nn.Module):
 
 DET_GEOMETRY_WALK = os.environ.get("BTC_DET_GEOMETRY_WALK", "1") != "0"  # VoxelBackBone8xOcc._walk_geometry
 FAST_STAGES = os.environ.get("BTC_FAST_STAGES", "1") != "0"               # VoxelBackBone8xOcc._stage: stages straight into the compiled chain call
-DET_WALK_ASYNC = os.environ.get("BTC_DET_WALK_ASYNC", "1") != "0"        # ... with the strided levels built on a side stream beside conv1
+# ... with the strided levels built beside conv1: 1 = on a side stream, 2 = on the current stream (the row counts travel to pinned memory
+# asynchronously, the first stage is launched behind the walk and the host waits for the counts only then), 0 = blocking walk first
+DET_WALK_ASYNC = int(os.environ.get("BTC_DET_WALK_ASYNC", "1"))
 
 
 class VoxelBackBone8xOcc(nn.Module):
@@ -250,7 +252,7 @@ class VoxelBackBone8xOcc(nn.Module):
             stages.append(self.squeezeBev)
         self.__dict__['_first_strided'] = _chain_lookahead(stages)
 
-    def start_walk(self, batch_dict):
+    def start_walk(self, batch_dict, blocking=False):
         """the rulebook walk of forward(), STARTED ahead of it by whoever produced `voxel_coords` (BtcHotPath.forward_occ, right behind
         PassOccVox): the level-0 submanifold rulebook on the current stream, the strided levels and the read-back of their row counts
         forked onto the walk's side stream.  forward() -- on whatever stream, from whatever thread -- then only sizes and fills the maps:
@@ -260,7 +262,15 @@ class VoxelBackBone8xOcc(nn.Module):
         if not coords.is_cuda:
             return
         indice_dict = {}
-        walk = self._walk_geometry(coords, batch_dict['batch_size'], indice_dict, force_async=True)
+        if blocking:   # the whole walk here and now: levels, the (blocking) read-back of their row counts, every map (see btc_path.DET_WALK_AHEAD)
+            global DET_WALK_ASYNC
+            saved, DET_WALK_ASYNC = DET_WALK_ASYNC, 0
+            try:
+                walk = self._walk_geometry(coords, batch_dict['batch_size'], indice_dict)
+            finally:
+                DET_WALK_ASYNC = saved
+        else:
+            walk = self._walk_geometry(coords, batch_dict['batch_size'], indice_dict, force_async=True)
         if isinstance(walk, tuple):
             batch_dict['__det_walk__'] = (coords, indice_dict, walk)
 
@@ -302,7 +312,8 @@ class VoxelBackBone8xOcc(nn.Module):
             if conv0.indice_key is not None:
                 indice_dict[conv0.indice_key] = rb0
             indice_dict.setdefault("__geometry_cache__", {})[conv0._gkey(coords, self.sparse_shape)] = (rb0, coords)
-            return (plan, plan.start(coords, side_stream=not force_async or os.environ.get("BTC_WALK_AHEAD_SIDE", "0") == "1"), {0: rb0}, coords)
+            side = (DET_WALK_ASYNC if DET_WALK_ASYNC in (2, 3) else True) if not force_async else os.environ.get("BTC_WALK_AHEAD_SIDE", "0") == "1"
+            return (plan, plan.start(coords, side_stream=side), {0: rb0}, coords)
         return ("done", plan, plan.run(coords, indice_dict))
 
     @staticmethod

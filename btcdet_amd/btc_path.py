@@ -25,7 +25,17 @@ from .processor import DataProcessor
 # (2.6 -> 1.5 ms of host time), but every kernel on the occupancy branch's stream and on the weight-gradient stream then runs 1.3-2x
 # longer (per-stream kernel totals 2.5 -> 4.8 ms and 2.4 -> 3.2 ms per step, tools/stream_timeline.py); round 2 had found the same
 # move neutral.  Kept for the record and for tests.
-DET_WALK_AHEAD = os.environ.get("BTC_DET_WALK_AHEAD", "0") == "1"
+# Round 4: what made it slow was not the schedule but the asynchronous read-back (hipMemcpyAsync into hipHostMalloc'ed memory + event +
+# hipEventSynchronize, binding.cpp geometry_walk_start side modes 1 / 2): the SAME walk with torch's blocking copy at finish time costs
+# nothing (BTC_DET_WALK_ASYNC=3: 434-445 scenes/s against 415-453 for the default and 306-321 for the pinned asynchronous copy, same
+# box).  BTC_DET_WALK_AHEAD=2 therefore runs the WHOLE walk -- levels, blocking read-back of the row counts, maps -- from the occupancy
+# branch's thread right behind PassOccVox: that thread's stream holds nothing but the occupancy forward at that point, so the wait is
+# the walk's own ~0.2 ms, and the training thread's forward_det finds every rulebook ready instead of sitting in a read-back behind the
+# previous step's detection backward (0.97 of its 3.07 ms, tools/host_profile_main.py).  Measured, same box, three pairs: 425-436 scenes/s
+# against 446-454 without -- det_forward falls from 3.2 to 1.8 ms of host time, but the training thread then waits 0.9 ms for the
+# worker, whose chain (occupancy backward 1.4 -> optimizer + prepared batch 0.6 -> occupancy forward + walk 2.1 ms) is the longer one
+# now: the three host threads are balanced around 4.4-4.6 ms either way.  Not the default.
+DET_WALK_AHEAD = int(os.environ.get("BTC_DET_WALK_AHEAD", "0"))
 
 
 class HotPathDataset(object):
@@ -227,8 +237,10 @@ class BtcHotPath(nn.Module):
         det_inputs_ready = None
         if torch.cuda.is_available() and batch_dict["voxels"].is_cuda:
             dbb = self.det_modules.backbone_3d
-            if DET_WALK_AHEAD and hasattr(dbb, "start_walk"):
-                dbb.start_walk(batch_dict)   # the detection branch's rulebook walk starts here, behind PassOccVox (backbones_3d.start_walk)
+            if DET_WALK_AHEAD and hasattr(dbb, "start_walk") and batch_dict.get("__gen_id__") is not None:
+                # the detection branch's rulebook walk starts (1) / runs (2) here, behind PassOccVox (backbones_3d.start_walk) -- only under a
+                # schedule that runs this branch ahead from a thread of its own (a prepared batch: __gen_id__)
+                dbb.start_walk(batch_dict, blocking=DET_WALK_AHEAD == 2)
             det_inputs_ready = torch.cuda.Event()
             det_inputs_ready.record()
         occ_loss, tb_dict = head.get_loss(batch_dict)
@@ -247,9 +259,14 @@ class BtcHotPath(nn.Module):
         ahead = batch_dict.get("__det_walk__")
         if ahead is not None:
             rec(ahead[0])
-            for rb in ahead[2][2].values():
-                for t in (rb.nbr_out, rb.out_indices):
-                    rec(t)
+            done = ahead[2][0] == "done"                   # ("done", plan, rulebooks) or (plan, handle, {0: level-0 rulebook}, coords)
+            seen = set()
+            for rb in (ahead[2][2] if done else ahead[2][2].values()):
+                if rb is None or id(rb) in seen:
+                    continue
+                seen.add(id(rb))
+                for name in ("nbr_out", "out_indices", "_nbr_in", "order_out", "order_in", "in_indices"):
+                    rec(getattr(rb, name, None))        # (_nbr_in: the stored map, not the property that would materialise a mirror)
         batch_dict["__recorded_for__"] = stream.cuda_stream
 
     def forward_det(self, batch_dict, inputs_ready=None):

@@ -720,7 +720,8 @@ std::shared_ptr<PendingWalk> geometry_walk_start(const Tensor& indices, int64_t 
                                                  const std::vector<int64_t>& ws_bytes, const std::vector<int64_t>& ref, int64_t side_mode) {
   // side_mode: 0 = current stream, blocking read-back; 1 = forked onto the walk's side stream, counts copied to pinned memory
   // asynchronously; 2 = current stream, counts copied asynchronously (no extra stream, no host wait here)
-  const bool side = side_mode != 0;
+  const bool late = side_mode == 3;     // 3 = current stream, NO read-back here: finish() does the blocking one (experiment: is the asynchronous copy the cost?)
+  const bool side = side_mode != 0 && !late;
   const size_t n = kind.size();
   need(a_in.size() == n && a_out.size() == n && a_k.size() == n && a_s.size() == n && a_p.size() == n && a_d.size() == n && mode.size() == n &&
            K.size() == n && ws_bytes.size() == n && ref.size() == n, "geometry_walk: per-layer argument lists differ in length");
@@ -783,7 +784,7 @@ std::shared_ptr<PendingWalk> geometry_walk_start(const Tensor& indices, int64_t 
       throw std::runtime_error("geometry walk: read-back enqueue failed");
     p->done = w->done[slot];
     p->counts = host;
-  } else {
+  } else if (!late) {
     p->h_counts = p->d_counts.to(at::kCPU);  // the one read-back of the chain (current stream only)
     p->counts = (const int32_t*)p->h_counts.data_ptr();
   }
@@ -805,6 +806,10 @@ std::vector<std::vector<Tensor>> geometry_walk_finish(const std::shared_ptr<Pend
     for (const Tensor* t : {&p->ws, &p->d_counts, &p->indices}) c10::hip::HIPCachingAllocator::recordStream(t->storage().data_ptr(), cur);
     for (const Tensor& t : p->out_idx)
       if (t.defined()) c10::hip::HIPCachingAllocator::recordStream(t.storage().data_ptr(), cur);
+  }
+  if (!p->side && !p->counts) {   // side_mode 3: the blocking read-back, now (whatever the caller launched since start() runs ahead of it)
+    const_cast<PendingWalk*>(p.get())->h_counts = p->d_counts.to(at::kCPU);
+    const_cast<PendingWalk*>(p.get())->counts = (const int32_t*)p->h_counts.data_ptr();
   }
   int32_t hc_copy[BTC_CHAIN_MAX_LAYERS];
   for (size_t i = 0; i < n; ++i) hc_copy[i] = p->counts[i];   // the pinned slot is recycled 8 walks later

@@ -401,14 +401,15 @@ class HotPathTrainer(object):
         ops.set_defer_wgrad_join(os.environ.get("BTC_DEFER_WGRAD", "1") != "0")
         cuda = self.device.type == "cuda"
         self.prefetch_stream = torch.cuda.Stream(device=self.device, priority=-1) if (cuda and schedule != "in_order") else None
-        self.det_stream = torch.cuda.Stream(device=self.device) if (cuda and schedule == "pipelined") else None
+        self.det_stream = torch.cuda.Stream(device=self.device, priority=int(os.environ.get("BTC_DET_STREAM_PRIORITY", "0"))) \
+            if (cuda and schedule == "pipelined") else None
         if self.det_stream is not None and "BTC_DET_WALK_ASYNC" not in os.environ:
             # The detection branch's rulebook walk beside its first stage (a fifth active stream) buys nothing once the whole branch runs
             # beside the occupancy backward, and costs a lot: round 4, same box, distinct batches -- 6.1-6.5 ms per step with it (what
             # tools/straggler.py measured in round 3, because only bench.py switched it off) against 4.4 ms without.  Part of the schedule,
             # so it is set here, for every user of the trainer.
             from . import backbones_3d as _bb3d
-            _bb3d.DET_WALK_ASYNC = False
+            _bb3d.DET_WALK_ASYNC = 0
         self._step = make_step(model, model, model.dataset.data_processor, [optimizer], self.grad_sync, self.prefetch_stream,
                                threaded=True, det_stream=self.det_stream, det_loss=det_loss, pipeline=schedule == "pipelined")
         self.end_stream = self._step.end_stream

@@ -1,17 +1,15 @@
 #!/bin/bash
-# kernel statistics of the step with every head behind the hot path (bench.py --heads full), in order
+# steady-state kernel statistics of the step with every head behind the hot path (bench.py --heads full), in order:
+# the last 10 timed steps of the trace only (tools/trace_tail.py) -- MIOpen's find runs and the warm-up stay out
 mkdir -p gpurun_out/full_heads
 export TMPDIR=/tmp
 cd /tmp
-BTC_SCHEDULE=in_order timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_fh -o bench -- python /root/repo/bench.py --heads full --steps 4 --warmup 2 --no-cpu-baseline --no-roofline --no-extras > /root/repo/gpurun_out/full_heads/bench.json 2> /root/repo/gpurun_out/full_heads/bench.err
+rm -rf /tmp/prof_fh
+BTC_BENCH_PRIMING=${PRIMING:-24} BTC_SCHEDULE=${SCHED:-in_order} timeout 900 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_fh -o bench -- python /root/repo/bench.py --heads ${HEADS:-full} --steps 10 --warmup 2 --no-cpu-baseline --no-roofline --no-extras > /root/repo/gpurun_out/full_heads/bench.json 2> /root/repo/gpurun_out/full_heads/bench.err
 cd /root/repo
-find /tmp/prof_fh -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} gpurun_out/full_heads/kernel_stats.csv
-python - <<'PY'
-import csv
-rows = list(csv.DictReader(open("gpurun_out/full_heads/kernel_stats.csv")))
-rows.sort(key=lambda r: -float(r["TotalDurationNs"]))
-tot = sum(float(r["TotalDurationNs"]) for r in rows)
-print("total kernel ms %.1f" % (tot / 1e6))
-for r in rows[:28]:
-    print("%-86s calls %5s  avg %9.1f us  total %8.2f ms" % (r["Name"][:86], r["Calls"], float(r["AverageNs"]) / 1e3, float(r["TotalDurationNs"]) / 1e6))
-PY
+ms=$(python -c "
+import json
+d=json.loads([l for l in open('gpurun_out/full_heads/bench.json') if l.startswith('{')][-1]); print(d['ms_per_step'])")
+# tail window = 8 steps' worth of time, ending at the last kernel (the timed region ends the run: --no-extras)
+find /tmp/prof_fh -name "*kernel_trace.csv" | head -1 | xargs -I{} python tools/trace_tail.py {} 8 -$(python -c "print(8*$ms)") 60 > gpurun_out/full_heads/tail_${HEADS:-full}.txt 2>&1
+head -70 gpurun_out/full_heads/tail_${HEADS:-full}.txt
