@@ -295,6 +295,12 @@ struct SideStream {
 // backward -- the occupancy head's merged weight goes through CatBackward -- must be complete when its node returns.
 std::atomic<bool> g_defer_join{false};
 
+// flags of events that only order streams of one device among themselves (never waited for by the host to read host memory)
+unsigned sync_event_flags() {
+  static const bool sys = getenv("BTC_EVENT_SYSTEM_FENCE") && atoi(getenv("BTC_EVENT_SYSTEM_FENCE")) == 1;
+  return sys ? hipEventDisableTiming : (hipEventDisableTiming | hipEventDisableSystemFence);
+}
+
 SideStream& side_of(int device) {
   static SideStream tab[64];
   static std::mutex mu;
@@ -306,7 +312,13 @@ SideStream& side_of(int device) {
     keep.push_back(c10::hip::getStreamFromPool(false, (c10::DeviceIndex)device));
     s.c10side = &keep.back();
     s.side = keep.back().stream();
-    if (hipEventCreateWithFlags(&s.fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&s.join, hipEventDisableTiming) != hipSuccess)
+    // stream-to-stream ordering on ONE device: a device-scope release is all these events need.  HIP's default is a SYSTEM-scope
+    // release at every record -- a write-back + invalidate of the caches (hip_runtime_api.h, hipEventDisableSystemFence: "avoiding
+    // the cost of cache writeback and invalidation, and the performance impact of those actions on the execution of following
+    // work") -- ~28 times per backward pass here, each one emptying the L2 the gathers of the next kernels live on.
+    // BTC_EVENT_SYSTEM_FENCE=1 restores the default (A/B knob).
+    const unsigned flags = sync_event_flags();
+    if (hipEventCreateWithFlags(&s.fork, flags) != hipSuccess || hipEventCreateWithFlags(&s.join, flags) != hipSuccess)
       throw std::runtime_error("hipEventCreateWithFlags failed");
   }
   return s;
@@ -533,7 +545,7 @@ RbLookahead& rb_of(int device) {
     bool ok = hipHostMalloc((void**)&r.host_n, 64 * sizeof(int32_t), hipHostMallocDefault) == hipSuccess;
     for (int i = 0; ok && i < 64; ++i)
       ok = hipEventCreateWithFlags(&r.done[i], hipEventDisableTiming) == hipSuccess &&
-           hipEventCreateWithFlags(&r.fork[i], hipEventDisableTiming) == hipSuccess;
+           hipEventCreateWithFlags(&r.fork[i], sync_event_flags()) == hipSuccess;
     if (!ok) throw std::runtime_error("rulebook lookahead: event / pinned-memory setup failed");
     r.side = side;
   }
@@ -690,7 +702,7 @@ WalkSide& walk_of(int device) {
     keep.push_back(c10::hip::getStreamFromPool(false, (c10::DeviceIndex)device));
     bool ok = hipHostMalloc((void**)&w.host_counts, 8 * BTC_CHAIN_MAX_LAYERS * sizeof(int32_t), hipHostMallocDefault) == hipSuccess;
     for (int i = 0; ok && i < 8; ++i)
-      ok = hipEventCreateWithFlags(&w.fork[i], hipEventDisableTiming) == hipSuccess &&
+      ok = hipEventCreateWithFlags(&w.fork[i], sync_event_flags()) == hipSuccess &&
            hipEventCreateWithFlags(&w.done[i], hipEventDisableTiming) == hipSuccess;
     if (!ok) throw std::runtime_error("geometry walk: event / pinned-memory setup failed");
     w.c10side = &keep.back();
