@@ -75,6 +75,8 @@ _SIGS = {
     "btc_boxes_pairwise_bev": (ci, [vp, ci, vp, ci, ci, vp, vp]),
     "btc_nms_ws_bytes": (sz, [ci]),
     "btc_nms": (ci, [vp, ci, ctypes.c_float, ci, vp, vp, vp, sz, vp]),
+    "btc_nms_topk_ws_bytes": (sz, [ci, ci, ci]),
+    "btc_nms_topk": (ci, [vp, ci, ci, ctypes.c_float, ci, ci, vp, vp, vp, sz, vp]),
     "btc_voxelize_ws_bytes": (sz, [ci, ci, ci]),
     "btc_voxelize": (ci, [vp, ci, ci, ci, ci, ci, vp, ci, c_f32p, c_f32p, c_i32p, ci, ci, vp, vp, vp, vp, vp, sz, vp]),
     "btc_cart_to_occ_coords": (ci, [vp, vp, ci, ci, ci, vp]),

@@ -199,7 +199,176 @@ __global__ __launch_bounds__(256) void nms_reduce(const unsigned long long* __re
   if (tid == 0) *num_keep = nk;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Greedy NMS that STOPS at max_keep kept boxes (round 4).  The reference runs the full chain over NMS_PRE_MAXSIZE = 9000 boxes per
+// scene and then takes keep[:NMS_POST_MAXSIZE] (model_nms_utils.py:6-25, roi_head_template.py:45-100); whether box i is kept depends on
+// the kept boxes before it only, so the first max_keep kept boxes of the full chain are exactly what a chain that stops there
+// produces -- and at 9000 boxes the full chain is 81 M pair tests (nms_mask 1.2 ms) plus a 2.5 ms walk of ONE workgroup per scene.
+// Here the candidates are taken in chunks of TOPK_CHUNK: the work array of a scene is [K slots: the boxes kept so far, unused slots =
+// far-away dummies that overlap nothing][the chunk]; the ordinary mask + chain over that array continues the greedy chain exactly
+// (kept boxes do not suppress each other, so they stay kept; a candidate is suppressed by a kept box or by an earlier candidate);
+// the chain appends the chunk's kept boxes to the kept slots.  Every kernel of a later chunk returns at once when the scene is full:
+// no host read-back anywhere.  All scenes of a batch share the launches (blockIdx.z).
+constexpr int TOPK_CHUNK = 2560;
+
+struct TopkArgs {
+  const float* boxes;        // (B, n, 7) sorted by descending score
+  float* work;               // (B, T, 7), T = K + TOPK_CHUNK
+  unsigned long long* mask;  // (B, T, T / 64)
+  long long* keep;           // (B, max_keep), -1 padded
+  int32_t* num_keep;         // (B)
+  int n, K, T, max_keep, chunk0, rotated;
+  float thresh;
+};
+
+__device__ __forceinline__ void dummy_box(float* b, int slot) {
+  b[0] = 1.0e7f + 64.f * (float)slot; b[1] = 1.0e7f; b[2] = 0.f; b[3] = 1.f; b[4] = 1.f; b[5] = 1.f; b[6] = 0.f;
+}
+
+__global__ __launch_bounds__(256) void topk_init(TopkArgs a) {
+  const int s = blockIdx.z;
+  for (int i = threadIdx.x; i < a.K; i += 256) dummy_box(a.work + ((size_t)s * a.T + i) * 7, i);
+  for (int i = threadIdx.x; i < a.max_keep; i += 256) a.keep[(size_t)s * a.max_keep + i] = -1;
+  if (threadIdx.x == 0) a.num_keep[s] = 0;
+}
+
+__global__ __launch_bounds__(256) void topk_load(TopkArgs a) {
+  const int s = blockIdx.z;
+  if (a.num_keep[s] >= a.max_keep) return;
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= TOPK_CHUNK) return;
+  float* dst = a.work + ((size_t)s * a.T + a.K + j) * 7;
+  const int src = a.chunk0 + j;
+  if (src < a.n) {
+    const float* p = a.boxes + ((size_t)s * a.n + src) * 7;
+#pragma unroll
+    for (int c = 0; c < 7; ++c) dst[c] = p[c];
+  } else {
+    dummy_box(dst, a.K + j);
+  }
+}
+
+__global__ __launch_bounds__(64) void topk_mask(TopkArgs a) {
+  const int s = blockIdx.z;
+  if (a.num_keep[s] >= a.max_keep) return;
+  const int rb = blockIdx.y, cb = blockIdx.x;
+  if (cb < rb) return;
+  __shared__ float sbox[64 * 7];
+  const float* boxes = a.work + (size_t)s * a.T * 7;
+  const int col_blocks = a.T / 64;
+  for (int e = threadIdx.x; e < 64 * 7; e += 64) sbox[e] = boxes[(size_t)cb * 64 * 7 + e];
+  __syncthreads();
+  const int i = rb * 64 + threadIdx.x;
+  float cur[7];
+#pragma unroll
+  for (int c = 0; c < 7; ++c) cur[c] = boxes[(size_t)i * 7 + c];
+  unsigned long long t = 0;
+  for (int j = (rb == cb) ? (int)threadIdx.x + 1 : 0; j < 64; ++j) {
+    const float v = a.rotated ? iou_bev(cur, sbox + j * 7) : iou_normal(cur, sbox + j * 7);
+    if (v > a.thresh) t |= 1ull << j;
+  }
+  a.mask[((size_t)s * a.T + i) * col_blocks + cb] = t;
+}
+
+// the chain of nms_reduce over the scene's work array; emits the chunk's kept boxes (positions >= K) into keep / the kept slots
+__global__ __launch_bounds__(256) void topk_chain(TopkArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  unsigned long long* remv = (unsigned long long*)smem;  // [col_blocks]
+  __shared__ unsigned long long s_kept;
+  __shared__ int s_nk;
+  const int s = blockIdx.z;
+  const int nk0 = a.num_keep[s];
+  if (nk0 >= a.max_keep) return;
+  const int col_blocks = a.T / 64;
+  const unsigned long long* mask = a.mask + (size_t)s * a.T * col_blocks;
+  float* work = a.work + (size_t)s * a.T * 7;
+  long long* keep = a.keep + (size_t)s * a.max_keep;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int j = tid; j < col_blocks; j += 256) remv[j] = 0ull;
+  if (tid == 0) s_nk = nk0;
+  __syncthreads();
+  const int n_here = min(a.n - a.chunk0, TOPK_CHUNK);   // real candidates of this chunk (the rest of the array is dummies)
+  for (int b = 0; b < col_blocks; ++b) {
+    if (wave == 0) {
+      const unsigned long long diag = mask[(size_t)(b * 64 + lane) * col_blocks + b];
+      const unsigned dlo = (unsigned)diag, dhi = (unsigned)(diag >> 32);
+      unsigned long long rem = remv[b], kept = 0ull;
+      for (int i = 0; i < 64; ++i) {  // wave-uniform
+        if (!((rem >> i) & 1ull)) {
+          kept |= 1ull << i;
+          rem |= ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)dhi, i) << 32) |
+                 (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)dlo, i);
+        }
+      }
+      // new kept boxes: candidates of this chunk (array position >= K, a real box), in order, until the scene is full
+      const int pos = b * 64 + lane;
+      const bool fresh = ((kept >> lane) & 1ull) && pos >= a.K && (pos - a.K) < n_here;
+      const unsigned long long fm = __ballot(fresh);
+      const int nk = s_nk;
+      const int rank = nk + __popcll(fm & ((1ull << lane) - 1ull));
+      if (fresh && rank < a.max_keep) {
+        keep[rank] = (long long)a.chunk0 + (pos - a.K);
+        if (rank < a.K) {
+#pragma unroll
+          for (int c = 0; c < 7; ++c) work[(size_t)rank * 7 + c] = work[(size_t)pos * 7 + c];   // (slot rank < K <= pos: no aliasing with a row still to be read)
+        }
+      }
+      if (lane == 0) {
+        s_kept = kept;
+        s_nk = min(nk + __popcll(fm), a.max_keep);
+      }
+    }
+    __syncthreads();
+    if (s_nk >= a.max_keep) break;   // block-uniform
+    const unsigned long long kept = s_kept;
+    for (int j = b + 1 + tid; j < col_blocks; j += 256) {
+      unsigned long long acc = remv[j], m = kept;
+      while (m) {
+        const int i = __ffsll((long long)m) - 1;
+        m &= m - 1;
+        acc |= mask[(size_t)(b * 64 + i) * col_blocks + j];
+      }
+      remv[j] = acc;
+    }
+    __syncthreads();
+  }
+  if (tid == 0) a.num_keep[s] = s_nk;
+}
+
 }  // namespace
+
+extern "C" size_t btc_nms_topk_ws_bytes(int batch, int n, int max_keep) {
+  if (batch <= 0 || max_keep <= 0) return 256;
+  const size_t K = (size_t)(max_keep + 63) / 64 * 64, T = K + TOPK_CHUNK;
+  return btc_align((size_t)batch * T * 7 * sizeof(float)) + btc_align((size_t)batch * T * (T / 64) * sizeof(unsigned long long));
+}
+
+extern "C" int btc_nms_topk(const float* boxes_sorted, int batch, int n, float thresh, int rotated, int max_keep, long long* keep,
+                            int32_t* d_num_keep, void* ws, size_t ws_bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  BTC_CHECK_ARG(batch >= 0 && n >= 0 && max_keep >= 1 && max_keep <= 4096, "btc_nms_topk: bad sizes (batch %d, n %d, max_keep %d)", batch, n, max_keep);
+  BTC_CHECK_ARG(ws_bytes >= btc_nms_topk_ws_bytes(batch, n, max_keep), "btc_nms_topk: workspace too small");
+  if (batch == 0) return BTC_OK;
+  TopkArgs a;
+  a.boxes = boxes_sorted; a.keep = keep; a.num_keep = d_num_keep; a.n = n; a.max_keep = max_keep; a.rotated = rotated; a.thresh = thresh;
+  a.K = (max_keep + 63) / 64 * 64;
+  a.T = a.K + TOPK_CHUNK;
+  BtcCarver cv(ws);
+  a.work = cv.take<float>((size_t)batch * a.T * 7);
+  a.mask = cv.take<unsigned long long>((size_t)batch * a.T * (a.T / 64));
+  a.chunk0 = 0;
+  topk_init<<<dim3(1, 1, batch), 256, 0, stream>>>(a);
+  BTC_LAUNCH_CHECK();
+  const int cb = a.T / 64;
+  for (int c0 = 0; c0 < n; c0 += TOPK_CHUNK) {
+    a.chunk0 = c0;
+    topk_load<<<dim3(TOPK_CHUNK / 256, 1, batch), 256, 0, stream>>>(a);
+    topk_mask<<<dim3(cb, cb, batch), 64, 0, stream>>>(a);
+    topk_chain<<<dim3(1, 1, batch), 256, (size_t)cb * 8, stream>>>(a);
+    BTC_LAUNCH_CHECK();
+  }
+  return BTC_OK;
+}
 
 extern "C" int btc_boxes_pairwise_bev(const float* boxes_a, int na, const float* boxes_b, int nb, int mode, float* out, void* stream) {
   BTC_CHECK_ARG(na >= 0 && nb >= 0 && (mode == 0 || mode == 1), "btc_boxes_pairwise_bev: bad arguments");

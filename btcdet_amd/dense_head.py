@@ -9,6 +9,8 @@ Same module protocol, parameter names (`conv_cls`, `conv_box`, `conv_dir_cls`), 
   class_agnostic_nms, proposal_layer      models/model_utils/model_nms_utils.py:6-25, roi_heads/roi_head_template.py:45-100
 checked against those modules run here (tests/golden/gen_head_golden.py -> tests/test_hip_dense_head.py).  Dense 1x1 convs are
 the vendor library's; the NMS inside the proposal step is this repository's HIP kernel (btcdet_amd.iou3d_nms.nms_gpu)."""
+import os
+
 import numpy as np
 import torch
 from torch import nn
@@ -329,6 +331,23 @@ def proposal_layer(batch_dict, nms_config):
     roi_labels = boxes.new_zeros((B, K), dtype=torch.long)
     if nms_config.MULTI_CLASSES_NMS:
         raise NotImplementedError
+    if batch_dict.get("batch_index", None) is None and boxes.is_cuda and boxes.dim() == 3 and boxes.shape[1] > 0 and boxes.shape[-1] == 7 \
+            and nms_config.NMS_TYPE in ("nms_gpu", "nms_normal_gpu") and os.environ.get("BTC_NMS_TOPK", "1") != "0":
+        # every scene at once, resident: top-k by score, the greedy chain stopped at NMS_POST_MAXSIZE kept boxes (iou3d_nms.nms_topk --
+        # exactly the reference's keep[:NMS_POST_MAXSIZE], model_nms_utils.py:6-25), padded rows gathered as zeros.  No read-back; the
+        # per-scene loop below is the reference's own shape (one full chain over NMS_PRE_MAXSIZE boxes and two read-backs per scene).
+        best, label = torch.max(scores, dim=2)                                                     # (B, A)
+        top_scores, top = torch.topk(best, k=min(nms_config.NMS_PRE_MAXSIZE, best.shape[1]), dim=1)   # sorted, descending
+        cand = torch.gather(boxes, 1, top.unsqueeze(-1).expand(-1, -1, boxes.shape[-1]))
+        keep, _ = iou3d_nms.nms_topk(cand[..., 0:7], nms_config.NMS_THRESH, K, rotated=nms_config.NMS_TYPE == "nms_gpu")
+        valid = keep >= 0
+        sel = torch.gather(top, 1, keep.clamp(min=0))                                              # (B, K) anchor indices
+        rois = torch.gather(boxes, 1, sel.unsqueeze(-1).expand(-1, -1, boxes.shape[-1])) * valid.unsqueeze(-1).to(boxes.dtype)
+        roi_scores = torch.gather(best, 1, sel) * valid.to(best.dtype)
+        roi_labels = torch.gather(label, 1, sel) * valid.to(label.dtype)
+        batch_dict.update(rois=rois, roi_scores=roi_scores, roi_labels=roi_labels + 1, has_class_labels=scores.shape[-1] > 1)
+        batch_dict.pop("batch_index", None)
+        return batch_dict
     for b in range(B):
         pick = (batch_dict["batch_index"] == b) if batch_dict.get("batch_index", None) is not None else b
         bx, sc = boxes[pick], scores[pick]

@@ -44,6 +44,22 @@ def _nms_sorted(boxes_sorted, thresh, rotated):
     return keep, int(cnt.item())
 
 
+def nms_topk(boxes_sorted, thresh, max_keep, rotated=True):
+    """boxes_sorted (B, n, 7) or (n, 7), every scene sorted by descending score -> (keep (B, max_keep) int64 positions, -1 padded,
+    num_keep (B,) int32), both on the device: the first max_keep entries of the greedy chain, which stops there (csrc/iou3d_nms.hip
+    btc_nms_topk) -- no host read-back, all scenes in shared launches"""
+    b = boxes_sorted if boxes_sorted.dim() == 3 else boxes_sorted.unsqueeze(0)
+    B, n = int(b.shape[0]), int(b.shape[1])
+    b = _boxes(b.reshape(-1, 7)).view(B, n, 7)
+    keep = torch.empty((B, int(max_keep)), dtype=torch.int64, device=b.device)
+    cnt = torch.empty((B,), dtype=torch.int32, device=b.device)
+    ws_bytes = lib().btc_nms_topk_ws_bytes(B, n, int(max_keep))
+    ws = workspace(ws_bytes, b.device)
+    check(lib().btc_nms_topk(ptr(b), B, n, float(thresh), int(bool(rotated)), int(max_keep), ptr(keep), ptr(cnt), ptr(ws), ws_bytes, stream_ptr()),
+          "btc_nms_topk")
+    return keep, cnt
+
+
 # ---------------------------------------------------------------- iou3d_nms_utils.py surface
 def boxes_iou_bev(boxes_a, boxes_b):
     """(N,7), (M,7) -> (N,M) rotated BEV IoU (iou3d_nms_utils.py:32-46)"""

@@ -531,6 +531,15 @@ int btc_boxes_pairwise_bev(const float* boxes_a, int na, const float* boxes_b, i
 size_t btc_nms_ws_bytes(int n);
 int btc_nms(const float* boxes_sorted, int n, float thresh, int rotated, long long* keep, int32_t* d_num_keep, void* ws,
             size_t ws_bytes, void* stream);
+/* The same greedy chain, stopped at max_keep kept boxes, for a BATCH of scenes in shared launches and without any host read-back:
+ * boxes_sorted (batch, n, 7) by descending score per scene; keep (batch, max_keep) int64 = the first max_keep entries of btc_nms's
+ * keep list, padded with -1; num_keep (batch).  What model_nms_utils.class_agnostic_nms keeps after its
+ * `selected[:NMS_POST_MAXSIZE]` (/root/reference/btcdet/models/model_utils/model_nms_utils.py:6-25) -- the decision for a box depends
+ * on the kept boxes before it only, so the truncated chain is exact.  ws: btc_nms_topk_ws_bytes(batch, n, max_keep). */
+size_t btc_nms_topk_ws_bytes(int batch, int n, int max_keep);
+int btc_nms_topk(const float* boxes_sorted, int batch, int n, float thresh, int rotated, int max_keep, long long* keep,
+                 int32_t* num_keep, void* ws, size_t ws_bytes, void* stream);
+
 
 /* ------------------------------------------------------------------------------------------------
  * pointnet2_stack.  Entry points = the functions the reference binds from its compiled module

@@ -85,3 +85,30 @@ def test_compiled_module_stand_in_signatures():
     cpu_out = torch.zeros((40, 30))
     m.boxes_iou_bev_cpu(torch.from_numpy(a), torch.from_numpy(b), cpu_out)
     np.testing.assert_allclose(cpu_out.numpy(), orc.boxes_iou_bev(a, b), rtol=1e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("n,spread,rotated,max_keep", [(100, 4.0, True, 16), (3000, 12.0, True, 256), (9000, 22.0, True, 256), (9000, 22.0, False, 512),
+                                                        (2560, 9.0, True, 64), (6000, 6.0, True, 512), (5, 3.0, True, 256)])
+def test_nms_topk_is_the_truncated_full_chain(n, spread, rotated, max_keep):
+    """btc_nms_topk (the chain stopped at max_keep, chunked, batched, no read-back) == the first max_keep entries of btc_nms's keep list,
+    bit for bit (same IoU function, same argument order), for a batch of two different scenes; dense clusters so that suppression
+    really happens, sizes on both sides of the 2560-box chunk"""
+    from btcdet_amd import iou3d_nms
+    rng = np.random.default_rng(n + max_keep)
+    scenes = []
+    for s in range(2):
+        b = rand_boxes(rng, n, spread)
+        scenes.append(_t(b))
+    thresh = 0.25
+    keep, cnt = iou3d_nms.nms_topk(torch.stack(scenes), thresh, max_keep, rotated=rotated)
+    assert tuple(keep.shape) == (2, max_keep) and keep.dtype == torch.int64 and cnt.dtype == torch.int32
+    for s in range(2):
+        full, m = iou3d_nms._nms_sorted(scenes[s], thresh, rotated)
+        want = full[:min(m, max_keep)].cpu().numpy()
+        got, c = keep[s].cpu().numpy(), int(cnt[s])
+        assert c == len(want), (c, len(want), m)
+        assert np.array_equal(got[:c], want) and np.all(got[c:] == -1)
+        if n >= 3000 and spread >= 12.0:
+            assert m > max_keep and m < n       # the chain really was cut short, and boxes really were suppressed
+        elif n == 6000:
+            assert m < max_keep                 # ... and here it runs through every chunk without filling up
