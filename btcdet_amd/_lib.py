@@ -76,6 +76,9 @@ _SIGS = {
     "btc_nms_ws_bytes": (sz, [ci]),
     "btc_nms": (ci, [vp, ci, ctypes.c_float, ci, vp, vp, vp, sz, vp]),
     "btc_nms_topk_ws_bytes": (sz, [ci, ci, ci]),
+    "btc_trilinear_corners": (ci, [vp, ctypes.c_longlong, ctypes.c_longlong, c_f32p, c_f32p, c_f32p, c_i32p, ci, vp, vp, vp, vp, vp, vp]),
+    "btc_trilinear_gather": (ci, [vp, ci, ctypes.c_longlong, vp, vp, vp, vp]),
+    "btc_trilinear_scatter": (ci, [vp, ci, vp, vp, vp, ci, vp, vp]),
     "btc_nms_topk": (ci, [vp, ci, ci, ctypes.c_float, ci, ci, vp, vp, vp, sz, vp]),
     "btc_voxelize_ws_bytes": (sz, [ci, ci, ci]),
     "btc_voxelize": (ci, [vp, ci, ci, ci, ci, ci, vp, ci, c_f32p, c_f32p, c_i32p, ci, ci, vp, vp, vp, vp, vp, sz, vp]),

@@ -75,6 +75,65 @@ def trilinear_readout(x, batch_index, zyx):
     return out
 
 
+class _TrilinearRead(torch.autograd.Function):
+    """out[p] = sum_c w[p][c] * feat[rows[p][c]] over the 8 corners of kept lattice point p (csrc/roi_pool.hip trilinear_gather); backward:
+    the (point, corner) pairs stably sorted by the row they read, one wave per row summing in that order (trilinear_scatter) --
+    deterministic, no float atomics, and only over the kept points (the reference's index_put(accumulate) runs over all of them)"""
+
+    @staticmethod
+    def forward(ctx, feat, rows_k, w_k):
+        from ._lib import check, lib, ptr, stream_ptr
+        feat = feat.contiguous()
+        M, C = int(rows_k.shape[0]), int(feat.shape[1])
+        out = torch.empty((M, C), dtype=torch.float32, device=feat.device)
+        check(lib().btc_trilinear_gather(ptr(feat), C, M, ptr(rows_k), ptr(w_k), ptr(out), stream_ptr()), "btc_trilinear_gather")
+        ctx.save_for_backward(rows_k, w_k)
+        ctx.n_rows = int(feat.shape[0])
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        from ._lib import check, lib, ptr, stream_ptr
+        rows_k, w_k = ctx.saved_tensors
+        n_rows, C = ctx.n_rows, int(grad.shape[1])
+        grad = grad.contiguous()
+        key = torch.where((rows_k >= 0) & (w_k != 0), rows_k, torch.full_like(rows_k, n_rows)).view(-1)
+        skey, perm = torch.sort(key, stable=True)                       # pairs e = 8 p + c grouped by row, in pair order inside a row
+        seg = torch.searchsorted(skey, torch.arange(n_rows + 1, dtype=skey.dtype, device=skey.device)).int()
+        gfeat = torch.empty((n_rows, C), dtype=torch.float32, device=grad.device)
+        check(lib().btc_trilinear_scatter(ptr(grad), C, ptr(perm.int()), ptr(seg), ptr(w_k), n_rows, ptr(gfeat), stream_ptr()), "btc_trilinear_scatter")
+        return gfeat, None, None
+
+
+def trilinear_splat_resident(x, flat_points, points_per_batch, batch_size, point_cloud_range, voxel_size, stride_zyx):
+    """-> (keep (M,) int64 lattice points that read something, features (M, C)) for the sparse tensor x at world points flat_points (Q, 3):
+    trilinear_readout() + the non-zero filter of ConvHead.splat without x.dense() and without the (Q, C) intermediates -- the corner
+    rows / weights of every point from ONE launch (btc_trilinear_corners), the read-out itself over the kept points only"""
+    import ctypes
+    from ._lib import check, lib, ptr, stream_ptr
+    feats = x.features
+    dev = feats.device
+    D, H, W = (int(v) for v in x.spatial_shape)
+    N = int(feats.shape[0])
+    idx = x.indices.long()
+    live = (feats.detach() != 0).any(dim=1).to(torch.uint8)          # (an all-zero row is read like any other but keeps no point alive)
+    cell_row = torch.full((int(batch_size), D, H, W), -1, dtype=torch.int32, device=dev)
+    cell_row[idx[:, 0], idx[:, 1], idx[:, 2], idx[:, 3]] = torch.arange(N, dtype=torch.int32, device=dev)
+    Q = int(flat_points.shape[0])
+    rows = torch.empty((Q, 8), dtype=torch.int32, device=dev)
+    wts = torch.empty((Q, 8), dtype=torch.float32, device=dev)
+    flag = torch.empty((Q,), dtype=torch.uint8, device=dev)
+    f3, i3 = ctypes.c_float * 3, ctypes.c_int32 * 3
+    check(lib().btc_trilinear_corners(ptr(flat_points), Q, int(points_per_batch), f3(*[float(v) for v in point_cloud_range[:3]]),
+                                      f3(*[float(v) for v in voxel_size[:3]]), f3(*[float(v) for v in stride_zyx]), i3(D, H, W), int(batch_size),
+                                      ptr(cell_row), ptr(live), ptr(rows), ptr(wts), ptr(flag), stream_ptr()), "btc_trilinear_corners")
+    keep = torch.nonzero(flag)[:, 0]                                   # (the one read-back, as the reference's nonzero)
+    return keep, _TrilinearRead.apply(feats, rows[keep].contiguous(), wts[keep].contiguous())
+
+
+RESIDENT_SPLAT = __import__("os").environ.get("BTC_ROI_TRILINEAR", "1") != "0"
+
+
 class ConvHead(nn.Module):
     def __init__(self, input_channels, model_cfg, num_class=1, **kwargs):
         super().__init__()
@@ -188,6 +247,10 @@ class ConvHead(nn.Module):
         s = [stride] * 3 if isinstance(stride, int) else list(stride)
         rng, vs = self.point_cloud_range, self.det_voxel_size
         flat = points.reshape(-1, 3)
+        if RESIDENT_SPLAT and x.features.is_cuda and x.features.dtype == torch.float32:
+            keep, feat = trilinear_splat_resident(x, flat.contiguous().float(), P * per_scene, batch_size, rng, vs, s)
+            coords = torch.cat([(keep // P).view(-1, 1), lattice_idx.reshape(-1, 3).long()[keep]], dim=-1)
+            return coords.int(), feat
         zyx = torch.stack([(flat[:, 2] - float(rng[2])) / float(vs[2]) / s[0] - 0.5, (flat[:, 1] - float(rng[1])) / float(vs[1]) / s[1] - 0.5,
                            (flat[:, 0] - float(rng[0])) / float(vs[0]) / s[2] - 0.5], dim=-1)
         scene = torch.arange(S, device=points.device)

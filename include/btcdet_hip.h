@@ -536,6 +536,29 @@ int btc_nms(const float* boxes_sorted, int n, float thresh, int rotated, long lo
  * keep list, padded with -1; num_keep (batch).  What model_nms_utils.class_agnostic_nms keeps after its
  * `selected[:NMS_POST_MAXSIZE]` (/root/reference/btcdet/models/model_utils/model_nms_utils.py:6-25) -- the decision for a box depends
  * on the kept boxes before it only, so the truncated chain is exact.  ws: btc_nms_topk_ws_bytes(batch, n, max_keep). */
+/* ------------------------------------------------------------------------------------------------
+ * ROI head, pooling stage: trilinear read-out of a sparse tensor at lattice points WITHOUT densifying it.  Replaces
+ * bilinear_interpolate_torch-style read-outs of /root/reference/btcdet/models/roi_heads/conv_head.py:509-610
+ * (common_utils.py:247-311, normalize False) on `x.dense()`: 8 advanced-indexing gathers of (points, C) forward and 8
+ * index_put(accumulate) backward over EVERY lattice point, four fifths of which read zeros and are dropped right after.
+ *   btc_trilinear_corners: xyz (n_points, 3) world coordinates, points_per_batch consecutive points per scene; range_lo (x, y, z),
+ *     voxel (x, y, z), stride_zyx, grid_dhw of the sparse tensor; cell_row (batch, D, H, W) i32 = row of the cell or -1 ->
+ *     rows (n_points, 8) i32 (corner order dz, dy, dx; -1 = empty / outside), weights (n_points, 8) f32 (|w|, 0 where no row),
+ *     flag (n_points) u8 = some corner contributes; row_live (n_rows) u8 or NULL: rows with a non-zero entry -- the reference keeps a
+ *     point iff its interpolated vector has one, so an all-zero row is read (and receives its gradient) but keeps no point alive
+ *   btc_trilinear_gather: rows / weights (n_keep, 8) of the KEPT points -> out (n_keep, C) = sum_c weights[p][c] * feat[rows[p][c]] in
+ *     corner order
+ *   btc_trilinear_scatter: the adjoint, deterministic: pair_sorted (n_pairs) i32 = the (point, corner) pairs e = 8 p + c stably sorted by
+ *     the row they read, seg (n_rows + 1) i32 = each row's segment -> grad_feat (n_rows, C) = sum in segment order of
+ *     weights[e] * grad_out[e >> 3]
+ * ---------------------------------------------------------------------------------------------- */
+int btc_trilinear_corners(const float* xyz, long long n_points, long long points_per_batch, const float* range_lo, const float* voxel,
+                          const float* stride_zyx, const int32_t* grid_dhw, int batch, const int32_t* cell_row, const uint8_t* row_live,
+                          int32_t* rows, float* weights, uint8_t* flag, void* stream);
+int btc_trilinear_gather(const float* feat, int C, long long n_keep, const int32_t* rows, const float* weights, float* out, void* stream);
+int btc_trilinear_scatter(const float* grad_out, int C, const int32_t* pair_sorted, const int32_t* seg, const float* weights, int n_rows,
+                          float* grad_feat, void* stream);
+
 size_t btc_nms_topk_ws_bytes(int batch, int n, int max_keep);
 int btc_nms_topk(const float* boxes_sorted, int batch, int n, float thresh, int rotated, int max_keep, long long* keep,
                  int32_t* num_keep, void* ws, size_t ws_bytes, void* stream);
