@@ -268,7 +268,8 @@ class ConvHead(nn.Module):
         flat = rois.reshape(B * N, -1)
         lattice, _ = world_lattice(flat, self.grid_size, self.dim_times)                         # (B*N, G, 3)
         centres = lattice.reshape(-1, 3).contiguous()
-        centre_cnt = torch.full((B,), N * self.grid_num, dtype=torch.int32, device=rois.device)
+        from .pointnet2_stack import with_host_counts
+        centre_cnt = with_host_counts(torch.full((B,), N * self.grid_num, dtype=torch.int32, device=rois.device), [N * self.grid_num] * B)
         rot = xy = zs = None
         if self.point_rot:                                                                        # rotation into the ROI's frame
             c, s = torch.cos(-flat[:, 6]), torch.sin(-flat[:, 6])

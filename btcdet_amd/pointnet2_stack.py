@@ -121,6 +121,27 @@ class BallQuery(Function):
 ball_query = BallQuery.apply
 
 
+def host_counts(cnt):
+    """the per-scene counts of a *_batch_cnt tensor as python ints.  The reference checks them against the row counts (and branches on
+    them) at every grouping call -- 50-odd blocking read-backs per training step of the ROI head when the tensors live on the GPU.
+    Here a count tensor carries its host copy (`_btc_host`, attached by whoever made it or by the first call) so that ONE read-back
+    serves every check of that tensor."""
+    h = getattr(cnt, "_btc_host", None)
+    if h is None:
+        h = [int(v) for v in cnt.tolist()]
+        try:
+            cnt._btc_host = h
+        except AttributeError:
+            pass
+    return h
+
+
+def with_host_counts(cnt, host):
+    """attach host-known counts to a count tensor (no read-back will be needed for it)"""
+    cnt._btc_host = [int(v) for v in host]
+    return cnt
+
+
 class GroupingOperation(Function):
     """features (N1+N2.., C) gathered at idx (M1+M2.., nsample) -> (M1+M2.., C, nsample); the backward scatter-adds
     (pointnet2_utils.py:52-104)"""
@@ -128,9 +149,9 @@ class GroupingOperation(Function):
     @staticmethod
     def forward(ctx, features, features_batch_cnt, idx, idx_batch_cnt):
         _contig(features, features_batch_cnt, idx, idx_batch_cnt)
-        if features.shape[0] != int(features_batch_cnt.sum()):
+        if features.shape[0] != sum(host_counts(features_batch_cnt)):
             raise AssertionError('features: %s, features_batch_cnt: %s' % (str(features.shape), str(features_batch_cnt)))
-        if idx.shape[0] != int(idx_batch_cnt.sum()):
+        if idx.shape[0] != sum(host_counts(idx_batch_cnt)):
             raise AssertionError('idx: %s, idx_batch_cnt: %s' % (str(idx.shape), str(idx_batch_cnt)))
         (n_query, nsample), (n_pts, ch) = idx.shape, features.shape
         n_scene = idx_batch_cnt.shape[0]
@@ -165,16 +186,18 @@ class QueryAndGroup(nn.Module):
     def _group(values, cnt, idx, qcnt, drop_last):
         if not drop_last:
             return grouping_operation(values, cnt, idx, qcnt)
-        n_last = int(qcnt[-1])
-        g = grouping_operation(values, cnt[0:-1], idx[:-n_last], qcnt[0:-1])
+        n_last = host_counts(qcnt)[-1]
+        g = grouping_operation(values, with_host_counts(cnt[0:-1], host_counts(cnt)[0:-1]), idx[:-n_last],
+                               with_host_counts(qcnt[0:-1], host_counts(qcnt)[0:-1]))
         return torch.cat([g, torch.zeros_like(g[:n_last])], dim=0)
 
     def forward(self, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, features=None, rotateMatrix=None, xyscales=None, zscales=None):
-        assert xyz.shape[0] == xyz_batch_cnt.sum(), 'xyz: %s, xyz_batch_cnt: %s' % (str(xyz.shape), str(new_xyz_batch_cnt))
-        assert new_xyz.shape[0] == new_xyz_batch_cnt.sum(), 'new_xyz: %s, new_xyz_batch_cnt: %s' % (str(new_xyz.shape), str(new_xyz_batch_cnt))
+        h_xyz, h_new = host_counts(xyz_batch_cnt), host_counts(new_xyz_batch_cnt)
+        assert xyz.shape[0] == sum(h_xyz), 'xyz: %s, xyz_batch_cnt: %s' % (str(xyz.shape), str(new_xyz_batch_cnt))
+        assert new_xyz.shape[0] == sum(h_new), 'new_xyz: %s, new_xyz_batch_cnt: %s' % (str(new_xyz.shape), str(new_xyz_batch_cnt))
         idx, empty = ball_query(self.radius, self.nsample, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt)
         several = len(xyz_batch_cnt) > 1
-        offsets = self._group(xyz, xyz_batch_cnt, idx, new_xyz_batch_cnt, several and xyz_batch_cnt[-1] == 0)  # (M, 3, nsample)
+        offsets = self._group(xyz, xyz_batch_cnt, idx, new_xyz_batch_cnt, several and h_xyz[-1] == 0)  # (M, 3, nsample)
         offsets = offsets - new_xyz.unsqueeze(-1)
         offsets[empty] = 0
         unrotated = offsets
@@ -187,7 +210,7 @@ class QueryAndGroup(nn.Module):
             out = offsets
         else:
             # (sic) the reference tests scene 1 here and the last scene above
-            grouped = self._group(features, xyz_batch_cnt, idx, new_xyz_batch_cnt, several and xyz_batch_cnt[1] == 0)
+            grouped = self._group(features, xyz_batch_cnt, idx, new_xyz_batch_cnt, several and h_xyz[1] == 0)
             grouped[empty] = 0
             out = torch.cat([offsets, grouped], dim=1) if self.use_xyz else grouped
         return (out, idx, unrotated) if rotateMatrix is not None else (out, idx)
