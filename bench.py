@@ -55,7 +55,7 @@ def pmc_traffic_per_launch():
     --pmc WRITE_SIZE in separate runs, FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md); PMC counters cannot be read
     inside the timed process, so this is null when the file is absent"""
     try:
-        name = next(n for n in ("r03j_pmc.json", "r03_pmc.json", "r02h_pmc.json") if os.path.exists(os.path.join(ROOT, "profiles", n)))
+        name = next(n for n in ("r04_pmc.json", "r03j_pmc.json", "r03_pmc.json", "r02h_pmc.json") if os.path.exists(os.path.join(ROOT, "profiles", n)))
         with open(os.path.join(ROOT, "profiles", name)) as f:
             return json.load(f)["conv_apply"]["hbm_bytes_per_launch"]
     except (OSError, KeyError, ValueError):

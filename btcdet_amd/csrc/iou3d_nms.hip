@@ -366,7 +366,7 @@ extern "C" int btc_nms_topk(const float* boxes_sorted, int batch, int n, float t
   BTC_LAUNCH_CHECK();
   for (int c0 = 0; c0 < n; c0 += a.chunk_n) {
     a.chunk0 = c0;
-    a.chunk_n = c0 == 0 ? TOPK_CHUNK0 : TOPK_CHUNK;
+    a.chunk_n = c0 == 0 ? TOPK_CHUNK0 : (a.chunk_n * 2 < TOPK_CHUNK ? a.chunk_n * 2 : TOPK_CHUNK);   // 768, 1536, 2560, 2560, ...
     a.T = a.K + a.chunk_n;          // (both chunk sizes are multiples of 64)
     const int cb = a.T / 64;
     topk_load<<<dim3(btc_cdiv(a.chunk_n, 256), 1, batch), 256, 0, stream>>>(a);

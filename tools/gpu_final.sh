@@ -1,7 +1,7 @@
 #!/bin/bash
 # the measurement set of a round: bench lines (default / bf16 / Waymo shape / Waymo bf16), kernel statistics of the default and the
 # in-order schedule, the two PMC passes, the straggler estimate -> gpurun_out/<tag>/ (copy what is to be judged into profiles/)
-tag=${1:-r03g}
+tag=${1:-r04z}
 mkdir -p gpurun_out/$tag
 cd /root/repo
 timeout 400 python bench.py > gpurun_out/$tag/bench.json 2> gpurun_out/$tag/bench.err
@@ -11,6 +11,7 @@ timeout 300 python bench.py --workload waymo --features bf16 --steps 40 --warmup
 SKIP_BENCH=1 bash tools/gpu_prof.sh $tag > gpurun_out/$tag/prof.log 2>&1
 bash tools/gpu_pmc.sh $tag > gpurun_out/$tag/pmc.log 2>&1
 timeout 300 python tools/straggler.py 64 gpurun_out/$tag/straggler.json > gpurun_out/$tag/straggler.log 2>&1
+bash tools/gpu_full_heads_prof.sh > gpurun_out/$tag/full_heads.log 2>&1; cp gpurun_out/full_heads/tail_full.txt gpurun_out/$tag/full_heads_tail.txt 2>/dev/null
 for f in bench bench_bf16 bench_waymo bench_waymo_bf16; do
   python - <<PY
 import json

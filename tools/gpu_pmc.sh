@@ -6,7 +6,7 @@ mkdir -p gpurun_out/$tag
 export TMPDIR=/tmp
 cd /tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 900 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_${tag}_$c -o pmc -- python /root/repo/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-roofline --no-extras > /root/repo/gpurun_out/$tag/bench_$c.json 2> /root/repo/gpurun_out/$tag/bench_$c.err
+  BTC_BENCH_PRIMING=16 timeout 900 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_${tag}_$c -o pmc -- python /root/repo/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-roofline --no-extras > /root/repo/gpurun_out/$tag/bench_$c.json 2> /root/repo/gpurun_out/$tag/bench_$c.err
 done
 cd /root/repo
 python tools/pmc_summary.py /tmp/pmc_${tag}_FETCH_SIZE /tmp/pmc_${tag}_WRITE_SIZE gpurun_out/$tag/pmc.json
