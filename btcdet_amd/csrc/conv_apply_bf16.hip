@@ -112,9 +112,12 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_apply_b(const unsigned shor
 #pragma unroll
   for (int nt = 0; nt < NTW; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  auto issue = [&](int item, int st) {
-    const int k = s_kact[item / n_chunks];
-    const int cc = (item % n_chunks) * KC;
+  // cursors of the issue walk (two items ahead) and of the compute walk: one item per call, no division by n_chunks in the loop
+  int iq = 0, ir = 0, cq = 0, cr = 0;
+  auto issue = [&](int st) {
+    const int k = s_kact[iq];
+    const int cc = ir * KC;
+    if (++ir == n_chunks) { ir = 0; ++iq; }
     char* As = ring + st * STAGE;
     char* Bs = As + A_BYTES;
 #pragma unroll
@@ -143,16 +146,17 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_apply_b(const unsigned shor
   };
 
   const int arow = lane & 15, kq = lane >> 4;
-  if (n_items > 0) issue(0, 0);
-  if (n_items > 1) issue(1, 1);
+  if (n_items > 0) issue(0);
+  if (n_items > 1) issue(1);
   int st = 0;
   for (int item = 0; item < n_items; ++item) {
     if (item + 1 < n_items) wait_vm_b<NPI>();
     else wait_vm_b<0>();
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    if (item + 2 < n_items) issue(item + 2, st == 0 ? 2 : st - 1);
-    const int k = s_kact[item / n_chunks];
+    if (item + 2 < n_items) issue(st == 0 ? 2 : st - 1);
+    const int k = s_kact[cq];
+    if (++cr == n_chunks) { cr = 0; ++cq; }
     if ((wave_act >> k) & 1ull) {
       const char* A = ring + st * STAGE + (wr * 16 + arow) * (KC * 2);
       const char* B = ring + st * STAGE + A_BYTES;

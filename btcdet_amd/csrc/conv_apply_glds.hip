@@ -133,15 +133,19 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_apply_g(const void* __restr
   __syncthreads();
   const int n_act = *s_nact;
   const int n_chunks = Cred / KC;
-  const int n_items = n_act * n_chunks;
+  const int n_items = (dbg & 32) ? 0 : n_act * n_chunks;   // timing experiments: 32 = no item loop (prologue + epilogue only)
+  if (dbg & 16) return;                                    //                     16 = prologue only
 
   f32x4 acc[NTW];
 #pragma unroll
   for (int nt = 0; nt < NTW; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  auto issue = [&](int item, int st) {
-    const int k = s_kact[item / n_chunks];
-    const int cc = (item % n_chunks) * KC;
+  // cursors of the issue walk (S - 1 items ahead) and of the compute walk: one item per call, no division by n_chunks in the loop
+  int iq = 0, ir = 0, cq = 0, cr = 0;
+  auto issue = [&](int st) {
+    const int k = s_kact[iq];
+    const int cc = ir * KC;
+    if (++ir == n_chunks) { ir = 0; ++iq; }
     char* As = ring + st * STAGE;
     float* Bs = (float*)(As + A_BYTES);
 #pragma unroll
@@ -180,7 +184,7 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_apply_g(const void* __restr
   const int arow = lane & 15, kq = lane >> 4;
   // vmcnt is a 6-bit counter: the launcher keeps (S - 2) * NPI <= 63 (btc_apply_glds_stages), the clamped cases below are never taken
 #define WAIT_ITEMS(n) wait_vm<((n) * NPI > 63 ? 63 : (n) * NPI)>()
-  for (int i = 0; i < S - 1 && i < n_items; ++i) issue(i, i);
+  for (int i = 0; i < S - 1 && i < n_items; ++i) issue(i);
   int st = 0;
   for (int item = 0; item < n_items; ++item) {
     // this item has landed; the min(S - 2, items left) issued behind it stay in flight
@@ -197,8 +201,9 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_apply_g(const void* __restr
 #undef WAIT_ITEMS
     __builtin_amdgcn_s_barrier();  // everyone's share of this item is in LDS, and everyone is done reading item - 1
     asm volatile("" ::: "memory");
-    if (item + S - 1 < n_items && !(dbg & 2)) issue(item + S - 1, st == 0 ? S - 1 : st - 1);  // into the stage item - 1 occupied
-    const int k = s_kact[item / n_chunks];
+    if (item + S - 1 < n_items && !(dbg & 2)) issue(st == 0 ? S - 1 : st - 1);  // into the stage item - 1 occupied
+    const int k = s_kact[cq];
+    if (++cr == n_chunks) { cr = 0; ++cq; }
     if (((wave_act >> k) & 1ull) && !(dbg & 1)) {
       // fragment reads are software-pipelined by hand in groups of G reduction steps: the reads of group g + 1 are issued
       // before the MFMAs of group g and pinned there (sched_barrier) -- left alone, hipcc sinks every ds_read next to its

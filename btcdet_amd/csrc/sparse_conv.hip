@@ -90,13 +90,18 @@ __global__ __launch_bounds__(THREADS) void conv_apply(const float* __restrict__ 
   float as_[KB][8];   // !VEC: 8 scalars
   float bv[KB][NB];
 
+  // cursors of the prefetch walk (one item ahead) and of the compute walk over the (offset, chunk) items: no integer division by
+  // the runtime n_chunks inside the loop (conv_apply_split.hip)
+  int pq = 0, pr = 0, cr = 0;
   auto prefetch = [&](int item) {
+    const int pq_now = pq, pr_now = pr;
+    if (KB == 1 && ++pr == n_chunks) { pr = 0; ++pq; }
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) {
-      const int ai = (KB > 1) ? item * KB + kb : item / n_chunks;
+      const int ai = (KB > 1) ? item * KB + kb : pq_now;
       const bool live = ai < n_act;
       const int k = live ? s_kact[ai] : 0;
-      const int cc = (KB > 1) ? 0 : (item % n_chunks) * KC;
+      const int cc = (KB > 1) ? 0 : pr_now * KC;
       const int kc = min(KC, Cred - cc);
       const float* Wk = W + (size_t)k * Cred * Cres;
       if (VEC) {
@@ -162,7 +167,8 @@ __global__ __launch_bounds__(THREADS) void conv_apply(const float* __restrict__ 
 
   if (n_items > 0) prefetch(0);
   for (int item = 0; item < n_items; ++item) {
-    const int cc = (KB > 1) ? 0 : (item % n_chunks) * KC;
+    const int cc = (KB > 1) ? 0 : cr * KC;
+    if (KB == 1 && ++cr == n_chunks) cr = 0;
     const int kc = min(KC, Cred - cc);
     __syncthreads();  // the previous item's fragment reads are done
     commit();
