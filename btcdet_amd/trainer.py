@@ -401,6 +401,9 @@ class HotPathTrainer(object):
         ops.set_defer_wgrad_join(os.environ.get("BTC_DEFER_WGRAD", "1") != "0")
         cuda = self.device.type == "cuda"
         self.prefetch_stream = torch.cuda.Stream(device=self.device, priority=-1) if (cuda and schedule != "in_order") else None
+        if os.environ.get("BTC_SWITCH_INTERVAL"):     # (A/B knob: CPython's GIL hand-over interval, default 5 ms)
+            import sys
+            sys.setswitchinterval(float(os.environ["BTC_SWITCH_INTERVAL"]))
         self.det_stream = torch.cuda.Stream(device=self.device, priority=int(os.environ.get("BTC_DET_STREAM_PRIORITY", "0"))) \
             if (cuda and schedule == "pipelined") else None
         if self.det_stream is not None and "BTC_DET_WALK_ASYNC" not in os.environ:
