@@ -285,7 +285,7 @@ def main():
     # occupancy head leave its random initialisation, so PassOccVox adds what a head in training adds (tools/workload_drift.py: the
     # detection levels hover around 32-34 K / 30-36 K / 14-19 K / 6-8 K rows from step ~30 on; config.level_rows reports the timed steps')
     priming = max(0, int(os.environ.get("BTC_BENCH_PRIMING", "64")) - args.warmup)
-    n_distinct = min(priming + args.warmup + args.steps + 1 + (0 if (args.no_extras or waymo) else 12) + (0 if args.no_roofline else 8),
+    n_distinct = min(priming + args.warmup + args.steps + 2 + (0 if (args.no_extras or waymo) else 12) + (0 if args.no_roofline else 8),
                      int(os.environ.get("BTC_BENCH_MAX_BATCHES", "192" if not waymo else "48")))
     batches = build_batches(n_distinct, rank, device, bs, args.workload)
     nb = len(batches)
@@ -314,8 +314,14 @@ def main():
         else:
             base = 0
         n = len(pool)
+        # BTC_BENCH_TWO_AHEAD=1: hand the trainer the batch after next as well (HotPathTrainer.step(batch, next, after_next): its front is
+        # prepared a step earlier, off the worker thread's chain).  Measured, same box: 434-442 scenes/s against 452-457 -- every chain gets
+        # shorter on paper and every phase gets longer in fact; the three host threads share one GIL.  Off.
+        two_ahead = bool(getattr(step_fn, "pipelined", False)) and os.environ.get("BTC_BENCH_TWO_AHEAD", "0") == "1"
+        call = (lambda j: step_fn(pool[(base + j) % n], pool[(base + j + 1) % n], pool[(base + j + 2) % n])) if two_ahead else \
+            (lambda j: step_fn(pool[(base + j) % n], pool[(base + j + 1) % n]))
         for i in range(n_warm):
-            step_fn(pool[(base + i) % n], pool[(base + i + 1) % n])
+            call(i)
         sync()
         if getattr(step_fn, "timing", None):
             step_fn.timing.clear()     # (BTC_TRAINER_TIMING=1: host phases of the timed steps only)
@@ -325,7 +331,7 @@ def main():
         t0 = time.perf_counter()
         marks[0].record(end_stream)
         for i in range(n_warm, n_warm + n_steps):  # each step prepares its successor: K steps, K preparations
-            step_fn(pool[(base + i) % n], pool[(base + i + 1) % n])
+            call(i)
             marks[i - n_warm + 1].record(end_stream)  # end of the step's work on the stream its last kernel runs on (no host wait)
             if rows_of is not None:
                 rows.append(getattr(rows_of, "last_level_rows", None))

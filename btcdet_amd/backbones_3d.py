@@ -252,7 +252,7 @@ class VoxelBackBone8xOcc(nn.Module):
             stages.append(self.squeezeBev)
         self.__dict__['_first_strided'] = _chain_lookahead(stages)
 
-    def start_walk(self, batch_dict, blocking=False):
+    def start_walk(self, batch_dict, blocking=False, handoff=False):
         """the rulebook walk of forward(), STARTED ahead of it by whoever produced `voxel_coords` (BtcHotPath.forward_occ, right behind
         PassOccVox): the level-0 submanifold rulebook on the current stream, the strided levels and the read-back of their row counts
         forked onto the walk's side stream.  forward() -- on whatever stream, from whatever thread -- then only sizes and fills the maps:
@@ -269,10 +269,15 @@ class VoxelBackBone8xOcc(nn.Module):
                 walk = self._walk_geometry(coords, batch_dict['batch_size'], indice_dict)
             finally:
                 DET_WALK_ASYNC = saved
+        elif handoff:
+            # the levels on THIS (the producer's) stream with nothing but an event behind them; forward() -- the training thread, the
+            # detection stream -- reads the row counts with a blocking copy on a copy stream that waits for that event only, so it
+            # neither sits behind the previous step's detection backward (the blocking walk) nor makes this thread wait (blocking=True)
+            walk = self._walk_geometry(coords, batch_dict['batch_size'], indice_dict, force_async=4)
         else:
             walk = self._walk_geometry(coords, batch_dict['batch_size'], indice_dict, force_async=True)
         if isinstance(walk, tuple):
-            batch_dict['__det_walk__'] = (coords, indice_dict, walk)
+            batch_dict['__det_walk__'] = (coords, indice_dict, walk, "handoff" if handoff else None)
 
     def _walk_geometry(self, coords, bs, indice_dict, force_async=False):
         """all rulebooks of the main chain (subm1, spconv2, subm2, ... spconv_down2, subm_down2) in one call of the compiled
@@ -312,7 +317,10 @@ class VoxelBackBone8xOcc(nn.Module):
             if conv0.indice_key is not None:
                 indice_dict[conv0.indice_key] = rb0
             indice_dict.setdefault("__geometry_cache__", {})[conv0._gkey(coords, self.sparse_shape)] = (rb0, coords)
-            side = (DET_WALK_ASYNC if DET_WALK_ASYNC in (2, 3) else True) if not force_async else os.environ.get("BTC_WALK_AHEAD_SIDE", "0") == "1"
+            if isinstance(force_async, int) and not isinstance(force_async, bool) and force_async > 1:
+                side = force_async     # a read-back mode of binding.cpp geometry_walk_start chosen by the caller (4: hand-over, see start_walk)
+            else:
+                side = (DET_WALK_ASYNC if DET_WALK_ASYNC in (2, 3) else True) if not force_async else os.environ.get("BTC_WALK_AHEAD_SIDE", "0") == "1"
             return (plan, plan.start(coords, side_stream=side), {0: rb0}, coords)
         return ("done", plan, plan.run(coords, indice_dict))
 
@@ -443,7 +451,9 @@ class VoxelBackBone8xOcc(nn.Module):
             self._first_strided.prefetch(coords, self.sparse_shape, bs, x.indice_dict)
         n_occ = len(self.occ_conv_exec)
         ready = None
-        if FAST_STAGES and isinstance(walk, tuple) and walk[0] == "done":   # (the blocking walk: every rulebook is there already)
+        if FAST_STAGES and isinstance(walk, tuple) and (walk[0] == "done" or (ahead is not None and len(ahead) > 3 and ahead[3] == "handoff")):
+            # the blocking walk (every rulebook is there already), or a walk handed over by the producer's thread: its levels ran long ago
+            # on the producer's stream, the counts come back without a wait -- finish it before the first stage
             ready = self._finish_walk(walk, x.indice_dict)
         x1 = self._stage(self.conv1, x, ready)
         occ = None

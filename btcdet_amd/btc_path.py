@@ -34,7 +34,12 @@ from .processor import DataProcessor
 # previous step's detection backward (0.97 of its 3.07 ms, tools/host_profile_main.py).  Measured, same box, three pairs: 425-436 scenes/s
 # against 446-454 without -- det_forward falls from 3.2 to 1.8 ms of host time, but the training thread then waits 0.9 ms for the
 # worker, whose chain (occupancy backward 1.4 -> optimizer + prepared batch 0.6 -> occupancy forward + walk 2.1 ms) is the longer one
-# now: the three host threads are balanced around 4.4-4.6 ms either way.  Not the default.
+# now: the three host threads are balanced around 4.4-4.6 ms either way.  Not the default.  BTC_DET_WALK_AHEAD=3 goes one step further:
+# the occupancy thread only ENQUEUES the levels (an event behind them) and the training thread reads the counts through a copy stream that
+# waits for that event alone -- nobody blocks (det_forward 2.3 ms, the worker's wait for the prepared batch gone with `after_next`) --
+# and the step is still 4.3-4.6 ms: with every wait removed, every phase of every thread got longer (detection backward 0.96 -> 1.39 ms,
+# occupancy backward 0.67 -> 1.55, occupancy forward 1.57 -> 2.28).  The three threads' CPU time adds up to 5.9 ms per step and they share
+# one GIL: the schedule is bound by the interpreter, not by any wait that can be moved.
 DET_WALK_AHEAD = int(os.environ.get("BTC_DET_WALK_AHEAD", "0"))
 
 
@@ -240,7 +245,7 @@ class BtcHotPath(nn.Module):
             if DET_WALK_AHEAD and hasattr(dbb, "start_walk") and batch_dict.get("__gen_id__") is not None:
                 # the detection branch's rulebook walk starts (1) / runs (2) here, behind PassOccVox (backbones_3d.start_walk) -- only under a
                 # schedule that runs this branch ahead from a thread of its own (a prepared batch: __gen_id__)
-                dbb.start_walk(batch_dict, blocking=DET_WALK_AHEAD == 2)
+                dbb.start_walk(batch_dict, blocking=DET_WALK_AHEAD == 2, handoff=DET_WALK_AHEAD == 3)
             det_inputs_ready = torch.cuda.Event()
             det_inputs_ready.record()
         occ_loss, tb_dict = head.get_loss(batch_dict)

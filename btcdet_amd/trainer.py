@@ -182,7 +182,9 @@ def make_step(model, ddp, proc, opts, grad_sync=None, prefetch_stream=None, thre
             return t
         return 0.0
 
-    def step_pipelined(batch, next_batch):
+    prepared_ahead = {}   # id(batch) -> future of its prepared front, submitted one step EARLIER than it is needed (after_next)
+
+    def step_pipelined(batch, next_batch, after_next=None):
         import time
         t = time.perf_counter() if timing is not None else 0.0
         c0 = time.thread_time() if timing is not None else 0.0
@@ -195,7 +197,18 @@ def make_step(model, ddp, proc, opts, grad_sync=None, prefetch_stream=None, thre
         pending.clear()
         bd, loss_occ, tb, inputs_ready, occ_fwd_done = cur
         occ_done = threading.Event()
-        prep_future = prep_pool.submit(prep, next_batch) if (prep_pool is not None and next_batch is not None) else None
+        # The worker needs next_batch's prepared front ~1 ms into this step, and preparing it takes the prep thread 2-2.6 ms: submitted
+        # now, it sits on the worker's critical chain (prepare -> occupancy forward = 4.2 ms, BTC_TRAINER_TIMING=1 'w_opt_prepare').  A
+        # caller that can look two batches ahead passes `after_next`: its front is prepared during THIS step and consumed in the next.
+        prep_future = None
+        if prep_pool is not None and next_batch is not None:
+            prep_future = prepared_ahead.pop(id(next_batch), None)
+            if prep_future is None:
+                prep_future = prep_pool.submit(prep, next_batch)
+        for k in [k for k in prepared_ahead if k != id(after_next)]:
+            prepared_ahead.pop(k)          # (a caller that changed its mind: drop what nobody will consume)
+        if prep_pool is not None and after_next is not None and id(after_next) not in prepared_ahead:
+            prepared_ahead[id(after_next)] = prep_pool.submit(prep, after_next)
         fut = pool.submit(occ_tail, loss_occ, next_batch, occ_done, prep_future)
         t = _mark("head", t)
         with torch.cuda.stream(det_stream):
@@ -234,9 +247,9 @@ def make_step(model, ddp, proc, opts, grad_sync=None, prefetch_stream=None, thre
             timing["cpu_main"] = timing.get("cpu_main", 0.0) + time.thread_time() - c0
         return loss
 
-    def step(batch, next_batch=None):
+    def step(batch, next_batch=None, after_next=None):
         if pipeline:
-            return step_pipelined(batch, next_batch)
+            return step_pipelined(batch, next_batch, after_next)
         for o in opts:
             o.zero_grad(set_to_none=True)
         bd = pending.pop(id(batch), None)
@@ -423,9 +436,10 @@ class HotPathTrainer(object):
                         block = torch.empty(self._reserve_bytes, dtype=torch.uint8, device=self.device)
                         del block
 
-    def step(self, batch, next_batch=None):
-        """one optimizer step on `batch`; next_batch (optional) lets the schedule prepare / start it ahead"""
-        return self._step(batch, next_batch)
+    def step(self, batch, next_batch=None, after_next=None):
+        """one optimizer step on `batch`; next_batch (optional) lets the schedule prepare / start it ahead; after_next (optional, the
+        batch behind that) lets the pipelined schedule prepare one step earlier still, off the worker thread's critical chain"""
+        return self._step(batch, next_batch, after_next) if after_next is not None else self._step(batch, next_batch)
 
     def broadcast_buffers(self, src_member=0):
         """BatchNorm running statistics (every module buffer) of group member `src_member` -> all ranks.  The reference trains under
