@@ -125,12 +125,37 @@ class VoxelBackBoneDeconv(nn.Module):
         ready = batch_dict.pop('occ_geometry', None)
         if ready is not None and ready[0] is voxel_coords:  # rulebooks of this very coordinate tensor (prefetch_geometry)
             x.indice_dict = ready[1]
-        for stage in (self.conv1, self.conv2, self.conv3, self.deconv4, self.deconv5):
-            x = stage(x)
+        x = self._forward_stages(x)
         if self.y_shift > 0:
             x = self.remove_shift(x)
         batch_dict.update({'encoded_spconv_tensor': x, 'encoded_spconv_tensor_stride': 1})
         return batch_dict
+
+    def _forward_stages(self, x):
+        """conv1 .. deconv5.  Nothing sits between the five stages, so with every rulebook at hand (prefetch_geometry) they are ONE call of
+        the compiled chain (nine conv -> BatchNorm -> ReLU layers) instead of five: the step is bound by the interpreter lock its three
+        host threads share, and every Python -> C++ transition that disappears is ~50 us of it"""
+        stages = (self.conv1, self.conv2, self.conv3, self.deconv4, self.deconv5)
+        from .spconv import modules as sp_modules, ops as sp_ops
+        if WHOLE_CHAIN and sp_ops.PROFILE is None and sp_ops.CAPTURE is None and sp_ops.NATIVE_AUTOGRAD and sp_ops.fast() is not None:
+            steps, cur, ok = [], x, True
+            for stage in stages:
+                pl = stage._chain_plan(cur)
+                if pl is None:
+                    ok = False
+                    break
+                plan, indices, shape = pl
+                steps.extend(plan)
+                cur = spconv.SparseConvTensor(x.features, indices, shape, x.batch_size)     # (a stand-in: _chain_plan reads dtype / indices / shape / rulebooks)
+                cur.indice_dict = x.indice_dict
+            if ok and steps:
+                holder = self.__dict__.get("_whole_chain")
+                if holder is None:
+                    holder = self.__dict__["_whole_chain"] = spconv.SparseSequential()
+                return holder._run_chain(x, steps, indices, shape)
+        for stage in stages:
+            x = stage(x)
+        return x
 
     def prefetch_geometry(self, batch_dict, head=None):
         """every rulebook forward (and the occupancy head) will need, built from the voxel coordinates alone -- they do not
@@ -191,6 +216,11 @@ class VoxelBackBoneDeconv(nn.Module):
         return x
 
 
+# consecutive stages with nothing in between as ONE compiled chain call (the occupancy backbone's five stages = one call of nine layers;
+# conv1 + conv1_combine, conv3 + conv3_combine, conv4 + conv4_combine of the detection backbone): same bits, seven Python -> C++
+# transitions per step fewer -- and, measured over three same-box pairs, 430 / 453 / 440 scenes/s against 438 / 458 / 455 per stage:
+# the longer uninterrupted calls do not pay.  Off.
+WHOLE_CHAIN = os.environ.get("BTC_WHOLE_CHAIN", "0") == "1"
 DET_GEOMETRY_WALK = os.environ.get("BTC_DET_GEOMETRY_WALK", "1") != "0"  # VoxelBackBone8xOcc._walk_geometry
 FAST_STAGES = os.environ.get("BTC_FAST_STAGES", "1") != "0"               # VoxelBackBone8xOcc._stage: stages straight into the compiled chain call
 # ... with the strided levels built beside conv1: 1 = on a side stream, 2 = on the current stream (the row counts travel to pinned memory
@@ -357,6 +387,38 @@ class VoxelBackBone8xOcc(nn.Module):
                     return stage._run_chain(x, steps, mine[-1].out_indices, plan.entries[sl[1] - 1][4])
         return stage(x)
 
+    def _stages(self, stages, x, ready):
+        """consecutive stages with nothing between them as ONE compiled chain call when the walk's rulebooks are at hand (see
+        VoxelBackBoneDeconv._forward_stages); -> (output of the last stage, outputs needed in between are not available: callers merge
+        only where nobody reads them)"""
+        from .spconv import fused_bn as sp_fused_bn, modules as sp_modules, ops as sp_ops
+        if WHOLE_CHAIN and ready is not None and len(stages) > 1 and sp_modules.CHAIN_LAYERS and sp_modules.FUSE_CONV_BN and sp_modules.FUSE_BN_RELU \
+                and sp_ops.PROFILE is None and sp_ops.CAPTURE is None and sp_ops.NATIVE_AUTOGRAD and sp_ops.fast() is not None:
+            plan, rbs = ready
+            steps, last, ok = [], None, True
+            f = x.features
+            for stage in stages:
+                sl = plan.stage_slices.get(id(stage))
+                triples = stage.__dict__.get("_chain_triples", False)
+                if triples is False:
+                    stage._chain_plan(x)
+                    triples = stage.__dict__.get("_chain_triples", None)
+                if not (sl is not None and triples and len(triples) == sl[1] - sl[0] and all(sp_fused_bn.fusable(bn) for _, bn, _ in triples)
+                        and (f.dtype == torch.float32 or all(c.in_channels % 16 == 0 and c.out_channels % 16 == 0 for c, _, _ in triples))):
+                    ok = False
+                    break
+                mine = rbs[sl[0]:sl[1]]
+                if not all(rb is not None and rb.n_out > 0 for rb in mine):
+                    ok = False
+                    break
+                steps += [(c, bn, relu, rb, False) for (c, bn, relu), rb in zip(triples, mine)]
+                last = (mine[-1].out_indices, plan.entries[sl[1] - 1][4])
+            if ok and f.is_cuda and f.shape[0] > 0:
+                return stages[0]._run_chain(x, steps, last[0], last[1])
+        for stage in stages:
+            x = self._stage(stage, x, ready)
+        return x
+
     def _build_occ_net(self, kind, i):
         """occupancy-code side branch at level i (1..3): maxpool / learned / fixed-mean / avg (spconv_backbone.py:793-866)"""
         n = self.occ_code_num
@@ -455,7 +517,8 @@ class VoxelBackBone8xOcc(nn.Module):
             # the blocking walk (every rulebook is there already), or a walk handed over by the producer's thread: its levels ran long ago
             # on the producer's stream, the counts come back without a wait -- finish it before the first stage
             ready = self._finish_walk(walk, x.indice_dict)
-        x1 = self._stage(self.conv1, x, ready)
+        merge_first = ready is not None and not (n_occ > 0 and self.occ_conv_exec[0])      # nothing between conv1 and conv1_combine
+        x1 = self._stages([self.conv1, self.conv1_combine], x, ready) if merge_first else self._stage(self.conv1, x, ready)
         occ = None
         if n_occ > 0:
             occ = spconv.SparseConvTensor(features=batch_dict["occ_voxel_features"], indices=coords,
@@ -466,7 +529,8 @@ class VoxelBackBone8xOcc(nn.Module):
                 x1 = self.sparse_cat([x1, occ])
                 if self.out_att[0]:
                     x1 = self.apply_att(x1, self.att_conv1)
-        x1 = self._stage(self.conv1_combine, x1, ready)
+        if not merge_first:
+            x1 = self._stage(self.conv1_combine, x1, ready)
         if ready is None:   # the strided levels' rulebooks, built beside the first stage
             ready = self._finish_walk(walk, x.indice_dict)
             if not FAST_STAGES:
@@ -474,6 +538,10 @@ class VoxelBackBone8xOcc(nn.Module):
         levels = [x1]
         cur = x1
         for lvl in (1, 2, 3):
+            if not (n_occ > lvl):   # no occupancy side branch at this level: conv{l} and conv{l}_combine back to back
+                cur = self._stages([getattr(self, 'conv%d' % (lvl + 1)), getattr(self, 'conv%d_combine' % (lvl + 1))], cur, ready)
+                levels.append(cur)
+                continue
             cur = self._stage(getattr(self, 'conv%d' % (lvl + 1)), cur, ready)
             if n_occ > lvl:
                 occ = getattr(self, 'occ_conv%d' % (lvl + 1))(occ)
