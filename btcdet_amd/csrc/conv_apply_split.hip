@@ -494,7 +494,7 @@ int btc_apply_split(const float* src, const void* Ws_, const float* bias_, const
   const int t_kc = btc_tune_get(BTC_TUNE_APPLY_KC), t_st = btc_tune_get(BTC_TUNE_APPLY_STAGES);
   int kc = (Cred % 64 == 0 && (shape % 10 == 4 || n_rows < 22000) && shape % 100 != 12) ? 64 : 32;
   if (t_kc == 32 || (t_kc == 64 && Cred % 64 == 0)) kc = t_kc;
-  if (shape % 100 == 12) kc = 32;   // (the 32-column tiles exist with 32-channel items only)
+  if (shape % 100 == 12 && !(t_kc == 64 && Cred % 64 == 0)) kc = 32;   // 32-column tiles: 32-channel items (64-channel instances exist for tuning runs: half the barriers, one workgroup per CU fewer)
   int stages = t_st ? t_st : 3;
   if (kc == 64) stages = (t_st == 3 && shape == 422) ? 3 : 2;
   // z-split (conv_apply_s header): few rows -> few tiles -> most CUs idle while each workgroup walks its tile's 27-108 items alone.
@@ -528,6 +528,8 @@ int btc_apply_split(const float* src, const void* Ws_, const float* bias_, const
     case 4223: rc = launch_s<4, 2, 2, 32, 3>(S_ARGS); break;
     case 4224: rc = launch_s<4, 2, 2, 32, 4>(S_ARGS); break;
     case 4227: rc = launch_s<4, 2, 2, 64, 2>(S_ARGS); break;
+    case 4127: rc = launch_s<4, 1, 2, 64, 2>(S_ARGS); break;
+    case 8127: rc = launch_s<8, 1, 2, 64, 2>(S_ARGS); break;
     case 4123: rc = launch_s<4, 1, 2, 32, 3>(S_ARGS); break;
     case 4124: rc = launch_s<4, 1, 2, 32, 4>(S_ARGS); break;
     case 8123: rc = launch_s<8, 1, 2, 32, 3>(S_ARGS); break;
