@@ -494,7 +494,10 @@ int btc_apply_split(const float* src, const void* Ws_, const float* bias_, const
   const int t_kc = btc_tune_get(BTC_TUNE_APPLY_KC), t_st = btc_tune_get(BTC_TUNE_APPLY_STAGES);
   int kc = (Cred % 64 == 0 && (shape % 10 == 4 || n_rows < 22000) && shape % 100 != 12) ? 64 : 32;
   if (t_kc == 32 || (t_kc == 64 && Cred % 64 == 0)) kc = t_kc;
-  if (shape % 100 == 12 && !(t_kc == 64 && Cred % 64 == 0)) kc = 32;   // 32-column tiles: 32-channel items (64-channel instances exist for tuning runs: half the barriers, one workgroup per CU fewer)
+  // 32-column tiles: 64-channel items where the reduction allows (round 4: half the barriers -- the empty item loop is 0.2-0.5 us per
+  // item, DESIGN.md section 5 --: 64 -> 32 at 28.8 K rows 47.6 -> 39.8 us, the dgrad of 32 -> 64 at 14.2 K rows 45.3 -> 37.4, at 3.1 K
+  // rows 43.6 -> 36.2; `tools/conv_bench.py split split:4=32` is the comparison)
+  if (shape % 100 == 12) kc = (Cred % 64 == 0 && t_kc != 32) ? 64 : 32;
   int stages = t_st ? t_st : 3;
   if (kc == 64) stages = (t_st == 3 && shape == 422) ? 3 : 2;
   // z-split (conv_apply_s header): few rows -> few tiles -> most CUs idle while each workgroup walks its tile's 27-108 items alone.
