@@ -12,7 +12,7 @@ for f in glob.glob(os.path.join(sys.argv[1], "**", "*counter_collection.csv"), r
         name = r["Kernel_Name"]
         if "conv_apply" not in name and "conv_wgrad" not in name:
             continue
-        short = name.split("(")[0].replace("void ", "").replace("(anonymous namespace)::", "")
+        short = name.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0]
         key = (short, r.get("Grid_Size", ""), r.get("LDS_Block_Size", ""))
         rows[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for key, cs in sorted(rows.items(), key=lambda kv: -sum(kv[1].get("SQ_WAVE_CYCLES", [0]))):
