@@ -36,7 +36,8 @@ class BtcOccConfig(ctypes.Structure):
                 ("det_zmin", ctypes.c_float), ("det_zmax", ctypes.c_float),
                 ("w_fore_cls", ctypes.c_float), ("w_mirr_cls", ctypes.c_float), ("w_bm_cls", ctypes.c_float),
                 ("w_neg_cls", ctypes.c_float), ("w_fore_res", ctypes.c_float), ("w_mirr_res", ctypes.c_float),
-                ("w_bm_res", ctypes.c_float), ("box_weight", ctypes.c_float), ("backproject_lut", ctypes.c_void_p)]
+                ("w_bm_res", ctypes.c_float), ("box_weight", ctypes.c_float), ("backproject_lut", ctypes.c_void_p),
+                ("reverse_vis", ctypes.c_int32), ("vis_half", ctypes.c_int32)]
 
 
 OCC_BUFFER_FIELDS = ["vcc_mask", "voxelwise_mask", "bm_voxelwise_mask", "occ_voxelwise_mask", "fore_voxelwise_mask",

@@ -258,7 +258,6 @@ __global__ __launch_bounds__(64) void topk_mask(TopkArgs a) {
   if (cb < rb) return;
   __shared__ float sbox[64 * 7];
   const float* boxes = a.work + (size_t)s * a.Tmax * 7;
-  const int col_blocks = a.T / 64;
   for (int e = threadIdx.x; e < 64 * 7; e += 64) sbox[e] = boxes[(size_t)cb * 64 * 7 + e];
   __syncthreads();
   const int i = rb * 64 + threadIdx.x;

@@ -36,6 +36,8 @@ struct OccParams {
   int G;                    // padded boxes per scene
   float w_fore_cls, w_mirr_cls, w_bm_cls, w_neg_cls, w_fore_res, w_mirr_res, w_bm_res, box_weight;
   int use_box_weight;
+  int reverse_vis;          // REVERSE_VIS: 0 NOTHING, 1 VCC, 2 BACK_TRACK (occ_targets_template.py:110-134)
+  int vis_half;             // VCC: cells in front of a hit that stay visible = (DIST_KERN[2] + 1) / 2
 };
 
 constexpr float kPi = 3.14159274101257324f;        // float32(np.pi)
@@ -230,9 +232,10 @@ __global__ __launch_bounds__(256) void occ_ray_project(const uint8_t* __restrict
   if (ray >= nrays) return;
   int sy = ray % P.sny, sz = (ray / P.sny) % P.snz, b = ray / (P.sny * P.snz);
   const uint8_t* r = smap + (size_t)ray * P.snx;
-  // value the reference writes into column 0 of this ray
-  int col0;
-  if (P.empt_thresh >= 0) {
+  // hits of the ray as bit masks, 64 range bins a word (snx <= 512); column 0 carries the EMPT_SUR_THRESH fix in the configured mode only
+  // (the reference applies it in the NOTHING branch of occ_from_sphere_ocp alone, occ_targets_template.py:128-130)
+  int col0 = r[0];
+  if (P.reverse_vis == 0 && P.empt_thresh >= 0) {
     int neigh = 0;
     for (int dz = -1; dz <= 1; ++dz)
       for (int dy = -1; dy <= 1; ++dy) {
@@ -240,28 +243,54 @@ __global__ __launch_bounds__(256) void occ_ray_project(const uint8_t* __restrict
         if (zz >= 0 && zz < P.snz && yy >= 0 && yy < P.sny) neigh += ray_cnt[((size_t)b * P.snz + zz) * P.sny + yy];
       }
     col0 = (ray_cnt[ray] == 0) && (neigh > P.empt_thresh);
-  } else {
-    col0 = r[0];
   }
-  // first occupied range bin
+  constexpr int MAXW = 8;
+  unsigned long long hit[MAXW + 1], sel[MAXW];
+  const int nw = (P.snx + 63) >> 6;
   int first = P.snx;
-  for (int base = 0; base < P.snx; base += 64) {
-    int x = base + lane;
-    int bit = 0;
-    if (x < P.snx) bit = (x == 0) ? col0 : r[x];
-    unsigned long long m = __ballot(bit != 0);
-    if (m) {
-      first = base + __ffsll((long long)m) - 1;
-      break;
+#pragma unroll
+  for (int w = 0; w < MAXW; ++w) {
+    hit[w] = 0ull;
+    if (w < nw) {
+      const int x = w * 64 + lane;
+      int bit = 0;
+      if (x < P.snx) bit = (x == 0) ? col0 : r[x];
+      hit[w] = __ballot(bit != 0);
+      if (hit[w] && first == P.snx) first = w * 64 + __ffsll((long long)hit[w]) - 1;
     }
   }
-  if (first >= P.snx) return;
+  hit[MAXW] = 0ull;
+  if (P.reverse_vis == 1) {
+    // VCC: every cell counts except the vis_half cells IN FRONT of a hit (x + 1 .. x + vis_half holds a hit), unless hit itself
+#pragma unroll
+    for (int w = 0; w < MAXW; ++w) {
+      unsigned long long front = 0ull;
+      for (int d = 1; d <= P.vis_half && d < 64; ++d) front |= (hit[w] >> d) | (hit[w + 1] << (64 - d));
+      sel[w] = hit[w] | ~front;
+    }
+  } else {
+    // NOTHING: at or behind the first hit (none: nothing).  BACK_TRACK: behind the last hit or at / behind the first = the same set on a
+    // ray with a hit, and EVERY cell of a ray without one
+    if (first >= P.snx) {
+      if (P.reverse_vis != 2) return;
+      first = 0;
+    }
+#pragma unroll
+    for (int w = 0; w < MAXW; ++w) {
+      const int lo = first - w * 64;
+      sel[w] = lo <= 0 ? ~0ull : (lo >= 64 ? 0ull : (~0ull << lo));
+    }
+  }
   uint8_t* occ_b = occ_raw + (size_t)b * P.nz * P.ny * P.nx;
   if (lut) {   // static table of the corner lattice (coalesced 4-byte reads, no transcendental in the step)
     const int32_t* l = lut + ((size_t)sz * P.sny + sy) * P.snx;
-    for (int x = first + lane; x < P.snx; x += 64) {
-      const int c = l[x];
-      if (c >= 0) occ_b[c] = 1;
+#pragma unroll
+    for (int w = 0; w < MAXW; ++w) {
+      const int x = w * 64 + lane;
+      if (w < nw && x < P.snx && ((sel[w] >> lane) & 1ull)) {
+        const int c = l[x];
+        if (c >= 0) occ_b[c] = 1;
+      }
     }
     return;
   }
@@ -269,9 +298,13 @@ __global__ __launch_bounds__(256) void occ_ray_project(const uint8_t* __restrict
   float el = __fadd_rn(__fmul_rn((float)sz, P.s_vs[2]), P.s_origin[2]);
   float az = __fadd_rn(__fmul_rn((float)sy, P.s_vs[1]), P.s_origin[1]);
   float ce = cr_cos(deg2rad(el)), se = cr_sin(deg2rad(el)), ca = cr_cos(deg2rad(az)), sa = cr_sin(deg2rad(az));
-  for (int x = first + lane; x < P.snx; x += 64) {
-    const int c = backproject_cell(P, x, ce, se, ca, sa);
-    if (c >= 0) occ_b[c] = 1;
+#pragma unroll
+  for (int w = 0; w < MAXW; ++w) {
+    const int x = w * 64 + lane;
+    if (w < nw && x < P.snx && ((sel[w] >> lane) & 1ull)) {
+      const int c = backproject_cell(P, x, ce, se, ca, sa);
+      if (c >= 0) occ_b[c] = 1;
+    }
   }
 }
 
@@ -484,6 +517,8 @@ static void occ_params_from(const BtcOccConfig* cfg, OccParams& P) {
   P.w_fore_cls = cfg->w_fore_cls; P.w_mirr_cls = cfg->w_mirr_cls; P.w_bm_cls = cfg->w_bm_cls; P.w_neg_cls = cfg->w_neg_cls;
   P.w_fore_res = cfg->w_fore_res; P.w_mirr_res = cfg->w_mirr_res; P.w_bm_res = cfg->w_bm_res; P.box_weight = cfg->box_weight;
   P.use_box_weight = cfg->use_box_weight;
+  P.reverse_vis = cfg->reverse_vis;
+  P.vis_half = cfg->vis_half;
 }
 
 extern "C" int btc_occ_backproject_lut(const BtcOccConfig* cfg, int32_t* lut, void* stream_) {
@@ -504,6 +539,8 @@ extern "C" int btc_occ_targets(const BtcOccConfig* cfg, float* voxels, const int
   BTC_CHECK_ARG(cfg && out, "btc_occ_targets: null config / buffers");
   BTC_CHECK_ARG(C >= 3 && M >= 0 && max_points >= 1, "btc_occ_targets: bad voxel layout");
   BTC_CHECK_ARG(ws_bytes >= btc_occ_targets_ws_bytes(cfg), "btc_occ_targets: workspace too small");
+  BTC_CHECK_ARG(cfg->sphere_grid[0] <= 512 && cfg->reverse_vis >= 0 && cfg->reverse_vis <= 2 && cfg->vis_half >= 0 && cfg->vis_half < 64,
+                "btc_occ_targets: support sphere wider than 512 range bins, or bad REVERSE_VIS settings");
   OccParams P;
   occ_params_from(cfg, P);
 

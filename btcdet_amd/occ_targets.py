@@ -69,8 +69,10 @@ class OccTargets3D(nn.Module):
         self.model_cfg, self.data_cfg, self.num_class = model_cfg, data_cfg, num_class
         occ = data_cfg.OCC
         assert occ.COORD_TYPE == "cylinder", "only the configured cylinder occupancy grid is implemented"
-        assert occ.DROPOUT_RATE <= 1e-3, "occupancy dropout is off in the configured model"
-        assert model_cfg.PARAMS.get("REVERSE_VIS", "NOTHING") == "NOTHING"
+        self.dropout_rate = float(occ.get("DROPOUT_RATE", 0.0))            # occ_targets_template.py:297-328 (round 4)
+        self.dropout_rmv = bool(occ.get("DROPOUT_RMV", False))
+        self.reverse_vis = model_cfg.PARAMS.get("REVERSE_VIS", "NOTHING")   # occ_targets_template.py:110-134 (round 4)
+        assert self.reverse_vis in ("NOTHING", "VCC", "BACK_TRACK"), self.reverse_vis
         self.reg = model_cfg.PARAMS.get("REG", False)
         assert self.reg and model_cfg.TARGETS.TMPLT, "configured variant: REG True, TMPLT True"
         self.nx, self.ny, self.nz = [int(g) for g in grid_size]
@@ -111,6 +113,10 @@ class OccTargets3D(nn.Module):
         c.w_bm_cls, c.w_neg_cls = lw["occ_bm_cls_weight"], lw["occ_neg_cls_weight"]
         c.w_fore_res, c.w_mirr_res = lw.get("occ_fore_res_weight", 0.1), lw.get("occ_mirr_res_weight", 0.1)
         c.w_bm_res, c.box_weight = lw.get("occ_bm_res_weight", 0.1), occ.BOX_WEIGHT
+        c.reverse_vis = {"NOTHING": 0, "VCC": 1, "BACK_TRACK": 2}[self.reverse_vis]
+        c.vis_half = (int(kern[2]) + 1) // 2
+        self.fore_dropout_cls_weight = float(lw.get("fore_dropout_cls_weight", 0.0))
+        self.fore_dropout_reg_weight = float(lw.get("fore_dropout_reg_weight", 0.0))
         self._cfg = c
         # back-projection of the occluded sphere cells (a10): "torch" (default) -- a static table made once with torch's own CPU
         # kernels, i.e. the arithmetic a CPU run of the reference quantises on (backproject_table_host: 0 cells differ from the
@@ -140,6 +146,46 @@ class OccTargets3D(nn.Module):
                 check(lib().btc_occ_backproject_lut(ctypes.byref(c), ptr(lut), stream_ptr()), "btc_occ_backproject_lut")
             self._lut[key] = lut
         return lut
+
+    def _dropout(self, batch_dict, out, coords, bs):
+        """OCC.DROPOUT_RATE > 1e-3 in training (occ_targets_template.py:305-328, :342-343, :391-392): per scene a random share (uniform in
+        [0, rate)) of the voxels is drawn WITH replacement; their payload is zeroed (DROPOUT_RMV: the voxels are removed) AFTER the targets
+        were formed from all of them, and dropped foreground cells weigh more in both loss maps.  The draw uses numpy's and torch's
+        generators as the reference does (`batch_dict['__dropped__']`, an (M,) bool tensor, replaces it: the tests compare on the
+        reference's own draw).  An option path: a few torch ops and one read-back of the per-scene voxel counts."""
+        dropped = batch_dict.pop("__dropped__", None)
+        M = coords.shape[0]
+        if dropped is None:
+            ratios = np.random.uniform(high=self.dropout_rate, size=bs)
+            counts = torch.bincount(coords[:, 0].long(), minlength=bs)[:bs].tolist()
+            starts = np.concatenate([[0], np.cumsum(counts)])       # (scenes are contiguous in collate order; a general batch sorts first)
+            order = torch.argsort(coords[:, 0].long(), stable=True)
+            dropped = torch.zeros((M,), dtype=torch.bool, device=coords.device)
+            for i in range(bs):
+                k = int(counts[i] * ratios[i])
+                if k > 0:
+                    pick = torch.randint(low=0, high=int(counts[i]), size=[k], device=coords.device)
+                    dropped[order[int(starts[i]) + pick]] = True
+        dropped = dropped.to(coords.device).bool()
+        dc = coords[dropped].long()
+        drop_mask = torch.zeros((bs, self.nz, self.ny, self.nx), dtype=torch.uint8, device=coords.device)
+        drop_mask[dc[:, 0], dc[:, 1], dc[:, 2], dc[:, 3]] = 1
+        fore_drop = out["fore_voxelwise_mask"] & drop_mask
+        if self.fore_dropout_cls_weight > 1e-4:
+            out["general_cls_loss_mask_float"] = out["general_cls_loss_mask_float"] + \
+                (out["general_cls_loss_mask"] & fore_drop).to(torch.float32) * self.fore_dropout_cls_weight
+        if self.fore_dropout_reg_weight > 1e-4:
+            out["general_reg_loss_mask_float"] = out["general_reg_loss_mask_float"] + \
+                (out["general_reg_loss_mask"] & fore_drop).to(torch.float32) * self.fore_dropout_reg_weight
+        out["voxel_drop_mask"], out["fore_voxel_drop_mask"] = drop_mask, fore_drop
+        if self.dropout_rmv:
+            keep = ~dropped
+            batch_dict['voxels'] = batch_dict['voxels'][keep]
+            batch_dict['voxel_coords'] = batch_dict['voxel_coords'][keep]
+            batch_dict['voxel_num_points'] = batch_dict['voxel_num_points'][keep]
+            # (voxel_point_mask / final_point_mask keep their M rows, as in the reference: occ_targets_3d.py:30-40)
+        else:
+            batch_dict['voxels'][dropped] = 0
 
     def get_paddings_indicator(self, actual_num, max_num, axis=0):
         return actual_num.int().unsqueeze(1) > torch.arange(max_num, dtype=torch.int, device=actual_num.device).view(1, -1)
@@ -191,6 +237,8 @@ class OccTargets3D(nn.Module):
                                 ptr(bm), n_bm, ptr(rot_z), ptr(self.all_voxel_centers), ctypes.byref(bufs), ptr(ws), ws_bytes,
                                 stream_ptr()), "btc_occ_targets")
         batch_dict['voxels'] = vox  # absolute xyz payload (USE_ABSXYZ True)
+        if self.dropout_rate > 1e-3 and batch_dict.get("is_train", True):
+            self._dropout(batch_dict, out, coords, bs)
         out["occ_voxelwise_mask"] = out["occ_voxelwise_mask"].bool()
         out["pos_all_num"] = out["pos_all_num"][0]
         if not batch_dict.get("is_train", True):

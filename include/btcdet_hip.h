@@ -400,6 +400,8 @@ typedef struct BtcOccConfig {
    * cos / sin / atan2 / sqrt; a table evaluated with that platform's arithmetic reproduces its cells exactly
    * (btc_occ_backproject_lut fills one with the device's own arithmetic). */
   const int32_t* backproject_lut;
+  int32_t reverse_vis;      /* MODEL.OCC.PARAMS.REVERSE_VIS (occ_targets_template.py:110-134): 0 NOTHING (configured), 1 VCC, 2 BACK_TRACK */
+  int32_t vis_half;         /* VCC: (DIST_KERN[2] + 1) / 2 cells in front of a hit stay visible */
 } BtcOccConfig;
 
 typedef struct BtcOccBuffers {

@@ -139,6 +139,9 @@ class OccOracle(object):
         self.lw = lw
         self.box_weight = d.OCC.BOX_WEIGHT
         self.empt_thresh = d.OCC.EMPT_SUR_THRESH
+        self.reverse_vis = m.PARAMS.get("REVERSE_VIS", "NOTHING")        # occ_targets_template.py:66
+        self.dropout_rate = d.OCC.get("DROPOUT_RATE", 0.0)
+        self.dropout_rmv = d.OCC.get("DROPOUT_RMV", False)
         self.centers, self.centers_2d = self.voxel_centers()
 
     def voxel_centers(self):
@@ -189,16 +192,37 @@ class OccOracle(object):
         c, inds = self.point2coords_inrange(sp, self.s_origin, self.s_max, self.s_max_grid, self.min_grid, self.s_vs)
         bb = b[inds]
         smap[bb, c[..., 2], c[..., 1], c[..., 0]] = 1
+        return smap
+
+    def occluded_sphere(self, smap):
+        """occ_from_sphere_ocp (occ_targets_template.py:110-134): which cells of the support sphere map count as occluded / unknown.
+        NOTHING (configured): the EMPT_SUR_THRESH fix (in place on column 0, :128-130,186-191), then everything at or behind the first hit
+        of a ray; VCC: everything except the DIST_KERN[2] + 1 >> 1 cells in front of a hit (unless hit themselves); BACK_TRACK: behind
+        the LAST hit, or at / behind the first -- which differs from NOTHING only on rays without any hit (all of them count)."""
+        if self.reverse_vis == "VCC":
+            stride = self.kern[2] + 1
+            inds = torch.nonzero(smap)
+            inds = inds.unsqueeze(1).repeat(1, stride // 2, 1)
+            inds[..., :, 3:4] -= torch.arange(1, stride // 2 + 1).view(1, stride // 2, 1).repeat(inds.shape[0], 1, 1)
+            inds[..., :, 3] = torch.clamp(inds[..., :, 3], min=0, max=None)
+            inds = inds.view(-1, 4)
+            occ = torch.ones_like(smap)
+            occ[inds[..., 0], inds[..., 1], inds[..., 2], inds[..., 3]] = 0
+            return occ | smap
+        if self.reverse_vis == "BACK_TRACK":
+            rev = torch.flip(smap, [3])
+            occ = torch.flip(torch.cumsum(rev, dim=3) < 0.9, [3])
+            return occ | (torch.cumsum(smap, dim=3) > 0.9)
         if self.empt_thresh != "None" and self.empt_thresh < 9:
             cnt = torch.sum(smap, dim=3)
             nb = F.conv2d(cnt.unsqueeze(1).to(torch.float32), torch.ones(1, 1, 3, 3), padding=1) > self.empt_thresh
             smap[:, :, :, 0] = (cnt == 0) & nb.squeeze(1)
-        return smap
+        return torch.cumsum(smap, dim=3) > 0.9
 
     def occ_from_cylin(self, bs, pts, b, rot_z):
         """occ_targets_template.py:136-155"""
         smap = self.sphere_map(bs, pts, b, rot_z)
-        occl = torch.cumsum(smap, dim=3) > 0.9
+        occl = self.occluded_sphere(smap)
         idx = torch.nonzero(occl)
         sb = idx[..., 0]
         sp = idx[..., 1:] * self.s_rev_vs + self.s_rev_origin
@@ -242,9 +266,11 @@ class OccOracle(object):
         return torch.cat([b[inds].unsqueeze(-1), torch.stack([c[..., 2], c[..., 1], c[..., 0]], dim=-1)], dim=-1), inds
 
     # ------------------------------------------------------------------ OccTargets3D.forward (REG = True)
-    def targets(self, bd):
+    def targets(self, bd, dropped=None):
         """occ_targets_3d.py:18-93 + occ_targets_template.py:330-401.  bd holds float32 tensors as after
-        load_data_to_gpu (models/__init__.py:16-22); returns the batch_dict additions."""
+        load_data_to_gpu (models/__init__.py:16-22); returns the batch_dict additions.
+        dropped: (M,) bool -- the voxels OCC.DROPOUT_RATE > 1e-3 drops in training (occ_targets_template.py:305-328 draws them with
+        np.random.uniform + torch.randint; the draw is an input here so that two implementations can be compared on the same one)"""
         vox, num, vcoords = bd['voxels'], bd['voxel_num_points'], bd['voxel_coords']
         gt, gtn, rot_z = bd["gt_boxes"], bd["gt_boxes_num"], bd["rot_z"]
         bs = gt.shape[0]
@@ -352,6 +378,23 @@ class OccOracle(object):
         reg_w = f_cls.float() * lw.get("occ_fore_res_weight", 0.1) + m_cls.float() * lw.get("occ_mirr_res_weight", 0.1) + \
             b_cls.float() * lw.get("occ_bm_res_weight", 0.1)
         reg_m = (reg_w > 0).to(torch.uint8)
+        if dropped is not None and self.dropout_rate > 1e-3 and bd.get("is_train", True):
+            # dropout (occ_targets_template.py:305-328): the dropped voxels' payload is zeroed (or the voxels removed, DROPOUT_RMV) AFTER the
+            # targets were formed from all of them; dropped foreground cells weigh more in both losses (:342-343, :391-392)
+            dc = vcoords[dropped].to(torch.int64)
+            drop_mask = self._scatter1(self._mask(bs), dc)
+            fore_drop = fore_mask & drop_mask
+            if lw["fore_dropout_cls_weight"] > 1e-4:
+                cls_w = cls_w + (gen & fore_drop).float() * lw["fore_dropout_cls_weight"]
+            if lw["fore_dropout_reg_weight"] > 1e-4:
+                reg_w = reg_w + (reg_m & fore_drop).float() * lw["fore_dropout_reg_weight"]
+            out["voxel_drop_mask"], out["fore_voxel_drop_mask"] = drop_mask, fore_drop
+            if self.dropout_rmv:
+                keep = ~dropped
+                out["voxels"], out["_voxel_coords"], out["_voxel_num_points"] = out["voxels"][keep], vcoords[keep], num[keep]
+            else:
+                out["voxels"] = out["voxels"].clone()
+                out["voxels"][dropped] = 0
         res = fore_res * reg_m.unsqueeze(1) + mirr_res * reg_m.unsqueeze(1) + bm_res * reg_m.unsqueeze(1)
         out.update({"vcc_mask": vcc, "voxelwise_mask": voxelwise, "bm_voxelwise_mask": bm_mask, "occ_voxelwise_mask": occ,
                     "fore_voxelwise_mask": fore_mask, "pos_mask": pos, "general_cls_loss_mask": gen,
