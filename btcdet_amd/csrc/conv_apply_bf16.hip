@@ -162,22 +162,22 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_apply_b(const unsigned shor
       const char* B = ring + st * STAGE + A_BYTES;
       const int aswz = ((wr * 16 + arow) / RPB) & (UPR - 1);
       constexpr int STEPS = KC / 32;
-      uint4 a[STEPS], b[STEPS][NTW];
+      bf16x8 a[STEPS], b[STEPS][NTW];   // typed vector loads: an untyped (uint4) LDS read draws a compiler-inserted vmcnt(0), see conv_apply_split.hip
 #pragma unroll
       for (int s = 0; s < STEPS; ++s) {
         const int q = s * 4 + kq;
-        a[s] = *(const uint4*)(A + ((q ^ aswz) * 16));
+        a[s] = *(const bf16x8*)(A + ((q ^ aswz) * 16));
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt) {
           const int col = (wc * NTW + nt) * 16 + arow;
-          b[s][nt] = *(const uint4*)(B + col * (KC * 2) + ((q ^ ((col / RPB) & (UPR - 1))) * 16));
+          b[s][nt] = *(const bf16x8*)(B + col * (KC * 2) + ((q ^ ((col / RPB) & (UPR - 1))) * 16));
         }
       }
 #pragma unroll
       for (int s = 0; s < STEPS; ++s)
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt)
-          acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[s]), __builtin_bit_cast(bf16x8, b[s][nt]), acc[nt], 0, 0, 0);
+          acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[s], b[s][nt], acc[nt], 0, 0, 0);
     }
     st = (st == B_STAGES - 1) ? 0 : st + 1;
   }

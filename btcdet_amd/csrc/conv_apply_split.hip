@@ -28,11 +28,20 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 namespace {
 
-__device__ float g_zero_row_s[64];  // zero-initialised source of gathers for absent neighbours (>= KC fp32)
 
 
 __device__ __forceinline__ void glds16s(const void* g, void* l) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+
+// gathered activation rows travel through a raw buffer descriptor over the feature tensor: a lane whose offset lies past num_records
+// reads nothing and WRITES ZEROS to its 16 bytes of LDS (tools/lds_dma_oob.hip checks exactly that on the device) -- the lanes of an
+// absent neighbour (submanifold levels: 17 of 27 on average) cost no L2 -> LDS traffic at all, where they used to fetch a zero row.
+// Offsets are 32-bit: a source tensor of 4 GB or more traps (conv_apply_g takes any size).
+#define BTC_RSRC_RECORDS 0xFFFFFF00u
+#define BTC_RSRC_ABSENT 0xFFFFFFF0u
+__device__ __forceinline__ void blds16s(__amdgpu_buffer_rsrc_t rsrc, unsigned voffset, void* l) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)l, 16, voffset, 0, 0, 0);
 }
 
 template <int N>
@@ -77,6 +86,7 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_apply_s(const float* __rest
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave / WC, wc = wave % WC;
   const int mirror = (flags >> 1) & 1;   // a submanifold FORWARD map read as the backward map (column K-1-k), see conv_apply_g
+  const int dbg = flags >> 8;            // timing experiments (BTC_TUNE_APPLY_DEBUG, wrong results): 1 no products, 2 no loads inside the loop, 4 no weight panels, 8 no row gathers
   int bx = blockIdx.x;
   if (flags & 1) {
     const int nb = gridDim.x, per = nb >> 3, main = per << 3;
@@ -86,6 +96,7 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_apply_s(const float* __rest
   const int n0 = blockIdx.y * TN;
   const size_t plane = (size_t)K * Cred * Cres;   // elements between two planes of Ws
 
+  const int nb_max = (int)(BTC_RSRC_RECORDS / ((unsigned)Cred * 4u)) - 1;   // rows the 32-bit offsets of the gathers reach
   for (int e = tid; e < K; e += THREADS) s_kact[e] = 0;
   for (int e = tid; e < TM; e += THREADS) s_row[e] = (row0 + e < n_rows) ? (order ? order[row0 + e] : row0 + e) : -1;
   __syncthreads();
@@ -93,6 +104,7 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_apply_s(const float* __rest
     const int rloc = e / K, kk = e - rloc * K;
     const int gr = s_row[rloc];
     const int v = gr >= 0 ? nbr[(long long)gr * K + (mirror ? K - 1 - kk : kk)] : -1;
+    if (v > nb_max) __builtin_trap();   // a source tensor past the 32-bit offsets of the gathers (4 GB)
     s_nbr[e] = v;
     if (v >= 0) s_kact[kk] = 1;
   }
@@ -112,13 +124,14 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_apply_s(const float* __rest
     if (lane == 0) *s_nact = __popcll(m);
   }
   __syncthreads();
-  const int n_act = *s_nact;
+  const int n_act = __builtin_amdgcn_readfirstlane(*s_nact);   // (uniform: keeps the item cursors in scalar registers)
   const int n_chunks = Cred / KC;
   // gridDim.z > 1: the workgroups z = 0 .. Z-1 of a tile share its (offset, chunk) items -- contiguous ranges, in order -- and each
   // writes its partial sums to slab z of `out` (n_rows x Cres floats each; split_reduce adds them up in z order).  For levels
   // of a few thousand rows: one workgroup per tile walks 54-108 items one after the other while most CUs have nothing to do.
   const int n_all = n_act * n_chunks;
-  const int i0 = (int)((long long)blockIdx.z * n_all / gridDim.z), n_items = (int)((long long)(blockIdx.z + 1) * n_all / gridDim.z);
+  const int i0 = (int)((long long)blockIdx.z * n_all / gridDim.z);
+  const int n_items = (dbg & 32) ? i0 : (int)((long long)(blockIdx.z + 1) * n_all / gridDim.z);   // (32: no item loop)
   float* const slab0 = out;
   out += (size_t)blockIdx.z * n_rows * Cres;
 
@@ -135,31 +148,51 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_apply_s(const float* __rest
   // per item and side: an EMPTY item loop measured 0.5 us per item with three workgroups per CU, additive to the loads and MFMAs)
   int iq = i0 / n_chunks, ir = i0 - iq * n_chunks;
   int cq = iq, cr = ir;
+  const __amdgpu_buffer_rsrc_t rfeat = __builtin_amdgcn_make_buffer_rsrc((void*)feat, 0, BTC_RSRC_RECORDS, 0x00020000);
+  // No LDS round trip on the way to a DMA: the tile's active offsets sit in one register across the lanes (lane a = the a-th active
+  // offset; v_readlane with the cursor), and the neighbours of the rows this wave gathers are read one item AHEAD, behind the issue of
+  // the item before (an item used to open with s_kact -> wait -> s_nbr -> wait -> address, per DMA instruction, in every wave at once).
+  const int kvec = lane < n_act ? s_kact[lane] : 0;
+  int nbq[NAI];
+  auto load_nbq = [&]() {
+    const int k = __builtin_amdgcn_readlane(kvec, iq);
+#pragma unroll
+    for (int t = 0; t < NAI; ++t) {
+      const int U = ((wave + NW * t) % NAI_TOTAL) * 64 + lane;
+      nbq[t] = s_nbr[(U / UPA) * K + k];
+    }
+  };
+  load_nbq();
   auto issue = [&](int st) {
-    const int k = s_kact[iq];
+    const int k = __builtin_amdgcn_readlane(kvec, iq);
     const int cc = ir * KC;
-    if (++ir == n_chunks) { ir = 0; ++iq; }
     char* As = ring + st * STAGE;
     char* Bs = As + A_BYTES;
 #pragma unroll
     for (int t = 0; t < NAI; ++t) {
+      if (dbg & 8) break;
       const int ai = (wave + NW * t) % NAI_TOTAL;
       const int U = ai * 64 + lane;
       const int rloc = U / UPA;
       const int u = (U % UPA) ^ ((rloc ^ (rloc >> 3)) & (UPA - 1));
-      const int nb = s_nbr[rloc * K + k];
-      const float* src = nb >= 0 ? feat + (size_t)nb * Cred + cc + u * 4 : g_zero_row_s;
-      glds16s(src, As + ai * 1024);
+      const int nb = nbq[t];
+      blds16s(rfeat, nb >= 0 ? ((unsigned)nb * (unsigned)Cred + (unsigned)(cc + u * 4)) * 4u : BTC_RSRC_ABSENT, As + ai * 1024);
     }
     const unsigned short* Wk = Ws + ((size_t)k * Cres + n0) * Cred + cc;
 #pragma unroll
     for (int t = 0; t < NBI; ++t) {
+      if (dbg & 4) break;
       const int bi = (wave + NW * t) % NBI_TOTAL;
       const int U = bi * 64 + lane;
       const int pl = U / (TN * UPB), rem = U % (TN * UPB);
       const int c = rem / UPB;
       const int u = (rem % UPB) ^ ((c >> 1) & (UPB - 1));
       glds16s(Wk + pl * plane + (size_t)c * Cred + u * 8, Bs + bi * 1024);
+    }
+    if (++ir == n_chunks) {
+      ir = 0;
+      ++iq;
+      load_nbq();   // (past the last active offset: lane n_act of kvec holds 0, a harmless read)
     }
   };
 
@@ -177,29 +210,46 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_apply_s(const float* __rest
     else wait_vm_s<0>();
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    if (item + S_STAGES - 1 < n_items) issue(st == 0 ? S_STAGES - 1 : st - 1);
-    const int k = s_kact[cq];
+    if (item + S_STAGES - 1 < n_items && !(dbg & 2)) issue(st == 0 ? S_STAGES - 1 : st - 1);
+    // (pinned: hipcc is free to sink the DMA issue below the products -- it did, in the 128-row instances -- and with two stages the
+    // loop's next wait then meets loads that were issued a moment ago)
+    asm volatile("" ::: "memory");
+    const int k = __builtin_amdgcn_readlane(kvec, cq);
     if (++cr == n_chunks) { cr = 0; ++cq; }
-    if ((wave_act >> k) & 1ull) {
+    if (((wave_act >> k) & 1ull) && !(dbg & 1)) {
       const int r = wr * 16 + arow;
       const char* A = ring + st * STAGE + r * (KC * 4);
       const char* B = ring + st * STAGE + A_BYTES;
       const int aswz = (r ^ (r >> 3)) & (UPA - 1);
       constexpr int STEPS = KC / 32;
+      // every fragment of the item is requested before the first product: one exposed LDS round trip per item instead of two per
+      // 32-channel step (left alone, hipcc reads A, waits, splits, reads B, waits, multiplies -- step after step)
+      // (typed vector loads: hipcc's waitcnt pass puts an `s_waitcnt vmcnt(0)` in front of an LDS read whose memory operand carries no
+      // type information -- a uint4 struct copy -- because it cannot order it against the LDS-DMA in flight: that wait sat between the
+      // A and the B reads of EVERY instance until round 4 and serialised the loads of item i + S - 1 with the products of item i;
+      // tools/isa_waits.py lists the waits inside the loop)
+      f32x4 av[STEPS][2];
+      bf16x8 bh[STEPS][NTW], bm[STEPS][NTW], bl[STEPS][NTW];
 #pragma unroll
       for (int s = 0; s < STEPS; ++s) {
         const int u0 = 8 * s + 2 * kg;   // channels 32 s + 8 kg .. + 7 of the lane's row
-        const f32x4 v0 = *(const f32x4*)(A + ((u0 ^ aswz) * 16));
-        const f32x4 v1 = *(const f32x4*)(A + (((u0 + 1) ^ aswz) * 16));
-        uint4 bh[NTW], bm[NTW], bl[NTW];
+        av[s][0] = *(const f32x4*)(A + ((u0 ^ aswz) * 16));
+        av[s][1] = *(const f32x4*)(A + (((u0 + 1) ^ aswz) * 16));
+      }
+#pragma unroll
+      for (int s = 0; s < STEPS; ++s)
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt) {
           const int col = (wc * NTW + nt) * 16 + arow;
           const char* bp = B + col * (KC * 2) + (((4 * s + kg) ^ ((col >> 1) & (UPB - 1))) * 16);
-          bh[nt] = *(const uint4*)bp;
-          bm[nt] = *(const uint4*)(bp + P_BYTES);
-          bl[nt] = *(const uint4*)(bp + 2 * P_BYTES);
+          bh[s][nt] = *(const bf16x8*)bp;
+          bm[s][nt] = *(const bf16x8*)(bp + P_BYTES);
+          bl[s][nt] = *(const bf16x8*)(bp + 2 * P_BYTES);
         }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int s = 0; s < STEPS; ++s) {
+        const f32x4 v0 = av[s][0], v1 = av[s][1];
         uint4 ah, am, al;
         split2(v0[0], v0[1], ah.x, am.x, al.x);
         split2(v0[2], v0[3], ah.y, am.y, al.y);
@@ -207,7 +257,7 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_apply_s(const float* __rest
         split2(v1[2], v1[3], ah.w, am.w, al.w);
         const bf16x8 Ah = __builtin_bit_cast(bf16x8, ah), Am = __builtin_bit_cast(bf16x8, am), Al = __builtin_bit_cast(bf16x8, al);
 #define S_MFMA(ACC, X, Y)                 \
-  _Pragma("unroll") for (int nt = 0; nt < NTW; ++nt) ACC[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(X, __builtin_bit_cast(bf16x8, Y[nt]), ACC[nt], 0, 0, 0)
+  _Pragma("unroll") for (int nt = 0; nt < NTW; ++nt) ACC[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(X, Y[s][nt], ACC[nt], 0, 0, 0)
         S_MFMA(accs, Al, bh);
         S_MFMA(accs, Ah, bl);
         S_MFMA(accs, Am, bm);
@@ -459,7 +509,7 @@ int btc_apply_split(const float* src, const void* Ws_, const float* bias_, const
   BTC_CHECK_ARG(btc_conv_split_supported(K, Cred, Cres), "conv_apply_s: needs K <= 64, Cred %% 32 == 0, Cres %% 64 == 0 (K=%d, %d -> %d)", K, Cred, Cres);
   const BnFuse bn = bn_ ? *bn_ : btc_bn_fuse_none();
   const unsigned short* Ws = (const unsigned short*)Ws_;
-  const int flags = (btc_tune_get(BTC_TUNE_APPLY_XCD) == 2 ? 1 : 0) | (mirror ? 2 : 0);
+  const int flags = (btc_tune_get(BTC_TUNE_APPLY_XCD) == 2 ? 1 : 0) | (mirror ? 2 : 0) | (btc_tune_get(BTC_TUNE_APPLY_DEBUG) << 8);
   const int t_nt = btc_tune_get(BTC_TUNE_APPLY_NT);
   // shapes / chunk from tools/conv_bench.py on MI355X (us per launch, exact fp32 chain -> this kernel): 256 -> 128 at 14 K rows 333 -> 200
   // (64 x 128 tile, 64-channel items, double buffer; 32-channel items with three stages 241), 128 -> 128 164 -> 102, 64 -> 64 at 14 K rows
@@ -490,7 +540,8 @@ int btc_apply_split(const float* src, const void* Ws_, const float* bias_, const
   if (Cres % 64 != 0) shape = n_rows >= 100000 ? 412 : 812;
   if ((t_nt == 812 || t_nt == 412) && Cres % 32 == 0) shape = t_nt;
   if ((t_nt == 224 || t_nt == 424) && Cres % 128 == 0) shape = t_nt;   // tuning runs
-  if ((t_nt == 222 || t_nt == 422) && Cres % 64 == 0) shape = t_nt;
+  if ((t_nt == 222 || t_nt == 422 || t_nt == 414 || t_nt == 814) && Cres % 64 == 0) shape = t_nt;
+  if ((t_nt == 418 || t_nt == 818) && Cres % 128 == 0) shape = t_nt;
   const int t_kc = btc_tune_get(BTC_TUNE_APPLY_KC), t_st = btc_tune_get(BTC_TUNE_APPLY_STAGES);
   int kc = (Cred % 64 == 0 && (shape % 10 == 4 || n_rows < 22000) && shape % 100 != 12) ? 64 : 32;
   if (t_kc == 32 || (t_kc == 64 && Cred % 64 == 0)) kc = t_kc;
@@ -498,6 +549,7 @@ int btc_apply_split(const float* src, const void* Ws_, const float* bias_, const
   // item, DESIGN.md section 5 --: 64 -> 32 at 28.8 K rows 47.6 -> 39.8 us, the dgrad of 32 -> 64 at 14.2 K rows 45.3 -> 37.4, at 3.1 K
   // rows 43.6 -> 36.2; `tools/conv_bench.py split split:4=32` is the comparison)
   if (shape % 100 == 12) kc = (Cred % 64 == 0 && t_kc != 32) ? 64 : 32;
+  if (shape == 818) kc = 32;   // (two 80 KB stages do not fit)
   int stages = t_st ? t_st : 3;
   if (kc == 64) stages = (t_st == 3 && shape == 422) ? 3 : 2;
   // z-split (conv_apply_s header): few rows -> few tiles -> most CUs idle while each workgroup walks its tile's 27-108 items alone.
@@ -537,6 +589,13 @@ int btc_apply_split(const float* src, const void* Ws_, const float* bias_, const
     case 4124: rc = launch_s<4, 1, 2, 32, 4>(S_ARGS); break;
     case 8123: rc = launch_s<8, 1, 2, 32, 3>(S_ARGS); break;
     case 8124: rc = launch_s<8, 1, 2, 32, 4>(S_ARGS); break;
+    case 4147: rc = launch_s<4, 1, 4, 64, 2>(S_ARGS); break;
+    case 4143: rc = launch_s<4, 1, 4, 32, 3>(S_ARGS); break;
+    case 8147: rc = launch_s<8, 1, 4, 64, 2>(S_ARGS); break;
+    case 8143: rc = launch_s<8, 1, 4, 32, 3>(S_ARGS); break;
+    case 4187: rc = launch_s<4, 1, 8, 64, 2>(S_ARGS); break;
+    case 4183: rc = launch_s<4, 1, 8, 32, 3>(S_ARGS); break;
+    case 8183: rc = launch_s<8, 1, 8, 32, 3>(S_ARGS); break;
     case 2223: rc = launch_s<2, 2, 2, 32, 3>(S_ARGS); break;
     case 2224: rc = launch_s<2, 2, 2, 32, 4>(S_ARGS); break;
     default:
