@@ -60,20 +60,26 @@ __device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned&
   lo = __builtin_amdgcn_perm(__float_as_uint(b2), __float_as_uint(a2), 0x07060302u);
 }
 
-template <int WR, int WC, int NTW, int KC, int S_STAGES>
-__global__ __launch_bounds__(64 * WR * WC) void conv_apply_s(const float* __restrict__ feat, const unsigned short* __restrict__ Ws,
+// LW > 0: LW extra LOADER waves per workgroup issue every LDS-DMA piece and wait for it; the WR x WC product waves never touch the
+// vector-memory queue.  An LDS-DMA instruction holds its wave until the CU's address unit has taken it (~20 cycles a piece behind
+// 40-64 pieces per item): with the product waves issuing their own pieces, every wave of the workgroup sat in that queue at the top
+// of every item and the matrix pipe idled -- loads and products ADDED (ablation: DESIGN.md section 5, round 4).
+template <int WR, int WC, int NTW, int KC, int S_STAGES, int LW>
+__global__ __launch_bounds__(64 * (WR * WC + LW)) void conv_apply_s(const float* __restrict__ feat, const unsigned short* __restrict__ Ws,
                                                              const float* __restrict__ bias, const int32_t* __restrict__ nbr,
                                                              const int32_t* __restrict__ order, int n_rows, int K, int Cred, int Cres,
                                                              float* __restrict__ out, int flags, const BnFuse bn, float* __restrict__ out_final,
                                                              int32_t* __restrict__ ztickets) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int NW = WR * WC, THREADS = 64 * NW;
+  constexpr int NW = WR * WC, THREADS = 64 * (NW + LW);
+  constexpr int NLD = LW ? LW : NW;                  // waves that issue the DMA pieces
   constexpr int TM = 16 * WR, TN = 16 * NTW * WC;
   constexpr int UPA = KC / 4, UPB = KC / 8;          // 16-byte units per A row (fp32) / per B^T row of one plane (bf16)
   constexpr int A_UNITS = TM * UPA, B_UNITS = 3 * TN * UPB;
   static_assert(A_UNITS % 64 == 0 && B_UNITS % 64 == 0, "whole DMA instructions");
-  constexpr int NAI_TOTAL = A_UNITS / 64, NAI = (NAI_TOTAL + NW - 1) / NW;
-  constexpr int NBI_TOTAL = B_UNITS / 64, NBI = (NBI_TOTAL + NW - 1) / NW;
+  constexpr int NAI_TOTAL = A_UNITS / 64, NAI = (NAI_TOTAL + NLD - 1) / NLD;
+  constexpr int NBI_TOTAL = B_UNITS / 64, NBI = (NBI_TOTAL + NLD - 1) / NLD;
+  static_assert(LW == 0 || (NAI_TOTAL % LW == 0 && NBI_TOTAL % LW == 0), "the loader waves share the pieces evenly");
   constexpr int NPI = NAI + NBI;
   constexpr int A_BYTES = TM * KC * 4, P_BYTES = TN * KC * 2;   // one plane of the weight panel
   constexpr int STAGE = A_BYTES + 3 * P_BYTES;
@@ -84,7 +90,9 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_apply_s(const float* __rest
   int32_t* s_row = s_nact + 1;                           // [TM] row of each tile slot (order[] or identity), -1 past the end
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wr = wave / WC, wc = wave % WC;
+  const bool computes = LW == 0 || wave < NW, loads = LW == 0 || wave >= NW;
+  const int wr = computes ? wave / WC : 0, wc = wave % WC;
+  const int lid = LW ? wave - NW : wave;   // this wave's place among the issuing waves
   const int mirror = (flags >> 1) & 1;   // a submanifold FORWARD map read as the backward map (column K-1-k), see conv_apply_g
   const int dbg = flags >> 8;            // timing experiments (BTC_TUNE_APPLY_DEBUG, wrong results): 1 no products, 2 no loads inside the loop, 4 no weight panels, 8 no row gathers
   int bx = blockIdx.x;
@@ -135,14 +143,6 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_apply_s(const float* __rest
   float* const slab0 = out;
   out += (size_t)blockIdx.z * n_rows * Cres;
 
-  // three accumulators per tile, one per magnitude class of the piece products (1, 2^-8, 2^-16 of |a b|): the matrix pipe aligns
-  // the 32 products of an instruction to the accumulator it adds them to, so small products added to a large running sum lose
-  // their low bits one by one (measured: 9x the exact chain's error on the 6912-term sums of the 256 -> 128 layer); summed among
-  // themselves they keep them, and the classes meet once, in the epilogue
-  f32x4 acc[NTW], accm[NTW], accs[NTW];
-#pragma unroll
-  for (int nt = 0; nt < NTW; ++nt) acc[nt] = accm[nt] = accs[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
   // cursors of the two walks over the tile's (offset, chunk) items -- issue runs S_STAGES - 1 items ahead of compute; both advance by
   // one item per call: no integer division by n_chunks inside the loop (a runtime divisor costs ~100 VALU instructions per wave, twice
   // per item and side: an EMPTY item loop measured 0.5 us per item with three workgroups per CU, additive to the loads and MFMAs)
@@ -158,11 +158,15 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_apply_s(const float* __rest
     const int k = __builtin_amdgcn_readlane(kvec, iq);
 #pragma unroll
     for (int t = 0; t < NAI; ++t) {
-      const int U = ((wave + NW * t) % NAI_TOTAL) * 64 + lane;
+      const int U = ((lid + NLD * t) % NAI_TOTAL) * 64 + lane;
       nbq[t] = s_nbr[(U / UPA) * K + k];
     }
   };
-  load_nbq();
+  if (loads) load_nbq();
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)Ws, 0, BTC_RSRC_RECORDS, 0x00020000);
+  static_assert(NLD % 2 == 0 && (TN * UPB) % 64 == 0 && 64 % UPB == 0, "one lane offset per issuing wave");
+  const int w_c = lane / UPB;   // panel row of the lane within a piece; (row >> 1) & (UPB - 1) of the piece's first row: 4 (lid & 1) at UPB = 8, 0 at UPB = 4
+  const unsigned w_lane = (unsigned)(w_c * Cred + (((lane % UPB) ^ (((w_c >> 1) + (UPB == 8 ? 4 * (lid & 1) : 0)) & (UPB - 1))) * 8)) * 2u;
   auto issue = [&](int st) {
     const int k = __builtin_amdgcn_readlane(kvec, iq);
     const int cc = ir * KC;
@@ -171,23 +175,24 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_apply_s(const float* __rest
 #pragma unroll
     for (int t = 0; t < NAI; ++t) {
       if (dbg & 8) break;
-      const int ai = (wave + NW * t) % NAI_TOTAL;
+      const int ai = (lid + NLD * t) % NAI_TOTAL;
       const int U = ai * 64 + lane;
       const int rloc = U / UPA;
       const int u = (U % UPA) ^ ((rloc ^ (rloc >> 3)) & (UPA - 1));
       const int nb = nbq[t];
       blds16s(rfeat, nb >= 0 ? ((unsigned)nb * (unsigned)Cred + (unsigned)(cc + u * 4)) * 4u : BTC_RSRC_ABSENT, As + ai * 1024);
     }
-    const unsigned short* Wk = Ws + ((size_t)k * Cres + n0) * Cred + cc;
+    // weight panel: piece bi of the issuing wave covers 64 / UPB panel rows (all three planes are 64-unit aligned); the lane's share
+    // of the address -- its row within the piece and its swizzled unit -- is the same for every piece of a wave (w_lane, below), the
+    // rest is scalar: one buffer load with a register offset + a scalar offset per piece, no per-piece address registers
+    const unsigned w_item = (unsigned)(((size_t)k * Cres + n0) * Cred + cc) * 2u;
 #pragma unroll
     for (int t = 0; t < NBI; ++t) {
       if (dbg & 4) break;
-      const int bi = (wave + NW * t) % NBI_TOTAL;
-      const int U = bi * 64 + lane;
-      const int pl = U / (TN * UPB), rem = U % (TN * UPB);
-      const int c = rem / UPB;
-      const int u = (rem % UPB) ^ ((c >> 1) & (UPB - 1));
-      glds16s(Wk + pl * plane + (size_t)c * Cred + u * 8, Bs + bi * 1024);
+      const int bi = (lid + NLD * t) % NBI_TOTAL;
+      const int pl = (bi * 64) / (TN * UPB), c0 = ((bi * 64) % (TN * UPB)) / UPB;
+      const unsigned w_piece = (unsigned)((size_t)pl * plane + (size_t)c0 * Cred) * 2u;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(Bs + bi * 1024), 16, w_lane, w_item + w_piece, 0, 0);
     }
     if (++ir == n_chunks) {
       ir = 0;
@@ -198,94 +203,133 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_apply_s(const float* __rest
 
   const int arow = lane & 15, kg = lane >> 4;
   static_assert((S_STAGES - 2) * NPI <= 63, "vmcnt is a 6-bit counter");
-#pragma unroll
-  for (int i = 0; i < S_STAGES - 1; ++i)
-    if (i0 + i < n_items) issue(i);
-  int st = 0;
-  for (int item = i0; item < n_items; ++item) {
-    // this item has landed; the min(S_STAGES - 2, items left) issued behind it stay in flight
-    const int left = n_items - 1 - item;
-    if (S_STAGES >= 4 && left >= 2) wait_vm_s<(S_STAGES >= 4 ? 2 : 0) * NPI>();
-    else if (S_STAGES >= 3 && left >= 1) wait_vm_s<(S_STAGES >= 3 ? 1 : 0) * NPI>();
-    else wait_vm_s<0>();
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    if (item + S_STAGES - 1 < n_items && !(dbg & 2)) issue(st == 0 ? S_STAGES - 1 : st - 1);
-    // (pinned: hipcc is free to sink the DMA issue below the products -- it did, in the 128-row instances -- and with two stages the
-    // loop's next wait then meets loads that were issued a moment ago)
-    asm volatile("" ::: "memory");
-    const int k = __builtin_amdgcn_readlane(kvec, cq);
-    if (++cr == n_chunks) { cr = 0; ++cq; }
-    if (((wave_act >> k) & 1ull) && !(dbg & 1)) {
-      const int r = wr * 16 + arow;
-      const char* A = ring + st * STAGE + r * (KC * 4);
-      const char* B = ring + st * STAGE + A_BYTES;
-      const int aswz = (r ^ (r >> 3)) & (UPA - 1);
-      constexpr int STEPS = KC / 32;
-      // every fragment of the item is requested before the first product: one exposed LDS round trip per item instead of two per
-      // 32-channel step (left alone, hipcc reads A, waits, splits, reads B, waits, multiplies -- step after step)
-      // (typed vector loads: hipcc's waitcnt pass puts an `s_waitcnt vmcnt(0)` in front of an LDS read whose memory operand carries no
-      // type information -- a uint4 struct copy -- because it cannot order it against the LDS-DMA in flight: that wait sat between the
-      // A and the B reads of EVERY instance until round 4 and serialised the loads of item i + S - 1 with the products of item i;
-      // tools/isa_waits.py lists the waits inside the loop)
-      f32x4 av[STEPS][2];
-      bf16x8 bh[STEPS][NTW], bm[STEPS][NTW], bl[STEPS][NTW];
-#pragma unroll
-      for (int s = 0; s < STEPS; ++s) {
-        const int u0 = 8 * s + 2 * kg;   // channels 32 s + 8 kg .. + 7 of the lane's row
-        av[s][0] = *(const f32x4*)(A + ((u0 ^ aswz) * 16));
-        av[s][1] = *(const f32x4*)(A + (((u0 + 1) ^ aswz) * 16));
-      }
-#pragma unroll
-      for (int s = 0; s < STEPS; ++s)
-#pragma unroll
-        for (int nt = 0; nt < NTW; ++nt) {
-          const int col = (wc * NTW + nt) * 16 + arow;
-          const char* bp = B + col * (KC * 2) + (((4 * s + kg) ^ ((col >> 1) & (UPB - 1))) * 16);
-          bh[s][nt] = *(const bf16x8*)bp;
-          bm[s][nt] = *(const bf16x8*)(bp + P_BYTES);
-          bl[s][nt] = *(const bf16x8*)(bp + 2 * P_BYTES);
-        }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int s = 0; s < STEPS; ++s) {
-        const f32x4 v0 = av[s][0], v1 = av[s][1];
-        uint4 ah, am, al;
-        split2(v0[0], v0[1], ah.x, am.x, al.x);
-        split2(v0[2], v0[3], ah.y, am.y, al.y);
-        split2(v1[0], v1[1], ah.z, am.z, al.z);
-        split2(v1[2], v1[3], ah.w, am.w, al.w);
-        const bf16x8 Ah = __builtin_bit_cast(bf16x8, ah), Am = __builtin_bit_cast(bf16x8, am), Al = __builtin_bit_cast(bf16x8, al);
-#define S_MFMA(ACC, X, Y)                 \
-  _Pragma("unroll") for (int nt = 0; nt < NTW; ++nt) ACC[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(X, Y[s][nt], ACC[nt], 0, 0, 0)
-        S_MFMA(accs, Al, bh);
-        S_MFMA(accs, Ah, bl);
-        S_MFMA(accs, Am, bm);
-        S_MFMA(accm, Am, bh);
-        S_MFMA(accm, Ah, bm);
-        S_MFMA(acc, Ah, bh);
-#undef S_MFMA
-      }
-    }
-    st = (st == S_STAGES - 1) ? 0 : st + 1;
-  }
-
-  // epilogue as conv_apply_g's: C/D layout of 16x16: col = lane & 15, row = (lane >> 4) * 4 + reg
   float vals[NTW][4];
   bool valid[4];
   const bool zred = ztickets != nullptr;   // z-split with the reduction in this launch: partial sums first, bias / statistics by the tile's last workgroup
+  if (LW > 0 && wave >= NW) {
+    // ---- loader waves: wait for an item's pieces, meet the product waves at the item's barrier, issue the item S - 1 ahead
+    // (two separate branches, so that the loaders' address registers and the product waves' accumulators share the register file)
 #pragma unroll
-  for (int nt = 0; nt < NTW; ++nt) {
-    const int col = n0 + (wc * NTW + nt) * 16 + (lane & 15);
-    const float bv0 = (bias && !zred) ? bias[col] : 0.f;
+    for (int i = 0; i < S_STAGES - 1; ++i)
+      if (i0 + i < n_items) issue(i);
+    int st = 0;
+    for (int item = i0; item < n_items; ++item) {
+      const int left = n_items - 1 - item;
+      if (S_STAGES >= 4 && left >= 2) wait_vm_s<(S_STAGES >= 4 ? 2 : 0) * NPI>();
+      else if (S_STAGES >= 3 && left >= 1) wait_vm_s<(S_STAGES >= 3 ? 1 : 0) * NPI>();
+      else wait_vm_s<0>();
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (item + S_STAGES - 1 < n_items && !(dbg & 2)) issue(st == 0 ? S_STAGES - 1 : st - 1);
+      st = (st == S_STAGES - 1) ? 0 : st + 1;
+    }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = s_row[wr * 16 + kg * 4 + r];
-      valid[r] = row >= 0;
-      const float sum = acc[nt][r] + (accm[nt][r] + accs[nt][r]);
-      const float v = (bias && !zred) ? (sum + bv0) : sum;
-      if (row >= 0) out[(size_t)row * Cres + col] = v;
-      vals[nt][r] = v;
+    for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) vals[nt][r] = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) valid[r] = false;   // (loader waves own no rows)
+  } else {
+    // three accumulators per tile, one per magnitude class of the piece products (1, 2^-8, 2^-16 of |a b|): the matrix pipe aligns
+    // the 32 products of an instruction to the accumulator it adds them to, so small products added to a large running sum lose
+    // their low bits one by one (measured: 9x the exact chain's error on the 6912-term sums of the 256 -> 128 layer); summed among
+    // themselves they keep them, and the classes meet once, in the epilogue
+    f32x4 acc[NTW], accm[NTW], accs[NTW];
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) acc[nt] = accm[nt] = accs[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < S_STAGES - 1; ++i)
+      if (LW == 0 && i0 + i < n_items) issue(i);
+    int st = 0;
+    for (int item = i0; item < n_items; ++item) {
+      // this item has landed; the min(S_STAGES - 2, items left) issued behind it stay in flight
+      const int left = n_items - 1 - item;
+      if (LW == 0) {
+        if (S_STAGES >= 4 && left >= 2) wait_vm_s<(S_STAGES >= 4 ? 2 : 0) * NPI>();
+        else if (S_STAGES >= 3 && left >= 1) wait_vm_s<(S_STAGES >= 3 ? 1 : 0) * NPI>();
+        else wait_vm_s<0>();
+      }
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (LW == 0 && item + S_STAGES - 1 < n_items && !(dbg & 2)) issue(st == 0 ? S_STAGES - 1 : st - 1);
+      // (pinned: hipcc is free to sink the DMA issue below the products -- it did, in the 128-row instances -- and with two stages the
+      // loop's next wait then meets loads that were issued a moment ago)
+      asm volatile("" ::: "memory");
+      const int k = __builtin_amdgcn_readlane(kvec, cq);
+      if (++cr == n_chunks) { cr = 0; ++cq; }
+      if (((wave_act >> k) & 1ull) && !(dbg & 1)) {
+        const int r = wr * 16 + arow;
+        const char* A = ring + st * STAGE + r * (KC * 4);
+        const char* B = ring + st * STAGE + A_BYTES;
+        const int aswz = (r ^ (r >> 3)) & (UPA - 1);
+        constexpr int STEPS = KC / 32;
+        // every fragment of the item is requested before the first product: one exposed LDS round trip per item instead of two per
+        // 32-channel step (left alone, hipcc reads A, waits, splits, reads B, waits, multiplies -- step after step)
+        // (typed vector loads: hipcc's waitcnt pass puts an `s_waitcnt vmcnt(0)` in front of an LDS read whose memory operand carries no
+        // type information -- a uint4 struct copy -- because it cannot order it against the LDS-DMA in flight: that wait sat between the
+        // A and the B reads of EVERY instance until round 4 and serialised the loads of item i + S - 1 with the products of item i;
+        // tools/isa_waits.py lists the waits inside the loop)
+        // (wide tiles: one 32-channel step's fragments at a time -- 56 registers of fragments beside 48 of accumulators)
+        constexpr int GS = (NTW >= 4) ? 1 : STEPS;   // steps whose fragments are in registers together
+#pragma unroll
+        for (int g = 0; g < STEPS / GS; ++g) {
+          f32x4 av[GS][2];
+          bf16x8 bh[GS][NTW], bm[GS][NTW], bl[GS][NTW];
+#pragma unroll
+          for (int j = 0; j < GS; ++j) {
+            const int u0 = 8 * (g * GS + j) + 2 * kg;   // channels 32 s + 8 kg .. + 7 of the lane's row
+            av[j][0] = *(const f32x4*)(A + ((u0 ^ aswz) * 16));
+            av[j][1] = *(const f32x4*)(A + (((u0 + 1) ^ aswz) * 16));
+          }
+#pragma unroll
+          for (int j = 0; j < GS; ++j)
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) {
+              const int col = (wc * NTW + nt) * 16 + arow;
+              const char* bp = B + col * (KC * 2) + (((4 * (g * GS + j) + kg) ^ ((col >> 1) & (UPB - 1))) * 16);
+              bh[j][nt] = *(const bf16x8*)bp;
+              bm[j][nt] = *(const bf16x8*)(bp + P_BYTES);
+              bl[j][nt] = *(const bf16x8*)(bp + 2 * P_BYTES);
+            }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int j = 0; j < GS; ++j) {
+            const f32x4 v0 = av[j][0], v1 = av[j][1];
+            uint4 ah, am, al;
+            split2(v0[0], v0[1], ah.x, am.x, al.x);
+            split2(v0[2], v0[3], ah.y, am.y, al.y);
+            split2(v1[0], v1[1], ah.z, am.z, al.z);
+            split2(v1[2], v1[3], ah.w, am.w, al.w);
+            const bf16x8 Ah = __builtin_bit_cast(bf16x8, ah), Am = __builtin_bit_cast(bf16x8, am), Al = __builtin_bit_cast(bf16x8, al);
+#define S_MFMA(ACC, X, Y)                 \
+    _Pragma("unroll") for (int nt = 0; nt < NTW; ++nt) ACC[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(X, Y[j][nt], ACC[nt], 0, 0, 0)
+            S_MFMA(accs, Al, bh);
+            S_MFMA(accs, Ah, bl);
+            S_MFMA(accs, Am, bm);
+            S_MFMA(accm, Am, bh);
+            S_MFMA(accm, Ah, bm);
+            S_MFMA(acc, Ah, bh);
+#undef S_MFMA
+          }
+        }
+      }
+      st = (st == S_STAGES - 1) ? 0 : st + 1;
+    }
+
+    // epilogue as conv_apply_g's: C/D layout of 16x16: col = lane & 15, row = (lane >> 4) * 4 + reg
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) {
+      const int col = n0 + (wc * NTW + nt) * 16 + (lane & 15);
+      const float bv0 = (bias && !zred) ? bias[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = s_row[wr * 16 + kg * 4 + r];
+        valid[r] = row >= 0;
+        const float sum = acc[nt][r] + (accm[nt][r] + accs[nt][r]);
+        const float v = (bias && !zred) ? (sum + bv0) : sum;
+        if (row >= 0) out[(size_t)row * Cres + col] = v;
+        vals[nt][r] = v;
+      }
     }
   }
   bool contribute = true;
@@ -317,7 +361,7 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_apply_s(const float* __rest
         const float bv0 = bias ? bias[col] : 0.f;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int row = s_row[wr * 16 + kg * 4 + r];
+          const int row = computes ? s_row[wr * 16 + kg * 4 + r] : -1;
           float v = 0.f;
           if (row >= 0) {
             const float* p = slab0 + (size_t)row * Cres + col;
@@ -332,7 +376,7 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_apply_s(const float* __rest
     }
   }
   if (bn.slots) {   // batch statistics for the BatchNorm behind this layer (bn_fuse.h)
-    if (contribute) bn_fuse_wave<NTW>(bn, vals, valid, n0 + wc * NTW * 16, (int)((bx * WR + wr) & (BN_FUSE_SLOTS - 1)));
+    if (contribute && computes) bn_fuse_wave<NTW>(bn, vals, valid, n0 + wc * NTW * 16, (int)((bx * WR + wr) & (BN_FUSE_SLOTS - 1)));
     bn_fuse_finish(bn, (int*)smem);
   }
 }
@@ -341,7 +385,7 @@ size_t lds_bytes_s(int tm, int tn, int kc, int K, int stages) {
   return (size_t)stages * ((size_t)tm * kc * 4 + (size_t)3 * tn * kc * 2) + (size_t)(tm * K + K + 1 + tm) * sizeof(int32_t);
 }
 
-template <int WR, int WC, int NTW, int KC, int S_STAGES>
+template <int WR, int WC, int NTW, int KC, int S_STAGES, int LW = 0>
 int launch_s(const float* feat, const unsigned short* Ws, const float* bias, const int32_t* nbr, const int32_t* order, int n_rows, int K, int Cred,
              int Cres, float* out, int flags, hipStream_t stream, const BnFuse& bn, int zsplit, float* out_final, int32_t* ztickets) {
   constexpr int TM = 16 * WR, TN = 16 * NTW * WC;
@@ -349,11 +393,11 @@ int launch_s(const float* feat, const unsigned short* Ws, const float* bias, con
   BTC_CHECK_ARG(lds <= 160 * 1024, "conv_apply_s: tile does not fit the LDS");
   static BtcPerDeviceOnce once;   // launches come from the training thread, the autograd thread and the prefetch thread
   btc_once_per_device(once, [] {
-    (void)hipFuncSetAttribute((const void*)conv_apply_s<WR, WC, NTW, KC, S_STAGES>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_apply_s<WR, WC, NTW, KC, S_STAGES, LW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   });
   dim3 grid(btc_cdiv(n_rows, TM), Cres / TN, zsplit);
   BTC_CHECK_ARG(!ztickets || (long long)grid.x * grid.y <= BTC_SCRATCH_TICKETS, "conv_apply_s: more tiles than z-split tickets");
-  conv_apply_s<WR, WC, NTW, KC, S_STAGES><<<grid, 64 * WR * WC, lds, stream>>>(feat, Ws, bias, nbr, order, n_rows, K, Cred, Cres, out, flags, bn, out_final,
+  conv_apply_s<WR, WC, NTW, KC, S_STAGES, LW><<<grid, 64 * (WR * WC + LW), lds, stream>>>(feat, Ws, bias, nbr, order, n_rows, K, Cred, Cres, out, flags, bn, out_final,
                                                                                ztickets);
   BTC_LAUNCH_CHECK();
   return BTC_OK;
@@ -571,37 +615,56 @@ int btc_apply_split(const float* src, const void* Ws_, const float* bias_, const
   if (Z > 1 && !in_kernel) bias = nullptr;
 #define S_ARGS src, Ws, bias, nbr, order, n_rows, K, Cred, Cres, dst, flags, stream, bn_kernel, Z, dst_, (in_kernel ? tickets : nullptr)
   int rc = BTC_EINVAL;
+  // BTC_TUNE_SPLIT_LOADERS: 0 = built-in policy, 1 = the product waves issue their own pieces, 2 / 4 = that many loader waves per workgroup
+  const int t_lw = btc_tune_get(BTC_TUNE_SPLIT_LOADERS);
+  // built-in (tools/conv_bench.py `split:17=1 split:17=2 split:17=4`, MI355X): four loaders with 64-channel items (64 -> 64 at 14 K rows
+  // 34.7 -> 32.1 us, 256 -> 128 at 6.4 K rows 91.5 -> 88.1, 64 -> 32 at 29 K rows 37.6 -> 33.4), two for the 64 x 32 tiles of the 210 K-row
+  // level (134.5 -> 125.9); the three-stage 32-channel items are faster when the product waves issue their own pieces (32 -> 32 at
+  // 12-29 K rows 24.5 against 27.8): two loaders spend longer on an item's pieces than its products take
+  int lw = t_lw == 2 ? 2 : (t_lw == 4 ? 4 : (t_lw == 1 ? 0 : (kc == 64 ? 4 : (shape == 412 ? 2 : 0))));
+  {
+    const int tm = (shape / 100) * 16, tn = 16 * ((shape / 10) % 10) * (shape % 10);
+    if (lw == 4 && ((tm * kc / 256) % 4 != 0 || (3 * tn * kc / 512) % 4 != 0)) lw = 2;   // the loaders share the pieces evenly
+  }
+#define S_CASE(code, WR_, WC_, NTW_, KC_, ST_)                                                                          \
+  case code:                                                                                                           \
+    if constexpr ((16 * WR_ * KC_ / 256) % 4 == 0 && (3 * 16 * NTW_ * WC_ * KC_ / 512) % 4 == 0) {                       \
+      if (lw == 4) { rc = launch_s<WR_, WC_, NTW_, KC_, ST_, 4>(S_ARGS); break; }                                       \
+    }                                                                                                                  \
+    rc = lw ? launch_s<WR_, WC_, NTW_, KC_, ST_, 2>(S_ARGS) : launch_s<WR_, WC_, NTW_, KC_, ST_, 0>(S_ARGS);            \
+    break
   switch (shape * 10 + stages + (kc == 64 ? 5 : 0)) {   // ...7 / ...8: KC = 64 with 2 / 3 stages
-    case 4243: rc = launch_s<4, 2, 4, 32, 3>(S_ARGS); break;
-    case 4244: rc = launch_s<4, 2, 4, 32, 4>(S_ARGS); break;
-    case 4247: rc = launch_s<4, 2, 4, 64, 2>(S_ARGS); break;
-    case 2243: rc = launch_s<2, 2, 4, 32, 3>(S_ARGS); break;
-    case 2247: rc = launch_s<2, 2, 4, 64, 2>(S_ARGS); break;
-    case 2227: rc = launch_s<2, 2, 2, 64, 2>(S_ARGS); break;
-    case 4228: rc = launch_s<4, 2, 2, 64, 3>(S_ARGS); break;
-    case 2244: rc = launch_s<2, 2, 4, 32, 4>(S_ARGS); break;
-    case 4223: rc = launch_s<4, 2, 2, 32, 3>(S_ARGS); break;
-    case 4224: rc = launch_s<4, 2, 2, 32, 4>(S_ARGS); break;
-    case 4227: rc = launch_s<4, 2, 2, 64, 2>(S_ARGS); break;
-    case 4127: rc = launch_s<4, 1, 2, 64, 2>(S_ARGS); break;
-    case 8127: rc = launch_s<8, 1, 2, 64, 2>(S_ARGS); break;
-    case 4123: rc = launch_s<4, 1, 2, 32, 3>(S_ARGS); break;
-    case 4124: rc = launch_s<4, 1, 2, 32, 4>(S_ARGS); break;
-    case 8123: rc = launch_s<8, 1, 2, 32, 3>(S_ARGS); break;
-    case 8124: rc = launch_s<8, 1, 2, 32, 4>(S_ARGS); break;
-    case 4147: rc = launch_s<4, 1, 4, 64, 2>(S_ARGS); break;
-    case 4143: rc = launch_s<4, 1, 4, 32, 3>(S_ARGS); break;
-    case 8147: rc = launch_s<8, 1, 4, 64, 2>(S_ARGS); break;
-    case 8143: rc = launch_s<8, 1, 4, 32, 3>(S_ARGS); break;
-    case 4187: rc = launch_s<4, 1, 8, 64, 2>(S_ARGS); break;
-    case 4183: rc = launch_s<4, 1, 8, 32, 3>(S_ARGS); break;
-    case 8183: rc = launch_s<8, 1, 8, 32, 3>(S_ARGS); break;
-    case 2223: rc = launch_s<2, 2, 2, 32, 3>(S_ARGS); break;
-    case 2224: rc = launch_s<2, 2, 2, 32, 4>(S_ARGS); break;
+    S_CASE(4243, 4, 2, 4, 32, 3);
+    S_CASE(4244, 4, 2, 4, 32, 4);
+    S_CASE(4247, 4, 2, 4, 64, 2);
+    S_CASE(2243, 2, 2, 4, 32, 3);
+    S_CASE(2247, 2, 2, 4, 64, 2);
+    S_CASE(2227, 2, 2, 2, 64, 2);
+    S_CASE(4228, 4, 2, 2, 64, 3);
+    S_CASE(2244, 2, 2, 4, 32, 4);
+    S_CASE(4223, 4, 2, 2, 32, 3);
+    S_CASE(4224, 4, 2, 2, 32, 4);
+    S_CASE(4227, 4, 2, 2, 64, 2);
+    S_CASE(4127, 4, 1, 2, 64, 2);
+    S_CASE(8127, 8, 1, 2, 64, 2);
+    S_CASE(4123, 4, 1, 2, 32, 3);
+    S_CASE(4124, 4, 1, 2, 32, 4);
+    S_CASE(8123, 8, 1, 2, 32, 3);
+    S_CASE(8124, 8, 1, 2, 32, 4);
+    S_CASE(4147, 4, 1, 4, 64, 2);
+    S_CASE(4143, 4, 1, 4, 32, 3);
+    S_CASE(8147, 8, 1, 4, 64, 2);
+    S_CASE(8143, 8, 1, 4, 32, 3);
+    S_CASE(4187, 4, 1, 8, 64, 2);
+    S_CASE(4183, 4, 1, 8, 32, 3);
+    S_CASE(8183, 8, 1, 8, 32, 3);
+    S_CASE(2223, 2, 2, 2, 32, 3);
+    S_CASE(2224, 2, 2, 2, 32, 4);
     default:
       btc_set_error("conv_apply_s: no instance for shape %d, %d stages, kc %d", shape, stages, kc);
       return BTC_EINVAL;
   }
+#undef S_CASE
 #undef S_ARGS
   if (rc != BTC_OK || Z == 1 || in_kernel) return rc;
   split_reduce<<<dim3(btc_cdiv(n_rows, 64), Cres / 64), 256, 0, stream>>>(dst, Z, bias_, n_rows, Cres, dst_, bn);
