@@ -41,6 +41,7 @@ from .processor import DataProcessor
 # occupancy backward 0.67 -> 1.55, occupancy forward 1.57 -> 2.28).  The three threads' CPU time adds up to 5.9 ms per step and they share
 # one GIL: the schedule is bound by the interpreter, not by any wait that can be moved.
 DET_WALK_AHEAD = int(os.environ.get("BTC_DET_WALK_AHEAD", "0"))
+HANDOVER_KEEPALIVE = os.environ.get("BTC_HANDOVER_KEEPALIVE", "1") != "0"   # forward_det: hold the producer's tensors (BtcHotPath._borrow) instead of record_stream
 
 
 class HotPathDataset(object):
@@ -204,7 +205,7 @@ class BtcHotPath(nn.Module):
             return
         limit = st["consumed"] if upto is None else min(st["consumed"], upto)
         ev = None
-        for g in st["gens"]:
+        for g in st["gens"] + self.__dict__.get("_borrowed", []):   # (_borrowed: forward_det's share, see _borrow)
             if g["ended"] is None and g["id"] <= limit:
                 if ev is None:
                     ev = torch.cuda.Event()
@@ -251,6 +252,21 @@ class BtcHotPath(nn.Module):
         occ_loss, tb_dict = head.get_loss(batch_dict)
         return batch_dict, occ_loss, tb_dict, det_inputs_ready
 
+    def _borrow(self, batch_dict):
+        """what hand_over() achieves with ~40 record_stream calls (0.25 ms of the training thread per step, tools/host_sampler.py), by
+        holding on instead: the tensors the occupancy branch produced on ITS stream stay referenced here until the consuming stream
+        has passed the end of the step that read them (mark_step_end() attaches that event; the references go once the event has
+        COMPLETED -- a host-side query, no stream is made to wait).  Their blocks cannot return to the producer's pool earlier, which
+        is all record_stream would have ensured.  Only for batches of a loop that calls mark_step_end() (a prepared batch: __gen_id__)."""
+        pend = self.__dict__.setdefault("_borrowed", [])
+        pend[:] = [b for b in pend if b["ended"] is None or not b["ended"].query()]
+        while sum(b["ended"] is None for b in pend) > 3:   # nobody calls mark_step_end(): register the oldest with the consumer after all
+            old = next(b for b in pend if b["ended"] is None)
+            pend.remove(old)
+            for t in old["refs"]:
+                t.record_stream(torch.cuda.current_stream())
+        pend.append({"id": batch_dict["__gen_id__"], "refs": list(batch_dict.pop("__produced_here__")), "ended": None})
+
     @staticmethod
     def hand_over(batch_dict, stream):
         """register every device tensor of batch_dict (and of a rulebook walk started ahead) with `stream`, which will consume them:
@@ -281,7 +297,11 @@ class BtcHotPath(nn.Module):
             cur = torch.cuda.current_stream()
             cur.wait_event(inputs_ready)
             if batch_dict.pop("__recorded_for__", None) != cur.cuda_stream:   # (hand_over() did it from the producer's thread)
-                self.hand_over(batch_dict, cur)
+                if HANDOVER_KEEPALIVE and batch_dict.get("__gen_id__") is not None and batch_dict.get("__det_walk__") is None \
+                        and batch_dict.get("__produced_here__") is not None:
+                    self._borrow(batch_dict)
+                else:
+                    self.hand_over(batch_dict, cur)
         rows = {}   # active rows per level of this batch -- tensor shapes, host integers, no read-back (bench.py reports them per timed step)
         enc = batch_dict.get("encoded_spconv_tensor")
         if enc is not None and hasattr(enc, "features"):

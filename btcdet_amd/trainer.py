@@ -414,6 +414,11 @@ class HotPathTrainer(object):
         ops.set_defer_wgrad_join(os.environ.get("BTC_DEFER_WGRAD", "1") != "0")
         cuda = self.device.type == "cuda"
         self.prefetch_stream = torch.cuda.Stream(device=self.device, priority=-1) if (cuda and schedule != "in_order") else None
+        if os.environ.get("BTC_AUTOGRAD_MT") == "0":
+            # (A/B knob) torch's autograd engine runs the backward nodes of EVERY cuda tensor of a device on ONE thread of its own: the
+            # detection branch's backward (training thread) and the occupancy branch's (worker thread) queue up behind each other there.
+            # Without the engine's threads each backward pass runs on the thread that called it.
+            torch.autograd.set_multithreading_enabled(False)
         if os.environ.get("BTC_SWITCH_INTERVAL"):     # (A/B knob: CPython's GIL hand-over interval, default 5 ms)
             import sys
             sys.setswitchinterval(float(os.environ["BTC_SWITCH_INTERVAL"]))
