@@ -657,7 +657,7 @@ int btc_apply_split(const float* src, const void* Ws_, const float* bias_, const
     S_CASE(8143, 8, 1, 4, 32, 3);
     S_CASE(4187, 4, 1, 8, 64, 2);
     S_CASE(4183, 4, 1, 8, 32, 3);
-    S_CASE(8183, 8, 1, 8, 32, 3);
+    case 8183: rc = launch_s<8, 1, 8, 32, 3, 0>(S_ARGS); break;   // (with loader waves the 168-register budget of 10-12 waves spills)
     S_CASE(2223, 2, 2, 2, 32, 3);
     S_CASE(2224, 2, 2, 2, 32, 4);
     default:
