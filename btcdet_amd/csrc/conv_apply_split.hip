@@ -582,6 +582,12 @@ int btc_apply_split(const float* src, const void* Ws_, const float* bias_, const
   // 32 result columns: 128 x 32 / 64 x 32 tiles, the waves split the rows.  32 -> 32 at 26-29 K rows 46 / 40 us (exact chain) -> 29 / 28
   // (128-row tiles; 64-row tiles 32 / 31), at 210 K rows 165 / 196 (forward / dgrad) -> 147 / 146 with 64-row tiles (128-row tiles 183)
   if (Cres % 64 != 0) shape = n_rows >= 100000 ? 412 : 812;
+  // 5-22 K rows with up to 64 result columns, and the 2- / 3-offset strided layers: 64 x 32 tiles (two workgroups of four product waves +
+  // loaders per CU, every tile resident at once; the gathered rows are fetched once per column half).  With the loader waves, us per
+  // launch against the 64 x 64 / 128 x 32 tiles: 64 -> 64 at 14 K rows 32.1 -> 28.6 (dgrad of the strided 64 -> 64 at 6.4 K 29.7 -> 25.3),
+  // 32 -> 32 at 12 K rows 24.4 -> 20.8, the 3-offset 64 -> 128 at 5.3 K rows 10.0 -> 7.9; at 3 K rows (z-split wins, 19.2 against 22.6) and
+  // from 25 K rows up (25.0 against 26.3) the larger tiles stay
+  if ((Cres % 128 != 0 && n_rows >= 5000 && n_rows < 22000) || (K <= 4 && n_rows < 22000)) shape = 412;
   if ((t_nt == 812 || t_nt == 412) && Cres % 32 == 0) shape = t_nt;
   if ((t_nt == 224 || t_nt == 424) && Cres % 128 == 0) shape = t_nt;   // tuning runs
   if ((t_nt == 222 || t_nt == 422 || t_nt == 414 || t_nt == 814) && Cres % 64 == 0) shape = t_nt;

@@ -152,12 +152,16 @@ def test_z_split_small_levels(cin, cout, n_pts):
     bias = rng.standard_normal(cout).astype(np.float32)
     f, w, b = (torch.from_numpy(a).to(dev()) for a in (feat, W, bias))
     outs = {}
+    # (64 result columns from 5 K rows up: the built-in policy takes the 64 x 32 tiles, which never split -- the 64 x 64 tiles are asked for)
+    assert L.btc_tune_set(1, 422 if cout == 64 else 0) == 0
     for z in (0, 1):                       # 0: the policy (z-split here), 1: never
         assert L.btc_tune_set(15, z) == 0
         try:
             outs[z] = [ops.indice_conv(f, w, b, rb).cpu().numpy() for _ in range(2)]
         finally:
             L.btc_tune_set(15, 0)
+            if z == 1:
+                L.btc_tune_set(1, 0)
         assert np.array_equal(outs[z][0], outs[z][1])
     assert not np.array_equal(outs[0][0], outs[1][0])          # (the split really ran: another summation order)
     ref64 = _f64_conv(feat, W, o_out, False) + bias.astype(np.float64)
@@ -309,3 +313,33 @@ def test_in_kernel_slab_reduction_gives_the_same_bits():
         finally:
             L.btc_tune_set(16, 0)
     assert all(torch.equal(outs[0], o) for o in outs[1:])
+
+
+@pytest.mark.parametrize("cin,cout,n_pts", [(64, 64, 3500), (64, 64, 7000), (64, 64, 16000), (256, 128, 6000), (64, 32, 26000), (32, 32, 26000)])
+def test_loader_waves_give_the_same_bits(cin, cout, n_pts):
+    """BTC_TUNE_SPLIT_LOADERS: 1 = the product waves issue their own LDS-DMA pieces, 2 / 4 = that many loader waves per workgroup issue them
+    all (conv_apply_s, LW template parameter; 0 = the built-in policy).  Who issues a piece changes neither what lands in the LDS nor the
+    order of a single product: forward and data gradient are bit-identical in every mode, with and without z-split."""
+    from btcdet_amd import _lib
+    from btcdet_amd.spconv import ops
+    L = _lib.lib()
+    rng = np.random.default_rng(cin * 7 + cout + n_pts)
+    shape, B = (16, 64, 64), 2
+    idx = rand_indices(rng, n_pts, B, shape)
+    (o_idx, o_out, o_in, o_sh), rb = _rb_both(idx, B, shape, (3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 1, 1), "subm")
+    n = o_out.shape[0]
+    assert L.btc_conv_split_wanted(27, cin, cout, n) == 1
+    f = torch.from_numpy(rng.standard_normal((n, cin)).astype(np.float32)).to(dev()).requires_grad_(True)
+    w = torch.from_numpy((rng.standard_normal((3, 3, 3, cin, cout)) / np.sqrt(cin)).astype(np.float32)).to(dev())
+    g = torch.from_numpy(rng.standard_normal((n, cout)).astype(np.float32)).to(dev())
+    res = []
+    for mode in (1, 2, 4, 0, 1):
+        assert L.btc_tune_set(17, mode) == 0
+        try:
+            y = ops.indice_conv(f, w, None, rb)
+            (dx,) = torch.autograd.grad(y, f, g)
+            res.append((y.detach().clone(), dx.clone()))
+        finally:
+            L.btc_tune_set(17, 0)
+    for y, dx in res[1:]:
+        assert torch.equal(res[0][0], y) and torch.equal(res[0][1], dx)
