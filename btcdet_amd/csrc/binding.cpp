@@ -153,6 +153,7 @@ void ensure_scratch(const Tensor& like, int64_t stream) {
 // fp32 launch of n_rows rows on the split-operand kernel (csrc/conv_apply_split.hip)?  The library's policy; BTC_TUNE_SPLIT = 1: never
 bool split_operands(const Tensor& src, int64_t K, int64_t cred, int64_t cres, int64_t n_rows, int64_t stream) {
   if (!(src.scalar_type() == at::kFloat && btc_conv_split_wanted((int)K, (int)cred, (int)cres, (int)n_rows))) return false;
+  if (src.numel() * 4 >= (int64_t)0xFFFFFF00LL) return false;   // the kernel's gathers use 32-bit byte offsets (it traps past them): exact kernels
   ensure_scratch(src, stream);
   return true;
 }

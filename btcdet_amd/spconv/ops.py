@@ -568,6 +568,8 @@ def _split_operands(src, K, cred, cres, n_rows):
     product block)?  The library's policy (btc_conv_split_wanted; never under BTC_TUNE_SPLIT = 1) -- same as binding.cpp"""
     if not (src.dtype == torch.float32 and lib().btc_conv_split_wanted(int(K), int(cred), int(cres), int(n_rows)) == 1):
         return False
+    if src.numel() * 4 >= 0xFFFFFF00:    # the kernel's gathers use 32-bit byte offsets (it traps past them): the exact kernels take any size
+        return False
     key = (src.device.index, stream_ptr())
     if key not in _SCRATCH:    # the stream's scratch buffer for z-split launches (btc_set_scratch), as binding.cpp ensure_scratch
         buf = _SCRATCH[key] = torch.empty(48 << 20, dtype=torch.uint8, device=src.device)

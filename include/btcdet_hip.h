@@ -66,7 +66,7 @@ int btc_version(void);
 #define BTC_TUNE_BN_FUSE 12 /* btc_conv_bn_relu_fwd: 1 = statistics by the separate bn_stats launch instead of the conv epilogue */
 #define BTC_TUNE_SPLIT_Z 15 /* split-operand kernel: workgroups sharing a tile's items (0 = built-in policy, 1 = never, 2..4 = always that many) */
 #define BTC_TUNE_SPLIT_REDUCE 16 /* split-operand kernel, z-split launches: 1 = the partial slabs are added by the tile's last workgroup inside the kernel instead of by the separate split_reduce launch (measured slower: its serial tail outweighs the launch) */
-#define BTC_TUNE_SPLIT_LOADERS 17 /* split-operand kernel: 0 = built-in policy, 1 = the product waves issue their own LDS-DMA pieces, 2 = two loader waves per workgroup issue them all */
+#define BTC_TUNE_SPLIT_LOADERS 17 /* split-operand kernel: 0 = built-in policy, 1 = the product waves issue their own LDS-DMA pieces, 2 / 4 = that many loader waves per workgroup issue them all (same bits in every mode) */
 #define BTC_TUNE_SPLIT 14 /* host bindings: 1 = never take the split-operand kernel (conv_apply_g's exact fmaf chain everywhere) */
 #define BTC_TUNE_APPLY_STAGES 13 /* conv_apply_g: depth of the LDS ring (3..8; 0 = built-in policy) */
 #define BTC_TUNE_APPLY_DEBUG 3 /* timing experiments only (WRONG results): 1 = no MFMA phase, 2 = no loads in the main loop */
