@@ -28,12 +28,6 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 namespace {
 
-
-
-__device__ __forceinline__ void glds16s(const void* g, void* l) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
-}
-
 // gathered activation rows travel through a raw buffer descriptor over the feature tensor: a lane whose offset lies past num_records
 // reads nothing and WRITES ZEROS to its 16 bytes of LDS (tools/lds_dma_oob.hip checks exactly that on the device) -- the lanes of an
 // absent neighbour (submanifold levels: 17 of 27 on average) cost no L2 -> LDS traffic at all, where they used to fetch a zero row.
