@@ -120,6 +120,8 @@ _SIGS = {
     "btc_row_orders_keyed": (ci, [vp, vp, c_i32p, c_i32p, ci, vp, vp]),
     "btc_conv_apply_ordered": (ci, [ci, ci, vp, vp, vp, vp, vp, ci, ci, ci, ci, vp, vp]),
     "btc_conv_wgrad_ordered": (ci, [ci, vp, vp, vp, ci, vp, ci, vp, vp, ci, ci, ci, vp, vp, sz, vp]),
+    "btc_conv_wgrad_slabs": (ci, [ci, vp, vp, vp, ci, vp, ci, vp, vp, ci, ci, ci, vp, vp, sz, vp, vp]),
+    "btc_wgrad_reduce_multi": (ci, [vp, vp, vp, vp, ci, vp]),
     "btc_adam_group_ws_bytes": (sz, [ci]),
     "btc_adam_max_segments": (ci, []),
     "btc_grads_pack": (ci, [vp, ci, vp, vp, vp, vp, c_i32p, vp, vp]),

@@ -280,10 +280,18 @@ std::tuple<Tensor, Tensor> bn_bwd(const Tensor& x, const Tensor& y, const Tensor
 }
 
 // fork / join of a side stream around wgrad (one pair of events and one pooled stream per device, reused in stream order)
+// a weight gradient whose partial slabs wait for the batched reduction at the side stream's join (btc_wgrad_reduce_multi)
+struct SlabJob {
+  Tensor ws, dw;   // held until the reduction has been ENQUEUED: a block released earlier could be handed out again while it is still owed a read
+  int S;
+};
+
 struct SideStream {
   hipStream_t side = nullptr;
   hipEvent_t fork = nullptr, join = nullptr;
   c10::hip::HIPStream* c10side = nullptr;
+  std::mutex slab_mu;
+  std::vector<SlabJob> slabs;             // deferred weight gradients in flight on `side`, not yet reduced
   std::atomic<bool> pending{false};     // deferred mode: wgrads are in flight on the side stream, the join is still owed
   std::atomic<int> queued_task{-1};     // id of the backward pass (autograd graph task) whose end-of-pass callback will pay it;
                                         // a pass that aborted never runs its callback -- the next pass has another id and queues anew
@@ -296,6 +304,8 @@ struct SideStream {
 // is deferred only if its weight is a leaf parameter (allow_defer): a dW that another autograd node consumes during
 // backward -- the occupancy head's merged weight goes through CatBackward -- must be complete when its node returns.
 std::atomic<bool> g_defer_join{false};
+// ... and their slab reductions are batched into the join (BTC_WGRAD_BATCH_REDUCE=0: one reduction per layer, as before round 5)
+const bool g_batch_reduce = !(getenv("BTC_WGRAD_BATCH_REDUCE") && atoi(getenv("BTC_WGRAD_BATCH_REDUCE")) == 0);
 
 // flags of events that only order streams of one device among themselves (never waited for by the host to read host memory)
 unsigned sync_event_flags() {
@@ -326,8 +336,30 @@ SideStream& side_of(int device) {
   return s;
 }
 
+// every weight gradient of the backward pass so far: ONE reduction launch (per 64 layers) on the side stream instead of one per layer
+void reduce_slabs(SideStream& s) {
+  std::vector<SlabJob> jobs;
+  {
+    std::lock_guard<std::mutex> lock(s.slab_mu);
+    jobs.swap(s.slabs);
+  }
+  if (jobs.empty()) return;
+  std::vector<const float*> parts(jobs.size());
+  std::vector<float*> dws(jobs.size());
+  std::vector<int> S(jobs.size());
+  std::vector<long long> counts(jobs.size());
+  for (size_t i = 0; i < jobs.size(); ++i) {
+    parts[i] = (const float*)jobs[i].ws.data_ptr();
+    dws[i] = (float*)jobs[i].dw.data_ptr();
+    S[i] = jobs[i].S;
+    counts[i] = (long long)jobs[i].dw.numel();
+  }
+  chk(btc_wgrad_reduce_multi(parts.data(), dws.data(), S.data(), counts.data(), (int)jobs.size(), (void*)s.side), "btc_wgrad_reduce_multi");
+}
+
 void join_side(SideStream& s, hipStream_t main) {
   if (!s.pending.load()) return;
+  reduce_slabs(s);
   if (hipEventRecord(s.join, s.side) != hipSuccess || hipStreamWaitEvent(main, s.join, 0) != hipSuccess)
     throw std::runtime_error("side-stream join failed");
   s.pending = false;
@@ -406,7 +438,18 @@ std::tuple<OptTensor, OptTensor> conv_bwd(const Tensor& features, const Tensor& 
     Tensor g = at::empty(w.sizes(), w.options());
     const size_t ws_bytes = btc_conv_wgrad_ws_bytes((int)n_res, (int)K, (int)cin, (int)cout, (int)n_src);
     ws = at::empty({(int64_t)(ws_bytes > 256 ? ws_bytes : 256)}, features.options().dtype(at::kByte));
-    if (bf)
+    if (defer && g_batch_reduce) {
+      // deferred: nobody reads dW before the side stream's join, so the partial slabs stay in `ws` and the join adds up every layer's in
+      // one launch (28 reduction launches per step -> 2)
+      int n_slabs = 0;
+      chk(btc_conv_wgrad_slabs((int)bf, features.data_ptr(), grad_out.data_ptr(), (const int32_t*)map_fwd.data_ptr(), (int)n_res, wg_map_bwd, (int)n_src,
+                               nullptr, nullptr, (int)K, (int)cin, (int)cout, (float*)g.data_ptr(), ws.data_ptr(), ws_bytes, &n_slabs, wstream),
+          "btc_conv_wgrad_slabs");
+      if (n_slabs > 0) {
+        std::lock_guard<std::mutex> lock(ss->slab_mu);
+        ss->slabs.push_back(SlabJob{ws, g, n_slabs});
+      }
+    } else if (bf)
       chk(btc_conv_wgrad_bf16(features.data_ptr(), grad_out.data_ptr(), (const int32_t*)map_fwd.data_ptr(), (int)n_res,
                               wg_map_bwd, (int)n_src, (int)K, (int)cin, (int)cout, (float*)g.data_ptr(), ws.data_ptr(),
                               ws_bytes, wstream), "btc_conv_wgrad_bf16");

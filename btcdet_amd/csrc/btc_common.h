@@ -59,6 +59,12 @@ int btc_conv_fwd_stats(int operands, const void* src, const float* W, const floa
 // conv_apply_bf16.hip: bf16 operands on the bf16 matrix pipe; Wq[k][Cres][Cred] bf16
 int btc_apply_bf16w(const void* src, const void* Wq, const float* bias, const int32_t* nbr, const int32_t* order, int n_rows, int K, int Cred,
                     int Cres, void* dst, hipStream_t stream, int mirror = 0);
+// conv_wgrad_x.hip: weight gradient on the bf16 matrix pipe (mode 0: bf16 activations, 1: fp32 activations as three exact bf16 pieces);
+// cg / cc = channels of the gathered / contiguous operand of the row walk
+bool btc_wgrad_x_supported(int mode, int K, int cg, int cc);
+int btc_wgrad_x_plan(int mode, int rows, int K, int cg, int cc, int* S, int* ph);   // -> offset groups; *S = slabs
+int btc_launch_wgrad_x(int mode, const void* g, const void* c, const int32_t* map, const int32_t* ord, int rows, int K, int cg, int cc, float* part,
+                       int swap, hipStream_t stream);
 constexpr size_t BTC_SCRATCH_HEAD = 64 * 1024;              // head of a registered scratch buffer: zeroed at registration, zero between launches
 constexpr long long BTC_SCRATCH_TICKETS = BTC_SCRATCH_HEAD / 4;   // (the z-split launches' per-tile tickets live there)
 void* btc_scratch(hipStream_t stream, size_t* bytes);   // the stream's registered scratch buffer (btc_set_scratch) or NULL

@@ -963,6 +963,38 @@ __global__ __launch_bounds__(256) void wgrad_reduce(const float* __restrict__ pa
   dW[e] = s;
 }
 
+// the slab reductions of MANY layers in one launch (btc_wgrad_reduce_multi: every weight gradient of a backward pass whose dW nobody
+// reads before the side stream's join): block b works on job j with block0[j] <= b < block0[j + 1]; same sums, same order as wgrad_reduce
+struct ReduceJobs {
+  const float* part[BTC_WGRAD_MULTI_MAX];
+  float* dW[BTC_WGRAD_MULTI_MAX];
+  long long count[BTC_WGRAD_MULTI_MAX];
+  int S[BTC_WGRAD_MULTI_MAX];
+  int block0[BTC_WGRAD_MULTI_MAX + 1];
+  int n;
+};
+
+__global__ __launch_bounds__(256) void wgrad_reduce_multi(const ReduceJobs jobs) {
+  int j = 0;
+  while (j + 1 < jobs.n && (int)blockIdx.x >= jobs.block0[j + 1]) ++j;   // (uniform: scalar loop over <= 64 entries)
+  const long long e = (long long)((int)blockIdx.x - jobs.block0[j]) * 256 + threadIdx.x;
+  const long long count = jobs.count[j];
+  if (e >= count) return;
+  const float* __restrict__ part = jobs.part[j];
+  const int S = jobs.S[j];
+  float s = 0.f;
+  int q = 0;
+  for (; q + 8 <= S; q += 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = part[(size_t)(q + u) * count + e];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u];
+  }
+  for (; q < S; ++q) s += part[(size_t)q * count + e];
+  jobs.dW[j][e] = s;
+}
+
 __global__ __launch_bounds__(256) void maxpool_fwd_k(const float* __restrict__ feat, const int32_t* __restrict__ nbr,
                                                      int n_out, int K, int C, float* __restrict__ out) {
   long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1291,24 +1323,66 @@ int btc_conv_fwd_stats(int operands, const void* src, const float* W, const floa
 extern "C" size_t btc_conv_wgrad_ws_bytes(int n_out, int K, int Cin, int Cout, int n_in) {
   // one size for both activation types (the bf16 instances of the pipelined kernel want Cin % 8 == 0, so the two plans can differ)
   const WgradPlan p = wgrad_plan(n_out, K, Cin, Cout, n_in, false), q = wgrad_plan(n_out, K, Cin, Cout, n_in, true);
-  return btc_align((size_t)(p.S > q.S ? p.S : q.S) * K * Cin * Cout * sizeof(float));
+  int S = p.S > q.S ? p.S : q.S;
+  if (p.rows_kernel) {   // ... and for the bf16-pipe kernel's split of the same walk (conv_wgrad_x.hip)
+    const int cg = p.swap ? Cout : Cin, cc = p.swap ? Cin : Cout;
+    for (int mode = 0; mode < 2; ++mode)
+      if (btc_wgrad_x_supported(mode, K, cg, cc)) {
+        int sx = 1, ph = 1;
+        btc_wgrad_x_plan(mode, p.rows, K, cg, cc, &sx, &ph);
+        if (sx > S) S = sx;
+      }
+  }
+  return btc_align((size_t)S * K * Cin * Cout * sizeof(float));
 }
 
 template <bool BF>
 static int wgrad_impl(const float* feat, const float* dout, const int32_t* nbr_out, int n_out, const int32_t* nbr_in,
                       int n_in, int K, int Cin, int Cout, float* dW, void* ws, size_t ws_bytes, void* stream_,
-                      const int32_t* order_out = nullptr, const int32_t* order_in = nullptr) {
+                      const int32_t* order_out = nullptr, const int32_t* order_in = nullptr, int* slabs_out = nullptr) {
+  // slabs_out: the caller adds the slabs up itself, later (btc_wgrad_reduce_multi): *slabs_out = S > 0 slabs of K Cin Cout floats
+  // in `ws`, dW untouched -- or 0: dW is complete (no rows: zeros)
   hipStream_t stream = (hipStream_t)stream_;
   BTC_CHECK_ARG(K >= 1 && Cin >= 1 && Cout >= 1 && n_out >= 0, "btc_conv_wgrad: bad sizes");
+  const int n_feat = n_in;   // rows of `feat` when the caller says so (n_in >= 0), with or without the backward map
   if (!nbr_in) n_in = -1;
   BTC_CHECK_ARG(ws_bytes >= btc_conv_wgrad_ws_bytes(n_out, K, Cin, Cout, n_in), "btc_conv_wgrad: workspace too small");
   long long count = (long long)K * Cin * Cout;
+  if (slabs_out) *slabs_out = 0;
   if (n_out <= 0) {
     BTC_HIP(hipMemsetAsync(dW, 0, (size_t)count * sizeof(float), stream));
     return BTC_OK;
   }
   WgradPlan p = wgrad_plan(n_out, K, Cin, Cout, n_in, BF);
   float* part = (float*)ws;
+  // every path below ends with the same reduction of p.S slabs
+#define BTC_WGRAD_FINISH()                                                             \
+  do {                                                                                 \
+    BTC_LAUNCH_CHECK();                                                                \
+    if (slabs_out) {                                                                   \
+      *slabs_out = p.S;                                                                \
+    } else {                                                                           \
+      wgrad_reduce<<<btc_cdiv(count, 256), 256, 0, stream>>>(part, p.S, count, dW);    \
+      BTC_LAUNCH_CHECK();                                                              \
+    }                                                                                  \
+    return BTC_OK;                                                                     \
+  } while (0)
+  if (p.rows_kernel && btc_tune_get(BTC_TUNE_WGRAD_X) != 1 && (BF || btc_tune_get(BTC_TUNE_SPLIT) != 1)) {
+    // the same walk on the bf16 matrix pipe (conv_wgrad_x.hip): bf16 activations as they are, fp32 activations as three exact bf16
+    // pieces.  Its gathers use 32-bit byte offsets: both operands must stay under 4 GB, and the row count of `feat` must be known.
+    const int mode = BF ? 0 : 1;
+    const int cg = p.swap ? Cout : Cin, cc = p.swap ? Cin : Cout;
+    const long long esz = BF ? 2 : 4;
+    const long long feat_bytes = n_feat >= 0 ? (long long)n_feat * Cin * esz : -1, dout_bytes = (long long)n_out * Cout * esz;
+    if (btc_wgrad_x_supported(mode, K, cg, cc) && feat_bytes >= 0 && feat_bytes < 0xFFFFFF00LL && dout_bytes < 0xFFFFFF00LL) {
+      int ph = 1;
+      btc_wgrad_x_plan(mode, p.rows, K, cg, cc, &p.S, &ph);
+      const int rc = btc_launch_wgrad_x(mode, p.swap ? (const void*)dout : (const void*)feat, p.swap ? (const void*)feat : (const void*)dout,
+                                        p.swap ? nbr_in : nbr_out, p.swap ? order_in : order_out, p.rows, K, cg, cc, part, p.swap, stream);
+      if (rc != BTC_OK) return rc;
+      BTC_WGRAD_FINISH();
+    }
+  }
   if (p.rows_kernel) {
     // operands of the walk: gathered rows (via the map) and contiguous rows, see conv_wgrad_rows
     const float* g_ = p.swap ? dout : feat;
@@ -1335,10 +1409,7 @@ static int wgrad_impl(const float* feat, const float* dout, const int32_t* nbr_o
       else BTC_WGP(4, 4, 1, 4);
 #undef BTC_WGP
 #undef BTC_WGP2
-      BTC_LAUNCH_CHECK();
-      wgrad_reduce<<<btc_cdiv(count, 256), 256, 0, stream>>>(part, p.S, count, dW);
-      BTC_LAUNCH_CHECK();
-      return BTC_OK;
+      BTC_WGRAD_FINISH();
     }
 #define BTC_WG_ROWS(MT_, NT_, KB_, PH_) \
   conv_wgrad_rows<MT_, NT_, KB_, PH_, BF><<<grid, 256, lds, stream>>>(g_, c_, map_, ord_, p.rows, K, Cg, Cc, part, p.swap, btc_tune_get(BTC_TUNE_APPLY_DEBUG))
@@ -1359,10 +1430,7 @@ static int wgrad_impl(const float* feat, const float* dout, const int32_t* nbr_o
     else BTC_WG_ROWS_PH(4, 4, 1);
 #undef BTC_WG_ROWS_PH
 #undef BTC_WG_ROWS
-    BTC_LAUNCH_CHECK();
-    wgrad_reduce<<<btc_cdiv(count, 256), 256, 0, stream>>>(part, p.S, count, dW);
-    BTC_LAUNCH_CHECK();
-    return BTC_OK;
+    BTC_WGRAD_FINISH();
   }
   dim3 grid(K, p.S, p.n_mblk * p.n_cblk);
   size_t lds = (size_t)(TM * WG_LDA + TM * ldb_of(p.nt)) * sizeof(float) + (4 * TM + 2) * sizeof(int32_t);
@@ -1373,10 +1441,7 @@ static int wgrad_impl(const float* feat, const float* dout, const int32_t* nbr_o
       case 4: conv_wgrad_partial_p<4, BF><<<grid, 256, lds, stream>>>(feat, dout, nbr_out, n_out, K, Cin, Cout, p.tiles_per_split, p.n_cblk, part); break;
       default: conv_wgrad_partial_p<8, BF><<<grid, 256, lds, stream>>>(feat, dout, nbr_out, n_out, K, Cin, Cout, p.tiles_per_split, p.n_cblk, part); break;
     }
-    BTC_LAUNCH_CHECK();
-    wgrad_reduce<<<btc_cdiv(count, 256), 256, 0, stream>>>(part, p.S, count, dW);
-    BTC_LAUNCH_CHECK();
-    return BTC_OK;
+    BTC_WGRAD_FINISH();
   }
   switch (p.nt) {
     case 1: conv_wgrad_partial<1, BF><<<grid, 256, lds, stream>>>(feat, dout, nbr_out, n_out, K, Cin, Cout, p.tiles_per_split, p.n_cblk, part); break;
@@ -1384,10 +1449,8 @@ static int wgrad_impl(const float* feat, const float* dout, const int32_t* nbr_o
     case 4: conv_wgrad_partial<4, BF><<<grid, 256, lds, stream>>>(feat, dout, nbr_out, n_out, K, Cin, Cout, p.tiles_per_split, p.n_cblk, part); break;
     default: conv_wgrad_partial<8, BF><<<grid, 256, lds, stream>>>(feat, dout, nbr_out, n_out, K, Cin, Cout, p.tiles_per_split, p.n_cblk, part); break;
   }
-  BTC_LAUNCH_CHECK();
-  wgrad_reduce<<<btc_cdiv(count, 256), 256, 0, stream>>>(part, p.S, count, dW);
-  BTC_LAUNCH_CHECK();
-  return BTC_OK;
+  BTC_WGRAD_FINISH();
+#undef BTC_WGRAD_FINISH
 }
 
 extern "C" int btc_conv_wgrad(const float* feat, const float* dout, const int32_t* nbr_out, int n_out, const int32_t* nbr_in,
@@ -1408,6 +1471,41 @@ extern "C" int btc_conv_wgrad_ordered(int bf16_act, const void* feat, const void
                             order_in);
   return wgrad_impl<false>((const float*)feat, (const float*)dout, nbr_out, n_out, nbr_in, n_in, K, Cin, Cout, dW, ws, ws_bytes, stream, order_out,
                            order_in);
+}
+
+extern "C" int btc_conv_wgrad_slabs(int bf16_act, const void* feat, const void* dout, const int32_t* nbr_out, int n_out, const int32_t* nbr_in,
+                                    int n_in, const int32_t* order_out, const int32_t* order_in, int K, int Cin, int Cout, float* dW, void* ws,
+                                    size_t ws_bytes, int* n_slabs, void* stream) {
+  BTC_CHECK_ARG(n_slabs != nullptr, "btc_conv_wgrad_slabs: n_slabs is NULL");
+  if (bf16_act)
+    return wgrad_impl<true>((const float*)feat, (const float*)dout, nbr_out, n_out, nbr_in, n_in, K, Cin, Cout, dW, ws, ws_bytes, stream, order_out,
+                            order_in, n_slabs);
+  return wgrad_impl<false>((const float*)feat, (const float*)dout, nbr_out, n_out, nbr_in, n_in, K, Cin, Cout, dW, ws, ws_bytes, stream, order_out,
+                           order_in, n_slabs);
+}
+
+extern "C" int btc_wgrad_reduce_multi(const float* const* parts, float* const* dWs, const int* n_slabs, const long long* counts, int n_jobs,
+                                      void* stream) {
+  BTC_CHECK_ARG(n_jobs >= 0 && (n_jobs == 0 || (parts && dWs && n_slabs && counts)), "btc_wgrad_reduce_multi: bad arguments");
+  for (int base = 0; base < n_jobs; base += BTC_WGRAD_MULTI_MAX) {
+    ReduceJobs jobs;
+    jobs.n = n_jobs - base < BTC_WGRAD_MULTI_MAX ? n_jobs - base : BTC_WGRAD_MULTI_MAX;
+    long long blocks = 0;
+    for (int j = 0; j < jobs.n; ++j) {
+      BTC_CHECK_ARG(n_slabs[base + j] >= 1 && counts[base + j] >= 1 && parts[base + j] && dWs[base + j], "btc_wgrad_reduce_multi: bad job %d", base + j);
+      jobs.part[j] = parts[base + j];
+      jobs.dW[j] = dWs[base + j];
+      jobs.S[j] = n_slabs[base + j];
+      jobs.count[j] = counts[base + j];
+      jobs.block0[j] = (int)blocks;
+      blocks += (counts[base + j] + 255) / 256;
+    }
+    jobs.block0[jobs.n] = (int)blocks;
+    BTC_CHECK_ARG(blocks < (1LL << 31), "btc_wgrad_reduce_multi: too many elements");
+    wgrad_reduce_multi<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>(jobs);
+    BTC_LAUNCH_CHECK();
+  }
+  return BTC_OK;
 }
 
 extern "C" int btc_maxpool_fwd(const float* feat, const int32_t* nbr_out, int n_out, int K, int C, float* out, void* stream) {

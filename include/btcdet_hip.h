@@ -69,6 +69,7 @@ int btc_version(void);
 #define BTC_TUNE_SPLIT_LOADERS 17 /* split-operand kernel: 0 = built-in policy, 1 = the product waves issue their own LDS-DMA pieces, 2 / 4 = that many loader waves per workgroup issue them all (same bits in every mode) */
 #define BTC_TUNE_SPLIT 14 /* host bindings: 1 = never take the split-operand kernel (conv_apply_g's exact fmaf chain everywhere) */
 #define BTC_TUNE_APPLY_STAGES 13 /* conv_apply_g: depth of the LDS ring (3..8; 0 = built-in policy) */
+#define BTC_TUNE_WGRAD_X 18 /* weight gradient on the bf16 matrix pipe (conv_wgrad_x.hip): 0 = where supported, 1 = never (the fp32-pipe kernels) */
 #define BTC_TUNE_APPLY_DEBUG 3 /* timing experiments only (WRONG results): 1 = no MFMA phase, 2 = no loads in the main loop */
 int btc_tune_set(int key, int value);
 int btc_tune_value(int key);   /* current value of a key (0 = built-in policy) */
@@ -309,6 +310,23 @@ int btc_conv_apply_ordered(int pass, int operands, const void* src, const void* 
 int btc_conv_wgrad_ordered(int bf16_act, const void* feat, const void* dout, const int32_t* nbr_out, int n_out,
                            const int32_t* nbr_in, int n_in, const int32_t* order_out, const int32_t* order_in, int K, int Cin,
                            int Cout, float* dW, void* ws, size_t ws_bytes, void* stream);
+/* The weight gradient in two halves, for a caller that has MANY of them in flight and needs none before a common point (the backward
+ * pass of a network: spconv's indice_conv_backward, one per layer, /root/reference/btcdet/models/backbones_3d/spconv_backbone.py:7-43
+ * through spconv/functional.py -- every dW is first read by the optimizer).  btc_conv_wgrad_slabs = btc_conv_wgrad_ordered without
+ * its final reduction: *n_slabs = S >= 1 partial sums of K Cin Cout floats each, in `ws` (dW untouched), or 0: dW is complete (a layer
+ * without rows: zeros).  btc_wgrad_reduce_multi adds the slabs of up to any number of such jobs in ONE launch per
+ * BTC_WGRAD_MULTI_MAX jobs (host arrays of device pointers / sizes): dWs[j][e] = sum_s parts[j][s * counts[j] + e] in slab order --
+ * the same sums, in the same order, as the one-call entry points.  `ws` must stay untouched until that launch has run.
+ * Row counts: n_in >= 0 is the row count of `feat` also when nbr_in is NULL; with it the walk may run on the bf16 matrix pipe
+ * (csrc/conv_wgrad_x.hip: bf16 activations as stored; fp32 activations as three exact bf16 pieces, six products per pair, unless
+ * BTC_TUNE_SPLIT = 1 or BTC_TUNE_WGRAD_X = 1), whose 32-bit gather offsets need both operands under 4 GB -- larger operands, or an
+ * unknown row count, take the fp32-pipe kernels. */
+#define BTC_WGRAD_MULTI_MAX 64
+int btc_conv_wgrad_slabs(int bf16_act, const void* feat, const void* dout, const int32_t* nbr_out, int n_out, const int32_t* nbr_in,
+                         int n_in, const int32_t* order_out, const int32_t* order_in, int K, int Cin, int Cout, float* dW, void* ws,
+                         size_t ws_bytes, int* n_slabs, void* stream);
+int btc_wgrad_reduce_multi(const float* const* parts, float* const* dWs, const int* n_slabs, const long long* counts, int n_jobs,
+                           void* stream);
 
 
 /* One parameter group's optimizer step of the reference's loop (tools/train_utils/train_utils.py:121-124: clip_grad_norm_,

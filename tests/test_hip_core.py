@@ -283,6 +283,7 @@ def test_wgrad_pipelined_kernel_both_phase_counts(cin, cout, full_ph):
     dout = rng.standard_normal((o_idx.shape[0], cout)).astype(np.float32)
     ref = orc.conv_wgrad(feat, dout, o_out, W.shape)
     got = []
+    lib().btc_tune_set(18, 1)    # BTC_TUNE_WGRAD_X: the fp32-pipe kernel this test is about (the bf16-pipe one: tests/test_hip_wgrad_x.py)
     for ph in (0, full_ph):
         lib().btc_tune_set(5, ph)
         try:
@@ -292,6 +293,8 @@ def test_wgrad_pipelined_kernel_both_phase_counts(cin, cout, full_ph):
             got.append(w.grad.cpu().numpy())
         finally:
             lib().btc_tune_set(5, 0)
+            if ph == full_ph:
+                lib().btc_tune_set(18, 0)
         assert np.abs(got[-1] - ref).max() <= 1e-4 * (np.abs(ref).max() + 1e-6)
     assert np.abs(got[0] - got[1]).max() <= 2e-6 * np.abs(ref).max()
 

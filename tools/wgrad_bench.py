@@ -1,6 +1,5 @@
 """Weight-gradient launches of one bench step, one by one (HIP events, one stream): us, algorithmic GB/s and TFLOP/s, and the
-same launch without its MFMA phase / without its gathers (BTC_TUNE_APPLY_DEBUG 4 / 8: wrong results, timing only) -- which
-side of the kernel bounds it."""
+same launch on the fp32-pipe kernels (BTC_TUNE_WGRAD_X = 1: conv_wgrad_rows_p / conv_wgrad_partial_p)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -38,8 +37,8 @@ def timed(fn, reps=10):
     return e0.elapsed_time(e1) / reps * 1e3
 
 
-print("%7s %7s %3s %4s %4s %8s | %7s %6s %6s | two-barrier kernel: %7s %8s %8s  same bits" % ("n_res", "n_src", "K", "cin", "cout", "pairs", "us", "GB/s", "TF/s", "us", "no-mfma", "no-gath"))
-tot = np.zeros(4)
+print("%7s %7s %3s %4s %4s %8s | %9s %6s %6s | fp32-pipe kernel (BTC_TUNE_WGRAD_X=1): %7s  rel. diff" % ("n_res", "n_src", "K", "cin", "cout", "pairs", "us", "GB/s", "TF/s", "us"))
+tot = np.zeros(2)
 for (f, w, b, mf, mb) in cap:
     cin, cout, K = w.shape[-2], w.shape[-1], mf.shape[1]
     n_res, n_src = mf.shape[0], mb.shape[0]
@@ -48,24 +47,17 @@ for (f, w, b, mf, mb) in cap:
     bf = f.dtype == torch.bfloat16
     wg = L.btc_conv_wgrad_bf16 if bf else L.btc_conv_wgrad
     wsb = L.btc_conv_wgrad_ws_bytes(n_res, K, cin, cout, n_src)
-    check(L.btc_tune_set(11, 1), "t")
-    wsb = max(wsb, L.btc_conv_wgrad_ws_bytes(n_res, K, cin, cout, n_src))   # the two kernels split the rows differently
-    check(L.btc_tune_set(11, 0), "t")
     ws = torch.empty((wsb,), dtype=torch.uint8, device=dev)
     dw = torch.empty_like(w)
-    fn = lambda: check(wg(ptr(f), ptr(g), ptr(mf), n_res, ptr(mb), n_src, K, cin, cout, ptr(dw), ptr(ws), wsb, stream_ptr()), "w")
+    pmb = None if mb.data_ptr() == mf.data_ptr() else ptr(mb)    # (a submanifold rulebook has one map)
+    fn = lambda: check(wg(ptr(f), ptr(g), ptr(mf), n_res, pmb, n_src, K, cin, cout, ptr(dw), ptr(ws), wsb, stream_ptr()), "w")
     ts = [timed(fn)]
     ref = dw.clone()
-    check(L.btc_tune_set(11, 1), "t")   # the two-barrier kernel, and its timing-only variants
-    for dbg in (0, 4, 8):
-        check(L.btc_tune_set(3, dbg), "t")
-        ts.append(timed(fn))
-        if dbg == 0:
-            same = bool(torch.equal(ref, dw))
-    check(L.btc_tune_set(3, 0), "t")
-    check(L.btc_tune_set(11, 0), "t")
+    check(L.btc_tune_set(18, 1), "t")   # the fp32-pipe kernels (conv_wgrad_rows_p / conv_wgrad_partial_p)
+    ts.append(timed(fn))
+    check(L.btc_tune_set(18, 0), "t")
+    diff = float((ref - dw).abs().max() / (dw.abs().max() + 1e-30))
     tot += np.array(ts)
     nbytes, flops = (2 if bf else 4) * pairs * (cin + cout) + 4 * K * cin * cout, 2 * pairs * cin * cout
-    print("%7d %7d %3d %4d %4d %8d | %7.1f %6.0f %6.2f | %26.1f %8.1f %8.1f  %s" % (n_res, n_src, K, cin, cout, pairs, ts[0], nbytes / ts[0] / 1e3, flops / ts[0] / 1e6,
-                                                                                 ts[1], ts[2], ts[3], same))
-print("totals us: %.0f; two-barrier kernel %.0f, no MFMA %.0f, no gathers %.0f" % tuple(tot))
+    print("%7d %7d %3d %4d %4d %8d | %9.1f %6.0f %6.2f | %46.1f  %.1e" % (n_res, n_src, K, cin, cout, pairs, ts[0], nbytes / ts[0] / 1e3, flops / ts[0] / 1e6, ts[1], diff))
+print("totals us: %.0f; fp32-pipe kernels %.0f" % tuple(tot))
