@@ -282,7 +282,12 @@ std::tuple<Tensor, Tensor> bn_bwd(const Tensor& x, const Tensor& y, const Tensor
 // fork / join of a side stream around wgrad (one pair of events and one pooled stream per device, reused in stream order)
 // a weight gradient whose partial slabs wait for the batched reduction at the side stream's join (btc_wgrad_reduce_multi)
 struct SlabJob {
-  Tensor ws, dw;   // held until the reduction has been ENQUEUED: a block released earlier could be handed out again while it is still owed a read
+  Tensor ws;       // held until the reduction has been ENQUEUED: a block released earlier could be handed out again while it is still owed a read
+  // dW is NOT held: AccumulateGrad adopts a gradient as `.grad` only when nobody else references the tensor (it clones otherwise -- and
+  // would clone a buffer that is written later).  A weak reference to its storage says at reduction time whether anybody still has it.
+  c10::weak_intrusive_ptr<c10::StorageImpl> dw_storage;
+  float* dw;
+  long long count;
   int S;
 };
 
@@ -344,17 +349,22 @@ void reduce_slabs(SideStream& s) {
     jobs.swap(s.slabs);
   }
   if (jobs.empty()) return;
-  std::vector<const float*> parts(jobs.size());
-  std::vector<float*> dws(jobs.size());
-  std::vector<int> S(jobs.size());
-  std::vector<long long> counts(jobs.size());
+  std::vector<const float*> parts;
+  std::vector<float*> dws;
+  std::vector<int> S;
+  std::vector<long long> counts;
+  std::vector<c10::intrusive_ptr<c10::StorageImpl>> alive;   // until the launch is enqueued (the storages are registered with the side stream)
   for (size_t i = 0; i < jobs.size(); ++i) {
-    parts[i] = (const float*)jobs[i].ws.data_ptr();
-    dws[i] = (float*)jobs[i].dw.data_ptr();
-    S[i] = jobs[i].S;
-    counts[i] = (long long)jobs[i].dw.numel();
+    auto st = jobs[i].dw_storage.lock();
+    if (!st) continue;                     // the gradient was dropped: nobody will read it, and its block may belong to somebody else
+    alive.push_back(std::move(st));
+    parts.push_back((const float*)jobs[i].ws.data_ptr());
+    dws.push_back(jobs[i].dw);
+    S.push_back(jobs[i].S);
+    counts.push_back(jobs[i].count);
   }
-  chk(btc_wgrad_reduce_multi(parts.data(), dws.data(), S.data(), counts.data(), (int)jobs.size(), (void*)s.side), "btc_wgrad_reduce_multi");
+  if (parts.empty()) return;
+  chk(btc_wgrad_reduce_multi(parts.data(), dws.data(), S.data(), counts.data(), (int)parts.size(), (void*)s.side), "btc_wgrad_reduce_multi");
 }
 
 void join_side(SideStream& s, hipStream_t main) {
@@ -447,7 +457,7 @@ std::tuple<OptTensor, OptTensor> conv_bwd(const Tensor& features, const Tensor& 
           "btc_conv_wgrad_slabs");
       if (n_slabs > 0) {
         std::lock_guard<std::mutex> lock(ss->slab_mu);
-        ss->slabs.push_back(SlabJob{ws, g, n_slabs});
+        ss->slabs.push_back(SlabJob{ws, g.storage().getWeakStorageImpl(), (float*)g.data_ptr(), (long long)g.numel(), n_slabs});
       }
     } else if (bf)
       chk(btc_conv_wgrad_bf16(features.data_ptr(), grad_out.data_ptr(), (const int32_t*)map_fwd.data_ptr(), (int)n_res,

@@ -62,7 +62,7 @@ int btc_apply_bf16w(const void* src, const void* Wq, const float* bias, const in
 // conv_wgrad_x.hip: weight gradient on the bf16 matrix pipe (mode 0: bf16 activations, 1: fp32 activations as three exact bf16 pieces);
 // cg / cc = channels of the gathered / contiguous operand of the row walk
 bool btc_wgrad_x_supported(int mode, int K, int cg, int cc);
-int btc_wgrad_x_plan(int mode, int rows, int K, int cg, int cc, int* S, int* ph);   // -> offset groups; *S = slabs
+int btc_wgrad_x_plan(int mode, int rows, int K, int cg, int cc, int* S, int* ph, int* z = nullptr);   // -> offset groups; *S = slabs, *z = channel blocks
 int btc_launch_wgrad_x(int mode, const void* g, const void* c, const int32_t* map, const int32_t* ord, int rows, int K, int cg, int cc, float* part,
                        int swap, hipStream_t stream);
 constexpr size_t BTC_SCRATCH_HEAD = 64 * 1024;              // head of a registered scratch buffer: zeroed at registration, zero between launches

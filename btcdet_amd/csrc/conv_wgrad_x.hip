@@ -61,9 +61,14 @@ __device__ __forceinline__ bf16x8 frag_tr(const char* p) {
 template <int MT, int NT, int KB, int PH, int MODE>
 __global__ __launch_bounds__(256) void conv_wgrad_x(const void* __restrict__ gsrc, const void* __restrict__ csrc,
                                                     const int32_t* __restrict__ nbr, const int32_t* __restrict__ order, int n_rows, int K,
-                                                    float* __restrict__ part, int swap) {
-  // gsrc: gathered operand (Cg = 16 MT channels, via the map), csrc: contiguous operand (Cc = 16 NT channels); swap: see conv_wgrad_rows
+                                                    int Cg_all, int Cc_all, float* __restrict__ part, int swap) {
+  // gsrc: gathered operand (rows of Cg_all channels, via the map), csrc: contiguous operand (rows of Cc_all channels); swap: see
+  // conv_wgrad_rows.  A workgroup owns a Cg x Cc block of every dW[k] of its offset group: blockIdx.z = (block of the gathered operand's
+  // channels) * n_cblk + (block of the contiguous operand's); Cg_all is a multiple of Cg, Cc_all need not be one of Cc (the 5-channel
+  // occupancy head: columns past the end are zeros and are not written)
   constexpr int Cg = MT * 16, Cc = NT * 16;
+  const int n_cblk = (Cc_all + Cc - 1) / Cc;
+  const int cg0 = ((int)blockIdx.z / n_cblk) * Cg, cc0 = ((int)blockIdx.z % n_cblk) * Cc;
   constexpr int NPL = MODE ? 3 : 1;
   constexpr int RS = Cg * 2 + 16;          // bytes per image row (16-byte aligned; the pad staggers the rows over the banks)
   constexpr int IMG = TMX * RS;            // one plane of one offset's gathered tile
@@ -82,7 +87,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_x(const void* __restrict__ gsr
   const int kg0 = blockIdx.y * NOFF;
   const int n_tiles = (n_rows + TMX - 1) / TMX;
   const int nt_wg = ((int)blockIdx.x < n_tiles) ? (n_tiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
-  const int bcol = (wave % NT) * 16 + t16;             // this lane's column of the contiguous operand
+  const int bcol = cc0 + (wave % NT) * 16 + t16;       // this lane's column of the contiguous operand
+  const bool bvalid = bcol < Cc_all;
   const int lane_off = (4 * g4 + (t16 >> 2)) * RS + (t16 & 3) * 8;   // transposing read: row 4 g + t / 4 of the block, 8-byte chunk t % 4
 
   constexpr int NC = MODE ? 3 : 1;          // accumulators per tile (magnitude classes)
@@ -131,7 +137,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_x(const void* __restrict__ gsr
 #pragma unroll
     for (int u = 0; u < 16; ++u) {
       // (buffer loads: a row past the tile's end is an out-of-range offset -- zeros come back, nothing is fetched, no branch)
-      const unsigned off = gr[u] >= 0 ? ((unsigned)gr[u] * (unsigned)Cc + (unsigned)bcol) * (MODE ? 4u : 2u) : X_ABSENT;
+      const unsigned off = (gr[u] >= 0 && bvalid) ? ((unsigned)gr[u] * (unsigned)Cc_all + (unsigned)bcol) * (MODE ? 4u : 2u) : X_ABSENT;
       if (MODE) bnf[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rc, off, 0, 0));
       else bnh[u] = __builtin_amdgcn_raw_buffer_load_b16(rc, off, 0, 0);
     }
@@ -173,7 +179,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_x(const void* __restrict__ gsr
     for (int u = 0; u < NU; ++u) {
       const int c = (u * 256 + tid) % UPR;
       // absent neighbour (17 of 27 on submanifold levels): out-of-range offset, zeros, no traffic
-      const unsigned off = jj[u] >= 0 ? (unsigned)jj[u] * (unsigned)(Cg * (MODE ? 4 : 2)) + (unsigned)c * 16u : X_ABSENT;
+      const unsigned off = jj[u] >= 0 ? ((unsigned)jj[u] * (unsigned)Cg_all + (unsigned)cg0) * (MODE ? 4u : 2u) + (unsigned)c * 16u : X_ABSENT;
       const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rg, off, 0, 0);
       gq[u] = make_uint4(v.x, v.y, v.z, v.w);
     }
@@ -260,7 +266,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_x(const void* __restrict__ gsr
   }
   // slab of this workgroup: part[blockIdx.x][k][ci][co]; D layout of 16x16: col = lane & 15 (contiguous operand's channel),
   // row = (lane >> 4) * 4 + reg (gathered operand's channel)
-  float* P = part + (size_t)blockIdx.x * K * Cg * Cc;
+  float* P = part + (size_t)blockIdx.x * K * Cg_all * Cc_all;
 #pragma unroll
   for (int p = 0; p < PH; ++p)
 #pragma unroll
@@ -268,15 +274,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_x(const void* __restrict__ gsr
       const int l = q * 4 + wave;
       const int nt = l % NT, mt = (l / NT) % MT, kb = l / (NT * MT);
       const int k = kg0 + p * KB + kb;
-      const int co = nt * 16 + t16;
-      if (k >= K) continue;
+      const int co = cc0 + nt * 16 + t16;
+      if (k >= K || co >= Cc_all) continue;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int ci = mt * 16 + g4 * 4 + r;
+        const int ci = cg0 + mt * 16 + g4 * 4 + r;
         float v = acc[0][p * TPP + q][r];
         if (MODE) v = v + (acc[NC > 1 ? 1 : 0][p * TPP + q][r] + acc[NC - 1][p * TPP + q][r]);
-        if (!swap) P[((size_t)k * Cg + ci) * Cc + co] = v;
-        else P[((size_t)k * Cc + co) * Cg + ci] = v;   // the walk is over the layer's INPUT rows: gathered = dOut, contiguous = features
+        if (!swap) P[((size_t)k * Cg_all + ci) * Cc_all + co] = v;
+        else P[((size_t)k * Cc_all + co) * Cg_all + ci] = v;   // the walk is over the layer's INPUT rows: gathered = dOut, contiguous = features
       }
     }
 }
@@ -288,27 +294,36 @@ size_t lds_x() {
 }
 
 template <int MT, int NT, int KB, int PH, int MODE>
-void launch_x(dim3 grid, hipStream_t stream, const void* g, const void* c, const int32_t* map, const int32_t* ord, int rows, int K, float* part,
-              int swap) {
+void launch_x(dim3 grid, hipStream_t stream, const void* g, const void* c, const int32_t* map, const int32_t* ord, int rows, int K, int cg_all,
+              int cc_all, float* part, int swap) {
   static BtcPerDeviceOnce once;
   btc_once_per_device(once, [] {
     (void)hipFuncSetAttribute((const void*)conv_wgrad_x<MT, NT, KB, PH, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   });
-  conv_wgrad_x<MT, NT, KB, PH, MODE><<<grid, 256, lds_x<MT, NT, KB, PH, MODE>(), stream>>>(g, c, map, ord, rows, K, part, swap);
+  conv_wgrad_x<MT, NT, KB, PH, MODE><<<grid, 256, lds_x<MT, NT, KB, PH, MODE>(), stream>>>(g, c, map, ord, rows, K, cg_all, cc_all, part, swap);
 }
 
-// (KB, PH) per tile shape; PH is halved when the launch has too few (tile, group) pairs to fill the machine
+// (KB, PH) per tile shape; PH is halved when the launch has too few (tile, group, block) triples to fill the machine
 struct XShape {
   int mt, nt, kb, ph;
 };
-const XShape X_BF16[] = {{1, 1, 4, 4}, {2, 1, 2, 8}, {1, 2, 4, 4}, {2, 2, 2, 8}, {3, 2, 2, 4}, {2, 4, 2, 4}, {4, 2, 1, 8}, {4, 4, 1, 4}};
-const XShape X_SPLIT[] = {{2, 1, 2, 8}, {1, 2, 2, 8}, {2, 2, 2, 4}, {3, 2, 2, 2}, {2, 4, 2, 2}, {4, 2, 1, 4}, {4, 4, 1, 2}};
+const XShape X_BF16[] = {{4, 4, 1, 4}, {4, 2, 1, 8}, {2, 4, 2, 4}, {3, 2, 2, 4}, {2, 2, 2, 8}, {2, 1, 2, 8}, {1, 2, 4, 4}, {1, 1, 4, 4}};
+const XShape X_SPLIT[] = {{4, 4, 1, 2}, {4, 2, 1, 4}, {2, 4, 2, 2}, {3, 2, 2, 2}, {2, 2, 2, 4}, {2, 1, 2, 8}, {1, 2, 2, 8}};
 
-const XShape* find_shape(int mode, int mt, int nt) {
+// the tile shape of a launch: the gathered operand's channels in whole blocks of 16 MT (48 channels: MT = 3, else the largest of 4, 2, 1
+// that divides), the contiguous operand's in blocks of the smallest 16 NT that covers them (at most 64)
+const XShape* find_shape(int mode, int cg_all, int cc_all) {
+  if (cg_all <= 0 || cc_all <= 0 || (cg_all & 15)) return nullptr;
   const XShape* tab = mode ? X_SPLIT : X_BF16;
   const int n = mode ? (int)(sizeof(X_SPLIT) / sizeof(XShape)) : (int)(sizeof(X_BF16) / sizeof(XShape));
-  for (int i = 0; i < n; ++i)
-    if (tab[i].mt == mt && tab[i].nt == nt) return tab + i;
+  const int nt_want = cc_all <= 16 ? 1 : (cc_all <= 32 ? 2 : 4);
+  for (int nt = nt_want; nt >= 1; nt >>= 1)
+    for (int i = 0; i < n; ++i) {   // (the tables list the larger gathered blocks first)
+      if (tab[i].nt != nt) continue;
+      const int cg = tab[i].mt * 16;
+      if (cg_all % cg != 0 || (tab[i].mt == 3 && cg_all != 48)) continue;
+      return tab + i;
+    }
   return nullptr;
 }
 
@@ -316,35 +331,37 @@ const XShape* find_shape(int mode, int mt, int nt) {
 
 // mode: 0 = bf16 activations, 1 = fp32 activations (split operands); cg / cc: channels of the gathered / contiguous operand
 bool btc_wgrad_x_supported(int mode, int K, int cg, int cc) {
-  if (K > 64 || (cg & 15) || (cc & 15)) return false;
-  return find_shape(mode, cg / 16, cc / 16) != nullptr;
+  if (K > 64 || K < 1) return false;
+  return find_shape(mode, cg, cc) != nullptr;
 }
 
-// the work split of a launch: -> offset groups, *S = row splits (slabs), *ph = phases per group actually used
-int btc_wgrad_x_plan(int mode, int rows, int K, int cg, int cc, int* S, int* ph) {
-  const XShape* sh = find_shape(mode, cg / 16, cc / 16);
+// the work split of a launch: -> offset groups, *S = row splits (slabs), *ph = phases per group actually used, *z = channel blocks
+int btc_wgrad_x_plan(int mode, int rows, int K, int cg, int cc, int* S, int* ph, int* z) {
+  const XShape* sh = find_shape(mode, cg, cc);
   const int t_wgs = btc_tune_get(BTC_TUNE_WGRAD_WGS);
   const int wgs = t_wgs ? t_wgs : 512;
   const int n_tiles = btc_cdiv(rows, TMX);
+  const int nz = (cg / (sh->mt * 16)) * btc_cdiv(cc, sh->nt * 16);
   int p = sh->ph;
-  if (p > 1 && (long long)n_tiles * btc_cdiv(K, sh->kb * p) < 3LL * wgs) p >>= 1;
+  if (p > 1 && (long long)n_tiles * btc_cdiv(K, sh->kb * p) * nz < 3LL * wgs) p >>= 1;
   const int groups = btc_cdiv(K, sh->kb * p);
-  int s = wgs / groups;
+  int s = wgs / (groups * nz);
   if (s > n_tiles / 2) s = n_tiles / 2;
   if (s < 1) s = 1;
   *S = s;
   *ph = p;
+  if (z) *z = nz;
   return groups;
 }
 
 int btc_launch_wgrad_x(int mode, const void* g, const void* c, const int32_t* map, const int32_t* ord, int rows, int K, int cg, int cc, float* part,
                        int swap, hipStream_t stream) {
-  const XShape* sh = find_shape(mode, cg / 16, cc / 16);
+  const XShape* sh = find_shape(mode, cg, cc);
   BTC_CHECK_ARG(sh != nullptr && K <= 64, "btc_launch_wgrad_x: unsupported shape %d x %d (mode %d)", cg, cc, mode);
-  int S = 1, ph = 1;
-  const int groups = btc_wgrad_x_plan(mode, rows, K, cg, cc, &S, &ph);
-  dim3 grid(S, groups);
-#define X2(MT_, NT_, KB_, PH_, MODE_) launch_x<MT_, NT_, KB_, PH_, MODE_>(grid, stream, g, c, map, ord, rows, K, part, swap)
+  int S = 1, ph = 1, nz = 1;
+  const int groups = btc_wgrad_x_plan(mode, rows, K, cg, cc, &S, &ph, &nz);
+  dim3 grid(S, groups, nz);
+#define X2(MT_, NT_, KB_, PH_, MODE_) launch_x<MT_, NT_, KB_, PH_, MODE_>(grid, stream, g, c, map, ord, rows, K, cg, cc, part, swap)
 #define X(MT_, NT_, KB_, PH_, MODE_)                                \
   do {                                                              \
     if (ph == PH_) X2(MT_, NT_, KB_, PH_, MODE_);                   \

@@ -1320,16 +1320,31 @@ int btc_conv_fwd_stats(int operands, const void* src, const float* W, const floa
   return launch_apply<false>((const float*)src, W, bias, nbr, n_rows, K, Cin, Cout, (float*)dst, stream, bf, order, 0, &bn);
 }
 
+// does a weight-gradient launch take the bf16-pipe kernel?  n_feat: rows of `feat` if known (>= 0); have_bwd: the backward map was given
+// (the walk may then run over the smaller side of the rulebook)
+static bool wgrad_x_wanted(bool bf, int n_out, int n_feat, bool have_bwd, int K, int Cin, int Cout, int* mode, int* swap, int* rows) {
+  if (btc_tune_get(BTC_TUNE_WGRAD_X) == 1 || (!bf && btc_tune_get(BTC_TUNE_SPLIT) == 1) || n_feat < 0) return false;
+  *mode = bf ? 0 : 1;
+  *swap = have_bwd && n_feat > 0 && 2 * (long long)n_feat < n_out;
+  *rows = *swap ? n_feat : n_out;
+  const int cg = *swap ? Cout : Cin, cc = *swap ? Cin : Cout;
+  const long long esz = bf ? 2 : 4;
+  if (*rows < 2048 || !btc_wgrad_x_supported(*mode, K, cg, cc)) return false;
+  return (long long)n_feat * Cin * esz < 0xFFFFFF00LL && (long long)n_out * Cout * esz < 0xFFFFFF00LL;
+}
+
 extern "C" size_t btc_conv_wgrad_ws_bytes(int n_out, int K, int Cin, int Cout, int n_in) {
   // one size for both activation types (the bf16 instances of the pipelined kernel want Cin % 8 == 0, so the two plans can differ)
   const WgradPlan p = wgrad_plan(n_out, K, Cin, Cout, n_in, false), q = wgrad_plan(n_out, K, Cin, Cout, n_in, true);
   int S = p.S > q.S ? p.S : q.S;
-  if (p.rows_kernel) {   // ... and for the bf16-pipe kernel's split of the same walk (conv_wgrad_x.hip)
-    const int cg = p.swap ? Cout : Cin, cc = p.swap ? Cin : Cout;
-    for (int mode = 0; mode < 2; ++mode)
+  // ... and for the bf16-pipe kernel's split of the walk (conv_wgrad_x.hip), over either side, either activation type
+  for (int swap = 0; swap < 2; ++swap) {
+    if (swap && !(n_in > 0 && 2 * (long long)n_in < n_out)) continue;
+    const int cg = swap ? Cout : Cin, cc = swap ? Cin : Cout, rows = swap ? n_in : n_out;
+    for (int mode = 0; mode < 2 && rows >= 2048; ++mode)
       if (btc_wgrad_x_supported(mode, K, cg, cc)) {
         int sx = 1, ph = 1;
-        btc_wgrad_x_plan(mode, p.rows, K, cg, cc, &sx, &ph);
+        btc_wgrad_x_plan(mode, rows, K, cg, cc, &sx, &ph);
         if (sx > S) S = sx;
       }
   }
@@ -1367,18 +1382,17 @@ static int wgrad_impl(const float* feat, const float* dout, const int32_t* nbr_o
     }                                                                                  \
     return BTC_OK;                                                                     \
   } while (0)
-  if (p.rows_kernel && btc_tune_get(BTC_TUNE_WGRAD_X) != 1 && (BF || btc_tune_get(BTC_TUNE_SPLIT) != 1)) {
-    // the same walk on the bf16 matrix pipe (conv_wgrad_x.hip): bf16 activations as they are, fp32 activations as three exact bf16
-    // pieces.  Its gathers use 32-bit byte offsets: both operands must stay under 4 GB, and the row count of `feat` must be known.
-    const int mode = BF ? 0 : 1;
-    const int cg = p.swap ? Cout : Cin, cc = p.swap ? Cin : Cout;
-    const long long esz = BF ? 2 : 4;
-    const long long feat_bytes = n_feat >= 0 ? (long long)n_feat * Cin * esz : -1, dout_bytes = (long long)n_out * Cout * esz;
-    if (btc_wgrad_x_supported(mode, K, cg, cc) && feat_bytes >= 0 && feat_bytes < 0xFFFFFF00LL && dout_bytes < 0xFFFFFF00LL) {
+  {
+    // the row-stationary walk on the bf16 matrix pipe (conv_wgrad_x.hip): bf16 activations as they are, fp32 activations as three exact
+    // bf16 pieces; any channel counts whose gathered side is a multiple of 16 (a workgroup owns a <= 64 x 64 block of every dW[k]).
+    // Its gathers use 32-bit byte offsets: both operands must stay under 4 GB, and the row count of `feat` must be known.
+    int x_mode, x_swap, x_rows;
+    if (wgrad_x_wanted(BF, n_out, n_feat, nbr_in != nullptr, K, Cin, Cout, &x_mode, &x_swap, &x_rows)) {
+      const int cg = x_swap ? Cout : Cin, cc = x_swap ? Cin : Cout;
       int ph = 1;
-      btc_wgrad_x_plan(mode, p.rows, K, cg, cc, &p.S, &ph);
-      const int rc = btc_launch_wgrad_x(mode, p.swap ? (const void*)dout : (const void*)feat, p.swap ? (const void*)feat : (const void*)dout,
-                                        p.swap ? nbr_in : nbr_out, p.swap ? order_in : order_out, p.rows, K, cg, cc, part, p.swap, stream);
+      btc_wgrad_x_plan(x_mode, x_rows, K, cg, cc, &p.S, &ph);
+      const int rc = btc_launch_wgrad_x(x_mode, x_swap ? (const void*)dout : (const void*)feat, x_swap ? (const void*)feat : (const void*)dout,
+                                        x_swap ? nbr_in : nbr_out, x_swap ? order_in : order_out, x_rows, K, cg, cc, part, x_swap, stream);
       if (rc != BTC_OK) return rc;
       BTC_WGRAD_FINISH();
     }

@@ -127,7 +127,10 @@ class OccTargets3D(nn.Module):
         self.backproject = os.environ.get("BTC_OCC_BACKPROJECT") or model_cfg.TARGETS.get("BACKPROJECT", "torch")
         assert self.backproject in ("torch", "device", "inline"), self.backproject
         self.sphere_offset = [float(v) for v in occ.get("SPHERE_OFFSET", [0.0, 0.0, 0.0])]
-        assert self.backproject == "torch" or not any(self.sphere_offset), "SPHERE_OFFSET needs the host-made table (BACKPROJECT: torch)"
+        # the reference adds the offset in BOTH directions (occ_pnts + sphere_offset going to the sphere grid, carte - offset coming back:
+        # occ_targets_template.py:95,150); the device's forward projection (occupancy.hip occ_point_pass) does not take it, so a non-zero
+        # offset would give targets that are silently inconsistent -- no shipped config sets one
+        assert not any(self.sphere_offset), "a non-zero OCC.SPHERE_OFFSET is not implemented (the forward projection on the device ignores it)"
         self._lut = {}   # device -> table (plain attribute: not a buffer, so state_dict keys stay the reference's)
 
     def backproject_table(self, dev):
@@ -164,8 +167,8 @@ class OccTargets3D(nn.Module):
             for i in range(bs):
                 k = int(counts[i] * ratios[i])
                 if k > 0:
-                    pick = torch.randint(low=0, high=int(counts[i]), size=[k], device=coords.device)
-                    dropped[order[int(starts[i]) + pick]] = True
+                    pick = torch.randint(low=0, high=int(counts[i]), size=[k])     # torch's CPU generator, as the reference's dropout() draws
+                    dropped[order[int(starts[i]) + pick.to(coords.device)]] = True
         dropped = dropped.to(coords.device).bool()
         dc = coords[dropped].long()
         drop_mask = torch.zeros((bs, self.nz, self.ny, self.nx), dtype=torch.uint8, device=coords.device)

@@ -138,27 +138,51 @@ def is_sync(bn):
     return getattr(bn, "sync_group", None) is not None and bn.training
 
 
+def _routed_here(parent, child):
+    """is `child` a BatchNorm1d whose forward goes through this module's kernels -- a direct member of a SparseSequential, or bn1 / bn2
+    of a residual block (backbones_3d._bn_act)?  Only those can be synchronised by marking."""
+    from .modules import SparseSequential
+    if not (isinstance(child, torch.nn.BatchNorm1d) and child.affine and child.momentum is not None):
+        return False
+    return isinstance(parent, SparseSequential) or type(parent).__name__ == "SparseBasicBlock"
+
+
 def convert_sync_batchnorm(module, process_group=None):
-    """mark every nn.BatchNorm1d under `module` to synchronise its batch statistics over process_group (default: the world) while in
-    training mode; a world of one rank leaves the module alone.  -> number of modules marked"""
+    """torch.nn.SyncBatchNorm.convert_sync_batchnorm for a model of this package (/root/reference/tools/train.py:130-131 converts EVERY
+    _BatchNorm): BatchNorm1d layers over sparse features (members of a SparseSequential / a residual block) are MARKED -- same objects,
+    parameters, buffers, state_dict keys -- and take their batch statistics over process_group (default: the world) while in training
+    mode; every other _BatchNorm under `module` (the BatchNorm2d layers of BaseBEVBackbone, ConvHead's and pointnet2_stack's 1-D / 2-D
+    ones) is replaced in its parent by torch's own SyncBatchNorm (which adopts the module's parameters and buffers: same keys).  A world
+    of one rank leaves the module alone.  -> number of modules that now synchronise (marked + replaced)"""
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(process_group) == 1:
         return 0
+    group = process_group if process_group is not None else dist.group.WORLD
     n = 0
-    for m in module.modules():
-        if isinstance(m, torch.nn.BatchNorm1d) and m.affine and m.momentum is not None:
-            m.sync_group = process_group if process_group is not None else dist.group.WORLD
-            n += 1
+    if isinstance(module, torch.nn.BatchNorm1d) and module.affine and module.momentum is not None:
+        module.sync_group = group      # a bare layer: its caller routes it (sync_batch_norm_relu); it cannot be replaced in a parent
+        return 1
+    for parent in list(module.modules()):
+        for name, child in list(parent.named_children()):
+            if isinstance(child, torch.nn.SyncBatchNorm):
+                continue
+            if _routed_here(parent, child):
+                child.sync_group = group
+                n += 1
+            elif isinstance(child, torch.nn.modules.batchnorm._BatchNorm):
+                setattr(parent, name, torch.nn.SyncBatchNorm.convert_sync_batchnorm(child, process_group))
+                n += 1
     return n
 
 
 def combine_stats(gathered, C):
     """gathered (W, 2C + 1): per rank (mean | biased var | row count) -> (mean, biased var, total count) of the concatenated batch
-    (Chan et al.'s pairwise update, all ranks at once; ranks without rows carry count 0)"""
+    (Chan et al.'s pairwise update, all ranks at once; ranks without rows carry count 0; no rows on ANY rank: zeros, count 0)"""
     cnt = gathered[:, 2 * C:2 * C + 1]
     n = cnt.sum()
-    mean = (gathered[:, :C] * cnt).sum(0) / n
-    var = ((gathered[:, C:2 * C] + (gathered[:, :C] - mean) ** 2) * cnt).sum(0) / n
+    d = n.clamp(min=1.0)
+    mean = (gathered[:, :C] * cnt).sum(0) / d
+    var = ((gathered[:, C:2 * C] + (gathered[:, :C] - mean) ** 2) * cnt).sum(0) / d
     return mean, var, n
 
 
@@ -199,10 +223,11 @@ class SyncBatchNormReLUFunction(torch.autograd.Function):
             var_l = mean_l = torch.zeros((C,), dtype=torch.float32, device=x.device)
         mine = torch.cat([mean_l, var_l, torch.full((1,), float(N), dtype=torch.float32, device=x.device)])
         mean, var, n = combine_stats(_all_gather_rows(mine, group), C)
-        if running_mean is not None:   # torch's update: unbiased variance of the WHOLE batch
+        if running_mean is not None:   # torch's update: unbiased variance of the WHOLE batch (a batch without rows on any rank moves nothing)
             with torch.no_grad():
-                running_mean.mul_(1.0 - momentum).add_(mean, alpha=momentum)
-                running_var.mul_(1.0 - momentum).add_(var * (n / (n - 1.0).clamp_(min=1.0)), alpha=momentum)
+                m = momentum * (n > 0).to(mean.dtype)
+                running_mean.mul_(1.0 - m).add_(mean * m)
+                running_var.mul_(1.0 - m).add_(var * (n / (n - 1.0).clamp_(min=1.0)) * m)
                 if num_batches_tracked is not None:
                     num_batches_tracked.add_(1)
         # normalisation (+ ReLU) with GIVEN statistics: the fused kernel's eval path

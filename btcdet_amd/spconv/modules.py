@@ -203,14 +203,15 @@ class SparseSequential(SparseModule):
                     input = module(input)
             else:
                 if isinstance(input, SparseConvTensor):
-                    if input.indices.shape[0] != 0:
-                        f = input.features
-                        if fused_bn.is_sync(module) and f.is_cuda and f.dtype in (nn_float32, _torch.bfloat16) and f.dim() == 2:
-                            # --sync_bn: batch statistics over all ranks' rows (fused_bn.SyncBatchNormReLUFunction)
-                            relu = i < len(mods) and type(mods[i]) is nn.ReLU
-                            input.features = fused_bn.sync_batch_norm_relu(module, f, relu)
-                            i += int(relu)
-                        elif FUSE_BN_RELU and fused_bn.fusable(module) and f.is_cuda and f.dtype in (nn_float32, _torch.bfloat16) and f.dim() == 2:
+                    f = input.features
+                    if fused_bn.is_sync(module) and f is not None and f.is_cuda and f.dtype in (nn_float32, _torch.bfloat16) and f.dim() == 2:
+                        # --sync_bn: batch statistics over all ranks' rows (fused_bn.SyncBatchNormReLUFunction).  BEFORE the empty-tensor
+                        # test: a rank without rows at this layer must still enter the all_gather / all_reduce the other ranks enter
+                        relu = i < len(mods) and type(mods[i]) is nn.ReLU
+                        input.features = fused_bn.sync_batch_norm_relu(module, f, relu)
+                        i += int(relu)
+                    elif input.indices.shape[0] != 0:
+                        if FUSE_BN_RELU and fused_bn.fusable(module) and f.is_cuda and f.dtype in (nn_float32, _torch.bfloat16) and f.dim() == 2:
                             # BatchNorm1d (+ the ReLU that follows it): one fused HIP call, same parameters / buffers
                             relu = i < len(mods) and type(mods[i]) is nn.ReLU
                             input.features = fused_bn.batch_norm_relu(module, f, relu)

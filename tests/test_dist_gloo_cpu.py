@@ -195,3 +195,41 @@ def test_reducer_raises_on_every_rank_when_ranks_disagree_on_used_parameters_glo
         assert ev[1][0] == "ok" and ev[1][2] is True            # the inconsistent step itself: same (mean) update everywhere
         assert ev[1][1] is (r == 1)                             # only rank 1 had local gaps
         assert ev[2][0] == "raised", ev                         # ... and both ranks raise at the next launch
+
+
+def _convert_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    from btcdet_amd.spconv import fused_bn
+    from btcdet_amd.spconv.modules import SparseSequential
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        net = torch.nn.Module()
+        net.sparse = SparseSequential(torch.nn.BatchNorm1d(8), torch.nn.ReLU())          # routed through this package's kernels: marked
+        net.bev = torch.nn.Sequential(torch.nn.Conv2d(4, 4, 1), torch.nn.BatchNorm2d(4))   # BaseBEVBackbone-style: torch's SyncBatchNorm
+        net.mlp = torch.nn.Sequential(torch.nn.Linear(8, 8), torch.nn.BatchNorm1d(8))      # a plain BatchNorm1d outside SparseSequential
+        keys = list(net.state_dict().keys())
+        w2d = net.bev[1].weight
+        n = fused_bn.convert_sync_batchnorm(net)
+        empty = fused_bn.combine_stats(torch.zeros((2, 2 * 8 + 1)), 8)
+        out[rank] = dict(n=n, sparse_marked=type(net.sparse[0]) is torch.nn.BatchNorm1d and net.sparse[0].sync_group is not None,
+                         bev=type(net.bev[1]).__name__, mlp=type(net.mlp[1]).__name__, same_param=net.bev[1].weight is w2d,
+                         keys_same=list(net.state_dict().keys()) == keys, again=fused_bn.convert_sync_batchnorm(net),
+                         empty_finite=bool(all(torch.isfinite(t).all() for t in empty)))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_convert_sync_batchnorm_covers_every_batchnorm():
+    """the reference's torch.nn.SyncBatchNorm.convert_sync_batchnorm(model) converts EVERY _BatchNorm; so does this one
+    (sparse BatchNorm1d layers marked, everything else replaced by torch's SyncBatchNorm), and counts only what synchronises"""
+    world, port = 2, 29741
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_convert_worker, args=(world, port, out), nprocs=world, join=True)
+    for r in range(world):
+        o = out[r]
+        assert o["n"] == 3 and o["sparse_marked"] and o["bev"] == "SyncBatchNorm" and o["mlp"] == "SyncBatchNorm"
+        assert o["same_param"] and o["keys_same"] and o["empty_finite"]
+        assert o["again"] == 1      # idempotent: only the marked layer is counted again, nothing is replaced twice
