@@ -314,12 +314,7 @@ def main():
         else:
             base = 0
         n = len(pool)
-        # BTC_BENCH_TWO_AHEAD=1: hand the trainer the batch after next as well (HotPathTrainer.step(batch, next, after_next): its front is
-        # prepared a step earlier, off the worker thread's chain).  Measured, same box: 434-442 scenes/s against 452-457 -- every chain gets
-        # shorter on paper and every phase gets longer in fact; the three host threads share one GIL.  Off.
-        two_ahead = bool(getattr(step_fn, "pipelined", False)) and os.environ.get("BTC_BENCH_TWO_AHEAD", "0") == "1"
-        call = (lambda j: step_fn(pool[(base + j) % n], pool[(base + j + 1) % n], pool[(base + j + 2) % n])) if two_ahead else \
-            (lambda j: step_fn(pool[(base + j) % n], pool[(base + j + 1) % n]))
+        call = lambda j: step_fn(pool[(base + j) % n], pool[(base + j + 1) % n])
         for i in range(n_warm):
             call(i)
         sync()

@@ -132,28 +132,9 @@ class VoxelBackBoneDeconv(nn.Module):
         return batch_dict
 
     def _forward_stages(self, x):
-        """conv1 .. deconv5.  Nothing sits between the five stages, so with every rulebook at hand (prefetch_geometry) they are ONE call of
-        the compiled chain (nine conv -> BatchNorm -> ReLU layers) instead of five: the step is bound by the interpreter lock its three
-        host threads share, and every Python -> C++ transition that disappears is ~50 us of it"""
-        stages = (self.conv1, self.conv2, self.conv3, self.deconv4, self.deconv5)
-        from .spconv import modules as sp_modules, ops as sp_ops
-        if WHOLE_CHAIN and sp_ops.PROFILE is None and sp_ops.CAPTURE is None and sp_ops.NATIVE_AUTOGRAD and sp_ops.fast() is not None:
-            steps, cur, ok = [], x, True
-            for stage in stages:
-                pl = stage._chain_plan(cur)
-                if pl is None:
-                    ok = False
-                    break
-                plan, indices, shape = pl
-                steps.extend(plan)
-                cur = spconv.SparseConvTensor(x.features, indices, shape, x.batch_size)     # (a stand-in: _chain_plan reads dtype / indices / shape / rulebooks)
-                cur.indice_dict = x.indice_dict
-            if ok and steps:
-                holder = self.__dict__.get("_whole_chain")
-                if holder is None:
-                    holder = self.__dict__["_whole_chain"] = spconv.SparseSequential()
-                return holder._run_chain(x, steps, indices, shape)
-        for stage in stages:
+        """conv1 .. deconv5, one compiled chain call per stage when its rulebooks are at hand (prefetch_geometry).  (All five stages as
+        ONE call measured no better -- 430 / 453 / 440 scenes/s against 438 / 458 / 455 per stage, round 4 -- and is not kept.)"""
+        for stage in (self.conv1, self.conv2, self.conv3, self.deconv4, self.deconv5):
             x = stage(x)
         return x
 
@@ -216,16 +197,8 @@ class VoxelBackBoneDeconv(nn.Module):
         return x
 
 
-# consecutive stages with nothing in between as ONE compiled chain call (the occupancy backbone's five stages = one call of nine layers;
-# conv1 + conv1_combine, conv3 + conv3_combine, conv4 + conv4_combine of the detection backbone): same bits, seven Python -> C++
-# transitions per step fewer -- and, measured over three same-box pairs, 430 / 453 / 440 scenes/s against 438 / 458 / 455 per stage:
-# the longer uninterrupted calls do not pay.  Off.
-WHOLE_CHAIN = os.environ.get("BTC_WHOLE_CHAIN", "0") == "1"
 DET_GEOMETRY_WALK = os.environ.get("BTC_DET_GEOMETRY_WALK", "1") != "0"  # VoxelBackBone8xOcc._walk_geometry
 FAST_STAGES = os.environ.get("BTC_FAST_STAGES", "1") != "0"               # VoxelBackBone8xOcc._stage: stages straight into the compiled chain call
-# ... with the strided levels built beside conv1: 1 = on a side stream, 2 = on the current stream (the row counts travel to pinned memory
-# asynchronously, the first stage is launched behind the walk and the host waits for the counts only then), 0 = blocking walk first
-DET_WALK_ASYNC = int(os.environ.get("BTC_DET_WALK_ASYNC", "1"))
 
 
 class VoxelBackBone8xOcc(nn.Module):
@@ -281,35 +254,12 @@ class VoxelBackBone8xOcc(nn.Module):
         if getattr(self, "squeezeBev", None) is not None:
             stages.append(self.squeezeBev)
         self.__dict__['_first_strided'] = _chain_lookahead(stages)
+        # the strided levels of the rulebook walk built beside the first stage on a side stream (True), or the whole walk first with one
+        # blocking read-back (False).  Per instance: a schedule that already runs the branch on a stream of its own switches it off
+        # (HotPathTrainer, pipelined: a fifth active stream costs 1.8 ms per step there).
+        self.walk_async = os.environ.get("BTC_DET_WALK_ASYNC", "1") != "0"
 
-    def start_walk(self, batch_dict, blocking=False, handoff=False):
-        """the rulebook walk of forward(), STARTED ahead of it by whoever produced `voxel_coords` (BtcHotPath.forward_occ, right behind
-        PassOccVox): the level-0 submanifold rulebook on the current stream, the strided levels and the read-back of their row counts
-        forked onto the walk's side stream.  forward() -- on whatever stream, from whatever thread -- then only sizes and fills the maps:
-        the counts are long there, and the training thread does not sit in a blocking read-back in the middle of its forward pass
-        (0.6 of its 3 ms of host time in forward_det, BTC_TRAINER_TIMING=1)."""
-        coords = batch_dict['voxel_coords'].int()
-        if not coords.is_cuda:
-            return
-        indice_dict = {}
-        if blocking:   # the whole walk here and now: levels, the (blocking) read-back of their row counts, every map (see btc_path.DET_WALK_AHEAD)
-            global DET_WALK_ASYNC
-            saved, DET_WALK_ASYNC = DET_WALK_ASYNC, 0
-            try:
-                walk = self._walk_geometry(coords, batch_dict['batch_size'], indice_dict)
-            finally:
-                DET_WALK_ASYNC = saved
-        elif handoff:
-            # the levels on THIS (the producer's) stream with nothing but an event behind them; forward() -- the training thread, the
-            # detection stream -- reads the row counts with a blocking copy on a copy stream that waits for that event only, so it
-            # neither sits behind the previous step's detection backward (the blocking walk) nor makes this thread wait (blocking=True)
-            walk = self._walk_geometry(coords, batch_dict['batch_size'], indice_dict, force_async=4)
-        else:
-            walk = self._walk_geometry(coords, batch_dict['batch_size'], indice_dict, force_async=True)
-        if isinstance(walk, tuple):
-            batch_dict['__det_walk__'] = (coords, indice_dict, walk, "handoff" if handoff else None)
-
-    def _walk_geometry(self, coords, bs, indice_dict, force_async=False):
+    def _walk_geometry(self, coords, bs, indice_dict):
         """all rulebooks of the main chain (subm1, spconv2, subm2, ... spconv_down2, subm_down2) in one call of the compiled
         binding before the first layer runs (spconv/geometry.py): every stage then finds its rulebooks ready and runs as one
         compiled call (SparseSequential._chain_plan) instead of ~100 us of Python per layer; the side-branch pools and the
@@ -337,7 +287,7 @@ class VoxelBackBone8xOcc(nn.Module):
                 offs[id(st)] = (pos, pos + n)
                 pos += n
             plan.stage_slices = offs
-        if (DET_WALK_ASYNC or force_async) and sp_ops.PROFILE is None and plan.entries[0][0] == 0:
+        if self.walk_async and sp_ops.PROFILE is None and plan.entries[0][0] == 0:
             # The first stage (conv1, conv1_combine) only needs the level-0 submanifold rulebook, which needs no read-back: build it
             # alone, fork the rest of the walk (the strided levels and the read-back of their row counts) onto a side stream, and
             # let the caller run the first stage before it joins (forward -> _finish_walk).  The walk's ~0.3 ms of kernels and its
@@ -347,11 +297,7 @@ class VoxelBackBone8xOcc(nn.Module):
             if conv0.indice_key is not None:
                 indice_dict[conv0.indice_key] = rb0
             indice_dict.setdefault("__geometry_cache__", {})[conv0._gkey(coords, self.sparse_shape)] = (rb0, coords)
-            if isinstance(force_async, int) and not isinstance(force_async, bool) and force_async > 1:
-                side = force_async     # a read-back mode of binding.cpp geometry_walk_start chosen by the caller (4: hand-over, see start_walk)
-            else:
-                side = (DET_WALK_ASYNC if DET_WALK_ASYNC in (2, 3) else True) if not force_async else os.environ.get("BTC_WALK_AHEAD_SIDE", "0") == "1"
-            return (plan, plan.start(coords, side_stream=side), {0: rb0}, coords)
+            return (plan, plan.start(coords, side_stream=True), {0: rb0}, coords)
         return ("done", plan, plan.run(coords, indice_dict))
 
     @staticmethod
@@ -388,33 +334,7 @@ class VoxelBackBone8xOcc(nn.Module):
         return stage(x)
 
     def _stages(self, stages, x, ready):
-        """consecutive stages with nothing between them as ONE compiled chain call when the walk's rulebooks are at hand (see
-        VoxelBackBoneDeconv._forward_stages); -> (output of the last stage, outputs needed in between are not available: callers merge
-        only where nobody reads them)"""
-        from .spconv import fused_bn as sp_fused_bn, modules as sp_modules, ops as sp_ops
-        if WHOLE_CHAIN and ready is not None and len(stages) > 1 and sp_modules.CHAIN_LAYERS and sp_modules.FUSE_CONV_BN and sp_modules.FUSE_BN_RELU \
-                and sp_ops.PROFILE is None and sp_ops.CAPTURE is None and sp_ops.NATIVE_AUTOGRAD and sp_ops.fast() is not None:
-            plan, rbs = ready
-            steps, last, ok = [], None, True
-            f = x.features
-            for stage in stages:
-                sl = plan.stage_slices.get(id(stage))
-                triples = stage.__dict__.get("_chain_triples", False)
-                if triples is False:
-                    stage._chain_plan(x)
-                    triples = stage.__dict__.get("_chain_triples", None)
-                if not (sl is not None and triples and len(triples) == sl[1] - sl[0] and all(sp_fused_bn.fusable(bn) for _, bn, _ in triples)
-                        and (f.dtype == torch.float32 or all(c.in_channels % 16 == 0 and c.out_channels % 16 == 0 for c, _, _ in triples))):
-                    ok = False
-                    break
-                mine = rbs[sl[0]:sl[1]]
-                if not all(rb is not None and rb.n_out > 0 for rb in mine):
-                    ok = False
-                    break
-                steps += [(c, bn, relu, rb, False) for (c, bn, relu), rb in zip(triples, mine)]
-                last = (mine[-1].out_indices, plan.entries[sl[1] - 1][4])
-            if ok and f.is_cuda and f.shape[0] > 0:
-                return stages[0]._run_chain(x, steps, last[0], last[1])
+        """consecutive stages with nothing between them, one compiled chain call each"""
         for stage in stages:
             x = self._stage(stage, x, ready)
         return x
@@ -452,10 +372,14 @@ class VoxelBackBone8xOcc(nn.Module):
                                       (c[3] * 2, c[3] * 2, 3, dict(padding=1, indice_key='subm4'))], norm_fn)
 
     @staticmethod
-    def sparse_cat(input_lst):
+    def sparse_cat(input_lst, pad=False):
         # rows of both tensors are aligned because both rulebooks emit outputs in (b,z,y,x) order
         xrep, xocc = input_lst
-        xrep.features = torch.cat((xrep.features, xocc.features.to(xrep.features.dtype)), dim=1)
+        if pad:   # the consumer is a sparse conv: the zero channels it pads its input to (34 -> 64) come out of the same launch
+            from .spconv import ops as sp_ops
+            xrep.features = sp_ops.cat_features(xrep.features, xocc.features)
+        else:
+            xrep.features = torch.cat((xrep.features, xocc.features.to(xrep.features.dtype)), dim=1)
         return xrep
 
     @staticmethod
@@ -499,23 +423,14 @@ class VoxelBackBone8xOcc(nn.Module):
         if self.feature_dtype is not None:
             feats = feats.to(self.feature_dtype)
         bs = batch_dict['batch_size']
-        ahead = batch_dict.pop('__det_walk__', None)
-        if ahead is not None:   # start_walk(): same coordinates, the walk is under way (or done)
-            coords = ahead[0]
         x = spconv.SparseConvTensor(features=feats, indices=coords, spatial_shape=self.sparse_shape, batch_size=bs)
-        if ahead is not None:
-            x.indice_dict = ahead[1]
-            walk = ahead[2]
-        else:
-            walk = self._walk_geometry(coords, bs, x.indice_dict)
+        walk = self._walk_geometry(coords, bs, x.indice_dict)
         if not walk and self._first_strided is not None:
             # conv2's row count runs beside conv1 (rulebook lookahead, spconv/ops.py)
             self._first_strided.prefetch(coords, self.sparse_shape, bs, x.indice_dict)
         n_occ = len(self.occ_conv_exec)
         ready = None
-        if FAST_STAGES and isinstance(walk, tuple) and (walk[0] == "done" or (ahead is not None and len(ahead) > 3 and ahead[3] == "handoff")):
-            # the blocking walk (every rulebook is there already), or a walk handed over by the producer's thread: its levels ran long ago
-            # on the producer's stream, the counts come back without a wait -- finish it before the first stage
+        if FAST_STAGES and isinstance(walk, tuple) and walk[0] == "done":   # the blocking walk: every rulebook is there already
             ready = self._finish_walk(walk, x.indice_dict)
         merge_first = ready is not None and not (n_occ > 0 and self.occ_conv_exec[0])      # nothing between conv1 and conv1_combine
         x1 = self._stages([self.conv1, self.conv1_combine], x, ready) if merge_first else self._stage(self.conv1, x, ready)
@@ -526,7 +441,7 @@ class VoxelBackBone8xOcc(nn.Module):
             # rulebooks are pure functions of (indices, geometry): the side branch's pools share the main branch's builds
             occ.indice_dict["__geometry_cache__"] = x.indice_dict.setdefault("__geometry_cache__", {})
             if self.occ_conv_exec[0]:
-                x1 = self.sparse_cat([x1, occ])
+                x1 = self.sparse_cat([x1, occ], pad=not self.out_att[0])
                 if self.out_att[0]:
                     x1 = self.apply_att(x1, self.att_conv1)
         if not merge_first:
@@ -546,7 +461,7 @@ class VoxelBackBone8xOcc(nn.Module):
             if n_occ > lvl:
                 occ = getattr(self, 'occ_conv%d' % (lvl + 1))(occ)
                 if self.occ_conv_exec[lvl]:
-                    cur = self.sparse_cat([cur, occ])
+                    cur = self.sparse_cat([cur, occ], pad=not self.out_att[lvl])
                     if self.out_att[lvl]:
                         cur = self.apply_att(cur, getattr(self, 'att_conv%d' % (lvl + 1)))
             cur = self._stage(getattr(self, 'conv%d_combine' % (lvl + 1)), cur, ready)

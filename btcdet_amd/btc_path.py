@@ -9,39 +9,12 @@ btcdet_amd/trainer.py).  ``heads="rpn"`` appends the §8f row-1 glue -- BaseBEVB
 reference's module names (``det_modules.backbone_2d`` / ``det_modules.dense_head``) and its RPN loss (btcnet.py:108-114);
 the ROI head (ConvHead) is not built, ``x_combine`` keeps its stand-in.
 """
-import os
-
 import numpy as np
 import torch
 import torch.nn as nn
 
 from . import backbones_3d, bev_backbone, dense_head, height_compression, occ_head, occ_targets, pass_occ_vox, vfe
 from .processor import DataProcessor
-
-
-# BTC_DET_WALK_AHEAD=1: start the detection branch's rulebook walk behind PassOccVox, from the occupancy branch's thread
-# (backbones_3d.start_walk).  Off: measured on one MI355X, same box, 100 timed steps -- 431 scenes/s without, 304-314 with it (on a
-# side stream or on the occupancy branch's stream alike): the training thread's forward_det loses its 0.6 ms blocking read-back
-# (2.6 -> 1.5 ms of host time), but every kernel on the occupancy branch's stream and on the weight-gradient stream then runs 1.3-2x
-# longer (per-stream kernel totals 2.5 -> 4.8 ms and 2.4 -> 3.2 ms per step, tools/stream_timeline.py); round 2 had found the same
-# move neutral.  Kept for the record and for tests.
-# Round 4: what made it slow was not the schedule but the asynchronous read-back (hipMemcpyAsync into hipHostMalloc'ed memory + event +
-# hipEventSynchronize, binding.cpp geometry_walk_start side modes 1 / 2): the SAME walk with torch's blocking copy at finish time costs
-# nothing (BTC_DET_WALK_ASYNC=3: 434-445 scenes/s against 415-453 for the default and 306-321 for the pinned asynchronous copy, same
-# box).  BTC_DET_WALK_AHEAD=2 therefore runs the WHOLE walk -- levels, blocking read-back of the row counts, maps -- from the occupancy
-# branch's thread right behind PassOccVox: that thread's stream holds nothing but the occupancy forward at that point, so the wait is
-# the walk's own ~0.2 ms, and the training thread's forward_det finds every rulebook ready instead of sitting in a read-back behind the
-# previous step's detection backward (0.97 of its 3.07 ms, tools/host_profile_main.py).  Measured, same box, three pairs: 425-436 scenes/s
-# against 446-454 without -- det_forward falls from 3.2 to 1.8 ms of host time, but the training thread then waits 0.9 ms for the
-# worker, whose chain (occupancy backward 1.4 -> optimizer + prepared batch 0.6 -> occupancy forward + walk 2.1 ms) is the longer one
-# now: the three host threads are balanced around 4.4-4.6 ms either way.  Not the default.  BTC_DET_WALK_AHEAD=3 goes one step further:
-# the occupancy thread only ENQUEUES the levels (an event behind them) and the training thread reads the counts through a copy stream that
-# waits for that event alone -- nobody blocks (det_forward 2.3 ms, the worker's wait for the prepared batch gone with `after_next`) --
-# and the step is still 4.3-4.6 ms: with every wait removed, every phase of every thread got longer (detection backward 0.96 -> 1.39 ms,
-# occupancy backward 0.67 -> 1.55, occupancy forward 1.57 -> 2.28).  The three threads' CPU time adds up to 5.9 ms per step and they share
-# one GIL: the schedule is bound by the interpreter, not by any wait that can be moved.
-DET_WALK_AHEAD = int(os.environ.get("BTC_DET_WALK_AHEAD", "0"))
-HANDOVER_KEEPALIVE = os.environ.get("BTC_HANDOVER_KEEPALIVE", "1") != "0"   # forward_det: hold the producer's tensors (BtcHotPath._borrow) instead of record_stream
 
 
 class HotPathDataset(object):
@@ -242,11 +215,6 @@ class BtcHotPath(nn.Module):
             batch_dict["__produced_here__"] = [v for v in batch_dict.values() if torch.is_tensor(v) and v.is_cuda and id(v) not in prepared]
         det_inputs_ready = None
         if torch.cuda.is_available() and batch_dict["voxels"].is_cuda:
-            dbb = self.det_modules.backbone_3d
-            if DET_WALK_AHEAD and hasattr(dbb, "start_walk") and batch_dict.get("__gen_id__") is not None:
-                # the detection branch's rulebook walk starts (1) / runs (2) here, behind PassOccVox (backbones_3d.start_walk) -- only under a
-                # schedule that runs this branch ahead from a thread of its own (a prepared batch: __gen_id__)
-                dbb.start_walk(batch_dict, blocking=DET_WALK_AHEAD == 2, handoff=DET_WALK_AHEAD == 3)
             det_inputs_ready = torch.cuda.Event()
             det_inputs_ready.record()
         occ_loss, tb_dict = head.get_loss(batch_dict)
@@ -269,7 +237,7 @@ class BtcHotPath(nn.Module):
 
     @staticmethod
     def hand_over(batch_dict, stream):
-        """register every device tensor of batch_dict (and of a rulebook walk started ahead) with `stream`, which will consume them:
+        """register every device tensor of batch_dict with `stream`, which will consume them:
         they were allocated on the producer's stream, whose pool would otherwise hand their blocks out again while `stream` still
         reads them.  ~40 calls of ~10 us: the pipelined step makes them from the producer's thread, off the training thread."""
         def rec(t):
@@ -277,17 +245,6 @@ class BtcHotPath(nn.Module):
                 t.record_stream(stream)
         for v in batch_dict.pop("__produced_here__", None) or batch_dict.values():
             rec(v)
-        ahead = batch_dict.get("__det_walk__")
-        if ahead is not None:
-            rec(ahead[0])
-            done = ahead[2][0] == "done"                   # ("done", plan, rulebooks) or (plan, handle, {0: level-0 rulebook}, coords)
-            seen = set()
-            for rb in (ahead[2][2] if done else ahead[2][2].values()):
-                if rb is None or id(rb) in seen:
-                    continue
-                seen.add(id(rb))
-                for name in ("nbr_out", "out_indices", "_nbr_in", "order_out", "order_in", "in_indices"):
-                    rec(getattr(rb, name, None))        # (_nbr_in: the stored map, not the property that would materialise a mirror)
         batch_dict["__recorded_for__"] = stream.cuda_stream
 
     def forward_det(self, batch_dict, inputs_ready=None):
@@ -297,8 +254,7 @@ class BtcHotPath(nn.Module):
             cur = torch.cuda.current_stream()
             cur.wait_event(inputs_ready)
             if batch_dict.pop("__recorded_for__", None) != cur.cuda_stream:   # (hand_over() did it from the producer's thread)
-                if HANDOVER_KEEPALIVE and batch_dict.get("__gen_id__") is not None and batch_dict.get("__det_walk__") is None \
-                        and batch_dict.get("__produced_here__") is not None:
+                if batch_dict.get("__gen_id__") is not None and batch_dict.get("__produced_here__") is not None:
                     self._borrow(batch_dict)
                 else:
                     self.hand_over(batch_dict, cur)
@@ -330,40 +286,12 @@ class BtcHotPath(nn.Module):
         return loss_rpn + MeanSquare.apply(ret["x_combine"], 1e-3)
 
     def forward(self, batch_dict):
-        """BtcNet.forward up to the BEV map (btcnet.py:32-56) + the occupancy loss (btcnet.py:91-101).
-
-        BTC_FORWARD_DET_STREAM=1 (off by default): the detection branch on a stream of its own inside this call, for a caller of the
-        plain module protocol (the reference's own train_one_epoch_multi_opt: model(batch) -> loss.backward() -> optimizer steps, no
-        trainer of this package).  Autograd runs every backward node on the stream its forward ran on, so ONE loss.backward() from ONE
-        thread then has the occupancy branch's backward, the detection branch's and the weight gradients on three streams.  Measured
-        (round 4, same box, bench.py's in-order leg): 283.7 scenes/s with it against 325.5 without -- one more ACTIVE stream costs
-        more than the overlap buys when one host thread feeds them all (the pipelined schedule pays off because each of its streams has
-        a thread of its own).  Kept for the record and for experiments."""
-        batch_dict, occ_loss, tb_dict, ready = self.forward_occ(batch_dict)
-        side = self._forward_det_stream(batch_dict) if ready is not None else None
-        if side is None:
-            out, batch_dict = self.forward_det(batch_dict)
-        else:
-            cur = torch.cuda.current_stream()
-            with torch.cuda.stream(side):
-                out, batch_dict = self.forward_det(batch_dict, ready)
-            cur.wait_stream(side)
-            for t in out.values():       # produced on the side stream's pool, consumed (loss) on the caller's stream
-                if torch.is_tensor(t) and t.is_cuda:
-                    t.record_stream(cur)
+        """BtcNet.forward up to the BEV map (btcnet.py:32-56) + the occupancy loss (btcnet.py:91-101), in order on the current stream --
+        what a caller of the plain module protocol gets (the reference's own train_one_epoch_multi_opt: model(batch) -> loss.backward()
+        -> optimizer steps).  (The detection branch on a stream of its own inside this call measured slower, 284 against 326 scenes/s:
+        one more active stream fed by the same host thread costs more than the overlap buys; HotPathTrainer's schedules give each
+        stream its own thread.)"""
+        batch_dict, occ_loss, tb_dict, _ = self.forward_occ(batch_dict)
+        out, batch_dict = self.forward_det(batch_dict)
         out["loss_occ"] = occ_loss
         return out, tb_dict, batch_dict
-
-    def _forward_det_stream(self, batch_dict):
-        """the detection branch's own stream for forward(), or None (evaluation, CPU tensors, attached branches, a per-launch profile
-        in progress, switched off)"""
-        from .spconv import ops as sp_ops
-        if not (self.training and batch_dict.get("is_train", True) and batch_dict["voxels"].is_cuda and sp_ops.PROFILE is None
-                and sp_ops.CAPTURE is None and os.environ.get("BTC_FORWARD_DET_STREAM", "0") == "1"):
-            return None
-        if getattr(self.occ_modules.occ_pnt_update, "pass_gradient", False):   # (PASS_GRAD: the occupancy branch's backward would depend on the detection branch's)
-            return None
-        st = self.__dict__.get("_det_side_stream")
-        if st is None or st.device != batch_dict["voxels"].device:
-            st = self.__dict__["_det_side_stream"] = torch.cuda.Stream(device=batch_dict["voxels"].device)
-        return st

@@ -785,13 +785,11 @@ std::shared_ptr<PendingWalk> geometry_walk_start(const Tensor& indices, int64_t 
                                                  const std::vector<int64_t>& a_p, const std::vector<int64_t>& a_d,
                                                  const std::vector<int64_t>& mode, const std::vector<int64_t>& K,
                                                  const std::vector<int64_t>& ws_bytes, const std::vector<int64_t>& ref, int64_t side_mode) {
-  // side_mode: 0 = current stream, blocking read-back; 1 = forked onto the walk's side stream, counts copied to pinned memory
-  // asynchronously; 2 = current stream, counts copied asynchronously (no extra stream, no host wait here)
-  const bool late = side_mode == 3;     // 3 = current stream, NO read-back here: finish() does the blocking one (experiment: is the asynchronous copy the cost?)
-  // 4 = current stream, no read-back here, an event behind the levels: finish() -- on ANOTHER thread and stream -- reads the counts with
-  // a blocking copy on a copy stream that waits for that event only (not for whatever else either stream holds)
-  const bool handoff = side_mode == 4;
-  const bool side = side_mode != 0 && !late;
+  // side_mode: 0 = current stream, blocking read-back; 1 = forked onto the walk's side stream, the counts copied to pinned memory
+  // asynchronously.  (Round 4 measured three more -- the asynchronous copy on the current stream, the read-back deferred to finish(), a
+  // hand-over between threads through a copy stream: none faster, DESIGN.md section 5 -- and they are gone.)
+  need(side_mode == 0 || side_mode == 1, "geometry_walk_start: side_mode must be 0 or 1");
+  const bool side = side_mode == 1;
   const size_t n = kind.size();
   need(a_in.size() == n && a_out.size() == n && a_k.size() == n && a_s.size() == n && a_p.size() == n && a_d.size() == n && mode.size() == n &&
            K.size() == n && ws_bytes.size() == n && ref.size() == n, "geometry_walk: per-layer argument lists differ in length");
@@ -836,7 +834,7 @@ std::shared_ptr<PendingWalk> geometry_walk_start(const Tensor& indices, int64_t 
     w = &walk_of(indices.get_device());
     slot = (int)(w->next.fetch_add(1) & 7u);
   }
-  if (side_mode == 1) {
+  if (side) {
     run = w->side;
     // fork after the allocations and the zero fill of d_counts: the side stream is ordered behind them and behind `indices`
     if (hipEventRecord(w->fork[slot], main) != hipSuccess || hipStreamWaitEvent(run, w->fork[slot], 0) != hipSuccess)
@@ -847,18 +845,14 @@ std::shared_ptr<PendingWalk> geometry_walk_start(const Tensor& indices, int64_t 
   }
   chk(btc_chain_levels((const int32_t*)indices.data_ptr(), p->n0, (int)batch, p->layers.data(), (int)n, p_out_idx.data(), cap.data(),
                        (int32_t*)p->d_counts.data_ptr(), p->ws.data_ptr(), p->wsb, (void*)run), "btc_chain_levels");
-  if (handoff) {
-    if (hipEventRecord(w->done[slot], run) != hipSuccess) throw std::runtime_error("geometry walk: event record failed");
-    p->done = w->done[slot];
-    p->counts = nullptr;
-  } else if (side) {
+  if (side) {
     int32_t* host = w->host_counts + slot * BTC_CHAIN_MAX_LAYERS;
     if (hipMemcpyAsync(host, p->d_counts.data_ptr(), n * sizeof(int32_t), hipMemcpyDeviceToHost, run) != hipSuccess ||
         hipEventRecord(w->done[slot], run) != hipSuccess)
       throw std::runtime_error("geometry walk: read-back enqueue failed");
     p->done = w->done[slot];
     p->counts = host;
-  } else if (!late) {
+  } else {
     p->h_counts = p->d_counts.to(at::kCPU);  // the one read-back of the chain (current stream only)
     p->counts = (const int32_t*)p->h_counts.data_ptr();
   }
@@ -871,41 +865,14 @@ std::vector<std::vector<Tensor>> geometry_walk_finish(const std::shared_ptr<Pend
   const std::vector<int64_t>&kind = p->kind, &K = p->K, &ref = p->ref;
   const Tensor& indices = p->indices;
   const int64_t stream = current_stream();
-  if (p->side && !p->counts) {   // side_mode 4: blocking read-back on the copy stream, ordered behind the levels' event only
-    static std::mutex cmu;
-    static std::vector<c10::hip::HIPStream> copy_streams;   // one per device, from the pool
-    c10::hip::HIPStream* cs = nullptr;
-    {
-      std::lock_guard<std::mutex> lock(cmu);
-      if (copy_streams.empty())
-        for (int d = 0; d < (int)c10::hip::device_count(); ++d) copy_streams.push_back(c10::hip::getStreamFromPool(false, (c10::DeviceIndex)d));
-      cs = &copy_streams[indices.get_device()];
-    }
-    if (hipStreamWaitEvent(cs->stream(), p->done, 0) != hipSuccess) throw std::runtime_error("geometry walk: copy-stream wait failed");
-    c10::hip::HIPCachingAllocator::recordStream(p->d_counts.storage().data_ptr(), *cs);
-    {
-      c10::hip::HIPStreamGuard guard(*cs);
-      const_cast<PendingWalk*>(p.get())->h_counts = p->d_counts.to(at::kCPU);
-    }
-    const_cast<PendingWalk*>(p.get())->counts = (const int32_t*)p->h_counts.data_ptr();
-    if (hipStreamWaitEvent((hipStream_t)st(stream), p->done, 0) != hipSuccess) throw std::runtime_error("geometry walk: join failed");
-    const c10::hip::HIPStream cur = c10::hip::getCurrentHIPStream();
-    for (const Tensor* t : {&p->ws, &p->d_counts, &p->indices}) c10::hip::HIPCachingAllocator::recordStream(t->storage().data_ptr(), cur);
-    for (const Tensor& t : p->out_idx)
-      if (t.defined()) c10::hip::HIPCachingAllocator::recordStream(t.storage().data_ptr(), cur);
-  } else if (p->side) {
+  if (p->side) {
     if (hipEventSynchronize(p->done) != hipSuccess || hipStreamWaitEvent((hipStream_t)st(stream), p->done, 0) != hipSuccess)
       throw std::runtime_error("geometry walk: join failed");
-    // finish() may run on another stream than start() did (the walk of the detection branch is started from the occupancy branch's
-    // thread): the buffers start() allocated are used by the fill below on THIS stream
+    // finish() may run on another stream than start() did: the buffers start() allocated are used by the fill below on THIS stream
     const c10::hip::HIPStream cur = c10::hip::getCurrentHIPStream();
     for (const Tensor* t : {&p->ws, &p->d_counts, &p->indices}) c10::hip::HIPCachingAllocator::recordStream(t->storage().data_ptr(), cur);
     for (const Tensor& t : p->out_idx)
       if (t.defined()) c10::hip::HIPCachingAllocator::recordStream(t.storage().data_ptr(), cur);
-  }
-  if (!p->side && !p->counts) {   // side_mode 3: the blocking read-back, now (whatever the caller launched since start() runs ahead of it)
-    const_cast<PendingWalk*>(p.get())->h_counts = p->d_counts.to(at::kCPU);
-    const_cast<PendingWalk*>(p.get())->counts = (const int32_t*)p->h_counts.data_ptr();
   }
   int32_t hc_copy[BTC_CHAIN_MAX_LAYERS];
   for (size_t i = 0; i < n; ++i) hc_copy[i] = p->counts[i];   // the pinned slot is recycled 8 walks later

@@ -58,20 +58,15 @@ __device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned&
 // vector-memory queue.  An LDS-DMA instruction holds its wave until the CU's address unit has taken it (~20 cycles a piece behind
 // 40-64 pieces per item): with the product waves issuing their own pieces, every wave of the workgroup sat in that queue at the top
 // of every item and the matrix pipe idled -- loads and products ADDED (ablation: DESIGN.md section 5, round 4).
-// MR: 16-row fragments per product wave (tile height 16 WR MR).  MR = 2 shares every weight panel between two row fragments: half the
-// panel bytes moved into the LDS per row and half the B fragment reads per MFMA (the panels are 60 % of an item's bytes).  Opt-in
-// instances (BTC_TUNE_APPLY_NT = 9000 + shape), not taken by the built-in policy: written at the end of round 4, after the round's
-// GPU minutes were spent -- compiled, the MR = 1 instances' ISA unchanged, NOT yet run.
-template <int WR, int WC, int NTW, int KC, int S_STAGES, int LW, int MR>
+template <int WR, int WC, int NTW, int KC, int S_STAGES, int LW>
 __global__ __launch_bounds__(64 * (WR * WC + LW)) void conv_apply_s(const float* __restrict__ feat, const unsigned short* __restrict__ Ws,
                                                              const float* __restrict__ bias, const int32_t* __restrict__ nbr,
                                                              const int32_t* __restrict__ order, int n_rows, int K, int Cred, int Cres,
-                                                             float* __restrict__ out, int flags, const BnFuse bn, float* __restrict__ out_final,
-                                                             int32_t* __restrict__ ztickets) {
+                                                             float* __restrict__ out, int flags, const BnFuse bn) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NW = WR * WC, THREADS = 64 * (NW + LW);
   constexpr int NLD = LW ? LW : NW;                  // waves that issue the DMA pieces
-  constexpr int TM = 16 * WR * MR, TN = 16 * NTW * WC;
+  constexpr int TM = 16 * WR, TN = 16 * NTW * WC;
   constexpr int UPA = KC / 4, UPB = KC / 8;          // 16-byte units per A row (fp32) / per B^T row of one plane (bf16)
   constexpr int A_UNITS = TM * UPA, B_UNITS = 3 * TN * UPB;
   static_assert(A_UNITS % 64 == 0 && B_UNITS % 64 == 0, "whole DMA instructions");
@@ -115,14 +110,12 @@ __global__ __launch_bounds__(64 * (WR * WC + LW)) void conv_apply_s(const float*
     if (v >= 0) s_kact[kk] = 1;
   }
   __syncthreads();
-  unsigned long long wave_act = 0, frag_act[MR];   // bit k: a row of this wave (of its fragment m) has a neighbour at offset k
-#pragma unroll
-  for (int m = 0; m < MR; ++m) {
+  unsigned long long wave_act;
+  {
     bool any = false;
     if (lane < K)
-      for (int r = 0; r < 16; ++r) any |= s_nbr[((wr * MR + m) * 16 + r) * K + lane] >= 0;
-    frag_act[m] = __ballot(any);
-    wave_act |= frag_act[m];
+      for (int r = 0; r < 16; ++r) any |= s_nbr[(wr * 16 + r) * K + lane] >= 0;
+    wave_act = __ballot(any);
   }
   const int kflag = (lane < K) ? s_kact[lane] : 0;
   __syncthreads();
@@ -140,7 +133,6 @@ __global__ __launch_bounds__(64 * (WR * WC + LW)) void conv_apply_s(const float*
   const int n_all = n_act * n_chunks;
   const int i0 = (int)((long long)blockIdx.z * n_all / gridDim.z);
   const int n_items = (dbg & 32) ? i0 : (int)((long long)(blockIdx.z + 1) * n_all / gridDim.z);   // (32: no item loop)
-  float* const slab0 = out;
   out += (size_t)blockIdx.z * n_rows * Cres;
 
   // cursors of the two walks over the tile's (offset, chunk) items -- issue runs S_STAGES - 1 items ahead of compute; both advance by
@@ -203,9 +195,8 @@ __global__ __launch_bounds__(64 * (WR * WC + LW)) void conv_apply_s(const float*
 
   const int arow = lane & 15, kg = lane >> 4;
   static_assert((S_STAGES - 2) * NPI <= 63, "vmcnt is a 6-bit counter");
-  float vals[MR][NTW][4];
-  bool valid[MR][4];
-  const bool zred = ztickets != nullptr;   // z-split with the reduction in this launch: partial sums first, bias / statistics by the tile's last workgroup
+  float vals[NTW][4];
+  bool valid[4];
   if (LW > 0 && wave >= NW) {
     // ---- loader waves: wait for an item's pieces, meet the product waves at the item's barrier, issue the item S - 1 ahead
     // (two separate branches, so that the loaders' address registers and the product waves' accumulators share the register file)
@@ -224,24 +215,19 @@ __global__ __launch_bounds__(64 * (WR * WC + LW)) void conv_apply_s(const float*
       st = (st == S_STAGES - 1) ? 0 : st + 1;
     }
 #pragma unroll
-    for (int m = 0; m < MR; ++m) {
+    for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
-      for (int nt = 0; nt < NTW; ++nt)
+      for (int r = 0; r < 4; ++r) vals[nt][r] = 0.f;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) vals[m][nt][r] = 0.f;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) valid[m][r] = false;   // (loader waves own no rows)
-    }
+    for (int r = 0; r < 4; ++r) valid[r] = false;   // (loader waves own no rows)
   } else {
     // three accumulators per tile, one per magnitude class of the piece products (1, 2^-8, 2^-16 of |a b|): the matrix pipe aligns
     // the 32 products of an instruction to the accumulator it adds them to, so small products added to a large running sum lose
     // their low bits one by one (measured: 9x the exact chain's error on the 6912-term sums of the 256 -> 128 layer); summed among
     // themselves they keep them, and the classes meet once, in the epilogue
-    f32x4 acc[MR][NTW], accm[MR][NTW], accs[MR][NTW];
+    f32x4 acc[NTW], accm[NTW], accs[NTW];
 #pragma unroll
-    for (int m = 0; m < MR; ++m)
-#pragma unroll
-      for (int nt = 0; nt < NTW; ++nt) acc[m][nt] = accm[m][nt] = accs[m][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int nt = 0; nt < NTW; ++nt) acc[nt] = accm[nt] = accs[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < S_STAGES - 1; ++i)
       if (LW == 0 && i0 + i < n_items) issue(i);
@@ -263,7 +249,10 @@ __global__ __launch_bounds__(64 * (WR * WC + LW)) void conv_apply_s(const float*
       const int k = __builtin_amdgcn_readlane(kvec, cq);
       if (++cr == n_chunks) { cr = 0; ++cq; }
       if (((wave_act >> k) & 1ull) && !(dbg & 1)) {
+        const int r = wr * 16 + arow;
+        const char* A = ring + st * STAGE + r * (KC * 4);
         const char* B = ring + st * STAGE + A_BYTES;
+        const int aswz = (r ^ (r >> 3)) & (UPA - 1);
         constexpr int STEPS = KC / 32;
         // every fragment of the item is requested before the first product: one exposed LDS round trip per item instead of two per
         // 32-channel step (left alone, hipcc reads A, waits, splits, reads B, waits, multiplies -- step after step)
@@ -272,22 +261,16 @@ __global__ __launch_bounds__(64 * (WR * WC + LW)) void conv_apply_s(const float*
         // A and the B reads of EVERY instance until round 4 and serialised the loads of item i + S - 1 with the products of item i;
         // tools/isa_waits.py lists the waits inside the loop)
         // (wide tiles: one 32-channel step's fragments at a time -- 56 registers of fragments beside 48 of accumulators)
-        constexpr int GS = (NTW >= 4 || MR > 1) ? 1 : STEPS;   // steps whose fragments are in registers together
+        constexpr int GS = (NTW >= 4) ? 1 : STEPS;   // steps whose fragments are in registers together
 #pragma unroll
         for (int g = 0; g < STEPS / GS; ++g) {
-          f32x4 av[MR][GS][2];
+          f32x4 av[GS][2];
           bf16x8 bh[GS][NTW], bm[GS][NTW], bl[GS][NTW];
 #pragma unroll
-          for (int m = 0; m < MR; ++m) {
-            const int r = (wr * MR + m) * 16 + arow;
-            const char* A = ring + st * STAGE + r * (KC * 4);
-            const int aswz = (r ^ (r >> 3)) & (UPA - 1);
-#pragma unroll
-            for (int j = 0; j < GS; ++j) {
-              const int u0 = 8 * (g * GS + j) + 2 * kg;   // channels 32 s + 8 kg .. + 7 of the lane's row
-              av[m][j][0] = *(const f32x4*)(A + ((u0 ^ aswz) * 16));
-              av[m][j][1] = *(const f32x4*)(A + (((u0 + 1) ^ aswz) * 16));
-            }
+          for (int j = 0; j < GS; ++j) {
+            const int u0 = 8 * (g * GS + j) + 2 * kg;   // channels 32 s + 8 kg .. + 7 of the lane's row
+            av[j][0] = *(const f32x4*)(A + ((u0 ^ aswz) * 16));
+            av[j][1] = *(const f32x4*)(A + (((u0 + 1) ^ aswz) * 16));
           }
 #pragma unroll
           for (int j = 0; j < GS; ++j)
@@ -301,27 +284,23 @@ __global__ __launch_bounds__(64 * (WR * WC + LW)) void conv_apply_s(const float*
             }
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int m = 0; m < MR; ++m) {
-            if (MR > 1 && !((frag_act[m] >> k) & 1ull)) continue;   // (a fragment none of whose rows has this neighbour: sums of zeros)
-#pragma unroll
-            for (int j = 0; j < GS; ++j) {
-              const f32x4 v0 = av[m][j][0], v1 = av[m][j][1];
-              uint4 ah, am, al;
-              split2(v0[0], v0[1], ah.x, am.x, al.x);
-              split2(v0[2], v0[3], ah.y, am.y, al.y);
-              split2(v1[0], v1[1], ah.z, am.z, al.z);
-              split2(v1[2], v1[3], ah.w, am.w, al.w);
-              const bf16x8 Ah = __builtin_bit_cast(bf16x8, ah), Am = __builtin_bit_cast(bf16x8, am), Al = __builtin_bit_cast(bf16x8, al);
+          for (int j = 0; j < GS; ++j) {
+            const f32x4 v0 = av[j][0], v1 = av[j][1];
+            uint4 ah, am, al;
+            split2(v0[0], v0[1], ah.x, am.x, al.x);
+            split2(v0[2], v0[3], ah.y, am.y, al.y);
+            split2(v1[0], v1[1], ah.z, am.z, al.z);
+            split2(v1[2], v1[3], ah.w, am.w, al.w);
+            const bf16x8 Ah = __builtin_bit_cast(bf16x8, ah), Am = __builtin_bit_cast(bf16x8, am), Al = __builtin_bit_cast(bf16x8, al);
 #define S_MFMA(ACC, X, Y)                 \
-    _Pragma("unroll") for (int nt = 0; nt < NTW; ++nt) ACC[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(X, Y[j][nt], ACC[m][nt], 0, 0, 0)
-              S_MFMA(accs, Al, bh);
-              S_MFMA(accs, Ah, bl);
-              S_MFMA(accs, Am, bm);
-              S_MFMA(accm, Am, bh);
-              S_MFMA(accm, Ah, bm);
-              S_MFMA(acc, Ah, bh);
+    _Pragma("unroll") for (int nt = 0; nt < NTW; ++nt) ACC[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(X, Y[j][nt], ACC[nt], 0, 0, 0)
+            S_MFMA(accs, Al, bh);
+            S_MFMA(accs, Ah, bl);
+            S_MFMA(accs, Am, bm);
+            S_MFMA(accm, Am, bh);
+            S_MFMA(accm, Ah, bm);
+            S_MFMA(acc, Ah, bh);
 #undef S_MFMA
-            }
           }
         }
       }
@@ -330,73 +309,22 @@ __global__ __launch_bounds__(64 * (WR * WC + LW)) void conv_apply_s(const float*
 
     // epilogue as conv_apply_g's: C/D layout of 16x16: col = lane & 15, row = (lane >> 4) * 4 + reg
 #pragma unroll
-    for (int m = 0; m < MR; ++m)
+    for (int nt = 0; nt < NTW; ++nt) {
+      const int col = n0 + (wc * NTW + nt) * 16 + (lane & 15);
+      const float bv0 = bias ? bias[col] : 0.f;
 #pragma unroll
-      for (int nt = 0; nt < NTW; ++nt) {
-        const int col = n0 + (wc * NTW + nt) * 16 + (lane & 15);
-        const float bv0 = (bias && !zred) ? bias[col] : 0.f;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = s_row[(wr * MR + m) * 16 + kg * 4 + r];
-          valid[m][r] = row >= 0;
-          const float sum = acc[m][nt][r] + (accm[m][nt][r] + accs[m][nt][r]);
-          const float v = (bias && !zred) ? (sum + bv0) : sum;
-          if (row >= 0) out[(size_t)row * Cres + col] = v;
-          vals[m][nt][r] = v;
-        }
+      for (int r = 0; r < 4; ++r) {
+        const int row = s_row[wr * 16 + kg * 4 + r];
+        valid[r] = row >= 0;
+        const float sum = acc[nt][r] + (accm[nt][r] + accs[nt][r]);
+        const float v = bias ? (sum + bv0) : sum;
+        if (row >= 0) out[(size_t)row * Cres + col] = v;
+        vals[nt][r] = v;
       }
-  }
-  bool contribute = true;
-  if (zred) {
-    // The Z workgroups of a tile meet at a ticket (release -> fetch_add -> acquire at agent scope, as bn_fuse_finish); the LAST one
-    // adds the Z partial slabs of the tile in z order -- deterministic, the sums split_reduce made -- with the bias, writes the result
-    // and contributes the BatchNorm statistics: no second launch (11 per training step at ~14 us each), the slabs are read from L2.
-    int* s_flag = (int*)smem;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      const int t = __hip_atomic_fetch_add(ztickets + blockIdx.y * gridDim.x + blockIdx.x, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      *s_flag = (t == (int)gridDim.z - 1);
-    }
-    __syncthreads();
-    contribute = *s_flag != 0;
-    if (contribute) {
-      if (tid == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        __hip_atomic_store(ztickets + blockIdx.y * gridDim.x + blockIdx.x, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // zero on exit
-      }
-      __syncthreads();
-      const size_t slab = (size_t)n_rows * Cres;
-      const int Z = (int)gridDim.z;
-#pragma unroll
-      for (int m = 0; m < MR; ++m)
-#pragma unroll
-        for (int nt = 0; nt < NTW; ++nt) {
-          const int col = n0 + (wc * NTW + nt) * 16 + (lane & 15);
-          const float bv0 = bias ? bias[col] : 0.f;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int row = computes ? s_row[(wr * MR + m) * 16 + kg * 4 + r] : -1;
-            float v = 0.f;
-            if (row >= 0) {
-              const float* p = slab0 + (size_t)row * Cres + col;
-              v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              for (int z = 1; z < Z; ++z) v += __hip_atomic_load(p + z * slab, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              if (bias) v += bv0;
-              out_final[(size_t)row * Cres + col] = v;
-            }
-            vals[m][nt][r] = v;
-          }
-        }
     }
   }
   if (bn.slots) {   // batch statistics for the BatchNorm behind this layer (bn_fuse.h)
-    if (contribute && computes) {
-#pragma unroll
-      for (int m = 0; m < MR; ++m)
-        bn_fuse_wave<NTW>(bn, vals[m], valid[m], n0 + wc * NTW * 16, (int)(((bx * WR + wr) * MR + m) & (BN_FUSE_SLOTS - 1)));
-    }
+    if (computes) bn_fuse_wave<NTW>(bn, vals, valid, n0 + wc * NTW * 16, (int)((bx * WR + wr) & (BN_FUSE_SLOTS - 1)));
     bn_fuse_finish(bn, (int*)smem);
   }
 }
@@ -405,20 +333,18 @@ size_t lds_bytes_s(int tm, int tn, int kc, int K, int stages) {
   return (size_t)stages * ((size_t)tm * kc * 4 + (size_t)3 * tn * kc * 2) + (size_t)(tm * K + K + 1 + tm) * sizeof(int32_t);
 }
 
-template <int WR, int WC, int NTW, int KC, int S_STAGES, int LW = 0, int MR = 1>
+template <int WR, int WC, int NTW, int KC, int S_STAGES, int LW = 0>
 int launch_s(const float* feat, const unsigned short* Ws, const float* bias, const int32_t* nbr, const int32_t* order, int n_rows, int K, int Cred,
-             int Cres, float* out, int flags, hipStream_t stream, const BnFuse& bn, int zsplit, float* out_final, int32_t* ztickets) {
-  constexpr int TM = 16 * WR * MR, TN = 16 * NTW * WC;
+             int Cres, float* out, int flags, hipStream_t stream, const BnFuse& bn, int zsplit) {
+  constexpr int TM = 16 * WR, TN = 16 * NTW * WC;
   const size_t lds = lds_bytes_s(TM, TN, KC, K, S_STAGES);
   BTC_CHECK_ARG(lds <= 160 * 1024, "conv_apply_s: tile does not fit the LDS");
   static BtcPerDeviceOnce once;   // launches come from the training thread, the autograd thread and the prefetch thread
   btc_once_per_device(once, [] {
-    (void)hipFuncSetAttribute((const void*)conv_apply_s<WR, WC, NTW, KC, S_STAGES, LW, MR>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_apply_s<WR, WC, NTW, KC, S_STAGES, LW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   });
   dim3 grid(btc_cdiv(n_rows, TM), Cres / TN, zsplit);
-  BTC_CHECK_ARG(!ztickets || (long long)grid.x * grid.y <= BTC_SCRATCH_TICKETS, "conv_apply_s: more tiles than z-split tickets");
-  conv_apply_s<WR, WC, NTW, KC, S_STAGES, LW, MR><<<grid, 64 * (WR * WC + LW), lds, stream>>>(feat, Ws, bias, nbr, order, n_rows, K, Cred, Cres, out, flags, bn, out_final,
-                                                                               ztickets);
+  conv_apply_s<WR, WC, NTW, KC, S_STAGES, LW><<<grid, 64 * (WR * WC + LW), lds, stream>>>(feat, Ws, bias, nbr, order, n_rows, K, Cred, Cres, out, flags, bn);
   BTC_LAUNCH_CHECK();
   return BTC_OK;
 }
@@ -574,9 +500,7 @@ int btc_apply_split(const float* src, const void* Ws_, const float* bias_, const
   const BnFuse bn = bn_ ? *bn_ : btc_bn_fuse_none();
   const unsigned short* Ws = (const unsigned short*)Ws_;
   const int flags = (btc_tune_get(BTC_TUNE_APPLY_XCD) == 2 ? 1 : 0) | (mirror ? 2 : 0) | (btc_tune_get(BTC_TUNE_APPLY_DEBUG) << 8);
-  int t_nt = btc_tune_get(BTC_TUNE_APPLY_NT);
-  const int mr = t_nt >= 9000 ? 2 : 1;   // 9000 + shape: two 16-row fragments per product wave (tile height doubles), tuning runs only
-  if (mr == 2) t_nt -= 9000;
+  const int t_nt = btc_tune_get(BTC_TUNE_APPLY_NT);
   // shapes / chunk from tools/conv_bench.py on MI355X (us per launch, exact fp32 chain -> this kernel): 256 -> 128 at 14 K rows 333 -> 200
   // (64 x 128 tile, 64-channel items, double buffer; 32-channel items with three stages 241), 128 -> 128 164 -> 102, 64 -> 64 at 14 K rows
   // 57 -> 37.5 (64-channel items; 32-channel items 46.7), at 30 K rows 110 -> 68 (32-channel items, three stages; 64-channel items 75),
@@ -590,9 +514,7 @@ int btc_apply_split(const float* src, const void* Ws_, const float* bias_, const
   float* scratch = (float*)btc_scratch(stream, &scratch_bytes);
   const int t_z = btc_tune_get(BTC_TUNE_SPLIT_Z);
   const bool few = n_rows < 10000;
-  // the scratch buffer's head (BTC_SCRATCH_HEAD bytes, zeroed by btc_set_scratch and left zeroed by every launch) holds the tiles' tickets
-  int32_t* const tickets = (int32_t*)scratch;
-  if (scratch_bytes > BTC_SCRATCH_HEAD) {
+  if (scratch_bytes > BTC_SCRATCH_HEAD) {   // (the head of a registered scratch buffer is reserved)
     scratch = (float*)((char*)scratch + BTC_SCRATCH_HEAD);
     scratch_bytes -= BTC_SCRATCH_HEAD;
   } else {
@@ -634,14 +556,12 @@ int btc_apply_split(const float* src, const void* Ws_, const float* bias_, const
     while (Z > 1 && (size_t)Z * n_rows * Cres * sizeof(float) > scratch_bytes) --Z;
     if (Z > 1) dst = scratch;
   }
-  // BTC_TUNE_SPLIT_REDUCE = 1: the tile's last workgroup adds the slabs inside the launch (no second launch).  Measured on MI355X
-  // (tools/conv_bench.py, round 4) and NOT the default: the serial tail of the last arriver (ticket, then Z dependent uncached reads of
-  // its 64 x 128 block) costs more than the launch it saves -- 256 -> 128 at 6.4 K rows 112.8 us against 101.8 with split_reduce,
-  // 128 -> 128 70.5 / 58.8, 64 -> 64 26.4 / 25.1; the step's conv launches 2296 us against 2219.
-  const bool in_kernel = Z > 1 && btc_tune_get(BTC_TUNE_SPLIT_REDUCE) == 1;
-  const BnFuse bn_kernel = (Z > 1 && !in_kernel) ? btc_bn_fuse_none() : bn;
-  if (Z > 1 && !in_kernel) bias = nullptr;
-#define S_ARGS src, Ws, bias, nbr, order, n_rows, K, Cred, Cres, dst, flags, stream, bn_kernel, Z, dst_, (in_kernel ? tickets : nullptr)
+  // (The slabs are added by a second launch, split_reduce.  Adding them inside the launch -- the tile's last workgroup, a ticket in the
+  // scratch head -- was measured in round 4 and is gone: the last arriver's serial tail costs more than the launch it saves, 256 -> 128 at
+  // 6.4 K rows 112.8 us against 101.8, 128 -> 128 70.5 / 58.8, the step's conv launches 2296 us against 2219.)
+  const BnFuse bn_kernel = Z > 1 ? btc_bn_fuse_none() : bn;
+  if (Z > 1) bias = nullptr;
+#define S_ARGS src, Ws, bias, nbr, order, n_rows, K, Cred, Cres, dst, flags, stream, bn_kernel, Z
   int rc = BTC_EINVAL;
   // BTC_TUNE_SPLIT_LOADERS: 0 = built-in policy, 1 = the product waves issue their own pieces, 2 / 4 = that many loader waves per workgroup
   const int t_lw = btc_tune_get(BTC_TUNE_SPLIT_LOADERS);
@@ -661,15 +581,6 @@ int btc_apply_split(const float* src, const void* Ws_, const float* bias_, const
     }                                                                                                                  \
     rc = lw ? launch_s<WR_, WC_, NTW_, KC_, ST_, 2>(S_ARGS) : launch_s<WR_, WC_, NTW_, KC_, ST_, 0>(S_ARGS);            \
     break
-  if (mr == 2) {
-    switch (shape * 10 + stages + (kc == 64 ? 5 : 0)) {
-      case 4227: rc = lw ? launch_s<4, 2, 2, 64, 2, 4, 2>(S_ARGS) : launch_s<4, 2, 2, 64, 2, 0, 2>(S_ARGS); break;   // 128 x 64
-      case 4223: rc = lw ? launch_s<4, 2, 2, 32, 3, 4, 2>(S_ARGS) : launch_s<4, 2, 2, 32, 3, 0, 2>(S_ARGS); break;
-      case 4243: rc = launch_s<4, 2, 4, 32, 3, 0, 2>(S_ARGS); break;   // 128 x 128 (with four loader waves the 168-register budget spills)
-      case 4127: rc = lw ? launch_s<4, 1, 2, 64, 2, 4, 2>(S_ARGS) : launch_s<4, 1, 2, 64, 2, 0, 2>(S_ARGS); break;   // 128 x 32, four product waves
-      default: btc_set_error("conv_apply_s: no two-fragment instance for shape %d, %d stages, kc %d", shape, stages, kc); return BTC_EINVAL;
-    }
-  } else
   switch (shape * 10 + stages + (kc == 64 ? 5 : 0)) {   // ...7 / ...8: KC = 64 with 2 / 3 stages
     S_CASE(4243, 4, 2, 4, 32, 3);
     S_CASE(4244, 4, 2, 4, 32, 4);
@@ -703,7 +614,7 @@ int btc_apply_split(const float* src, const void* Ws_, const float* bias_, const
   }
 #undef S_CASE
 #undef S_ARGS
-  if (rc != BTC_OK || Z == 1 || in_kernel) return rc;
+  if (rc != BTC_OK || Z == 1) return rc;
   split_reduce<<<dim3(btc_cdiv(n_rows, 64), Cres / 64), 256, 0, stream>>>(dst, Z, bias_, n_rows, Cres, dst_, bn);
   BTC_LAUNCH_CHECK();
   return BTC_OK;

@@ -58,7 +58,8 @@ __global__ __launch_bounds__(256) void occ_loss_fwd(const float* __restrict__ lo
                                                     const uint8_t* __restrict__ pos_mask, const uint8_t* __restrict__ cls_mask,
                                                     const float* __restrict__ cls_w, const uint8_t* __restrict__ reg_mask,
                                                     const float* __restrict__ reg_w, LossParams P, double* __restrict__ partial,
-                                                    int32_t* __restrict__ counter, float* __restrict__ out, float* __restrict__ norms) {
+                                                    int32_t* __restrict__ counter, float* __restrict__ out, float* __restrict__ norms,
+                                                    int with_total) {
   __shared__ double s_red[4][4];
   double acc[4] = {0, 0, 0, 0};
   const long long total = (long long)P.B * P.ncell;
@@ -91,25 +92,38 @@ __global__ __launch_bounds__(256) void occ_loss_fwd(const float* __restrict__ lo
     const double nc = s[1] > 1.0 ? s[1] : 1.0, nr = s[3] > 1.0 ? s[3] : 1.0;   // clamp(sum w, min=1)
     out[0] = (float)(s[0] / nc * P.w_cls);
     out[1] = (float)(s[2] / nr * P.w_res);
+    if (with_total) out[2] = out[0] + out[1];   // (the fp32 sum `cls + reg` the caller would otherwise make with one more launch)
     norms[0] = (float)(P.w_cls / nc);
     norms[1] = (float)(P.w_res / nr);
     __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
-// d_logit, d_res dense (pre-zeroed by the caller); g[0], g[1] = upstream gradients of the two scalars
+// d_logit, d_res dense; g[0], g[g_stride] = upstream gradients of the two scalars (g_stride = 0: one gradient of their sum).
+// fill = 0: the caller pre-zeroed both maps, only cells inside a mask are written; fill = 1: every cell is written (zeros outside the masks)
 __global__ __launch_bounds__(256) void occ_loss_bwd(const float* __restrict__ logit, const float* __restrict__ res, const float* __restrict__ tgt,
                                                     const uint8_t* __restrict__ pos_mask, const uint8_t* __restrict__ cls_mask,
                                                     const float* __restrict__ cls_w, const uint8_t* __restrict__ reg_mask,
                                                     const float* __restrict__ reg_w, LossParams P, const float* __restrict__ norms,
-                                                    const float* __restrict__ g, float* __restrict__ d_logit, float* __restrict__ d_res) {
+                                                    const float* __restrict__ g, float* __restrict__ d_logit, float* __restrict__ d_res,
+                                                    int g_stride, int fill) {
   const long long total = (long long)P.B * P.ncell;
   long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= total) return;
   const int cm = cls_mask[t], rm = res ? reg_mask[t] : 0;
-  if (!cm && !rm) return;
+  if (!cm && !rm && !fill) return;
   const int b = (int)(t / P.ncell);
   const long long sp = t % P.ncell;
+  if (fill) {
+    if (!cm) {
+      d_logit[((size_t)b * 2 + 0) * P.ncell + sp] = 0.f;
+      d_logit[((size_t)b * 2 + 1) * P.ncell + sp] = 0.f;
+    }
+    if (!rm && d_res) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) d_res[((size_t)b * 3 + k) * P.ncell + sp] = 0.f;
+    }
+  }
   if (cm) {
     const size_t i0 = ((size_t)b * 2 + 0) * P.ncell + sp, i1 = ((size_t)b * 2 + 1) * P.ncell + sp;
     const float z0 = logit[i0], z1 = logit[i1];
@@ -129,7 +143,7 @@ __global__ __launch_bounds__(256) void occ_loss_bwd(const float* __restrict__ lo
     d_logit[i1] = pos ? dt : dother;
   }
   if (rm) {
-    const float scale = g[1] * norms[1] * reg_w[t];
+    const float scale = g[g_stride] * norms[1] * reg_w[t];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       const size_t i = ((size_t)b * 3 + k) * P.ncell + sp;
@@ -145,10 +159,10 @@ __global__ __launch_bounds__(256) void occ_loss_bwd(const float* __restrict__ lo
 
 extern "C" size_t btc_occ_loss_ws_bytes(void) { return 256 + 1024 * 4 * sizeof(double); }
 
-extern "C" int btc_occ_loss_fwd(const float* logit, const float* res, const float* res_target, const uint8_t* pos_mask,
-                                const uint8_t* cls_mask, const float* cls_w, const uint8_t* reg_mask, const float* reg_w, int B,
-                                long long ncell, float beta, float w_cls, float w_res, float* out2, float* norms2, void* ws, size_t ws_bytes,
-                                void* stream_) {
+static int occ_loss_fwd_impl(const float* logit, const float* res, const float* res_target, const uint8_t* pos_mask,
+                             const uint8_t* cls_mask, const float* cls_w, const uint8_t* reg_mask, const float* reg_w, int B,
+                             long long ncell, float beta, float w_cls, float w_res, float* out2, float* norms2, void* ws, size_t ws_bytes,
+                             void* stream_, int with_total) {
   hipStream_t stream = (hipStream_t)stream_;
   BTC_CHECK_ARG(ws_bytes >= btc_occ_loss_ws_bytes(), "btc_occ_loss_fwd: workspace too small");
   LossParams P{ncell, B, beta, 1e-6f, w_cls, w_res};
@@ -158,9 +172,26 @@ extern "C" int btc_occ_loss_fwd(const float* logit, const float* res, const floa
   int grid = btc_cdiv(total, 256 * 8);
   if (grid > 1024) grid = 1024;
   if (grid < 1) grid = 1;
-  occ_loss_fwd<<<grid, 256, 0, stream>>>(logit, res, res_target, pos_mask, cls_mask, cls_w, reg_mask, reg_w, P, partial, counter, out2, norms2);
+  occ_loss_fwd<<<grid, 256, 0, stream>>>(logit, res, res_target, pos_mask, cls_mask, cls_w, reg_mask, reg_w, P, partial, counter, out2, norms2, with_total);
   BTC_LAUNCH_CHECK();
   return BTC_OK;
+}
+
+extern "C" int btc_occ_loss_fwd(const float* logit, const float* res, const float* res_target, const uint8_t* pos_mask,
+                                const uint8_t* cls_mask, const float* cls_w, const uint8_t* reg_mask, const float* reg_w, int B,
+                                long long ncell, float beta, float w_cls, float w_res, float* out2, float* norms2, void* ws, size_t ws_bytes,
+                                void* stream_) {
+  return occ_loss_fwd_impl(logit, res, res_target, pos_mask, cls_mask, cls_w, reg_mask, reg_w, B, ncell, beta, w_cls, w_res, out2, norms2, ws,
+                           ws_bytes, stream_, 0);
+}
+
+// the same with out3[2] = out3[0] + out3[1] (the loss the head returns): no separate add launch, and one upstream gradient in backward
+extern "C" int btc_occ_loss_fwd_total(const float* logit, const float* res, const float* res_target, const uint8_t* pos_mask,
+                                      const uint8_t* cls_mask, const float* cls_w, const uint8_t* reg_mask, const float* reg_w, int B,
+                                      long long ncell, float beta, float w_cls, float w_res, float* out3, float* norms2, void* ws,
+                                      size_t ws_bytes, void* stream_) {
+  return occ_loss_fwd_impl(logit, res, res_target, pos_mask, cls_mask, cls_w, reg_mask, reg_w, B, ncell, beta, w_cls, w_res, out3, norms2, ws,
+                           ws_bytes, stream_, 1);
 }
 
 extern "C" int btc_occ_loss_bwd(const float* logit, const float* res, const float* res_target, const uint8_t* pos_mask,
@@ -171,7 +202,22 @@ extern "C" int btc_occ_loss_bwd(const float* logit, const float* res, const floa
   LossParams P{ncell, B, beta, 1e-6f, 0.f, 0.f};
   long long total = (long long)B * ncell;
   occ_loss_bwd<<<btc_cdiv(total, 256), 256, 0, stream>>>(logit, res, res_target, pos_mask, cls_mask, cls_w, reg_mask, reg_w, P, norms2, grad2,
-                                                         d_logit, d_res);
+                                                         d_logit, d_res, 1, 0);
+  BTC_LAUNCH_CHECK();
+  return BTC_OK;
+}
+
+// backward of btc_occ_loss_fwd_total: ONE upstream gradient (of the sum); every cell of d_logit / d_res is written -- the caller allocates
+// them uninitialised (no two fill launches)
+extern "C" int btc_occ_loss_bwd_total(const float* logit, const float* res, const float* res_target, const uint8_t* pos_mask,
+                                      const uint8_t* cls_mask, const float* cls_w, const uint8_t* reg_mask, const float* reg_w, int B,
+                                      long long ncell, float beta, const float* norms2, const float* grad_total, float* d_logit, float* d_res,
+                                      void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  LossParams P{ncell, B, beta, 1e-6f, 0.f, 0.f};
+  long long total = (long long)B * ncell;
+  occ_loss_bwd<<<btc_cdiv(total, 256), 256, 0, stream>>>(logit, res, res_target, pos_mask, cls_mask, cls_w, reg_mask, reg_w, P, norms2, grad_total,
+                                                         d_logit, d_res, 0, 1);
   BTC_LAUNCH_CHECK();
   return BTC_OK;
 }

@@ -71,11 +71,10 @@ class GeometryPlan(object):
                      [x[1] for x in e])
 
     def start(self, indices, side_stream=True):
-        """phase A of the walk (the levels + the read-back of their row counts) forked onto a side stream (side_stream=False: on the
-        current stream, the counts still copied to pinned memory asynchronously); finish() joins it.  Whatever is launched in
-        between overlaps with it / runs behind it without a host wait."""
-        mode = side_stream if isinstance(side_stream, int) and not isinstance(side_stream, bool) else (1 if side_stream else 2)
-        return ops.fast().geometry_walk_start(indices, self.batch_size, *self.args, mode)
+        """phase A of the walk (the levels + the read-back of their row counts) forked onto the walk's side stream; finish() joins it.
+        Whatever is launched in between overlaps with it without a host wait.  (side_stream=False: on the current stream with the
+        blocking read-back at once -- run() in two calls.)"""
+        return ops.fast().geometry_walk_start(indices, self.batch_size, *self.args, 1 if side_stream else 0)
 
     def finish(self, handle, indices, indice_dict, have=None):
         """join start(): size and fill the maps on the current stream and file the rulebooks as run() does.  have: {layer

@@ -817,6 +817,77 @@ class ToDenseFunction(torch.autograd.Function):
         return dfeat, None, None, None
 
 
+class DenseSplitFunction(torch.autograd.Function):
+    """dense() of a tensor whose channels are two heads side by side (the occupancy head's merged conv_cls | conv_res output) into the
+    two dense maps: one fill + one scatter launch forward, one gather launch backward (csrc/glue.hip) -- the same values as dense() of the
+    two column slices, which cost two copies, two fills and two scatters (and four fills / copies + an add in backward)."""
+
+    @staticmethod
+    def forward(ctx, features, indices, batch_size, spatial_shape, ca):
+        features = _f32c(features)
+        indices = _as_idx(indices)
+        n, C = features.shape
+        cb = C - int(ca)
+        sh = i3([int(v) for v in spatial_shape])
+        B, vol = int(batch_size), int(sh[0]) * int(sh[1]) * int(sh[2])
+        flat = torch.zeros((B * C * vol,), dtype=torch.float32, device=features.device)     # ONE fill for both maps
+        da = flat[:B * ca * vol].view(B, ca, int(sh[0]), int(sh[1]), int(sh[2]))
+        db = flat[B * ca * vol:].view(B, cb, int(sh[0]), int(sh[1]), int(sh[2]))
+        check(lib().btc_dense_split_fwd(ptr(features), ptr(indices), n, int(ca), cb, i3p(sh), ptr(da), ptr(db), stream_ptr()), "btc_dense_split_fwd")
+        ctx.save_for_backward(indices)
+        ctx.meta = (sh, n, int(ca), cb)
+        return da, db
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        (indices,) = ctx.saved_tensors
+        sh, n, ca, cb = ctx.meta
+        ga = _f32c(ga) if ga is not None else None
+        gb = _f32c(gb) if gb is not None else None
+        dev = (ga if ga is not None else gb).device
+        dfeat = torch.empty((n, ca + cb), dtype=torch.float32, device=dev)
+        check(lib().btc_dense_split_bwd(ptr(ga), ptr(gb), ptr(indices), n, ca, cb, i3p(sh), ptr(dfeat), stream_ptr()), "btc_dense_split_bwd")
+        return dfeat, None, None, None, None
+
+
+def dense_split(features, indices, batch_size, spatial_shape, ca):
+    """-> (dense of features[:, :ca], dense of features[:, ca:]), each (B, c, D, H, W) contiguous"""
+    return DenseSplitFunction.apply(features, indices, batch_size, spatial_shape, ca)
+
+
+class CatPadFunction(torch.autograd.Function):
+    """[a | b | zeros] along the channels in one launch each way (csrc/glue.hip); fp32 GPU tensors"""
+
+    @staticmethod
+    def forward(ctx, a, b, cout):
+        a, b = _f32c(a), _f32c(b)
+        n, ca, cb = a.shape[0], a.shape[1], b.shape[1]
+        out = torch.empty((n, int(cout)), dtype=torch.float32, device=a.device)
+        check(lib().btc_cat_pad_fwd(ptr(a), ca, ptr(b), cb, n, int(cout), ptr(out), stream_ptr()), "btc_cat_pad_fwd")
+        ctx.meta = (n, ca, cb, int(cout))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        n, ca, cb, cout = ctx.meta
+        g = _f32c(g)
+        da = torch.empty((n, ca), dtype=torch.float32, device=g.device)
+        db = torch.empty((n, cb), dtype=torch.float32, device=g.device)
+        check(lib().btc_cat_pad_bwd(ptr(g), cout, n, ptr(da), ca, ptr(db), cb, stream_ptr()), "btc_cat_pad_bwd")
+        return da, db, None
+
+
+def cat_features(a, b):
+    """torch.cat((a, b), dim=1) of two (n, c) feature matrices.  When the layer behind it would zero-pad the sum's channel count
+    (_pad_in_channels: 32 + 2 -> 64), the padding is appended HERE, in the same launch: the consumer finds its input already as wide as
+    it wants it and only pads its weight."""
+    b = b.to(a.dtype)
+    cc = a.shape[1] + b.shape[1]
+    if a.is_cuda and a.dtype == torch.float32 and a.dim() == 2 and a.shape[0] > 0 and pads_in_channels(cc):
+        return CatPadFunction.apply(a, b, cc + _pad_amount(cc, a.dtype))
+    return torch.cat((a, b), dim=1)
+
+
 # fp32 features: 34 -> 64 channels (one 64-channel item per offset instead of three 16-channel ones: 83 -> 60 us forward, 68 -> 55 us dgrad
 # at 29 K rows, and the dgrad becomes a 32 -> 64 layer the split-operand kernel takes); bf16 features: 34 -> 48, which keeps that layer on
 # fp32 weights (48 is not a multiple of 32: no bf16 weight copy), i.e. bit-equal to the oracle's chain on the widened activations
@@ -826,6 +897,10 @@ PAD_CHANNELS = int(os.environ.get("BTC_PAD_CHANNELS", "0"))   # 0 = by dtype as 
 def pads_in_channels(cin):
     """whether indice_conv zero-pads a layer's input channels (to the next multiple of PAD_CHANNELS)"""
     return cin > 16 and cin % 16 != 0
+
+
+def _pad_amount(cin, dtype):
+    return (-cin) % (PAD_CHANNELS or (32 if dtype == torch.float32 else 16))
 
 
 def _pad_in_channels(features, weight):
@@ -838,7 +913,9 @@ def _pad_in_channels(features, weight):
     if features.is_cuda and pads_in_channels(cin):
         # to the next multiple of PAD_CHANNELS: with 48 channels the LDS-DMA kernel walks 16-channel items (3 per offset, 81 per
         # workgroup for a 3 x 3 x 3 kernel), with 64 one 64-channel item per offset
-        pad = (-cin) % (PAD_CHANNELS or (32 if features.dtype == torch.float32 else 16))
+        pad = _pad_amount(cin, features.dtype)
+        if features.shape[1] == cin + pad:     # cat_features appended the zero channels already
+            return features, torch.nn.functional.pad(weight, (0, 0, 0, pad))
         return torch.nn.functional.pad(features, (0, pad)), torch.nn.functional.pad(weight, (0, 0, 0, pad))
     return features, weight
 

@@ -38,7 +38,7 @@ def voxelize_batch(points, scene_offsets, point_cloud_range, voxel_size, grid_si
     voxels = torch.empty((cap, int(max_points), C), dtype=torch.float32, device=dev)
     coords = torch.empty((cap, 4), dtype=torch.int32, device=dev)
     num = torch.empty((cap,), dtype=torch.int32, device=dev)
-    d_total = torch.zeros((1,), dtype=torch.int32, device=dev)
+    d_total = torch.empty((1,), dtype=torch.int32, device=dev)     # (written by every path of btc_voxelize)
     L = lib()
     ws_bytes = L.btc_voxelize_ws_bytes(n, batch, int(max_points))
     ws = workspace(ws_bytes, dev)

@@ -28,26 +28,66 @@ import threading
 import torch
 
 
-class MeanSquare(torch.autograd.Function):
-    """scale * mean(x^2): the L2 stand-in for consumers of the detection branch that are not built (the ROI head; without
-    --heads rpn also BEV backbone + anchor head), one reduction forward and one elementwise launch backward"""
+_SUMSQ_WS = {}
+
+
+class MeanSquare2(torch.autograd.Function):
+    """ka * mean(a^2) + kb * mean(b^2) over one or two tensors: the L2 stand-in for consumers of the detection branch that are not built
+    (the ROI head; without --heads rpn also BEV backbone + anchor head).  GPU tensors: ONE reduction launch forward (fp64 partial sums
+    in a fixed order) and ONE elementwise launch backward (csrc/glue.hip btc_sumsq2_*) -- the torch formulation was a norm, two
+    multiplications and an add per tensor forward and three multiplications backward, 13 launches of the step's ~400."""
 
     @staticmethod
-    def forward(ctx, x, scale):
-        ctx.save_for_backward(x)
-        ctx.k = float(scale) / max(x.numel(), 1)
-        n = torch.linalg.vector_norm(x.reshape(-1), dtype=torch.float32)
-        return n * n * ctx.k
+    def forward(ctx, a, scale_a, b, scale_b):
+        ka = float(scale_a) / max(a.numel(), 1)
+        kb = float(scale_b) / max(b.numel(), 1) if b is not None else 0.0
+        ctx.k = (ka, kb)
+        ok = lambda t: t is None or (t.is_cuda and t.dtype in (torch.float32, torch.bfloat16))
+        if not (ok(a) and ok(b)):      # CPU tensors (host-side tests of the schedules): plain torch
+            ctx.save_for_backward(a, b)
+            ctx.fused = False
+            out = torch.linalg.vector_norm(a.reshape(-1), dtype=torch.float32) ** 2 * ka
+            return out if b is None else out + torch.linalg.vector_norm(b.reshape(-1), dtype=torch.float32) ** 2 * kb
+        from ._lib import check, lib, ptr, stream_ptr
+        a = a.contiguous()
+        b = b.contiguous() if b is not None else None
+        key = (a.device.index, stream_ptr())
+        ws = _SUMSQ_WS.get(key)
+        if ws is None:
+            ws = _SUMSQ_WS[key] = torch.zeros(int(lib().btc_sumsq2_ws_bytes()), dtype=torch.uint8, device=a.device)
+        out = torch.empty((1,), dtype=torch.float32, device=a.device)
+        check(lib().btc_sumsq2_fwd(ptr(a), a.numel(), int(a.dtype == torch.bfloat16), ka, ptr(b), b.numel() if b is not None else 0,
+                                   int(b is not None and b.dtype == torch.bfloat16), kb, ptr(out), ptr(ws), ws.numel(), stream_ptr()), "btc_sumsq2_fwd")
+        ctx.save_for_backward(a, b)
+        ctx.fused = True
+        return out.reshape(())
 
     @staticmethod
     def backward(ctx, g):
-        (x,) = ctx.saved_tensors
-        return (x * (g * (2.0 * ctx.k)).to(x.dtype)), None
+        a, b = ctx.saved_tensors
+        ka, kb = ctx.k
+        if not ctx.fused:
+            return (a * (g * (2.0 * ka)).to(a.dtype)), None, (b * (g * (2.0 * kb)).to(b.dtype)) if b is not None else None, None
+        from ._lib import check, lib, ptr, stream_ptr
+        g = g.reshape(1).to(torch.float32).contiguous()
+        da = torch.empty_like(a)
+        db = torch.empty_like(b) if b is not None else None
+        check(lib().btc_sumsq2_bwd(ptr(a), a.numel(), int(a.dtype == torch.bfloat16), 2.0 * ka, ptr(da), ptr(b), b.numel() if b is not None else 0,
+                                   int(b is not None and b.dtype == torch.bfloat16), 2.0 * kb, ptr(db), ptr(g), stream_ptr()), "btc_sumsq2_bwd")
+        return da, None, db, None
+
+
+class MeanSquare(object):
+    """scale * mean(x^2) of ONE tensor (callers that add their own terms: --heads rpn, tests)"""
+
+    @staticmethod
+    def apply(x, scale):
+        return MeanSquare2.apply(x, scale, None, 0.0)
 
 
 def stand_in_det_loss(ret, batch_dict):
     """L2 stand-ins for both consumers of the detection branch (bench.py's headline configuration)"""
-    return MeanSquare.apply(ret["spatial_features"], 1e-3) + MeanSquare.apply(ret["x_combine"], 1e-3)
+    return MeanSquare2.apply(ret["spatial_features"], 1e-3, ret["x_combine"], 1e-3)
 
 
 def make_step(model, ddp, proc, opts, grad_sync=None, prefetch_stream=None, threaded=True, det_stream=None, opt_stream=None,
@@ -120,6 +160,17 @@ def make_step(model, ddp, proc, opts, grad_sync=None, prefetch_stream=None, thre
     pipeline = bool(pipeline and det_stream is not None and ddp is model and (grad_sync is None or bucket_of is not None)
                     and prefetch_stream is not None and threaded and len(opts) == 1 and hasattr(opts[0], "groups") and len(opts[0].groups) == 2)
     ahead_occ = {}
+
+    # work done ahead for a batch is filed with the batch OBJECT and claimed by identity: an id() alone can be reused by another batch
+    # once the caller has dropped this one
+    def _put(slot, batch, value):
+        slot.clear()
+        slot["batch"], slot["value"] = batch, value
+
+    def _take(slot, batch):
+        hit = slot.get("value") if slot.get("batch") is batch else None
+        slot.clear()
+        return hit
     # the NEXT batch's weight-independent front on a thread of its own: it shares nothing with the occupancy branch's backward /
     # optimizer step / next forward but the worker thread they all used to queue on -- the step is bound by its host threads (measured,
     # BTC_TRAINER_TIMING=1: training thread 4.1 ms and worker 4.45 ms of host time per 4.9 ms step, the front 1.7 ms of the worker's)
@@ -166,8 +217,6 @@ def make_step(model, ddp, proc, opts, grad_sync=None, prefetch_stream=None, thre
 
     def occ_forward(bd):
         out = model.forward_occ(bd)
-        if det_stream is not None and hasattr(model, "hand_over") and os.environ.get("BTC_HANDOVER_WORKER", "0") == "1":
-            model.hand_over(out[0], det_stream)   # (A/B knob: the record_stream calls from this thread instead of the training thread -- 407 vs 442 scenes/s)
         done = torch.cuda.Event()
         done.record()                    # the loss tensor is complete on this (the main) stream
         return out + (done,)
@@ -182,33 +231,19 @@ def make_step(model, ddp, proc, opts, grad_sync=None, prefetch_stream=None, thre
             return t
         return 0.0
 
-    prepared_ahead = {}   # id(batch) -> future of its prepared front, submitted one step EARLIER than it is needed (after_next)
-
-    def step_pipelined(batch, next_batch, after_next=None):
+    def step_pipelined(batch, next_batch):
         import time
         t = time.perf_counter() if timing is not None else 0.0
         c0 = time.thread_time() if timing is not None else 0.0
         opts[0].zero_grad(set_to_none=True)
-        cur = ahead_occ.pop(id(batch), None)
-        ahead_occ.clear()
+        cur = _take(ahead_occ, batch)
         if cur is None:
-            bd = pending.pop(id(batch), None)
+            bd = _take(pending, batch)
             cur = occ_forward(bd if bd is not None else model.prepare(batch))
         pending.clear()
         bd, loss_occ, tb, inputs_ready, occ_fwd_done = cur
         occ_done = threading.Event()
-        # The worker needs next_batch's prepared front ~1 ms into this step, and preparing it takes the prep thread 2-2.6 ms: submitted
-        # now, it sits on the worker's critical chain (prepare -> occupancy forward = 4.2 ms, BTC_TRAINER_TIMING=1 'w_opt_prepare').  A
-        # caller that can look two batches ahead passes `after_next`: its front is prepared during THIS step and consumed in the next.
-        prep_future = None
-        if prep_pool is not None and next_batch is not None:
-            prep_future = prepared_ahead.pop(id(next_batch), None)
-            if prep_future is None:
-                prep_future = prep_pool.submit(prep, next_batch)
-        for k in [k for k in prepared_ahead if k != id(after_next)]:
-            prepared_ahead.pop(k)          # (a caller that changed its mind: drop what nobody will consume)
-        if prep_pool is not None and after_next is not None and id(after_next) not in prepared_ahead:
-            prepared_ahead[id(after_next)] = prep_pool.submit(prep, after_next)
+        prep_future = prep_pool.submit(prep, next_batch) if (prep_pool is not None and next_batch is not None) else None
         fut = pool.submit(occ_tail, loss_occ, next_batch, occ_done, prep_future)
         t = _mark("head", t)
         with torch.cuda.stream(det_stream):
@@ -240,22 +275,21 @@ def make_step(model, ddp, proc, opts, grad_sync=None, prefetch_stream=None, thre
         t = _mark("det_optimizer", t)
         nxt = fut.result()
         if nxt is not None:
-            ahead_occ[id(next_batch)] = nxt
+            _put(ahead_occ, next_batch, nxt)
         t = _mark("wait_worker", t)
         if timing is not None:
             timing["n"] = timing.get("n", 0) + 1
             timing["cpu_main"] = timing.get("cpu_main", 0.0) + time.thread_time() - c0
         return loss
 
-    def step(batch, next_batch=None, after_next=None):
+    def step(batch, next_batch=None):
         if pipeline:
-            return step_pipelined(batch, next_batch, after_next)
+            return step_pipelined(batch, next_batch)
         for o in opts:
             o.zero_grad(set_to_none=True)
-        bd = pending.pop(id(batch), None)
+        bd = _take(pending, batch)
         if bd is None:
             bd = model.prepare(batch)
-        pending.clear()
         ahead = prefetch_stream is not None and next_batch is not None
         fut = None
         if det_stream is not None and ddp is model:
@@ -295,7 +329,7 @@ def make_step(model, ddp, proc, opts, grad_sync=None, prefetch_stream=None, thre
                 loss = ret["loss_occ"] + loss_det
                 loss.backward()
         if fut is not None:
-            pending[id(next_batch)] = fut.result()
+            _put(pending, next_batch, fut.result())
         _ops.join_wgrad()   # no-op unless weight gradients are still owed (e.g. a backward pass whose end-of-pass callback never ran)
         if grad_sync is not None:
             grad_sync.finish()  # all-reduced mean gradients in the buckets (and in param.grad with assign_grads)
@@ -309,7 +343,7 @@ def make_step(model, ddp, proc, opts, grad_sync=None, prefetch_stream=None, thre
                 refresh_planes(0)
                 refresh_planes(1)
         if ahead and not threaded:
-            pending[id(next_batch)] = model.prepare(next_batch, stream=prefetch_stream)
+            _put(pending, next_batch, model.prepare(next_batch, stream=prefetch_stream))
         model.mark_step_end()
         return loss
     step.timing = timing
@@ -414,23 +448,14 @@ class HotPathTrainer(object):
         ops.set_defer_wgrad_join(os.environ.get("BTC_DEFER_WGRAD", "1") != "0")
         cuda = self.device.type == "cuda"
         self.prefetch_stream = torch.cuda.Stream(device=self.device, priority=-1) if (cuda and schedule != "in_order") else None
-        if os.environ.get("BTC_AUTOGRAD_MT") == "0":
-            # (A/B knob) torch's autograd engine runs the backward nodes of EVERY cuda tensor of a device on ONE thread of its own: the
-            # detection branch's backward (training thread) and the occupancy branch's (worker thread) queue up behind each other there.
-            # Without the engine's threads each backward pass runs on the thread that called it.
-            torch.autograd.set_multithreading_enabled(False)
-        if os.environ.get("BTC_SWITCH_INTERVAL"):     # (A/B knob: CPython's GIL hand-over interval, default 5 ms)
-            import sys
-            sys.setswitchinterval(float(os.environ["BTC_SWITCH_INTERVAL"]))
-        self.det_stream = torch.cuda.Stream(device=self.device, priority=int(os.environ.get("BTC_DET_STREAM_PRIORITY", "0"))) \
-            if (cuda and schedule == "pipelined") else None
-        if self.det_stream is not None and "BTC_DET_WALK_ASYNC" not in os.environ:
+        self.det_stream = torch.cuda.Stream(device=self.device) if (cuda and schedule == "pipelined") else None
+        if self.det_stream is not None:
             # The detection branch's rulebook walk beside its first stage (a fifth active stream) buys nothing once the whole branch runs
-            # beside the occupancy backward, and costs a lot: round 4, same box, distinct batches -- 6.1-6.5 ms per step with it (what
-            # tools/straggler.py measured in round 3, because only bench.py switched it off) against 4.4 ms without.  Part of the schedule,
-            # so it is set here, for every user of the trainer.
-            from . import backbones_3d as _bb3d
-            _bb3d.DET_WALK_ASYNC = 0
+            # beside the occupancy backward, and costs a lot: round 4, same box, distinct batches -- 6.1-6.5 ms per step with it against
+            # 4.4 ms without.  Part of the schedule, so it is set here, on this model's backbone (not process-wide).
+            dbb = getattr(getattr(model, "det_modules", None), "backbone_3d", None)
+            if dbb is not None and hasattr(dbb, "walk_async"):
+                dbb.walk_async = False
         self._step = make_step(model, model, model.dataset.data_processor, [optimizer], self.grad_sync, self.prefetch_stream,
                                threaded=True, det_stream=self.det_stream, det_loss=det_loss, pipeline=schedule == "pipelined")
         self.end_stream = self._step.end_stream
@@ -441,10 +466,9 @@ class HotPathTrainer(object):
                         block = torch.empty(self._reserve_bytes, dtype=torch.uint8, device=self.device)
                         del block
 
-    def step(self, batch, next_batch=None, after_next=None):
-        """one optimizer step on `batch`; next_batch (optional) lets the schedule prepare / start it ahead; after_next (optional, the
-        batch behind that) lets the pipelined schedule prepare one step earlier still, off the worker thread's critical chain"""
-        return self._step(batch, next_batch, after_next) if after_next is not None else self._step(batch, next_batch)
+    def step(self, batch, next_batch=None):
+        """one optimizer step on `batch`; next_batch (optional) lets the schedule prepare / start it ahead"""
+        return self._step(batch, next_batch)
 
     def broadcast_buffers(self, src_member=0):
         """BatchNorm running statistics (every module buffer) of group member `src_member` -> all ranks.  The reference trains under

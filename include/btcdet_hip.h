@@ -65,7 +65,6 @@ int btc_version(void);
 #define BTC_TUNE_WGRAD_PIPE 11 /* conv_wgrad_rows: 1 = the two-barrier kernel instead of the software-pipelined one */
 #define BTC_TUNE_BN_FUSE 12 /* btc_conv_bn_relu_fwd: 1 = statistics by the separate bn_stats launch instead of the conv epilogue */
 #define BTC_TUNE_SPLIT_Z 15 /* split-operand kernel: workgroups sharing a tile's items (0 = built-in policy, 1 = never, 2..4 = always that many) */
-#define BTC_TUNE_SPLIT_REDUCE 16 /* split-operand kernel, z-split launches: 1 = the partial slabs are added by the tile's last workgroup inside the kernel instead of by the separate split_reduce launch (measured slower: its serial tail outweighs the launch) */
 #define BTC_TUNE_SPLIT_LOADERS 17 /* split-operand kernel: 0 = built-in policy, 1 = the product waves issue their own LDS-DMA pieces, 2 / 4 = that many loader waves per workgroup issue them all (same bits in every mode) */
 #define BTC_TUNE_SPLIT 14 /* host bindings: 1 = never take the split-operand kernel (conv_apply_g's exact fmaf chain everywhere) */
 #define BTC_TUNE_APPLY_STAGES 13 /* conv_apply_g: depth of the LDS ring (3..8; 0 = built-in policy) */
@@ -364,6 +363,28 @@ int btc_dense_fwd(const float* feat, const int32_t* indices, int n, int C, const
                   void* stream);
 int btc_dense_bwd(const float* ddense, const int32_t* indices, int n, int C, const int32_t* h_shape, float* dfeat,
                   void* stream);
+/* dense() of a tensor whose channels are two heads side by side -- the occupancy head's merged conv_cls | conv_res output
+ * (occ_head_3D.py:25-31,46,51) -- into the two dense maps in one launch: dense_a (B,Ca,D,H,W), dense_b (B,Cb,D,H,W), both zero-filled
+ * by the caller (one fill when they are carved out of one buffer); backward gathers both gradients (either may be NULL = zeros)
+ * into dfeat (n, Ca + Cb).  Same values as btc_dense_fwd / _bwd on the column slices. */
+int btc_dense_split_fwd(const float* feat, const int32_t* indices, int n, int Ca, int Cb, const int32_t* h_shape, float* dense_a,
+                        float* dense_b, void* stream);
+int btc_dense_split_bwd(const float* grad_a, const float* grad_b, const int32_t* indices, int n, int Ca, int Cb,
+                        const int32_t* h_shape, float* dfeat, void* stream);
+/* out (n, cout) = [a (n, ca) | b (n, cb) | zeros]: the detection backbone's sparse_cat (spconv_backbone.py:869-873) together with the
+ * zero channels the apply kernels want (34 -> 64); backward splits grad (n, cout) into da, db.  fp32. */
+int btc_cat_pad_fwd(const float* a, int ca, const float* b, int cb, long long n, int cout, float* out, void* stream);
+int btc_cat_pad_bwd(const float* grad, int cout, long long n, float* da, int ca, float* db, int cb, void* stream);
+/* out[0] = ka sum a^2 + kb sum b^2 over two tensors of fp32 (x_bf16 = 0) or bfloat16 (1) elements, fp64 accumulation in a fixed order
+ * (b may be NULL with nb = 0); backward: da = a * (g[0] * ka2), db = b * (g[0] * kb2), the factor rounded to the tensor's type first.
+ * The L2 stand-in loss of the heads behind the hot path (btcdet_amd/trainer.py stand_in_det_loss), not a reference operator.
+ * ws: btc_sumsq2_ws_bytes() bytes, first 256 zero before the first call (kept zero). */
+size_t btc_sumsq2_ws_bytes(void);
+int btc_sumsq2_fwd(const void* a, long long na, int a_bf16, double ka, const void* b, long long nb, int b_bf16, double kb, float* out,
+                   void* ws, size_t ws_bytes, void* stream);
+int btc_sumsq2_bwd(const void* a, long long na, int a_bf16, float ka2, void* da, const void* b, long long nb, int b_bf16, float kb2,
+                   void* db, const float* g, void* stream);
+
 
 /* ------------------------------------------------------------------------------------------------
  * Sorted-unique re-voxelization.  Replaces torch.unique(coords, dim=0, sorted=True,
@@ -522,6 +543,17 @@ int btc_occ_loss_fwd(const float* logit, const float* res, const float* res_targ
 int btc_occ_loss_bwd(const float* logit, const float* res, const float* res_target, const uint8_t* pos_mask,
                      const uint8_t* cls_mask, const float* cls_w, const uint8_t* reg_mask, const float* reg_w, int B,
                      long long ncell, float beta, const float* norms2, const float* grad2, float* d_logit, float* d_res, void* stream);
+/* the same pair for a caller that wants the SUM (OccHeadTemplate.get_loss returns occ_loss_cls + occ_loss_res, occ_head_template.py:
+ * 52-111): out3[2] = out3[0] + out3[1] comes out of the forward launch, and the backward takes ONE upstream gradient (of the sum) and
+ * writes EVERY cell of d_logit / d_res (zeros outside the masks): the caller allocates them uninitialised. */
+int btc_occ_loss_fwd_total(const float* logit, const float* res, const float* res_target, const uint8_t* pos_mask,
+                           const uint8_t* cls_mask, const float* cls_w, const uint8_t* reg_mask, const float* reg_w, int B,
+                           long long ncell, float beta, float w_cls, float w_res, float* out3, float* norms2, void* ws, size_t ws_bytes,
+                           void* stream);
+int btc_occ_loss_bwd_total(const float* logit, const float* res, const float* res_target, const uint8_t* pos_mask,
+                           const uint8_t* cls_mask, const float* cls_w, const uint8_t* reg_mask, const float* reg_w, int B,
+                           long long ncell, float beta, const float* norms2, const float* grad_total, float* d_logit, float* d_res,
+                           void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Voxel feature encoders, one launch each.  Replace the torch arithmetic of
