@@ -119,6 +119,7 @@ _SIGS = {
     "btc_row_orders": (ci, [vp, c_i32p, c_i32p, ci, vp, vp]),
     "btc_row_orders_keyed": (ci, [vp, vp, c_i32p, c_i32p, ci, vp, vp]),
     "btc_conv_apply_ordered": (ci, [ci, ci, vp, vp, vp, vp, vp, ci, ci, ci, ci, vp, vp]),
+    "btc_conv_apply_src": (ci, [ci, ci, vp, ctypes.c_longlong, vp, vp, vp, vp, ci, ci, ci, ci, vp, vp]),
     "btc_conv_wgrad_ordered": (ci, [ci, vp, vp, vp, ci, vp, ci, vp, vp, ci, ci, ci, vp, vp, sz, vp]),
     "btc_conv_wgrad_slabs": (ci, [ci, vp, vp, vp, ci, vp, ci, vp, vp, ci, ci, ci, vp, vp, sz, vp, vp]),
     "btc_wgrad_reduce_multi": (ci, [vp, vp, vp, vp, ci, vp]),
@@ -165,6 +166,7 @@ _SIGS = {
     "btc_three_interpolate_grad": (ci, [vp, vp, vp, ci, ci, ci, vp, vp]),
     "btc_bn_fuse_ws_bytes": (sz, []),
     "btc_conv_bn_relu_fwd": (ci, [ci, vp, vp, vp, vp, vp, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, ctypes.c_float, ctypes.c_float, ci, vp, vp, vp, vp, sz, vp, vp]),
+    "btc_conv_bn_relu_fwd_src": (ci, [ci, vp, ctypes.c_longlong, vp, vp, vp, vp, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, ctypes.c_float, ctypes.c_float, ci, vp, vp, vp, vp, sz, vp, vp]),
     "btc_col_sum": (ci, [vp, ci, ci, vp, vp, sz, vp]),
     "btc_col_sum_bf16": (ci, [vp, ci, ci, vp, vp, sz, vp]),
     "btc_occ_targets_ws_bytes": (sz, [ctypes.POINTER(BtcOccConfig)]),

@@ -153,7 +153,7 @@ void ensure_scratch(const Tensor& like, int64_t stream) {
 // fp32 launch of n_rows rows on the split-operand kernel (csrc/conv_apply_split.hip)?  The library's policy; BTC_TUNE_SPLIT = 1: never
 bool split_operands(const Tensor& src, int64_t K, int64_t cred, int64_t cres, int64_t n_rows, int64_t stream) {
   if (!(src.scalar_type() == at::kFloat && btc_conv_split_wanted((int)K, (int)cred, (int)cres, (int)n_rows))) return false;
-  if (src.numel() * 4 >= (int64_t)0xFFFFFF00LL) return false;   // the kernel's gathers use 32-bit byte offsets (it traps past them): exact kernels
+  if (src.numel() * 4 >= (int64_t)0xFFFFFF00LL) return false;   // the kernel's gathers use 32-bit byte offsets (the C entry refuses past them): exact kernels
   ensure_scratch(src, stream);
   return true;
 }
@@ -179,9 +179,9 @@ Tensor conv_fwd(const Tensor& features, const Tensor& w, const OptTensor& bias, 
         "btc_conv_apply_ordered (fwd, bf16 operands)");
   } else if (split_operands(features, K, cin, cout, n_res, stream)) {
     Tensor q = weights_q(w, K, cin, cout, stream, 3);
-    chk(btc_conv_apply_ordered(BTC_PASS_FWD, BTC_OPERANDS_F32_SPLIT, features.data_ptr(), (const char*)q.data_ptr() + 6 * w.numel(), fptr(bias),
+    chk(btc_conv_apply_src(BTC_PASS_FWD, BTC_OPERANDS_F32_SPLIT, features.data_ptr(), (long long)features.size(0), (const char*)q.data_ptr() + 6 * w.numel(), fptr(bias),
                                (const int32_t*)map_fwd.data_ptr(), order, (int)n_res, (int)K, (int)cin, (int)cout, out.data_ptr(), st(stream)),
-        "btc_conv_apply_ordered (fwd, split operands)");
+        "btc_conv_apply_src (fwd, split operands)");
   } else {
     const int operands = features.scalar_type() == at::kBFloat16 ? BTC_OPERANDS_BF16_ACT : BTC_OPERANDS_F32;
     chk(btc_conv_apply_ordered(BTC_PASS_FWD, operands, features.data_ptr(), w.data_ptr(), fptr(bias), (const int32_t*)map_fwd.data_ptr(), order,
@@ -249,7 +249,7 @@ std::tuple<Tensor, Tensor, Tensor> conv_bn_fwd(const Tensor& features, const Ten
       operands = BTC_OPERANDS_F32_SPLIT;
       wp = (const char*)q.data_ptr() + 6 * w.numel();
     }
-    chk(btc_conv_bn_relu_fwd(operands, features.data_ptr(), wp, fptr(bias), (const int32_t*)map_fwd.data_ptr(), order, (int)n_res, (int)K,
+    chk(btc_conv_bn_relu_fwd_src(operands, features.data_ptr(), (long long)features.size(0), wp, fptr(bias), (const int32_t*)map_fwd.data_ptr(), order, (int)n_res, (int)K,
                              (int)cin, (int)cout, x.data_ptr(), fptr(gamma), fptr(beta), (float*)vptr(rm), (float*)vptr(rv), nb, (float)momentum,
                              (float)eps, (int)relu, y.data_ptr(), mean, mean + cout, ws.data_ptr(), (size_t)ws_bytes, fw.data_ptr(), st(stream)),
         "btc_conv_bn_relu_fwd");
@@ -434,8 +434,8 @@ std::tuple<OptTensor, OptTensor> conv_bwd(const Tensor& features, const Tensor& 
                                  order, (int)n_src, (int)K, (int)cin, (int)cout, d.data_ptr(), st(stream)), "btc_conv_apply_ordered (dgrad, bf16 operands)");
     } else if (split_operands(grad_out, K, cout, cin, n_src, stream)) {
       Tensor q = q_hold = weights_q(w, K, cin, cout, stream, 3);
-      chk(btc_conv_apply_ordered(pass_dgrad, BTC_OPERANDS_F32_SPLIT, grad_out.data_ptr(), q.data_ptr(), nullptr, (const int32_t*)map_bwd.data_ptr(),
-                                 order, (int)n_src, (int)K, (int)cin, (int)cout, d.data_ptr(), st(stream)), "btc_conv_apply_ordered (dgrad, split operands)");
+      chk(btc_conv_apply_src(pass_dgrad, BTC_OPERANDS_F32_SPLIT, grad_out.data_ptr(), (long long)grad_out.size(0), q.data_ptr(), nullptr, (const int32_t*)map_bwd.data_ptr(),
+                                 order, (int)n_src, (int)K, (int)cin, (int)cout, d.data_ptr(), st(stream)), "btc_conv_apply_src (dgrad, split operands)");
     } else
       chk(btc_conv_apply_ordered(pass_dgrad, bf ? BTC_OPERANDS_BF16_ACT : BTC_OPERANDS_F32, grad_out.data_ptr(), w.data_ptr(), nullptr,
                                  (const int32_t*)map_bwd.data_ptr(), order, (int)n_src, (int)K, (int)cin, (int)cout, d.data_ptr(), st(stream)),

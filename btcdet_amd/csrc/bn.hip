@@ -575,6 +575,14 @@ extern "C" int btc_conv_bn_relu_fwd(int operands, const void* src, const void* W
                                     int n_rows, int K, int Cin, int Cout, void* x, const float* gamma, const float* beta, float* running_mean,
                                     float* running_var, long long* num_batches_tracked, float momentum, float eps, int relu, void* y,
                                     float* save_mean, float* save_rstd, void* ws, size_t ws_bytes, void* fuse_ws, void* stream) {
+  return btc_conv_bn_relu_fwd_src(operands, src, -1LL, W, bias, nbr, order, n_rows, K, Cin, Cout, x, gamma, beta, running_mean, running_var,
+                                  num_batches_tracked, momentum, eps, relu, y, save_mean, save_rstd, ws, ws_bytes, fuse_ws, stream);
+}
+
+extern "C" int btc_conv_bn_relu_fwd_src(int operands, const void* src, long long src_rows, const void* W, const float* bias, const int32_t* nbr,
+                                        const int32_t* order, int n_rows, int K, int Cin, int Cout, void* x, const float* gamma, const float* beta,
+                                        float* running_mean, float* running_var, long long* num_batches_tracked, float momentum, float eps, int relu,
+                                        void* y, float* save_mean, float* save_rstd, void* ws, size_t ws_bytes, void* fuse_ws, void* stream) {
   BTC_CHECK_ARG(n_rows >= 1, "btc_conv_bn_relu_fwd: empty input");
   BTC_CHECK_ARG(operands >= BTC_OPERANDS_F32 && operands <= BTC_OPERANDS_F32_SPLIT, "btc_conv_bn_relu_fwd: operands=%d", operands);
   const bool bf = operands == BTC_OPERANDS_BF16_ACT || operands == BTC_OPERANDS_BF16;
@@ -586,10 +594,10 @@ extern "C" int btc_conv_bn_relu_fwd(int operands, const void* src, const void* W
     bn.mean_out = save_mean; bn.rstd_out = save_rstd;
     bn.running_mean = running_mean; bn.running_var = running_var; bn.num_batches = num_batches_tracked;
     bn.momentum = momentum; bn.eps = eps; bn.N = n_rows; bn.C = Cout;
-    int rc = btc_conv_fwd_stats(operands, src, (const float*)W, bias, nbr, order, n_rows, K, Cin, Cout, x, bn, (hipStream_t)stream, &fused);
+    int rc = btc_conv_fwd_stats(operands, src, src_rows, (const float*)W, bias, nbr, order, n_rows, K, Cin, Cout, x, bn, (hipStream_t)stream, &fused);
     if (rc) return rc;
   } else {
-    int rc = btc_conv_apply_ordered(BTC_PASS_FWD, operands, src, W, bias, nbr, order, n_rows, K, Cin, Cout, x, stream);
+    int rc = btc_conv_apply_src(BTC_PASS_FWD, operands, src, src_rows, W, bias, nbr, order, n_rows, K, Cin, Cout, x, stream);
     if (rc) return rc;
   }
   if (bf)

@@ -53,8 +53,8 @@ int btc_launch_apply_glds(bool trans_w, int shape, int kc, int xcd, bool bf, con
                           hipStream_t stream, const struct BnFuse* bn = nullptr /* bn_fuse.h: batch statistics of the result in the epilogue */);
 
 // sparse_conv.hip: forward conv + batch statistics of its result in the epilogue (bn_fuse.h), fp32 weights
-int btc_conv_fwd_stats(int operands, const void* src, const float* W, const float* bias, const int32_t* nbr, const int32_t* order, int n_rows, int K,
-                       int Cin, int Cout, void* dst, const struct BnFuse& bn, hipStream_t stream, int* fused);
+int btc_conv_fwd_stats(int operands, const void* src, long long src_rows, const float* W, const float* bias, const int32_t* nbr, const int32_t* order,
+                       int n_rows, int K, int Cin, int Cout, void* dst, const struct BnFuse& bn, hipStream_t stream, int* fused);
 
 // conv_apply_bf16.hip: bf16 operands on the bf16 matrix pipe; Wq[k][Cres][Cred] bf16
 int btc_apply_bf16w(const void* src, const void* Wq, const float* bias, const int32_t* nbr, const int32_t* order, int n_rows, int K, int Cred,

@@ -31,7 +31,7 @@ namespace {
 // gathered activation rows travel through a raw buffer descriptor over the feature tensor: a lane whose offset lies past num_records
 // reads nothing and WRITES ZEROS to its 16 bytes of LDS (tools/lds_dma_oob.hip checks exactly that on the device) -- the lanes of an
 // absent neighbour (submanifold levels: 17 of 27 on average) cost no L2 -> LDS traffic at all, where they used to fetch a zero row.
-// Offsets are 32-bit: a source tensor of 4 GB or more traps (conv_apply_g takes any size).
+// Offsets are 32-bit: the host entry points refuse a source tensor of 4 GB or more (btc_conv_apply_src; conv_apply_g takes any size).
 #define BTC_RSRC_RECORDS 0xFFFFFF00u
 #define BTC_RSRC_ABSENT 0xFFFFFFF0u
 __device__ __forceinline__ void blds16s(__amdgpu_buffer_rsrc_t rsrc, unsigned voffset, void* l) {
@@ -97,7 +97,6 @@ __global__ __launch_bounds__(64 * (WR * WC + LW)) void conv_apply_s(const float*
   const int n0 = blockIdx.y * TN;
   const size_t plane = (size_t)K * Cred * Cres;   // elements between two planes of Ws
 
-  const int nb_max = (int)(BTC_RSRC_RECORDS / ((unsigned)Cred * 4u)) - 1;   // rows the 32-bit offsets of the gathers reach
   for (int e = tid; e < K; e += THREADS) s_kact[e] = 0;
   for (int e = tid; e < TM; e += THREADS) s_row[e] = (row0 + e < n_rows) ? (order ? order[row0 + e] : row0 + e) : -1;
   __syncthreads();
@@ -105,7 +104,6 @@ __global__ __launch_bounds__(64 * (WR * WC + LW)) void conv_apply_s(const float*
     const int rloc = e / K, kk = e - rloc * K;
     const int gr = s_row[rloc];
     const int v = gr >= 0 ? nbr[(long long)gr * K + (mirror ? K - 1 - kk : kk)] : -1;
-    if (v > nb_max) __builtin_trap();   // a source tensor past the 32-bit offsets of the gathers (4 GB)
     s_nbr[e] = v;
     if (v >= 0) s_kact[kk] = 1;
   }

@@ -227,6 +227,99 @@ __global__ __launch_bounds__(RB_T) void rb_mark(const int4* __restrict__ idx, in
   }
 }
 
+// rb_mark for a level that was BUILT here (a ranked-bitmap level): walk the input level's BITMAP instead of its row list -- a set bit is
+// a row, its coordinates follow from the cell index -- so marking level l + 1 needs neither level l's rows (rb_emit) nor its ranks
+// (rb_scan): a chain's levels are marked back to back and then scanned and emitted by ONE launch each (rb_scan_all, rb_emit_all): n + 2
+// dependent launches in front of the chain's read-back instead of 3 n (round 5; the detection branch 18 -> 8).  A workgroup takes
+// MARKB_WORDS consecutive words of the input bitmap (4 threads a word); spans without a set bit leave at once.  Same LDS window as
+// rb_mark when the span lies in one (batch, z) plane -- cells of a span are neighbours in space and reach the same few output words.
+constexpr int MARKB_WORDS = 64;
+
+__global__ __launch_bounds__(RB_T) void rb_mark_b(Level in, long long in_ncell, BtcGeom g, Level out) {
+  __shared__ unsigned s_win[3][MARK_WIN];
+  __shared__ long long s_w0[3];
+  __shared__ int s_cnt[3];
+  __shared__ int s_stage;
+  const int tid = threadIdx.x;
+  const long long w = (long long)blockIdx.x * MARKB_WORDS + (tid >> 2);
+  unsigned bits = w < in.nblk * RB_BLK ? in.words[w] : 0u;
+  bits &= 0xFFu << ((tid & 3) * 8);
+  if (!__syncthreads_or(bits != 0u)) return;
+  const int hw = in.shape[1] * in.shape[2];
+  if (tid == 0) {
+    int stage = 0;
+    const long long c0 = (long long)blockIdx.x * MARKB_WORDS * 32;
+    long long c1 = c0 + MARKB_WORDS * 32 - 1;
+    if (c1 >= in_ncell) c1 = in_ncell - 1;
+    const int b0 = (int)(c0 / in.vol), b1 = (int)(c1 / in.vol);
+    const int r0 = (int)(c0 - (long long)b0 * in.vol), r1 = (int)(c1 - (long long)b1 * in.vol);
+    const int z0 = r0 / hw, z1 = r1 / hw;
+    if (g.k[0] <= 3 && b0 == b1 && z0 == z1) {
+      const int y0 = (r0 - z0 * hw) / in.shape[2], y1 = (r1 - z1 * hw) / in.shape[2];
+      int ylo, yhi;
+      if (g.mode == BTC_MODE_CONV) {
+        const int t0 = y0 + g.p[1] - (g.k[1] - 1) * g.d[1];
+        ylo = t0 <= 0 ? 0 : t0 / g.s[1];
+        yhi = (y1 + g.p[1]) / g.s[1];
+      } else {
+        ylo = y0 * g.s[1] - g.p[1];
+        yhi = y1 * g.s[1] - g.p[1] + (g.k[1] - 1) * g.d[1];
+      }
+      ylo = ylo < 0 ? 0 : ylo;
+      yhi = yhi >= g.out_shape[1] ? g.out_shape[1] - 1 : yhi;
+      stage = 1;
+      for (int kz = 0; kz < 3; ++kz) {
+        int oz;
+        s_cnt[kz] = 0;
+        s_w0[kz] = 0;
+        if (kz >= g.k[0] || ylo > yhi || !fwd_axis(g, 0, z0, kz, &oz)) continue;
+        const long long w_lo = lvl_cell(out, b0, oz, ylo, 0) >> 5, w_hi = lvl_cell(out, b0, oz, yhi, out.shape[2] - 1) >> 5;
+        if (w_hi - w_lo + 1 > MARK_WIN) { stage = 0; break; }
+        s_w0[kz] = w_lo;
+        s_cnt[kz] = (int)(w_hi - w_lo + 1);
+      }
+    }
+    s_stage = stage;
+  }
+  for (int e = tid; e < 3 * MARK_WIN; e += RB_T) (&s_win[0][0])[e] = 0u;
+  __syncthreads();
+  const bool staged = s_stage != 0;
+  while (bits) {
+    const int bit = __ffs(bits) - 1;
+    bits &= bits - 1;
+    const long long cell = w * 32 + bit;
+    const int bb = (int)(cell / in.vol);
+    const int rem = (int)(cell - (long long)bb * in.vol);
+    const int z = rem / hw;
+    const int r2 = rem - z * hw;
+    const int y = r2 / in.shape[2], x = r2 - y * in.shape[2];
+    for (int kz = 0; kz < g.k[0]; ++kz)
+      for (int ky = 0; ky < g.k[1]; ++ky) {
+        if (!staged) {
+          mark_line(g, out, bb, z, y, x, kz, ky);
+          continue;
+        }
+        int oz, oy;
+        if (!fwd_axis(g, 0, z, kz, &oz) || !fwd_axis(g, 1, y, ky, &oy)) continue;
+        const long long line = lvl_cell(out, bb, oz, oy, 0);
+        for (int kx = 0; kx < g.k[2]; ++kx) {
+          int ox;
+          if (!fwd_axis(g, 2, x, kx, &ox)) continue;
+          const long long oc = line + ox;
+          atomicOr(&s_win[kz][(int)((oc >> 5) - s_w0[kz])], 1u << ((unsigned)oc & 31u));
+        }
+      }
+  }
+  if (!staged) return;   // (block-uniform)
+  __syncthreads();
+  for (int e = tid; e < 3 * MARK_WIN; e += RB_T) {
+    const int pz = e / MARK_WIN, j = e - pz * MARK_WIN;
+    if (j >= s_cnt[pz]) continue;
+    const unsigned wb = s_win[pz][j];
+    if (wb) or_word(out.words, s_w0[pz] + j, wb);
+  }
+}
+
 __device__ __forceinline__ int rb_wave_incl_scan(int v) {
   const int lane = threadIdx.x & 63;
 #pragma unroll
@@ -239,11 +332,11 @@ __device__ __forceinline__ int rb_wave_incl_scan(int v) {
 
 // one thread per 32-byte block: chunk-relative block prefixes; the LAST workgroup to arrive turns the chunk sums into
 // chunk prefixes and publishes the level's row count (device, and a pinned host word when given)
-__global__ __launch_bounds__(RB_T) void rb_scan(Level L, int32_t* __restrict__ chunk_sums, int32_t* __restrict__ counter, int nchunks,
-                                                int32_t* __restrict__ d_total) {
+__device__ __forceinline__ void scan_chunk(const Level& L, int32_t* __restrict__ chunk_sums, int32_t* __restrict__ counter, int nchunks,
+                                           int32_t* __restrict__ d_total, int chunk) {
   __shared__ int s_wave[RB_T / 64 + 1];
   __shared__ int s_last;
-  const long long blk = (long long)blockIdx.x * RB_CHUNK + threadIdx.x;
+  const long long blk = (long long)chunk * RB_CHUNK + threadIdx.x;
   int cnt = 0;
   if (blk < L.nblk) {
     const uint4* p = reinterpret_cast<const uint4*>(L.words + blk * RB_BLK);
@@ -262,7 +355,7 @@ __global__ __launch_bounds__(RB_T) void rb_scan(Level L, int32_t* __restrict__ c
   }
   if (blk < L.nblk) L.bprefix[blk] = base + incl - cnt;
   if (threadIdx.x == 0) {
-    chunk_sums[blockIdx.x] = tot;
+    chunk_sums[chunk] = tot;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     const int t = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     s_last = (t == nchunks - 1);
@@ -293,6 +386,36 @@ __global__ __launch_bounds__(RB_T) void rb_scan(Level L, int32_t* __restrict__ c
     *d_total = carry;
     __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+}
+
+__global__ __launch_bounds__(RB_T) void rb_scan(Level L, int32_t* __restrict__ chunk_sums, int32_t* __restrict__ counter, int nchunks,
+                                                int32_t* __restrict__ d_total) {
+  scan_chunk(L, chunk_sums, counter, nchunks, d_total, (int)blockIdx.x);
+}
+
+// every level of a chain in one launch: workgroup b works on level j with block0[j] <= b < block0[j + 1] (scan: one chunk, its level's
+// own last-arriver; emit: 256 words)
+struct LevelSet {
+  Level lv[BTC_CHAIN_MAX_LAYERS];
+  int32_t* chunk_sums[BTC_CHAIN_MAX_LAYERS];
+  int32_t* counter[BTC_CHAIN_MAX_LAYERS];
+  int32_t* d_total[BTC_CHAIN_MAX_LAYERS];
+  int4* out_idx[BTC_CHAIN_MAX_LAYERS];
+  long long cap[BTC_CHAIN_MAX_LAYERS];
+  int nchunks[BTC_CHAIN_MAX_LAYERS];
+  int block0[BTC_CHAIN_MAX_LAYERS + 1];
+  int n;
+};
+
+__device__ __forceinline__ int level_of_block(const LevelSet& S) {
+  int j = 0;
+  while (j + 1 < S.n && (int)blockIdx.x >= S.block0[j + 1]) ++j;
+  return j;
+}
+
+__global__ __launch_bounds__(RB_T) void rb_scan_all(const LevelSet S) {
+  const int j = level_of_block(S);
+  scan_chunk(S.lv[j], S.chunk_sums[j], S.counter[j], S.nchunks[j], S.d_total[j], (int)blockIdx.x - S.block0[j]);
 }
 
 // rows of a scanned level in ascending cell order: one thread per bitmap word (its rank base = chunk prefix + block prefix +
@@ -327,6 +450,13 @@ __global__ __launch_bounds__(RB_T) void rb_emit(Level L, int4* __restrict__ out_
   const long long w = (long long)blockIdx.x * RB_T + threadIdx.x;
   if (w >= L.nblk * RB_BLK) return;
   emit_word(L, w, out_idx, cap);
+}
+
+__global__ __launch_bounds__(RB_T) void rb_emit_all(const LevelSet S) {
+  const int j = level_of_block(S);
+  const long long w = (long long)((int)blockIdx.x - S.block0[j]) * RB_T + threadIdx.x;
+  if (w >= S.lv[j].nblk * RB_BLK) return;
+  emit_word(S.lv[j], w, S.out_idx[j], S.cap[j]);
 }
 
 // ---- 64-bit-key hash of an arbitrary (unsorted) input level: key = cell + 1, 0 = empty (one memset clears bitmaps and hash)
@@ -920,15 +1050,11 @@ extern "C" int btc_chain_levels(const int32_t* indices, int n0, int batch, const
     rb_hash_insert<<<btc_cdiv(n0, RB_T), RB_T, 0, stream>>>((const int4*)indices, n0, L0, W.hash_cap - 1, W.keys, W.vals);
     BTC_LAUNCH_CHECK();
   }
-  bool emitted[BTC_CHAIN_MAX_LAYERS + 1] = {false};
-  emitted[0] = true;
-  auto emit = [&](int lv) -> int {
-    const int prod = P.producer[lv];
-    rb_emit<<<btc_cdiv(W.lo[lv].nblk * RB_BLK, RB_T), RB_T, 0, stream>>>(W.lv[lv], (int4*)out_indices[prod], (long long)h_cap[prod]);
-    BTC_LAUNCH_CHECK();
-    emitted[lv] = true;
-    return BTC_OK;
-  };
+  // mark every level (level 0's rows drive the first; every later level is marked from its input level's bitmap), then ONE scan launch
+  // and ONE emit launch for all of them
+  LevelSet S;
+  S.n = 0;
+  long long scan_blocks = 0;
   for (int i = 0; i < n_layers; ++i) {
     if (layers[i].kind != 1) continue;
     const int li = P.lvl_in[i], lo = P.lvl_out[i];
@@ -939,22 +1065,36 @@ extern "C" int btc_chain_levels(const int32_t* indices, int n0, int batch, const
         BTC_LAUNCH_CHECK();
       }
     } else {
-      if (!emitted[li]) {
-        rc = emit(li);
-        if (rc) return rc;
-      }
-      const int prod = P.producer[li];   // row-parallel over the producing level's rows; their count stays on the device
-      rb_mark<<<mark_grid(h_cap[prod]), RB_T, 0, stream>>>((const int4*)out_indices[prod], 0, d_counts + prod, g, W.lv[lo], 1);
+      const long long nw = W.lo[li].nblk * RB_BLK;
+      rb_mark_b<<<btc_cdiv(nw, MARKB_WORDS), RB_T, 0, stream>>>(W.lv[li], W.lo[li].ncell, g, W.lv[lo]);
       BTC_LAUNCH_CHECK();
     }
-    rb_scan<<<W.lo[lo].nchunks, RB_T, 0, stream>>>(W.lv[lo], W.chunk_sums[lo], W.counters + lo, W.lo[lo].nchunks, d_counts + i);
-    BTC_LAUNCH_CHECK();
+    BTC_CHECK_ARG(S.n < BTC_CHAIN_MAX_LAYERS, "btc_chain_levels: too many levels");
+    S.lv[S.n] = W.lv[lo];
+    S.chunk_sums[S.n] = W.chunk_sums[lo];
+    S.counter[S.n] = W.counters + lo;
+    S.d_total[S.n] = d_counts + i;
+    S.out_idx[S.n] = (int4*)out_indices[i];
+    S.cap[S.n] = (long long)h_cap[i];
+    S.nchunks[S.n] = W.lo[lo].nchunks;
+    S.block0[S.n] = (int)scan_blocks;
+    scan_blocks += W.lo[lo].nchunks;
+    ++S.n;
   }
-  for (int lv = 1; lv < P.n_levels; ++lv)
-    if (!emitted[lv]) {
-      rc = emit(lv);
-      if (rc) return rc;
-    }
+  if (S.n == 0) return BTC_OK;
+  S.block0[S.n] = (int)scan_blocks;
+  BTC_CHECK_ARG(scan_blocks < (1LL << 31), "btc_chain_levels: grids too large");
+  rb_scan_all<<<(unsigned)scan_blocks, RB_T, 0, stream>>>(S);
+  BTC_LAUNCH_CHECK();
+  long long emit_blocks = 0;
+  for (int q = 0; q < S.n; ++q) {
+    S.block0[q] = (int)emit_blocks;
+    emit_blocks += btc_cdiv(S.lv[q].nblk * RB_BLK, RB_T);
+  }
+  S.block0[S.n] = (int)emit_blocks;
+  BTC_CHECK_ARG(emit_blocks < (1LL << 31), "btc_chain_levels: grids too large");
+  rb_emit_all<<<(unsigned)emit_blocks, RB_T, 0, stream>>>(S);
+  BTC_LAUNCH_CHECK();
   return BTC_OK;
 }
 

@@ -1277,8 +1277,24 @@ extern "C" int btc_conv_dgrad(const float* dout, const float* W, const int32_t* 
   return launch_apply<true>(dout, W, nullptr, nbr_in, n_in, K, /*Cred=*/Cout, /*Cres=*/Cin, din, (hipStream_t)stream);
 }
 
+// split operands: the kernel gathers through 32-bit byte offsets -- the HOST refuses a source it cannot reach (or whose size it was not
+// told), nothing traps on the device
+static int split_source_ok(const char* who, long long src_rows, int Cred) {
+  BTC_CHECK_ARG(src_rows >= 0, "%s: BTC_OPERANDS_F32_SPLIT needs the row count of src (btc_conv_apply_src / btc_conv_bn_relu_fwd_src)", who);
+  BTC_CHECK_ARG(src_rows * Cred * 4 < 0xFFFFFF00LL, "%s: a source of %lld rows x %d channels is past the 32-bit gather offsets of the split-operand "
+                "kernel (4 GB): use BTC_OPERANDS_F32", who, src_rows, Cred);
+  return BTC_OK;
+}
+
 extern "C" int btc_conv_apply_ordered(int pass, int operands, const void* src, const void* W, const float* bias, const int32_t* nbr,
                                       const int32_t* order, int n_rows, int K, int Cin, int Cout, void* dst, void* stream) {
+  // (a submanifold layer's source has as many rows as its result; any other source's size is the caller's to state)
+  return btc_conv_apply_src(pass, operands, src, pass == BTC_PASS_DGRAD_MIRROR ? (long long)n_rows : -1LL, W, bias, nbr, order, n_rows, K, Cin, Cout,
+                            dst, stream);
+}
+
+extern "C" int btc_conv_apply_src(int pass, int operands, const void* src, long long src_rows, const void* W, const float* bias, const int32_t* nbr,
+                                  const int32_t* order, int n_rows, int K, int Cin, int Cout, void* dst, void* stream) {
   BTC_CHECK_ARG((pass == BTC_PASS_FWD || pass == BTC_PASS_DGRAD || pass == BTC_PASS_DGRAD_MIRROR) && operands >= BTC_OPERANDS_F32 &&
                     operands <= BTC_OPERANDS_F32_SPLIT, "btc_conv_apply_ordered: pass=%d operands=%d", pass, operands);
   // BTC_PASS_DGRAD_MIRROR: dgrad of a submanifold layer through its FORWARD map -- nbr_in[j][k] == nbr_out[j][K-1-k] there, so the
@@ -1293,8 +1309,13 @@ extern "C" int btc_conv_apply_ordered(int pass, int operands, const void* src, c
                   K, Cin, Cout);
     return btc_apply_bf16w(src, W, bias, nbr, order, n_rows, K, Cred, Cres, dst, (hipStream_t)stream, mirror);
   }
-  if (operands == BTC_OPERANDS_F32_SPLIT)
+  if (operands == BTC_OPERANDS_F32_SPLIT) {
+    if (n_rows > 0) {
+      const int rc = split_source_ok("btc_conv_apply_src", src_rows, Cred);
+      if (rc) return rc;
+    }
     return btc_apply_split((const float*)src, W, bias, nbr, order, n_rows, K, Cred, Cres, (float*)dst, (hipStream_t)stream, mirror, nullptr);
+  }
   const bool bf = operands == BTC_OPERANDS_BF16_ACT;
   if (pass == BTC_PASS_FWD)
     return launch_apply<false>((const float*)src, (const float*)W, bias, nbr, n_rows, K, Cred, Cres, (float*)dst, (hipStream_t)stream, bf, order);
@@ -1303,8 +1324,8 @@ extern "C" int btc_conv_apply_ordered(int pass, int operands, const void* src, c
 
 // forward conv whose epilogue also gathers the batch statistics of its result (bn_fuse.h); operands F32 / BF16_ACT only.
 // -> BTC_OK, *fused = 1 when the statistics were taken (always, for these operand kinds and n_rows > 0)
-int btc_conv_fwd_stats(int operands, const void* src, const float* W, const float* bias, const int32_t* nbr, const int32_t* order, int n_rows, int K,
-                       int Cin, int Cout, void* dst, const BnFuse& bn, hipStream_t stream, int* fused) {
+int btc_conv_fwd_stats(int operands, const void* src, long long src_rows, const float* W, const float* bias, const int32_t* nbr, const int32_t* order,
+                       int n_rows, int K, int Cin, int Cout, void* dst, const BnFuse& bn, hipStream_t stream, int* fused) {
   *fused = 0;
   BTC_CHECK_ARG(K >= 1 && K <= 512 && Cin >= 1 && Cout >= 1 && n_rows >= 0, "btc_conv_fwd_stats: bad sizes");
   BTC_CHECK_ARG(operands == BTC_OPERANDS_F32 || operands == BTC_OPERANDS_BF16_ACT || operands == BTC_OPERANDS_F32_SPLIT,
@@ -1312,6 +1333,8 @@ int btc_conv_fwd_stats(int operands, const void* src, const float* W, const floa
   BTC_CHECK_ARG(Cout <= BN_FUSE_CMAX, "btc_conv_fwd_stats: more than %d channels", BN_FUSE_CMAX);
   if (n_rows <= 0) return BTC_OK;
   if (operands == BTC_OPERANDS_F32_SPLIT) {
+    const int rc = split_source_ok("btc_conv_bn_relu_fwd_src", src_rows, Cin);
+    if (rc) return rc;
     *fused = 1;
     return btc_apply_split((const float*)src, W, bias, nbr, order, n_rows, K, Cin, Cout, (float*)dst, stream, 0, &bn);
   }

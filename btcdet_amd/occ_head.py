@@ -329,6 +329,8 @@ class OccHead3D(OccHeadTemplate):
         out = ops.indice_conv(x.features, w, bias, rb)
         # -> the two dense maps (logits (B, nc, D, H, W), residuals) straight from the merged rows: one fill + one scatter launch
         # (ops.dense_split) where slicing, copying and densifying the two parts took six -- same values
+        if out.dtype != torch.float32:     # bf16 features: the 2 / 3-channel head computes in fp32 and rounds; the dense maps are fp32
+            out = out.float()
         return ops.dense_split(out, x.indices, x.batch_size, x.spatial_shape, cls.out_channels)
 
     def forward(self, data_dict):

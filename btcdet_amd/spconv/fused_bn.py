@@ -48,10 +48,10 @@ def conv_bn_forward(features, w, b, map_fwd, ord_fwd, gamma, beta, running_mean,
     from . import ops
     if ops._split_operands(features, K, cin, cout, n):   # split-operand kernel: W = the forward planes
         operands, w = 3, ops._weights_split(w, K, cin, cout)[1]
-    check(lib().btc_conv_bn_relu_fwd(operands, ptr(features), ptr(w), ptr(b), ptr(map_fwd), ptr(ord_fwd), n, K, cin, cout,
+    check(lib().btc_conv_bn_relu_fwd_src(operands, ptr(features), int(features.shape[0]), ptr(w), ptr(b), ptr(map_fwd), ptr(ord_fwd), n, K, cin, cout,
                                      ptr(x), ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), ptr(num_batches_tracked), float(momentum),
                                      float(eps), int(relu), ptr(y), ptr(stats[0]), ptr(stats[1]), ptr(ws), need, ptr(fuse_ws(features.device)),
-                                     stream_ptr()), "btc_conv_bn_relu_fwd")
+                                     stream_ptr()), "btc_conv_bn_relu_fwd_src")
     return x, y, stats
 
 

@@ -615,8 +615,8 @@ def _conv_forward(features, w, b, map_fwd, ord_fwd=None):
     if _split_operands(features, K, cin, cout, n_res):
         q = _weights_split(w, K, cin, cout)
         with _span("conv_apply", _conv_cost, (map_fwd, n_res, K, cin, cout, 4)):
-            check(lib().btc_conv_apply_ordered(0, 3, ptr(features), ptr(q[1]), ptr(b), ptr(map_fwd), ptr(ord_fwd), n_res, K, cin, cout, ptr(out),
-                                               stream_ptr()), "btc_conv_apply_ordered")
+            check(lib().btc_conv_apply_src(0, 3, ptr(features), int(features.shape[0]), ptr(q[1]), ptr(b), ptr(map_fwd), ptr(ord_fwd), n_res, K, cin, cout,
+                                           ptr(out), stream_ptr()), "btc_conv_apply_src")
         return out
     with _span("conv_apply", _conv_cost, (map_fwd, n_res, K, cin, cout, 2 if bf else 4)):
         check(lib().btc_conv_apply_ordered(0, 1 if bf else 0, ptr(features), ptr(w), ptr(b), ptr(map_fwd), ptr(ord_fwd), n_res, K, cin, cout,
@@ -669,8 +669,8 @@ def _conv_backward(features, w, map_fwd, map_bwd, grad_out, wshape, need_din, ne
                                                stream_ptr()), "btc_conv_apply_ordered")
             elif _split_operands(grad_out, K, cout, cin, n_src):
                 q = _weights_split(w, K, cin, cout)
-                check(L.btc_conv_apply_ordered(pass_dgrad, 3, ptr(grad_out), ptr(q[0]), None, ptr(map_bwd), ptr(ord_bwd), n_src, K, cin, cout, ptr(din),
-                                               stream_ptr()), "btc_conv_apply_ordered")
+                check(L.btc_conv_apply_src(pass_dgrad, 3, ptr(grad_out), int(grad_out.shape[0]), ptr(q[0]), None, ptr(map_bwd), ptr(ord_bwd), n_src, K, cin,
+                                           cout, ptr(din), stream_ptr()), "btc_conv_apply_src")
             else:
                 check(L.btc_conv_apply_ordered(pass_dgrad, 1 if bf else 0, ptr(grad_out), ptr(w), None, ptr(map_bwd), ptr(ord_bwd), n_src, K, cin, cout,
                                                ptr(din), stream_ptr()), "btc_conv_apply_ordered")

@@ -306,6 +306,11 @@ int btc_row_orders_keyed(const int32_t* const* nbrs, const int32_t* const* first
                          int32_t* order, void* stream);
 int btc_conv_apply_ordered(int pass, int operands, const void* src, const void* W, const float* bias, const int32_t* nbr,
                            const int32_t* order, int n_rows, int K, int Cin, int Cout, void* dst, void* stream);
+/* the same with the row count of `src` stated.  BTC_OPERANDS_F32_SPLIT gathers through 32-bit byte offsets: its launches NEED src_rows
+ * (>= 0) and are refused with BTC_EINVAL -- on the host, nothing traps on the device -- for a source of 4 GB or more (take
+ * BTC_OPERANDS_F32 then).  btc_conv_apply_ordered knows the count only for BTC_PASS_DGRAD_MIRROR (a submanifold layer: n_rows). */
+int btc_conv_apply_src(int pass, int operands, const void* src, long long src_rows, const void* W, const float* bias, const int32_t* nbr,
+                       const int32_t* order, int n_rows, int K, int Cin, int Cout, void* dst, void* stream);
 int btc_conv_wgrad_ordered(int bf16_act, const void* feat, const void* dout, const int32_t* nbr_out, int n_out,
                            const int32_t* nbr_in, int n_in, const int32_t* order_out, const int32_t* order_in, int K, int Cin,
                            int Cout, float* dW, void* ws, size_t ws_bytes, void* stream);
@@ -492,6 +497,11 @@ int btc_bn_relu_bwd_bf16(const void* x, const void* y, const void* dy, int N, in
  * statistics come from the separate pass of btc_bn_relu_fwd (ws / ws_bytes as there).  n_rows >= 1. */
 size_t btc_bn_fuse_ws_bytes(void);
 int btc_conv_bn_relu_fwd(int operands, const void* src, const void* W, const float* bias, const int32_t* nbr, const int32_t* order,
+                         int n_rows, int K, int Cin, int Cout, void* x, const float* gamma, const float* beta, float* running_mean,
+                         float* running_var, long long* num_batches_tracked, float momentum, float eps, int relu, void* y,
+                         float* save_mean, float* save_rstd, void* ws, size_t ws_bytes, void* fuse_ws, void* stream);
+/* ... with the row count of `src` stated (required for BTC_OPERANDS_F32_SPLIT, see btc_conv_apply_src) */
+int btc_conv_bn_relu_fwd_src(int operands, const void* src, long long src_rows, const void* W, const float* bias, const int32_t* nbr, const int32_t* order,
                          int n_rows, int K, int Cin, int Cout, void* x, const float* gamma, const float* beta, float* running_mean,
                          float* running_var, long long* num_batches_tracked, float momentum, float eps, int relu, void* y,
                          float* save_mean, float* save_rstd, void* ws, size_t ws_bytes, void* fuse_ws, void* stream);

@@ -98,16 +98,25 @@ def test_split_kernel_row_order_and_mirror_do_not_change_bits():
     outs = []
     for o in (None, order):
         out = torch.empty((n, cout), device=dev())
-        check(L.btc_conv_apply_ordered(0, 3, ptr(feat), ptr(q[1]), None, ptr(rb.nbr_out), ptr(o), n, 27, cin, cout, ptr(out), stream_ptr()), "fwd")
+        check(L.btc_conv_apply_src(0, 3, ptr(feat), n, ptr(q[1]), None, ptr(rb.nbr_out), ptr(o), n, 27, cin, cout, ptr(out), stream_ptr()), "fwd")
         outs.append(out)
     assert torch.equal(outs[0], outs[1])
     nbr_in = rb.nbr_in.contiguous()           # materialised mirror image
     dins = []
     for pass_, m in ((1, nbr_in), (2, rb.nbr_out)):
         din = torch.empty((n, cin), device=dev())
-        check(L.btc_conv_apply_ordered(pass_, 3, ptr(outs[0]), ptr(q[0]), None, ptr(m), None, n, 27, cin, cout, ptr(din), stream_ptr()), "dgrad")
+        check(L.btc_conv_apply_src(pass_, 3, ptr(outs[0]), n, ptr(q[0]), None, ptr(m), None, n, 27, cin, cout, ptr(din), stream_ptr()), "dgrad")
         dins.append(din)
     assert torch.equal(dins[0], dins[1])
+    # the split kernel gathers through 32-bit byte offsets: a source whose size is unknown, or past 4 GB, is refused ON THE HOST with an
+    # error code and a message -- nothing is launched, nothing traps on the device (the boundary never kills the process)
+    out = torch.empty((n, cout), device=dev())
+    rc = L.btc_conv_apply_ordered(0, 3, ptr(feat), ptr(q[1]), None, ptr(rb.nbr_out), None, n, 27, cin, cout, ptr(out), stream_ptr())
+    assert rc != 0 and b"row count" in L.btc_last_error()
+    rc = L.btc_conv_apply_src(0, 3, ptr(feat), (1 << 32) // (4 * cin) + 1, ptr(q[1]), None, ptr(rb.nbr_out), None, n, 27, cin, cout, ptr(out), stream_ptr())
+    assert rc != 0 and b"4 GB" in L.btc_last_error()
+    check(L.btc_conv_apply_ordered(2, 3, ptr(outs[0]), ptr(q[0]), None, ptr(rb.nbr_out), None, n, 27, cin, cout, ptr(dins[0]), stream_ptr()), "mirror")   # a submanifold source: n rows, known
+    torch.cuda.synchronize()
 
 
 def test_split_planes_are_an_exact_decomposition():

@@ -99,10 +99,10 @@ for feats, w, b, mf, mb in cap:
                     ws_cache["planes"] = q
                 q = ws_cache["planes"]
                 if direction == "fwd":
-                    fn = lambda: check(L.btc_conv_apply_ordered(0, 3, ptr(feats), ptr(q[1]), ptr(b), ptr(mf), None, n_res, K, cin, cout, ptr(out), stream_ptr()), "fwd split")
+                    fn = lambda: check(L.btc_conv_apply_src(0, 3, ptr(feats), int(feats.shape[0]), ptr(q[1]), ptr(b), ptr(mf), None, n_res, K, cin, cout, ptr(out), stream_ptr()), "fwd split")
                     res = out
                 else:
-                    fn = lambda: check(L.btc_conv_apply_ordered(1, 3, ptr(dout), ptr(q[0]), None, ptr(mb), None, n_src, K, cin, cout, ptr(din), stream_ptr()), "dgrad split")
+                    fn = lambda: check(L.btc_conv_apply_src(1, 3, ptr(dout), int(dout.shape[0]), ptr(q[0]), None, ptr(mb), None, n_src, K, cin, cout, ptr(din), stream_ptr()), "dgrad split")
                     res = din
             elif direction == "fwd":
                 fn = lambda: check(L.btc_conv_fwd(ptr(feats), ptr(w), ptr(b), ptr(mf), n_res, K, cin, cout, ptr(out), stream_ptr()), "fwd")

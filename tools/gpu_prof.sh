@@ -8,7 +8,8 @@ cd /root/repo
 (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$tag -o bench -- python /root/repo/bench.py --no-cpu-baseline --no-roofline --no-extras > /root/repo/gpurun_out/$tag/bench_prof.json 2> /root/repo/gpurun_out/$tag/bench_prof.err)
 find /tmp/prof_$tag -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} gpurun_out/$tag/bench_kernel_stats.csv
 find /tmp/prof_$tag -name "*kernel_trace.csv" | head -1 | xargs -I{} python tools/stream_timeline.py {} > gpurun_out/$tag/bench_timeline.txt 2>&1
-(cd /tmp && BTC_SCHEDULE=in_order BTC_DEFER_WGRAD=0 BTC_OVERLAP_MIN_ROWS=2000000000 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_${tag}s -o bench -- python /root/repo/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-roofline --no-extras > /root/repo/gpurun_out/$tag/serial_prof.json 2> /root/repo/gpurun_out/$tag/serial_prof.err)
+# (in order, one host thread; the weight gradients keep the trainer's default: deferred to the side stream, their slab reductions batched)
+(cd /tmp && BTC_SCHEDULE=in_order timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_${tag}s -o bench -- python /root/repo/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-roofline --no-extras > /root/repo/gpurun_out/$tag/serial_prof.json 2> /root/repo/gpurun_out/$tag/serial_prof.err)
 find /tmp/prof_${tag}s -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} gpurun_out/$tag/serial_kernel_stats.csv
 find /tmp/prof_${tag}s -name "*kernel_trace.csv" | head -1 | xargs -I{} python tools/rb_trace.py {} 36 > gpurun_out/$tag/serial_rb_trace.txt 2>&1
 find /tmp/prof_${tag}s -name "*kernel_trace.csv" | head -1 | xargs -I{} python tools/step_trace.py {} conv > gpurun_out/$tag/serial_step_conv.txt 2>&1
