@@ -114,6 +114,7 @@ _SIGS = {
     "btc_conv_split_wanted": (ci, [ci, ci, ci, ci]),
     "btc_weights_split3": (ci, [vp, ci, ci, ci, vp, vp, vp]),
     "btc_weights_split3_multi": (ci, [vp, vp, vp, c_i32p, c_i32p, c_i32p, ci, vp]),
+    "btc_weights_to_bf16_multi": (ci, [vp, vp, vp, c_i32p, c_i32p, c_i32p, ci, vp]),
     "btc_conv_fwd_bf16w": (ci, [vp, vp, vp, vp, ci, ci, ci, ci, vp, vp]),
     "btc_conv_dgrad_bf16w": (ci, [vp, vp, vp, ci, ci, ci, ci, vp, vp]),
     "btc_row_orders": (ci, [vp, c_i32p, c_i32p, ci, vp, vp]),

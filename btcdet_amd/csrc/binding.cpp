@@ -110,32 +110,40 @@ Tensor weights_q(const Tensor& w, int64_t K, int64_t cin, int64_t cout, int64_t 
 
 Tensor weights_bf16(const Tensor& w, int64_t K, int64_t cin, int64_t cout, int64_t stream) { return weights_q(w, K, cin, cout, stream, 1); }
 
-// the split planes of MANY leaf weights in one launch (a parameter group's eligible layers right after its optimizer step, on the
-// stream its next forward runs on): every cache entry is brought to the weight's current version, later weights_q calls hit
-void split_weights(const std::vector<Tensor>& weights, int64_t stream) {
+// the operand copies of MANY leaf weights in one launch (a parameter group's eligible layers right after its optimizer step, on the
+// stream its next forward runs on): every cache entry is brought to the weight's current version, later weights_q calls hit.
+// planes = 3: the hi / mid / lo planes of the split-operand kernel (fp32 features); planes = 1: the bf16 copies (bf16 features)
+void refresh_weights(const std::vector<Tensor>& weights, int64_t stream, int planes) {
   const size_t n = weights.size();
   if (n == 0) return;
   std::vector<const float*> W(n);
   std::vector<void*> ws(n), wts(n);
   std::vector<int32_t> K(n), Cin(n), Cout(n);
   std::lock_guard<std::mutex> lock(g_wq_mu);
+  auto& tab = planes == 1 ? g_wq : g_ws;
   for (size_t i = 0; i < n; ++i) {
     const Tensor& w = weights[i];
-    need(w.is_leaf() && w.is_contiguous() && w.scalar_type() == at::kFloat && w.dim() >= 3, "split_weights: contiguous fp32 leaf weights [.., Cin, Cout] expected");
+    need(w.is_leaf() && w.is_contiguous() && w.scalar_type() == at::kFloat && w.dim() >= 3, "refresh_weights: contiguous fp32 leaf weights [.., Cin, Cout] expected");
     const int64_t cin = w.size(-2), cout = w.size(-1);
     const void* key = w.unsafeGetTensorImpl();
-    auto it = g_ws.find(key);
-    Tensor q = (it != g_ws.end() && !it->second.weak.expired() && it->second.q.numel() == 6 * w.numel() && it->second.q.get_device() == w.get_device())
-                   ? it->second.q : at::empty({2, 3 * w.numel()}, w.options().dtype(at::kBFloat16));
-    if (it != g_ws.end()) g_ws.erase(it);
-    g_ws.emplace(key, WqEntry(c10::weak_intrusive_ptr<c10::TensorImpl>(w.getIntrusivePtr()), (uint32_t)w._version(), q));
+    auto it = tab.find(key);
+    Tensor q = (it != tab.end() && !it->second.weak.expired() && it->second.q.numel() == 2 * planes * w.numel() && it->second.q.get_device() == w.get_device())
+                   ? it->second.q : at::empty({2, planes * w.numel()}, w.options().dtype(at::kBFloat16));
+    if (it != tab.end()) tab.erase(it);
+    tab.emplace(key, WqEntry(c10::weak_intrusive_ptr<c10::TensorImpl>(w.getIntrusivePtr()), (uint32_t)w._version(), q));
     W[i] = (const float*)w.data_ptr();
     ws[i] = q.data_ptr();
-    wts[i] = (char*)q.data_ptr() + 6 * w.numel();
+    wts[i] = (char*)q.data_ptr() + 2 * planes * w.numel();
     K[i] = (int32_t)(w.numel() / (cin * cout)); Cin[i] = (int32_t)cin; Cout[i] = (int32_t)cout;
   }
-  chk(btc_weights_split3_multi(W.data(), ws.data(), wts.data(), K.data(), Cin.data(), Cout.data(), (int)n, st(stream)), "btc_weights_split3_multi");
+  if (planes == 1)
+    chk(btc_weights_to_bf16_multi(W.data(), ws.data(), wts.data(), K.data(), Cin.data(), Cout.data(), (int)n, st(stream)), "btc_weights_to_bf16_multi");
+  else
+    chk(btc_weights_split3_multi(W.data(), ws.data(), wts.data(), K.data(), Cin.data(), Cout.data(), (int)n, st(stream)), "btc_weights_split3_multi");
 }
+
+void split_weights(const std::vector<Tensor>& weights, int64_t stream) { refresh_weights(weights, stream, 3); }
+void bf16_weights(const std::vector<Tensor>& weights, int64_t stream) { refresh_weights(weights, stream, 1); }
 
 // the stream's scratch buffer for z-split launches of the split-operand kernel (btc_set_scratch): 48 MB, allocated on first use
 // from the stream's own pool and kept for the life of the process
@@ -1059,6 +1067,7 @@ void pack_grads(const std::vector<Tensor>& grads, const Tensor& chunk_seg, const
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.doc() = "compiled PyTorch binding of libbtcdet_hip.so's hot entry points";
   m.def("split_weights", &split_weights, py::call_guard<py::gil_scoped_release>());
+  m.def("bf16_weights", &bf16_weights, py::call_guard<py::gil_scoped_release>());
   m.def("conv_fwd", &conv_fwd, py::call_guard<py::gil_scoped_release>());
   m.def("bn_fwd", &bn_fwd, py::call_guard<py::gil_scoped_release>());
   m.def("conv_bn_fwd", &conv_bn_fwd, py::call_guard<py::gil_scoped_release>());

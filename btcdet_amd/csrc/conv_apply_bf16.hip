@@ -255,7 +255,56 @@ __global__ __launch_bounds__(256) void weights_to_bf16(const float* __restrict__
   wt_b[(long long)k * per + (long long)co * Cin + ci] = h;
 }
 
+// the same for up to BF16_MULTI_MAX weights in ONE launch (a parameter group's layers right behind its optimizer step: ~20 launches of 5 us
+// per step become two) -- the table travels in the kernel arguments, a block finds its weight by its first-block entry
+constexpr int BF16_MULTI_MAX = 32;
+struct Bf16Table {
+  const float* W[BF16_MULTI_MAX];
+  unsigned short* w_b[BF16_MULTI_MAX];
+  unsigned short* wt_b[BF16_MULTI_MAX];
+  int K[BF16_MULTI_MAX], Cin[BF16_MULTI_MAX], Cout[BF16_MULTI_MAX], first_block[BF16_MULTI_MAX + 1];
+  int n;
+};
+
+__global__ __launch_bounds__(256) void weights_to_bf16_multi(const Bf16Table t) {
+  int s = 0;
+  while (s + 1 < t.n && (int)blockIdx.x >= t.first_block[s + 1]) ++s;
+  const long long e = (long long)((int)blockIdx.x - t.first_block[s]) * 256 + threadIdx.x;
+  const int Cin = t.Cin[s], Cout = t.Cout[s];
+  const long long per = (long long)Cin * Cout;
+  if (e >= (long long)t.K[s] * per) return;
+  const unsigned short h = btc_f32_to_bf16(t.W[s][e]);
+  t.w_b[s][e] = h;
+  const int k = (int)(e / per);
+  const int rem = (int)(e - (long long)k * per);
+  const int ci = rem / Cout, co = rem - ci * Cout;
+  t.wt_b[s][(long long)k * per + (long long)co * Cin + ci] = h;
+}
+
 }  // namespace
+
+extern "C" int btc_weights_to_bf16_multi(const float* const* W, void* const* w_bf16, void* const* wt_bf16, const int32_t* K, const int32_t* Cin,
+                                         const int32_t* Cout, int n, void* stream) {
+  BTC_CHECK_ARG(n >= 0, "btc_weights_to_bf16_multi: bad count");
+  for (int base = 0; base < n; base += BF16_MULTI_MAX) {
+    Bf16Table t;
+    t.n = n - base < BF16_MULTI_MAX ? n - base : BF16_MULTI_MAX;
+    int blocks = 0;
+    for (int i = 0; i < t.n; ++i) {
+      BTC_CHECK_ARG(K[base + i] >= 1 && Cin[base + i] >= 1 && Cout[base + i] >= 1, "btc_weights_to_bf16_multi: bad sizes");
+      t.W[i] = W[base + i];
+      t.w_b[i] = (unsigned short*)w_bf16[base + i];
+      t.wt_b[i] = (unsigned short*)wt_bf16[base + i];
+      t.K[i] = K[base + i]; t.Cin[i] = Cin[base + i]; t.Cout[i] = Cout[base + i];
+      t.first_block[i] = blocks;
+      blocks += (int)btc_cdiv((long long)K[base + i] * Cin[base + i] * Cout[base + i], 256);
+    }
+    t.first_block[t.n] = blocks;
+    if (blocks > 0) weights_to_bf16_multi<<<blocks, 256, 0, (hipStream_t)stream>>>(t);
+    BTC_LAUNCH_CHECK();
+  }
+  return BTC_OK;
+}
 
 int btc_apply_bf16w(const void* src, const void* Wq, const float* bias, const int32_t* nbr, const int32_t* order, int n_rows, int K, int Cred,
                     int Cres, void* dst, hipStream_t stream, int mirror) {

@@ -233,27 +233,42 @@ __global__ __launch_bounds__(RB_T) void rb_mark(const int4* __restrict__ idx, in
 // dependent launches in front of the chain's read-back instead of 3 n (round 5; the detection branch 18 -> 8).  A workgroup takes
 // MARKB_WORDS consecutive words of the input bitmap (4 threads a word); spans without a set bit leave at once.  Same LDS window as
 // rb_mark when the span lies in one (batch, z) plane -- cells of a span are neighbours in space and reach the same few output words.
-constexpr int MARKB_WORDS = 64;
-
-__global__ __launch_bounds__(RB_T) void rb_mark_b(Level in, long long in_ncell, BtcGeom g, Level out) {
+// lw = log2 of the span (words per workgroup), 3..8, chosen per level by the host (markb_span): large sparse levels take 256-word spans
+// (few workgroups, most of them not empty), small dense ones 8-word spans (enough workgroups to fill the chip -- a [3, 40, 53] x 2 level
+// is 398 words).  Two phases, because the set bits of a span are unevenly spread over its words (a BEV level near the sensor is dense,
+// the rest empty): the threads first push the span's active cells into an LDS list, then ALL threads share the (cell, kernel line)
+// items of that list as rb_mark shares its (row, line) items -- one thread walking the 27 offsets of all 8 bits of a dense word was the
+// critical path of the first version (15 us for a 69-workgroup launch).
+__global__ __launch_bounds__(RB_T) void rb_mark_b(Level in, long long in_ncell, BtcGeom g, Level out, int lw) {
   __shared__ unsigned s_win[3][MARK_WIN];
+  __shared__ unsigned short s_list[8192];       // active cells of the span: offset from the span's first cell
   __shared__ long long s_w0[3];
   __shared__ int s_cnt[3];
-  __shared__ int s_stage;
+  __shared__ int s_stage, s_n, s_b0, s_z0, s_rp0;
   const int tid = threadIdx.x;
-  const long long w = (long long)blockIdx.x * MARKB_WORDS + (tid >> 2);
+  const int tshift = 8 - lw;                    // log2 threads per word
+  const int span = 1 << lw;                     // words per workgroup
+  const int wl = tid >> tshift;                 // word of the span this thread looks at
+  const long long w = (long long)blockIdx.x * span + wl;
   unsigned bits = w < in.nblk * RB_BLK ? in.words[w] : 0u;
-  bits &= 0xFFu << ((tid & 3) * 8);
+  {
+    const int nb = 32 >> tshift;                // bits per thread
+    const unsigned m = nb >= 32 ? 0xFFFFFFFFu : ((1u << nb) - 1u);
+    bits &= m << ((tid & ((1 << tshift) - 1)) * nb);
+  }
   if (!__syncthreads_or(bits != 0u)) return;
   const int hw = in.shape[1] * in.shape[2];
+  const long long c0 = (long long)blockIdx.x * span * 32;
   if (tid == 0) {
     int stage = 0;
-    const long long c0 = (long long)blockIdx.x * MARKB_WORDS * 32;
-    long long c1 = c0 + MARKB_WORDS * 32 - 1;
+    long long c1 = c0 + (long long)span * 32 - 1;
     if (c1 >= in_ncell) c1 = in_ncell - 1;
     const int b0 = (int)(c0 / in.vol), b1 = (int)(c1 / in.vol);
     const int r0 = (int)(c0 - (long long)b0 * in.vol), r1 = (int)(c1 - (long long)b1 * in.vol);
     const int z0 = r0 / hw, z1 = r1 / hw;
+    s_cnt[0] = s_cnt[1] = s_cnt[2] = 0;
+    s_n = 0;
+    s_b0 = b0; s_z0 = z0; s_rp0 = r0 - z0 * hw;
     if (g.k[0] <= 3 && b0 == b1 && z0 == z1) {
       const int y0 = (r0 - z0 * hw) / in.shape[2], y1 = (r1 - z1 * hw) / in.shape[2];
       int ylo, yhi;
@@ -281,43 +296,57 @@ __global__ __launch_bounds__(RB_T) void rb_mark_b(Level in, long long in_ncell, 
     }
     s_stage = stage;
   }
-  for (int e = tid; e < 3 * MARK_WIN; e += RB_T) (&s_win[0][0])[e] = 0u;
   __syncthreads();
   const bool staged = s_stage != 0;
-  while (bits) {
+  if (staged)
+    for (int pz = 0; pz < 3; ++pz)
+      for (int j = tid; j < s_cnt[pz]; j += RB_T) s_win[pz][j] = 0u;
+  while (bits) {   // phase 1: the span's active cells
     const int bit = __ffs(bits) - 1;
     bits &= bits - 1;
-    const long long cell = w * 32 + bit;
-    const int bb = (int)(cell / in.vol);
-    const int rem = (int)(cell - (long long)bb * in.vol);
-    const int z = rem / hw;
-    const int r2 = rem - z * hw;
-    const int y = r2 / in.shape[2], x = r2 - y * in.shape[2];
-    for (int kz = 0; kz < g.k[0]; ++kz)
-      for (int ky = 0; ky < g.k[1]; ++ky) {
-        if (!staged) {
-          mark_line(g, out, bb, z, y, x, kz, ky);
-          continue;
-        }
-        int oz, oy;
-        if (!fwd_axis(g, 0, z, kz, &oz) || !fwd_axis(g, 1, y, ky, &oy)) continue;
-        const long long line = lvl_cell(out, bb, oz, oy, 0);
-        for (int kx = 0; kx < g.k[2]; ++kx) {
-          int ox;
-          if (!fwd_axis(g, 2, x, kx, &ox)) continue;
-          const long long oc = line + ox;
-          atomicOr(&s_win[kz][(int)((oc >> 5) - s_w0[kz])], 1u << ((unsigned)oc & 31u));
-        }
-      }
+    s_list[atomicAdd(&s_n, 1)] = (unsigned short)(wl * 32 + bit);
+  }
+  __syncthreads();
+  const int n = s_n, lines = g.k[0] * g.k[1];
+  const int b0 = s_b0, z0 = s_z0, rp0 = s_rp0;
+  for (int e = tid; e < n * lines; e += RB_T) {   // phase 2: (cell, kernel line) items over all threads
+    const int ci = e / lines, l = e - ci * lines;
+    const int kz = l / g.k[1], ky = l - kz * g.k[1];
+    const int off = s_list[ci];
+    int bb, z, y, x;
+    if (staged) {   // one (batch, z) plane: the cell's row and column follow from its offset in the plane
+      const int rp = rp0 + off;
+      bb = b0; z = z0;
+      y = rp / in.shape[2];
+      x = rp - y * in.shape[2];
+    } else {
+      const long long cell = c0 + off;
+      bb = (int)(cell / in.vol);
+      const int rem = (int)(cell - (long long)bb * in.vol);
+      z = rem / hw;
+      const int r2 = rem - z * hw;
+      y = r2 / in.shape[2];
+      x = r2 - y * in.shape[2];
+      mark_line(g, out, bb, z, y, x, kz, ky);
+      continue;
+    }
+    int oz, oy;
+    if (!fwd_axis(g, 0, z, kz, &oz) || !fwd_axis(g, 1, y, ky, &oy)) continue;
+    const long long line = lvl_cell(out, bb, oz, oy, 0);
+    for (int kx = 0; kx < g.k[2]; ++kx) {
+      int ox;
+      if (!fwd_axis(g, 2, x, kx, &ox)) continue;
+      const long long oc = line + ox;
+      atomicOr(&s_win[kz][(int)((oc >> 5) - s_w0[kz])], 1u << ((unsigned)oc & 31u));
+    }
   }
   if (!staged) return;   // (block-uniform)
   __syncthreads();
-  for (int e = tid; e < 3 * MARK_WIN; e += RB_T) {
-    const int pz = e / MARK_WIN, j = e - pz * MARK_WIN;
-    if (j >= s_cnt[pz]) continue;
-    const unsigned wb = s_win[pz][j];
-    if (wb) or_word(out.words, s_w0[pz] + j, wb);
-  }
+  for (int pz = 0; pz < 3; ++pz)
+    for (int j = tid; j < s_cnt[pz]; j += RB_T) {
+      const unsigned wb = s_win[pz][j];
+      if (wb) or_word(out.words, s_w0[pz] + j, wb);
+    }
 }
 
 __device__ __forceinline__ int rb_wave_incl_scan(int v) {
@@ -762,6 +791,12 @@ Level make_level(const LevelLayout& lo, const int32_t* shape, unsigned* words, i
   return L;
 }
 
+int markb_span(long long nw) {   // log2 words per workgroup of rb_mark_b: about 2 K workgroups, 8..256 words each
+  int lw = 3;
+  while (lw < 8 && (nw >> lw) > 2048) ++lw;
+  return lw;
+}
+
 int mark_grid(long long n_rows) {   // one workgroup per MARK_ROWS rows of the host-side bound, at most 4096 (they stride over the real tiles)
   long long g = (n_rows + MARK_ROWS - 1) / MARK_ROWS;
   return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
@@ -1066,7 +1101,8 @@ extern "C" int btc_chain_levels(const int32_t* indices, int n0, int batch, const
       }
     } else {
       const long long nw = W.lo[li].nblk * RB_BLK;
-      rb_mark_b<<<btc_cdiv(nw, MARKB_WORDS), RB_T, 0, stream>>>(W.lv[li], W.lo[li].ncell, g, W.lv[lo]);
+      const int lw = markb_span(nw);
+      rb_mark_b<<<btc_cdiv(nw, 1LL << lw), RB_T, 0, stream>>>(W.lv[li], W.lo[li].ncell, g, W.lv[lo], lw);
       BTC_LAUNCH_CHECK();
     }
     BTC_CHECK_ARG(S.n < BTC_CHAIN_MAX_LAYERS, "btc_chain_levels: too many levels");

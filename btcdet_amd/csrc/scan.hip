@@ -163,6 +163,41 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_final(const int32_t* __rest
   }
 }
 
+// scan_block_sums + scan_final in one launch (round 5: the step is bound by its launch count): every block adds up the block sums in front
+// of it itself -- at most SCAN_FUSE_BLOCKS values, read from L2 -- instead of waiting for a one-workgroup launch that scans them
+constexpr int SCAN_FUSE_BLOCKS = 4096;
+
+__global__ __launch_bounds__(SCAN_THREADS) void scan_final_fused(const int32_t* __restrict__ in, int32_t* __restrict__ out, long long n,
+                                                                 const int32_t* __restrict__ block_sums, int32_t* __restrict__ total) {
+  __shared__ int s_wave[SCAN_THREADS / 64 + 1];
+  __shared__ int s_off[SCAN_THREADS / 64];
+  int part = 0;
+  for (int j = threadIdx.x; j < (int)blockIdx.x; j += SCAN_THREADS) part += block_sums[j];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) part += __shfl_down(part, o, 64);
+  if ((threadIdx.x & 63) == 0) s_off[threadIdx.x >> 6] = part;
+  __syncthreads();
+  int offset = 0;
+#pragma unroll
+  for (int w = 0; w < SCAN_THREADS / 64; ++w) offset += s_off[w];
+  long long base = (long long)blockIdx.x * SCAN_TILE + (long long)threadIdx.x * SCAN_ITEMS;
+  int v[SCAN_ITEMS];
+  int sum = 0;
+#pragma unroll
+  for (int j = 0; j < SCAN_ITEMS; ++j) {
+    v[j] = (base + j < n) ? in[base + j] : 0;
+    sum += v[j];
+  }
+  int tot;
+  int ex = block_excl_scan<SCAN_THREADS>(sum, s_wave, &tot) + offset;
+#pragma unroll
+  for (int j = 0; j < SCAN_ITEMS; ++j) {
+    if (base + j < n) out[base + j] = ex;
+    ex += v[j];
+  }
+  if (total && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *total = offset + tot;
+}
+
 // ---- byte map -> ranked bitmap (rulebook of strided / transposed convs and pools) ------------------------------
 // The reachable output cells are marked with plain byte stores (many writers, one value: no atomics -- device-scope
 // atomicOr on a shared bitmap word runs at the memory side on this multi-XCD part and measured 40-80 us per rulebook).
@@ -235,6 +270,11 @@ int btc_scan_exclusive_i32(const int32_t* in, int32_t* out, long long n, int32_t
   int32_t* block_sums = (int32_t*)ws;
   scan_block_reduce<<<nblocks, SCAN_THREADS, 0, stream>>>(in, n, block_sums);
   BTC_LAUNCH_CHECK();
+  if (nblocks <= SCAN_FUSE_BLOCKS) {   // (in may alias out: a block reads its own tile before it writes it, and block_sums is a separate buffer)
+    scan_final_fused<<<nblocks, SCAN_THREADS, 0, stream>>>(in, out, n, block_sums, total);
+    BTC_LAUNCH_CHECK();
+    return BTC_OK;
+  }
   scan_block_sums<<<1, 1024, 0, stream>>>(block_sums, nblocks, total);
   BTC_LAUNCH_CHECK();
   scan_final<<<nblocks, SCAN_THREADS, 0, stream>>>(in, out, n, block_sums);

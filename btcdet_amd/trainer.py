@@ -125,12 +125,12 @@ def make_step(model, ddp, proc, opts, grad_sync=None, prefetch_stream=None, thre
 
     def refresh_planes(group):
         if "lists" not in _split:
-            _split["lists"] = split_weight_lists(model) if hasattr(model, "occ_modules") else ((), ())
-        ws = _split["lists"][group]
+            _split["lists"] = split_weight_lists(model) if hasattr(model, "occ_modules") else ((None, ()), (None, ()))
+        kind, ws = _split["lists"][group]
         if ws:
             from .spconv import ops as _o
             from ._lib import stream_ptr
-            _o.fast().split_weights(ws, stream_ptr())
+            (_o.fast().bf16_weights if kind == "bf16" else _o.fast().split_weights)(ws, stream_ptr())
 
     def prep(next_batch):
         torch.cuda.set_device(device)
@@ -354,18 +354,30 @@ def make_step(model, ddp, proc, opts, grad_sync=None, prefetch_stream=None, thre
 
 
 def split_weight_lists(model):
-    """per parameter group (occupancy, detection): the sparse-conv weights the split-operand kernel can take (both channel counts
-    multiples of 32, fp32, on the GPU) -- their bf16 planes are refreshed by ONE launch right after the group's optimizer step
-    (binding.cpp split_weights) instead of one launch per layer at the layer's next forward; () when that kernel is switched off"""
+    """per parameter group (occupancy, detection): ("split" | "bf16", the sparse-conv weights whose operand copies the apply kernels read)
+    -- fp32 features: the three bf16 planes of the split-operand kernel (both channel counts multiples of 32); bf16 features
+    (FEATURE_DTYPE: bf16): the bf16 copies of the bf16-operand kernel (one side a multiple of 32, the other of 16).  They are refreshed by
+    ONE launch right after the group's optimizer step (binding.cpp split_weights / bf16_weights) instead of one launch per layer at the
+    layer's next forward -- ~20 launches per step for a bf16 model.  (None, ()) when the kernels are switched off."""
     from . import _lib
     from .spconv import ops
     from .spconv.conv import SparseConvolution
     F = ops.fast()
-    if F is None or not hasattr(F, "split_weights") or _lib.lib().btc_tune_value(14) == 1:
-        return (), ()
+    L = _lib.lib()
+
     def pick(root):
-        return [m.weight for m in root.modules() if isinstance(m, SparseConvolution) and m.in_channels % 32 == 0 and m.out_channels % 32 == 0
-                and m.weight.is_cuda and m.weight.dtype == torch.float32 and m.weight.requires_grad]
+        if F is None or not hasattr(F, "split_weights"):
+            return None, ()
+        convs = [m for m in root.modules() if isinstance(m, SparseConvolution) and m.weight.is_cuda and m.weight.dtype == torch.float32 and m.weight.requires_grad]
+        bb = getattr(root, "backbone_3d", None)
+        if getattr(bb, "feature_dtype", None) == torch.bfloat16:
+            if L.btc_tune_value(8) == 1 or not hasattr(F, "bf16_weights"):      # BTC_TUNE_BF16_OPERANDS = 1: fp32 weights under bf16 activations
+                return None, ()
+            ok = lambda m: (m.in_channels % 32 == 0 and m.out_channels % 16 == 0) or (m.out_channels % 32 == 0 and m.in_channels % 16 == 0)
+            return "bf16", [m.weight for m in convs if ok(m)]
+        if L.btc_tune_value(14) == 1:                                               # BTC_TUNE_SPLIT = 1: the exact kernels everywhere
+            return None, ()
+        return "split", [m.weight for m in convs if m.in_channels % 32 == 0 and m.out_channels % 32 == 0]
     return pick(model.occ_modules), pick(model.det_modules)
 
 

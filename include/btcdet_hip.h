@@ -244,6 +244,9 @@ int btc_conv_wgrad_bf16(const void* feat, const void* dout, const int32_t* nbr_o
  * Tolerance vs the fp32 path: see csrc/conv_apply_bf16.hip and tests/test_hip_bf16_mfma.py. */
 int btc_conv_bf16w_supported(int K, int Cred, int Cres);
 int btc_weights_to_bf16(const float* W, int K, int Cin, int Cout, void* w_bf16, void* wt_bf16, void* stream);
+/* ... of n weights in one launch (host arrays of device pointers / sizes): a parameter group's layers right behind its optimizer step */
+int btc_weights_to_bf16_multi(const float* const* W, void* const* w_bf16, void* const* wt_bf16, const int32_t* K, const int32_t* Cin,
+                              const int32_t* Cout, int n, void* stream);
 int btc_conv_fwd_bf16w(const void* feat, const void* wt_bf16, const float* bias, const int32_t* nbr_out, int n_out, int K, int Cin,
                        int Cout, void* out, void* stream);
 int btc_conv_dgrad_bf16w(const void* dout, const void* w_bf16, const int32_t* nbr_in, int n_in, int K, int Cin, int Cout, void* din,
