@@ -179,8 +179,41 @@ class GroupOptimizer(object):
 
     def zero_grad(self, set_to_none=True):
         for g in self.groups:
+            pl = self._param_list(g)
+            if pl is not None:
+                g["flat"]["F"].clear_grads_pl(pl)      # one call instead of ~300 attribute stores (0.13 ms of Python per step)
+                continue
             for p in g["params"]:
                 p.grad = None
+
+    @staticmethod
+    def _param_list(g):
+        """the group's parameters as an object of the compiled binding (binding.cpp ParamList: built once), or None"""
+        fl = g.get("flat")
+        if fl is None or not hasattr(fl.get("F"), "make_param_list"):
+            return None
+        pl = fl.get("plist")
+        if pl is None:
+            pl = fl["plist"] = fl["F"].make_param_list(list(g["params"]))
+        return pl
+
+    def _flat_step_params(self, g):
+        """_flat_step with the gradients read from the parameters' .grad inside the binding (no 300-element Python lists per step);
+        False: a gradient is missing or unusual, nothing was launched -- the caller builds the lists and decides"""
+        fl = g.get("flat")
+        if fl is None or fl["n"] < 0:
+            return False
+        pl = self._param_list(g)
+        if pl is None:
+            return False
+        from ._lib import stream_ptr
+        if not fl["F"].adam_group_step_pl(pl, fl["seg"], fl["off"], fl["len"], fl["flat"], fl["seg0"], fl["p"], fl["m"], fl["v"], fl["n"] + 1,
+                                          float(g["lr"]), float(g["mom"]), float(self.beta2), float(self.eps), float(g["weight_decay"]),
+                                          float(g["clip"]), fl["ws"], stream_ptr()):
+            return False
+        fl["n"] += 1
+        fl["synced"] = False
+        return True
 
     def lrs(self):
         return [g["lr"] for g in self.groups]
@@ -195,6 +228,13 @@ class GroupOptimizer(object):
             if groups is not None and gi not in groups:
                 continue
             params = g["params"]
+            if params and "grad_views" not in g and self._flat_step_params(g):
+                if g["clip"] > 0:
+                    last_norms.append(g["flat"]["ws"][:8].view(torch.float64))
+                nlr, nmom = g["sched"].at(g["it"])
+                g["lr"], g["mom"] = max(nlr, g["lr_clip"]), nmom
+                g["it"] += 1
+                continue
             if "grad_views" in g:
                 grads = g["grad_views"]
                 if self._present is None or (self._missing is not None and not self._missing()):

@@ -12,7 +12,11 @@ from btcdet_amd.spconv import ops
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
 HEADS = os.environ.get("HEADS") or None   # HEADS=rpn|full: the heads behind the hot path too
-model = BtcHotPath(load_cfg(), device=dev, heads=HEADS).to(dev).train()
+cfg = load_cfg()
+if os.environ.get("FEATURES") == "bf16":      # bench.py --features bf16
+    cfg.MODEL.OCC.BACKBONE_3D["FEATURE_DTYPE"] = "bf16"
+    cfg.MODEL.BACKBONE_3D["FEATURE_DTYPE"] = "bf16"
+model = BtcHotPath(cfg, device=dev, heads=HEADS).to(dev).train()
 occ = [p for p in model.occ_modules.parameters() if p.requires_grad]
 det = [p for p in model.det_modules.parameters() if p.requires_grad]
 opt = GroupOptimizer([dict(params=occ, lr=3e-3, weight_decay=1e-3, grad_norm_clip=10.0), dict(params=det, lr=1e-2, weight_decay=1e-2, grad_norm_clip=10.0)], 1000)
