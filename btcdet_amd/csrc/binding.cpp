@@ -238,7 +238,7 @@ std::tuple<Tensor, Tensor, Tensor> conv_bn_fwd(const Tensor& features, const Ten
                                                const OptTensor& nbt, bool use_batch, double momentum, double eps, bool relu, const Tensor& ws,
                                                int64_t ws_bytes, int64_t stream) {
   const int64_t cin = w.size(-2), cout = w.size(-1), K = map_fwd.size(1), n_res = map_fwd.size(0);
-  if (use_batch && n_res >= 1 && !bf16_operands(features, K, cin, cout)) {
+  if (use_batch && n_res >= 1) {
     // training-mode BatchNorm: its batch statistics come out of the conv kernel's epilogue (btc_conv_bn_relu_fwd, csrc/bn_fuse.h)
     need(features.is_contiguous() && w.is_contiguous() && map_fwd.is_contiguous(), "conv_bn_fwd: contiguous tensors expected");
     need(w.numel() == K * cin * cout && features.size(1) == cin, "conv_bn_fwd: weight does not match the rulebook / features");
@@ -252,7 +252,11 @@ std::tuple<Tensor, Tensor, Tensor> conv_bn_fwd(const Tensor& features, const Ten
     int operands = features.scalar_type() == at::kBFloat16 ? BTC_OPERANDS_BF16_ACT : BTC_OPERANDS_F32;
     const void* wp = w.data_ptr();
     Tensor q;
-    if (split_operands(features, K, cin, cout, n_res, stream)) {
+    if (bf16_operands(features, K, cin, cout)) {          // (round 5: the bf16-operand kernel gathers the statistics too)
+      q = weights_bf16(w, K, cin, cout, stream);
+      operands = BTC_OPERANDS_BF16;
+      wp = (const char*)q.data_ptr() + 2 * w.numel();
+    } else if (split_operands(features, K, cin, cout, n_res, stream)) {
       q = weights_q(w, K, cin, cout, stream, 3);
       operands = BTC_OPERANDS_F32_SPLIT;
       wp = (const char*)q.data_ptr() + 6 * w.numel();

@@ -587,7 +587,7 @@ extern "C" int btc_conv_bn_relu_fwd_src(int operands, const void* src, long long
   BTC_CHECK_ARG(operands >= BTC_OPERANDS_F32 && operands <= BTC_OPERANDS_F32_SPLIT, "btc_conv_bn_relu_fwd: operands=%d", operands);
   const bool bf = operands == BTC_OPERANDS_BF16_ACT || operands == BTC_OPERANDS_BF16;
   int fused = 0;
-  if (fuse_ws && operands != BTC_OPERANDS_BF16 && Cout <= BN_FUSE_CMAX && btc_tune_get(BTC_TUNE_BN_FUSE) != 1) {
+  if (fuse_ws && Cout <= BN_FUSE_CMAX && btc_tune_get(BTC_TUNE_BN_FUSE) != 1) {
     BnFuse bn;
     bn.counter = (int32_t*)fuse_ws;
     bn.slots = (double*)((char*)fuse_ws + 256);

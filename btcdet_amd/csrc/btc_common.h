@@ -58,7 +58,7 @@ int btc_conv_fwd_stats(int operands, const void* src, long long src_rows, const 
 
 // conv_apply_bf16.hip: bf16 operands on the bf16 matrix pipe; Wq[k][Cres][Cred] bf16
 int btc_apply_bf16w(const void* src, const void* Wq, const float* bias, const int32_t* nbr, const int32_t* order, int n_rows, int K, int Cred,
-                    int Cres, void* dst, hipStream_t stream, int mirror = 0);
+                    int Cres, void* dst, hipStream_t stream, int mirror = 0, const struct BnFuse* bn = nullptr);
 // conv_wgrad_x.hip: weight gradient on the bf16 matrix pipe (mode 0: bf16 activations, 1: fp32 activations as three exact bf16 pieces);
 // cg / cc = channels of the gathered / contiguous operand of the row walk
 bool btc_wgrad_x_supported(int mode, int K, int cg, int cc);

@@ -24,6 +24,7 @@
 #include <mutex>
 
 #include "btc_common.h"
+#include "bn_fuse.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -47,7 +48,7 @@ template <int WR, int WC, int NTW, int KC>
 __global__ __launch_bounds__(64 * WR * WC) void conv_apply_b(const unsigned short* __restrict__ feat, const unsigned short* __restrict__ Wq,
                                                              const float* __restrict__ bias, const int32_t* __restrict__ nbr,
                                                              const int32_t* __restrict__ order, int n_rows, int K, int Cred, int Cres,
-                                                             unsigned short* __restrict__ out, int xcd_swizzle) {
+                                                             unsigned short* __restrict__ out, int xcd_swizzle, const BnFuse bn) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NW = WR * WC, THREADS = 64 * NW;
   constexpr int TM = 16 * WR, TN = 16 * NTW * WC;
@@ -183,6 +184,8 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_apply_b(const unsigned shor
   }
 
   // C/D layout of 16x16: col = lane & 15, row = (lane >> 4) * 4 + reg
+  float vals[NTW][4];
+  bool valid[4];
 #pragma unroll
   for (int nt = 0; nt < NTW; ++nt) {
     const int col = n0 + (wc * NTW + nt) * 16 + (lane & 15);
@@ -190,8 +193,15 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_apply_b(const unsigned shor
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = s_row[wr * 16 + kq * 4 + r];
-      if (row >= 0) out[(size_t)row * Cres + col] = btc_f32_to_bf16(bias ? (acc[nt][r] + bv0) : acc[nt][r]);
+      const unsigned short h = btc_f32_to_bf16(bias ? (acc[nt][r] + bv0) : acc[nt][r]);
+      if (row >= 0) out[(size_t)row * Cres + col] = h;
+      valid[r] = row >= 0;
+      vals[nt][r] = btc_bf16_to_f32(h);   // the value as STORED: what the BatchNorm behind this layer reads
     }
+  }
+  if (bn.slots) {   // batch statistics for the BatchNorm behind this layer (bn_fuse.h), round 5: the bf16 step carried 23 bn_stats launches
+    bn_fuse_wave<NTW>(bn, vals, valid, n0 + wc * NTW * 16, (int)((bx * WR + wr) & (BN_FUSE_SLOTS - 1)));
+    bn_fuse_finish(bn, (int*)smem);
   }
 }
 
@@ -202,7 +212,7 @@ size_t lds_bytes_b(int tm, int tn, int kc, int K) {
 
 template <int WR, int WC, int NTW, int KC>
 int launch_b(const unsigned short* feat, const unsigned short* Wq, const float* bias, const int32_t* nbr, const int32_t* order, int n_rows, int K, int Cred,
-             int Cres, unsigned short* out, int xcd, hipStream_t stream) {
+             int Cres, unsigned short* out, int xcd, hipStream_t stream, const BnFuse& bn) {
   constexpr int TM = 16 * WR, TN = 16 * NTW * WC;
   const size_t lds = lds_bytes_b(TM, TN, KC, K);
   BTC_CHECK_ARG(lds <= 160 * 1024, "conv_apply_b: tile does not fit the LDS");
@@ -211,21 +221,22 @@ int launch_b(const unsigned short* feat, const unsigned short* Wq, const float* 
     (void)hipFuncSetAttribute((const void*)conv_apply_b<WR, WC, NTW, KC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   });
   dim3 grid(btc_cdiv(n_rows, TM), Cres / TN);
-  conv_apply_b<WR, WC, NTW, KC><<<grid, 64 * WR * WC, lds, stream>>>(feat, Wq, bias, nbr, order, n_rows, K, Cred, Cres, out, xcd);
+  conv_apply_b<WR, WC, NTW, KC><<<grid, 64 * WR * WC, lds, stream>>>(feat, Wq, bias, nbr, order, n_rows, K, Cred, Cres, out, xcd, bn);
   BTC_LAUNCH_CHECK();
   return BTC_OK;
 }
 
 template <int WR, int WC, int NTW>
 int launch_b_kc(int kc, const unsigned short* feat, const unsigned short* Wq, const float* bias, const int32_t* nbr, const int32_t* order, int n_rows,
-                int K, int Cred, int Cres, unsigned short* out, int xcd, hipStream_t stream) {
-  if (kc == 64) return launch_b<WR, WC, NTW, 64>(feat, Wq, bias, nbr, order, n_rows, K, Cred, Cres, out, xcd, stream);
-  return launch_b<WR, WC, NTW, 32>(feat, Wq, bias, nbr, order, n_rows, K, Cred, Cres, out, xcd, stream);
+                int K, int Cred, int Cres, unsigned short* out, int xcd, hipStream_t stream, const BnFuse& bn) {
+  if (kc == 64) return launch_b<WR, WC, NTW, 64>(feat, Wq, bias, nbr, order, n_rows, K, Cred, Cres, out, xcd, stream, bn);
+  return launch_b<WR, WC, NTW, 32>(feat, Wq, bias, nbr, order, n_rows, K, Cred, Cres, out, xcd, stream, bn);
 }
 
 int apply_b(const void* feat_, const void* Wq_, const float* bias, const int32_t* nbr, const int32_t* order, int n_rows, int K, int Cred, int Cres,
-            void* out_, hipStream_t stream, int mirror = 0) {
+            void* out_, hipStream_t stream, int mirror = 0, const BnFuse* bn_ = nullptr) {
   if (n_rows <= 0) return BTC_OK;
+  const BnFuse bn = bn_ ? *bn_ : btc_bn_fuse_none();
   const unsigned short* feat = (const unsigned short*)feat_;
   const unsigned short* Wq = (const unsigned short*)Wq_;
   unsigned short* out = (unsigned short*)out_;
@@ -233,13 +244,13 @@ int apply_b(const void* feat_, const void* Wq_, const float* bias, const int32_t
   const int xcd = (btc_tune_get(BTC_TUNE_APPLY_XCD) == 2 ? 1 : 0) | (mirror ? 2 : 0);   // kernel flags: bit 0 XCD mapping, bit 1 mirrored map
   // wave shapes as conv_apply_g's policy (sparse_conv.hip): 64 rows x 128 columns on 8 waves for wide results, 16-row
   // workgroups with 4 waves across the columns when there are few rows
-  if (Cres % 128 == 0) return launch_b_kc<4, 2, 4>(kc, feat, Wq, bias, nbr, order, n_rows, K, Cred, Cres, out, xcd, stream);
+  if (Cres % 128 == 0) return launch_b_kc<4, 2, 4>(kc, feat, Wq, bias, nbr, order, n_rows, K, Cred, Cres, out, xcd, stream, bn);
   if (Cres % 64 == 0) {
-    if (n_rows < 8192) return launch_b_kc<1, 4, 1>(kc, feat, Wq, bias, nbr, order, n_rows, K, Cred, Cres, out, xcd, stream);
-    return launch_b_kc<4, 2, 2>(kc, feat, Wq, bias, nbr, order, n_rows, K, Cred, Cres, out, xcd, stream);
+    if (n_rows < 8192) return launch_b_kc<1, 4, 1>(kc, feat, Wq, bias, nbr, order, n_rows, K, Cred, Cres, out, xcd, stream, bn);
+    return launch_b_kc<4, 2, 2>(kc, feat, Wq, bias, nbr, order, n_rows, K, Cred, Cres, out, xcd, stream, bn);
   }
-  if (Cres % 32 == 0) return launch_b_kc<2, 2, 1>(kc, feat, Wq, bias, nbr, order, n_rows, K, Cred, Cres, out, xcd, stream);
-  return launch_b_kc<4, 1, 1>(kc, feat, Wq, bias, nbr, order, n_rows, K, Cred, Cres, out, xcd, stream);
+  if (Cres % 32 == 0) return launch_b_kc<2, 2, 1>(kc, feat, Wq, bias, nbr, order, n_rows, K, Cred, Cres, out, xcd, stream, bn);
+  return launch_b_kc<4, 1, 1>(kc, feat, Wq, bias, nbr, order, n_rows, K, Cred, Cres, out, xcd, stream, bn);
 }
 
 __global__ __launch_bounds__(256) void weights_to_bf16(const float* __restrict__ W, int K, int Cin, int Cout, unsigned short* __restrict__ w_b,
@@ -307,8 +318,8 @@ extern "C" int btc_weights_to_bf16_multi(const float* const* W, void* const* w_b
 }
 
 int btc_apply_bf16w(const void* src, const void* Wq, const float* bias, const int32_t* nbr, const int32_t* order, int n_rows, int K, int Cred,
-                    int Cres, void* dst, hipStream_t stream, int mirror) {
-  return apply_b(src, Wq, bias, nbr, order, n_rows, K, Cred, Cres, dst, stream, mirror);
+                    int Cres, void* dst, hipStream_t stream, int mirror, const BnFuse* bn) {
+  return apply_b(src, Wq, bias, nbr, order, n_rows, K, Cred, Cres, dst, stream, mirror, bn);
 }
 
 extern "C" int btc_conv_bf16w_supported(int K, int Cred, int Cres) { return K >= 1 && K <= 64 && Cred >= 32 && Cred % 32 == 0 && Cres % 16 == 0; }

@@ -1328,10 +1328,14 @@ int btc_conv_fwd_stats(int operands, const void* src, long long src_rows, const 
                        int n_rows, int K, int Cin, int Cout, void* dst, const BnFuse& bn, hipStream_t stream, int* fused) {
   *fused = 0;
   BTC_CHECK_ARG(K >= 1 && K <= 512 && Cin >= 1 && Cout >= 1 && n_rows >= 0, "btc_conv_fwd_stats: bad sizes");
-  BTC_CHECK_ARG(operands == BTC_OPERANDS_F32 || operands == BTC_OPERANDS_BF16_ACT || operands == BTC_OPERANDS_F32_SPLIT,
-                "btc_conv_fwd_stats: fp32 weights (or their split planes) only");
+  BTC_CHECK_ARG(operands >= BTC_OPERANDS_F32 && operands <= BTC_OPERANDS_F32_SPLIT, "btc_conv_fwd_stats: operands=%d", operands);
   BTC_CHECK_ARG(Cout <= BN_FUSE_CMAX, "btc_conv_fwd_stats: more than %d channels", BN_FUSE_CMAX);
   if (n_rows <= 0) return BTC_OK;
+  if (operands == BTC_OPERANDS_BF16) {   // W = wt_bf16 (the forward copy of btc_weights_to_bf16)
+    BTC_CHECK_ARG(btc_conv_bf16w_supported(K, Cin, Cout), "btc_conv_fwd_stats: bf16 operands need K <= 64, Cin %% 32 == 0, Cout %% 16 == 0");
+    *fused = 1;
+    return btc_apply_bf16w(src, W, bias, nbr, order, n_rows, K, Cin, Cout, dst, stream, 0, &bn);
+  }
   if (operands == BTC_OPERANDS_F32_SPLIT) {
     const int rc = split_source_ok("btc_conv_bn_relu_fwd_src", src_rows, Cin);
     if (rc) return rc;

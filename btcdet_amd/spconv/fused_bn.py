@@ -35,8 +35,8 @@ def fuse_ws(device):
 
 
 def conv_bn_forward(features, w, b, map_fwd, ord_fwd, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, relu):
-    """training-mode conv -> BatchNorm -> [ReLU] through btc_conv_bn_relu_fwd (statistics in the conv's epilogue); fp32 weights
-    or their split planes.
+    """training-mode conv -> BatchNorm -> [ReLU] through btc_conv_bn_relu_fwd (statistics in the conv's epilogue); fp32 weights,
+    their split planes, or (bf16 features) their bf16 copy.
     -> (x, y, stats (2, C) = mean | rstd)"""
     n, K = map_fwd.shape
     cin, cout = w.shape[-2], w.shape[-1]
@@ -46,7 +46,9 @@ def conv_bn_forward(features, w, b, map_fwd, ord_fwd, gamma, beta, running_mean,
     ws, need = _ws(features.device, cout)
     operands = 1 if features.dtype == torch.bfloat16 else 0
     from . import ops
-    if ops._split_operands(features, K, cin, cout, n):   # split-operand kernel: W = the forward planes
+    if ops._bf16_operands(features, K, cin, cout):       # bf16-operand kernel: W = the forward (transposed) bf16 copy
+        operands, w = 2, ops._weights_bf16(w, K, cin, cout)[1]
+    elif ops._split_operands(features, K, cin, cout, n):   # split-operand kernel: W = the forward planes
         operands, w = 3, ops._weights_split(w, K, cin, cout)[1]
     check(lib().btc_conv_bn_relu_fwd_src(operands, ptr(features), int(features.shape[0]), ptr(w), ptr(b), ptr(map_fwd), ptr(ord_fwd), n, K, cin, cout,
                                      ptr(x), ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), ptr(num_batches_tracked), float(momentum),

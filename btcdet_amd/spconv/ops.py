@@ -736,7 +736,7 @@ class SparseConvBNReLUFunction(torch.autograd.Function):
             x, y, stats = F.conv_bn_fwd(features, w, b, map_fwd, ord_fwd, gamma, beta, running_mean, running_var, nbt if training else None, use_batch,
                                         float(momentum), float(eps), bool(relu), ws, need, stream_ptr())
         elif (use_batch and PROFILE is None and map_fwd.shape[0] >= 1 and w.numel() == map_fwd.shape[1] * w.shape[-2] * w.shape[-1]
-              and features.shape[1] == w.shape[-2] and not _bf16_operands(features, map_fwd.shape[1], w.shape[-2], w.shape[-1])):
+              and features.shape[1] == w.shape[-2]):
             # the ctypes route of the same fused entry point the compiled binding takes (statistics in the conv's epilogue)
             x, y, stats = fused_bn.conv_bn_forward(features, w, b, map_fwd, ord_fwd, gamma, beta, running_mean, running_var,
                                                    nbt if training else None, momentum, eps, relu)

@@ -453,7 +453,8 @@ def test_compiled_binding_and_ctypes_binding_agree(dtype):
 
 
 @pytest.mark.parametrize("cin,cout,n,dtype", [(4, 16, 6000, "f32"), (16, 16, 3000, "f32"), (64, 128, 900, "f32"), (32, 32, 120000, "f32"), (20, 150, 700, "f32"),
-                                               (34, 32, 5000, "f32"), (64, 64, 5000, "bf16")])
+                                               (34, 32, 5000, "f32"), (64, 64, 5000, "bf16"), (64, 64, 12000, "bf16"), (32, 32, 30000, "bf16"),
+                                               (64, 128, 9000, "bf16"), (32, 16, 5000, "bf16"), (16, 32, 5000, "bf16")])
 def test_conv_epilogue_batch_statistics_match_the_separate_pass(cin, cout, n, dtype):
     """btc_conv_bn_relu_fwd gathers the BatchNorm batch statistics in the conv kernel's epilogue (csrc/bn_fuse.h) in every kernel
     family the dispatch can pick (weight-stationary, LDS-DMA, register-staged; bf16 activations): conv result bit-identical to the

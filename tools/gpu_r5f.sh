@@ -2,7 +2,7 @@
 # round 5: bf16 against fp32 on one box (bench lines, launches per step), where the bf16 step's extra torch ops come from; canary
 out=gpurun_out/r5f; mkdir -p $out
 cd /root/repo
-timeout 600 python -m pytest tests/test_hip_borrow_canary.py tests/test_hip_prefetch.py tests/test_hip_bf16.py tests/test_hip_stress.py -q -m gpu -s > $out/t.txt 2>&1; tail -4 $out/t.txt; grep "poisoned" $out/t.txt
+timeout 600 python -m pytest tests/test_hip_core.py tests/test_hip_bf16.py tests/test_hip_bf16_mfma.py tests/test_hip_pipeline.py tests/test_hip_prefetch.py -q -m gpu -s > $out/t.txt 2>&1; tail -4 $out/t.txt; grep "poisoned" $out/t.txt
 AB_STEPS=80 bash tools/ab_env.sh 2 "fp32:" > $out/ab.txt 2>&1
 for r in 1 2; do timeout 300 python bench.py --features bf16 --steps 80 --warmup 10 --no-cpu-baseline --no-roofline --no-extras 2>/dev/null | grep '^{' | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('bf16 run %.1f scenes/s %.3f ms' % (d['value'], d['ms_per_step']))" >> $out/ab.txt; done
 cat $out/ab.txt
