@@ -593,7 +593,7 @@ extern "C" int btc_conv_bn_relu_fwd_src(int operands, const void* src, long long
     bn.slots = (double*)((char*)fuse_ws + 256);
     bn.mean_out = save_mean; bn.rstd_out = save_rstd;
     bn.running_mean = running_mean; bn.running_var = running_var; bn.num_batches = num_batches_tracked;
-    bn.momentum = momentum; bn.eps = eps; bn.N = n_rows; bn.C = Cout;
+    bn.momentum = momentum; bn.eps = eps; bn.N = n_rows; bn.C = Cout; bn.nslots = btc_bn_fuse_nslots(n_rows);
     int rc = btc_conv_fwd_stats(operands, src, src_rows, (const float*)W, bias, nbr, order, n_rows, K, Cin, Cout, x, bn, (hipStream_t)stream, &fused);
     if (rc) return rc;
   } else {

@@ -3,7 +3,7 @@
 // 16 x 16 result tiles are still in registers there, so the separate statistics pass over the freshly written (N, C) tensor -- one
 // launch per layer at its latency floor and a second read of every activation -- disappears (27 launches per training step).
 //
-// Each wave reduces its tile columns (fp64), adds them to one of BN_FUSE_SLOTS slot rows with device-scope fp64 atomics, and the
+// Each wave reduces its tile columns (fp64), adds them to one of nslots slot rows with device-scope fp64 atomics, and the
 // LAST workgroup to arrive (release -> ticket -> acquire, as bn.hip) sums the slots in index order, publishes mean / rstd, updates
 // the running statistics and num_batches_tracked and leaves slots and counter zeroed for the next layer on that stream.  The slot
 // stride is fixed (BN_FUSE_CMAX channels), so whatever channel count used the buffer last has cleaned exactly what it touched.
@@ -12,11 +12,15 @@
 #pragma once
 #include "btc_common.h"
 
-constexpr int BN_FUSE_SLOTS = 32;
+// Slots: a wave adds its column sums to slot (its tile index) mod nslots.  Atomics on ONE address are served one after the other at the
+// L2 (~150 ns each): a 210 K-row layer issues ~840 K of them, with 32 slots x 64 channel sums that was ~400 per address = 60 us of
+// a 100 us launch (found in round 5 when the bf16-operand kernel got this epilogue).  nslots therefore grows with the row count
+// (btc_bn_fuse_nslots: 32 .. BN_FUSE_SLOTS_MAX), and the last workgroup sums the slots with all of its threads.
+constexpr int BN_FUSE_SLOTS_MAX = 512;
 constexpr int BN_FUSE_CMAX = 1024;
 
 struct BnFuse {
-  double* slots;        // [BN_FUSE_SLOTS][2][BN_FUSE_CMAX]: sum, sum of squares; zero on entry, zero on exit.  nullptr: no statistics
+  double* slots;        // [nslots <= BN_FUSE_SLOTS_MAX][2][BN_FUSE_CMAX]: sum, sum of squares; zero on entry, zero on exit.  nullptr: no statistics
   int32_t* counter;     // arrival counter, zero on entry / exit
   float* mean_out;      // [C]
   float* rstd_out;      // [C]
@@ -25,14 +29,21 @@ struct BnFuse {
   long long* num_batches;
   float momentum, eps;
   int N, C;
+  int nslots;           // power of two, 32 .. BN_FUSE_SLOTS_MAX
 };
 
-static inline size_t btc_bn_fuse_bytes() { return 256 + (size_t)BN_FUSE_SLOTS * 2 * BN_FUSE_CMAX * sizeof(double); }
+static inline size_t btc_bn_fuse_bytes() { return 256 + (size_t)BN_FUSE_SLOTS_MAX * 2 * BN_FUSE_CMAX * sizeof(double); }
+
+static inline int btc_bn_fuse_nslots(long long n_rows) {
+  int s = 32;
+  while (s < BN_FUSE_SLOTS_MAX && (long long)s * 1024 < n_rows) s <<= 1;
+  return s;
+}
 
 static inline BnFuse btc_bn_fuse_none() {
   BnFuse b;
   b.slots = nullptr; b.counter = nullptr; b.mean_out = b.rstd_out = b.running_mean = b.running_var = nullptr; b.num_batches = nullptr;
-  b.momentum = b.eps = 0.f; b.N = b.C = 0;
+  b.momentum = b.eps = 0.f; b.N = b.C = 0; b.nslots = 32;
   return b;
 }
 
@@ -64,8 +75,9 @@ __device__ __forceinline__ void bn_fuse_wave(const BnFuse& bn, const float (&v)[
 }
 
 // end of the kernel, every thread of every workgroup: the last workgroup to arrive turns the slots into mean / rstd.
-// s_flag: one int of the workgroup's LDS that nobody needs any more (the kernels run at the 160 KB dynamic limit: no static LDS here)
-__device__ __forceinline__ void bn_fuse_finish(const BnFuse& bn, int* s_flag) {
+// s_flag: one int of the workgroup's LDS that nobody needs any more (the kernels run at the 160 KB dynamic limit: no static LDS here);
+// s_part: blockDim.x * 2 doubles of dead LDS (or nullptr): with it the slot sums of a channel are shared by blockDim.x / C threads
+__device__ __forceinline__ void bn_fuse_finish(const BnFuse& bn, int* s_flag, double* s_part = nullptr) {
   const int tid = threadIdx.x;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -80,16 +92,7 @@ __device__ __forceinline__ void bn_fuse_finish(const BnFuse& bn, int* s_flag) {
   if (!*s_flag) return;
   if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   __syncthreads();
-  for (int c = tid; c < bn.C; c += blockDim.x) {
-    double a = 0.0, b = 0.0;
-#pragma unroll 8
-    for (int s = 0; s < BN_FUSE_SLOTS; ++s) {
-      double* p = bn.slots + ((size_t)s * 2) * BN_FUSE_CMAX + c;
-      a += __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      b += __hip_atomic_load(p + BN_FUSE_CMAX, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      p[0] = 0.0;
-      p[BN_FUSE_CMAX] = 0.0;
-    }
+  auto publish = [&](int c, double a, double b) {
     const double mean = a / bn.N;
     double var = b / bn.N - mean * mean;  // biased, as F.batch_norm normalises with
     if (var < 0.0) var = 0.0;
@@ -99,6 +102,44 @@ __device__ __forceinline__ void bn_fuse_finish(const BnFuse& bn, int* s_flag) {
       const double unb = bn.N > 1 ? var * ((double)bn.N / (double)(bn.N - 1)) : var;
       bn.running_mean[c] = (float)((1.0 - bn.momentum) * bn.running_mean[c] + bn.momentum * mean);
       bn.running_var[c] = (float)((1.0 - bn.momentum) * bn.running_var[c] + bn.momentum * unb);
+    }
+  };
+  const int T = (int)blockDim.x;
+  if (s_part && bn.C <= T) {
+    const int G = T / bn.C;                 // threads per channel
+    const int c = tid % bn.C, g = tid / bn.C;
+    double a = 0.0, b = 0.0;
+    if (g < G)
+      for (int s = g; s < bn.nslots; s += G) {
+        double* p = bn.slots + ((size_t)s * 2) * BN_FUSE_CMAX + c;
+        a += __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        b += __hip_atomic_load(p + BN_FUSE_CMAX, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        p[0] = 0.0;
+        p[BN_FUSE_CMAX] = 0.0;
+      }
+    s_part[2 * tid] = a;
+    s_part[2 * tid + 1] = b;
+    __syncthreads();
+    if (tid < bn.C) {
+      a = b = 0.0;
+      for (int q = 0; q < G; ++q) {         // (fixed order: deterministic given the slot contents)
+        a += s_part[2 * (q * bn.C + tid)];
+        b += s_part[2 * (q * bn.C + tid) + 1];
+      }
+      publish(tid, a, b);
+    }
+  } else {
+    for (int c = tid; c < bn.C; c += T) {
+      double a = 0.0, b = 0.0;
+#pragma unroll 8
+      for (int s = 0; s < bn.nslots; ++s) {
+        double* p = bn.slots + ((size_t)s * 2) * BN_FUSE_CMAX + c;
+        a += __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        b += __hip_atomic_load(p + BN_FUSE_CMAX, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        p[0] = 0.0;
+        p[BN_FUSE_CMAX] = 0.0;
+      }
+      publish(c, a, b);
     }
   }
   if (tid == 0) {

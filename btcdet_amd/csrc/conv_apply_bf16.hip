@@ -200,8 +200,8 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_apply_b(const unsigned shor
     }
   }
   if (bn.slots) {   // batch statistics for the BatchNorm behind this layer (bn_fuse.h), round 5: the bf16 step carried 23 bn_stats launches
-    bn_fuse_wave<NTW>(bn, vals, valid, n0 + wc * NTW * 16, (int)((bx * WR + wr) & (BN_FUSE_SLOTS - 1)));
-    bn_fuse_finish(bn, (int*)smem);
+    bn_fuse_wave<NTW>(bn, vals, valid, n0 + wc * NTW * 16, (int)((bx * WR + wr) & (bn.nslots - 1)));
+    bn_fuse_finish(bn, (int*)smem, (double*)(smem + 16));
   }
 }
 

@@ -301,8 +301,8 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_apply_g(const void* __restr
     }
   }
   if (bn.slots) {   // batch statistics for the BatchNorm behind this layer (bn_fuse.h)
-    bn_fuse_wave<NTW>(bn, vals, valid, n0 + wc * NTW * 16, (int)((bx * WR + wr) & (BN_FUSE_SLOTS - 1)));
-    bn_fuse_finish(bn, (int*)smem);
+    bn_fuse_wave<NTW>(bn, vals, valid, n0 + wc * NTW * 16, (int)((bx * WR + wr) & (bn.nslots - 1)));
+    bn_fuse_finish(bn, (int*)smem, (double*)(smem + 16));
   }
 }
 

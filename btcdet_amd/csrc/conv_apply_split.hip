@@ -322,8 +322,8 @@ __global__ __launch_bounds__(64 * (WR * WC + LW)) void conv_apply_s(const float*
     }
   }
   if (bn.slots) {   // batch statistics for the BatchNorm behind this layer (bn_fuse.h)
-    if (computes) bn_fuse_wave<NTW>(bn, vals, valid, n0 + wc * NTW * 16, (int)((bx * WR + wr) & (BN_FUSE_SLOTS - 1)));
-    bn_fuse_finish(bn, (int*)smem);
+    if (computes) bn_fuse_wave<NTW>(bn, vals, valid, n0 + wc * NTW * 16, (int)((bx * WR + wr) & (bn.nslots - 1)));
+    bn_fuse_finish(bn, (int*)smem, (double*)(smem + 16));
   }
 }
 
@@ -378,7 +378,7 @@ __global__ __launch_bounds__(256) void split_reduce(const float* __restrict__ sl
     }
   }
   if (bn.slots) {
-    const int slot = (int)((blockIdx.x * 4 + wave) & (BN_FUSE_SLOTS - 1));
+    const int slot = (int)((blockIdx.x * 4 + wave) & (bn.nslots - 1));
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       s1[e] += __shfl_xor(s1[e], 16, 64);

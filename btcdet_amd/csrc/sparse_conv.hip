@@ -207,8 +207,8 @@ __global__ __launch_bounds__(THREADS) void conv_apply(const float* __restrict__ 
     }
   }
   if (bn.slots) {
-    bn_fuse_wave<NT>(bn, vals, valid, n0, (int)((blockIdx.x * (THREADS / 64) + wave) & (BN_FUSE_SLOTS - 1)));
-    bn_fuse_finish(bn, (int*)smem);
+    bn_fuse_wave<NT>(bn, vals, valid, n0, (int)((blockIdx.x * (THREADS / 64) + wave) & (bn.nslots - 1)));
+    bn_fuse_finish(bn, (int*)smem, (double*)(smem + 16));
   }
 }
 
@@ -342,10 +342,10 @@ __global__ __launch_bounds__(WS_WAVES * 64) void conv_apply_ws(const float* __re
         if (col < Cres && row < n_rows) out[(size_t)row * Cres + col] = vals[nt][r];
       }
     }
-    if (bn.slots) bn_fuse_wave<NT>(bn, vals, valid, 0, (int)(tile & (BN_FUSE_SLOTS - 1)));
+    if (bn.slots) bn_fuse_wave<NT>(bn, vals, valid, 0, (int)(tile & (bn.nslots - 1)));
     __builtin_amdgcn_wave_barrier();
   }
-  if (bn.slots) bn_fuse_finish(bn, (int*)smem);
+  if (bn.slots) bn_fuse_finish(bn, (int*)smem, (double*)(smem + 16));
 }
 
 // dW partial: part[s][k][ci][co] = sum over the split's rows of feat[nbr[i][k]][ci] * dout[i][co]
