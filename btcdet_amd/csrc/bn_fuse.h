@@ -82,8 +82,12 @@ __device__ __forceinline__ void bn_fuse_finish(const BnFuse& bn, int* s_flag, do
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (tid == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // NO agent-scope release fence here (round 5).  What the last arriver reads are the slot sums, and those are written by device-scope
+    // ATOMICS only -- sc1 operations, performed at the coherence point, never left dirty in this XCD's L2 -- so "every wave drained its
+    // vector-memory queue (the s_waitcnt above), then the ticket" is the whole protocol (MI355X_MICROARCH.md, handoff-flag: `sc1`
+    // payload -> vmcnt(0) -> `sc1` flag).  The fence that stood here is `buffer_wbl2 sc1`: a write-back of the XCD L2's dirty lines --
+    // i.e. of every conv result tile written a moment ago -- ONCE PER WORKGROUP: 2-6 us each, ~430 us of the 13 K-workgroup launches
+    // of the bf16-operand kernel on the 210 K-row level, which is how it was found.
     const int total = (int)(gridDim.x * gridDim.y * gridDim.z);
     const int t = __hip_atomic_fetch_add(bn.counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     *s_flag = (t == total - 1);
