@@ -20,14 +20,17 @@ struct BnShape {
   int N, C, cpow, rpi;  // cpow = pow2 >= min(C,256); rpi = rows per iteration of a workgroup
 };
 
-// last-arriver election (placement independent: release -> ticket -> acquire)
+// a workgroup's partial sums are published with device-scope (sc1, write-through) stores: they are at the coherence point once the
+// storing wave's vector-memory queue has drained -- no agent-scope release fence, i.e. no write-back of the XCD L2's dirty lines (all
+// the activations the previous kernels wrote) once per workgroup (MI355X_MICROARCH.md, handoff-flag: `sc1` payload -> vmcnt(0) -> flag)
+__device__ __forceinline__ void st_partial(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// last-arriver election (placement independent: sc1 partials, drained -> ticket -> acquire)
 __device__ __forceinline__ bool last_block(int32_t* counter) {
   __shared__ int s_last;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     int t = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     s_last = (t == (int)gridDim.x - 1);
   }
@@ -105,8 +108,8 @@ __global__ __launch_bounds__(BN_T) void bn_stats(const float* __restrict__ x, Bn
           for (int j = 0; j < 4; ++j) { a[j] += s_a[(tid + q * SV.cpow) * 4 + j]; b[j] += s_b[(tid + q * SV.cpow) * 4 + j]; }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          partial[((size_t)blockIdx.x * 2 + 0) * S.C + cv * 4 + j] = a[j];
-          partial[((size_t)blockIdx.x * 2 + 1) * S.C + cv * 4 + j] = b[j];
+          st_partial(&partial[((size_t)blockIdx.x * 2 + 0) * S.C + cv * 4 + j], a[j]);
+          st_partial(&partial[((size_t)blockIdx.x * 2 + 1) * S.C + cv * 4 + j], b[j]);
         }
       }
       __syncthreads();
@@ -138,8 +141,8 @@ __global__ __launch_bounds__(BN_T) void bn_stats(const float* __restrict__ x, Bn
         a += s_a[tid + q * S.cpow];
         b += s_b[tid + q * S.cpow];
       }
-      partial[((size_t)blockIdx.x * 2 + 0) * S.C + c] = a;
-      partial[((size_t)blockIdx.x * 2 + 1) * S.C + c] = b;
+      st_partial(&partial[((size_t)blockIdx.x * 2 + 0) * S.C + c], a);
+      st_partial(&partial[((size_t)blockIdx.x * 2 + 1) * S.C + c], b);
     }
     __syncthreads();
   }
@@ -265,8 +268,8 @@ __global__ __launch_bounds__(BN_T) void bn_bwd_stats(const float* __restrict__ x
           for (int j = 0; j < 4; ++j) { a[j] += s_a[(tid + q * SV.cpow) * 4 + j]; b[j] += s_b[(tid + q * SV.cpow) * 4 + j]; }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          partial[((size_t)blockIdx.x * 2 + 0) * S.C + cv * 4 + j] = a[j];
-          partial[((size_t)blockIdx.x * 2 + 1) * S.C + cv * 4 + j] = b[j];
+          st_partial(&partial[((size_t)blockIdx.x * 2 + 0) * S.C + cv * 4 + j], a[j]);
+          st_partial(&partial[((size_t)blockIdx.x * 2 + 1) * S.C + cv * 4 + j], b[j]);
         }
       }
       __syncthreads();
@@ -310,8 +313,8 @@ __global__ __launch_bounds__(BN_T) void bn_bwd_stats(const float* __restrict__ x
         a += s_a[tid + q * S.cpow];
         b += s_b[tid + q * S.cpow];
       }
-      partial[((size_t)blockIdx.x * 2 + 0) * S.C + c] = a;
-      partial[((size_t)blockIdx.x * 2 + 1) * S.C + c] = b;
+      st_partial(&partial[((size_t)blockIdx.x * 2 + 0) * S.C + c], a);
+      st_partial(&partial[((size_t)blockIdx.x * 2 + 1) * S.C + c], b);
     }
     __syncthreads();
   }
@@ -396,7 +399,7 @@ __global__ __launch_bounds__(BN_T) void col_sum(const float* __restrict__ x, BnS
     __syncthreads();
     if (rr == 0 && c < S.C) {
       for (int q = 1; q < S.rpi; ++q) a += s_a[tid + q * S.cpow];
-      partial[(size_t)blockIdx.x * S.C + c] = a;
+      st_partial(&partial[(size_t)blockIdx.x * S.C + c], a);
     }
     __syncthreads();
   }

@@ -21,9 +21,7 @@ __device__ __forceinline__ bool last_block_l(int32_t* counter) {
   __shared__ int s_last;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (threadIdx.x == 0) {   // (the partials were stored device-scope and the queues are drained: no release fence, see csrc/bn_fuse.h)
     int t = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     s_last = (t == (int)gridDim.x - 1);
   }
@@ -82,7 +80,7 @@ __global__ __launch_bounds__(256) void occ_loss_fwd(const float* __restrict__ lo
   __syncthreads();
   if (threadIdx.x < 4) {
     double v = s_red[0][threadIdx.x] + s_red[1][threadIdx.x] + s_red[2][threadIdx.x] + s_red[3][threadIdx.x];
-    partial[(size_t)blockIdx.x * 4 + threadIdx.x] = v;
+    __hip_atomic_store(&partial[(size_t)blockIdx.x * 4 + threadIdx.x], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   if (!last_block_l(counter)) return;
   if (threadIdx.x == 0) {

@@ -384,8 +384,9 @@ __device__ __forceinline__ void scan_chunk(const Level& L, int32_t* __restrict__
   }
   if (blk < L.nblk) L.bprefix[blk] = base + incl - cnt;
   if (threadIdx.x == 0) {
-    chunk_sums[chunk] = tot;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    // (device-scope store + drained queue instead of a release fence -- which writes back the XCD L2 once per workgroup, bn_fuse.h)
+    __hip_atomic_store(&chunk_sums[chunk], tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const int t = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     s_last = (t == nchunks - 1);
     if (s_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
