@@ -148,8 +148,8 @@ _SIGS = {
     "btc_occ_loss_bwd_total": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, ci, ctypes.c_longlong, ctypes.c_float, vp, vp, vp, vp, vp]),
     "btc_dense_split_fwd": (ci, [vp, vp, ci, ci, ci, vp, vp, vp, vp]),
     "btc_dense_split_bwd": (ci, [vp, vp, vp, ci, ci, ci, vp, vp, vp]),
-    "btc_cat_pad_fwd": (ci, [vp, ci, vp, ci, ctypes.c_longlong, ci, vp, vp]),
-    "btc_cat_pad_bwd": (ci, [vp, ci, ctypes.c_longlong, vp, ci, vp, ci, vp]),
+    "btc_cat_pad_fwd": (ci, [vp, ci, vp, ci, ctypes.c_longlong, ci, ci, vp, vp]),
+    "btc_cat_pad_bwd": (ci, [vp, ci, ctypes.c_longlong, ci, vp, ci, vp, ci, vp]),
     "btc_sumsq2_ws_bytes": (sz, []),
     "btc_sumsq2_fwd": (ci, [vp, ctypes.c_longlong, ci, ctypes.c_double, vp, ctypes.c_longlong, ci, ctypes.c_double, vp, vp, sz, vp]),
     "btc_sumsq2_bwd": (ci, [vp, ctypes.c_longlong, ci, ctypes.c_float, vp, vp, ctypes.c_longlong, ci, ctypes.c_float, vp, vp, vp]),

@@ -67,6 +67,13 @@ class fixSparseConv3d(spconv.SparseConv3d):
         self.weight.data.fill_(defaultvalue)
 
 
+def _to_feature_dtype(x, dtype):
+    """the sparse tensor with its features in the backbone's FEATURE_DTYPE (a no-op for fp32 models and once the features are there)"""
+    if dtype is not None and x.features is not None and x.features.dtype != dtype and x.features.shape[1] % 16 == 0:
+        x.features = x.features.to(dtype)
+    return x
+
+
 def _strided(seq):
     """first sparse layer of a SparseSequential stage if it builds its own (strided / transposed / dilating) rulebook"""
     m = seq[0]
@@ -116,8 +123,10 @@ class VoxelBackBoneDeconv(nn.Module):
 
     def forward(self, batch_dict):
         voxel_features, voxel_coords = batch_dict['voxel_features'], batch_dict['voxel_coords'].int()
-        if self.feature_dtype is not None:
+        if self.feature_dtype is not None and voxel_features.shape[1] % 16 == 0:
             voxel_features = voxel_features.to(self.feature_dtype)
+        # (a 4-channel input stays fp32: the first layer computes in fp32 either way -- rounding its input to bf16, widening it again
+        # and rounding the result were three launches for nothing; the cast follows the first stage, _forward_stages)
         if self.y_shift > 0:
             voxel_features, voxel_coords = self.add_shift(voxel_features, voxel_coords)
         x = spconv.SparseConvTensor(features=voxel_features, indices=voxel_coords, spatial_shape=self.sparse_shape,
@@ -136,6 +145,7 @@ class VoxelBackBoneDeconv(nn.Module):
         ONE call measured no better -- 430 / 453 / 440 scenes/s against 438 / 458 / 455 per stage, round 4 -- and is not kept.)"""
         for stage in (self.conv1, self.conv2, self.conv3, self.deconv4, self.deconv5):
             x = stage(x)
+            x = _to_feature_dtype(x, self.feature_dtype)
         return x
 
     def prefetch_geometry(self, batch_dict, head=None):
@@ -420,8 +430,8 @@ class VoxelBackBone8xOcc(nn.Module):
 
     def forward(self, batch_dict):
         feats, coords = batch_dict['voxel_features'], batch_dict['voxel_coords'].int()
-        if self.feature_dtype is not None:
-            feats = feats.to(self.feature_dtype)
+        if self.feature_dtype is not None and feats.shape[1] % 16 == 0:
+            feats = feats.to(self.feature_dtype)     # (a 6-channel input stays fp32 through conv1, see VoxelBackBoneDeconv.forward)
         bs = batch_dict['batch_size']
         x = spconv.SparseConvTensor(features=feats, indices=coords, spatial_shape=self.sparse_shape, batch_size=bs)
         walk = self._walk_geometry(coords, bs, x.indice_dict)
@@ -433,7 +443,9 @@ class VoxelBackBone8xOcc(nn.Module):
         if FAST_STAGES and isinstance(walk, tuple) and walk[0] == "done":   # the blocking walk: every rulebook is there already
             ready = self._finish_walk(walk, x.indice_dict)
         merge_first = ready is not None and not (n_occ > 0 and self.occ_conv_exec[0])      # nothing between conv1 and conv1_combine
-        x1 = self._stages([self.conv1, self.conv1_combine], x, ready) if merge_first else self._stage(self.conv1, x, ready)
+        x1 = _to_feature_dtype(self._stage(self.conv1, x, ready), self.feature_dtype)
+        if merge_first:
+            x1 = self._stage(self.conv1_combine, x1, ready)
         occ = None
         if n_occ > 0:
             occ = spconv.SparseConvTensor(features=batch_dict["occ_voxel_features"], indices=coords,

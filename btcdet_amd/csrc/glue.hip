@@ -44,23 +44,25 @@ __global__ __launch_bounds__(256) void dense_split_bwd_k(const float* __restrict
   dfeat[(size_t)i * C + c] = v;
 }
 
-__global__ __launch_bounds__(256) void cat_pad_fwd_k(const float* __restrict__ a, int ca, const float* __restrict__ b, int cb, long long n, int cout,
-                                                     float* __restrict__ out) {
+template <typename T>
+__global__ __launch_bounds__(256) void cat_pad_fwd_k(const T* __restrict__ a, int ca, const T* __restrict__ b, int cb, long long n, int cout,
+                                                     T* __restrict__ out) {
   long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n * cout) return;
   const long long i = t / cout;
   const int c = (int)(t - i * cout);
-  out[t] = c < ca ? a[i * ca + c] : (c < ca + cb ? b[i * cb + (c - ca)] : 0.f);
+  out[t] = c < ca ? a[i * ca + c] : (c < ca + cb ? b[i * cb + (c - ca)] : (T)0);   // (the zero bit pattern is 0.0 in fp32 and in bf16)
 }
 
-__global__ __launch_bounds__(256) void cat_pad_bwd_k(const float* __restrict__ g, int cout, long long n, float* __restrict__ da, int ca,
-                                                     float* __restrict__ db, int cb) {
+template <typename T>
+__global__ __launch_bounds__(256) void cat_pad_bwd_k(const T* __restrict__ g, int cout, long long n, T* __restrict__ da, int ca,
+                                                     T* __restrict__ db, int cb) {
   long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const int cc = ca + cb;
   if (t >= n * cc) return;
   const long long i = t / cc;
   const int c = (int)(t - i * cc);
-  const float v = g[i * cout + c];
+  const T v = g[i * cout + c];
   if (c < ca) da[i * ca + c] = v;
   else db[i * cb + (c - ca)] = v;
 }
@@ -174,18 +176,26 @@ extern "C" int btc_dense_split_bwd(const float* grad_a, const float* grad_b, con
   return BTC_OK;
 }
 
-extern "C" int btc_cat_pad_fwd(const float* a, int ca, const float* b, int cb, long long n, int cout, float* out, void* stream) {
-  BTC_CHECK_ARG(ca >= 1 && cb >= 0 && cout >= ca + cb && n >= 0, "btc_cat_pad_fwd: bad sizes");
+extern "C" int btc_cat_pad_fwd(const void* a, int ca, const void* b, int cb, long long n, int cout, int elem_bytes, void* out, void* stream) {
+  BTC_CHECK_ARG(ca >= 1 && cb >= 0 && cout >= ca + cb && n >= 0 && (elem_bytes == 4 || elem_bytes == 2), "btc_cat_pad_fwd: bad sizes");
   if (n <= 0) return BTC_OK;
-  cat_pad_fwd_k<<<btc_cdiv(n * cout, 256), 256, 0, (hipStream_t)stream>>>(a, ca, b, cb, n, cout, out);
+  if (elem_bytes == 4)
+    cat_pad_fwd_k<unsigned><<<btc_cdiv(n * cout, 256), 256, 0, (hipStream_t)stream>>>((const unsigned*)a, ca, (const unsigned*)b, cb, n, cout, (unsigned*)out);
+  else
+    cat_pad_fwd_k<unsigned short><<<btc_cdiv(n * cout, 256), 256, 0, (hipStream_t)stream>>>((const unsigned short*)a, ca, (const unsigned short*)b, cb, n,
+                                                                                        cout, (unsigned short*)out);
   BTC_LAUNCH_CHECK();
   return BTC_OK;
 }
 
-extern "C" int btc_cat_pad_bwd(const float* grad, int cout, long long n, float* da, int ca, float* db, int cb, void* stream) {
-  BTC_CHECK_ARG(ca >= 1 && cb >= 0 && cout >= ca + cb && n >= 0, "btc_cat_pad_bwd: bad sizes");
+extern "C" int btc_cat_pad_bwd(const void* grad, int cout, long long n, int elem_bytes, void* da, int ca, void* db, int cb, void* stream) {
+  BTC_CHECK_ARG(ca >= 1 && cb >= 0 && cout >= ca + cb && n >= 0 && (elem_bytes == 4 || elem_bytes == 2), "btc_cat_pad_bwd: bad sizes");
   if (n <= 0) return BTC_OK;
-  cat_pad_bwd_k<<<btc_cdiv(n * (ca + cb), 256), 256, 0, (hipStream_t)stream>>>(grad, cout, n, da, ca, db, cb);
+  if (elem_bytes == 4)
+    cat_pad_bwd_k<unsigned><<<btc_cdiv(n * (ca + cb), 256), 256, 0, (hipStream_t)stream>>>((const unsigned*)grad, cout, n, (unsigned*)da, ca, (unsigned*)db, cb);
+  else
+    cat_pad_bwd_k<unsigned short><<<btc_cdiv(n * (ca + cb), 256), 256, 0, (hipStream_t)stream>>>((const unsigned short*)grad, cout, n, (unsigned short*)da,
+                                                                                             ca, (unsigned short*)db, cb);
   BTC_LAUNCH_CHECK();
   return BTC_OK;
 }

@@ -326,10 +326,10 @@ class OccHead3D(OccHeadTemplate):
         (w, bias), self._merged = self._merged, None
         from .spconv import ops
         rb = self._head_rulebook(x)
-        out = ops.indice_conv(x.features, w, bias, rb)
+        out = ops.indice_conv(x.features, w, bias, rb, keep_fp32=True)
         # -> the two dense maps (logits (B, nc, D, H, W), residuals) straight from the merged rows: one fill + one scatter launch
         # (ops.dense_split) where slicing, copying and densifying the two parts took six -- same values
-        if out.dtype != torch.float32:     # bf16 features: the 2 / 3-channel head computes in fp32 and rounds; the dense maps are fp32
+        if out.dtype != torch.float32:     # (a bf16 result: only if the head's channel counts ever allow the bf16 kernels; the dense maps are fp32)
             out = out.float()
         return ops.dense_split(out, x.indices, x.batch_size, x.spatial_shape, cls.out_channels)
 

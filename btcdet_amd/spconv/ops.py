@@ -856,24 +856,24 @@ def dense_split(features, indices, batch_size, spatial_shape, ca):
 
 
 class CatPadFunction(torch.autograd.Function):
-    """[a | b | zeros] along the channels in one launch each way (csrc/glue.hip); fp32 GPU tensors"""
+    """[a | b | zeros] along the channels in one launch each way (csrc/glue.hip); fp32 or bf16 GPU tensors of one dtype"""
 
     @staticmethod
     def forward(ctx, a, b, cout):
-        a, b = _f32c(a), _f32c(b)
+        a, b = a.contiguous(), b.contiguous()
         n, ca, cb = a.shape[0], a.shape[1], b.shape[1]
-        out = torch.empty((n, int(cout)), dtype=torch.float32, device=a.device)
-        check(lib().btc_cat_pad_fwd(ptr(a), ca, ptr(b), cb, n, int(cout), ptr(out), stream_ptr()), "btc_cat_pad_fwd")
-        ctx.meta = (n, ca, cb, int(cout))
+        out = torch.empty((n, int(cout)), dtype=a.dtype, device=a.device)
+        check(lib().btc_cat_pad_fwd(ptr(a), ca, ptr(b), cb, n, int(cout), a.element_size(), ptr(out), stream_ptr()), "btc_cat_pad_fwd")
+        ctx.meta = (n, ca, cb, int(cout), a.dtype)
         return out
 
     @staticmethod
     def backward(ctx, g):
-        n, ca, cb, cout = ctx.meta
-        g = _f32c(g)
-        da = torch.empty((n, ca), dtype=torch.float32, device=g.device)
-        db = torch.empty((n, cb), dtype=torch.float32, device=g.device)
-        check(lib().btc_cat_pad_bwd(ptr(g), cout, n, ptr(da), ca, ptr(db), cb, stream_ptr()), "btc_cat_pad_bwd")
+        n, ca, cb, cout, dt = ctx.meta
+        g = (g if g.dtype == dt else g.to(dt)).contiguous()
+        da = torch.empty((n, ca), dtype=dt, device=g.device)
+        db = torch.empty((n, cb), dtype=dt, device=g.device)
+        check(lib().btc_cat_pad_bwd(ptr(g), cout, n, g.element_size(), ptr(da), ca, ptr(db), cb, stream_ptr()), "btc_cat_pad_bwd")
         return da, db, None
 
 
@@ -883,7 +883,7 @@ def cat_features(a, b):
     it wants it and only pads its weight."""
     b = b.to(a.dtype)
     cc = a.shape[1] + b.shape[1]
-    if a.is_cuda and a.dtype == torch.float32 and a.dim() == 2 and a.shape[0] > 0 and pads_in_channels(cc):
+    if a.is_cuda and a.dtype in (torch.float32, torch.bfloat16) and a.dim() == 2 and a.shape[0] > 0 and pads_in_channels(cc):
         return CatPadFunction.apply(a, b, cc + _pad_amount(cc, a.dtype))
     return torch.cat((a, b), dim=1)
 
@@ -920,12 +920,15 @@ def _pad_in_channels(features, weight):
     return features, weight
 
 
-def indice_conv(features, weight, bias, rulebook, inverse=False):
+def indice_conv(features, weight, bias, rulebook, inverse=False, keep_fp32=False):
+    """keep_fp32: a layer that computes in fp32 under bf16 features (below) hands its fp32 result on as it is -- for a consumer that
+    wants fp32 anyway (the occupancy head's dense maps): no rounding launch here, no widening launch there"""
     features, weight = _pad_in_channels(features, weight)
     if features.dtype == torch.bfloat16 and (weight.shape[-2] % 16 or weight.shape[-1] % 16):
         # bf16 activations exist in the LDS-DMA kernel only (channel counts that are multiples of 16); the few other layers
         # (4 / 6 / 34 input channels, 2 / 3-channel heads) run in fp32 and round their result
-        return indice_conv(features.float(), weight, bias, rulebook, inverse).to(torch.bfloat16)
+        out = indice_conv(features.float(), weight, bias, rulebook, inverse)
+        return out if keep_fp32 else out.to(torch.bfloat16)
     if inverse:   # (inverse convs run on strided rulebooks: both maps exist)
         return SparseConvFunction.apply(features, weight, bias, rulebook.nbr_in, rulebook.nbr_out, rulebook.order_in, rulebook.order_out)
     return SparseConvFunction.apply(features, weight, bias, rulebook.nbr_out, rulebook.map_bwd, rulebook.order_out, rulebook.order_in)

@@ -380,9 +380,9 @@ int btc_dense_split_fwd(const float* feat, const int32_t* indices, int n, int Ca
 int btc_dense_split_bwd(const float* grad_a, const float* grad_b, const int32_t* indices, int n, int Ca, int Cb,
                         const int32_t* h_shape, float* dfeat, void* stream);
 /* out (n, cout) = [a (n, ca) | b (n, cb) | zeros]: the detection backbone's sparse_cat (spconv_backbone.py:869-873) together with the
- * zero channels the apply kernels want (34 -> 64); backward splits grad (n, cout) into da, db.  fp32. */
-int btc_cat_pad_fwd(const float* a, int ca, const float* b, int cb, long long n, int cout, float* out, void* stream);
-int btc_cat_pad_bwd(const float* grad, int cout, long long n, float* da, int ca, float* db, int cb, void* stream);
+ * zero channels the apply kernels want (34 -> 64 / 48); backward splits grad (n, cout) into da, db.  elem_bytes: 4 (fp32) | 2 (bf16). */
+int btc_cat_pad_fwd(const void* a, int ca, const void* b, int cb, long long n, int cout, int elem_bytes, void* out, void* stream);
+int btc_cat_pad_bwd(const void* grad, int cout, long long n, int elem_bytes, void* da, int ca, void* db, int cb, void* stream);
 /* out[0] = ka sum a^2 + kb sum b^2 over two tensors of fp32 (x_bf16 = 0) or bfloat16 (1) elements, fp64 accumulation in a fixed order
  * (b may be NULL with nb = 0); backward: da = a * (g[0] * ka2), db = b * (g[0] * kb2), the factor rounded to the tensor's type first.
  * The L2 stand-in loss of the heads behind the hot path (btcdet_amd/trainer.py stand_in_det_loss), not a reference operator.

@@ -2,7 +2,7 @@
 # round 5: the BatchNorm-statistics epilogue without its per-workgroup L2 write-back: fused == unfused tests, bench fp32 / bf16, kernel stats
 out=gpurun_out/r5g; mkdir -p $out
 cd /root/repo
-timeout 900 python -m pytest tests/test_hip_core.py tests/test_hip_split.py tests/test_hip_bf16.py tests/test_hip_bf16_mfma.py tests/test_hip_golden_full.py tests/test_hip_det_backbone.py tests/test_hip_prefetch.py tests/test_hip_stress.py -q -m gpu > $out/t.txt 2>&1; tail -3 $out/t.txt
+timeout 900 python -m pytest tests/test_hip_glue.py tests/test_hip_bf16.py tests/test_hip_bf16_mfma.py tests/test_hip_golden_full.py tests/test_hip_det_backbone.py tests/test_hip_pipeline.py tests/test_hip_prefetch.py tests/test_hip_borrow_canary.py -q -m gpu > $out/t.txt 2>&1; tail -3 $out/t.txt
 AB_STEPS=80 bash tools/ab_env.sh 2 "fp32:" > $out/ab.txt 2>&1
 for r in 1 2; do timeout 300 python bench.py --features bf16 --steps 80 --warmup 10 --no-cpu-baseline --no-roofline --no-extras 2>/dev/null | grep '^{' | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('bf16 run %.1f scenes/s %.3f ms' % (d['value'], d['ms_per_step']))" >> $out/ab.txt; done
 cat $out/ab.txt
