@@ -50,15 +50,18 @@ FP32_MFMA_PEAK_TF = 157.3   # same guide: fp32-input MFMA peak
 BF16_MFMA_PEAK_TF = 2500.0  # same guide: dense bf16 MFMA peak (AMD's 5 PF figure is 2:1 sparse)
 
 
-def pmc_traffic_per_launch():
-    """HBM bytes per conv_apply launch from the committed PMC passes (profiles/r02h_pmc.json: rocprofv3 --pmc FETCH_SIZE and
-    --pmc WRITE_SIZE in separate runs, FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md); PMC counters cannot be read
-    inside the timed process, so this is null when the file is absent"""
+def pmc_traffic_per_launch(waymo=False, bf=False):
+    """HBM bytes per conv_apply launch of this configuration from the committed PMC passes (profiles/r05_pmc*.json: rocprofv3 --pmc
+    FETCH_SIZE and --pmc WRITE_SIZE in separate runs of the same bench command, FETCH_SIZE doubled per the gfx950 note of
+    MI355X_MICROARCH.md); PMC counters cannot be read inside the timed process, so this is null when there is no pass of the
+    configuration on file"""
+    sfx = ("_waymo" if waymo else "") + ("_bf16" if bf else "")
+    names = ["r05_pmc%s.json" % sfx] + ([] if sfx else ["r04_pmc.json", "r03j_pmc.json", "r03_pmc.json", "r02h_pmc.json"])
     try:
-        name = next(n for n in ("r04_pmc.json", "r03j_pmc.json", "r03_pmc.json", "r02h_pmc.json") if os.path.exists(os.path.join(ROOT, "profiles", n)))
+        name = next(n for n in names if os.path.exists(os.path.join(ROOT, "profiles", n)))
         with open(os.path.join(ROOT, "profiles", name)) as f:
             return json.load(f)["conv_apply"]["hbm_bytes_per_launch"]
-    except (OSError, KeyError, ValueError):
+    except (StopIteration, OSError, KeyError, ValueError):
         return None
 
 
@@ -463,7 +466,7 @@ def main():
                 bf = args.features == "bf16"
                 tf = k["flops"] / (k["ms"] * 1e-3) / 1e12
                 mfma_peak = BF16_MFMA_PEAK_TF if bf else FP32_MFMA_PEAK_TF
-                traffic = None if (waymo or bf) else pmc_traffic_per_launch()
+                traffic = pmc_traffic_per_launch(waymo, bf)
                 avg_s = 1e-3 * k["ms"] / k["launches"]
                 # `bound`: algorithmic bytes (every gathered row counts, although most gathers are served by
                 # L2 / MALL) against the HBM peak, flops against the dense MFMA peak of the operand type, and -- from the committed PMC
@@ -526,7 +529,7 @@ def straggler_estimate():
     (tools/straggler.py -> profiles/*_straggler.json): the gradient all-reduce is a barrier, so a step takes as long as the
     slowest of the 8 ranks' batches; E[mean] / E[max of 8 independent draws].  None when the file is absent."""
     try:
-        name = next(n for n in ("r04_straggler.json", "r03j_straggler.json") if os.path.exists(os.path.join(ROOT, "profiles", n)))
+        name = next(n for n in ("r05_straggler.json", "r04_straggler.json", "r03j_straggler.json") if os.path.exists(os.path.join(ROOT, "profiles", n)))
         with open(os.path.join(ROOT, "profiles", name)) as f:
             d = json.load(f)
         return {"world": 8, "efficiency": d["predicted_eff_world8"], "source": "committed profile (not measured in this run)",

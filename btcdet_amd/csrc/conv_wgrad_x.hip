@@ -21,6 +21,9 @@
 // 32 s + 16 hh + 4 g + j, for BOTH operands (any permutation of the reduction index is fine as long as the two agree).
 // Results: fp32 sums in walk order per slab, slabs added in index order: deterministic; not the fp32 kernel's bit pattern (tolerances in
 // tests/test_hip_wgrad_x.py: MODE 1 against float64 no worse than the fp32 MFMA chain; MODE 0 exact products of the bf16 inputs).
+#include <type_traits>
+#include <utility>
+
 #include "btc_common.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -58,7 +61,22 @@ __device__ __forceinline__ bf16x8 frag_tr(const char* p) {
   return __builtin_bit_cast(bf16x8, v);
 }
 
-template <int MT, int NT, int KB, int PH, int MODE>
+template <int N, typename F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl<N>(f, std::make_integer_sequence<int, N>{});
+}
+
+// DEPTH: items of gathered rows in flight ahead of the products (register sets).  1: item t + 1 is loaded during item t's products, and
+// the top of item t + 1 waits for it.  2: item t + 2 is issued during item t (a second register set, NU more uint4), a gather has two
+// items to land.  Measured per layer (tools/wgrad_bench.py ALT=16=..): MODE 0 is 4 % faster over the step's 28 layers with two in flight
+// (the 210 K-row layers 10-17 %), MODE 1 is not (+1 %): its waves spend their issue slots on the split (SQ counters: the two waves of a
+// SIMD are issuing 92 % of the time, the matrix pipe is busy 26 %) -- halving the products, dropping two thirds of the fragment reads,
+// the contiguous operand's fetches or the gather's bytes each moved its total by < 10 % (profiles/r05_wgrad_x_experiments.txt).
+template <int MT, int NT, int KB, int PH, int MODE, int DEPTH>
 __global__ __launch_bounds__(256) void conv_wgrad_x(const void* __restrict__ gsrc, const void* __restrict__ csrc,
                                                     const int32_t* __restrict__ nbr, const int32_t* __restrict__ order, int n_rows, int K,
                                                     int Cg_all, int Cc_all, float* __restrict__ part, int swap) {
@@ -80,8 +98,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_x(const void* __restrict__ gsr
   constexpr int NV = (TMX * NOFF + 255) / 256;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* As = smem;                                     // [2][KB][NPL][TMX] rows of RS bytes
-  int32_t* s_nbr = (int32_t*)(As + 2 * ITEM);          // [3][TMX][NOFF]
-  int32_t* s_row = s_nbr + 3 * TMX * NOFF;             // [3][TMX]
+  constexpr int RING = (DEPTH == 2 && PH == 1) ? 4 : 3;   // map rows of tiles in LDS (DEPTH 2, one phase a tile: item t + 2 is tile i + 2)
+  int32_t* s_nbr = (int32_t*)(As + 2 * ITEM);          // [RING][TMX][NOFF]
+  constexpr int RROW = DEPTH == 2 ? RING + 1 : RING;   // rows of tiles (through `order`) in LDS: DEPTH 2 resolves them one tile ahead of the map
+  int32_t* s_row = s_nbr + RING * TMX * NOFF;          // [RROW][TMX]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g4 = lane >> 4, t16 = lane & 15;
   const int kg0 = blockIdx.y * NOFF;
@@ -116,13 +136,45 @@ __global__ __launch_bounds__(256) void conv_wgrad_x(const void* __restrict__ gsr
     }
   };
   auto store_map = [&](int i) {
-    int32_t* dn = s_nbr + (i % 3) * TMX * NOFF;
+    int32_t* dn = s_nbr + (i % RING) * TMX * NOFF;
 #pragma unroll
     for (int u = 0; u < NV; ++u) {
       const int e = u * 256 + tid;
       if (e < TMX * NOFF) dn[e] = nv[u];
     }
-    if (tid < TMX) s_row[(i % 3) * TMX + tid] = nrow;
+    if (tid < TMX) s_row[(i % RROW) * TMX + tid] = nrow;
+  };
+
+  // DEPTH 2: the same in two stages a barrier apart -- rows through `order` first, the map rows read them from LDS.  load_map() above
+  // follows order[] with a dependent load, i.e. a wait for EVERY load in flight (vector-memory loads return in order), the gathers
+  // issued ahead included: that wait would bring the walk back to one item in flight once a tile
+  auto load_rows = [&](int i) {
+    const int row0 = (blockIdx.x + i * gridDim.x) * TMX;
+    if (tid < TMX) nrow = (row0 + tid < n_rows) ? (order ? order[row0 + tid] : row0 + tid) : -1;
+  };
+  auto store_rows = [&](int i) {
+    if (tid < TMX) s_row[(i % RROW) * TMX + tid] = nrow;
+  };
+  auto load_map2 = [&](int i) {
+    const int32_t* rw = s_row + (i % RROW) * TMX;
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+      const int e = u * 256 + tid, r = e / NOFF, o = e - r * NOFF;
+      int v = -1;
+      if (e < TMX * NOFF && kg0 + o < K) {
+        const int gr = rw[r];
+        if (gr >= 0) v = nbr[(long long)gr * K + kg0 + o];
+      }
+      nv[u] = v;
+    }
+  };
+  auto store_map2 = [&](int i) {
+    int32_t* dn = s_nbr + (i % RING) * TMX * NOFF;
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+      const int e = u * 256 + tid;
+      if (e < TMX * NOFF) dn[e] = nv[u];
+    }
   };
 
   // ---- contiguous operand: 16 elements per tile and lane (slot order s, hh, j), in flight as loaded, split / packed at the tile's top
@@ -130,7 +182,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_x(const void* __restrict__ gsr
   unsigned short bnh[MODE ? 1 : 16];
   bf16x8 bh[2], bm[MODE ? 2 : 1], bl[MODE ? 2 : 1];
   auto load_b = [&](int i) {
-    const int32_t* rows = s_row + (i % 3) * TMX + 4 * g4;
+    const int32_t* rows = s_row + (i % RROW) * TMX + 4 * g4;
     int gr[16];
 #pragma unroll
     for (int u = 0; u < 16; ++u) gr[u] = rows[(u >> 2) * 16 + (u & 3)];   // u = 8 s + 4 hh + j -> tile row 32 s + 16 hh + 4 g + j
@@ -166,9 +218,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_x(const void* __restrict__ gsr
   // ---- gathered operand: registers -> (split ->) row-major bf16 image(s) in LDS
   constexpr int UPR = MODE ? MT * 4 : MT * 2;                  // 16-byte units per gathered row
   constexpr int NU = (KB * TMX * UPR + 255) / 256;             // units per thread and item
-  uint4 gq[NU];
-  auto load_g = [&](int i, int p) {
-    const int32_t* mp = s_nbr + (i % 3) * TMX * NOFF + p * KB;
+  uint4 gq[DEPTH][NU];
+  auto load_g = [&](int i, int p, auto set_c) {
+    constexpr int SET = decltype(set_c)::value;
+    const int32_t* mp = s_nbr + (i % RING) * TMX * NOFF + p * KB;
     int jj[NU];
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
@@ -181,10 +234,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_x(const void* __restrict__ gsr
       // absent neighbour (17 of 27 on submanifold levels): out-of-range offset, zeros, no traffic
       const unsigned off = jj[u] >= 0 ? ((unsigned)jj[u] * (unsigned)Cg_all + (unsigned)cg0) * (MODE ? 4u : 2u) + (unsigned)c * 16u : X_ABSENT;
       const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rg, off, 0, 0);
-      gq[u] = make_uint4(v.x, v.y, v.z, v.w);
+      gq[SET][u] = make_uint4(v.x, v.y, v.z, v.w);
     }
   };
-  auto store_g = [&](int buf) {
+  auto store_g = [&](int buf, auto set_c) {
+    constexpr int SET = decltype(set_c)::value;
     char* A = As + buf * ITEM;
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
@@ -193,19 +247,21 @@ __global__ __launch_bounds__(256) void conv_wgrad_x(const void* __restrict__ gsr
         char* d = A + kb * NPL * IMG + r * RS;
         if (MODE) {
           uint2 h, m, l;
-          split2(__uint_as_float(gq[u].x), __uint_as_float(gq[u].y), h.x, m.x, l.x);
-          split2(__uint_as_float(gq[u].z), __uint_as_float(gq[u].w), h.y, m.y, l.y);
+          split2(__uint_as_float(gq[SET][u].x), __uint_as_float(gq[SET][u].y), h.x, m.x, l.x);
+          split2(__uint_as_float(gq[SET][u].z), __uint_as_float(gq[SET][u].w), h.y, m.y, l.y);
           *reinterpret_cast<uint2*>(d + c * 8) = h;
           *reinterpret_cast<uint2*>(d + IMG + c * 8) = m;
           *reinterpret_cast<uint2*>(d + 2 * IMG + c * 8) = l;
         } else {
-          *reinterpret_cast<uint4*>(d + c * 16) = gq[u];
+          *reinterpret_cast<uint4*>(d + c * 16) = gq[SET][u];
         }
       }
     }
   };
 
-  if (nt_wg > 0) {
+  typedef std::integral_constant<int, 0> Set0;
+  typedef std::integral_constant<int, DEPTH - 1> Set1;
+  if (nt_wg > 0 && DEPTH == 1) {
     load_map(0);
     store_map(0);
     if (nt_wg > 1) {
@@ -214,54 +270,128 @@ __global__ __launch_bounds__(256) void conv_wgrad_x(const void* __restrict__ gsr
     }
     __syncthreads();
     load_b(0);
-    load_g(0, 0);
+    load_g(0, 0, Set0{});
+  }
+  if (nt_wg > 0 && DEPTH == 2) {
+    for (int j = 0; j < RROW - 1 && j < nt_wg; ++j) {
+      load_rows(j);
+      store_rows(j);
+    }
+    __syncthreads();
+    for (int j = 0; j < RING - 1 && j < nt_wg; ++j) {
+      load_map2(j);
+      store_map2(j);
+    }
+    __syncthreads();
+    load_b(0);
+    load_g(0, 0, Set0{});
+    if (PH > 1) load_g(0, 1, Set1{});
+    else if (nt_wg > 1) load_g(1, 0, Set1{});
   }
   int buf = 0;
-  for (int i = 0; i < nt_wg; ++i) {
-#pragma unroll
-    for (int p = 0; p < PH; ++p) {
-      store_g(buf);
-      if (p == 0) take_b();
-      if (PH > 1 ? (p == 1 && i + 2 < nt_wg) : (i >= 1 && i + 1 < nt_wg)) store_map(PH > 1 ? i + 2 : i + 1);
-      __syncthreads();
-      // ---- loads for the next item, in flight during this item's products
-      if (p + 1 < PH) {
-        load_g(i, p + 1);
-      } else if (i + 1 < nt_wg) {
-        load_b(i + 1);
-        load_g(i + 1, 0);
+  // ---- products of item (i, p) from LDS buffer `buf`
+  // The fragments of step t + 1 (a step = 32 rows of one accumulator tile) are read while step t's products issue: with one or two
+  // waves a SIMD nothing else covers the LDS latency (read -> wait -> six products -> read ... left the matrix pipe idle for most of
+  // an item: 3 full LDS waits per 12 products in the ISA)
+  // The fragments of step t + 1 (a step = 32 rows of one accumulator tile) are read before step t's products issue
+  auto products = [&](auto p_c) {
+    constexpr int p = decltype(p_c)::value;
+    constexpr int STEPS = 2 * TPP;
+    const char* A = As + buf * ITEM + lane_off;
+    bf16x8 fh[2], fm[MODE ? 2 : 1], fl[MODE ? 2 : 1];
+    auto read_step = [&](int t, int w) {
+      const int q = t >> 1, s2 = t & 1, l = q * 4 + wave;      // phase-local tile (kb, mt, nt), nt == wave % NT
+      const int mt = (l / NT) % MT, kb = l / (NT * MT);
+      const char* ap = A + kb * NPL * IMG + mt * 32 + 32 * s2 * RS;
+      fh[w] = frag_tr<RS>(ap);
+      if (MODE) {
+        fm[MODE ? w : 0] = frag_tr<RS>(ap + IMG);
+        fl[MODE ? w : 0] = frag_tr<RS>(ap + 2 * IMG);
       }
-      if (PH > 1 ? (p == 0 && i + 2 < nt_wg) : (i + 2 < nt_wg)) load_map(i + 2);
-      // ---- products of item (i, p)
-      const char* A = As + buf * ITEM + lane_off;
+    };
+    read_step(0, 0);
 #pragma unroll
-      for (int q = 0; q < TPP; ++q) {
-        const int l = q * 4 + wave;      // phase-local tile (kb, mt, nt), nt == wave % NT
-        const int mt = (l / NT) % MT, kb = l / (NT * MT);
-        const char* ap = A + kb * NPL * IMG + mt * 32;
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-          const bf16x8 ah = frag_tr<RS>(ap + 32 * s * RS);
-          if (MODE) {
-            const bf16x8 am = frag_tr<RS>(ap + IMG + 32 * s * RS);
-            const bf16x8 al = frag_tr<RS>(ap + 2 * IMG + 32 * s * RS);
-            // (issue order: no two consecutive products add to the same accumulator)
-            f32x4 c2 = acc[NC - 1][p * TPP + q], c1 = acc[NC > 1 ? 1 : 0][p * TPP + q], c0 = acc[0][p * TPP + q];
-            c2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[s], c2, 0, 0, 0);
-            c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bh[s], c1, 0, 0, 0);
-            c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[s], c0, 0, 0, 0);
-            c2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[MODE ? s : 0], c2, 0, 0, 0);
-            c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm[MODE ? s : 0], c1, 0, 0, 0);
-            c2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bm[MODE ? s : 0], c2, 0, 0, 0);
-            acc[NC - 1][p * TPP + q] = c2;
-            acc[NC > 1 ? 1 : 0][p * TPP + q] = c1;
-            acc[0][p * TPP + q] = c0;
-          } else {
-            acc[0][p * TPP + q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[s], acc[0][p * TPP + q], 0, 0, 0);
-          }
+    for (int t = 0; t < STEPS; ++t) {
+      const int q = t >> 1, s2 = t & 1, w = t & 1;
+      if (t + 1 < STEPS) read_step(t + 1, w ^ 1);
+      const bf16x8 ah = fh[w];
+      if (MODE) {
+        const bf16x8 am = fm[MODE ? w : 0], al = fl[MODE ? w : 0];
+        // (issue order: no two consecutive products add to the same accumulator)
+        f32x4 c2 = acc[NC - 1][p * TPP + q], c1 = acc[NC > 1 ? 1 : 0][p * TPP + q], c0 = acc[0][p * TPP + q];
+        c2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[s2], c2, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bh[s2], c1, 0, 0, 0);
+        c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[s2], c0, 0, 0, 0);
+        c2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[MODE ? s2 : 0], c2, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm[MODE ? s2 : 0], c1, 0, 0, 0);
+        c2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bm[MODE ? s2 : 0], c2, 0, 0, 0);
+        acc[NC - 1][p * TPP + q] = c2;
+        acc[NC > 1 ? 1 : 0][p * TPP + q] = c1;
+        acc[0][p * TPP + q] = c0;
+      } else {
+        acc[0][p * TPP + q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[s2], acc[0][p * TPP + q], 0, 0, 0);
+      }
+    }
+  };
+  if (DEPTH == 1) {
+    for (int i = 0; i < nt_wg; ++i) {
+      static_for<PH>([&](auto p_c) {
+        constexpr int p = decltype(p_c)::value;
+        store_g(buf, Set0{});
+        if (p == 0) take_b();
+        if (PH > 1 ? (p == 1 && i + 2 < nt_wg) : (i >= 1 && i + 1 < nt_wg)) store_map(PH > 1 ? i + 2 : i + 1);
+        __syncthreads();
+        // ---- loads for the next item, in flight during this item's products
+        if (p + 1 < PH) {
+          load_g(i, p + 1, Set0{});
+        } else if (i + 1 < nt_wg) {
+          load_b(i + 1);
+          load_g(i + 1, 0, Set0{});
         }
-      }
+        if (PH > 1 ? (p == 0 && i + 2 < nt_wg) : (i + 2 < nt_wg)) load_map(i + 2);
+        products(p_c);
+        buf ^= 1;
+      });
+    }
+  } else if (PH > 1) {
+    // register set of item (i, p): p & 1 (PH is even).  Issue order after the barrier = the order the top of the next items waits in
+    // (vector-memory loads return in order): contiguous operand of the next tile, map rows, then the gather two items ahead
+    for (int i = 0; i < nt_wg; ++i) {
+      static_for<PH>([&](auto p_c) {
+        constexpr int p = decltype(p_c)::value;
+        typedef std::integral_constant<int, (p & 1) ? DEPTH - 1 : 0> Set;
+        store_g(buf, Set{});
+        if (p == 0) take_b();
+        if (p == 1 && i + 2 < nt_wg) store_map2(i + 2);
+        if (p == 1 && i + 3 < nt_wg) store_rows(i + 3);
+        __syncthreads();
+        if (p == PH - 2 && i + 1 < nt_wg) load_b(i + 1);
+        if (p == 0 && i + 3 < nt_wg) load_rows(i + 3);
+        if (p == 0 && i + 2 < nt_wg) load_map2(i + 2);
+        if (p + 2 < PH) load_g(i, p + 2, Set{});
+        else if (i + 1 < nt_wg) load_g(i + 1, p + 2 - PH, Set{});
+        products(p_c);
+        buf ^= 1;
+      });
+    }
+  } else {
+    // one phase a tile: item = tile, register set = i & 1 (the loop is unrolled by two), map rows of four tiles (rows of five) in LDS
+    auto tile = [&](int i, auto set_c) {
+      store_g(buf, set_c);
+      take_b();
+      if (i >= 1 && i + 2 < nt_wg) store_map2(i + 2);
+      if (i >= 1 && i + 3 < nt_wg) store_rows(i + 3);
+      __syncthreads();
+      if (i + 1 < nt_wg) load_b(i + 1);
+      if (i + 4 < nt_wg) load_rows(i + 4);
+      if (i + 3 < nt_wg) load_map2(i + 3);
+      if (i + 2 < nt_wg) load_g(i + 2, 0, set_c);
+      products(std::integral_constant<int, 0>{});
       buf ^= 1;
+    };
+    for (int i = 0; i < nt_wg; i += 2) {
+      tile(i, Set0{});
+      if (i + 1 < nt_wg) tile(i + 1, Set1{});
     }
   }
   // slab of this workgroup: part[blockIdx.x][k][ci][co]; D layout of 16x16: col = lane & 15 (contiguous operand's channel),
@@ -287,20 +417,22 @@ __global__ __launch_bounds__(256) void conv_wgrad_x(const void* __restrict__ gsr
     }
 }
 
-template <int MT, int NT, int KB, int PH, int MODE>
+template <int MT, int NT, int KB, int PH, int MODE, int DEPTH>
 size_t lds_x() {
   constexpr int NPL = MODE ? 3 : 1;
-  return (size_t)2 * KB * NPL * TMX * (MT * 32 + 16) + (size_t)(3 * TMX * PH * KB + 3 * TMX) * sizeof(int32_t);
+  constexpr int RING = (DEPTH == 2 && PH == 1) ? 4 : 3;
+  constexpr int RROW = DEPTH == 2 ? RING + 1 : RING;
+  return (size_t)2 * KB * NPL * TMX * (MT * 32 + 16) + (size_t)(RING * TMX * PH * KB + RROW * TMX) * sizeof(int32_t);
 }
 
-template <int MT, int NT, int KB, int PH, int MODE>
+template <int MT, int NT, int KB, int PH, int MODE, int DEPTH>
 void launch_x(dim3 grid, hipStream_t stream, const void* g, const void* c, const int32_t* map, const int32_t* ord, int rows, int K, int cg_all,
               int cc_all, float* part, int swap) {
   static BtcPerDeviceOnce once;
   btc_once_per_device(once, [] {
-    (void)hipFuncSetAttribute((const void*)conv_wgrad_x<MT, NT, KB, PH, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_wgrad_x<MT, NT, KB, PH, MODE, DEPTH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   });
-  conv_wgrad_x<MT, NT, KB, PH, MODE><<<grid, 256, lds_x<MT, NT, KB, PH, MODE>(), stream>>>(g, c, map, ord, rows, K, cg_all, cc_all, part, swap);
+  conv_wgrad_x<MT, NT, KB, PH, MODE, DEPTH><<<grid, 256, lds_x<MT, NT, KB, PH, MODE, DEPTH>(), stream>>>(g, c, map, ord, rows, K, cg_all, cc_all, part, swap);
 }
 
 // (KB, PH) per tile shape; PH is halved when the launch has too few (tile, group, block) triples to fill the machine
@@ -361,7 +493,13 @@ int btc_launch_wgrad_x(int mode, const void* g, const void* c, const int32_t* ma
   int S = 1, ph = 1, nz = 1;
   const int groups = btc_wgrad_x_plan(mode, rows, K, cg, cc, &S, &ph, &nz);
   dim3 grid(S, groups, nz);
-#define X2(MT_, NT_, KB_, PH_, MODE_) launch_x<MT_, NT_, KB_, PH_, MODE_>(grid, stream, g, c, map, ord, rows, K, cg, cc, part, swap)
+  const int t_depth = btc_tune_get(BTC_TUNE_WGRAD_X_DEPTH);
+  const bool shallow = t_depth ? t_depth == 1 : mode == 1;   // default: two items in flight for bf16 activations, one for split fp32
+#define X2(MT_, NT_, KB_, PH_, MODE_)                                                                            \
+  do {                                                                                                           \
+    if (shallow) launch_x<MT_, NT_, KB_, PH_, MODE_, 1>(grid, stream, g, c, map, ord, rows, K, cg, cc, part, swap);  \
+    else launch_x<MT_, NT_, KB_, PH_, MODE_, 2>(grid, stream, g, c, map, ord, rows, K, cg, cc, part, swap);          \
+  } while (0)
 #define X(MT_, NT_, KB_, PH_, MODE_)                                \
   do {                                                              \
     if (ph == PH_) X2(MT_, NT_, KB_, PH_, MODE_);                   \

@@ -73,7 +73,7 @@ __device__ __forceinline__ float ld_elem(const void* p, long long i) {
   return ((const float*)p)[i];
 }
 
-// partial[block] = sum over the block's share of ka a^2 (+ kb b^2); the last block to arrive adds the partials in block order
+// partial[block] = sum over the block's share of ka a^2 (+ kb b^2); the last block to arrive adds the partials in a fixed order
 template <bool BFA, bool BFB>
 __global__ __launch_bounds__(256) void sumsq2_fwd_k(const void* __restrict__ a, long long na, double ka, const void* __restrict__ b, long long nb,
                                                     double kb, double* __restrict__ partial, int32_t* __restrict__ counter, float* __restrict__ out) {
@@ -129,11 +129,19 @@ __global__ __launch_bounds__(256) void sumsq2_fwd_k(const void* __restrict__ a, 
     s_last = (t == (int)gridDim.x - 1);
   }
   __syncthreads();
-  if (!s_last || threadIdx.x != 0) return;
+  if (!s_last) return;
+  // the last workgroup: all 256 threads walk the partials (thread t: blocks t, t + 256, ... in order), then the same fixed tree as
+  // above -- one thread reading up to 1024 partials one L2 round trip at a time took ~100 us, four times the pass over the data
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   double s = 0.0;
-  for (int g = 0; g < (int)gridDim.x; ++g) s += __hip_atomic_load(partial + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  out[0] = (float)s;
+  for (int g = threadIdx.x; g < (int)gridDim.x; g += 256) s += partial[g];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  out[0] = (float)((s_red[0] + s_red[1]) + (s_red[2] + s_red[3]));
   __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // zero on exit
 }
 

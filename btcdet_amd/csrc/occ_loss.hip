@@ -83,10 +83,21 @@ __global__ __launch_bounds__(256) void occ_loss_fwd(const float* __restrict__ lo
     __hip_atomic_store(&partial[(size_t)blockIdx.x * 4 + threadIdx.x], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   if (!last_block_l(counter)) return;
+  // the last workgroup: thread t sums quantity t % 4 over blocks t / 4, t / 4 + 64, ... in order, then a fixed tree over the 64 threads
+  // of each quantity (one thread walking every block's four partials was most of this launch)
+  {
+    const int q = threadIdx.x & 3;
+    double v = 0.0;
+    for (int g = threadIdx.x >> 2; g < (int)gridDim.x; g += 64) v += partial[(size_t)g * 4 + q];
+#pragma unroll
+    for (int o = 32; o >= 4; o >>= 1) v += __shfl_down(v, o, 64);   // lanes 0..3 of a wave: its 16 threads of quantity 0..3
+    __syncthreads();
+    if ((threadIdx.x & 63) < 4) s_red[threadIdx.x >> 6][q] = v;
+    __syncthreads();
+  }
   if (threadIdx.x == 0) {
-    double s[4] = {0, 0, 0, 0};
-    for (int g = 0; g < (int)gridDim.x; ++g)
-      for (int q = 0; q < 4; ++q) s[q] += partial[(size_t)g * 4 + q];
+    double s[4];
+    for (int q = 0; q < 4; ++q) s[q] = (s_red[0][q] + s_red[1][q]) + (s_red[2][q] + s_red[3][q]);
     const double nc = s[1] > 1.0 ? s[1] : 1.0, nr = s[3] > 1.0 ? s[3] : 1.0;   // clamp(sum w, min=1)
     out[0] = (float)(s[0] / nc * P.w_cls);
     out[1] = (float)(s[2] / nr * P.w_res);

@@ -150,6 +150,29 @@ def test_bf16_wgrad_on_the_matrix_pipe(cin, cout, kind, n_vox):
     assert e_new <= 4e-6
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("cin,cout,kind,n_vox", [(64, 64, "subm", 60000), (32, 32, "subm", 9000), (64, 32, "conv", 30000), (32, 64, "transpose", 5000),
+                                                 (128, 128, "subm", 9000), (48, 32, "subm", 30000), (32, 5, "subm", 60000), (16, 16, "subm", 3000), (64, 64, "subm", 2500)])
+def test_one_and_two_items_in_flight_give_the_same_bits(cin, cout, kind, n_vox, dtype):
+    """BTC_TUNE_WGRAD_X_DEPTH: the walk with one item of gathered rows in flight ahead of the products, and with two (a second register
+    set, map rows resolved in two stages, a deeper LDS ring of map rows): same sums in the same order -> identical bits.  Every
+    phase count the plans use (one phase a tile included: small launches halve PH) for both operand modes."""
+    from btcdet_amd._lib import check, lib
+    rng = np.random.default_rng(cin * 7 + cout + n_vox)
+    shape = (6, 30, 28) if kind == "transpose" else (12, 48, 44)
+    rb, feat, dout = _case(rng, cin, cout, kind, n_vox, shape)
+    feat, dout = feat.to(dtype), dout.to(dtype)
+    got = {}
+    try:
+        for depth in (1, 2):
+            check(lib().btc_tune_set(16, depth), "tune")
+            got[depth] = _wgrad(feat, dout, rb, cin, cout)
+    finally:
+        check(lib().btc_tune_set(16, 0), "tune")
+    assert bool(torch.isfinite(got[1]).all()) and torch.equal(got[1], got[2])
+    assert torch.equal(_wgrad(feat, dout, rb, cin, cout), got[1])      # and the built-in choice
+
+
 def test_two_call_form_equals_one_call_and_batches_layers():
     from btcdet_amd._lib import check, lib, ptr, stream_ptr
     rng = np.random.default_rng(3)

@@ -1,7 +1,7 @@
 #!/bin/bash
 # the measurement set of a round: bench lines (default / bf16 / Waymo shape / Waymo bf16), kernel statistics of the default and the
 # in-order schedule, the two PMC passes, the straggler estimate -> gpurun_out/<tag>/ (copy what is to be judged into profiles/)
-tag=${1:-r04z}
+tag=${1:-r05}
 mkdir -p gpurun_out/$tag
 cd /root/repo
 timeout 400 python bench.py > gpurun_out/$tag/bench.json 2> gpurun_out/$tag/bench.err
@@ -9,7 +9,16 @@ timeout 300 python bench.py --features bf16 --no-cpu-baseline --no-extras > gpur
 timeout 300 python bench.py --workload waymo --steps 40 --warmup 5 --no-cpu-baseline --no-extras > gpurun_out/$tag/bench_waymo.json 2> gpurun_out/$tag/bench_waymo.err
 timeout 300 python bench.py --workload waymo --features bf16 --steps 40 --warmup 5 --no-cpu-baseline --no-extras > gpurun_out/$tag/bench_waymo_bf16.json 2> gpurun_out/$tag/bench_waymo_bf16.err
 SKIP_BENCH=1 bash tools/gpu_prof.sh $tag > gpurun_out/$tag/prof.log 2>&1
+# kernel statistics of the in-order schedule for the other three configurations (bf16, Waymo shape, Waymo bf16)
+for cfg in "bf16|--features bf16 --steps 100 --warmup 10" "waymo|--workload waymo --steps 40 --warmup 5" "waymo_bf16|--workload waymo --features bf16 --steps 40 --warmup 5"; do
+  name=${cfg%%|*}; extra=${cfg#*|}
+  (cd /tmp && export TMPDIR=/tmp && BTC_SCHEDULE=in_order timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_${tag}_$name -o bench -- python /root/repo/bench.py $extra --no-cpu-baseline --no-roofline --no-extras > /root/repo/gpurun_out/$tag/serial_${name}_prof.json 2> /root/repo/gpurun_out/$tag/serial_${name}_prof.err)
+  find /tmp/prof_${tag}_$name -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} gpurun_out/$tag/serial_${name}_kernel_stats.csv
+done
 bash tools/gpu_pmc.sh $tag > gpurun_out/$tag/pmc.log 2>&1
+bash tools/gpu_pmc.sh $tag "--features bf16" _bf16 >> gpurun_out/$tag/pmc.log 2>&1
+bash tools/gpu_pmc.sh $tag "--workload waymo" _waymo >> gpurun_out/$tag/pmc.log 2>&1
+bash tools/gpu_pmc.sh $tag "--workload waymo --features bf16" _waymo_bf16 >> gpurun_out/$tag/pmc.log 2>&1
 timeout 300 python tools/straggler.py 64 gpurun_out/$tag/straggler.json > gpurun_out/$tag/straggler.log 2>&1
 bash tools/gpu_full_heads_prof.sh > gpurun_out/$tag/full_heads.log 2>&1; cp gpurun_out/full_heads/tail_full.txt gpurun_out/$tag/full_heads_tail.txt 2>/dev/null
 for f in bench bench_bf16 bench_waymo bench_waymo_bf16; do
@@ -23,5 +32,6 @@ except Exception as e:
     print("$f failed", e)
 PY
 done
-tail -3 gpurun_out/$tag/pmc.log
+grep -h "^{" gpurun_out/$tag/pmc.log | cut -c1-600
 tail -3 gpurun_out/$tag/straggler.log
+timeout 1100 python -m pytest tests -m gpu -x -q > gpurun_out/$tag/pytest_gpu.log 2>&1; tail -3 gpurun_out/$tag/pytest_gpu.log

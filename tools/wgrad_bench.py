@@ -26,6 +26,7 @@ ops.PROFILE = ops.LaunchProfile(); ops.CAPTURE = []
 step(batches[0]); torch.cuda.synchronize()
 cap, ops.CAPTURE, ops.PROFILE = ops.CAPTURE, None, None
 L = lib()
+ALT = tuple(int(v) for v in os.environ.get("ALT", "18=1").split("="))   # the tuning key = value of the second column (ALT=16=1: one item in flight)
 
 
 def timed(fn, reps=10):
@@ -37,7 +38,7 @@ def timed(fn, reps=10):
     return e0.elapsed_time(e1) / reps * 1e3
 
 
-print("%7s %7s %3s %4s %4s %8s | %9s %6s %6s | fp32-pipe kernel (BTC_TUNE_WGRAD_X=1): %7s  rel. diff" % ("n_res", "n_src", "K", "cin", "cout", "pairs", "us", "GB/s", "TF/s", "us"))
+print("%7s %7s %3s %4s %4s %8s | %9s %6s %6s | second column (tune %d = %d; default: the fp32-pipe kernels): %7s  rel. diff" % ("n_res", "n_src", "K", "cin", "cout", "pairs", "us", "GB/s", "TF/s", ALT[0], ALT[1], "us"))
 tot = np.zeros(2)
 for (f, w, b, mf, mb) in cap:
     cin, cout, K = w.shape[-2], w.shape[-1], mf.shape[1]
@@ -53,11 +54,11 @@ for (f, w, b, mf, mb) in cap:
     fn = lambda: check(wg(ptr(f), ptr(g), ptr(mf), n_res, pmb, n_src, K, cin, cout, ptr(dw), ptr(ws), wsb, stream_ptr()), "w")
     ts = [timed(fn)]
     ref = dw.clone()
-    check(L.btc_tune_set(18, 1), "t")   # the fp32-pipe kernels (conv_wgrad_rows_p / conv_wgrad_partial_p)
+    check(L.btc_tune_set(ALT[0], ALT[1]), "t")   # default: the fp32-pipe kernels (conv_wgrad_rows_p / conv_wgrad_partial_p)
     ts.append(timed(fn))
-    check(L.btc_tune_set(18, 0), "t")
+    check(L.btc_tune_set(ALT[0], 0), "t")
     diff = float((ref - dw).abs().max() / (dw.abs().max() + 1e-30))
     tot += np.array(ts)
     nbytes, flops = (2 if bf else 4) * pairs * (cin + cout) + 4 * K * cin * cout, 2 * pairs * cin * cout
     print("%7d %7d %3d %4d %4d %8d | %9.1f %6.0f %6.2f | %46.1f  %.1e" % (n_res, n_src, K, cin, cout, pairs, ts[0], nbytes / ts[0] / 1e3, flops / ts[0] / 1e6, ts[1], diff))
-print("totals us: %.0f; fp32-pipe kernels %.0f" % tuple(tot))
+print("totals us: %.0f; second column %.0f" % tuple(tot))
