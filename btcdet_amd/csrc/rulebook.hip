@@ -349,6 +349,126 @@ __global__ __launch_bounds__(RB_T) void rb_mark_b(Level in, long long in_ncell, 
     }
 }
 
+// Marks of SEVERAL levels from the chain's input rows in ONE launch (round 5): a run of strided CONV-mode layers, each reading the level
+// the one before built (an encoder: the detection branch's conv2 .. conv_out).  Marking is monotone -- a level is a set, bits are only
+// ever set -- so the levels need no barrier between them, only a rule for WHO carries a cell on to the next level: the thread whose
+// atomicOr set the cell's bit (the returned word says which of its bits were new).  Every active cell of level j then has exactly one
+// owner, which marks the cells IT reaches at level j + 1 (one axis of one cell: the contiguous range [ceil((c + p - K + 1) / s),
+// floor((c + p) / s)] clipped to the grid, dilation 1) and descends into those it set first: the work per level is cells x box, what the
+// level-by-level launches do, without their launch boundaries.  (Marking every level from every input ROW instead -- boxes composed per
+// axis -- is correct too and was 158 us a launch: tens of thousands of threads test and OR the same few words of the deep levels.)
+// Transposed layers are left to rb_mark_b (a decoder level is 8 x its input: the queues would not hold a tile's share).
+__device__ __forceinline__ unsigned long long rb_hash64(unsigned long long k) {
+  k ^= k >> 33;
+  k *= 0xff51afd7ed558ccdULL;
+  k ^= k >> 29;
+  return k;
+}
+
+constexpr int MARKM_MAX = 6;      // levels per launch
+
+struct MarkMulti {
+  int n;
+  int lines[MARKM_MAX];   // bound on the (z, y) lines of one cell's box at that level
+  BtcGeom g[MARKM_MAX];
+  Level out[MARKM_MAX];
+  // the chain's input level is probed through a hash (its rows come in voxelizer order): filled here too when keys != NULL (rb_hash_insert's job)
+  unsigned long long* keys;
+  int32_t* vals;
+  unsigned long long mask;
+  Level l0;               // shape / vol of level 0 (cell index of a row)
+};
+
+__device__ __forceinline__ bool box_axis(const BtcGeom& g, int j, int c, int* lo, int* hi) {   // a cell of the input level -> its range at the output level
+  const int a = c + g.p[j] - g.k[j] + 1, s = g.s[j];
+  const int olo = a <= 0 ? 0 : (s == 1 ? a : (s == 2 ? (a + 1) >> 1 : (a + s - 1) / s));
+  int ohi = s == 1 ? c + g.p[j] : (s == 2 ? (c + g.p[j]) >> 1 : (c + g.p[j]) / s);
+  if (ohi >= g.out_shape[j]) ohi = g.out_shape[j] - 1;
+  *lo = olo;
+  *hi = ohi;
+  return olo <= ohi;
+}
+
+// The walk of a workgroup's MARKM_TILE input rows is breadth first: generation j = the cells of level j the workgroup's threads own, in
+// an LDS queue; all threads share a generation's (cell, line of its box) units, newly owned cells go to the next generation's queue.
+// (One thread walking its row's subtree depth first -- two dependent L2 round trips per word, level after level -- took 203 us a launch.)
+// A generation cannot outgrow its queue: what MARKM_TILE rows reach at a level is at most MARKM_TILE x the box of one ROW there, and
+// the host ends the run where that bound passes MARKM_QCAP (stride-2 encoders keep 2 cells an axis: 512 entries).
+constexpr int MARKM_TILE = 64;    // (32 and 64 rows a workgroup measure the same, 256 is 2.4x slower)
+constexpr int MARKM_QCAP = 2048;
+
+__device__ __forceinline__ unsigned long long mq_pack(int b, int z, int y, int x) {
+  return ((unsigned long long)(unsigned)b << 56) | ((unsigned long long)(unsigned)z << 40) | ((unsigned long long)(unsigned)y << 20) | (unsigned long long)(unsigned)x;
+}
+
+__global__ __launch_bounds__(RB_T) void rb_mark_multi(const int4* __restrict__ idx, int n, MarkMulti M) {
+  __shared__ unsigned long long s_q[2][MARKM_QCAP];
+  __shared__ int s_cnt[2];
+  const int tid = threadIdx.x;
+  const int r0 = blockIdx.x * MARKM_TILE;
+  if (tid == 0) {
+    s_cnt[0] = n - r0 < MARKM_TILE ? n - r0 : MARKM_TILE;
+    s_cnt[1] = 0;
+  }
+  if (tid < MARKM_TILE && r0 + tid < n) {
+    const int4 c = idx[r0 + tid];
+    s_q[0][tid] = mq_pack(c.x, c.y, c.z, c.w);
+  }
+  __syncthreads();
+  for (int lv = 0; lv < M.n; ++lv) {
+    const int cur = lv & 1, nxt = cur ^ 1;
+    const int cnt = s_cnt[cur];
+    if (cnt == 0) break;   // (block-uniform)
+    const BtcGeom& g = M.g[lv];
+    const Level& L = M.out[lv];
+    const int lb = M.lines[lv];
+    for (int u = tid; u < cnt * lb; u += RB_T) {
+      const int it = u / lb, ln = u - it * lb;
+      const unsigned long long q = s_q[cur][it];
+      const int b = (int)(q >> 56), z = (int)((q >> 40) & 0xFFFF), y = (int)((q >> 20) & 0xFFFFF), x = (int)(q & 0xFFFFF);
+      int zl, zh, yl, yh, xl, xh;
+      if (!box_axis(g, 0, z, &zl, &zh) || !box_axis(g, 1, y, &yl, &yh) || !box_axis(g, 2, x, &xl, &xh)) continue;
+      const int ny = yh - yl + 1, lz = ln / ny, ly = ln - lz * ny;
+      if (lz > zh - zl) continue;
+      const int oz = zl + lz, oy = yl + ly;
+      const long long line = lvl_cell(L, b, oz, oy, 0);
+      const long long first = line + xl, last = line + xh;
+      for (long long w = first >> 5; w <= (last >> 5); ++w) {
+        const int b0 = w == (first >> 5) ? (int)(first & 31) : 0, b1 = w == (last >> 5) ? (int)(last & 31) : 31;
+        const unsigned bits = (b1 == 31 ? 0xFFFFFFFFu : ((1u << (b1 + 1)) - 1u)) & ~((1u << b0) - 1u);
+        // (no read in front of the atomic: a device-scope access is a round trip past the XCD's L2 either way, and this one is on the
+        // generation's critical path -- 47 -> 43 us a launch)
+        unsigned mine = bits & ~atomicOr(&L.words[w], bits);
+        if (lv + 1 >= M.n) continue;   // the last level of the run: nobody to carry it on to
+        while (mine) {
+          const int bit = __ffs(mine) - 1;
+          mine &= mine - 1;
+          const int ox = (int)((w << 5) + bit - line);
+          const int pos = atomicAdd(&s_cnt[nxt], 1);
+          if (pos < MARKM_QCAP) s_q[nxt][pos] = mq_pack(b, oz, oy, ox);   // (always: the host's bound)
+        }
+      }
+    }
+    __syncthreads();
+    if (tid == 0) {
+      s_cnt[cur] = 0;
+      if (s_cnt[nxt] > MARKM_QCAP) s_cnt[nxt] = MARKM_QCAP;
+    }
+    __syncthreads();
+  }
+  if (M.keys && tid < MARKM_TILE && r0 + tid < n) {   // cell -> row of the input level (as rb_hash_insert)
+    const int4 c = idx[r0 + tid];
+    const unsigned long long key = (unsigned long long)lvl_cell(M.l0, c.x, c.y, c.z, c.w) + 1ull;
+    unsigned long long slot = rb_hash64(key) & M.mask;
+    while (true) {
+      const unsigned long long prev = atomicCAS(&M.keys[slot], 0ull, key);
+      if (prev == 0ull || prev == key) break;
+      slot = (slot + 1) & M.mask;
+    }
+    M.vals[slot] = r0 + tid;
+  }
+}
+
 __device__ __forceinline__ int rb_wave_incl_scan(int v) {
   const int lane = threadIdx.x & 63;
 #pragma unroll
@@ -490,12 +610,6 @@ __global__ __launch_bounds__(RB_T) void rb_emit_all(const LevelSet S) {
 }
 
 // ---- 64-bit-key hash of an arbitrary (unsorted) input level: key = cell + 1, 0 = empty (one memset clears bitmaps and hash)
-__device__ __forceinline__ unsigned long long rb_hash64(unsigned long long k) {
-  k ^= k >> 33;
-  k *= 0xff51afd7ed558ccdULL;
-  k ^= k >> 29;
-  return k;
-}
 
 __global__ __launch_bounds__(RB_T) void rb_hash_insert(const int4* __restrict__ idx, int n, Level L, unsigned long long mask,
                                                        unsigned long long* __restrict__ keys, int32_t* __restrict__ vals) {
@@ -1074,6 +1188,40 @@ extern "C" int btc_chain_levels(const int32_t* indices, int n0, int batch, const
   if (rc) return rc;
   BTC_CHECK_ARG(ws_bytes >= W.total_bytes, "btc_chain_levels: workspace too small");
   BTC_HIP(hipMemsetAsync(ws, 0, W.zero_bytes, stream));
+  // the run of CONV-mode strided layers that starts at level 0 is marked by ONE launch from the input rows (rb_mark_multi), which fills
+  // the input level's hash as well; `composed[i]` = layer i's level is covered by it
+  bool composed[BTC_CHAIN_MAX_LAYERS] = {false};
+  MarkMulti M;
+  M.n = 0;
+  M.keys = nullptr;
+  M.vals = nullptr;
+  M.mask = 0;
+  if (n0 > 0 && btc_tune_get(BTC_TUNE_RB_MARK_MULTI) != 1) {
+    int at = 0;   // the level the run has reached
+    int size[3] = {1, 1, 1};   // bound on what ONE input row reaches at that level, per axis (a range of `size` cells maps onto
+                               // at most floor((size - 1 + K - 1) / s) + 1 cells)
+    int members[MARKM_MAX];
+    for (int i = 0; i < n_layers && M.n < MARKM_MAX; ++i) {
+      const BtcChainLayer& l = layers[i];
+      if (l.kind != 1) continue;
+      if (P.lvl_in[i] != at) continue;          // (a layer that reads an earlier level: not part of the run, but does not end it either)
+      if (l.mode != BTC_MODE_CONV || l.d[0] != 1 || l.d[1] != 1 || l.d[2] != 1 || l.s[0] < 1 || l.s[1] < 1 || l.s[2] < 1) break;
+      int nsz[3];
+      for (int j = 0; j < 3; ++j) nsz[j] = (size[j] - 1 + l.k[j] - 1) / l.s[j] + 1;
+      if ((long long)MARKM_TILE * nsz[0] * nsz[1] * nsz[2] > MARKM_QCAP) break;
+      for (int j = 0; j < 3; ++j) size[j] = nsz[j];
+      M.g[M.n] = geom_of(l);
+      M.out[M.n] = W.lv[P.lvl_out[i]];
+      M.lines[M.n] = ((l.k[0] - 1) / l.s[0] + 1) * ((l.k[1] - 1) / l.s[1] + 1);
+      members[M.n++] = i;
+      at = P.lvl_out[i];
+    }
+    if (M.n >= 2) {   // (a single level: rb_mark's per-tile path is the same work)
+      for (int q = 0; q < M.n; ++q) composed[members[q]] = true;
+    } else {
+      M.n = 0;
+    }
+  }
   if (P.need_hash && n0 > 0) {
     // level 0's grid is the input shape of the first layer that runs on it
     int first = -1;
@@ -1083,11 +1231,20 @@ extern "C" int btc_chain_levels(const int32_t* indices, int n0, int batch, const
     rc = level_layout(batch, layers[first].in_shape, &l0);
     if (rc) return rc;
     Level L0 = make_level(l0, layers[first].in_shape, nullptr, nullptr, nullptr);
-    rb_hash_insert<<<btc_cdiv(n0, RB_T), RB_T, 0, stream>>>((const int4*)indices, n0, L0, W.hash_cap - 1, W.keys, W.vals);
+    if (M.n > 0) {
+      M.keys = W.keys;
+      M.vals = W.vals;
+      M.mask = W.hash_cap - 1;
+      M.l0 = L0;
+    } else {
+      rb_hash_insert<<<btc_cdiv(n0, RB_T), RB_T, 0, stream>>>((const int4*)indices, n0, L0, W.hash_cap - 1, W.keys, W.vals);
+      BTC_LAUNCH_CHECK();
+    }
+  }
+  if (M.n > 0) {
+    rb_mark_multi<<<btc_cdiv(n0, MARKM_TILE), RB_T, 0, stream>>>((const int4*)indices, n0, M);
     BTC_LAUNCH_CHECK();
   }
-  // mark every level (level 0's rows drive the first; every later level is marked from its input level's bitmap), then ONE scan launch
-  // and ONE emit launch for all of them
   LevelSet S;
   S.n = 0;
   long long scan_blocks = 0;
@@ -1095,7 +1252,9 @@ extern "C" int btc_chain_levels(const int32_t* indices, int n0, int batch, const
     if (layers[i].kind != 1) continue;
     const int li = P.lvl_in[i], lo = P.lvl_out[i];
     const BtcGeom g = geom_of(layers[i]);
-    if (li == 0) {
+    if (composed[i]) {
+      // marked above
+    } else if (li == 0) {
       if (n0 > 0) {
         rb_mark<<<mark_grid(n0), RB_T, 0, stream>>>((const int4*)indices, n0, nullptr, g, W.lv[lo], 0);
         BTC_LAUNCH_CHECK();

@@ -63,13 +63,40 @@ def _check_chain(idx, B, shape, chain):
     return rbs
 
 
+@pytest.fixture(params=[0, 1], ids=["composed_marks", "one_launch_per_level"])
+def mark_mode(request):
+    """BTC_TUNE_RB_MARK_MULTI: the leading run of strided conv layers marked by ONE launch from the input rows (boxes composed per axis,
+    round 5), or every level by its own launch -- both must give the oracle's levels"""
+    from btcdet_amd._lib import lib
+    assert lib().btc_tune_set(19, request.param) == 0
+    yield request.param
+    lib().btc_tune_set(19, 0)
+
+
 @pytest.mark.parametrize("shape,n,B", [((9, 40, 60), 9000, 2), ((9, 40, 60), 300, 3), ((5, 12, 300), 4000, 2), ((17, 64, 64), 20000, 1)])
-def test_chain_rulebooks_small_grids(shape, n, B):
+def test_chain_rulebooks_small_grids(shape, n, B, mark_mode):
     rng = np.random.default_rng(n + shape[2])
     _check_chain(_random_indices(rng, n, B, shape), B, shape, CHAIN)
 
 
-def test_chain_rulebooks_kitti_occupancy_and_detection_grids():
+# encoder runs the composed marks cover end to end: stride 1 / 2 / 3, even kernels, asymmetric padding, a (3, 1, 1) tail, cells on every
+# face of the grid (a full small grid), a run that outgrows the box bound (four stride-1 layers: the last is marked from its bitmap)
+ENCODERS = [
+    [(3, 2, 1, "conv", "a"), (3, 2, 1, "conv", "b"), (3, 2, (0, 1, 1), "conv", "c"), ((3, 1, 1), (2, 1, 1), 0, "conv", "d")],
+    [(2, 2, 0, "conv", "a"), (3, 1, 1, "conv", "b"), ((3, 3, 2), (3, 2, 2), (1, 0, 1), "conv", "c")],
+    [(3, 1, 1, "conv", "a"), (3, 1, 0, "conv", "b"), (3, 1, 1, "conv", "c"), (3, 1, 1, "conv", "d")],
+    [(3, 2, 1, "conv", "a"), (3, 1, 0, "subm", "s"), (3, 2, 1, "conv", "b"), (3, 2, 1, "transpose", "u"), (3, 2, 1, "conv", "c")],
+]
+
+
+@pytest.mark.parametrize("chain", ENCODERS)
+@pytest.mark.parametrize("shape,n,B", [((25, 31, 45), 5000, 2), ((27, 6, 5), 120, 1), ((29, 20, 70), 40, 3)])
+def test_encoder_runs(chain, shape, n, B, mark_mode):
+    rng = np.random.default_rng(n + len(chain))
+    _check_chain(_random_indices(rng, n, B, shape), B, shape, chain)
+
+
+def test_chain_rulebooks_kitti_occupancy_and_detection_grids(mark_mode):
     from btcdet_amd import synth
     b = synth.make_batch([31, 32])
     og = orc.VoxelGeneratorV2(synth.KITTI_OCC_VOXEL, synth.KITTI_OCC_RANGE, 12, 20000)
