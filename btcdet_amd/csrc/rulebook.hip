@@ -32,7 +32,7 @@ namespace {
 constexpr int RB_T = 256;
 constexpr int RB_BLK = 8;           // words per rank block (one 32-byte sector)
 constexpr int RB_CHUNK = 256;       // blocks per chunk: one thread per block in rb_scan
-constexpr int RB_MAX_JOBS = 12;
+constexpr int RB_MAX_JOBS = 17;      // (a chain of the hot path is 13-14 jobs: one launch; the table travels in the kernel arguments, 4 KB at most)
 
 struct Level {
   unsigned* words;
@@ -679,6 +679,7 @@ struct Jobs {
   int count;
   Job j[RB_MAX_JOBS];
 };
+static_assert(sizeof(Jobs) <= 4096, "rb_fill's job table must fit the kernel argument segment");
 
 // one axis of a probe: coordinate c of the walked row + kernel offset kv -> coordinate in the probed level
 __device__ __forceinline__ bool probe_axis(const Job& J, int j, int c, int kv, int* o) {

@@ -268,6 +268,11 @@ int btc_scan_exclusive_i32(const int32_t* in, int32_t* out, long long n, int32_t
   }
   int nblocks = (int)((n + SCAN_TILE - 1) / SCAN_TILE);
   int32_t* block_sums = (int32_t*)ws;
+  if (nblocks == 1) {   // one tile: the fused kernel's block 0 reads no block sums at all
+    scan_final_fused<<<1, SCAN_THREADS, 0, stream>>>(in, out, n, block_sums, total);
+    BTC_LAUNCH_CHECK();
+    return BTC_OK;
+  }
   scan_block_reduce<<<nblocks, SCAN_THREADS, 0, stream>>>(in, n, block_sums);
   BTC_LAUNCH_CHECK();
   if (nblocks <= SCAN_FUSE_BLOCKS) {   // (in may alias out: a block reads its own tile before it writes it, and block_sums is a separate buffer)
