@@ -1207,6 +1207,9 @@ extern "C" int btc_chain_levels(const int32_t* indices, int n0, int batch, const
       if (l.kind != 1) continue;
       if (P.lvl_in[i] != at) continue;          // (a layer that reads an earlier level: not part of the run, but does not end it either)
       if (l.mode != BTC_MODE_CONV || l.d[0] != 1 || l.d[1] != 1 || l.d[2] != 1 || l.s[0] < 1 || l.s[1] < 1 || l.s[2] < 1) break;
+      // a queue entry packs (batch, z, y, x) into 8 + 16 + 20 + 20 bits: grids or batches beyond that keep the launch-per-level marks
+      if (batch > 255 || l.in_shape[0] >= (1 << 16) || l.in_shape[1] >= (1 << 20) || l.in_shape[2] >= (1 << 20) ||
+          l.out_shape[0] >= (1 << 16) || l.out_shape[1] >= (1 << 20) || l.out_shape[2] >= (1 << 20)) break;
       int nsz[3];
       for (int j = 0; j < 3; ++j) nsz[j] = (size[j] - 1 + l.k[j] - 1) / l.s[j] + 1;
       if ((long long)MARKM_TILE * nsz[0] * nsz[1] * nsz[2] > MARKM_QCAP) break;
