@@ -23,20 +23,17 @@ struct BnShape {
 // a workgroup's partial sums are published with device-scope (sc1, write-through) stores: they are at the coherence point once the
 // storing wave's vector-memory queue has drained -- no agent-scope release fence, i.e. no write-back of the XCD L2's dirty lines (all
 // the activations the previous kernels wrote) once per workgroup (MI355X_MICROARCH.md, handoff-flag: `sc1` payload -> vmcnt(0) -> flag)
-__device__ __forceinline__ void st_partial(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_partial(double* p, double v) { btc_st_agent(p, v); }
 
 // last-arriver election (placement independent: sc1 partials, drained -> ticket -> acquire)
 __device__ __forceinline__ bool last_block(int32_t* counter) {
   __shared__ int s_last;
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every wave's partials have left its queue before the workgroup's ticket (btc_common.h)
   __syncthreads();
-  if (threadIdx.x == 0) {
-    int t = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    s_last = (t == (int)gridDim.x - 1);
-  }
+  if (threadIdx.x == 0) s_last = (btc_ticket_take(counter) == (int)gridDim.x - 1);
   __syncthreads();
   if (!s_last) return false;
-  if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  if (threadIdx.x == 0) btc_ticket_acquire();
   __syncthreads();
   return true;
 }
@@ -50,15 +47,15 @@ __device__ __forceinline__ void reduce_partials(const double* __restrict__ parti
     double av[8], bv[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-      av[u] = partial[((size_t)(g + u * rpi) * 2 + 0) * C + c];
-      bv[u] = partial[((size_t)(g + u * rpi) * 2 + 1) * C + c];
+      av[u] = btc_ld_agent(&partial[((size_t)(g + u * rpi) * 2 + 0) * C + c]);
+      bv[u] = btc_ld_agent(&partial[((size_t)(g + u * rpi) * 2 + 1) * C + c]);
     }
     a += ((av[0] + av[1]) + (av[2] + av[3])) + ((av[4] + av[5]) + (av[6] + av[7]));
     b += ((bv[0] + bv[1]) + (bv[2] + bv[3])) + ((bv[4] + bv[5]) + (bv[6] + bv[7]));
   }
   for (; g < G; g += rpi) {
-    a += partial[((size_t)g * 2 + 0) * C + c];
-    b += partial[((size_t)g * 2 + 1) * C + c];
+    a += btc_ld_agent(&partial[((size_t)g * 2 + 0) * C + c]);
+    b += btc_ld_agent(&partial[((size_t)g * 2 + 1) * C + c]);
   }
 }
 
@@ -408,7 +405,7 @@ __global__ __launch_bounds__(BN_T) void col_sum(const float* __restrict__ x, BnS
     const int c = c0 + (tid % S.cpow), rr = tid / S.cpow;
     double a = 0.0;
     if (c < S.C)
-      for (int g = rr; g < (int)gridDim.x; g += S.rpi) a += partial[(size_t)g * S.C + c];
+      for (int g = rr; g < (int)gridDim.x; g += S.rpi) a += btc_ld_agent(&partial[(size_t)g * S.C + c]);
     s_a[tid] = a;
     __syncthreads();
     if (rr == 0 && c < S.C) {

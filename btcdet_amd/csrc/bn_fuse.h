@@ -89,12 +89,11 @@ __device__ __forceinline__ void bn_fuse_finish(const BnFuse& bn, int* s_flag, do
     // i.e. of every conv result tile written a moment ago -- ONCE PER WORKGROUP: 2-6 us each, ~430 us of the 13 K-workgroup launches
     // of the bf16-operand kernel on the 210 K-row level, which is how it was found.
     const int total = (int)(gridDim.x * gridDim.y * gridDim.z);
-    const int t = __hip_atomic_fetch_add(bn.counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    *s_flag = (t == total - 1);
+    *s_flag = (btc_ticket_take(bn.counter) == total - 1);   // (the protocol in one place: btc_common.h)
   }
   __syncthreads();
   if (!*s_flag) return;
-  if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  if (tid == 0) btc_ticket_acquire();
   __syncthreads();
   auto publish = [&](int c, double a, double b) {
     const double mean = a / bn.N;
@@ -116,8 +115,8 @@ __device__ __forceinline__ void bn_fuse_finish(const BnFuse& bn, int* s_flag, do
     if (g < G)
       for (int s = g; s < bn.nslots; s += G) {
         double* p = bn.slots + ((size_t)s * 2) * BN_FUSE_CMAX + c;
-        a += __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        b += __hip_atomic_load(p + BN_FUSE_CMAX, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        a += btc_ld_agent(p);
+        b += btc_ld_agent(p + BN_FUSE_CMAX);
         p[0] = 0.0;
         p[BN_FUSE_CMAX] = 0.0;
       }
@@ -138,8 +137,8 @@ __device__ __forceinline__ void bn_fuse_finish(const BnFuse& bn, int* s_flag, do
 #pragma unroll 8
       for (int s = 0; s < bn.nslots; ++s) {
         double* p = bn.slots + ((size_t)s * 2) * BN_FUSE_CMAX + c;
-        a += __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        b += __hip_atomic_load(p + BN_FUSE_CMAX, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        a += btc_ld_agent(p);
+        b += btc_ld_agent(p + BN_FUSE_CMAX);
         p[0] = 0.0;
         p[BN_FUSE_CMAX] = 0.0;
       }

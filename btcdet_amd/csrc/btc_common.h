@@ -37,6 +37,34 @@ void btc_set_error(const char* fmt, ...);
     }                                                                             \
   } while (0)
 
+// ---- last-arriver reductions: ONE statement of the protocol (bn.hip, bn_fuse.h, rulebook.hip rb_scan, occ_loss.hip, glue.hip sumsq2) ----
+// producers : publish their partial results with agent-scope relaxed stores / atomics (btc_st_agent, unsafeAtomicAdd: `sc1` operations,
+//             performed at the device's coherence point, never left dirty in one XCD's L2), then btc_ticket_take(): drain the wave's
+//             vector-memory queue (s_waitcnt vmcnt(0)) and take a relaxed agent-scope ticket;
+// consumer  : the workgroup that draws the last ticket calls btc_ticket_acquire() (agent-scope acquire fence) and reads every partial
+//             with btc_ld_agent (agent-scope atomic load: never served from a stale line of its own XCD's L2).
+// There is deliberately NO agent-scope release fence on the producer side: on gfx950 it is `buffer_wbl2 sc1`, a write-back of the XCD
+// L2's dirty lines -- every activation the previous kernels wrote -- once per workgroup (2-6 us each).
+// That the payload is visible once vmcnt has drained rests on the sc1 write-through behaviour MI355X_MICROARCH.md documents for this
+// target ("handoff-flag: sc1 payload -> vmcnt(0) -> sc1 flag"), not on the HSA memory model -- hence the guard: another target must
+// re-derive it (or put the release fence back).  tests/test_hip_core.py::test_last_arriver_reductions_stress repeats every such
+// reduction on grids that span all eight XCDs, behind kernels that leave the L2s dirty, against float64 sums made by torch.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "the fence-free last-arriver protocol (btc_ticket_take) is derived for gfx950's sc1 write-through stores only"
+#endif
+#if defined(__HIPCC__)
+template <class T>
+__device__ __forceinline__ void btc_st_agent(T* p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <class T>
+__device__ __forceinline__ T btc_ld_agent(const T* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// the calling thread's ticket (0 .. total-1)
+__device__ __forceinline__ int btc_ticket_take(int32_t* counter) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  return __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void btc_ticket_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
+#endif
+
 // tuning overrides (btc_tune_set): 0 = built-in policy
 #define BTC_TUNE_KEYS 24
 int btc_tune_get(int key);

@@ -72,7 +72,7 @@ __device__ __forceinline__ void static_for(F&& f) {
 
 // DEPTH: items of gathered rows in flight ahead of the products (register sets).  1: item t + 1 is loaded during item t's products, and
 // the top of item t + 1 waits for it.  2: item t + 2 is issued during item t (a second register set, NU more uint4), a gather has two
-// items to land.  Measured per layer (tools/wgrad_bench.py ALT=16=..): MODE 0 is 4 % faster over the step's 28 layers with two in flight
+// items to land.  Measured per layer (tools/wgrad_bench.py ALT=20=..): MODE 0 is 4 % faster over the step's 28 layers with two in flight
 // (the 210 K-row layers 10-17 %), MODE 1 is not (+1 %): its waves spend their issue slots on the split (SQ counters: the two waves of a
 // SIMD are issuing 92 % of the time, the matrix pipe is busy 26 %) -- halving the products, dropping two thirds of the fragment reads,
 // the contiguous operand's fetches or the gather's bytes each moved its total by < 10 % (profiles/r05_wgrad_x_experiments.txt).

@@ -123,18 +123,16 @@ __global__ __launch_bounds__(256) void sumsq2_fwd_k(const void* __restrict__ a, 
   __syncthreads();
   if (threadIdx.x == 0) {
     // (device-scope store + drained queue instead of a release fence: no write-back of the XCD L2 once per workgroup, see bn_fuse.h)
-    __hip_atomic_store(partial + blockIdx.x, s_red[0] + s_red[1] + s_red[2] + s_red[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const int t = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    s_last = (t == (int)gridDim.x - 1);
+    btc_st_agent(partial + blockIdx.x, s_red[0] + s_red[1] + s_red[2] + s_red[3]);
+    s_last = (btc_ticket_take(counter) == (int)gridDim.x - 1);
   }
   __syncthreads();
   if (!s_last) return;
   // the last workgroup: all 256 threads walk the partials (thread t: blocks t, t + 256, ... in order), then the same fixed tree as
   // above -- one thread reading up to 1024 partials one L2 round trip at a time took ~100 us, four times the pass over the data
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  btc_ticket_acquire();
   double s = 0.0;
-  for (int g = threadIdx.x; g < (int)gridDim.x; g += 256) s += partial[g];
+  for (int g = threadIdx.x; g < (int)gridDim.x; g += 256) s += btc_ld_agent(partial + g);
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
   __syncthreads();

@@ -21,13 +21,10 @@ __device__ __forceinline__ bool last_block_l(int32_t* counter) {
   __shared__ int s_last;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  if (threadIdx.x == 0) {   // (the partials were stored device-scope and the queues are drained: no release fence, see csrc/bn_fuse.h)
-    int t = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    s_last = (t == (int)gridDim.x - 1);
-  }
+  if (threadIdx.x == 0) s_last = (btc_ticket_take(counter) == (int)gridDim.x - 1);   // (the protocol: btc_common.h)
   __syncthreads();
   if (!s_last) return false;
-  if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  if (threadIdx.x == 0) btc_ticket_acquire();
   __syncthreads();
   return true;
 }
@@ -80,7 +77,7 @@ __global__ __launch_bounds__(256) void occ_loss_fwd(const float* __restrict__ lo
   __syncthreads();
   if (threadIdx.x < 4) {
     double v = s_red[0][threadIdx.x] + s_red[1][threadIdx.x] + s_red[2][threadIdx.x] + s_red[3][threadIdx.x];
-    __hip_atomic_store(&partial[(size_t)blockIdx.x * 4 + threadIdx.x], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    btc_st_agent(&partial[(size_t)blockIdx.x * 4 + threadIdx.x], v);
   }
   if (!last_block_l(counter)) return;
   // the last workgroup: thread t sums quantity t % 4 over blocks t / 4, t / 4 + 64, ... in order, then a fixed tree over the 64 threads
@@ -88,7 +85,7 @@ __global__ __launch_bounds__(256) void occ_loss_fwd(const float* __restrict__ lo
   {
     const int q = threadIdx.x & 3;
     double v = 0.0;
-    for (int g = threadIdx.x >> 2; g < (int)gridDim.x; g += 64) v += partial[(size_t)g * 4 + q];
+    for (int g = threadIdx.x >> 2; g < (int)gridDim.x; g += 64) v += btc_ld_agent(&partial[(size_t)g * 4 + q]);
 #pragma unroll
     for (int o = 32; o >= 4; o >>= 1) v += __shfl_down(v, o, 64);   // lanes 0..3 of a wave: its 16 threads of quantity 0..3
     __syncthreads();

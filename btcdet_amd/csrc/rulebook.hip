@@ -505,11 +505,9 @@ __device__ __forceinline__ void scan_chunk(const Level& L, int32_t* __restrict__
   if (blk < L.nblk) L.bprefix[blk] = base + incl - cnt;
   if (threadIdx.x == 0) {
     // (device-scope store + drained queue instead of a release fence -- which writes back the XCD L2 once per workgroup, bn_fuse.h)
-    __hip_atomic_store(&chunk_sums[chunk], tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const int t = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    s_last = (t == nchunks - 1);
-    if (s_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    btc_st_agent(&chunk_sums[chunk], tot);
+    s_last = (btc_ticket_take(counter) == nchunks - 1);
+    if (s_last) btc_ticket_acquire();
   }
   __syncthreads();
   if (!s_last) return;
@@ -517,7 +515,7 @@ __device__ __forceinline__ void scan_chunk(const Level& L, int32_t* __restrict__
   int carry = 0;
   for (int c0 = 0; c0 < nchunks; c0 += RB_T) {
     const int c = c0 + threadIdx.x;
-    const int v = c < nchunks ? __hip_atomic_load(&chunk_sums[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+    const int v = c < nchunks ? btc_ld_agent(&chunk_sums[c]) : 0;
     const int inc = rb_wave_incl_scan(v);
     __syncthreads();
     if (lane == 63) s_wave[wave] = inc;

@@ -1112,6 +1112,9 @@ int launch_apply(const float* feat, const float* W, const float* bias, const int
     int wgs = btc_cdiv(n_tiles16, WS_WAVES);
     if (wgs > 256) wgs = 256;
     size_t lds = ws_lds_bytes(K, Cred, nt);
+    // the statistics epilogue's last arriver shares the slot sums through 16 + 16 bytes x threads of (by then dead) LDS
+    // (bn_fuse_finish's s_part): few offsets x few channels -- K = 8 with 4 input channels is 10 KB -- would leave it short
+    if (bn.slots && lds < 16 + (size_t)16 * WS_WAVES * 64) lds = 16 + (size_t)16 * WS_WAVES * 64;
     static BtcPerDeviceOnce once;
     btc_once_per_device(once, [] {
       (void)hipFuncSetAttribute((const void*)conv_apply_ws<1, TRANS_W>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1386,7 +1389,9 @@ static int wgrad_impl(const float* feat, const float* dout, const int32_t* nbr_o
   // in `ws`, dW untouched -- or 0: dW is complete (no rows: zeros)
   hipStream_t stream = (hipStream_t)stream_;
   BTC_CHECK_ARG(K >= 1 && Cin >= 1 && Cout >= 1 && n_out >= 0, "btc_conv_wgrad: bad sizes");
-  const int n_feat = n_in;   // rows of `feat` when the caller says so (n_in >= 0), with or without the backward map
+  // rows of `feat`: n_in when the backward map comes with it, or when a caller without one states a positive count; a legacy call that
+  // passes NULL and 0 (the argument used to be ignored without a map) leaves it unknown -> the fp32-pipe kernels, which need no bound
+  const int n_feat = (nbr_in || n_in > 0) ? n_in : -1;
   if (!nbr_in) n_in = -1;
   BTC_CHECK_ARG(ws_bytes >= btc_conv_wgrad_ws_bytes(n_out, K, Cin, Cout, n_in), "btc_conv_wgrad: workspace too small");
   long long count = (long long)K * Cin * Cout;

@@ -218,6 +218,11 @@ class SparseSequential(SparseModule):
                             i += int(relu)
                         else:
                             input.features = module(f)
+                    elif isinstance(module, nn.SyncBatchNorm) and module.training and f is not None and f.is_cuda:
+                        # a torch SyncBatchNorm (what convert_sync_batchnorm puts in place of a layer it cannot mark: affine=False,
+                        # momentum=None) on a rank WITHOUT rows at this layer: the other ranks enter its collectives, so this one must
+                        # too (torch's SyncBatchNorm takes a 0-row batch); skipping it hangs the job
+                        input.features = module(f)
                 else:
                     input = module(input)
         return input

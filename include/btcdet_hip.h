@@ -69,7 +69,7 @@ int btc_version(void);
 #define BTC_TUNE_SPLIT 14 /* host bindings: 1 = never take the split-operand kernel (conv_apply_g's exact fmaf chain everywhere) */
 #define BTC_TUNE_APPLY_STAGES 13 /* conv_apply_g: depth of the LDS ring (3..8; 0 = built-in policy) */
 #define BTC_TUNE_WGRAD_X 18 /* weight gradient on the bf16 matrix pipe (conv_wgrad_x.hip): 0 = where supported, 1 = never (the fp32-pipe kernels) */
-#define BTC_TUNE_WGRAD_X_DEPTH 16 /* conv_wgrad_x: items of gathered rows in flight ahead of the products: 0 = built-in (2 for bf16 activations, 1 for split fp32), 1, 2 (same bits) */
+#define BTC_TUNE_WGRAD_X_DEPTH 20 /* (key 16 is retired: it named the deleted in-kernel z-split reduction) conv_wgrad_x: items of gathered rows in flight ahead of the products: 0 = built-in (2 for bf16 activations, 1 for split fp32), 1, 2 (same bits) */
 #define BTC_TUNE_RB_MARK_MULTI 19 /* chain rulebooks: 1 = mark every level by its own launch (rb_mark / rb_mark_b) instead of one launch for the leading run of strided conv layers (cross-check: same levels) */
 #define BTC_TUNE_APPLY_DEBUG 3 /* timing experiments only (WRONG results): 1 = no MFMA phase, 2 = no loads in the main loop */
 int btc_tune_set(int key, int value);
@@ -326,7 +326,7 @@ int btc_conv_wgrad_ordered(int bf16_act, const void* feat, const void* dout, con
  * without rows: zeros).  btc_wgrad_reduce_multi adds the slabs of up to any number of such jobs in ONE launch per
  * BTC_WGRAD_MULTI_MAX jobs (host arrays of device pointers / sizes): dWs[j][e] = sum_s parts[j][s * counts[j] + e] in slab order --
  * the same sums, in the same order, as the one-call entry points.  `ws` must stay untouched until that launch has run.
- * Row counts: n_in >= 0 is the row count of `feat` also when nbr_in is NULL; with it the walk may run on the bf16 matrix pipe
+ * Row counts: n_in > 0 is the row count of `feat` also when nbr_in is NULL (NULL with 0 = unknown); with it the walk may run on the bf16 matrix pipe
  * (csrc/conv_wgrad_x.hip: bf16 activations as stored; fp32 activations as three exact bf16 pieces, six products per pair, unless
  * BTC_TUNE_SPLIT = 1 or BTC_TUNE_WGRAD_X = 1), whose 32-bit gather offsets need both operands under 4 GB -- larger operands, or an
  * unknown row count, take the fp32-pipe kernels. */

@@ -452,6 +452,80 @@ def test_compiled_binding_and_ctypes_binding_agree(dtype):
         assert a.dtype == b.dtype and torch.equal(a, b)
 
 
+def test_last_arriver_reductions_stress():
+    """the fence-free last-arriver protocol (csrc/btc_common.h btc_ticket_take: sc1 partials -> drained queue -> relaxed ticket; consumer:
+    acquire + agent-scope loads) on grids that span all eight XCDs, every launch behind a kernel that leaves the L2s full of dirty lines,
+    60 rounds with fresh data: column sums, BatchNorm statistics forward / backward (the separate-pass kernels), and the two-tensor
+    sum of squares against float64 sums made by torch.  A partial read stale, or a ticket overtaking its payload, shows as a wrong sum
+    (ADVICE round 5)."""
+    from btcdet_amd.spconv import fused_bn
+    from btcdet_amd.trainer import MeanSquare2
+    g = torch.Generator(device=dev()).manual_seed(7)
+    N, C = 150000, 32
+    dirty = torch.empty((64 << 20) // 4, dtype=torch.float32, device=dev())
+    for it in range(60):
+        x = torch.randn((N, C), generator=g, device=dev()) * (1.0 + it % 5) + 0.25 * it
+        dy = torch.randn((N, C), generator=g, device=dev())
+        dirty.fill_(float(it))                                                    # 64 MB of dirty lines across the XCDs' L2s
+        cs = fused_bn.col_sum(x)
+        dirty.add_(1.0)
+        y, stats = fused_bn.bn_forward(x, None, None, None, None, None, True, 0.01, 1e-3, True)
+        dirty.add_(1.0)
+        dx, dgamma, dbeta = fused_bn.bn_backward(x, y, dy, None, stats, True, True)
+        dirty.add_(1.0)
+        ms = MeanSquare2.apply(x, 1.0, dy, 3.0)
+        x64, dy64 = x.double(), dy.double()
+        np.testing.assert_allclose(cs.cpu().numpy(), x64.sum(0).cpu().numpy(), rtol=2e-6, atol=2e-3)
+        mean, var = x64.mean(0), x64.var(0, unbiased=False)
+        np.testing.assert_allclose(stats[0].cpu().numpy(), mean.cpu().numpy(), rtol=2e-6, atol=1e-6)
+        np.testing.assert_allclose(stats[1].cpu().numpy(), torch.rsqrt(var + 1e-3).cpu().numpy(), rtol=2e-6)
+        xh = (x64 - mean) * torch.rsqrt(var + 1e-3)
+        gm = dy64 * (xh > 0)
+        np.testing.assert_allclose(dbeta.cpu().numpy(), gm.sum(0).cpu().numpy(), rtol=1e-5, atol=2e-3)
+        np.testing.assert_allclose(dgamma.cpu().numpy(), (gm * xh).sum(0).cpu().numpy(), rtol=1e-5, atol=2e-3)
+        ref = (x64 * x64).mean() + 3.0 * (dy64 * dy64).mean()
+        assert abs(float(ms) - float(ref)) <= 2e-6 * float(ref)
+
+
+def test_conv_epilogue_batch_statistics_few_offsets_few_channels():
+    """a stride-2 kernel-2 layer with 4 input channels (K = 8) takes the weight-stationary kernel with only ~10 KB of panel + map LDS:
+    the statistics epilogue's last arriver needs 16 + 16 B x 1024 threads of it (the launch now reserves that much) --
+    mean / rstd / running statistics equal the separate statistics pass, slots left zeroed, two calls in a row agree"""
+    from btcdet_amd import _lib
+    from btcdet_amd.spconv import fused_bn, ops
+    L = _lib.lib()
+    rng = np.random.default_rng(84)
+    shape, B, cin, cout = (8, 40, 48), 2, 4, 16
+    idx = rand_indices(rng, 9000, B, shape)
+    rb = ops.build_rulebook(torch.from_numpy(idx).to(dev()), B, shape, 2, 2, 0, 1, 0, False, False)
+    m = rb.nbr_out.shape[0]
+    assert rb.nbr_out.shape[1] == 8 and m >= 2048          # (>= 2048 rows: the weight-stationary kernel's range)
+    feat = torch.from_numpy(rng.standard_normal((idx.shape[0], cin)).astype(np.float32)).to(dev())
+    w = torch.from_numpy((rng.standard_normal((8, cin, cout)) / np.sqrt(cin)).astype(np.float32)).to(dev())
+    gamma = torch.from_numpy(rng.uniform(0.5, 1.5, cout).astype(np.float32)).to(dev())
+    beta = torch.from_numpy(rng.uniform(-0.3, 0.3, cout).astype(np.float32)).to(dev())
+    outs = []
+    for tune in (0, 1, 0):
+        rm, rv = torch.zeros(cout, device=dev()), torch.ones(cout, device=dev())
+        nbt = torch.zeros((), dtype=torch.long, device=dev())
+        assert L.btc_tune_set(12, tune) == 0
+        try:
+            x, y, stats = fused_bn.conv_bn_forward(feat, w, None, rb.nbr_out, None, gamma, beta, rm, rv, nbt, 0.01, 1e-3, True)
+            torch.cuda.synchronize()
+        finally:
+            L.btc_tune_set(12, 0)
+        outs.append((x, y, stats, rm, rv, int(nbt)))
+    assert bool((fused_bn.fuse_ws(feat.device) == 0).all())
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][0], ops.indice_conv(feat, w, None, rb))
+    for a, b in ((outs[0], outs[1]), (outs[0], outs[2])):
+        assert a[5] == b[5] == 1
+        for i, tol in ((2, 1e-7), (3, 1e-8), (4, 1e-8)):
+            np.testing.assert_allclose(a[i].cpu().numpy(), b[i].cpu().numpy(), rtol=2e-6, atol=tol)
+        np.testing.assert_allclose(a[1].cpu().numpy(), b[1].cpu().numpy(), rtol=1e-5, atol=1e-5)
+    ref = torch.nn.functional.batch_norm(outs[0][0], None, None, gamma, beta, True, 0.0, 1e-3).relu()
+    np.testing.assert_allclose(outs[0][1].cpu().numpy(), ref.cpu().numpy(), rtol=2e-5, atol=2e-5)
+
+
 @pytest.mark.parametrize("cin,cout,n,dtype", [(4, 16, 6000, "f32"), (16, 16, 3000, "f32"), (64, 128, 900, "f32"), (32, 32, 120000, "f32"), (20, 150, 700, "f32"),
                                                (34, 32, 5000, "f32"), (64, 64, 5000, "bf16"), (64, 64, 12000, "bf16"), (32, 32, 30000, "bf16"),
                                                (64, 128, 9000, "bf16"), (32, 16, 5000, "bf16"), (16, 32, 5000, "bf16")])

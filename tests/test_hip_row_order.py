@@ -123,13 +123,13 @@ def test_ordered_wgrad(bf):
         # rows through `order` must give the same bits as the direct one
         try:
             for depth in (1, 2):
-                check(lib.btc_tune_set(16, depth), "tune")
+                check(lib.btc_tune_set(20, depth), "tune")
                 dw = torch.full((K, cin, cout), float("nan"), device="cuda")
                 check(lib.btc_conv_wgrad_ordered(bf, ptr(feat), ptr(dout), ptr(rb.nbr_out), rb.n_out, ptr(rb.nbr_in), rb.n_in, ptr(o_out), ptr(o_in), K,
                                                  cin, cout, ptr(dw), ptr(ws), wsb, sp()), "btc_conv_wgrad_ordered")
                 np.testing.assert_array_equal(dw.cpu().numpy(), res[1])
         finally:
-            check(lib.btc_tune_set(16, 0), "tune")
+            check(lib.btc_tune_set(20, 0), "tune")
         scale = np.abs(res[0]).max()
         assert np.abs(res[1] - res[0]).max() <= 2e-6 * scale * np.sqrt(rb.n_out / 64.0) + 1e-30   # fp32 summation order only
 

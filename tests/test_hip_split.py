@@ -456,31 +456,6 @@ def test_split_kernel_exponent_range_of_activations():
         assert e_s.max() <= 1.5 * e_x.max() + 2e-8 and np.sqrt((e_s ** 2).mean()) <= 1.2 * np.sqrt((e_x ** 2).mean()), name
 
 
-def test_in_kernel_slab_reduction_gives_the_same_bits():
-    """BTC_TUNE_SPLIT_REDUCE = 1: the z-split partial slabs added by the tile's last workgroup (ticket in the scratch head) instead of
-    the split_reduce launch -- same summation order, same bits, and the ticket area is left zeroed"""
-    from btcdet_amd import _lib
-    from btcdet_amd.spconv import ops
-    L = _lib.lib()
-    rng = np.random.default_rng(5)
-    shape, B, cin, cout = (10, 40, 40), 2, 128, 128
-    idx = rand_indices(rng, 6000, B, shape)
-    (o_idx, o_out, o_in, o_sh), rb = _rb_both(idx, B, shape, (3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 1, 1), "subm")
-    n = o_out.shape[0]
-    assert 2500 <= n < 10000
-    f = torch.from_numpy(rng.standard_normal((n, cin)).astype(np.float32)).to(dev())
-    w = torch.from_numpy((rng.standard_normal((3, 3, 3, cin, cout)) / np.sqrt(cin)).astype(np.float32)).to(dev())
-    b = torch.from_numpy(rng.standard_normal(cout).astype(np.float32)).to(dev())
-    outs = []
-    for mode in (0, 1, 1, 0):
-        assert L.btc_tune_set(16, mode) == 0
-        try:
-            outs.append(ops.indice_conv(f, w, b, rb).clone())
-        finally:
-            L.btc_tune_set(16, 0)
-    assert all(torch.equal(outs[0], o) for o in outs[1:])
-
-
 @pytest.mark.parametrize("cin,cout,n_pts", [(64, 64, 3500), (64, 64, 7000), (64, 64, 16000), (256, 128, 6000), (64, 32, 26000), (32, 32, 26000)])
 def test_loader_waves_give_the_same_bits(cin, cout, n_pts):
     """BTC_TUNE_SPLIT_LOADERS: 1 = the product waves issue their own LDS-DMA pieces, 2 / 4 = that many loader waves per workgroup issue them

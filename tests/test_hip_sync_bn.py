@@ -65,3 +65,26 @@ def test_checkpoint_state_carries_rank0_buffers_two_ranks_one_gpu():
     assert abs(a["before"] - b["before"]) > 1e-9 * a["before"]          # different scenes: rank-local running statistics differ ...
     assert a["after"] == a["before"] and b["after"] == a["after"]       # ... and the checkpoint of EITHER rank holds rank 0's
     assert a["it"] == 1 and "model_state" in a["keys"] and "optimizer_state_lst" in a["keys"]
+
+
+@pytest.mark.gpu
+def test_rank_without_rows_still_enters_a_torch_syncbatchnorm():
+    """SparseSequential applies dense modules only to tensors with rows -- except the ones that hold a collective: a torch SyncBatchNorm
+    (what convert_sync_batchnorm leaves for layers it cannot mark) in training mode is called with the 0-row batch too, or the ranks
+    that do have rows would wait for this one forever.  One process: the module records that it was entered."""
+    from btcdet_amd import spconv
+
+    class Recording(torch.nn.SyncBatchNorm):
+        calls = 0
+
+        def forward(self, x):
+            Recording.calls += 1
+            return x
+
+    dev = torch.device("cuda:0")
+    seq = spconv.SparseSequential(Recording(8, affine=False)).to(dev).train()
+    x = spconv.SparseConvTensor(torch.zeros((0, 8), device=dev), torch.zeros((0, 4), dtype=torch.int32, device=dev), [4, 8, 8], 1)
+    seq(x)
+    assert Recording.calls == 1
+    seq.eval()(x)                       # eval mode holds no collective: the empty tensor skips the module as before
+    assert Recording.calls == 1

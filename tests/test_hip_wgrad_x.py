@@ -165,10 +165,10 @@ def test_one_and_two_items_in_flight_give_the_same_bits(cin, cout, kind, n_vox, 
     got = {}
     try:
         for depth in (1, 2):
-            check(lib().btc_tune_set(16, depth), "tune")
+            check(lib().btc_tune_set(20, depth), "tune")
             got[depth] = _wgrad(feat, dout, rb, cin, cout)
     finally:
-        check(lib().btc_tune_set(16, 0), "tune")
+        check(lib().btc_tune_set(20, 0), "tune")
     assert bool(torch.isfinite(got[1]).all()) and torch.equal(got[1], got[2])
     assert torch.equal(_wgrad(feat, dout, rb, cin, cout), got[1])      # and the built-in choice
 

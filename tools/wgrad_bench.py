@@ -26,7 +26,7 @@ ops.PROFILE = ops.LaunchProfile(); ops.CAPTURE = []
 step(batches[0]); torch.cuda.synchronize()
 cap, ops.CAPTURE, ops.PROFILE = ops.CAPTURE, None, None
 L = lib()
-ALT = tuple(int(v) for v in os.environ.get("ALT", "18=1").split("="))   # the tuning key = value of the second column (ALT=16=1: one item in flight)
+ALT = tuple(int(v) for v in os.environ.get("ALT", "18=1").split("="))   # the tuning key = value of the second column (ALT=20=1: one item in flight)
 
 
 def timed(fn, reps=10):
