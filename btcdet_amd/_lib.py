@@ -139,6 +139,7 @@ _SIGS = {
     "btc_pass_occ_vox_ws_bytes": (sz, [ctypes.POINTER(BtcPovConfig), ci, ci]),
     "btc_pass_occ_vox_count": (ci, [ctypes.POINTER(BtcPovConfig), vp, vp, vp, vp, vp, vp, ci, ci, ci, vp, vp, sz, vp]),
     "btc_pass_occ_vox_fill": (ci, [ctypes.POINTER(BtcPovConfig), vp, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, sz, vp]),
+    "btc_pass_occ_vox_fill_i32": (ci, [ctypes.POINTER(BtcPovConfig), vp, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]),
     "btc_occ_loss_ws_bytes": (sz, []),
     "btc_occ_loss_fwd": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, ci, ctypes.c_longlong, ctypes.c_float, ctypes.c_float, ctypes.c_float, vp, vp, vp,
                               sz, vp]),
@@ -147,6 +148,7 @@ _SIGS = {
                                     vp, sz, vp]),
     "btc_occ_loss_bwd_total": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, ci, ctypes.c_longlong, ctypes.c_float, vp, vp, vp, vp, vp]),
     "btc_dense_split_fwd": (ci, [vp, vp, ci, ci, ci, vp, vp, vp, vp]),
+    "btc_occ_prob": (ci, [vp, vp, ci, ctypes.c_longlong, vp, vp]),
     "btc_dense_split_bwd": (ci, [vp, vp, vp, ci, ci, ci, vp, vp, vp]),
     "btc_cat_pad_fwd": (ci, [vp, ci, vp, ci, ctypes.c_longlong, ci, ci, vp, vp]),
     "btc_cat_pad_bwd": (ci, [vp, ci, ctypes.c_longlong, ci, vp, ci, vp, ci, vp]),

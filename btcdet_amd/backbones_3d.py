@@ -429,7 +429,10 @@ class VoxelBackBone8xOcc(nn.Module):
         return self._stage(self.down_combine, x4, ready)
 
     def forward(self, batch_dict):
-        feats, coords = batch_dict['voxel_features'], batch_dict['voxel_coords'].int()
+        from .vfe import i32_twin
+        coords = batch_dict['voxel_coords']
+        tw = i32_twin(batch_dict, coords)      # (PassOccVox's int64 coordinates come with an int32 twin: no conversion launch)
+        feats, coords = batch_dict['voxel_features'], (tw if tw is not None else coords.int())
         if self.feature_dtype is not None and feats.shape[1] % 16 == 0:
             feats = feats.to(self.feature_dtype)     # (a 6-channel input stays fp32 through conv1, see VoxelBackBoneDeconv.forward)
         bs = batch_dict['batch_size']

@@ -160,6 +160,19 @@ __global__ __launch_bounds__(256) void sumsq2_bwd_k(const void* __restrict__ a, 
   }
 }
 
+// prob[b][cell] = softmax(logit[b][:, cell])[1] * mask[b][cell] for two-class logits (B, 2, cells): torch's Softmax(dim=1), the slice of
+// its last channel and the product with the loss mask (occ_head_3D.py:34-38) in one launch -- exp(x - max) / sum, as torch evaluates it
+__global__ __launch_bounds__(256) void occ_prob_k(const float* __restrict__ logit, const unsigned char* __restrict__ mask, long long ncell,
+                                                  long long total, float* __restrict__ out) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const long long b = i / ncell, c = i - b * ncell;
+  const float z0 = logit[(b * 2 + 0) * ncell + c], z1 = logit[(b * 2 + 1) * ncell + c];
+  const float m = fmaxf(z0, z1);
+  const float e0 = expf(z0 - m), e1 = expf(z1 - m);
+  out[i] = (e1 / (e0 + e1)) * (float)mask[i];
+}
+
 }  // namespace
 
 extern "C" int btc_dense_split_fwd(const float* feat, const int32_t* indices, int n, int Ca, int Cb, const int32_t* h_shape, float* dense_a,
@@ -239,6 +252,14 @@ extern "C" int btc_sumsq2_bwd(const void* a, long long na, int a_bf16, float ka2
   else if (a_bf16) sumsq2_bwd_k<true, false><<<grid, 256, 0, stream>>>(a, na, ka2, da, b, nb, kb2, db, g);
   else if (b_bf16) sumsq2_bwd_k<false, true><<<grid, 256, 0, stream>>>(a, na, ka2, da, b, nb, kb2, db, g);
   else sumsq2_bwd_k<false, false><<<grid, 256, 0, stream>>>(a, na, ka2, da, b, nb, kb2, db, g);
+  BTC_LAUNCH_CHECK();
+  return BTC_OK;
+}
+
+extern "C" int btc_occ_prob(const float* logit, const unsigned char* mask, int B, long long ncell, float* prob, void* stream) {
+  BTC_CHECK_ARG(B >= 0 && ncell >= 0, "btc_occ_prob: bad sizes");
+  const long long total = (long long)B * ncell;
+  if (total > 0) occ_prob_k<<<btc_cdiv(total, 256), 256, 0, (hipStream_t)stream>>>(logit, mask, ncell, total, prob);
   BTC_LAUNCH_CHECK();
   return BTC_OK;
 }

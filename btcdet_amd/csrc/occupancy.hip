@@ -552,20 +552,27 @@ extern "C" int btc_occ_targets(const BtcOccConfig* cfg, float* voxels, const int
   float *fore_sum = sums, *mirr_sum = sums + vol * 3, *bm_sum = sums + vol * 6;
   int32_t *fore_cnt = cnts, *mirr_cnt = cnts + vol, *bm_cnt = cnts + vol * 2;
 
-  // workspace: smap | occ_raw | mirr_raw | sums | cnts are carved back to back (occ_ws_layout) -> one memset
-  BTC_HIP(hipMemsetAsync(smap, 0, (size_t)((char*)ray_cnt - (char*)smap), stream));
+  // What the kernels accumulate into starts zeroed: the workspace's smap | occ_raw | mirr_raw | sums | cnts (carved back to back,
+  // occ_ws_layout), the byte masks, the positive count.  A caller that lays them out as ONE arena -- pos_all_num, 256 bytes on the five
+  // masks as a (5, vol) block, rounded up to 256 bytes the workspace (btcdet_amd/occ_targets.py) -- gets one fill for all of it
+  // (separate tensors of the caching allocator sit on 512-byte blocks and cannot meet these offsets by accident).
   uint8_t* m0 = (uint8_t*)out->vcc_mask;
-  if ((uint8_t*)out->voxelwise_mask == m0 + vol && (uint8_t*)out->bm_voxelwise_mask == m0 + 2 * vol &&
-      (uint8_t*)out->occ_voxelwise_mask == m0 + 3 * vol && (uint8_t*)out->fore_voxelwise_mask == m0 + 4 * vol) {
-    // the caller laid the five byte masks out as one (5, vol) block (occ_voxelwise_mask is overwritten by occ_finalize)
-    BTC_HIP(hipMemsetAsync(m0, 0, 5 * vol, stream));
+  const bool block5 = (uint8_t*)out->voxelwise_mask == m0 + vol && (uint8_t*)out->bm_voxelwise_mask == m0 + 2 * vol &&
+                      (uint8_t*)out->occ_voxelwise_mask == m0 + 3 * vol && (uint8_t*)out->fore_voxelwise_mask == m0 + 4 * vol;
+  if (block5 && (uint8_t*)out->pos_all_num + 256 == m0 && m0 + ((5 * vol + 255) & ~(size_t)255) == (uint8_t*)ws && smap == (uint8_t*)ws) {
+    BTC_HIP(hipMemsetAsync(out->pos_all_num, 0, (size_t)((char*)ray_cnt - (char*)out->pos_all_num), stream));
   } else {
-    BTC_HIP(hipMemsetAsync(out->vcc_mask, 0, vol, stream));
-    BTC_HIP(hipMemsetAsync(out->voxelwise_mask, 0, vol, stream));
-    BTC_HIP(hipMemsetAsync(out->fore_voxelwise_mask, 0, vol, stream));
-    BTC_HIP(hipMemsetAsync(out->bm_voxelwise_mask, 0, vol, stream));
+    BTC_HIP(hipMemsetAsync(smap, 0, (size_t)((char*)ray_cnt - (char*)smap), stream));
+    if (block5) {   // (occ_voxelwise_mask is overwritten by occ_finalize)
+      BTC_HIP(hipMemsetAsync(m0, 0, 5 * vol, stream));
+    } else {
+      BTC_HIP(hipMemsetAsync(out->vcc_mask, 0, vol, stream));
+      BTC_HIP(hipMemsetAsync(out->voxelwise_mask, 0, vol, stream));
+      BTC_HIP(hipMemsetAsync(out->fore_voxelwise_mask, 0, vol, stream));
+      BTC_HIP(hipMemsetAsync(out->bm_voxelwise_mask, 0, vol, stream));
+    }
+    BTC_HIP(hipMemsetAsync(out->pos_all_num, 0, sizeof(int32_t), stream));
   }
-  BTC_HIP(hipMemsetAsync(out->pos_all_num, 0, sizeof(int32_t), stream));
 
   const int T = 256;
   if (M > 0) {

@@ -426,7 +426,7 @@ __global__ __launch_bounds__(256) void pov_scatter(const int32_t* __restrict__ p
 __global__ __launch_bounds__(256) void pov_fill(PovGeom G, int m, int pmax, const float* __restrict__ dvoxels, const float* __restrict__ occ_xyzp,
                                                 const int32_t* __restrict__ offs, const int32_t* __restrict__ perm,
                                                 const unsigned* __restrict__ bitmap_unused, float* __restrict__ voxels,
-                                                int64_t* __restrict__ vcoords, int64_t* __restrict__ vnum) {
+                                                int64_t* __restrict__ vcoords, int64_t* __restrict__ vnum, int32_t* __restrict__ vnum32) {
   long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= (long long)m * pmax) return;
   const int row = (int)(t / pmax), slot = (int)(t % pmax);
@@ -456,12 +456,15 @@ __global__ __launch_bounds__(256) void pov_fill(PovGeom G, int m, int pmax, cons
     o[G.C] = src[3];
     if (G.code_dim > 1) o[G.C + 1] = 1.f;
   }
-  if (slot == 0) vnum[row] = cnt;
+  if (slot == 0) {
+    vnum[row] = cnt;
+    if (vnum32) vnum32[row] = cnt;   // (the int32 twin the VFE / backbone read: no conversion launch)
+  }
 }
 
 // vcoords from the bitmap (cells ascending) -- one thread per set word
 __global__ __launch_bounds__(256) void pov_coords(const unsigned* __restrict__ bitmap, const int32_t* __restrict__ prefix, long long nwords,
-                                                  PovGeom G, int64_t* __restrict__ vcoords) {
+                                                  PovGeom G, int64_t* __restrict__ vcoords, int32_t* __restrict__ vcoords32) {
   long long w = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (w >= nwords) return;
   unsigned bits = bitmap[w];
@@ -475,6 +478,7 @@ __global__ __launch_bounds__(256) void pov_coords(const unsigned* __restrict__ b
     long long b = cell / G.dvol, rem = cell % G.dvol;
     int64_t* c = vcoords + (size_t)row * 4;
     c[0] = b; c[1] = rem / hw; c[2] = (rem % hw) / G.W; c[3] = rem % G.W;
+    if (vcoords32) *(int4*)(vcoords32 + (size_t)row * 4) = make_int4((int)c[0], (int)c[1], (int)c[2], (int)c[3]);
     ++row;
   }
 }
@@ -614,9 +618,9 @@ extern "C" int btc_pass_occ_vox_count(const BtcPovConfig* cfg, const float* prob
   return BTC_OK;
 }
 
-extern "C" int btc_pass_occ_vox_fill(const BtcPovConfig* cfg, const float* det_voxels, int M, int P, int C, int m, int pmax, int k_total,
-                                     float* voxels, int64_t* vcoords, int64_t* vnum, float* occ_pnts, int64_t* occ_b, void* ws,
-                                     size_t ws_bytes, void* stream_) {
+extern "C" int btc_pass_occ_vox_fill_i32(const BtcPovConfig* cfg, const float* det_voxels, int M, int P, int C, int m, int pmax, int k_total,
+                                         float* voxels, int64_t* vcoords, int64_t* vnum, float* occ_pnts, int64_t* occ_b, int32_t* vcoords32,
+                                         int32_t* vnum32, void* ws, size_t ws_bytes, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   BTC_CHECK_ARG(ws_bytes >= btc_pass_occ_vox_ws_bytes(cfg, M, P), "btc_pass_occ_vox_fill: workspace too small");
   PovGeom G;
@@ -625,9 +629,9 @@ extern "C" int btc_pass_occ_vox_fill(const BtcPovConfig* cfg, const float* det_v
   PovWs w = pov_carve(ws, G);
   if (m > 0 && pmax > 0) {
     pov_fill<<<btc_cdiv((long long)m * pmax, 256), 256, 0, stream>>>(G, m, pmax, det_voxels, w.occ_xyzp, w.offs, w.perm, w.bitmap, voxels,
-                                                                     vcoords, vnum);
+                                                                     vcoords, vnum, vnum32);
     BTC_LAUNCH_CHECK();
-    pov_coords<<<btc_cdiv(w.nw, 256), 256, 0, stream>>>(w.bitmap, w.prefix, w.nw, G, vcoords);
+    pov_coords<<<btc_cdiv(w.nw, 256), 256, 0, stream>>>(w.bitmap, w.prefix, w.nw, G, vcoords, vcoords32);
     BTC_LAUNCH_CHECK();
   }
   if (k_total > 0) {
@@ -635,4 +639,11 @@ extern "C" int btc_pass_occ_vox_fill(const BtcPovConfig* cfg, const float* det_v
     BTC_LAUNCH_CHECK();
   }
   return BTC_OK;
+}
+
+extern "C" int btc_pass_occ_vox_fill(const BtcPovConfig* cfg, const float* det_voxels, int M, int P, int C, int m, int pmax, int k_total,
+                                     float* voxels, int64_t* vcoords, int64_t* vnum, float* occ_pnts, int64_t* occ_b, void* ws,
+                                     size_t ws_bytes, void* stream_) {
+  return btc_pass_occ_vox_fill_i32(cfg, det_voxels, M, P, C, m, pmax, k_total, voxels, vcoords, vnum, occ_pnts, occ_b, nullptr, nullptr, ws, ws_bytes,
+                                   stream_);
 }

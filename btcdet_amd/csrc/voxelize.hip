@@ -15,6 +15,9 @@
 
 namespace {
 
+#define VOX_EMPTY_KEY 0x7F7F7F7F7F7F7F7FLL   // an empty hash slot: the byte pattern of the point lists' sentinel (one fill for both)
+
+
 struct VoxParams {
   float lo[3];
   float vs[3];
@@ -56,8 +59,8 @@ __global__ __launch_bounds__(256) void vox_insert(const float* __restrict__ pts,
   const long long key = (long long)b * P.vol + lin;
   unsigned slot = btc_hash32((unsigned)lin ^ ((unsigned)b * 0x9E3779B9u)) & P.mask;
   while (true) {
-    const long long prev = (long long)atomicCAS((unsigned long long*)&keys[slot], (unsigned long long)-1LL, (unsigned long long)key);
-    if (prev == -1LL || prev == key) break;
+    const long long prev = (long long)atomicCAS((unsigned long long*)&keys[slot], (unsigned long long)VOX_EMPTY_KEY, (unsigned long long)key);
+    if (prev == VOX_EMPTY_KEY || prev == key) break;
     slot = (slot + 1) & P.mask;
   }
   cellslot[i] = (int)slot;
@@ -234,8 +237,9 @@ extern "C" int btc_voxelize(const float* points, int n, int ld, int xyz_col, int
   int32_t* scene_info = cv.take<int32_t>((size_t)batch * 2);
   void* scan_ws = cv.take<char>(btc_scan_ws_bytes(n + 1));
 
-  BTC_HIP(hipMemsetAsync(keys, 0xFF, (size_t)cap * sizeof(long long), stream));
-  BTC_HIP(hipMemsetAsync(lists, 0x7F, (size_t)cap * max_points * sizeof(int32_t), stream));
+  // keys | lists are carved back to back and share one byte pattern (an empty key is 0x7F7F.., above every real key: keys are below
+  // batch x 2^31; an empty list entry is BTC_EMPTY_IDX = 0x7F7F7F7F): ONE fill
+  BTC_HIP(hipMemsetAsync(keys, 0x7F, (size_t)((char*)(lists + (size_t)cap * max_points) - (char*)keys), stream));
   const int T = 256;
   vox_insert<<<btc_cdiv(n, T), T, 0, stream>>>(points, scene_offsets, P, keys, lists, cellslot);
   BTC_LAUNCH_CHECK();

@@ -260,6 +260,8 @@ class OccHead3D(OccHeadTemplate):
         self.is_softmax = lc.get("CLS_LOSS_TYPE", None) == "softmax"
         super().__init__(model_cfg=model_cfg, data_cfg=data_cfg, num_class=num_class, grid_size=grid_size)
         self.stride = int(model_cfg.BACKBONE_3D.STRIDE)
+        upd = model_cfg.get("OCC_PNT_UPDATE", None)
+        self.prob_needs_grad = bool(upd.get("PASS_GRAD", False)) if upd is not None else True   # (does PassOccVox propagate into the probability)
         cls_channel = num_class + 1 if self.is_softmax else num_class
         self.conv_cls = spconv.SparseSequential(
             spconv.SubMConv3d(input_channels, (self.stride ** 3) * cls_channel, 3, padding=1, bias=True, indice_key='cls_ind'))
@@ -283,8 +285,11 @@ class OccHead3D(OccHeadTemplate):
         from .spconv import ops
         cls, res = self.conv_cls[0], self.conv_res[0]
         w = torch.cat([cls.weight, res.weight], dim=-1)
-        bias = torch.cat([cls.bias if cls.bias is not None else cls.weight.new_zeros(cls.out_channels),
-                          res.bias if res.bias is not None else res.weight.new_zeros(res.out_channels)])
+        zeros = self.__dict__.get("_bias_zeros")     # (a missing bias: zeros made once, not a fill launch per step)
+        if zeros is None or zeros.device != cls.weight.device:
+            zeros = self.__dict__["_bias_zeros"] = cls.weight.new_zeros(max(cls.out_channels, res.out_channels))
+        bias = torch.cat([cls.bias if cls.bias is not None else zeros[:cls.out_channels],
+                          res.bias if res.bias is not None else zeros[:res.out_channels]])
         if w.requires_grad and torch.is_grad_enabled():
             w.register_hook(_join_wgrad_hook)
             w._btc_join_before_use = True  # SparseConvFunction: this non-leaf weight's gradient may be deferred
@@ -338,9 +343,20 @@ class OccHead3D(OccHeadTemplate):
         x = data_dict['encoded_spconv_tensor']
         if self._merge_ok() and x.features.is_cuda:
             logit, residuals = self._merged_heads(x)
-            prob = self.logit2prob(logit)[:, -1:, ...]
             data_dict['pred_occ_logit'] = logit
-            data_dict['batch_pred_occ_prob'] = prob[:, -1, ...] * data_dict["general_cls_loss_mask"]
+            mask = data_dict["general_cls_loss_mask"]
+            if self.is_softmax and logit.shape[1] == 2 and logit.dtype == torch.float32 and mask.dtype == torch.uint8 and mask.is_contiguous() \
+                    and not (self.prob_needs_grad and torch.is_grad_enabled() and logit.requires_grad):
+                # softmax + slice + mask product in one launch (btc_occ_prob) where the probability is a DETACHED input of PassOccVox
+                # (OCC_PNT_UPDATE.PASS_GRAD False, the shipped configuration); with PASS_GRAD the torch ops below keep the graph
+                from ._lib import check, lib, ptr, stream_ptr
+                lg = logit.detach().contiguous()
+                prob = torch.empty((lg.shape[0],) + tuple(lg.shape[2:]), dtype=torch.float32, device=lg.device)
+                check(lib().btc_occ_prob(ptr(lg), ptr(mask), int(lg.shape[0]), int(prob[0].numel()), ptr(prob), stream_ptr()), "btc_occ_prob")
+                data_dict['batch_pred_occ_prob'] = prob
+            else:
+                prob = self.logit2prob(logit)[:, -1:, ...]
+                data_dict['batch_pred_occ_prob'] = prob[:, -1, ...] * mask
             data_dict['pred_sem_residuals'] = residuals
             return data_dict
         logit = self.conv_cls(x).dense()

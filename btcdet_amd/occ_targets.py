@@ -191,7 +191,11 @@ class OccTargets3D(nn.Module):
             batch_dict['voxels'][dropped] = 0
 
     def get_paddings_indicator(self, actual_num, max_num, axis=0):
-        return actual_num.int().unsqueeze(1) > torch.arange(max_num, dtype=torch.int, device=actual_num.device).view(1, -1)
+        key = (int(max_num), actual_num.device)
+        rng = self.__dict__.setdefault("_arange", {}).get(key)
+        if rng is None:
+            rng = self._arange[key] = torch.arange(max_num, dtype=torch.int, device=actual_num.device).view(1, -1)
+        return actual_num.int().unsqueeze(1) > rng
 
     def forward(self, batch_dict, **kwargs):
         vox = batch_dict['voxels']
@@ -209,19 +213,33 @@ class OccTargets3D(nn.Module):
         bm = batch_dict.get("bm_points", None)
         n_bm = 0 if bm is None else int(bm.shape[0])
         bm = bm.float().contiguous() if n_bm > 0 else None
-        vox = vox.float().contiguous().clone() if not vox.is_contiguous() or vox.dtype != torch.float32 else vox.clone()
+        # the kernels write the absolute coordinates into the voxel payload: a copy, unless the producer says nobody else holds the tensor
+        # (DataProcessor.forward_batch: "__voxels_owned__")
+        owned = bool(batch_dict.pop("__voxels_owned__", False)) and vox.is_contiguous() and vox.dtype == torch.float32
+        if not owned:
+            vox = vox.float().contiguous().clone() if not vox.is_contiguous() or vox.dtype != torch.float32 else vox.clone()
         M, P, C = vox.shape
         shape = (bs, self.nz, self.ny, self.nx)
         out = {}
-        zeroed = OCC_BUFFER_FIELDS[:5]  # the byte masks the kernels accumulate into: one block, one memset in btc_occ_targets
-        block = torch.empty((len(zeroed),) + shape, dtype=torch.uint8, device=dev)
+        # ONE arena for what btc_occ_targets zeroes: [pos_all_num | the five byte masks the kernels accumulate into | the workspace] at the
+        # offsets it recognises (csrc/occupancy.hip) -> one fill instead of three
+        cfg = self._cfg
+        cfg.batch, cfg.max_boxes = bs, G
+        L = lib()
+        ws_bytes = L.btc_occ_targets_ws_bytes(ctypes.byref(cfg))
+        zeroed = OCC_BUFFER_FIELDS[:5]
+        vol = bs * self.nz * self.ny * self.nx
+        masks_bytes = (len(zeroed) * vol + 255) & ~255
+        arena = torch.empty((256 + masks_bytes + max(int(ws_bytes), 256),), dtype=torch.uint8, device=dev)
+        block = arena[256:256 + len(zeroed) * vol].view((len(zeroed),) + shape)
+        ws = arena[256 + masks_bytes:]
         for i, k in enumerate(zeroed):
             out[k] = block[i]
         for k in OCC_BUFFER_FIELDS[5:]:
             if k == "res_mtrx":
                 out[k] = torch.empty((bs, 3, self.nz, self.ny, self.nx), dtype=torch.float32, device=dev)
             elif k == "pos_all_num":
-                out[k] = torch.empty((1,), dtype=torch.int32, device=dev)
+                out[k] = arena[0:4].view(torch.int32)
             elif k.endswith("_float"):
                 out[k] = torch.empty(shape, dtype=torch.float32, device=dev)
             elif k == "forebox_label":
@@ -229,20 +247,15 @@ class OccTargets3D(nn.Module):
             else:
                 out[k] = torch.empty(shape, dtype=torch.uint8, device=dev)
         bufs = BtcOccBuffers(**{k: out[k].data_ptr() for k in OCC_BUFFER_FIELDS})
-        cfg = self._cfg
-        cfg.batch, cfg.max_boxes = bs, G
         lut = self.backproject_table(dev)
         cfg.backproject_lut = lut.data_ptr() if lut is not None else None
-        L = lib()
-        ws_bytes = L.btc_occ_targets_ws_bytes(ctypes.byref(cfg))
-        ws = workspace(ws_bytes, dev)
         check(L.btc_occ_targets(ctypes.byref(cfg), ptr(vox), ptr(coords), ptr(num), M, P, C, ptr(gt), ptr(gtn), ptr(mirr),
                                 ptr(bm), n_bm, ptr(rot_z), ptr(self.all_voxel_centers), ctypes.byref(bufs), ptr(ws), ws_bytes,
                                 stream_ptr()), "btc_occ_targets")
         batch_dict['voxels'] = vox  # absolute xyz payload (USE_ABSXYZ True)
         if self.dropout_rate > 1e-3 and batch_dict.get("is_train", True):
             self._dropout(batch_dict, out, coords, bs)
-        out["occ_voxelwise_mask"] = out["occ_voxelwise_mask"].bool()
+        out["occ_voxelwise_mask"] = out["occ_voxelwise_mask"].view(torch.bool)   # (0 / 1 bytes: the same memory as bool, no copy)
         out["pos_all_num"] = out["pos_all_num"][0]
         if not batch_dict.get("is_train", True):
             out["neg_mask"] = out["general_cls_loss_mask"] & (1 - out["pos_mask"])

@@ -183,9 +183,15 @@ class PassOccVox(torch.nn.Module):
         vnum = torch.empty((m,), dtype=torch.int64, device=dev)
         occ_pnts = torch.empty((k_total, 4), dtype=torch.float32, device=dev)
         occ_b = torch.empty((k_total,), dtype=torch.int64, device=dev)
-        check(L.btc_pass_occ_vox_fill(ctypes.byref(c), ptr(dv), M, P, C, m, pmax, k_total, ptr(voxels), ptr(vcoords), ptr(vnum),
-                                      ptr(occ_pnts), ptr(occ_b), ptr(ws), ws_bytes, stream_ptr()), "btc_pass_occ_vox_fill")
+        # int32 twins of the coordinates / counts for the modules behind this one (OccVFE, the detection backbone): the int64 tensors are
+        # what the reference's torch.unique hands on, and converting them cost a launch each
+        vcoords32 = torch.empty((m, 4), dtype=torch.int32, device=dev)
+        vnum32 = torch.empty((m,), dtype=torch.int32, device=dev)
+        check(L.btc_pass_occ_vox_fill_i32(ctypes.byref(c), ptr(dv), M, P, C, m, pmax, k_total, ptr(voxels), ptr(vcoords), ptr(vnum),
+                                          ptr(occ_pnts), ptr(occ_b), ptr(vcoords32), ptr(vnum32), ptr(ws), ws_bytes, stream_ptr()),
+              "btc_pass_occ_vox_fill_i32")
         batch_dict['voxels'], batch_dict['voxel_num_points'], batch_dict['voxel_coords'] = voxels, vnum, vcoords
+        batch_dict['__voxel_i32__'] = (vcoords, vcoords32, vnum, vnum32)   # (tensor, its int32 twin) pairs, matched by identity
         batch_dict["occ_pnts"], batch_dict["added_occ_xyz"], batch_dict["added_occ_b_ind"] = occ_pnts, occ_pnts[:, :3], occ_b
         return batch_dict
 

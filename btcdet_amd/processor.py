@@ -218,13 +218,15 @@ class DataProcessor(object):
         -> the voxel keys of collate_batch (dataset.py:185-192), on the GPU."""
         cyl = cart_to_occ_coords(pre_rot_points, self.occ_config.COORD_TYPE)
         # both voxelizations are enqueued back to back; ONE read-back returns the two voxel counts
-        vox, coords, num, m_occ = self._occ_gen.generate_batch(cyl, scene_offsets, sync=False)
-        dvox, dcoords, dnum, m_det = self._det_gen.generate_batch(points, scene_offsets, sync=False)
-        m_occ, m_det = torch.cat([m_occ, m_det]).tolist()
+        totals = torch.empty((2,), dtype=torch.int32, device=points.device)     # (one tensor for both counts: no cat in front of the read-back)
+        vox, coords, num, _ = self._occ_gen.generate_batch(cyl, scene_offsets, sync=False, total_out=totals[0:1])
+        dvox, dcoords, dnum, _ = self._det_gen.generate_batch(points, scene_offsets, sync=False, total_out=totals[1:2])
+        m_occ, m_det = totals.tolist()
         vox, coords, num = vox[:m_occ], coords[:m_occ], num[:m_occ]
         dvox, dcoords, dnum = dvox[:m_det], dcoords[:m_det], dnum[:m_det]
         if m_occ > 0:
             check(lib().btc_voxel_shift_col(ptr(vox), ptr(coords), m_occ, vox.shape[1], vox.shape[2], 1, ptr(rot_z), -1.0,
                                             stream_ptr()), "btc_voxel_shift_col")
+        # "__voxels_owned__": `voxels` is a fresh tensor nobody else holds -- OccTargets3D may write the absolute coordinates into it in place
         return {"voxels": vox, "voxel_coords": coords, "voxel_num_points": num, "det_voxels": dvox,
-                "det_voxel_coords": dcoords, "det_voxel_num_points": dnum}
+                "det_voxel_coords": dcoords, "det_voxel_num_points": dnum, "__voxels_owned__": True}

@@ -17,11 +17,12 @@ from .._lib import check, f32p, i3p, lib, ptr, stream_ptr, workspace
 
 
 def voxelize_batch(points, scene_offsets, point_cloud_range, voxel_size, grid_size, max_points, max_voxels,
-                   xyz_col=0, feat_col=0, num_feat=None, sync=True):
+                   xyz_col=0, feat_col=0, num_feat=None, sync=True, total_out=None):
     """points (n, ld) float32 GPU tensor with scenes stored contiguously; scene_offsets (B+1) int32
     GPU tensor.  Returns voxels (M,P,C), coords (M,4) [b,z,y,x] int32, num (M,) int32.
     With sync=False the tensors keep their capacity (B*max_voxels rows) and the voxel count stays on
-    the device as the 4th return value."""
+    the device as the 4th return value (total_out: a caller's (1,) int32 device tensor to hold it -- two voxelizations whose counts
+    come back in ONE read-back write into the halves of one tensor)."""
     if not points.is_cuda:
         raise _lib.BtcHipError("voxelize_batch: points must live on the GPU")
     points = points.contiguous()
@@ -38,7 +39,7 @@ def voxelize_batch(points, scene_offsets, point_cloud_range, voxel_size, grid_si
     voxels = torch.empty((cap, int(max_points), C), dtype=torch.float32, device=dev)
     coords = torch.empty((cap, 4), dtype=torch.int32, device=dev)
     num = torch.empty((cap,), dtype=torch.int32, device=dev)
-    d_total = torch.empty((1,), dtype=torch.int32, device=dev)     # (written by every path of btc_voxelize)
+    d_total = total_out if total_out is not None else torch.empty((1,), dtype=torch.int32, device=dev)     # (written by every path of btc_voxelize)
     L = lib()
     ws_bytes = L.btc_voxelize_ws_bytes(n, batch, int(max_points))
     ws = workspace(ws_bytes, dev)
@@ -84,9 +85,9 @@ class VoxelGeneratorV2(object):
             res = {k: (v.cpu().numpy() if torch.is_tensor(v) else v) for k, v in res.items()}
         return res
 
-    def generate_batch(self, points, scene_offsets, xyz_col=0, feat_col=0, num_feat=None, max_voxels=None, sync=True):
+    def generate_batch(self, points, scene_offsets, xyz_col=0, feat_col=0, num_feat=None, max_voxels=None, sync=True, total_out=None):
         return voxelize_batch(points, scene_offsets, self._point_cloud_range, self._voxel_size, self._grid_size,
-                              self._max_num_points, int(max_voxels or self._max_voxels), xyz_col, feat_col, num_feat, sync)
+                              self._max_num_points, int(max_voxels or self._max_voxels), xyz_col, feat_col, num_feat, sync, total_out)
 
     @property
     def voxel_size(self):

@@ -90,6 +90,22 @@ def stand_in_det_loss(ret, batch_dict):
     return MeanSquare2.apply(ret["spatial_features"], 1e-3, ret["x_combine"], 1e-3)
 
 
+_ONES = {}
+
+
+def _backward(loss, *more):
+    """loss.backward() (of one scalar, or of several at once) with the seed gradient taken from a cache: autograd's own `ones_like` is a
+    fill launch per call -- two or three a step"""
+    seeds = []
+    for t in (loss,) + more:
+        key = (t.device, t.dtype, tuple(t.shape))
+        one = _ONES.get(key)
+        if one is None:
+            one = _ONES[key] = torch.ones(t.shape, dtype=t.dtype, device=t.device)
+        seeds.append(one)
+    torch.autograd.backward((loss,) + more, seeds)
+
+
 def make_step(model, ddp, proc, opts, grad_sync=None, prefetch_stream=None, threaded=True, det_stream=None, opt_stream=None,
               det_loss=None, pipeline=None):
     """one training step of the hot path -> step(batch, next_batch=None) -> detached loss.
@@ -145,7 +161,7 @@ def make_step(model, ddp, proc, opts, grad_sync=None, prefetch_stream=None, thre
 
     def occ_backward(loss):
         torch.cuda.set_device(device)
-        loss.backward()
+        _backward(loss)
 
     # pipelined variant of the det_stream schedule: once the occupancy branch's backward has returned, the worker thread goes on
     # -- the occupancy bucket's all-reduce (process group), the occupancy group's optimizer step (its gradients are complete), the
@@ -187,7 +203,7 @@ def make_step(model, ddp, proc, opts, grad_sync=None, prefetch_stream=None, thre
         tw = time.perf_counter() if timing is not None else 0.0
         cw = time.thread_time() if timing is not None else 0.0
         try:
-            loss_occ.backward()
+            _backward(loss_occ)
             _ops.join_wgrad()            # (no-op: the end-of-pass callback has joined the side stream into this thread's stream)
             if grad_sync is not None:    # issued BEFORE the hand-over: every rank's order is occupancy bucket, then detection bucket
                 grad_sync.launch(bucket_of["occ"])
@@ -260,7 +276,7 @@ def make_step(model, ddp, proc, opts, grad_sync=None, prefetch_stream=None, thre
                                "is NOT issued (collective order)") from err
         t = _mark("wait_occ_backward", t)
         with torch.cuda.stream(det_stream):
-            loss_det.backward()
+            _backward(loss_det)
             _ops.join_wgrad()
             t = _mark("det_backward", t)
             if grad_sync is not None:
@@ -304,7 +320,7 @@ def make_step(model, ddp, proc, opts, grad_sync=None, prefetch_stream=None, thre
                 grad_sync.launch_ready()  # the occupancy bucket travels during the detection branch's backward
             fut = pool.submit(prep, next_batch) if (ahead and threaded) else None
             with torch.cuda.stream(det_stream):
-                loss_det.backward()
+                _backward(loss_det)
             main.wait_stream(det_stream)
             loss = loss_occ.detach() + loss_det.detach()
         else:
@@ -313,21 +329,21 @@ def make_step(model, ddp, proc, opts, grad_sync=None, prefetch_stream=None, thre
             fut = pool.submit(prep, next_batch) if (ahead and threaded) else None
             if opt_stream is not None:
                 with torch.cuda.stream(opt_stream):
-                    loss_det.backward()
+                    _backward(loss_det)
                     opts[0].step(groups=[1])
-                ret["loss_occ"].backward()
+                _backward(ret["loss_occ"])
                 loss = ret["loss_occ"].detach() + loss_det.detach()
             elif split_backward:
                 # the branches are detached (PASS_GRAD False): two backward passes give the same gradients as one over the sum.
                 # The detection bucket (~90 % of the bytes) is packed and all-reduced BETWEEN them, from this thread -- it travels
                 # over xGMI while the occupancy branch's backward runs, with no hook in the autograd thread
-                loss_det.backward()
+                _backward(loss_det)
                 grad_sync.launch_ready()
-                ret["loss_occ"].backward()
+                _backward(ret["loss_occ"])
                 loss = ret["loss_occ"].detach() + loss_det.detach()
             else:
-                loss = ret["loss_occ"] + loss_det
-                loss.backward()
+                _backward(ret["loss_occ"], loss_det)   # (one pass over both roots: the sum itself is only reported)
+                loss = ret["loss_occ"].detach() + loss_det.detach()
         if fut is not None:
             _put(pending, next_batch, fut.result())
         _ops.join_wgrad()   # no-op unless weight gradients are still owed (e.g. a backward pass whose end-of-pass callback never ran)

@@ -15,9 +15,22 @@ def _fusable(vox, num):
         and not vox.requires_grad
 
 
-def _num_arg(num):
-    if num.dtype == torch.int64:  # PassOccVox hands over int64 counts (as the reference's torch.unique does)
-        num = num.to(torch.int32)
+def i32_twin(batch_dict, t):
+    """the int32 twin PassOccVox made of one of its int64 outputs (batch_dict['__voxel_i32__']: coords, coords32, num, num32), if `t` IS that
+    tensor; else None"""
+    tw = batch_dict.get('__voxel_i32__') if batch_dict is not None else None
+    if tw is not None:
+        if t is tw[0]:
+            return tw[1]
+        if t is tw[2]:
+            return tw[3]
+    return None
+
+
+def _num_arg(num, batch_dict=None):
+    if num.dtype == torch.int64:  # PassOccVox hands over int64 counts (as the reference's torch.unique does) -- and an int32 twin
+        tw = i32_twin(batch_dict, num)
+        num = tw if tw is not None else num.to(torch.int32)
     return num.contiguous(), int(num.dtype == torch.float32)
 
 
@@ -58,7 +71,7 @@ class MeanVFE(VFETemplate):
             vox = vox.contiguous()
             M, P, C = vox.shape
             out = torch.empty((M, C), dtype=torch.float32, device=vox.device)
-            n, isf = _num_arg(num)
+            n, isf = _num_arg(num, batch_dict)
             check(lib().btc_mean_vfe(ptr(vox), ptr(n), isf, M, P, C, ptr(out), stream_ptr()), "btc_mean_vfe")
             batch_dict['voxel_features'] = out
             return batch_dict
@@ -94,7 +107,7 @@ class OccVFE(VFETemplate):
             M, P, F = vox.shape
             feat = torch.empty((M, F), dtype=torch.float32, device=vox.device)
             occ = torch.empty((M, F - R), dtype=torch.float32, device=vox.device)
-            n, isf = _num_arg(num)
+            n, isf = _num_arg(num, batch_dict)
             check(lib().btc_occ_vfe(ptr(vox), ptr(n), isf, M, P, F, R, ptr(feat), ptr(occ), stream_ptr()), "btc_occ_vfe")
             batch_dict['voxel_features'], batch_dict['occ_voxel_features'] = feat, occ
             return batch_dict

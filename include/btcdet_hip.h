@@ -381,6 +381,10 @@ int btc_dense_split_fwd(const float* feat, const int32_t* indices, int n, int Ca
                         float* dense_b, void* stream);
 int btc_dense_split_bwd(const float* grad_a, const float* grad_b, const int32_t* indices, int n, int Ca, int Cb,
                         const int32_t* h_shape, float* dfeat, void* stream);
+/* prob (B, cells) = softmax over the two channels of logit (B, 2, cells), last channel, times mask (B, cells) of 0 / 1 bytes: the
+ * occupancy head's `logit2prob(logit)[:, -1] * general_cls_loss_mask` (/root/reference/btcdet/models/occ_dense_heads/occ_head_3D.py:34-38)
+ * in one launch; no gradient (the caller uses it where the probability is a detached input: PASS_GRAD False). */
+int btc_occ_prob(const float* logit, const unsigned char* mask, int B, long long ncell, float* prob, void* stream);
 /* out (n, cout) = [a (n, ca) | b (n, cb) | zeros]: the detection backbone's sparse_cat (spconv_backbone.py:869-873) together with the
  * zero channels the apply kernels want (34 -> 64 / 48); backward splits grad (n, cout) into da, db.  elem_bytes: 4 (fp32) | 2 (bf16). */
 int btc_cat_pad_fwd(const void* a, int ca, const void* b, int cb, long long n, int cout, int elem_bytes, void* out, void* stream);
@@ -540,6 +544,11 @@ int btc_pass_occ_vox_count(const BtcPovConfig* cfg, const float* probs /* B,nz,n
 int btc_pass_occ_vox_fill(const BtcPovConfig* cfg, const float* det_voxels, int M, int P, int C, int m, int pmax, int k_total,
                           float* voxels, int64_t* vcoords, int64_t* vnum, float* occ_pnts, int64_t* occ_b, void* ws,
                           size_t ws_bytes, void* stream);
+/* the same, and int32 twins of the merged voxels' coordinates (m, 4) and point counts (m) beside the int64 tensors the reference's
+ * torch.unique hands on (either may be NULL): what the next modules of this package read, without a conversion launch each */
+int btc_pass_occ_vox_fill_i32(const BtcPovConfig* cfg, const float* det_voxels, int M, int P, int C, int m, int pmax, int k_total,
+                              float* voxels, int64_t* vcoords, int64_t* vnum, float* occ_pnts, int64_t* occ_b, int32_t* vcoords32,
+                              int32_t* vnum32, void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Occupancy head losses, fused.  Replaces OccHeadTemplate.get_loss (occ_head_template.py:52-111) with
