@@ -269,7 +269,7 @@ class VoxelBackBone8xOcc(nn.Module):
         # (HotPathTrainer, pipelined: a fifth active stream costs 1.8 ms per step there).
         self.walk_async = os.environ.get("BTC_DET_WALK_ASYNC", "1") != "0"
 
-    def _walk_geometry(self, coords, bs, indice_dict):
+    def _walk_geometry(self, coords, bs, indice_dict, allow_async=True):
         """all rulebooks of the main chain (subm1, spconv2, subm2, ... spconv_down2, subm_down2) in one call of the compiled
         binding before the first layer runs (spconv/geometry.py): every stage then finds its rulebooks ready and runs as one
         compiled call (SparseSequential._chain_plan) instead of ~100 us of Python per layer; the side-branch pools and the
@@ -297,7 +297,7 @@ class VoxelBackBone8xOcc(nn.Module):
                 offs[id(st)] = (pos, pos + n)
                 pos += n
             plan.stage_slices = offs
-        if self.walk_async and sp_ops.PROFILE is None and plan.entries[0][0] == 0:
+        if allow_async and self.walk_async and sp_ops.PROFILE is None and plan.entries[0][0] == 0:
             # The first stage (conv1, conv1_combine) only needs the level-0 submanifold rulebook, which needs no read-back: build it
             # alone, fork the rest of the walk (the strided levels and the read-back of their row counts) onto a side stream, and
             # let the caller run the first stage before it joins (forward -> _finish_walk).  The walk's ~0.3 ms of kernels and its
@@ -428,16 +428,42 @@ class VoxelBackBone8xOcc(nn.Module):
             x4.features = torch.cat((x2.features, x3.features, x4.features), dim=1)
         return self._stage(self.down_combine, x4, ready)
 
-    def forward(self, batch_dict):
+    @staticmethod
+    def _coords_i32(batch_dict):
         from .vfe import i32_twin
         coords = batch_dict['voxel_coords']
         tw = i32_twin(batch_dict, coords)      # (PassOccVox's int64 coordinates come with an int32 twin: no conversion launch)
-        feats, coords = batch_dict['voxel_features'], (tw if tw is not None else coords.int())
+        return tw if tw is not None else coords.int()
+
+    def prefetch_geometry(self, batch_dict):
+        """every rulebook of this backbone for batch_dict['voxel_coords'] NOW -- by whoever has just produced the coordinates
+        (BtcHotPath.forward_occ, right behind PassOccVox): the walk is a function of the coordinates alone, its ~0.3 ms of host time
+        (one compiled call with a blocking read-back of the level sizes) is then off the thread that runs this branch's forward --
+        under the pipelined schedule the training thread, whose host time IS the step (BTC_TRAINER_TIMING=1: det_forward 2.6 of
+        4.6 ms, never waiting for anybody) -- and on the occupancy branch's worker, which has a millisecond to spare.
+        forward() picks the result up if it is given the very same coordinate tensor."""
+        coords = self._coords_i32(batch_dict)
+        if not coords.is_cuda or coords.shape[0] == 0:
+            return batch_dict
+        indice_dict = {}
+        walk = self._walk_geometry(coords, batch_dict['batch_size'], indice_dict, allow_async=False)
+        if isinstance(walk, tuple) and walk[0] == "done":
+            batch_dict['det_geometry'] = (coords, indice_dict, walk)
+        return batch_dict
+
+    def forward(self, batch_dict):
+        coords = self._coords_i32(batch_dict)
+        feats = batch_dict['voxel_features']
         if self.feature_dtype is not None and feats.shape[1] % 16 == 0:
             feats = feats.to(self.feature_dtype)     # (a 6-channel input stays fp32 through conv1, see VoxelBackBoneDeconv.forward)
         bs = batch_dict['batch_size']
         x = spconv.SparseConvTensor(features=feats, indices=coords, spatial_shape=self.sparse_shape, batch_size=bs)
-        walk = self._walk_geometry(coords, bs, x.indice_dict)
+        pre = batch_dict.pop('det_geometry', None)
+        if pre is not None and pre[0] is coords:     # rulebooks of this very coordinate tensor (prefetch_geometry)
+            x.indice_dict = pre[1]
+            walk = pre[2]
+        else:
+            walk = self._walk_geometry(coords, bs, x.indice_dict)
         if not walk and self._first_strided is not None:
             # conv2's row count runs beside conv1 (rulebook lookahead, spconv/ops.py)
             self._first_strided.prefetch(coords, self.sparse_shape, bs, x.indice_dict)

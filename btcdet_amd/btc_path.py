@@ -17,6 +17,30 @@ from . import backbones_3d, bev_backbone, dense_head, height_compression, occ_he
 from .processor import DataProcessor
 
 
+def _device_tensors(obj, depth=0):
+    """the device tensors inside a batch_dict value: a tensor (anything with record_stream), or a container (tuple / list / dict / an
+    object with __slots__ such as spconv.ops.Rulebook) of them"""
+    if torch.is_tensor(obj):
+        if obj.is_cuda:
+            yield obj
+    elif hasattr(obj, "record_stream"):
+        yield obj
+    elif depth < 5 and not isinstance(obj, (str, bytes, int, float, bool, type(None))):
+        if isinstance(obj, dict):
+            items = list(obj.values())
+        elif isinstance(obj, (tuple, list)):
+            items = obj
+        elif hasattr(obj, "__slots__"):
+            items = [getattr(obj, a, None) for a in obj.__slots__]
+        else:
+            return
+        for v in items:
+            yield from _device_tensors(v, depth + 1)
+
+
+DET_GEOMETRY_AHEAD = True   # forward_occ walks the detection backbone's rulebooks right behind PassOccVox (False: forward_det does, as before round 6)
+
+
 class HotPathDataset(object):
     """the attributes Detector3DTemplate reads from its dataset (dataset.py:27-41)"""
 
@@ -209,10 +233,17 @@ class BtcHotPath(nn.Module):
         prepared = {id(v) for v in batch_dict.values()} if gen is not None else None
         for mod in self.occ_module_list[n_done:]:
             batch_dict = mod(batch_dict)
+        dbb = self.det_modules.backbone_3d
+        if DET_GEOMETRY_AHEAD and hasattr(dbb, "prefetch_geometry") and "voxel_coords" in batch_dict and batch_dict["voxel_coords"].is_cuda:
+            # the detection backbone's rulebooks are a function of the coordinates PassOccVox has just made: walked here, on the thread
+            # that has them first (see VoxelBackBone8xOcc.prefetch_geometry)
+            batch_dict = dbb.prefetch_geometry(batch_dict)
         if prepared is not None:
             # what THIS call produced (on the current stream's pool): the only tensors a consumer on another stream has to register
             # (hand_over) -- the prepared front is kept alive by its generation until the step has ended on every stream
             batch_dict["__produced_here__"] = [v for v in batch_dict.values() if torch.is_tensor(v) and v.is_cuda and id(v) not in prepared]
+            if "det_geometry" in batch_dict:     # (the rulebooks' tensors live in this stream's pool too: kept alive with the rest)
+                batch_dict["__produced_here__"].append(batch_dict["det_geometry"])
         det_inputs_ready = None
         if torch.cuda.is_available() and batch_dict["voxels"].is_cuda:
             det_inputs_ready = torch.cuda.Event()
@@ -227,15 +258,20 @@ class BtcHotPath(nn.Module):
         COMPLETED -- a host-side query, no stream is made to wait).  Their blocks cannot return to the producer's pool earlier, which
         is all record_stream would have ensured.  Only for batches of a loop that calls mark_step_end() (a prepared batch: __gen_id__)."""
         pend = self.__dict__.setdefault("_borrowed", [])
-        # steps end in order on the consuming stream: drop from the oldest on and stop at the first event that has not completed (an event
-        # query is a driver call, ~50 us: querying every pending generation was 0.25 ms of the training thread per step)
-        # -- and not at all while fewer than three generations are held (two steps' worth of the occupancy branch's outputs)
-        while len(pend) >= 3 and pend[0]["ended"] is not None and pend[0]["ended"].query():
+        # Steps end in order on the consuming stream, and every forward_det contains a BLOCKING read-back on that stream (the rulebook
+        # walk's level sizes, or PassOccVox's counts on the producer's side): when this is called for generation g, the last such wait
+        # -- in step g - 1 -- was enqueued behind the end-of-step event of generation g - 2, which has therefore completed.  So
+        # generations up to g - 3 are dropped without asking the driver (an event query is ~50 us: the queries were 0.24 ms of the
+        # training thread per step, on the thread whose host time is the step); anything older than six generations is queried.
+        gen = batch_dict["__gen_id__"]
+        while pend and pend[0]["ended"] is not None and pend[0]["id"] <= gen - 3:
+            pend.pop(0)
+        while len(pend) >= 6 and pend[0]["ended"] is not None and pend[0]["ended"].query():
             pend.pop(0)
         while sum(b["ended"] is None for b in pend) > 3:   # nobody calls mark_step_end(): register the oldest with the consumer after all
             old = next(b for b in pend if b["ended"] is None)
             pend.remove(old)
-            for t in old["refs"]:
+            for t in _device_tensors(old["refs"]):
                 t.record_stream(torch.cuda.current_stream())
         pend.append({"id": batch_dict["__gen_id__"], "refs": list(batch_dict.pop("__produced_here__")), "ended": None})
 
@@ -244,11 +280,8 @@ class BtcHotPath(nn.Module):
         """register every device tensor of batch_dict with `stream`, which will consume them:
         they were allocated on the producer's stream, whose pool would otherwise hand their blocks out again while `stream` still
         reads them.  ~40 calls of ~10 us: the pipelined step makes them from the producer's thread, off the training thread."""
-        def rec(t):
-            if torch.is_tensor(t) and t.is_cuda:
-                t.record_stream(stream)
-        for v in batch_dict.pop("__produced_here__", None) or batch_dict.values():
-            rec(v)
+        for t in _device_tensors(batch_dict.pop("__produced_here__", None) or list(batch_dict.values())):
+            t.record_stream(stream)
         batch_dict["__recorded_for__"] = stream.cuda_stream
 
     def forward_det(self, batch_dict, inputs_ready=None):

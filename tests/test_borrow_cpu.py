@@ -57,9 +57,8 @@ def test_borrowed_tensors_are_released_only_after_the_steps_end_event_completed(
     p._prep_state["consumed"] = 8
     BtcHotPath._borrow(p, {"__gen_id__": 8, "__produced_here__": [FakeTensor()]})
     assert [e["id"] for e in p._borrowed] == [7, 8]
-    # ... and lets go once the event has completed -- looked at only when three generations are held (an event query is a driver
-    # call; two steps' worth of outputs is what the pipelined schedule keeps alive anyway); nothing was ever registered with a stream
-    ev.done = True
+    # ... and lets go of a generation once a call three generations later comes in (every forward_det holds a blocking read-back on the
+    # consuming stream: by then the event of generation g - 3 has completed -- no driver query); nothing was ever registered with a stream
     BtcHotPath._borrow(p, {"__gen_id__": 9, "__produced_here__": [FakeTensor()]})
     assert [e["id"] for e in p._borrowed] == [7, 8, 9]
     BtcHotPath._borrow(p, {"__gen_id__": 10, "__produced_here__": [FakeTensor()]})
