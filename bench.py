@@ -317,7 +317,9 @@ def main():
         else:
             base = 0
         n = len(pool)
-        call = lambda j: step_fn(pool[(base + j) % n], pool[(base + j + 1) % n])
+        two_ahead = getattr(step_fn, "pipelined", False) and os.environ.get("BTC_BENCH_AHEAD", "2") == "2"   # (a loader's second prefetched batch)
+        call = (lambda j: step_fn(pool[(base + j) % n], pool[(base + j + 1) % n], pool[(base + j + 2) % n])) if two_ahead else \
+            (lambda j: step_fn(pool[(base + j) % n], pool[(base + j + 1) % n]))
         for i in range(n_warm):
             call(i)
         sync()
@@ -335,7 +337,10 @@ def main():
                 rows.append(getattr(rows_of, "last_level_rows", None))
         sync()
         dt = time.perf_counter() - t0
-        ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(n_steps))
+        ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(n_steps)]
+        if os.environ.get("BTC_BENCH_DUMP_STEPS") == "1" and rank == 0:   # (the timed steps one by one, in order: mode flips inside a run)
+            print("step ms: " + " ".join("%.2f" % v for v in ms), file=sys.stderr)
+        ms = sorted(ms)
         return dt, ms, torch.cuda.memory_stats(device).get("num_device_alloc", 0) - allocs0, rows
 
     # Setup, before the W warmup steps: the caching allocator, the per-batch-size geometry plans and the flat optimizer buffers reach

@@ -247,7 +247,9 @@ def make_step(model, ddp, proc, opts, grad_sync=None, prefetch_stream=None, thre
             return t
         return 0.0
 
-    def step_pipelined(batch, next_batch):
+    prep_ahead = {}
+
+    def step_pipelined(batch, next_batch, after_next=None):
         import time
         t = time.perf_counter() if timing is not None else 0.0
         c0 = time.thread_time() if timing is not None else 0.0
@@ -259,7 +261,14 @@ def make_step(model, ddp, proc, opts, grad_sync=None, prefetch_stream=None, thre
         pending.clear()
         bd, loss_occ, tb, inputs_ready, occ_fwd_done = cur
         occ_done = threading.Event()
-        prep_future = prep_pool.submit(prep, next_batch) if (prep_pool is not None and next_batch is not None) else None
+        # the weight-independent front: of the NEXT batch if nobody has started it yet, and -- given the batch after that -- of THAT one,
+        # a step ahead of its turn (the front of batch k + 2 and the worker's occupancy forward of batch k + 1 were one chain,
+        # prepare -> forward, 1.65 + 1.73 ms of host time: the longest in the step once the training thread's share had shrunk)
+        prep_future = _take(prep_ahead, next_batch) if next_batch is not None else None
+        if prep_future is None and prep_pool is not None and next_batch is not None:
+            prep_future = prep_pool.submit(prep, next_batch)
+        if prep_pool is not None and after_next is not None and after_next is not next_batch:
+            _put(prep_ahead, after_next, prep_pool.submit(prep, after_next))
         fut = pool.submit(occ_tail, loss_occ, next_batch, occ_done, prep_future)
         t = _mark("head", t)
         with torch.cuda.stream(det_stream):
@@ -298,9 +307,9 @@ def make_step(model, ddp, proc, opts, grad_sync=None, prefetch_stream=None, thre
             timing["cpu_main"] = timing.get("cpu_main", 0.0) + time.thread_time() - c0
         return loss
 
-    def step(batch, next_batch=None):
+    def step(batch, next_batch=None, after_next=None):
         if pipeline:
-            return step_pipelined(batch, next_batch)
+            return step_pipelined(batch, next_batch, after_next)
         for o in opts:
             o.zero_grad(set_to_none=True)
         bd = _take(pending, batch)
@@ -432,6 +441,9 @@ class HotPathTrainer(object):
         if distributed is None:
             distributed = dist.is_available() and dist.is_initialized()
         self.world = dist.get_world_size(process_group) if distributed else 1
+        if os.environ.get("BTC_SWITCH_INTERVAL"):      # (experiment: the interpreter's thread switch interval, seconds)
+            import sys
+            sys.setswitchinterval(float(os.environ["BTC_SWITCH_INTERVAL"]))
         schedule = schedule or os.environ.get("BTC_SCHEDULE", "pipelined")
         if schedule not in ("in_order", "split", "pipelined"):
             raise ValueError("schedule must be in_order, split or pipelined, got %r" % (schedule,))
@@ -494,9 +506,11 @@ class HotPathTrainer(object):
                         block = torch.empty(self._reserve_bytes, dtype=torch.uint8, device=self.device)
                         del block
 
-    def step(self, batch, next_batch=None):
-        """one optimizer step on `batch`; next_batch (optional) lets the schedule prepare / start it ahead"""
-        return self._step(batch, next_batch)
+    def step(self, batch, next_batch=None, after_next=None):
+        """one optimizer step on `batch`; next_batch (optional) lets the schedule prepare / start it ahead, after_next (optional, the batch
+        behind that: a loader's second prefetched batch) lets the pipelined schedule run the weight-independent front two batches
+        ahead -- every step still prepares exactly one batch"""
+        return self._step(batch, next_batch, after_next)
 
     def broadcast_buffers(self, src_member=0):
         """BatchNorm running statistics (every module buffer) of group member `src_member` -> all ranks.  The reference trains under
