@@ -51,18 +51,38 @@ BF16_MFMA_PEAK_TF = 2500.0  # same guide: dense bf16 MFMA peak (AMD's 5 PF figur
 
 
 def pmc_traffic_per_launch(waymo=False, bf=False):
-    """HBM bytes per conv_apply launch of this configuration from the committed PMC passes (profiles/r05_pmc*.json: rocprofv3 --pmc
+    """HBM bytes per conv_apply launch of this configuration from the committed PMC passes (profiles/r06_pmc*.json, else r05: rocprofv3 --pmc
     FETCH_SIZE and --pmc WRITE_SIZE in separate runs of the same bench command, FETCH_SIZE doubled per the gfx950 note of
     MI355X_MICROARCH.md); PMC counters cannot be read inside the timed process, so this is null when there is no pass of the
     configuration on file"""
     sfx = ("_waymo" if waymo else "") + ("_bf16" if bf else "")
-    names = ["r05_pmc%s.json" % sfx] + ([] if sfx else ["r04_pmc.json", "r03j_pmc.json", "r03_pmc.json", "r02h_pmc.json"])
+    names = ["r06_pmc%s.json" % sfx, "r05_pmc%s.json" % sfx] + ([] if sfx else ["r04_pmc.json", "r03j_pmc.json", "r03_pmc.json", "r02h_pmc.json"])
     try:
         name = next(n for n in names if os.path.exists(os.path.join(ROOT, "profiles", n)))
         with open(os.path.join(ROOT, "profiles", name)) as f:
             return json.load(f)["conv_apply"]["hbm_bytes_per_launch"]
     except (StopIteration, OSError, KeyError, ValueError):
         return None
+
+
+def scheduled_conv_ms(waymo=False, bf=False):
+    """conv_apply (+ split_reduce) milliseconds per step as the kernels run IN the step, from the committed rocprofv3 kernel statistics of
+    the same command: {"serial": in order with the weight gradients on their side stream, "default": the pipelined schedule}.  The
+    roofline leg below times the launches alone (nothing beside them); these say what contention costs.  None where no file exists."""
+    import csv
+    sfx = ("_waymo" if waymo else "") + ("_bf16" if bf else "")
+    out = {}
+    for kind, name in (("serial", "r06_serial%s_kernel_stats.csv" % sfx), ("default", "r06_bench%s_kernel_stats.csv" % sfx)):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                rows = list(csv.DictReader(f))
+            steps = sum(int(r["Calls"]) for r in rows if "adam_apply" in r["Name"]) / 2.0
+            ns = sum(int(r["TotalDurationNs"]) for r in rows if "conv_apply" in r["Name"] or "split_reduce" in r["Name"])
+            if steps > 0:
+                out[kind] = {"ms_per_step": round(ns / steps / 1e6, 4), "source": "profiles/" + name}
+        except (OSError, KeyError, ValueError):
+            pass
+    return out or None
 
 
 def rank_seeds(rank, i, batch_size=2):
@@ -295,8 +315,8 @@ def main():
     cursor = [0]       # next unseen batch (wraps around only past BTC_BENCH_MAX_BATCHES distinct ones)
     # Schedule: HotPathTrainer's default ("pipelined": detection branch on its own stream, occupancy branch one step ahead, each
     # thread's bucket all-reduced behind its backward when a process group exists).  BTC_SCHEDULE=in_order|split|pipelined
-    # overrides; BTC_PREFETCH=0 is the old spelling of in_order.
-    schedule = os.environ.get("BTC_SCHEDULE") or ("in_order" if os.environ.get("BTC_PREFETCH") == "0" else "pipelined")
+    # overrides.
+    schedule = os.environ.get("BTC_SCHEDULE") or "pipelined"
     # the reference's optimizer step per parameter group (tools/train_utils/train_utils.py:121-124; yaml:331-372): gradient-norm
     # clip at 10, adam_onecycle = decoupled weight decay + Adam(betas=(mom, 0.99)) with lr / mom on the OneCycle schedule of a
     # 40-epoch run over KITTI's 3712 training frames -- btcdet_amd/train_step.py (checked against the reference's own
@@ -496,6 +516,13 @@ def main():
                                       "tflops": round(tf, 3), "mfma_peak_tflops": mfma_peak, "frac_mfma": round(f_mfma, 5),
                                       "frac_hbm_measured": None if f_meas is None else round(f_meas, 5),
                                       "kernel_ms_per_step": round(k["ms"] / prof_steps, 3)}
+                # the same algorithmic bytes against the kernels' durations INSIDE the step (committed rocprofv3 statistics of this command)
+                sched = scheduled_conv_ms(waymo, bf)
+                if sched:
+                    bps = k["bytes"] / prof_steps
+                    for kind, v in sched.items():
+                        result["roofline"]["frac_scheduled" if kind == "serial" else "frac_default_schedule"] = round(bps / (v["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
+                    result["roofline"]["scheduled_source"] = {kind: v for kind, v in sched.items()}
             for name in ("conv_wgrad", "rulebook"):
                 k = summ.get(name)
                 if k:
@@ -534,7 +561,7 @@ def straggler_estimate():
     (tools/straggler.py -> profiles/*_straggler.json): the gradient all-reduce is a barrier, so a step takes as long as the
     slowest of the 8 ranks' batches; E[mean] / E[max of 8 independent draws].  None when the file is absent."""
     try:
-        name = next(n for n in ("r05_straggler.json", "r04_straggler.json", "r03j_straggler.json") if os.path.exists(os.path.join(ROOT, "profiles", n)))
+        name = next(n for n in ("r06_straggler.json", "r05_straggler.json", "r04_straggler.json", "r03j_straggler.json") if os.path.exists(os.path.join(ROOT, "profiles", n)))
         with open(os.path.join(ROOT, "profiles", name)) as f:
             d = json.load(f)
         return {"world": 8, "efficiency": d["predicted_eff_world8"], "source": "committed profile (not measured in this run)",

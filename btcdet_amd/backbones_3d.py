@@ -207,8 +207,8 @@ class VoxelBackBoneDeconv(nn.Module):
         return x
 
 
-DET_GEOMETRY_WALK = os.environ.get("BTC_DET_GEOMETRY_WALK", "1") != "0"  # VoxelBackBone8xOcc._walk_geometry
-FAST_STAGES = os.environ.get("BTC_FAST_STAGES", "1") != "0"               # VoxelBackBone8xOcc._stage: stages straight into the compiled chain call
+DET_GEOMETRY_WALK = True  # VoxelBackBone8xOcc._walk_geometry (False: the layers build their rulebooks one by one; tests flip it)
+FAST_STAGES = True        # VoxelBackBone8xOcc._stage: stages straight into the compiled chain call
 
 
 class VoxelBackBone8xOcc(nn.Module):
@@ -267,7 +267,7 @@ class VoxelBackBone8xOcc(nn.Module):
         # the strided levels of the rulebook walk built beside the first stage on a side stream (True), or the whole walk first with one
         # blocking read-back (False).  Per instance: a schedule that already runs the branch on a stream of its own switches it off
         # (HotPathTrainer, pipelined: a fifth active stream costs 1.8 ms per step there).
-        self.walk_async = os.environ.get("BTC_DET_WALK_ASYNC", "1") != "0"
+        self.walk_async = True
 
     def _walk_geometry(self, coords, bs, indice_dict, allow_async=True):
         """all rulebooks of the main chain (subm1, spconv2, subm2, ... spconv_down2, subm_down2) in one call of the compiled

@@ -131,7 +131,7 @@ def trilinear_splat_resident(x, flat_points, points_per_batch, batch_size, point
     return keep, _TrilinearRead.apply(feats, rows[keep].contiguous(), wts[keep].contiguous())
 
 
-RESIDENT_SPLAT = __import__("os").environ.get("BTC_ROI_TRILINEAR", "1") != "0"
+RESIDENT_SPLAT = True   # the read-out of x_combine without densifying it (csrc/roi_pool.hip); False: the dense formulation (tests compare the two)
 
 
 class ConvHead(nn.Module):

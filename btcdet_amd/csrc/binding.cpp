@@ -321,13 +321,12 @@ struct SideStream {
 // is deferred only if its weight is a leaf parameter (allow_defer): a dW that another autograd node consumes during
 // backward -- the occupancy head's merged weight goes through CatBackward -- must be complete when its node returns.
 std::atomic<bool> g_defer_join{false};
-// ... and their slab reductions are batched into the join (BTC_WGRAD_BATCH_REDUCE=0: one reduction per layer, as before round 5)
-const bool g_batch_reduce = !(getenv("BTC_WGRAD_BATCH_REDUCE") && atoi(getenv("BTC_WGRAD_BATCH_REDUCE")) == 0);
+// ... and their slab reductions are batched into the join (false: one reduction per layer, as before round 5)
+const bool g_batch_reduce = true;
 
 // flags of events that only order streams of one device among themselves (never waited for by the host to read host memory)
 unsigned sync_event_flags() {
-  static const bool sys = getenv("BTC_EVENT_SYSTEM_FENCE") && atoi(getenv("BTC_EVENT_SYSTEM_FENCE")) == 1;
-  return sys ? hipEventDisableTiming : (hipEventDisableTiming | hipEventDisableSystemFence);
+  return hipEventDisableTiming | hipEventDisableSystemFence;
 }
 
 SideStream& side_of(int device) {
@@ -345,7 +344,6 @@ SideStream& side_of(int device) {
     // release at every record -- a write-back + invalidate of the caches (hip_runtime_api.h, hipEventDisableSystemFence: "avoiding
     // the cost of cache writeback and invalidation, and the performance impact of those actions on the execution of following
     // work") -- ~28 times per backward pass here, each one emptying the L2 the gathers of the next kernels live on.
-    // BTC_EVENT_SYSTEM_FENCE=1 restores the default (A/B knob).
     const unsigned flags = sync_event_flags();
     if (hipEventCreateWithFlags(&s.fork, flags) != hipSuccess || hipEventCreateWithFlags(&s.join, flags) != hipSuccess)
       throw std::runtime_error("hipEventCreateWithFlags failed");
@@ -428,9 +426,8 @@ std::tuple<OptTensor, OptTensor> conv_bwd(const Tensor& features, const Tensor& 
   // may start, so neither waits for the other).  Whichever is enqueued first gets the compute units first.  fp32: dgrad first --
   // it feeds the next backward node, the critical path (6.57 -> 6.42 ms per step).  bf16 operands: the weight gradient (still
   // fp32-accumulated from widened activations) is the long pole of the backward pass, 2-3x the dgrad beside it; started late
-  // it leaves an exposed tail at the join (7.4 ms per step dgrad-first, 6.1 wgrad-first).  BTC_WGRAD_FIRST=0/1 overrides.
-  static const int order_env = getenv("BTC_WGRAD_FIRST") ? atoi(getenv("BTC_WGRAD_FIRST")) : -1;
-  const bool wgrad_first = order_env >= 0 ? order_env != 0 : bf;
+  // it leaves an exposed tail at the join (7.4 ms per step dgrad-first, 6.1 wgrad-first).
+  const bool wgrad_first = bf;
   // The operand copy of a NON-leaf weight (the zero-padded 34 -> 64-channel one) is a temporary of this call.  It must outlive the
   // allocations of run_wgrad: this layer's weight gradient runs on the side stream BESIDE the dgrad (its fork was recorded before
   // either launch), so a dW / workspace block carved out of the just-released planes would be written while the dgrad still
@@ -923,10 +920,10 @@ std::vector<std::vector<Tensor>> geometry_walk_finish(const std::shared_ptr<Pend
   int64_t off_s = 0, off_o = 0;
   std::vector<std::vector<Tensor>> out(n);
   // row-order hints of the strided / transposed layers' maps (both directions), one launch for the chain: these are the maps
-  // whose 16-row tiles are mostly empty in coordinate order (csrc/row_order.hip).  BTC_ROW_ORDER=2 orders the SubM maps too
-  // (measured: within noise at KITTI sizes), 0 none.  The sort keys (first present offset of every row) come out of the fill
+  // whose 16-row tiles are mostly empty in coordinate order (csrc/row_order.hip); order_mode 2 would order the SubM maps too (measured:
+  // within noise at KITTI sizes), 0 none.  The sort keys (first present offset of every row) come out of the fill
   // itself (btc_chain_maps first_out / first_in).
-  static const int order_mode = getenv("BTC_ROW_ORDER") ? atoi(getenv("BTC_ROW_ORDER")) : 1;
+  constexpr int order_mode = 1;
   auto wants_order = [&](size_t i) {
     return !skip[i] && K[i] <= 64 && ((kind[i] == 1 && order_mode >= 1) || (kind[i] == 0 && order_mode >= 2));
   };

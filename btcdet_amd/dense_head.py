@@ -332,7 +332,7 @@ def proposal_layer(batch_dict, nms_config):
     if nms_config.MULTI_CLASSES_NMS:
         raise NotImplementedError
     if batch_dict.get("batch_index", None) is None and boxes.is_cuda and boxes.dim() == 3 and boxes.shape[1] > 0 and boxes.shape[-1] == 7 \
-            and nms_config.NMS_TYPE in ("nms_gpu", "nms_normal_gpu") and os.environ.get("BTC_NMS_TOPK", "1") != "0":
+            and nms_config.NMS_TYPE in ("nms_gpu", "nms_normal_gpu"):
         # every scene at once, resident: top-k by score, the greedy chain stopped at NMS_POST_MAXSIZE kept boxes (iou3d_nms.nms_topk --
         # exactly the reference's keep[:NMS_POST_MAXSIZE], model_nms_utils.py:6-25), padded rows gathered as zeros.  No read-back; the
         # per-scene loop below is the reference's own shape (one full chain over NMS_PRE_MAXSIZE boxes and two read-backs per scene).

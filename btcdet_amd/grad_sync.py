@@ -37,8 +37,8 @@ import torch
 import torch.distributed as dist
 
 _TIMING = {} if os.environ.get("BTC_SYNC_TIMING") == "1" else None  # host seconds spent in launch / wait (tools)
-_DRYRUN = os.environ.get("BTC_SYNC_DRYRUN") == "1"                   # A-B runs: everything but the collective itself
-_PACK_KERNEL = os.environ.get("BTC_SYNC_PACK", "1") != "0"            # one-launch pack (csrc/optim.hip) instead of a multi-tensor copy
+_DRYRUN = False                  # (tools: everything but the collective itself)
+_PACK_KERNEL = True              # one-launch pack (csrc/optim.hip) instead of a multi-tensor copy
 
 
 class GradSyncError(RuntimeError):
@@ -94,8 +94,8 @@ class BucketedGradSync(object):
         self.stage_on_host = want == "host"
         # RCCL averages in the collective (ncclAvg); elsewhere sum, then one scaling launch per bucket
         self.reduce_op = dist.ReduceOp.AVG if backend == "nccl" else dist.ReduceOp.SUM
-        self.use_comm_stream = os.environ.get("BTC_SYNC_COMM_STREAM", "1") != "0"
-        self.check_consistency = os.environ.get("BTC_SYNC_CHECK", "1") != "0"
+        self.use_comm_stream = True
+        self.check_consistency = True
         self._cs = {}
         self._handles = []
         for b in self.buckets:

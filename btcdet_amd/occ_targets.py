@@ -124,7 +124,7 @@ class OccTargets3D(nn.Module):
         # (btc_occ_backproject_lut); "inline" -- no table, the kernel evaluates them per occluded cell (rounds 1-3).
         # OCC.TARGETS.BACKPROJECT in the model config, BTC_OCC_BACKPROJECT in the environment.
         import os
-        self.backproject = os.environ.get("BTC_OCC_BACKPROJECT") or model_cfg.TARGETS.get("BACKPROJECT", "torch")
+        self.backproject = model_cfg.TARGETS.get("BACKPROJECT", "torch")
         assert self.backproject in ("torch", "device", "inline"), self.backproject
         self.sphere_offset = [float(v) for v in occ.get("SPHERE_OFFSET", [0.0, 0.0, 0.0])]
         # the reference adds the offset in BOTH directions (occ_pnts + sphere_offset going to the sphere grid, carte - offset coming back:

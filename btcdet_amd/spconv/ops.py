@@ -65,7 +65,7 @@ class _NoSpan(object):
 
 PROFILE = None  # set to a LaunchProfile() to instrument
 CAPTURE = None  # set to a list to record (features, weight, bias, map_fwd, map_bwd) of every sparse conv (tools/conv_bench.py)
-OVERLAP_WGRAD = os.environ.get("BTC_OVERLAP_WGRAD", "1") != "0"  # run wgrad on a side stream concurrently with dgrad (backward of every sparse conv)
+OVERLAP_WGRAD = True  # run wgrad on a side stream concurrently with dgrad (backward of every sparse conv)
 _SIDE = {}
 
 
@@ -167,7 +167,7 @@ class Rulebook(object):
         return pairs[:, :, :self.n_in], num
 
 
-ROW_ORDER = int(os.environ.get("BTC_ROW_ORDER", "1"))  # row-order hints: 1 = strided / transposed rulebooks, 2 = SubM too, 0 = none
+ROW_ORDER = 1  # row-order hints: 1 = strided / transposed rulebooks, 0 = none (tests flip it)
 
 
 def row_orders(maps):
@@ -347,14 +347,9 @@ def _fill_conv_rulebook(indices, batch_size, g, n_out, ws, ws_bytes):
 # Measured at KITTI size: with the halves managed in Python (ctypes route) neutral to negative -- stream contexts, events
 # and the pinned copy cost the host what the wait saved; managed inside the compiled binding (_btcfast.rulebook_conv_start /
 # _finish) +1.5 % (221 -> 224.5 scenes/s) -- see lookahead_enabled().
-_LOOKAHEAD_ENV = os.environ.get("BTC_LOOKAHEAD", "auto")
-
-
 def lookahead_enabled():
-    """BTC_LOOKAHEAD=1 / 0 force it; default: on when the compiled binding manages the two halves (events, pinned slot and
-    side stream in C++: 221 -> 224.5 scenes/s), off on the ctypes route (its Python per event costs what the wait saved)"""
-    if _LOOKAHEAD_ENV in ("0", "1"):
-        return _LOOKAHEAD_ENV == "1"
+    """on when the compiled binding manages the two halves (events, pinned slot and side stream in C++: 221 -> 224.5 scenes/s), off on
+    the ctypes route (its Python per event costs what the wait saved)"""
     return fast() is not None
 
 
@@ -507,9 +502,9 @@ def _wgrad_cost(nbr, n_res, K, cin, cout, act_bytes=4):
 # rows; on smaller layers the stream switches cost more host time than the overlap returns (the forward pass is bound by
 # the host's launch rate, the backward pass by the GPU: tools/host_phases.py).  Measured: 60000 -> 191, 20000 -> 194,
 # 0 -> 194 scenes/s
-NATIVE_AUTOGRAD = os.environ.get("BTC_NATIVE_AUTOGRAD", "1") != "0"  # conv -> BN -> ReLU as a C++ autograd node when _btcfast is built
+NATIVE_AUTOGRAD = True  # conv -> BN -> ReLU as a C++ autograd node when _btcfast is built
 OVERLAP_MIN_ROWS = int(os.environ.get("BTC_OVERLAP_MIN_ROWS", "20000"))
-OVERLAP_MAX_ROWS = int(os.environ.get("BTC_OVERLAP_MAX_ROWS", "100000"))  # above: both kernels fill the GPU alone, side by side 450 us vs 219 + 150
+OVERLAP_MAX_ROWS = 100000  # above: both kernels fill the GPU alone, side by side 450 us vs 219 + 150
 
 
 def set_defer_wgrad_join(on):
@@ -891,7 +886,7 @@ def cat_features(a, b):
 # fp32 features: 34 -> 64 channels (one 64-channel item per offset instead of three 16-channel ones: 83 -> 60 us forward, 68 -> 55 us dgrad
 # at 29 K rows, and the dgrad becomes a 32 -> 64 layer the split-operand kernel takes); bf16 features: 34 -> 48, which keeps that layer on
 # fp32 weights (48 is not a multiple of 32: no bf16 weight copy), i.e. bit-equal to the oracle's chain on the widened activations
-PAD_CHANNELS = int(os.environ.get("BTC_PAD_CHANNELS", "0"))   # 0 = by dtype as above
+PAD_CHANNELS = 0   # 0 = by dtype as above
 
 
 def pads_in_channels(cin):

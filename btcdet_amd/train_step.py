@@ -100,7 +100,7 @@ class GroupOptimizer(object):
         self.beta2, self.eps = beta2, eps
         self._present = self._missing = None
         if flat is None:
-            flat = os.environ.get("BTC_FLAT_OPTIM", "1") != "0"
+            flat = True
         if flat:
             for g in self.groups:
                 self._make_flat(g)

@@ -172,7 +172,7 @@ def make_step(model, ddp, proc, opts, grad_sync=None, prefetch_stream=None, thre
     # step i's detection optimizer on det_stream.  Two backward passes never run at the same time (the weight-gradient side
     # stream's join bookkeeping assumes one).
     if pipeline is None:
-        pipeline = os.environ.get("BTC_PIPELINE_OCC", "1") != "0"
+        pipeline = True
     pipeline = bool(pipeline and det_stream is not None and ddp is model and (grad_sync is None or bucket_of is not None)
                     and prefetch_stream is not None and threaded and len(opts) == 1 and hasattr(opts[0], "groups") and len(opts[0].groups) == 2)
     ahead_occ = {}
@@ -191,7 +191,7 @@ def make_step(model, ddp, proc, opts, grad_sync=None, prefetch_stream=None, thre
     # optimizer step / next forward but the worker thread they all used to queue on -- the step is bound by its host threads (measured,
     # BTC_TRAINER_TIMING=1: training thread 4.1 ms and worker 4.45 ms of host time per 4.9 ms step, the front 1.7 ms of the worker's)
     prep_pool = None
-    if pipeline and os.environ.get("BTC_PREP_THREAD", "1") != "0":
+    if pipeline:
         from concurrent.futures import ThreadPoolExecutor as _TPE
         prep_pool = _TPE(max_workers=1)
 
@@ -441,9 +441,6 @@ class HotPathTrainer(object):
         if distributed is None:
             distributed = dist.is_available() and dist.is_initialized()
         self.world = dist.get_world_size(process_group) if distributed else 1
-        if os.environ.get("BTC_SWITCH_INTERVAL"):      # (experiment: the interpreter's thread switch interval, seconds)
-            import sys
-            sys.setswitchinterval(float(os.environ["BTC_SWITCH_INTERVAL"]))
         schedule = schedule or os.environ.get("BTC_SCHEDULE", "pipelined")
         if schedule not in ("in_order", "split", "pipelined"):
             raise ValueError("schedule must be in_order, split or pipelined, got %r" % (schedule,))

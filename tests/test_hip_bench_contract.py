@@ -47,8 +47,8 @@ def test_bench_json_line_contract():
 
 
 def test_bench_in_order_schedule_still_runs():
-    """BTC_PREFETCH=0: no worker thread, no side-stream preparation -- the plain step the roofline leg uses"""
-    env = dict(os.environ, BTC_PREFETCH="0")
+    """BTC_SCHEDULE=in_order: no worker thread, no side-stream preparation -- the plain step the roofline leg uses"""
+    env = dict(os.environ, BTC_SCHEDULE="in_order")
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-roofline"],
                        cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, text=True)
     assert p.returncode == 0, p.stderr[-2000:]
