@@ -99,12 +99,13 @@ def max_over_ranks(dt, dist, device):
     return float(t.item())
 
 
-def build_batches(n_batches, rank, device, batch_size=2, profile="kitti"):
+def build_batches(n_batches, rank, device, batch_size=2, profile="kitti", az_step=None):
+    """az_step: azimuth step of the synthetic scan in degrees (tools: tiny scenes, whose step time is host / launch cost)"""
     from btcdet_amd import synth
     batches = []
     for i in range(n_batches):
         seeds = rank_seeds(rank, i, batch_size)
-        kw = {"az_step": float(os.environ["BTC_BENCH_AZ_STEP"])} if os.environ.get("BTC_BENCH_AZ_STEP") else {}  # tiny scenes: host-cost probe
+        kw = {"az_step": float(az_step)} if az_step else {}
         b = synth.make_batch(seeds, profile=profile, **kw)
         batches.append({
             "batch_size": batch_size,
@@ -215,6 +216,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--priming", type=int, default=64, help="optimizer steps before the timed region, warm-up included (see the comment at `priming`)")
     ap.add_argument("--no-extras", action="store_true", help="skip the two secondary measurements (in-order rate, RPN-head run)")
     ap.add_argument("--workload", choices=["kitti", "waymo"], default="kitti",
                     help="kitti: the configuration BASELINE.json's metric is quoted on (default); waymo: the Waymo-shaped synthetic "
@@ -234,10 +236,7 @@ def main():
     if args.gpus > 1 and world == 1:
         raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback for the hot path)"
-    # BTC_BENCH_BACKEND=gloo lets N ranks share one GPU (functional check of the N > 1 path on a 1-GPU box); the default
-    # is one rank per GPU over RCCL ("nccl" on ROCm)
-    backend = os.environ.get("BTC_BENCH_BACKEND", "nccl")
-    dev_index = local_rank % torch.cuda.device_count() if backend != "nccl" else local_rank
+    dev_index = local_rank            # one rank per GPU over RCCL ("nccl" on ROCm)
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
     # host threads of this rank next to its GPU (btcdet_amd/affinity.py): the step is launch-rate sensitive, and on a two-socket
@@ -267,10 +266,7 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         with _StdoutToStderr():
-            if backend == "nccl":
-                dist.init_process_group(backend="nccl", **({} if os.environ.get("BTC_BENCH_LAZY_NCCL") == "1" else {"device_id": device}))
-            else:
-                dist.init_process_group(backend=backend)
+            dist.init_process_group(backend="nccl", device_id=device)
             dist.barrier()   # the communicator exists (and has printed its banner) before anything else happens
 
     from btcdet_amd.btc_path import BtcHotPath
@@ -307,12 +303,12 @@ def main():
     # priming + warm-up = 64 optimizer steps: the caching allocator and the plans reach their steady state within ~16; the rest lets the
     # occupancy head leave its random initialisation, so PassOccVox adds what a head in training adds (tools/workload_drift.py: the
     # detection levels hover around 32-34 K / 30-36 K / 14-19 K / 6-8 K rows from step ~30 on; config.level_rows reports the timed steps')
-    priming = max(0, int(os.environ.get("BTC_BENCH_PRIMING", "64")) - args.warmup)
+    priming = max(0, args.priming - args.warmup)
     n_distinct = min(priming + args.warmup + args.steps + 2 + (0 if (args.no_extras or waymo) else 12) + (0 if args.no_roofline else 8),
-                     int(os.environ.get("BTC_BENCH_MAX_BATCHES", "192" if not waymo else "48")))
+                     192 if not waymo else 48)
     batches = build_batches(n_distinct, rank, device, bs, args.workload)
     nb = len(batches)
-    cursor = [0]       # next unseen batch (wraps around only past BTC_BENCH_MAX_BATCHES distinct ones)
+    cursor = [0]       # next unseen batch (wraps around only past 192 distinct ones; Waymo shape: 48)
     # Schedule: HotPathTrainer's default ("pipelined": detection branch on its own stream, occupancy branch one step ahead, each
     # thread's bucket all-reduced behind its backward when a process group exists).  BTC_SCHEDULE=in_order|split|pipelined
     # overrides.
@@ -321,8 +317,7 @@ def main():
     # clip at 10, adam_onecycle = decoupled weight decay + Adam(betas=(mom, 0.99)) with lr / mom on the OneCycle schedule of a
     # 40-epoch run over KITTI's 3712 training frames -- btcdet_amd/train_step.py (checked against the reference's own
     # OptimWrapper / OneCycle, tests/test_train_step_cpu.py).  The two optimizers are the two groups of one object.
-    # (BTC_BENCH_NOSYNC=1: process group without a reducer -- an A/B knob for what the group itself costs)
-    with_reducer = use_dist and os.environ.get("BTC_BENCH_NOSYNC") != "1"
+    with_reducer = use_dist
     with _StdoutToStderr():
         trainer = HotPathTrainer(model, schedule=schedule, distributed=with_reducer, det_loss=model.det_loss)
     step, grad_sync, opt = trainer._step, trainer.grad_sync, trainer.optimizer
@@ -337,7 +332,7 @@ def main():
         else:
             base = 0
         n = len(pool)
-        two_ahead = getattr(step_fn, "pipelined", False) and os.environ.get("BTC_BENCH_AHEAD", "2") == "2"   # (a loader's second prefetched batch)
+        two_ahead = getattr(step_fn, "pipelined", False)   # a loader's second prefetched batch: its weight-independent front runs one step earlier
         call = (lambda j: step_fn(pool[(base + j) % n], pool[(base + j + 1) % n], pool[(base + j + 2) % n])) if two_ahead else \
             (lambda j: step_fn(pool[(base + j) % n], pool[(base + j + 1) % n]))
         for i in range(n_warm):
@@ -358,8 +353,6 @@ def main():
         sync()
         dt = time.perf_counter() - t0
         ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(n_steps)]
-        if os.environ.get("BTC_BENCH_DUMP_STEPS") == "1" and rank == 0:   # (the timed steps one by one, in order: mode flips inside a run)
-            print("step ms: " + " ".join("%.2f" % v for v in ms), file=sys.stderr)
         ms = sorted(ms)
         return dt, ms, torch.cuda.memory_stats(device).get("num_device_alloc", 0) - allocs0, rows
 
@@ -405,11 +398,7 @@ def main():
         extras["recurring_batches_scenes_per_s"] = {"scenes_per_s": round(bs * world * k_rec / dt_rec, 2), "steps": k_rec, "warm": 16,
                                                     "level_rows_last_step": rows_rec[-1] if rows_rec else None,
                                                     "what": "4 recurring batches (round 3's workload): NOT the headline -- the optimizer memorises them"}
-    if grad_sync is not None and os.environ.get("BTC_SYNC_TIMING") == "1" and rank == 0:
-        from btcdet_amd import grad_sync as _gs
-        n = max(_gs._TIMING.get("n", 1), 1)
-        print("grad_sync host ms per step:", {k: round(v / n * 1e3, 3) for k, v in _gs._TIMING.items() if k != "n"}, file=sys.stderr)
-    if want_extras and args.heads == "standin" and os.environ.get("BTC_BENCH_RPN", "1") != "0":
+    if want_extras and args.heads == "standin":
         # the same step with the §8f row-1 heads behind the BEV map (BaseBEVBackbone + AnchorHeadSingle, RPN loss of btcnet.py:108-114;
         # dense 2-D convs = vendor library): a second model, trainer and optimizer, run after the headline measurement
         del plain_step

@@ -42,14 +42,6 @@ inline void* vptr(const OptTensor& t) { return (t.has_value() && t->defined()) ?
 inline void* st(int64_t stream) { return reinterpret_cast<void*>(stream); }
 inline const int32_t* ip(int64_t p) { return reinterpret_cast<const int32_t*>(p); }
 
-// BTC_DEBUG_SYNC=1: synchronise the device after every binding call and name the call a fault surfaces in
-inline void dbg_sync(const char* where) {
-  static const bool on = getenv("BTC_DEBUG_SYNC") != nullptr;
-  if (!on) return;
-  hipError_t e = hipDeviceSynchronize();
-  fprintf(stderr, "[btcfast] %s: %s\n", where, hipGetErrorString(e));
-  fflush(stderr);
-}
 
 inline void need(bool ok, const char* msg) {
   if (!ok) throw std::runtime_error(msg);
@@ -508,7 +500,6 @@ std::tuple<OptTensor, OptTensor> conv_bwd(const Tensor& features, const Tensor& 
       }
     }
   }
-  dbg_sync("conv_bwd");
   return std::make_tuple(din, dw);
 }
 
@@ -642,7 +633,6 @@ std::shared_ptr<PendingRb> rulebook_conv_start(const Tensor& indices, int64_t ba
                               ip(p_p), ip(p_d), (int)mode, (int32_t*)p->host_n, p->ws.data_ptr(), (size_t)ws_bytes, (void*)r.side),
       "btc_rulebook_conv_count");
   if (hipEventRecord(p->done, r.side) != hipSuccess) throw std::runtime_error("rulebook lookahead: event record failed");
-  dbg_sync("rulebook_conv_start");
   return p;
 }
 
@@ -658,7 +648,6 @@ std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor> rulebook_conv_finish(const st
                              ip(p->p_p), ip(p->p_d), (int)p->mode, (int)n_out, (int32_t*)out_indices.data_ptr(), (int32_t*)nbr_out.data_ptr(),
                              (int32_t*)nbr_in.data_ptr(), p->ws.data_ptr(), (size_t)p->ws_bytes, (void*)main), "btc_rulebook_conv_fill");
   auto ord = row_orders({nbr_out, nbr_in}, (int64_t)(intptr_t)main);
-  dbg_sync("rulebook_conv_finish");
   return std::make_tuple(out_indices, nbr_out, nbr_in, ord[0], ord[1]);
 }
 
@@ -865,7 +854,6 @@ std::shared_ptr<PendingWalk> geometry_walk_start(const Tensor& indices, int64_t 
     p->h_counts = p->d_counts.to(at::kCPU);  // the one read-back of the chain (current stream only)
     p->counts = (const int32_t*)p->h_counts.data_ptr();
   }
-  dbg_sync("geometry_walk_start");
   return p;
 }
 
@@ -982,7 +970,6 @@ std::vector<std::vector<Tensor>> geometry_walk_finish(const std::shared_ptr<Pend
         out[i].push_back(ord[q++]);
       }
   }
-  dbg_sync("geometry_walk");
   return out;
 }
 

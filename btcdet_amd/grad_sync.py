@@ -16,10 +16,10 @@ plus per-parameter hooks), so the step uses this reducer instead -- same result,
 Transports (``transport=`` / BTC_SYNC_TRANSPORT): ``torch`` -- ``dist.all_reduce`` of the process group (backend "nccl" = RCCL over
 xGMI; the default), ``rccl`` -- ncclAllReduce(ncclAvg) on a communicator of our own (btcdet_amd/rccl_direct.py), ``host`` -- reduce
 a host copy over gloo (ranks sharing one GPU in the functional tests; the way DDP treats gloo).  Measured at world size 1 on one
-MI355X (tools/ab_dist.sh, pipelined schedule, scenes/s): no process group 445, ``torch`` 422, ``rccl`` 162 -- the call itself is
-cheaper there (4 us of host time and an 11 us kernel per 10 MB bucket against 18 us / 46 us, tools/rccl_probe.py), but a SECOND RCCL
+MI355X (round 5, pipelined schedule, scenes/s): no process group 445, ``torch`` 422, ``rccl`` 162 -- the call itself is
+cheaper there (4 us of host time and an 11 us kernel per 10 MB bucket against 18 us / 46 us), but a SECOND RCCL
 communicator in the process takes hardware queues of its own and the step's streams end up sharing theirs (the same run with the
-collective switched off, BTC_SYNC_DRYRUN=1: 156), so it is opt-in, for a process whose control plane is not on RCCL.
+collective itself skipped: 156), so it is opt-in, for a process whose control plane is not on RCCL.
 
 Rank consistency (the contract of DDP with find_unused_parameters=False): every rank must produce a gradient for the same
 parameters.  The optimizer treats EVERY parameter of a reduced bucket as present -- a rank that had no gradient for one
@@ -36,8 +36,6 @@ import os
 import torch
 import torch.distributed as dist
 
-_TIMING = {} if os.environ.get("BTC_SYNC_TIMING") == "1" else None  # host seconds spent in launch / wait (tools)
-_DRYRUN = False                  # (tools: everything but the collective itself)
 _PACK_KERNEL = True              # one-launch pack (csrc/optim.hip) instead of a multi-tensor copy
 
 
@@ -110,16 +108,6 @@ class BucketedGradSync(object):
             b = self.buckets[b]
         if b.launched or not b.params:
             return
-        if _TIMING is not None:
-            import time
-            t0 = time.perf_counter()
-            try:
-                return self._launch_impl(b, only_if_complete)
-            finally:
-                _TIMING["launch"] = _TIMING.get("launch", 0.0) + time.perf_counter() - t0
-        return self._launch_impl(b, only_if_complete)
-
-    def _launch_impl(self, b, only_if_complete):
         grads = [p.grad for p in b.params]
         n_missing = sum(g is None for g in grads)
         if only_if_complete and n_missing:
@@ -163,8 +151,6 @@ class BucketedGradSync(object):
             self._read_tail(b, torch.cuda.current_stream() if on_gpu else None)
 
     def _all_reduce(self, b, stream):
-        if _DRYRUN:
-            return
         if self.comm is not None:
             self.comm.all_reduce_(b.flat, stream, average=True)
         else:
@@ -172,7 +158,7 @@ class BucketedGradSync(object):
 
     def _read_tail(self, b, stream):
         """the reduced count of missing gradients -> pinned host memory, asynchronously; looked at when the bucket is next launched"""
-        if not self.check_consistency or _DRYRUN:
+        if not self.check_consistency:
             return
         if b.flat.is_cuda:
             if b.work is not None:   # torch transport: the collective runs on the process group's stream
@@ -225,7 +211,7 @@ class BucketedGradSync(object):
             b.flat[-2:].copy_(torch.tensor([float(n_missing), float(n_missing) ** 2], dtype=torch.float32), non_blocking=False)
             b.dirty_tail = True
         elif b.dirty_tail or not self.check_consistency:
-            # (BTC_SYNC_CHECK=0: nobody reads the reduced tail back, so nobody learns that another rank made it non-zero -- zero it
+            # (check_consistency=False: nobody reads the reduced tail back, so nobody learns that another rank made it non-zero -- zero it
             # every step, 8 bytes)
             b.flat[-2:].zero_()
             b.dirty_tail = False
@@ -279,17 +265,6 @@ class BucketedGradSync(object):
 
     def finish(self):
         """call after backward, before the optimizer step"""
-        if _TIMING is not None:
-            import time
-            t0 = time.perf_counter()
-            try:
-                return self._finish_impl()
-            finally:
-                _TIMING["finish"] = _TIMING.get("finish", 0.0) + time.perf_counter() - t0
-                _TIMING["n"] = _TIMING.get("n", 0) + 1
-        return self._finish_impl()
-
-    def _finish_impl(self):
         for b in self.buckets:
             self.launch(b)
         for b in self.buckets:

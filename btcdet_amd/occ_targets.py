@@ -122,8 +122,7 @@ class OccTargets3D(nn.Module):
         # kernels, i.e. the arithmetic a CPU run of the reference quantises on (backproject_table_host: 0 cells differ from the
         # reference-pinned oracle); "device" -- the same table filled by the device's correctly-rounded transcendentals
         # (btc_occ_backproject_lut); "inline" -- no table, the kernel evaluates them per occluded cell (rounds 1-3).
-        # OCC.TARGETS.BACKPROJECT in the model config, BTC_OCC_BACKPROJECT in the environment.
-        import os
+        # OCC.TARGETS.BACKPROJECT in the model config.
         self.backproject = model_cfg.TARGETS.get("BACKPROJECT", "torch")
         assert self.backproject in ("torch", "device", "inline"), self.backproject
         self.sphere_offset = [float(v) for v in occ.get("SPHERE_OFFSET", [0.0, 0.0, 0.0])]

@@ -11,7 +11,7 @@ The library is the ``librccl.so`` PyTorch itself loads (``torch/lib``), so both 
 
 Opt-in (BTC_SYNC_TRANSPORT=rccl), not the default: beside the process group's own RCCL communicator a second one takes further
 hardware queues and the step's streams end up sharing theirs -- measured at world size 1, the whole step 422 scenes/s through the
-process group, 162 with this communicator merely EXISTING (grad_sync.py docstring, tools/ab_dist.sh).  It pays where the control
+process group, 162 with this communicator merely EXISTING (grad_sync.py docstring).  It pays where the control
 plane is not on RCCL (process group on gloo).
 """
 import ctypes

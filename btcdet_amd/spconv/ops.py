@@ -501,7 +501,7 @@ def _wgrad_cost(nbr, n_res, K, cin, cout, act_bytes=4):
 # wgrad goes to a side HIP stream (fork / join with events, no host sync) beside dgrad for layers with at least this many
 # rows; on smaller layers the stream switches cost more host time than the overlap returns (the forward pass is bound by
 # the host's launch rate, the backward pass by the GPU: tools/host_phases.py).  Measured: 60000 -> 191, 20000 -> 194,
-# 0 -> 194 scenes/s
+# 0 -> 194 scenes/s.  BTC_OVERLAP_MIN_ROWS in the environment (measurement scripts: a huge value = no kernel beside another).
 NATIVE_AUTOGRAD = True  # conv -> BN -> ReLU as a C++ autograd node when _btcfast is built
 OVERLAP_MIN_ROWS = int(os.environ.get("BTC_OVERLAP_MIN_ROWS", "20000"))
 OVERLAP_MAX_ROWS = 100000  # above: both kernels fill the GPU alone, side by side 450 us vs 219 + 150
@@ -515,7 +515,15 @@ def set_defer_wgrad_join(on):
     F = fast()
     if F is not None:
         F.set_defer_wgrad_join(bool(on))
+    _defer_state[0] = bool(on) and F is not None
     return F is not None
+
+
+_defer_state = [False]
+
+
+def defer_wgrad_join_enabled():
+    return _defer_state[0]
 
 
 def join_wgrad():

@@ -81,7 +81,7 @@ class GroupOptimizer(object):
     With "module" the group's parameters are taken (and numbered, for state_dict_lst) as the reference's optimizer does."""
 
     def __init__(self, groups, total_steps, beta2=0.99, eps=1e-8, flat=None):
-        """flat (default: on for CUDA parameters when the compiled binding is there, BTC_FLAT_OPTIM=0 turns it off): a group's
+        """flat (default: on for CUDA parameters when the compiled binding is there): a group's
         parameters and Adam moments become views into one flat buffer each and the whole step of the group is three launches of
         csrc/optim.hip instead of ~10 multi-tensor torch ops over ~120-tensor lists (same arithmetic; the host side of those ops
         was what the GPU waited for).  A step in which some parameter has no (or an unusual) gradient takes the list path."""

@@ -436,7 +436,7 @@ class HotPathTrainer(object):
         # steady-state steps.  One large block, allocated and released here, leaves the allocator a pool it can carve those from.
         # (The allocator's pools are per stream: the block is taken on each stream the schedule allocates on.)
         if reserve_bytes is None:
-            reserve_bytes = int(os.environ.get("BTC_RESERVE_MB", "512")) << 20
+            reserve_bytes = 512 << 20
         self._reserve_bytes = reserve_bytes if self.device.type == "cuda" else 0
         if distributed is None:
             distributed = dist.is_available() and dist.is_initialized()

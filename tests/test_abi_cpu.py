@@ -50,6 +50,39 @@ def test_host_only_entry_points():
     assert L.btc_occ_targets_ws_bytes(ctypes.byref(cfg)) > 2 * 209 * 157 * 9 * (9 * 4 + 3 * 4)
 
 
+def test_environment_switches_of_the_loader(monkeypatch):
+    """BTC_TUNE="key=value,..." reaches btc_tune_set when the library is loaded (a bad entry is an error, not ignored);
+    BTC_TUNE_APPLY_DEBUG -- the one key that changes results -- is refused unless BTC_ALLOW_WRONG_RESULTS is set;
+    BTC_FASTPATH=0 keeps the compiled torch binding out (the ctypes route of INTEGRATION.md section 2 stays)"""
+    from btcdet_amd import _lib
+    L0 = _lib.lib()
+    try:
+        monkeypatch.setattr(_lib, "_lib", None)
+        monkeypatch.setenv("BTC_TUNE", "14=1,20=2")
+        L = _lib.lib()
+        assert L.btc_tune_value(14) == 1 and L.btc_tune_value(20) == 2 and L.btc_tune_value(15) == 0
+        monkeypatch.setattr(_lib, "_lib", None)
+        monkeypatch.setenv("BTC_TUNE", "9999=1")
+        with pytest.raises(_lib.BtcHipError):
+            _lib.lib()
+        monkeypatch.delenv("BTC_TUNE")
+        monkeypatch.delenv("BTC_ALLOW_WRONG_RESULTS", raising=False)
+        assert L.btc_tune_set(3, 1) != 0 and L.btc_tune_value(3) == 0
+        assert L.btc_tune_set(3, 0) == 0
+        monkeypatch.setenv("BTC_ALLOW_WRONG_RESULTS", "1")
+        assert L.btc_tune_set(3, 1) == 0 and L.btc_tune_value(3) == 1
+    finally:
+        for k in (3, 14, 20):
+            L0.btc_tune_set(k, 0)
+        monkeypatch.setattr(_lib, "_lib", L0)
+    monkeypatch.setattr(_lib, "_fast", False)
+    monkeypatch.setenv("BTC_FASTPATH", "0")
+    assert _lib.fast() is None
+    monkeypatch.setattr(_lib, "_fast", False)
+    monkeypatch.setenv("BTC_FASTPATH", "1")
+    assert _lib.fast() is not None, "the compiled binding is not built"
+
+
 def test_no_fallback_when_library_missing(monkeypatch):
     from btcdet_amd import _lib
     monkeypatch.setattr(_lib, "_lib", None)

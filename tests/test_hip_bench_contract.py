@@ -54,3 +54,17 @@ def test_bench_in_order_schedule_still_runs():
     assert p.returncode == 0, p.stderr[-2000:]
     d = json.loads([l for l in p.stdout.splitlines() if l.strip()][-1])
     assert d["value"] > 50 and d["config"]["schedule"].startswith("in order, one stream")
+
+
+def test_bench_distributed_path_at_world_size_one():
+    """BTC_BENCH_FORCE_DIST=1: process group over RCCL, bucketed reducer, barriers and max-over-ranks timing at world size 1 -- the code
+    path the driver's N > 1 launches take, on the one GPU a test box has (--priming: fewer optimizer steps before the timed region)"""
+    env = dict(os.environ, BTC_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--priming", "8", "--no-cpu-baseline",
+                        "--no-roofline", "--no-extras"], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, text=True)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines                      # RCCL's banner went to stderr
+    d = json.loads(lines[0])
+    assert d["value"] > 50 and d["n_gpus"] == 1 and d["config"]["priming_steps"] == 7
+    assert d["config"]["collective"]["backend"] == "nccl" and d["config"]["collective"]["world_size"] == 1

@@ -573,3 +573,61 @@ def test_conv_epilogue_batch_statistics_match_the_separate_pass(cin, cout, n, dt
         np.testing.assert_allclose(a[1].cpu().numpy(), b[1].cpu().numpy(), rtol=tol, atol=tol)
     ref = torch.nn.functional.batch_norm(plain.float(), None, None, gamma, beta, True, 0.0, 1e-3).relu()
     np.testing.assert_allclose(outs[0][1].cpu().numpy(), ref.cpu().numpy(), rtol=(2e-2 if dtype == "bf16" else 2e-5), atol=(2e-2 if dtype == "bf16" else 2e-5))
+
+
+@pytest.mark.parametrize("exact", [True, False], ids=["exact_kernels", "split_operand_kernels"])
+@pytest.mark.parametrize("key,values,what", [
+    (0, (1, 2), "BTC_TUNE_APPLY_KERNEL: register-staged / LDS-DMA exact kernels"),
+    (2, (1, 2), "BTC_TUNE_APPLY_XCD: XCD-contiguous row-tile mapping off / on"),
+    (4, (16, 32), "BTC_TUNE_APPLY_KC: reduction channels per pipeline item"),
+    (13, (3, 4, 5), "BTC_TUNE_APPLY_STAGES: depth of the LDS ring"),
+    (6, (128, 256, 1024), "BTC_TUNE_WGRAD_WGS: workgroups of the weight-gradient walk"),
+    (11, (1,), "BTC_TUNE_WGRAD_PIPE: the two-barrier weight-gradient kernel"),
+    (9, (16, 256), "BTC_TUNE_BN_FWD_KB: input per workgroup of the statistics pass"),
+    (10, (32, 512), "BTC_TUNE_BN_BWD_KB: input per workgroup of the backward statistics pass")])
+def test_tuning_keys_change_the_work_split_not_the_result(key, values, what, exact):
+    """the tuning keys of include/btcdet_hip.h that select a tiling / a grid: a conv -> BatchNorm -> ReLU layer (64 -> 64, 9 K rows)
+    forward and backward under each value against the built-in policy.  With the exact kernels (BTC_TUNE_SPLIT = 1: one fmaf chain
+    per output whatever the tiling) features and input gradients are bit-identical; with the split-operand kernels and for every
+    cross-row sum (weight gradient, BatchNorm statistics and parameter gradients) the grid decides the summation order: fp32
+    rounding of the same sums"""
+    from btcdet_amd._lib import check, lib
+    from btcdet_amd import spconv
+    rng = np.random.default_rng(100 + key)
+    shape, B, cin, cout = (10, 44, 40), 2, 64, 64
+    idx = rand_indices(rng, 9000, B, shape)
+    feat = rng.standard_normal((idx.shape[0], cin)).astype(np.float32)
+    dout = rng.standard_normal((idx.shape[0], cout)).astype(np.float32)
+    torch.manual_seed(5)
+    net = spconv.SparseSequential(spconv.SubMConv3d(cin, cout, 3, padding=1, bias=False, indice_key="s"),
+                                  torch.nn.BatchNorm1d(cout, eps=1e-3, momentum=0.01), torch.nn.ReLU()).to(dev()).train()
+
+    def run():
+        for p in net.parameters():
+            p.grad = None
+        f = torch.from_numpy(feat).to(dev()).requires_grad_(True)
+        y = net(spconv.SparseConvTensor(f, torch.from_numpy(idx).to(dev()), list(shape), B))
+        y.features.backward(torch.from_numpy(dout).to(dev()))
+        return [y.features.detach().clone(), f.grad.clone()] + [p.grad.clone() for p in net.parameters()]
+
+    def close(a, b, rel):
+        return float((a - b).abs().max()) <= rel * float(a.abs().max()) + 1e-12
+
+    check(lib().btc_tune_set(14, 1 if exact else 0), "btc_tune_set")
+    try:
+        ref = run()
+        for v in values:
+            check(lib().btc_tune_set(key, v), "btc_tune_set")
+            try:
+                got = run()
+            finally:
+                check(lib().btc_tune_set(key, 0), "btc_tune_set")
+            # BatchNorm's batch statistics feed the features: bit-identical only while the statistics' own grid is untouched
+            bits = exact and key not in (9, 10, 0)
+            for j, (a, b) in enumerate(zip(ref, got)):
+                if bits and j < 2:
+                    assert torch.equal(a, b), (what, v, j)
+                else:
+                    assert close(a, b, 2e-5), (what, v, j)
+    finally:
+        check(lib().btc_tune_set(14, 0), "btc_tune_set")

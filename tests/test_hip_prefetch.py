@@ -228,3 +228,55 @@ def test_pipelined_training_steps_equal_plain_ones():
         assert dev <= max(20 * noise, 2e-4), (mode, a, c)
         for x, y in zip(na, nc):
             assert abs(x - y) <= 1e-4 * abs(x)
+
+
+def _run_trainer(steps, env, monkeypatch, overlap_min_rows=None):
+    """HotPathTrainer (the object bench.py and a training loop use) for a few optimizer steps under a set of environment switches"""
+    import bench
+    import numpy as np
+    from btcdet_amd.btc_path import BtcHotPath
+    from btcdet_amd.config import load_cfg
+    from btcdet_amd.spconv import ops
+    from btcdet_amd.trainer import HotPathTrainer
+    for k in ("BTC_SCHEDULE", "BTC_DEFER_WGRAD", "BTC_TRAINER_TIMING"):
+        monkeypatch.delenv(k, raising=False)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    if overlap_min_rows is not None:
+        monkeypatch.setattr(ops, "OVERLAP_MIN_ROWS", overlap_min_rows)
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    np.random.seed(3)
+    model = BtcHotPath(load_cfg(), device=dev).to(dev).train()
+    trainer = HotPathTrainer(model, total_steps=1000, distributed=False)
+    try:
+        batches = bench.build_batches(3, 0, dev)
+        losses = [trainer.step(batches[it % 3], batches[(it + 1) % 3], batches[(it + 2) % 3]) for it in range(steps)]
+        torch.cuda.synchronize()
+        norms = [float(torch.linalg.vector_norm(torch.cat([p.detach().reshape(-1) for p in g["params"]]))) for g in trainer.optimizer.groups]
+        return [float(l) for l in losses], norms, trainer.schedule, ops.defer_wgrad_join_enabled(), dict(getattr(trainer._step, "timing", None) or {})
+    finally:
+        trainer.finish()
+        ops.set_defer_wgrad_join(False)
+
+
+@pytest.mark.parametrize("env,overlap", [({"BTC_SCHEDULE": "in_order"}, None), ({"BTC_SCHEDULE": "split"}, None), ({"BTC_DEFER_WGRAD": "0"}, None),
+                                         ({"BTC_SCHEDULE": "in_order", "BTC_DEFER_WGRAD": "0"}, 2000000000), ({"BTC_DEFER_WGRAD": "0"}, 0),
+                                         ({"BTC_TRAINER_TIMING": "1"}, None)],
+                         ids=["in_order", "split", "no_deferred_wgrad", "alone", "overlap_every_layer", "host_timing"])
+def test_trainer_environment_switches_change_the_schedule_not_the_training(env, overlap, monkeypatch):
+    """the switches INTEGRATION.md section 11 lists for HotPathTrainer -- BTC_SCHEDULE (in_order / split / pipelined), BTC_DEFER_WGRAD (weight
+    gradients on the side stream with one join per backward), BTC_OVERLAP_MIN_ROWS (ops.OVERLAP_MIN_ROWS: layers from that many rows on
+    put their weight gradient beside the next dgrad), BTC_TRAINER_TIMING (host seconds per phase) -- are taken and leave the losses and the
+    parameters after 6 optimizer steps where the default schedule puts them (tolerance: the occupancy targets' float atomics)"""
+    steps = 6
+    a, na, sched_a, defer_a, timing_a = _run_trainer(steps, {}, monkeypatch)
+    assert sched_a == "pipelined" and defer_a and not timing_a
+    b, nb, sched_b, defer_b, timing_b = _run_trainer(steps, env, monkeypatch, overlap)
+    assert sched_b == env.get("BTC_SCHEDULE", "pipelined")
+    assert defer_b == (env.get("BTC_DEFER_WGRAD", "1") != "0")
+    assert bool(timing_b) == (env.get("BTC_TRAINER_TIMING") == "1")
+    dev = max(abs(x - y) / abs(x) for x, y in zip(a, b))
+    assert dev <= 5e-4, (env, a, b)
+    for x, y in zip(na, nb):
+        assert abs(x - y) <= 1e-4 * abs(x)

@@ -5,7 +5,7 @@ mkdir -p gpurun_out/full_heads
 export TMPDIR=/tmp
 cd /tmp
 rm -rf /tmp/prof_fh
-BTC_BENCH_PRIMING=${PRIMING:-24} BTC_SCHEDULE=${SCHED:-in_order} timeout 900 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_fh -o bench -- python /root/repo/bench.py --heads ${HEADS:-full} --steps 10 --warmup 2 --no-cpu-baseline --no-roofline --no-extras > /root/repo/gpurun_out/full_heads/bench.json 2> /root/repo/gpurun_out/full_heads/bench.err
+BTC_SCHEDULE=${SCHED:-in_order} timeout 900 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_fh -o bench -- python /root/repo/bench.py --heads ${HEADS:-full} --priming ${PRIMING:-24} --steps 10 --warmup 2 --no-cpu-baseline --no-roofline --no-extras > /root/repo/gpurun_out/full_heads/bench.json 2> /root/repo/gpurun_out/full_heads/bench.err
 cd /root/repo
 ms=$(python -c "
 import json

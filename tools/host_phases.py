@@ -1,7 +1,6 @@
 """host-side time per phase of a step on TINY scenes (GPU work negligible => wall time ~ host / launch cost)"""
 import os, sys, time
-if os.environ.get("HOST_PHASES_FULL") != "1":
-    os.environ.setdefault("BTC_BENCH_AZ_STEP", "4.0")
+AZ = None if os.environ.get("HOST_PHASES_FULL") == "1" else 4.0
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -14,7 +13,7 @@ model = BtcHotPath(load_cfg(), device=dev).to(dev).train()
 occ = [p for p in model.occ_modules.parameters() if p.requires_grad]
 det = [p for p in model.det_modules.parameters() if p.requires_grad]
 opt = torch.optim.Adam([{"params": occ}, {"params": det}], lr=1e-3, fused=True)
-batches = bench.build_batches(2, 0, dev)
+batches = bench.build_batches(2, 0, dev, az_step=AZ)
 proc = model.dataset.data_processor
 T = {}
 def tick(name, t0):

@@ -1,6 +1,5 @@
 """exclusive host time of the pieces of one sparse layer's forward (tiny scenes; perf_counter wrappers)"""
 import os, sys, time
-os.environ.setdefault("BTC_BENCH_AZ_STEP", "4.0")
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -10,7 +9,7 @@ from btcdet_amd.config import load_cfg
 from btcdet_amd.spconv import ops, fused_bn, conv, modules
 dev = torch.device("cuda:0")
 model = BtcHotPath(load_cfg(), device=dev).to(dev).train()
-batches = bench.build_batches(2, 0, dev)
+batches = bench.build_batches(2, 0, dev, az_step=4.0)
 proc = model.dataset.data_processor
 T, C = {}, {}
 def wrap(obj, name, label):
