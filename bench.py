@@ -247,15 +247,27 @@ def main():
     dist = None
 
     class _StdoutToStderr(object):
-        """RCCL prints a version banner to STDOUT when a communicator is created; this script's stdout is ONE JSON line"""
+        """RCCL prints a version banner to STDOUT when a communicator is created; this script's stdout is ONE JSON line.  The banner goes
+        through C stdio, which buffers fully when stdout is a pipe (the driver's case): without the fflush below it sits in that buffer
+        past the redirection and comes out on the real stdout at exit, BEHIND the JSON line"""
+
+        @staticmethod
+        def _fflush():
+            import ctypes
+            try:
+                ctypes.CDLL(None).fflush(None)
+            except (OSError, AttributeError):
+                pass
 
         def __enter__(self):
             sys.stdout.flush()
+            self._fflush()
             self.saved = os.dup(1)
             os.dup2(2, 1)
 
         def __exit__(self, *a):
             sys.stdout.flush()
+            self._fflush()
             os.dup2(self.saved, 1)
             os.close(self.saved)
 
@@ -525,10 +537,13 @@ def main():
             if pinned and all_cpus:   # the CPU legs (one core; one worker per host core) run unpinned
                 os.sched_setaffinity(0, all_cpus)
             result["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(result))
+        with _StdoutToStderr():   # whatever a library still holds in C stdio's buffer leaves on stderr, not behind the line
+            pass
+        print(json.dumps(result), flush=True)
     if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+        with _StdoutToStderr():
+            dist.barrier()
+            dist.destroy_process_group()
 
 
 def level_row_stats(rows):

@@ -3,9 +3,10 @@
 One process per GPU: the step is a chain of ~430 small launches, and on a two-socket MI355X host the
 process that lands on (or migrates to) the socket the GPU is NOT attached to pays for it on every launch -- bench.py measured
 324-341 scenes/s unpinned against 343 +- 3 pinned to the GPU's socket on the same box (tools/ab.sh).  pin_to_gpu() restricts
-the calling process (and the threads it starts later: the prefetch worker, the autograd thread) to a slice of the CPUs that
-sysfs lists as local to the GPU's PCI function.  Nothing happens when the topology cannot be read (containers without sysfs,
-non-Linux) or when BTC_PIN_CPUS=0."""
+the process -- every thread it has and the threads it starts later -- to a slice of the CPUs that sysfs lists as local to the GPU's PCI
+function, one hardware thread per core; the schedule (trainer.make_step) then gives each of its busy host threads a CPU of its own
+inside that slice (place_thread).  Nothing happens when the topology cannot be read (containers without sysfs, non-Linux) or when
+BTC_PIN_CPUS=0."""
 import os
 
 
@@ -46,6 +47,7 @@ def pin_to_gpu(device_index, local_rank=0, ranks_on_node=1, cpus_per_rank=16):
     allowed = sorted(set(cpus) & set(os.sched_getaffinity(0)))
     if not allowed:
         return None
+    allowed = _one_per_core(allowed)
     per = max(1, min(cpus_per_rank, len(allowed) // max(1, min(ranks_on_node, len(allowed)))))
     start = (local_rank * per) % len(allowed)
     mine = (allowed + allowed)[start:start + per]
@@ -53,4 +55,82 @@ def pin_to_gpu(device_index, local_rank=0, ranks_on_node=1, cpus_per_rank=16):
         os.sched_setaffinity(0, mine)
     except OSError:
         return None
+    _pin_existing_threads(mine)
+    _MINE[:] = mine
     return mine
+
+
+def _one_per_core(cpus):
+    """the first hardware thread of every core in `cpus` (sysfs thread_siblings_list); `cpus` unchanged when the topology is unreadable"""
+    keep, seen = [], set()
+    for c in cpus:
+        try:
+            with open("/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list" % c) as f:
+                core = tuple(_parse_cpulist(f.read()))
+        except (OSError, ValueError):
+            return cpus
+        if core not in seen:
+            seen.add(core)
+            keep.append(c)
+    return keep or cpus
+
+
+def _pin_existing_threads(cpus):
+    """sched_setaffinity(0, ...) moves the CALLING thread only (later threads inherit its mask); the threads the process already has --
+    the HIP runtime's, started when the device was opened to read its PCI address -- keep theirs.  One of those is busy for the whole
+    step (it handles the completion signals of ~330 launches) and floated over all 256 CPUs of the host (tools/step_phases.py).  The mask
+    is 16 CPUs of 16 different cores; place_thread / place_other_threads then separate the busy threads inside it."""
+    try:
+        tids = [int(t) for t in os.listdir("/proc/self/task")]
+    except OSError:
+        return
+    for tid in tids:
+        try:
+            os.sched_setaffinity(tid, cpus)
+        except OSError:
+            pass
+
+
+_MINE = []        # the CPUs pin_to_gpu gave this process (empty: not pinned -- threads are then left where the scheduler puts them)
+ROLES = ("train", "autograd", "occupancy", "prepare")
+
+
+def place_thread(role, tid=0):
+    """give one of the schedule's busy host threads a CPU of its own: the training thread, autograd's device thread, the occupancy
+    worker and the prepare worker of trainer.make_step take the first four CPUs of the process's mask (16 CPUs on 16 different cores,
+    pin_to_gpu), `place_other_threads` confines everything else to the remaining ones.  Why: the step is as fast as its slowest host
+    thread, and a floating thread shares a core now and then -- with another of these four, or with the HIP runtime's signal thread,
+    which is busy for the whole step and, woken from the training thread, tends to land on its core's SMT sibling.  Same box, same
+    build, 80-step runs (profiles/r06_thread_placement_ab.txt): process-wide mask only 460-557 scenes/s, one CPU per thread 553-560.
+    No-op when the process is not pinned (BTC_PIN_CPUS=0, no sysfs topology, fewer than 8 CPUs)."""
+    if len(_MINE) < 8:
+        return False
+    try:
+        os.sched_setaffinity(tid, {_MINE[ROLES.index(role)]})
+        return True
+    except OSError:
+        return False
+
+
+def place_other_threads():
+    """autograd's device threads (created by the first backward pass; named pt_autograd_<n>) -> their CPU; every thread that has not been
+    given a CPU of its own (the HIP runtime's, torch's pools) -> the CPUs no role owns.  Called by the schedule after its first steps."""
+    if len(_MINE) < 8:
+        return 0
+    rest, n = set(_MINE[len(ROLES):]), 0
+    try:
+        tids = [int(t) for t in os.listdir("/proc/self/task")]
+    except OSError:
+        return 0
+    for t in tids:
+        try:
+            with open("/proc/self/task/%d/comm" % t) as f:
+                name = f.read().strip()
+            if name.startswith("pt_autograd"):
+                n += int(place_thread("autograd", t))
+            elif len(os.sched_getaffinity(t)) > 1:
+                os.sched_setaffinity(t, rest)
+                n += 1
+        except OSError:
+            pass
+    return n

@@ -125,13 +125,24 @@ def make_step(model, ddp, proc, opts, grad_sync=None, prefetch_stream=None, thre
     attribute the one-stream schedules are used (split_backward: detection bucket between the two backward passes).
 
     det_loss(ret, batch_dict) -> scalar: the detection branch's loss (default: the L2 stand-ins)."""
+    from . import affinity as _aff
     from .spconv import ops as _ops
     det_loss = det_loss or stand_in_det_loss
+    pipeline_wanted = pipeline is None or bool(pipeline)
+    _placed = [0]
+
+    def _place_threads():
+        """the calling (training) thread, autograd's device thread and the runtime's threads on their CPUs (affinity.place_thread; the
+        workers place themselves when they start) -- after each of the first three steps: autograd's thread exists after the first backward"""
+        if _placed[0] < 3:
+            _placed[0] += 1
+            _aff.place_thread("train")
+            _aff.place_other_threads()
     pending = {}
     pool = None
     if (prefetch_stream is not None and threaded) or det_stream is not None:
         from concurrent.futures import ThreadPoolExecutor
-        pool = ThreadPoolExecutor(max_workers=1)
+        pool = ThreadPoolExecutor(max_workers=1, initializer=_aff.place_thread, initargs=("occupancy" if pipeline_wanted else "prepare",))
     device = next(model.parameters()).device
     split_backward = grad_sync is not None and ddp is model and len(grad_sync.buckets) > 1 and getattr(grad_sync, "split_backward", False)
     bucket_of = getattr(grad_sync, "bucket_of", None) if grad_sync is not None else None
@@ -193,7 +204,7 @@ def make_step(model, ddp, proc, opts, grad_sync=None, prefetch_stream=None, thre
     prep_pool = None
     if pipeline:
         from concurrent.futures import ThreadPoolExecutor as _TPE
-        prep_pool = _TPE(max_workers=1)
+        prep_pool = _TPE(max_workers=1, initializer=_aff.place_thread, initargs=("prepare",))
 
     occ_failed = []   # the worker's exception, if its backward / bucket launch raised (looked at by the training thread, below)
 
@@ -298,6 +309,7 @@ def make_step(model, ddp, proc, opts, grad_sync=None, prefetch_stream=None, thre
             loss = loss_occ.detach() + loss_det.detach()
             model.mark_step_end(stream=det_stream, upto=bd.get("__gen_id__", -1))
         t = _mark("det_optimizer", t)
+        _place_threads()
         nxt = fut.result()
         if nxt is not None:
             _put(ahead_occ, next_batch, nxt)
@@ -356,6 +368,7 @@ def make_step(model, ddp, proc, opts, grad_sync=None, prefetch_stream=None, thre
         if fut is not None:
             _put(pending, next_batch, fut.result())
         _ops.join_wgrad()   # no-op unless weight gradients are still owed (e.g. a backward pass whose end-of-pass callback never ran)
+        _place_threads()
         if grad_sync is not None:
             grad_sync.finish()  # all-reduced mean gradients in the buckets (and in param.grad with assign_grads)
         if opt_stream is not None:

@@ -13,7 +13,8 @@ def test_ranks_take_disjoint_slices(monkeypatch):
     avail = sorted(os.sched_getaffinity(0))
     monkeypatch.setattr(affinity, "local_cpus", lambda d: list(avail))
     got = []
-    monkeypatch.setattr(os, "sched_setaffinity", lambda pid, cpus: got.append(list(cpus)))
+    monkeypatch.setattr(os, "sched_setaffinity", lambda pid, cpus: got.append(list(cpus)) if pid == 0 else None)   # (pid != 0: the threads that exist already)
+    monkeypatch.setattr(affinity, "_one_per_core", lambda cpus: cpus)
     n = min(2, len(avail))
     for r in range(n):
         mine = affinity.pin_to_gpu(0, local_rank=r, ranks_on_node=n, cpus_per_rank=max(1, len(avail) // n))
@@ -26,3 +27,72 @@ def test_no_topology_means_no_pinning(monkeypatch):
     assert affinity.pin_to_gpu(0) is None
     monkeypatch.setenv("BTC_PIN_CPUS", "0")
     assert affinity.pin_to_gpu(0) is None
+
+
+def test_existing_threads_are_moved_too(monkeypatch):
+    """sched_setaffinity(0, ...) moves the calling thread only: the threads the process already has (the HIP runtime's) get the mask one by one"""
+    import threading
+    avail = sorted(os.sched_getaffinity(0))
+    stop = threading.Event()
+    tid = []
+    th = threading.Thread(target=lambda: (tid.append(threading.get_native_id()), stop.wait(30)))
+    th.start()
+    try:
+        while not tid:
+            pass
+        monkeypatch.setattr(affinity, "local_cpus", lambda d: list(avail))
+        monkeypatch.setattr(affinity, "_one_per_core", lambda cpus: cpus)
+        mine = affinity.pin_to_gpu(0, cpus_per_rank=1)
+        assert mine == avail[:1]
+        assert sorted(os.sched_getaffinity(tid[0])) == mine
+    finally:
+        stop.set()
+        th.join()
+        for t in os.listdir("/proc/self/task"):
+            os.sched_setaffinity(int(t), avail)
+
+
+def test_one_cpu_per_core():
+    cpus = sorted(os.sched_getaffinity(0))
+    keep = affinity._one_per_core(cpus)
+    assert keep and set(keep) <= set(cpus) and keep == sorted(keep)
+    assert affinity._one_per_core(keep) == keep
+
+
+def test_busy_threads_get_a_cpu_each(monkeypatch):
+    """place_thread: the schedule's four busy host threads on the first four CPUs of the process's mask, place_other_threads: every other
+    thread on the remaining ones (a thread that owns a CPU keeps it); nothing moves in a process that was not pinned"""
+    import threading
+    avail = sorted(os.sched_getaffinity(0))
+    if len(avail) < 8:
+        import pytest
+        pytest.skip("needs 8 CPUs")
+    monkeypatch.setattr(affinity, "_MINE", [])
+    assert affinity.place_thread("train") is False and affinity.place_other_threads() == 0
+    assert sorted(os.sched_getaffinity(0)) == avail
+    mine = avail[:8]
+    monkeypatch.setattr(affinity, "_MINE", list(mine))
+    stop, tids = threading.Event(), {}
+
+    def worker(role):
+        if role is not None:
+            affinity.place_thread(role)
+        tids[role] = threading.get_native_id()
+        stop.wait(30)
+    threads = [threading.Thread(target=worker, args=(r,)) for r in ("occupancy", "prepare", None)]
+    for t in threads:
+        t.start()
+    try:
+        while len(tids) < 3:
+            pass
+        assert affinity.place_thread("train")
+        assert affinity.place_other_threads() >= 1
+        assert sorted(os.sched_getaffinity(0)) == [mine[0]]
+        assert sorted(os.sched_getaffinity(tids["occupancy"])) == [mine[2]] and sorted(os.sched_getaffinity(tids["prepare"])) == [mine[3]]
+        assert sorted(os.sched_getaffinity(tids[None])) == mine[4:]
+    finally:
+        stop.set()
+        for t in threads:
+            t.join()
+        for t in os.listdir("/proc/self/task"):
+            os.sched_setaffinity(int(t), avail)
