@@ -93,20 +93,24 @@ def _pin_existing_threads(cpus):
 
 _MINE = []        # the CPUs pin_to_gpu gave this process (empty: not pinned -- threads are then left where the scheduler puts them)
 ROLES = ("train", "autograd", "occupancy", "prepare")
+ROLE_CPUS = 2     # CPUs (of different cores) per role: the thread has somewhere to go when another tenant's thread sits on one of them.  Same
+#                   box, six interleaved 80-step runs each: 1 CPU 547 / 548 / 551 / 547 scenes/s, 2 CPUs 553 / 551 / 551 / 551, 3 CPUs (four left
+#                   for the runtime's threads) 536 / 536 / 535 / 536; with a neighbour loading the host (load average 9 -> 65) all three lose 5-9 %
 
 
 def place_thread(role, tid=0):
-    """give one of the schedule's busy host threads a CPU of its own: the training thread, autograd's device thread, the occupancy
-    worker and the prepare worker of trainer.make_step take the first four CPUs of the process's mask (16 CPUs on 16 different cores,
-    pin_to_gpu), `place_other_threads` confines everything else to the remaining ones.  Why: the step is as fast as its slowest host
+    """give one of the schedule's busy host threads CPUs of its own: the training thread, autograd's device thread, the occupancy
+    worker and the prepare worker of trainer.make_step take ROLE_CPUS each from the front of the process's mask (16 CPUs on 16 different
+    cores, pin_to_gpu), `place_other_threads` confines everything else to the remaining ones.  Why: the step is as fast as its slowest host
     thread, and a floating thread shares a core now and then -- with another of these four, or with the HIP runtime's signal thread,
     which is busy for the whole step and, woken from the training thread, tends to land on its core's SMT sibling.  Same box, same
-    build, 80-step runs (profiles/r06_thread_placement_ab.txt): process-wide mask only 460-557 scenes/s, one CPU per thread 553-560.
+    build, 80-step runs (profiles/r06_thread_placement_ab.txt): process-wide mask only 460-557 scenes/s, CPUs per thread 553-560.
     No-op when the process is not pinned (BTC_PIN_CPUS=0, no sysfs topology, fewer than 8 CPUs)."""
     if len(_MINE) < 8:
         return False
     try:
-        os.sched_setaffinity(tid, {_MINE[ROLES.index(role)]})
+        k = ROLES.index(role)
+        os.sched_setaffinity(tid, set(_MINE[ROLE_CPUS * k:ROLE_CPUS * k + ROLE_CPUS]))
         return True
     except OSError:
         return False
@@ -117,7 +121,7 @@ def place_other_threads():
     given a CPU of its own (the HIP runtime's, torch's pools) -> the CPUs no role owns.  Called by the schedule after its first steps."""
     if len(_MINE) < 8:
         return 0
-    rest, n = set(_MINE[len(ROLES):]), 0
+    rest, n = set(_MINE[len(ROLES) * ROLE_CPUS:]), 0
     try:
         tids = [int(t) for t in os.listdir("/proc/self/task")]
     except OSError:
@@ -128,7 +132,7 @@ def place_other_threads():
                 name = f.read().strip()
             if name.startswith("pt_autograd"):
                 n += int(place_thread("autograd", t))
-            elif len(os.sched_getaffinity(t)) > 1:
+            elif len(os.sched_getaffinity(t)) > ROLE_CPUS:
                 os.sched_setaffinity(t, rest)
                 n += 1
         except OSError:

@@ -72,6 +72,7 @@ def test_busy_threads_get_a_cpu_each(monkeypatch):
     assert sorted(os.sched_getaffinity(0)) == avail
     mine = avail[:8]
     monkeypatch.setattr(affinity, "_MINE", list(mine))
+    monkeypatch.setattr(affinity, "ROLE_CPUS", 1)      # (8 CPUs here: one per role leaves four for the other threads)
     stop, tids = threading.Event(), {}
 
     def worker(role):
@@ -87,9 +88,10 @@ def test_busy_threads_get_a_cpu_each(monkeypatch):
             pass
         assert affinity.place_thread("train")
         assert affinity.place_other_threads() >= 1
-        assert sorted(os.sched_getaffinity(0)) == [mine[0]]
-        assert sorted(os.sched_getaffinity(tids["occupancy"])) == [mine[2]] and sorted(os.sched_getaffinity(tids["prepare"])) == [mine[3]]
-        assert sorted(os.sched_getaffinity(tids[None])) == mine[4:]
+        w = affinity.ROLE_CPUS
+        assert sorted(os.sched_getaffinity(0)) == mine[0:w]
+        assert sorted(os.sched_getaffinity(tids["occupancy"])) == mine[2 * w:3 * w] and sorted(os.sched_getaffinity(tids["prepare"])) == mine[3 * w:4 * w]
+        assert sorted(os.sched_getaffinity(tids[None])) == mine[4 * w:]
     finally:
         stop.set()
         for t in threads:
