@@ -98,6 +98,11 @@ ROLE_CPUS = 2     # CPUs (of different cores) per role: the thread has somewhere
 #                   for the runtime's threads) 536 / 536 / 535 / 536; with a neighbour loading the host (load average 9 -> 65) all three lose 5-9 %
 
 
+def _role_width():
+    """ROLE_CPUS while that leaves at least four CPUs of the mask to the other threads, else 1"""
+    return ROLE_CPUS if len(_MINE) >= len(ROLES) * ROLE_CPUS + 4 else 1
+
+
 def place_thread(role, tid=0):
     """give one of the schedule's busy host threads CPUs of its own: the training thread, autograd's device thread, the occupancy
     worker and the prepare worker of trainer.make_step take ROLE_CPUS each from the front of the process's mask (16 CPUs on 16 different
@@ -109,8 +114,8 @@ def place_thread(role, tid=0):
     if len(_MINE) < 8:
         return False
     try:
-        k = ROLES.index(role)
-        os.sched_setaffinity(tid, set(_MINE[ROLE_CPUS * k:ROLE_CPUS * k + ROLE_CPUS]))
+        k, w = ROLES.index(role), _role_width()
+        os.sched_setaffinity(tid, set(_MINE[w * k:w * k + w]))
         return True
     except OSError:
         return False
@@ -121,7 +126,7 @@ def place_other_threads():
     given a CPU of its own (the HIP runtime's, torch's pools) -> the CPUs no role owns.  Called by the schedule after its first steps."""
     if len(_MINE) < 8:
         return 0
-    rest, n = set(_MINE[len(ROLES) * ROLE_CPUS:]), 0
+    rest, n = set(_MINE[len(ROLES) * _role_width():]), 0
     try:
         tids = [int(t) for t in os.listdir("/proc/self/task")]
     except OSError:
@@ -132,7 +137,7 @@ def place_other_threads():
                 name = f.read().strip()
             if name.startswith("pt_autograd"):
                 n += int(place_thread("autograd", t))
-            elif len(os.sched_getaffinity(t)) > ROLE_CPUS:
+            elif len(os.sched_getaffinity(t)) > _role_width():
                 os.sched_setaffinity(t, rest)
                 n += 1
         except OSError:

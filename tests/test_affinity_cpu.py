@@ -72,7 +72,7 @@ def test_busy_threads_get_a_cpu_each(monkeypatch):
     assert sorted(os.sched_getaffinity(0)) == avail
     mine = avail[:8]
     monkeypatch.setattr(affinity, "_MINE", list(mine))
-    monkeypatch.setattr(affinity, "ROLE_CPUS", 1)      # (8 CPUs here: one per role leaves four for the other threads)
+    # (a mask of 8 CPUs: one per role, four for the other threads -- affinity._role_width)
     stop, tids = threading.Event(), {}
 
     def worker(role):
@@ -88,7 +88,8 @@ def test_busy_threads_get_a_cpu_each(monkeypatch):
             pass
         assert affinity.place_thread("train")
         assert affinity.place_other_threads() >= 1
-        w = affinity.ROLE_CPUS
+        w = affinity._role_width()
+        assert w == 1
         assert sorted(os.sched_getaffinity(0)) == mine[0:w]
         assert sorted(os.sched_getaffinity(tids["occupancy"])) == mine[2 * w:3 * w] and sorted(os.sched_getaffinity(tids["prepare"])) == mine[3 * w:4 * w]
         assert sorted(os.sched_getaffinity(tids[None])) == mine[4 * w:]
