@@ -32,12 +32,10 @@ import os
 import sys
 import time
 
-if int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("BTC_BENCH_FORCE_DIST") == "1":
-    # HIP multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4).  The step keeps four streams busy
-    # (main, weight gradients, next-batch preparation, rulebook lookahead); RCCL's streams take queues of their own, and with
-    # the default the weight-gradient stream ends up sharing a queue with the main stream: measured at world size 1 over RCCL
-    # 8.3 ms per step with 4 queues, 7.3 ms with 8 (no effect without a process group).  Must be set before HIP initialises.
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# HIP multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), and two streams on one queue run one after
+# the other.  The step keeps four streams busy (occupancy chain, detection chain, next batch's front, weight gradients) and RCCL takes
+# queues of its own: eight leave HotPathTrainer room to find a queue for each (btcdet_amd/streams.py).  Must be set before HIP initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import numpy as np
 import torch
@@ -475,7 +473,7 @@ def main():
                        "collective": (None if dist is None else {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
                                                                  "transport": None if grad_sync is None else grad_sync.transport}),
                        "host_cpus": (None if not pinned else "%d CPUs local to the GPU (sysfs local_cpulist), first %d" % (len(pinned), pinned[0])),
-                       "distinct_batches": nb, "batches": "every priming / warm-up / timed step draws a batch of unseen scenes (seeds bench.rank_seeds)",
+                       "streams_on_own_hw_queues": getattr(trainer, "queues_distinct", None), "distinct_batches": nb, "batches": "every priming / warm-up / timed step draws a batch of unseen scenes (seeds bench.rank_seeds)",
                        "points_per_batch": {"min": min(b["n_points"] for b in batches), "max": max(b["n_points"] for b in batches),
                                             "mean": round(sum(b["n_points"] for b in batches) / nb, 1)},
                        "level_rows": level_row_stats(level_rows), "priming_steps": priming, "heads": args.heads},

@@ -157,6 +157,7 @@ _SIGS = {
     "btc_sumsq2_bwd": (ci, [vp, ctypes.c_longlong, ci, ctypes.c_float, vp, vp, ctypes.c_longlong, ci, ctypes.c_float, vp, vp, vp]),
     "btc_bn_ws_bytes": (sz, [ci]),
     "btc_bn_relu_fwd": (ci, [vp, ci, ci, vp, vp, vp, vp, vp, ctypes.c_float, ctypes.c_float, ci, ci, vp, vp, vp, vp, sz, vp]),
+    "btc_spin": (ci, [ci, vp]),
     "btc_bn_relu_bwd": (ci, [vp, vp, vp, ci, ci, vp, vp, vp, ci, ci, vp, vp, vp, vp, sz, vp]),
     "btc_bn_relu_fwd_bf16": (ci, [vp, ci, ci, vp, vp, vp, vp, vp, ctypes.c_float, ctypes.c_float, ci, ci, vp, vp, vp, vp, sz, vp]),
     "btc_bn_relu_bwd_bf16": (ci, [vp, vp, vp, ci, ci, vp, vp, vp, ci, ci, vp, vp, vp, vp, sz, vp]),

@@ -385,6 +385,20 @@ void join_wgrad() {
 
 void set_defer_wgrad_join(bool on) { g_defer_join = on; }
 
+// the weight-gradient side stream of `device_index`: a stream the caller has chosen (btcdet_amd/streams.py: one that does not share a hardware
+// queue with the streams the step's chains run on) instead of the next one of torch's pool.  Call it while no weight gradient is in flight.
+void set_side_stream(int64_t raw_stream, int64_t device_index) {
+  SideStream& s = side_of((int)device_index);
+  if (s.pending.load()) throw std::runtime_error("set_side_stream: weight gradients are in flight on the current side stream");
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lock(mu);
+  static std::vector<c10::hip::HIPStream> keep;
+  keep.reserve(256);
+  keep.push_back(c10::hip::getStreamFromExternal(reinterpret_cast<hipStream_t>(raw_stream), (c10::DeviceIndex)device_index));
+  s.c10side = &keep.back();
+  s.side = keep.back().stream();
+}
+
 // din (n_src, Cin), dw (shape of w); either may come back undefined (None) when not needed.  overlap: wgrad runs on a side
 // stream beside dgrad (fork / join with events, no host sync); every temporary is released after the join has been enqueued,
 // so the caching allocator's stream-ordered reuse stays valid without recordStream.
@@ -1112,6 +1126,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("clear_grads_pl", &clear_grads_pl);
   m.def("join_wgrad", &join_wgrad, py::call_guard<py::gil_scoped_release>());
   m.def("set_defer_wgrad_join", &set_defer_wgrad_join);
+  m.def("set_side_stream", &set_side_stream);
   m.def("rulebook_subm", &rulebook_subm, py::call_guard<py::gil_scoped_release>());
   m.def("rulebook_conv", &rulebook_conv, py::call_guard<py::gil_scoped_release>());
   py::class_<PendingRb, std::shared_ptr<PendingRb>>(m, "PendingRb");

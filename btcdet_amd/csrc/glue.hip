@@ -256,6 +256,22 @@ extern "C" int btc_sumsq2_bwd(const void* a, long long na, int a_bf16, float ka2
   return BTC_OK;
 }
 
+// one wave that does nothing for `microseconds` (constant-rate 100 MHz counter): the probe of btcdet_amd/streams.py -- work enqueued on ANOTHER
+// stream finishes behind it exactly when the two streams were dealt the same hardware queue
+namespace {
+__global__ void spin_k(long long ticks) {
+  const long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+}  // namespace
+
+extern "C" int btc_spin(int microseconds, void* stream) {
+  BTC_CHECK_ARG(microseconds >= 0 && microseconds <= 100000, "btc_spin: 0 .. 100000 us");
+  spin_k<<<1, 64, 0, (hipStream_t)stream>>>(100LL * microseconds);
+  BTC_LAUNCH_CHECK();
+  return BTC_OK;
+}
+
 extern "C" int btc_occ_prob(const float* logit, const unsigned char* mask, int B, long long ncell, float* prob, void* stream) {
   BTC_CHECK_ARG(B >= 0 && ncell >= 0, "btc_occ_prob: bad sizes");
   const long long total = (long long)B * ncell;

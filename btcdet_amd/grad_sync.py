@@ -154,7 +154,11 @@ class BucketedGradSync(object):
         if self.comm is not None:
             self.comm.all_reduce_(b.flat, stream, average=True)
         else:
-            b.work = dist.all_reduce(b.flat, op=self.reduce_op, group=self.group, async_op=True)
+            # a synchronous call runs the collective ON the current stream (ProcessGroupNCCL, PyTorch >= 2.7); async_op=True would take the
+            # process group's own stream: two more event hops per bucket, and one more stream that may share a hardware queue with the
+            # weight gradients' (btcdet_amd/streams.py).  Host-side it returns as soon as the collective is enqueued either way.
+            on_own = b.flat.is_cuda and not b.on_comm
+            b.work = dist.all_reduce(b.flat, op=self.reduce_op, group=self.group, async_op=not on_own)
 
     def _read_tail(self, b, stream):
         """the reduced count of missing gradients -> pinned host memory, asynchronously; looked at when the bucket is next launched"""

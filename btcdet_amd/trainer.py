@@ -497,8 +497,28 @@ class HotPathTrainer(object):
             optimizer.read_grads_from(self.grad_sync.view_of, self.grad_sync.has_grad, self.grad_sync.missing)
         ops.set_defer_wgrad_join(os.environ.get("BTC_DEFER_WGRAD", "1") != "0")
         cuda = self.device.type == "cuda"
-        self.prefetch_stream = torch.cuda.Stream(device=self.device, priority=-1) if (cuda and schedule != "in_order") else None
-        self.det_stream = torch.cuda.Stream(device=self.device) if (cuda and schedule == "pipelined") else None
+        # the schedule's streams, each on a command-processor pipe of its own (btcdet_amd/streams.py: which of them the runtime had dealt one
+        # pipe decided between 3.6 and 5.5 ms per step): detection chain, the next batch's front, the weight gradients' side stream
+        self.prefetch_stream = self.det_stream = None
+        self.queues_distinct = None
+        if cuda:
+            from . import _lib
+            from .streams import distinct_stream
+            used, ok = [torch.cuda.current_stream(self.device)], True
+            if schedule == "pipelined":
+                self.det_stream, o = distinct_stream(used, self.device)
+                used.append(self.det_stream)
+                ok = ok and o
+            if schedule != "in_order":
+                self.prefetch_stream, o = distinct_stream(used, self.device, priority=-1)
+                used.append(self.prefetch_stream)
+                ok = ok and o
+            if _lib.fast() is not None:
+                side, o = distinct_stream(used, self.device)
+                self._side_stream = side          # (the binding wraps the raw handle: the torch object must outlive it)
+                _lib.fast().set_side_stream(side.cuda_stream, self.device.index if self.device.index is not None else torch.cuda.current_device())
+                ok = ok and o
+            self.queues_distinct = ok
         if self.det_stream is not None:
             # The detection branch's rulebook walk beside its first stage (a fifth active stream) buys nothing once the whole branch runs
             # beside the occupancy backward, and costs a lot: round 4, same box, distinct batches -- 6.1-6.5 ms per step with it against

@@ -389,6 +389,9 @@ int btc_occ_prob(const float* logit, const unsigned char* mask, int B, long long
  * zero channels the apply kernels want (34 -> 64 / 48); backward splits grad (n, cout) into da, db.  elem_bytes: 4 (fp32) | 2 (bf16). */
 int btc_cat_pad_fwd(const void* a, int ca, const void* b, int cb, long long n, int cout, int elem_bytes, void* out, void* stream);
 int btc_cat_pad_bwd(const void* grad, int cout, long long n, int elem_bytes, void* da, int ca, void* db, int cb, void* stream);
+/* A single wave that idles for `microseconds` on `stream` (0 .. 100000).  Not part of the data path: btcdet_amd/streams.py uses it to find
+ * out which of its streams the runtime dealt the same hardware queue (work on one then waits behind work on the other), see DESIGN.md section 5. */
+int btc_spin(int microseconds, void* stream);
 /* out[0] = ka sum a^2 + kb sum b^2 over two tensors of fp32 (x_bf16 = 0) or bfloat16 (1) elements, fp64 accumulation in a fixed order
  * (b may be NULL with nb = 0); backward: da = a * (g[0] * ka2), db = b * (g[0] * kb2), the factor rounded to the tensor's type first.
  * The L2 stand-in loss of the heads behind the hot path (btcdet_amd/trainer.py stand_in_det_loss), not a reference operator.

@@ -37,7 +37,14 @@ if features == "bf16":
     cfg.MODEL.OCC.BACKBONE_3D["FEATURE_DTYPE"] = "bf16"
     cfg.MODEL.BACKBONE_3D["FEATURE_DTYPE"] = "bf16"
 model = BtcHotPath(cfg, device=dev).to(dev).train()
-tr = HotPathTrainer(model, det_loss=model.det_loss)
+use_dist = os.environ.get("BTC_BENCH_FORCE_DIST") == "1"      # the reducer's share: a process group of one rank over RCCL
+if use_dist:
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29541")
+    dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=dev)
+    dist.barrier()
+tr = HotPathTrainer(model, det_loss=model.det_loss, distributed=use_dist)
 step = tr._step
 batches = bench.build_batches(n_warm + n_steps + 2, 0, dev)
 nb = len(batches)
