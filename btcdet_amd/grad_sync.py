@@ -154,11 +154,11 @@ class BucketedGradSync(object):
         if self.comm is not None:
             self.comm.all_reduce_(b.flat, stream, average=True)
         else:
-            # a synchronous call runs the collective ON the current stream (ProcessGroupNCCL, PyTorch >= 2.7); async_op=True would take the
-            # process group's own stream: two more event hops per bucket, and one more stream that may share a hardware queue with the
-            # weight gradients' (btcdet_amd/streams.py).  Host-side it returns as soon as the collective is enqueued either way.
-            on_own = b.flat.is_cuda and not b.on_comm
-            b.work = dist.all_reduce(b.flat, op=self.reduce_op, group=self.group, async_op=not on_own)
+            # a synchronous call runs the collective ON the current stream -- the thread's own, or the communication stream the pack went to
+            # (ProcessGroupNCCL, PyTorch >= 2.7); async_op=True would take the process group's own stream: two more event hops per bucket and
+            # one more busy stream than the command processor has pipes (btcdet_amd/streams.py).  Host-side it returns as soon as the
+            # collective is enqueued either way.  (CPU tensors, gloo: asynchronous, waited for in wait().)
+            b.work = dist.all_reduce(b.flat, op=self.reduce_op, group=self.group, async_op=not b.flat.is_cuda)
 
     def _read_tail(self, b, stream):
         """the reduced count of missing gradients -> pinned host memory, asynchronously; looked at when the bucket is next launched"""
@@ -237,7 +237,8 @@ class BucketedGradSync(object):
     def _comm_stream(self, device):
         st = self._cs.get(device.index)
         if st is None:
-            st = self._cs[device.index] = torch.cuda.Stream(device=device)
+            from .streams import distinct_stream   # (one whose launches overlap with the compute stream's)
+            st = self._cs[device.index] = distinct_stream([torch.cuda.current_stream(device)], device)[0]
         return st
 
     def launch_ready(self):
