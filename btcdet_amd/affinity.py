@@ -48,8 +48,9 @@ def pin_to_gpu(device_index, local_rank=0, ranks_on_node=1, cpus_per_rank=16):
     if not allowed:
         return None
     allowed = _one_per_core(allowed)
-    per = max(1, min(cpus_per_rank, len(allowed) // max(1, min(ranks_on_node, len(allowed)))))
-    start = (local_rank * per) % len(allowed)
+    share, slot = _sharers(device_index, cpus, local_rank, ranks_on_node)
+    per = max(1, min(cpus_per_rank, len(allowed) // max(1, min(share, len(allowed)))))
+    start = (slot * per) % len(allowed)
     mine = (allowed + allowed)[start:start + per]
     try:
         os.sched_setaffinity(0, mine)
@@ -58,6 +59,22 @@ def pin_to_gpu(device_index, local_rank=0, ranks_on_node=1, cpus_per_rank=16):
     _pin_existing_threads(mine)
     _MINE[:] = mine
     return mine
+
+
+def _sharers(device_index, cpus, local_rank, ranks_on_node):
+    """(how many ranks divide this GPU's local CPU list, this rank's position among them).  With one rank per visible GPU -- the launch
+    the reference and bench.py use -- those are the GPUs whose local list is the same (the GPUs of one socket: 4 of 8 on a two-socket
+    host, so a rank gets 16 of the socket's 64 cores, not 8); otherwise every rank of the node is assumed to share it."""
+    try:
+        import torch
+        n_dev = torch.cuda.device_count()
+        if n_dev > 1 and ranks_on_node == n_dev:
+            same = [d for d in range(n_dev) if local_cpus(d) == cpus]
+            if device_index in same:
+                return len(same), same.index(device_index)
+    except Exception:
+        pass
+    return ranks_on_node, local_rank
 
 
 def _one_per_core(cpus):

@@ -99,3 +99,21 @@ def test_busy_threads_get_a_cpu_each(monkeypatch):
             t.join()
         for t in os.listdir("/proc/self/task"):
             os.sched_setaffinity(int(t), avail)
+
+
+def test_ranks_share_only_their_own_sockets_cpus(monkeypatch):
+    """8 ranks, one per GPU, 4 GPUs per socket: a rank's slice comes out of its socket's list divided by FOUR, and the slices of one
+    socket's ranks are disjoint"""
+    import torch
+    sockets = {0: list(range(0, 64)), 1: list(range(64, 128))}
+    monkeypatch.setattr(affinity, "local_cpus", lambda d: list(sockets[d // 4]))
+    monkeypatch.setattr(affinity, "_one_per_core", lambda cpus: cpus)
+    monkeypatch.setattr(affinity, "_pin_existing_threads", lambda cpus: None)
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 8)
+    monkeypatch.setattr(os, "sched_getaffinity", lambda pid: set(range(128)))
+    got = []
+    monkeypatch.setattr(os, "sched_setaffinity", lambda pid, cpus: got.append(list(cpus)))
+    for r in range(8):
+        mine = affinity.pin_to_gpu(r, local_rank=r, ranks_on_node=8)
+        assert len(mine) == 16 and set(mine) <= set(sockets[r // 4])
+    assert len({c for m in got for c in m}) == 128
