@@ -463,8 +463,10 @@ def main():
                        "schedule": {"in_order": "in order, one stream (what the reference's own loop gets from these modules)",
                                     "split": "one stream; next batch's weight-independent front on a side stream beside backward; backward in two passes "
                                              "with the detection bucket's all-reduce between them",
-                                    "pipelined": "btcdet_amd.trainer.HotPathTrainer 'pipelined': each step prepares the NEXT batch's weight-independent front "
-                                                 "(both voxelizations, occupancy targets, occupancy-branch rulebooks) on a side stream; weight gradients on a "
+                                    "pipelined": "btcdet_amd.trainer.HotPathTrainer 'pipelined': each step prepares ONE batch's weight-independent front "
+                                                 "(both voxelizations, occupancy targets, occupancy-branch rulebooks; of the batch after the next one: a loader's "
+                                                 "second prefetched batch) on a side stream from a thread of its own; the detection rulebooks are walked by the "
+                                                 "occupancy worker right behind PassOccVox; weight gradients on a "
                                                  "side stream, one join per backward; the detection branch's forward on its own stream beside the occupancy "
                                                  "branch's backward; the occupancy bucket's all-reduce (N > 1), the occupancy group's optimizer step and the "
                                                  "NEXT batch's occupancy forward run from a worker thread beside the detection branch's backward, all-reduce "
