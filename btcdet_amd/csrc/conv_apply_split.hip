@@ -58,7 +58,12 @@ __device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned&
 // vector-memory queue.  An LDS-DMA instruction holds its wave until the CU's address unit has taken it (~20 cycles a piece behind
 // 40-64 pieces per item): with the product waves issuing their own pieces, every wave of the workgroup sat in that queue at the top
 // of every item and the matrix pipe idled -- loads and products ADDED (ablation: DESIGN.md section 5, round 4).
-template <int WR, int WC, int NTW, int KC, int S_STAGES, int LW>
+// PAIR (KC = 64 over a 32-channel reduction): an item is TWO active offsets -- channels 0..31 of the item's 64 are the rows gathered
+// for the first, 32..63 the rows gathered for the second, the weight panel is the two offsets' panels side by side -- so a tile walks
+// ceil(n_act / 2) items instead of n_act: half the barriers and waits of a 32-channel layer (a dense level is bound by its item loop,
+// not by what it fetches: profiles/r06_rejected_experiments.txt).  Every accumulator sees the same products in the same order as
+// with one offset per item: the results are bit-identical.
+template <int WR, int WC, int NTW, int KC, int S_STAGES, int LW, bool PAIR = false>
 __global__ __launch_bounds__(64 * (WR * WC + LW)) void conv_apply_s(const float* __restrict__ feat, const unsigned short* __restrict__ Ws,
                                                              const float* __restrict__ bias, const int32_t* __restrict__ nbr,
                                                              const int32_t* __restrict__ order, int n_rows, int K, int Cred, int Cres,
@@ -124,11 +129,13 @@ __global__ __launch_bounds__(64 * (WR * WC + LW)) void conv_apply_s(const float*
   }
   __syncthreads();
   const int n_act = __builtin_amdgcn_readfirstlane(*s_nact);   // (uniform: keeps the item cursors in scalar registers)
-  const int n_chunks = Cred / KC;
+  static_assert(!PAIR || KC == 64, "PAIR: two 32-channel offsets per 64-channel item");
+  const int n_chunks = PAIR ? 1 : Cred / KC;
+  const int n_pairs = PAIR ? (n_act + 1) >> 1 : n_act;   // entries of the item walk's outer index
   // gridDim.z > 1: the workgroups z = 0 .. Z-1 of a tile share its (offset, chunk) items -- contiguous ranges, in order -- and each
   // writes its partial sums to slab z of `out` (n_rows x Cres floats each; split_reduce adds them up in z order).  For levels
   // of a few thousand rows: one workgroup per tile walks 54-108 items one after the other while most CUs have nothing to do.
-  const int n_all = n_act * n_chunks;
+  const int n_all = n_pairs * n_chunks;
   const int i0 = (int)((long long)blockIdx.z * n_all / gridDim.z);
   const int n_items = (dbg & 32) ? i0 : (int)((long long)(blockIdx.z + 1) * n_all / gridDim.z);   // (32: no item loop)
   out += (size_t)blockIdx.z * n_rows * Cres;
@@ -145,6 +152,20 @@ __global__ __launch_bounds__(64 * (WR * WC + LW)) void conv_apply_s(const float*
   const int kvec = lane < n_act ? s_kact[lane] : 0;
   int nbq[NAI];
   auto load_nbq = [&]() {
+    if (PAIR) {
+      // (iq may run one pair past the end, as it runs one offset past the end without PAIR: lanes >= n_act of kvec hold 0)
+      const int k0 = __builtin_amdgcn_readlane(kvec, (2 * iq) & 63);
+      const int k1 = (2 * iq + 1 < n_act) ? __builtin_amdgcn_readlane(kvec, (2 * iq + 1) & 63) : -1;
+#pragma unroll
+      for (int t = 0; t < NAI; ++t) {
+        const int U = ((lid + NLD * t) % NAI_TOTAL) * 64 + lane;
+        const int rloc = U / UPA;
+        const int u = (U % UPA) ^ ((rloc ^ (rloc >> 3)) & (UPA - 1));   // the SOURCE unit this lane moves: units 8..15 belong to the second offset
+        const int k = (u & 8) ? k1 : k0;
+        nbq[t] = k >= 0 ? s_nbr[rloc * K + k] : -1;
+      }
+      return;
+    }
     const int k = __builtin_amdgcn_readlane(kvec, iq);
 #pragma unroll
     for (int t = 0; t < NAI; ++t) {
@@ -156,9 +177,15 @@ __global__ __launch_bounds__(64 * (WR * WC + LW)) void conv_apply_s(const float*
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)Ws, 0, BTC_RSRC_RECORDS, 0x00020000);
   static_assert(NLD % 2 == 0 && (TN * UPB) % 64 == 0 && 64 % UPB == 0, "one lane offset per issuing wave");
   const int w_c = lane / UPB;   // panel row of the lane within a piece; (row >> 1) & (UPB - 1) of the piece's first row: 4 (lid & 1) at UPB = 8, 0 at UPB = 4
-  const unsigned w_lane = (unsigned)(w_c * Cred + (((lane % UPB) ^ (((w_c >> 1) + (UPB == 8 ? 4 * (lid & 1) : 0)) & (UPB - 1))) * 8)) * 2u;
+  const int w_su = (lane % UPB) ^ (((w_c >> 1) + (UPB == 8 ? 4 * (lid & 1) : 0)) & (UPB - 1));   // the source unit of the panel row this lane moves
+  // PAIR: a panel row is 4 units of the first offset's row + 4 of the second's (each offset's B^T row is 32 channels = 4 units long)
+  const unsigned w_lane = (unsigned)(w_c * Cred + (PAIR ? (w_su & 3) : w_su) * 8) * 2u;
   auto issue = [&](int st) {
-    const int k = __builtin_amdgcn_readlane(kvec, iq);
+    const int k = __builtin_amdgcn_readlane(kvec, PAIR ? ((2 * iq) & 63) : iq);
+    // (a pair without a second offset loads the first one's panel twice: its half of the gathered rows is zeros, and zeros times
+    // finite weights add nothing)
+    const int k1 = PAIR ? ((2 * iq + 1 < n_act) ? __builtin_amdgcn_readlane(kvec, (2 * iq + 1) & 63) : k) : k;
+    const unsigned w_lane_i = PAIR ? w_lane + ((w_su & 4) ? (unsigned)((size_t)(k1 - k) * Cres * Cred) * 2u : 0u) : w_lane;
     const int cc = ir * KC;
     char* As = ring + st * STAGE;
     char* Bs = As + A_BYTES;
@@ -170,19 +197,19 @@ __global__ __launch_bounds__(64 * (WR * WC + LW)) void conv_apply_s(const float*
       const int rloc = U / UPA;
       const int u = (U % UPA) ^ ((rloc ^ (rloc >> 3)) & (UPA - 1));
       const int nb = nbq[t];
-      blds16s(rfeat, nb >= 0 ? ((unsigned)nb * (unsigned)Cred + (unsigned)(cc + u * 4)) * 4u : BTC_RSRC_ABSENT, As + ai * 1024);
+      blds16s(rfeat, nb >= 0 ? ((unsigned)nb * (unsigned)Cred + (unsigned)(PAIR ? (u & 7) * 4 : cc + u * 4)) * 4u : BTC_RSRC_ABSENT, As + ai * 1024);
     }
     // weight panel: piece bi of the issuing wave covers 64 / UPB panel rows (all three planes are 64-unit aligned); the lane's share
     // of the address -- its row within the piece and its swizzled unit -- is the same for every piece of a wave (w_lane, below), the
     // rest is scalar: one buffer load with a register offset + a scalar offset per piece, no per-piece address registers
-    const unsigned w_item = (unsigned)(((size_t)k * Cres + n0) * Cred + cc) * 2u;
+    const unsigned w_item = (unsigned)(((size_t)k * Cres + n0) * Cred + (PAIR ? 0 : cc)) * 2u;
 #pragma unroll
     for (int t = 0; t < NBI; ++t) {
       if (dbg & 4) break;
       const int bi = (lid + NLD * t) % NBI_TOTAL;
       const int pl = (bi * 64) / (TN * UPB), c0 = ((bi * 64) % (TN * UPB)) / UPB;
       const unsigned w_piece = (unsigned)((size_t)pl * plane + (size_t)c0 * Cred) * 2u;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(Bs + bi * 1024), 16, w_lane, w_item + w_piece, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(Bs + bi * 1024), 16, w_lane_i, w_item + w_piece, 0, 0);
     }
     if (++ir == n_chunks) {
       ir = 0;
@@ -244,9 +271,11 @@ __global__ __launch_bounds__(64 * (WR * WC + LW)) void conv_apply_s(const float*
       // (pinned: hipcc is free to sink the DMA issue below the products -- it did, in the 128-row instances -- and with two stages the
       // loop's next wait then meets loads that were issued a moment ago)
       asm volatile("" ::: "memory");
-      const int k = __builtin_amdgcn_readlane(kvec, cq);
+      const int k = __builtin_amdgcn_readlane(kvec, PAIR ? ((2 * cq) & 63) : cq);
+      const int k2 = (PAIR && 2 * cq + 1 < n_act) ? __builtin_amdgcn_readlane(kvec, (2 * cq + 1) & 63) : -1;
       if (++cr == n_chunks) { cr = 0; ++cq; }
-      if (((wave_act >> k) & 1ull) && !(dbg & 1)) {
+      const bool act0 = (wave_act >> k) & 1ull, act1 = PAIR && k2 >= 0 && ((wave_act >> k2) & 1ull);
+      if ((act0 || act1) && !(dbg & 1)) {
         const int r = wr * 16 + arow;
         const char* A = ring + st * STAGE + r * (KC * 4);
         const char* B = ring + st * STAGE + A_BYTES;
@@ -283,6 +312,7 @@ __global__ __launch_bounds__(64 * (WR * WC + LW)) void conv_apply_s(const float*
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int j = 0; j < GS; ++j) {
+            if (PAIR && !((g * GS + j) ? act1 : act0)) continue;   // (this wave's 16 rows have nothing under that offset: as an item skipped)
             const f32x4 v0 = av[j][0], v1 = av[j][1];
             uint4 ah, am, al;
             split2(v0[0], v0[1], ah.x, am.x, al.x);
@@ -331,7 +361,7 @@ size_t lds_bytes_s(int tm, int tn, int kc, int K, int stages) {
   return (size_t)stages * ((size_t)tm * kc * 4 + (size_t)3 * tn * kc * 2) + (size_t)(tm * K + K + 1 + tm) * sizeof(int32_t);
 }
 
-template <int WR, int WC, int NTW, int KC, int S_STAGES, int LW = 0>
+template <int WR, int WC, int NTW, int KC, int S_STAGES, int LW = 0, bool PAIR = false>
 int launch_s(const float* feat, const unsigned short* Ws, const float* bias, const int32_t* nbr, const int32_t* order, int n_rows, int K, int Cred,
              int Cres, float* out, int flags, hipStream_t stream, const BnFuse& bn, int zsplit) {
   constexpr int TM = 16 * WR, TN = 16 * NTW * WC;
@@ -339,10 +369,10 @@ int launch_s(const float* feat, const unsigned short* Ws, const float* bias, con
   BTC_CHECK_ARG(lds <= 160 * 1024, "conv_apply_s: tile does not fit the LDS");
   static BtcPerDeviceOnce once;   // launches come from the training thread, the autograd thread and the prefetch thread
   btc_once_per_device(once, [] {
-    (void)hipFuncSetAttribute((const void*)conv_apply_s<WR, WC, NTW, KC, S_STAGES, LW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_apply_s<WR, WC, NTW, KC, S_STAGES, LW, PAIR>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   });
   dim3 grid(btc_cdiv(n_rows, TM), Cres / TN, zsplit);
-  conv_apply_s<WR, WC, NTW, KC, S_STAGES, LW><<<grid, 64 * (WR * WC + LW), lds, stream>>>(feat, Ws, bias, nbr, order, n_rows, K, Cred, Cres, out, flags, bn);
+  conv_apply_s<WR, WC, NTW, KC, S_STAGES, LW, PAIR><<<grid, 64 * (WR * WC + LW), lds, stream>>>(feat, Ws, bias, nbr, order, n_rows, K, Cred, Cres, out, flags, bn);
   BTC_LAUNCH_CHECK();
   return BTC_OK;
 }
@@ -483,6 +513,12 @@ extern "C" int btc_conv_split_supported(int K, int Cred, int Cres) {
 
 // the built-in policy of the host bindings (which register a scratch buffer per stream, so small levels run z-split): take this
 // kernel for an fp32 launch of n_rows rows?
+// two offsets per item (PAIR) from this many rows on -- tools/conv_bench.py `split split:21=2`
+// (us per launch, one offset per item -> two: 32 -> 32 at 210 K rows 122.8 / 128.3 -> 111.7 / 112.4 (forward / dgrad), at 12 K rows 20.1 -> 16.0,
+// at 26-29 K rows 24.1 -> 22.6, 32 -> 64 at 14 K rows 23.5 -> 18.6; the 64 x 64 tiles lose -- dgrad of 64 -> 32 at 29 K rows 32.1 -> 38.1 --
+// and so do the layers with few pairs per row)
+static bool btc_split_pair_wanted(int K, int n_rows, int shape) { return K >= 8 && shape != 422 && n_rows >= 5000; }
+
 extern "C" int btc_conv_split_wanted(int K, int Cred, int Cres, int n_rows) {
   return btc_tune_get(BTC_TUNE_SPLIT) != 1 && btc_conv_split_supported(K, Cred, Cres) &&
          n_rows >= ((Cred >= 128 || Cres >= 128) ? 2500 : (Cres % 64 == 0 ? (Cred >= 64 ? 2500 : 6000) : 20000));
@@ -530,6 +566,8 @@ int btc_apply_split(const float* src, const void* Ws_, const float* bias_, const
   // 32 -> 32 at 12 K rows 24.4 -> 20.8, the 3-offset 64 -> 128 at 5.3 K rows 10.0 -> 7.9; at 3 K rows (z-split wins, 19.2 against 22.6) and
   // from 25 K rows up (25.0 against 26.3) the larger tiles stay
   if ((Cres % 128 != 0 && n_rows >= 5000 && n_rows < 22000) || (K <= 4 && n_rows < 22000)) shape = 412;
+  // two offsets per item (PAIR, below) change the balance for 32 -> 32: 64-row tiles at every size (26-29 K rows 23.0 -> 20.9 / 19.9 us)
+  if (Cres % 64 != 0 && Cred == 32 && K >= 8 && n_rows >= 5000 && btc_tune_get(BTC_TUNE_SPLIT_PAIR) != 1 && btc_tune_get(BTC_TUNE_APPLY_KC) != 32) shape = 412;
   if ((t_nt == 812 || t_nt == 412) && Cres % 32 == 0) shape = t_nt;
   if ((t_nt == 224 || t_nt == 424) && Cres % 128 == 0) shape = t_nt;   // tuning runs
   if ((t_nt == 222 || t_nt == 422 || t_nt == 414 || t_nt == 814) && Cres % 64 == 0) shape = t_nt;
@@ -542,6 +580,10 @@ int btc_apply_split(const float* src, const void* Ws_, const float* bias_, const
   // rows 43.6 -> 36.2; `tools/conv_bench.py split split:4=32` is the comparison)
   if (shape % 100 == 12) kc = (Cred % 64 == 0 && t_kc != 32) ? 64 : 32;
   if (shape == 818) kc = 32;   // (two 80 KB stages do not fit)
+  // 32-channel reductions: two offsets per 64-channel item (PAIR, kernel header) on the 32- and 64-column tiles
+  const int t_pair = btc_tune_get(BTC_TUNE_SPLIT_PAIR);
+  const bool pair = Cred == 32 && t_pair != 1 && t_kc != 32 && (shape == 412 || shape == 812 || shape == 422) && (t_pair == 2 || btc_split_pair_wanted(K, n_rows, shape));
+  if (pair) kc = 64;
   int stages = t_st ? t_st : 3;
   if (kc == 64) stages = (t_st == 3 && shape == 422) ? 3 : 2;
   // z-split (conv_apply_s header): few rows -> few tiles -> most CUs idle while each workgroup walks its tile's 27-108 items alone.
@@ -579,6 +621,20 @@ int btc_apply_split(const float* src, const void* Ws_, const float* bias_, const
     }                                                                                                                  \
     rc = lw ? launch_s<WR_, WC_, NTW_, KC_, ST_, 2>(S_ARGS) : launch_s<WR_, WC_, NTW_, KC_, ST_, 0>(S_ARGS);            \
     break
+#define S_PAIR(code, WR_, WC_, NTW_)                                                                                     \
+  case code:                                                                                                           \
+    rc = lw == 4 ? launch_s<WR_, WC_, NTW_, 64, 2, 4, true>(S_ARGS)                                                      \
+                 : (lw ? launch_s<WR_, WC_, NTW_, 64, 2, 2, true>(S_ARGS) : launch_s<WR_, WC_, NTW_, 64, 2, 0, true>(S_ARGS)); \
+    break
+  if (pair) {
+    switch (shape) {
+      S_PAIR(412, 4, 1, 2);
+      S_PAIR(812, 8, 1, 2);
+      S_PAIR(422, 4, 2, 2);
+    }
+#undef S_PAIR
+    return rc;
+  }
   switch (shape * 10 + stages + (kc == 64 ? 5 : 0)) {   // ...7 / ...8: KC = 64 with 2 / 3 stages
     S_CASE(4243, 4, 2, 4, 32, 3);
     S_CASE(4244, 4, 2, 4, 32, 4);
