@@ -8,6 +8,7 @@ function, one hardware thread per core; the schedule (trainer.make_step) then gi
 inside that slice (place_thread).  Nothing happens when the topology cannot be read (containers without sysfs, non-Linux) or when
 BTC_PIN_CPUS=0."""
 import os
+import threading
 
 
 def _parse_cpulist(text):
@@ -108,6 +109,7 @@ def _pin_existing_threads(cpus):
             pass
 
 
+_PLACED = {}      # native thread id -> role, of the threads place_thread has placed
 _MINE = []        # the CPUs pin_to_gpu gave this process (empty: not pinned -- threads are then left where the scheduler puts them)
 ROLES = ("train", "autograd", "occupancy", "prepare")
 ROLE_CPUS = 2     # CPUs (of different cores) per role: the thread has somewhere to go when another tenant's thread sits on one of them.  Same
@@ -133,6 +135,7 @@ def place_thread(role, tid=0):
     try:
         k, w = ROLES.index(role), _role_width()
         os.sched_setaffinity(tid, set(_MINE[w * k:w * k + w]))
+        _PLACED[tid or threading.get_native_id()] = role
         return True
     except OSError:
         return False
@@ -154,7 +157,9 @@ def place_other_threads():
                 name = f.read().strip()
             if name.startswith("pt_autograd"):
                 n += int(place_thread("autograd", t))
-            elif len(os.sched_getaffinity(t)) > _role_width():
+            elif t not in _PLACED and set(os.sched_getaffinity(t)) != rest:
+                # (by thread id, not by the size of its mask: a thread that one of the placed threads STARTED -- a communication library's
+                # helpers at the first collective -- inherits that thread's two CPUs and would sit on them for good)
                 os.sched_setaffinity(t, rest)
                 n += 1
         except OSError:

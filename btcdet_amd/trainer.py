@@ -133,11 +133,13 @@ def make_step(model, ddp, proc, opts, grad_sync=None, prefetch_stream=None, thre
 
     def _place_threads():
         """the calling (training) thread, autograd's device thread and the runtime's threads on their CPUs (affinity.place_thread; the
-        workers place themselves when they start) -- after each of the first three steps: autograd's thread exists after the first backward"""
-        if _placed[0] < 3:
+        workers place themselves when they start) -- after each of the first three steps (autograd's thread exists after the first backward,
+        a communication library's helpers after the first collective) and once more after the 16th"""
+        if _placed[0] < 16:
             _placed[0] += 1
-            _aff.place_thread("train")
-            _aff.place_other_threads()
+            if _placed[0] <= 3 or _placed[0] == 16:
+                _aff.place_thread("train")
+                _aff.place_other_threads()
     pending = {}
     pool = None
     if (prefetch_stream is not None and threaded) or det_stream is not None:

@@ -117,3 +117,44 @@ def test_ranks_share_only_their_own_sockets_cpus(monkeypatch):
         mine = affinity.pin_to_gpu(r, local_rank=r, ranks_on_node=8)
         assert len(mine) == 16 and set(mine) <= set(sockets[r // 4])
     assert len({c for m in got for c in m}) == 128
+
+
+def test_a_thread_started_by_a_placed_thread_does_not_keep_its_cpus(monkeypatch):
+    """a helper thread created from a placed thread inherits that thread's mask; place_other_threads moves it to the shared CPUs all the same"""
+    import threading
+    avail = sorted(os.sched_getaffinity(0))
+    if len(avail) < 8:
+        import pytest
+        pytest.skip("needs 8 CPUs")
+    mine = avail[:8]
+    monkeypatch.setattr(affinity, "_MINE", list(mine))
+    monkeypatch.setattr(affinity, "_PLACED", {})
+    stop, tids = threading.Event(), {}
+
+    def child():
+        tids["child"] = threading.get_native_id()
+        stop.wait(30)
+
+    def parent():
+        affinity.place_thread("occupancy")
+        tids["parent"] = threading.get_native_id()
+        c = threading.Thread(target=child)
+        c.start()
+        stop.wait(30)
+        c.join()
+    p = threading.Thread(target=parent)
+    p.start()
+    try:
+        while len(tids) < 2:
+            pass
+        w = affinity._role_width()
+        assert sorted(os.sched_getaffinity(tids["child"])) == mine[2 * w:3 * w]        # inherited
+        affinity.place_thread("train")
+        affinity.place_other_threads()
+        assert sorted(os.sched_getaffinity(tids["parent"])) == mine[2 * w:3 * w]
+        assert sorted(os.sched_getaffinity(tids["child"])) == mine[4 * w:]
+    finally:
+        stop.set()
+        p.join()
+        for t in os.listdir("/proc/self/task"):
+            os.sched_setaffinity(int(t), avail)
