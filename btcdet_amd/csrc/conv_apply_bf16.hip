@@ -44,7 +44,10 @@ __device__ __forceinline__ void wait_vm_b() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int WR, int WC, int NTW, int KC>
+// PAIR (KC = 64 over a 32-channel reduction), as in conv_apply_s: an item is TWO active offsets -- units 0..3 of a 64-channel A row are
+// the row gathered for the first, 4..7 for the second; the weight panel is the two offsets' panels side by side -- so a tile walks
+// ceil(n_act / 2) items.  The accumulators see the same products in the same order: bit-identical results.
+template <int WR, int WC, int NTW, int KC, bool PAIR = false>
 __global__ __launch_bounds__(64 * WR * WC) void conv_apply_b(const unsigned short* __restrict__ feat, const unsigned short* __restrict__ Wq,
                                                              const float* __restrict__ bias, const int32_t* __restrict__ nbr,
                                                              const int32_t* __restrict__ order, int n_rows, int K, int Cred, int Cres,
@@ -106,8 +109,9 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_apply_b(const unsigned shor
   }
   __syncthreads();
   const int n_act = *s_nact;
-  const int n_chunks = Cred / KC;
-  const int n_items = n_act * n_chunks;
+  static_assert(!PAIR || KC == 64, "PAIR: two 32-channel offsets per 64-channel item");
+  const int n_chunks = PAIR ? 1 : Cred / KC;
+  const int n_items = PAIR ? (n_act + 1) >> 1 : n_act * n_chunks;
 
   f32x4 acc[NTW];
 #pragma unroll
@@ -116,8 +120,9 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_apply_b(const unsigned shor
   // cursors of the issue walk (two items ahead) and of the compute walk: one item per call, no division by n_chunks in the loop
   int iq = 0, ir = 0, cq = 0, cr = 0;
   auto issue = [&](int st) {
-    const int k = s_kact[iq];
-    const int cc = ir * KC;
+    const int k = s_kact[PAIR ? 2 * iq : iq];
+    const int k1 = (PAIR && 2 * iq + 1 < n_act) ? s_kact[2 * iq + 1] : -1;
+    const int cc = PAIR ? 0 : ir * KC;
     if (++ir == n_chunks) { ir = 0; ++iq; }
     char* As = ring + st * STAGE;
     char* Bs = As + A_BYTES;
@@ -128,12 +133,15 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_apply_b(const unsigned shor
       if (A_UNITS % 64 == 0 || U < A_UNITS) {
         const int rloc = U / UPR;
         const int u = (U % UPR) ^ ((rloc / RPB) & (UPR - 1));
-        const int nb = s_nbr[rloc * K + k];
-        const unsigned short* src = nb >= 0 ? feat + (size_t)nb * Cred + cc + u * 8 : g_zero_row_b;
+        const int ku = (PAIR && (u & 4)) ? k1 : k;
+        const int nb = ku >= 0 ? s_nbr[rloc * K + ku] : -1;
+        const unsigned short* src = nb >= 0 ? feat + (size_t)nb * Cred + cc + (PAIR ? (u & 3) : u) * 8 : g_zero_row_b;
         glds16b(src, As + ai * 1024);
       }
     }
     const unsigned short* Wk = Wq + ((size_t)k * Cres + n0) * Cred + cc;
+    // (a pair without a second offset reads the first one's panel twice: its half of the gathered rows is zeros)
+    const unsigned short* Wk1 = PAIR ? Wq + ((size_t)(k1 >= 0 ? k1 : k) * Cres + n0) * Cred : Wk;
 #pragma unroll
     for (int t = 0; t < NBI; ++t) {
       const int bi = (wave + NW * t) % NBI_TOTAL;
@@ -141,7 +149,7 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_apply_b(const unsigned shor
       if (B_UNITS % 64 == 0 || U < B_UNITS) {
         const int c = U / UPR;
         const int u = (U % UPR) ^ ((c / RPB) & (UPR - 1));
-        glds16b(Wk + (size_t)c * Cred + u * 8, Bs + bi * 1024);
+        glds16b(((PAIR && (u & 4)) ? Wk1 : Wk) + (size_t)c * Cred + (PAIR ? (u & 3) : u) * 8, Bs + bi * 1024);
       }
     }
   };
@@ -156,9 +164,11 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_apply_b(const unsigned shor
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     if (item + 2 < n_items) issue(st == 0 ? 2 : st - 1);
-    const int k = s_kact[cq];
+    const int k = s_kact[PAIR ? 2 * cq : cq];
+    const int k2 = (PAIR && 2 * cq + 1 < n_act) ? s_kact[2 * cq + 1] : -1;
     if (++cr == n_chunks) { cr = 0; ++cq; }
-    if ((wave_act >> k) & 1ull) {
+    const bool act0 = (wave_act >> k) & 1ull, act1 = PAIR && k2 >= 0 && ((wave_act >> k2) & 1ull);
+    if (act0 || act1) {
       const char* A = ring + st * STAGE + (wr * 16 + arow) * (KC * 2);
       const char* B = ring + st * STAGE + A_BYTES;
       const int aswz = ((wr * 16 + arow) / RPB) & (UPR - 1);
@@ -175,10 +185,12 @@ __global__ __launch_bounds__(64 * WR * WC) void conv_apply_b(const unsigned shor
         }
       }
 #pragma unroll
-      for (int s = 0; s < STEPS; ++s)
+      for (int s = 0; s < STEPS; ++s) {
+        if (PAIR && !(s ? act1 : act0)) continue;   // (this wave's 16 rows have nothing under that offset: as an item skipped)
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt)
           acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[s], b[s][nt], acc[nt], 0, 0, 0);
+      }
     }
     st = (st == B_STAGES - 1) ? 0 : st + 1;
   }
@@ -210,7 +222,7 @@ size_t lds_bytes_b(int tm, int tn, int kc, int K) {
   return (size_t)B_STAGES * (a + b) + (size_t)(tm * K + K + 1 + tm) * sizeof(int32_t);
 }
 
-template <int WR, int WC, int NTW, int KC>
+template <int WR, int WC, int NTW, int KC, bool PAIR = false>
 int launch_b(const unsigned short* feat, const unsigned short* Wq, const float* bias, const int32_t* nbr, const int32_t* order, int n_rows, int K, int Cred,
              int Cres, unsigned short* out, int xcd, hipStream_t stream, const BnFuse& bn) {
   constexpr int TM = 16 * WR, TN = 16 * NTW * WC;
@@ -218,10 +230,10 @@ int launch_b(const unsigned short* feat, const unsigned short* Wq, const float* 
   BTC_CHECK_ARG(lds <= 160 * 1024, "conv_apply_b: tile does not fit the LDS");
   static BtcPerDeviceOnce once;   // launches come from the training thread, the autograd thread and the prefetch thread
   btc_once_per_device(once, [] {
-    (void)hipFuncSetAttribute((const void*)conv_apply_b<WR, WC, NTW, KC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_apply_b<WR, WC, NTW, KC, PAIR>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   });
   dim3 grid(btc_cdiv(n_rows, TM), Cres / TN);
-  conv_apply_b<WR, WC, NTW, KC><<<grid, 64 * WR * WC, lds, stream>>>(feat, Wq, bias, nbr, order, n_rows, K, Cred, Cres, out, xcd, bn);
+  conv_apply_b<WR, WC, NTW, KC, PAIR><<<grid, 64 * WR * WC, lds, stream>>>(feat, Wq, bias, nbr, order, n_rows, K, Cred, Cres, out, xcd, bn);
   BTC_LAUNCH_CHECK();
   return BTC_OK;
 }
@@ -229,6 +241,7 @@ int launch_b(const unsigned short* feat, const unsigned short* Wq, const float* 
 template <int WR, int WC, int NTW>
 int launch_b_kc(int kc, const unsigned short* feat, const unsigned short* Wq, const float* bias, const int32_t* nbr, const int32_t* order, int n_rows,
                 int K, int Cred, int Cres, unsigned short* out, int xcd, hipStream_t stream, const BnFuse& bn) {
+  if (kc == 128) return launch_b<WR, WC, NTW, 64, true>(feat, Wq, bias, nbr, order, n_rows, K, Cred, Cres, out, xcd, stream, bn);   // (code for PAIR)
   if (kc == 64) return launch_b<WR, WC, NTW, 64>(feat, Wq, bias, nbr, order, n_rows, K, Cred, Cres, out, xcd, stream, bn);
   return launch_b<WR, WC, NTW, 32>(feat, Wq, bias, nbr, order, n_rows, K, Cred, Cres, out, xcd, stream, bn);
 }
@@ -240,7 +253,9 @@ int apply_b(const void* feat_, const void* Wq_, const float* bias, const int32_t
   const unsigned short* feat = (const unsigned short*)feat_;
   const unsigned short* Wq = (const unsigned short*)Wq_;
   unsigned short* out = (unsigned short*)out_;
-  const int kc = (Cred % 64 == 0) ? 64 : 32;
+  int kc = (Cred % 64 == 0) ? 64 : 32;
+  // 32-channel reductions: two offsets per 64-channel item (PAIR; BTC_TUNE_SPLIT_PAIR = 1 switches it off, same bits)
+  if (Cred == 32 && K >= 8 && btc_tune_get(BTC_TUNE_SPLIT_PAIR) != 1 && (btc_tune_get(BTC_TUNE_SPLIT_PAIR) == 2 || n_rows >= 5000)) kc = 128;
   const int xcd = (btc_tune_get(BTC_TUNE_APPLY_XCD) == 2 ? 1 : 0) | (mirror ? 2 : 0);   // kernel flags: bit 0 XCD mapping, bit 1 mirrored map
   // wave shapes as conv_apply_g's policy (sparse_conv.hip): 64 rows x 128 columns on 8 waves for wide results, 16-row
   // workgroups with 4 waves across the columns when there are few rows

@@ -71,7 +71,7 @@ int btc_version(void);
 #define BTC_TUNE_WGRAD_X 18 /* weight gradient on the bf16 matrix pipe (conv_wgrad_x.hip): 0 = where supported, 1 = never (the fp32-pipe kernels) */
 #define BTC_TUNE_WGRAD_X_DEPTH 20 /* (key 16 is retired: it named the deleted in-kernel z-split reduction) conv_wgrad_x: items of gathered rows in flight ahead of the products: 0 = built-in (2 for bf16 activations, 1 for split fp32), 1, 2 (same bits) */
 #define BTC_TUNE_RB_MARK_MULTI 19 /* chain rulebooks: 1 = mark every level by its own launch (rb_mark / rb_mark_b) instead of one launch for the leading run of strided conv layers (cross-check: same levels) */
-#define BTC_TUNE_SPLIT_PAIR 21 /* split-operand kernel, 32-channel reductions: 0 = built-in policy, 1 = one offset per item, 2 = two offsets per 64-channel item wherever a tile shape has the instance (same bits) */
+#define BTC_TUNE_SPLIT_PAIR 21 /* split-operand kernel and bf16-operand kernel, 32-channel reductions: 0 = built-in policy, 1 = one offset per item, 2 = two offsets per 64-channel item wherever a tile shape has the instance (same bits) */
 #define BTC_TUNE_APPLY_DEBUG 3 /* timing experiments only (WRONG results): 1 = no MFMA phase, 2 = no loads in the main loop */
 int btc_tune_set(int key, int value);
 int btc_tune_value(int key);   /* current value of a key (0 = built-in policy) */

@@ -82,3 +82,34 @@ def test_weights_to_bf16_layouts():
     b = q[1].float().cpu().numpy().reshape(K, co, ci)
     np.testing.assert_array_equal(a, orc.bf16_round(W))
     np.testing.assert_array_equal(b, orc.bf16_round(W).transpose(0, 2, 1))
+
+
+@pytest.mark.parametrize("cin,cout,n,kind", [(32, 32, 26000, "subm"), (32, 64, 9000, "subm"), (32, 32, 20000, "conv"), (32, 16, 12000, "subm")])
+def test_bf16_two_offsets_per_item_give_the_same_bits(cin, cout, n, kind):
+    """conv_apply_b's PAIR instances (two active offsets per 64-channel item on 32-channel reductions, BTC_TUNE_SPLIT_PAIR as for the
+    split-operand kernel): forward and data gradient bit-identical to one offset per item"""
+    from btcdet_amd import _lib
+    from btcdet_amd.spconv import ops
+    if _lib.fast() is None:
+        pytest.skip("the bf16-operand path is driven by the compiled binding")
+    L = _lib.lib()
+    rng = np.random.default_rng(cin * 13 + cout + n)
+    shape, B = (16, 64, 64), 2
+    idx = rand_indices(rng, n, B, shape)
+    s = (1, 1, 1) if kind == "subm" else (2, 2, 2)
+    (o_idx, o_out, o_in, o_sh), rb = _rb_both(idx, B, shape, (3, 3, 3), s, (1, 1, 1), (1, 1, 1), kind)
+    f = torch.from_numpy(rng.standard_normal((idx.shape[0], cin)).astype(np.float32)).to(dev()).to(torch.bfloat16).requires_grad_(True)
+    w = torch.from_numpy((rng.standard_normal((3, 3, 3, cin, cout)) / np.sqrt(cin)).astype(np.float32)).to(dev())
+    g = torch.from_numpy(rng.standard_normal((o_out.shape[0], cout)).astype(np.float32)).to(dev()).to(torch.bfloat16)
+    res = []
+    for pair in (1, 2, 0, 1):
+        assert L.btc_tune_set(21, pair) == 0
+        try:
+            y = ops.indice_conv(f, w, None, rb)
+            (dx,) = torch.autograd.grad(y, f, g)
+            res.append((y.detach().clone(), dx.clone()))
+        finally:
+            L.btc_tune_set(21, 0)
+    assert res[0][0].dtype == torch.bfloat16
+    for y, dx in res[1:]:
+        assert torch.equal(res[0][0], y) and torch.equal(res[0][1], dx)
