@@ -413,7 +413,7 @@ std::tuple<OptTensor, OptTensor> conv_bwd(const Tensor& features, const Tensor& 
   // in the same tensor for both (ops.Rulebook.map_bwd) -- the dgrad kernels then read column K-1-k for offset k
   const bool mirror = map_fwd.numel() > 0 && map_bwd.data_ptr() == map_fwd.data_ptr();
   const int pass_dgrad = mirror ? BTC_PASS_DGRAD_MIRROR : BTC_PASS_DGRAD;
-  const int32_t* wg_map_bwd = mirror ? nullptr : (const int32_t*)map_bwd.data_ptr();   // (weight gradient: the forward map alone)
+  const int32_t* wg_map_bwd = (const int32_t*)map_bwd.data_ptr();   // (weight gradient: the same pointer twice = "one map, mirrored")
   OptTensor din, dw;
   Tensor ws;
   hipStream_t main = (hipStream_t)st(stream);

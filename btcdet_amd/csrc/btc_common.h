@@ -93,6 +93,12 @@ bool btc_wgrad_x_supported(int mode, int K, int cg, int cc);
 int btc_wgrad_x_plan(int mode, int rows, int K, int cg, int cc, int* S, int* ph, int* z = nullptr);   // -> offset groups; *S = slabs, *z = channel blocks
 int btc_launch_wgrad_x(int mode, const void* g, const void* c, const int32_t* map, const int32_t* ord, int rows, int K, int cg, int cc, float* part,
                        int swap, hipStream_t stream);
+// conv_wgrad_n.hip: weight gradient of a layer with a narrow result side (<= 8 channels), walked over the layer's INPUT rows: x read once,
+// dy gathered through the backward map (mirror: a submanifold layer's forward map, column k' = offset K-1-k'); fp32 matrix pipe
+bool btc_wgrad_n_supported(int K, int Cin, int Cout);
+int btc_wgrad_n_plan(int rows);   // -> slabs
+int btc_launch_wgrad_n(bool bf, const void* x, const void* dy, const int32_t* map, int rows, int K, int Cin, int Cout, float* part, int mirror,
+                       hipStream_t stream);
 constexpr size_t BTC_SCRATCH_HEAD = 64 * 1024;              // head of a registered scratch buffer: zeroed at registration, zero between launches
 constexpr long long BTC_SCRATCH_TICKETS = BTC_SCRATCH_HEAD / 4;   // (the z-split launches' per-tile tickets live there)
 void* btc_scratch(hipStream_t stream, size_t* bytes);   // the stream's registered scratch buffer (btc_set_scratch) or NULL

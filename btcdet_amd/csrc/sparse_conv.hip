@@ -952,6 +952,15 @@ __global__ __launch_bounds__(256) void wgrad_reduce(const float* __restrict__ pa
   if (e >= count) return;
   float s = 0.f;
   int q = 0;
+  // (a chain of S dependent additions per element, bound by the round trips of its loads: 16 in flight, then 8; the order of the
+  // additions is the slab order either way)
+  for (; q + 16 <= S; q += 16) {
+    float v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) v[u] = part[(size_t)(q + u) * count + e];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) s += v[u];
+  }
   for (; q + 8 <= S; q += 8) {
     float v[8];
 #pragma unroll
@@ -984,6 +993,15 @@ __global__ __launch_bounds__(256) void wgrad_reduce_multi(const ReduceJobs jobs)
   const int S = jobs.S[j];
   float s = 0.f;
   int q = 0;
+  // (a chain of S dependent additions per element, bound by the round trips of its loads: 16 in flight, then 8; the order of the
+  // additions is the slab order either way)
+  for (; q + 16 <= S; q += 16) {
+    float v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) v[u] = part[(size_t)(q + u) * count + e];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) s += v[u];
+  }
   for (; q + 8 <= S; q += 8) {
     float v[8];
 #pragma unroll
@@ -1378,6 +1396,12 @@ extern "C" size_t btc_conv_wgrad_ws_bytes(int n_out, int K, int Cin, int Cout, i
         if (sx > S) S = sx;
       }
   }
+  // ... and for the narrow-result walk over the input rows (conv_wgrad_n.hip)
+  if (btc_wgrad_n_supported(K, Cin, Cout)) {
+    const int sn = btc_wgrad_n_plan(n_out), sm = n_in > 0 ? btc_wgrad_n_plan(n_in) : 0;
+    if (sn > S) S = sn;
+    if (sm > S) S = sm;
+  }
   return btc_align((size_t)S * K * Cin * Cout * sizeof(float));
 }
 
@@ -1391,6 +1415,10 @@ static int wgrad_impl(const float* feat, const float* dout, const int32_t* nbr_o
   BTC_CHECK_ARG(K >= 1 && Cin >= 1 && Cout >= 1 && n_out >= 0, "btc_conv_wgrad: bad sizes");
   // rows of `feat`: n_in when the backward map comes with it, or when a caller without one states a positive count; a legacy call that
   // passes NULL and 0 (the argument used to be ignored without a map) leaves it unknown -> the fp32-pipe kernels, which need no bound
+  // nbr_in == nbr_out (the same pointer, n_in == n_out): a submanifold layer -- its backward map is the forward map with the offset index
+  // mirrored, nothing else is stored (rulebook.hip); the kernels that walk the output rows take it as "no backward map"
+  const bool mirror = nbr_in != nullptr && nbr_in == nbr_out && n_in == n_out;
+  if (mirror) nbr_in = nullptr;
   const int n_feat = (nbr_in || n_in > 0) ? n_in : -1;
   if (!nbr_in) n_in = -1;
   BTC_CHECK_ARG(ws_bytes >= btc_conv_wgrad_ws_bytes(n_out, K, Cin, Cout, n_in), "btc_conv_wgrad: workspace too small");
@@ -1414,6 +1442,17 @@ static int wgrad_impl(const float* feat, const float* dout, const int32_t* nbr_o
     }                                                                                  \
     return BTC_OK;                                                                     \
   } while (0)
+  if ((mirror || nbr_in) && btc_tune_get(BTC_TUNE_WGRAD_NARROW) != 1 && btc_wgrad_n_supported(K, Cin, Cout)) {
+    // narrow result side (the 5-channel occupancy head): walk the layer's INPUT rows -- x read once, dy gathered (conv_wgrad_n.hip).
+    // 32-bit byte offsets: map and both operands under 4 GB.
+    const long long rows = mirror ? n_out : n_in, esz = BF ? 2 : 4;
+    if (rows >= 2048 && rows * K * 4 < 0xFFFFFF00LL && rows * Cin * esz < 0xFFFFFF00LL && (long long)n_out * Cout * esz < 0xFFFFFF00LL) {
+      p.S = btc_wgrad_n_plan((int)rows);
+      const int rc = btc_launch_wgrad_n(BF, feat, dout, mirror ? nbr_out : nbr_in, (int)rows, K, Cin, Cout, part, mirror ? 1 : 0, stream);
+      if (rc != BTC_OK) return rc;
+      BTC_WGRAD_FINISH();
+    }
+  }
   {
     // the row-stationary walk on the bf16 matrix pipe (conv_wgrad_x.hip): bf16 activations as they are, fp32 activations as three exact
     // bf16 pieces; any channel counts whose gathered side is a multiple of 16 (a workgroup owns a <= 64 x 64 block of every dW[k]).

@@ -638,7 +638,7 @@ def _conv_backward(features, w, map_fwd, map_bwd, grad_out, wshape, need_din, ne
     n_res, n_src = map_fwd.shape[0], map_bwd.shape[0]
     mirror = map_bwd is map_fwd or (map_fwd.numel() > 0 and map_bwd.data_ptr() == map_fwd.data_ptr())   # a submanifold rulebook's single map (Rulebook docstring)
     pass_dgrad = 2 if mirror else 1                                            # BTC_PASS_DGRAD_MIRROR / BTC_PASS_DGRAD
-    wg_bwd = None if mirror else map_bwd
+    wg_bwd = map_bwd   # (weight gradient: the same pointer twice says "one map, mirrored"; btcdet_hip.h)
     overlap = bool(need_din and need_dw and _overlap_ok(n_res))
     if PROFILE is None:
         F = fast()

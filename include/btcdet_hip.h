@@ -72,6 +72,7 @@ int btc_version(void);
 #define BTC_TUNE_WGRAD_X_DEPTH 20 /* (key 16 is retired: it named the deleted in-kernel z-split reduction) conv_wgrad_x: items of gathered rows in flight ahead of the products: 0 = built-in (2 for bf16 activations, 1 for split fp32), 1, 2 (same bits) */
 #define BTC_TUNE_RB_MARK_MULTI 19 /* chain rulebooks: 1 = mark every level by its own launch (rb_mark / rb_mark_b) instead of one launch for the leading run of strided conv layers (cross-check: same levels) */
 #define BTC_TUNE_SPLIT_PAIR 21 /* split-operand kernel and bf16-operand kernel, 32-channel reductions: 0 = built-in policy, 1 = one offset per item, 2 = two offsets per 64-channel item wherever a tile shape has the instance (same bits) */
+#define BTC_TUNE_WGRAD_NARROW 22 /* weight gradient of a layer with <= 8 result channels walked over its input rows (conv_wgrad_n.hip; needs the backward map or nbr_in == nbr_out): 0 = where supported, 1 = never */
 #define BTC_TUNE_APPLY_DEBUG 3 /* timing experiments only (WRONG results): 1 = no MFMA phase, 2 = no loads in the main loop */
 int btc_tune_set(int key, int value);
 int btc_tune_value(int key);   /* current value of a key (0 = built-in policy) */
@@ -214,7 +215,9 @@ int btc_pairs_from_nbr(const int32_t* nbr_out, int n_out, int K, int n_in, int32
  *   fwd   : out[i]  = bias + sum_k feat[nbr_out[i][k]] @ W[k]
  *   dgrad : din[j]  = sum_k dout[nbr_in[j][k]] @ W[k]^T
  *   wgrad : dW[k]   = sum_i feat[nbr_out[i][k]]^T dout[i]    (ws: btc_conv_wgrad_ws_bytes; nbr_in / n_in are optional
- *           (NULL / -1): when given, the kernel may walk the smaller side of the rulebook)
+ *           (NULL / -1): when given, the kernel may walk the smaller side of the rulebook, and a layer with <= 8 result channels is
+ *           walked over its input rows (conv_wgrad_n.hip).  A submanifold layer stores one map (its backward map is the mirror image,
+ *           btc_rulebook_subm): pass nbr_in == nbr_out (the same pointer) and n_in == n_out to say so)
  * An inverse conv (SparseInverseConv3d) is fwd with nbr_in of the cached rulebook as the map.
  * ---------------------------------------------------------------------------------------------- */
 int btc_conv_fwd(const float* feat, const float* W, const float* bias /* may be NULL */, const int32_t* nbr_out,

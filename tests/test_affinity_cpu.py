@@ -4,6 +4,15 @@ import os
 from btcdet_amd import affinity
 
 
+def _restore(avail):
+    """every thread of the process back on the whole mask (a thread may end between the listing and the call)"""
+    for t in os.listdir("/proc/self/task"):
+        try:
+            os.sched_setaffinity(int(t), avail)
+        except OSError:
+            pass
+
+
 def test_parse_cpulist():
     assert affinity._parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]
     assert affinity._parse_cpulist("") == []
@@ -48,8 +57,7 @@ def test_existing_threads_are_moved_too(monkeypatch):
     finally:
         stop.set()
         th.join()
-        for t in os.listdir("/proc/self/task"):
-            os.sched_setaffinity(int(t), avail)
+        _restore(avail)
 
 
 def test_one_cpu_per_core():
@@ -97,8 +105,7 @@ def test_busy_threads_get_a_cpu_each(monkeypatch):
         stop.set()
         for t in threads:
             t.join()
-        for t in os.listdir("/proc/self/task"):
-            os.sched_setaffinity(int(t), avail)
+        _restore(avail)
 
 
 def test_ranks_share_only_their_own_sockets_cpus(monkeypatch):
@@ -156,5 +163,4 @@ def test_a_thread_started_by_a_placed_thread_does_not_keep_its_cpus(monkeypatch)
     finally:
         stop.set()
         p.join()
-        for t in os.listdir("/proc/self/task"):
-            os.sched_setaffinity(int(t), avail)
+        _restore(avail)

@@ -24,6 +24,16 @@ pytestmark = pytest.mark.gpu
 X_KEY = 18   # BTC_TUNE_WGRAD_X
 
 
+@pytest.fixture(autouse=True)
+def _no_narrow_kernel():
+    """the 5 / 3-channel heads of this file's strided / transposed cases would take conv_wgrad_n (tests/test_hip_wgrad_n.py) since round 6:
+    BTC_TUNE_WGRAD_NARROW = 1 keeps this file on the kernel it is about"""
+    from btcdet_amd._lib import lib
+    assert lib().btc_tune_set(22, 1) == 0
+    yield
+    assert lib().btc_tune_set(22, 0) == 0
+
+
 def _ref64(feat, dout, nbr_out, K, cin, cout):
     """dW[k] = sum_i feat[nbr_out[i][k]]^T dout[i] in float64 on the device"""
     f, d = feat.double(), dout.double()

@@ -42,6 +42,7 @@ print("%7s %7s %3s %4s %4s %8s | %9s %6s %6s | second column (tune %d = %d; defa
 tot = np.zeros(2)
 for (f, w, b, mf, mb) in cap:
     cin, cout, K = w.shape[-2], w.shape[-1], mf.shape[1]
+    if os.environ.get("NARROW") == "1" and cout > 8: continue   # (only the layers conv_wgrad_n takes)
     n_res, n_src = mf.shape[0], mb.shape[0]
     pairs = int((mf >= 0).sum())
     g = torch.randn((n_res, cout), device=dev).to(f.dtype)
@@ -50,7 +51,7 @@ for (f, w, b, mf, mb) in cap:
     wsb = L.btc_conv_wgrad_ws_bytes(n_res, K, cin, cout, n_src)
     ws = torch.empty((wsb,), dtype=torch.uint8, device=dev)
     dw = torch.empty_like(w)
-    pmb = None if mb.data_ptr() == mf.data_ptr() else ptr(mb)    # (a submanifold rulebook has one map)
+    pmb = ptr(mb)    # (a submanifold rulebook has one map: the same pointer twice)
     fn = lambda: check(wg(ptr(f), ptr(g), ptr(mf), n_res, pmb, n_src, K, cin, cout, ptr(dw), ptr(ws), wsb, stream_ptr()), "w")
     ts = [timed(fn)]
     ref = dw.clone()
