@@ -95,10 +95,12 @@ int btc_launch_wgrad_x(int mode, const void* g, const void* c, const int32_t* ma
                        int swap, hipStream_t stream);
 // conv_wgrad_n.hip: weight gradient of a layer with a narrow result side (<= 8 channels), walked over the layer's INPUT rows: x read once,
 // dy gathered through the backward map (mirror: a submanifold layer's forward map, column k' = offset K-1-k'); fp32 matrix pipe
-bool btc_wgrad_n_supported(int K, int Cin, int Cout);
+// ... or with a narrow input (<= 8 channels: the first layers), walked over its OUTPUT rows with the features gathered through nbr_out
+int btc_wgrad_n_kind(int K, int Cin, int Cout);   // 1 narrow result, 2 narrow input, 0 neither
+bool btc_wgrad_n_supported(int K, int Cin, int Cout);   // kind 1
 int btc_wgrad_n_plan(int rows);   // -> slabs
-int btc_launch_wgrad_n(bool bf, const void* x, const void* dy, const int32_t* map, int rows, int K, int Cin, int Cout, float* part, int mirror,
-                       hipStream_t stream);
+int btc_launch_wgrad_n(bool bf, const void* walked, const void* gathered, const int32_t* map, int rows, int K, int Cw, int Cn, float* part,
+                       int flags /* 1 mirrored map, 2 narrow input (slab written [k][narrow][walked]) */, hipStream_t stream);
 constexpr size_t BTC_SCRATCH_HEAD = 64 * 1024;              // head of a registered scratch buffer: zeroed at registration, zero between launches
 constexpr long long BTC_SCRATCH_TICKETS = BTC_SCRATCH_HEAD / 4;   // (the z-split launches' per-tile tickets live there)
 void* btc_scratch(hipStream_t stream, size_t* bytes);   // the stream's registered scratch buffer (btc_set_scratch) or NULL

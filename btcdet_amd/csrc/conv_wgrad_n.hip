@@ -15,6 +15,8 @@
 //   * no LDS and no barrier in the walk: a wave owns every (8 S)-th group of 4 rows, keeps its 16 MT x 144 block of dW in accumulators,
 //     has the map values of the groups up to five steps ahead and the operand values of the next three groups in flight during a group's
 //     products (51 loads in flight per wave: one wave a SIMD measured faster than two).
+// A layer with a narrow INPUT (the 4- / 6-channel first layers: 52 us for 36 K rows on the fp32-pipe kernel) is the same walk with the roles
+// exchanged: over its output rows (dOut contiguous), the features gathered through nbr_out, columns (k, ci), slab written [k][ci][co].
 // The backward map of a submanifold layer is its forward map with the offset index mirrored (rulebook.hip): `mirror` reads column k' of
 // nbr_out as nbr_in's column K-1-k', i.e. writes dW[K-1-k'].  The four waves of a workgroup add their blocks in wave order through LDS,
 // one slab per workgroup, slabs added in index order by wgrad_reduce / btc_wgrad_reduce_multi: deterministic.
@@ -24,16 +26,20 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-constexpr int NTL = 9;                      // 16-column tiles of the (k', co) dimension: K * Cout <= 144
+constexpr int NTL_MAX = 11;                 // 16-column tiles of the (k', narrow channel) dimension: 9 (K Cn <= 144) or 11 (<= 176) per instance
 constexpr int NW = 4;                       // waves per workgroup; one slab per workgroup (8 waves on 256 workgroups measured 57 against 48 us)
 #define N_RECORDS 0xFFFFFF00u
 #define N_ABSENT 0xFFFFFFF0u
 
-template <int MT, bool BF>
+template <int MT, int NTL, bool BF>
 __global__ __launch_bounds__(NW * 64, 2) void conv_wgrad_n(const void* __restrict__ xsrc, const void* __restrict__ dysrc, const int32_t* __restrict__ map,
-                                                    int n_rows, int K, int Cx_all, int Cy, float* __restrict__ part, int mirror) {
+                                                    int n_rows, int K, int Cx_all, int Cy, float* __restrict__ part, int flags) {
   // xsrc: the layer's input rows (n_rows x Cx_all), walked contiguously; dysrc: the result side's gradient rows (Cy channels), gathered
   // through map (n_rows x K: for input row j and column k' the result row, or -1).  blockIdx.y: block of 16 MT input channels.
+  // flags bit 0: mirrored map (above); bit 1: the roles are the other way round -- a layer with a narrow INPUT (the 4- / 6-channel first
+  // layers): the walk is over its OUTPUT rows (xsrc = dOut, contiguous), the gathered rows are its input features through nbr_out, the
+  // columns are (k, ci) and the slab is written as [k][narrow][walked].
+  const bool mirror = flags & 1, narrow_in = flags & 2;
   constexpr unsigned ESZ = BF ? 2u : 4u;
   const int tid = threadIdx.x, lane = tid & 63, g4 = lane >> 4, t16 = lane & 15;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (wave-uniform: the walk's loop counter lives in scalar registers)
@@ -149,25 +155,32 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_wgrad_n(const void* __restric
     }
     __syncthreads();
   }
-  // D layout of a 16 x 16 tile: column = lane & 15 (the (k', co) column), row = (lane >> 4) * 4 + reg (the input channel)
+  // D layout of a 16 x 16 tile: column = lane & 15 (the (k', narrow channel) column), row = (lane >> 4) * 4 + reg (the walked side's channel)
   float* P = part + (size_t)blockIdx.x * K * Cx_all * Cy;
-  const int per_k = 16 * MT * Cy;           // this workgroup's elements of one dW[k]: contiguous in the slab
+  const int per_k = 16 * MT * Cy;           // this workgroup's elements of one dW[k] ([walked][narrow]: contiguous in the slab)
   for (int e = tid; e < K * per_k; e += NW * 64) {
-    const int k = e / per_k, f = e - k * per_k, cil = f / Cy, co = f - cil * Cy;
-    const int c = (mirror ? K - 1 - k : k) * Cy + co;
+    const int k = e / per_k, f = e - k * per_k, cil = f / Cy, cn = f - cil * Cy;
+    const int c = (mirror ? K - 1 - k : k) * Cy + cn;
     const int mt = cil >> 4, r16 = cil & 15;
-    P[((size_t)k * Cx_all + cx0) * Cy + f] = red[((mt * NTL + (c >> 4)) * 4 + (r16 & 3)) * 64 + (r16 >> 2) * 16 + (c & 15)];
+    const float v = red[((mt * NTL + (c >> 4)) * 4 + (r16 & 3)) * 64 + (r16 >> 2) * 16 + (c & 15)];
+    if (!narrow_in) P[((size_t)k * Cx_all + cx0) * Cy + f] = v;
+    else P[((size_t)k * Cy + cn) * Cx_all + cx0 + cil] = v;
   }
 }
 
 }  // namespace
 
-// Cin: channels of the walked side (the layer's input), Cout: of the gathered side (its result)
-bool btc_wgrad_n_supported(int K, int Cin, int Cout) {
-  return K >= 1 && Cout >= 1 && Cout <= 8 && K * Cout <= 16 * NTL && Cin >= 16 && (Cin & 15) == 0;
+// a layer with a narrow RESULT (Cout <= 8: walked over its input rows, Cin a multiple of 16) or a narrow INPUT (Cin <= 8: walked over its
+// output rows, Cout a multiple of 16): -> 1 / 2, or 0
+int btc_wgrad_n_kind(int K, int Cin, int Cout) {
+  if (K < 1 || Cin < 1 || Cout < 1) return 0;
+  if (Cout <= 8 && K * Cout <= 16 * NTL_MAX && Cin >= 16 && (Cin & 15) == 0) return 1;
+  if (Cin <= 8 && K * Cin <= 16 * NTL_MAX && Cout >= 16 && (Cout & 15) == 0) return 2;
+  return 0;
 }
+bool btc_wgrad_n_supported(int K, int Cin, int Cout) { return btc_wgrad_n_kind(K, Cin, Cout) == 1; }
 
-// slabs (= workgroups along x) of a launch over `rows` input rows
+// slabs (= workgroups along x) of a launch over `rows` walked rows
 int btc_wgrad_n_plan(int rows) {
   const int t_wgs = btc_tune_get(BTC_TUNE_WGRAD_WGS);
   // one workgroup per CU: every slab is 4 K Cin Cout bytes written and read again, and one more term of the reduction's chain
@@ -178,19 +191,24 @@ int btc_wgrad_n_plan(int rows) {
   return s < 1 ? 1 : s;
 }
 
-int btc_launch_wgrad_n(bool bf, const void* x, const void* dy, const int32_t* map, int rows, int K, int Cin, int Cout, float* part, int mirror,
+// walked: rows of Cw channels (a multiple of 16), read once; gathered: rows of Cn <= 8 channels through map (rows x K); flags as the kernel's
+int btc_launch_wgrad_n(bool bf, const void* walked, const void* gathered, const int32_t* map, int rows, int K, int Cw, int Cn, float* part, int flags,
                        hipStream_t stream) {
-  BTC_CHECK_ARG(btc_wgrad_n_supported(K, Cin, Cout), "btc_launch_wgrad_n: unsupported shape %d x %d, K = %d", Cin, Cout, K);
+  BTC_CHECK_ARG(K >= 1 && K <= 64 && Cn >= 1 && Cn <= 8 && K * Cn <= 16 * NTL_MAX && Cw >= 16 && (Cw & 15) == 0,
+                "btc_launch_wgrad_n: unsupported shape %d x %d, K = %d", Cw, Cn, K);
   const int S = btc_wgrad_n_plan(rows);
-  if ((Cin & 31) == 0) {
-    dim3 grid(S, Cin / 32);
-    if (bf) conv_wgrad_n<2, true><<<grid, NW * 64, 0, stream>>>(x, dy, map, rows, K, Cin, Cout, part, mirror);
-    else conv_wgrad_n<2, false><<<grid, NW * 64, 0, stream>>>(x, dy, map, rows, K, Cin, Cout, part, mirror);
-  } else {
-    dim3 grid(S, Cin / 16);
-    if (bf) conv_wgrad_n<1, true><<<grid, NW * 64, 0, stream>>>(x, dy, map, rows, K, Cin, Cout, part, mirror);
-    else conv_wgrad_n<1, false><<<grid, NW * 64, 0, stream>>>(x, dy, map, rows, K, Cin, Cout, part, mirror);
-  }
+  const bool wide = K * Cn > 144, two = (Cw & 31) == 0;
+  dim3 grid(S, Cw / (two ? 32 : 16));
+#define N_LAUNCH(MT_, NTL_)                                                                                                            \
+  do {                                                                                                                                 \
+    if (bf) conv_wgrad_n<MT_, NTL_, true><<<grid, NW * 64, 0, stream>>>(walked, gathered, map, rows, K, Cw, Cn, part, flags);          \
+    else conv_wgrad_n<MT_, NTL_, false><<<grid, NW * 64, 0, stream>>>(walked, gathered, map, rows, K, Cw, Cn, part, flags);            \
+  } while (0)
+  if (two && !wide) N_LAUNCH(2, 9);
+  else if (two) N_LAUNCH(2, 11);
+  else if (!wide) N_LAUNCH(1, 9);
+  else N_LAUNCH(1, 11);
+#undef N_LAUNCH
   BTC_LAUNCH_CHECK();
   return BTC_OK;
 }

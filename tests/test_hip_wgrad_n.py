@@ -2,7 +2,8 @@
 
 The kernel walks the layer's INPUT rows (x read once, dy gathered through the backward map -- for a submanifold layer the forward map
 read mirrored, requested by passing nbr_in == nbr_out) with the K offsets and the <= 8 result channels as one matrix dimension on the fp32
-matrix pipe.  Asserted, for the 5 / 3-channel heads and other narrow shapes, submanifold / strided / transposed, row counts that are not
+matrix pipe; a layer with a narrow INPUT (the 4- / 6-channel first layers) is walked the other way round: over its output rows, the features
+gathered through nbr_out.  Asserted, for the 5 / 3-channel heads and other narrow shapes, submanifold / strided / transposed, row counts that are not
 multiples of 4, both activation types:
   * fp32: the error against a float64 product is no larger than 1.5x the fp32 MFMA chain's (conv_wgrad_rows_p: BTC_TUNE_WGRAD_NARROW = 1
     and BTC_TUNE_WGRAD_X = 1) + 2e-7 of the scale -- or 1e-6 of it: the strided cases sum over the other side of the rulebook, in other
@@ -71,11 +72,15 @@ def _tuned(pairs, fn):
 
 
 def _applies(rb, n_src, cin, cout):
-    K = rb.nbr_out.shape[1]
-    return n_src >= 2048 and cout <= 8 and K * cout <= 144 and cin % 16 == 0
+    """btc_wgrad_n_kind + the row counts of sparse_conv.hip: narrow result (walk over the input rows) or narrow input (over the output rows)"""
+    K, n_out = rb.nbr_out.shape[1], rb.nbr_out.shape[0]
+    if cout <= 8 and K * cout <= 176 and cin % 16 == 0:
+        return n_src >= 2048
+    return cin <= 8 and K * cin <= 176 and cout % 16 == 0 and n_out >= 2048 and (rb.mirrored or 2 * n_src >= n_out)
 
 
-SHAPES = [(32, 5), (64, 3), (16, 5), (48, 2), (32, 1), (96, 4), (64, 5)]
+# narrow result: the 5 / 3-channel heads ...; narrow input: the 4- / 6-channel first layers (27 x 6 = 162 columns: the 11-tile instances)
+SHAPES = [(32, 5), (64, 3), (16, 5), (48, 2), (32, 1), (96, 4), (64, 5), (32, 6), (6, 16), (4, 16), (4, 32), (3, 48), (6, 64)]
 CASES = [("subm", 9001), ("subm", 60003), ("conv", 30002), ("transpose", 5001)]
 
 
@@ -85,10 +90,13 @@ def test_narrow_wgrad_is_as_accurate_as_the_fp32_chain(cin, cout, kind, n_vox):
     rng = np.random.default_rng(cin * 131 + cout + n_vox)
     rb, feat, dout = _case(rng, cin, cout, kind, n_vox)
     K = rb.nbr_out.shape[1]
-    assert _applies(rb, feat.shape[0], cin, cout)
+    got = _wgrad(feat, dout, rb, cin, cout)
+    if not _applies(rb, feat.shape[0], cin, cout):      # (a narrow input whose rulebook has the smaller side there: the kernels of before)
+        assert kind == "transpose" and cin <= 8
+        assert torch.equal(got, _tuned([(N_KEY, 1)], lambda: _wgrad(feat, dout, rb, cin, cout)))
+        return
     ref = _ref64(feat, dout, rb.nbr_out, K, cin, cout)
     scale = float(ref.abs().max()) + 1e-12
-    got = _wgrad(feat, dout, rb, cin, cout)
     assert bool(torch.isfinite(got).all())
     assert torch.equal(got, _wgrad(feat, dout, rb, cin, cout)), "not deterministic"
     old = _tuned([(N_KEY, 1), (X_KEY, 1)], lambda: _wgrad(feat, dout, rb, cin, cout))
@@ -125,7 +133,7 @@ def test_narrow_wgrad_bf16_activations(cin, cout, kind, n_vox):
     got = _wgrad(fb, db, rb, cin, cout)
     assert torch.equal(got, _wgrad(fb, db, rb, cin, cout)), "not deterministic"
     old = _tuned([(N_KEY, 1)], lambda: _wgrad(fb, db, rb, cin, cout))
-    assert not torch.equal(got, old), "the narrow kernel was not taken"
+    assert _applies(rb, feat.shape[0], cin, cout) == (not torch.equal(got, old)), "kernel selection differs from the stated policy"
     e_new = float((got.double() - ref).abs().max()) / scale
     print("%d->%d %s bf16: max err %.2e" % (cin, cout, kind, e_new))
     assert e_new <= 4e-6
@@ -146,7 +154,9 @@ def test_kernel_2_stride_2_layer_with_8_result_channels():
 
 
 @pytest.mark.parametrize("cin,cout,kind,n_vox,why", [(32, 5, "subm", 1500, "fewer than 2048 input rows"), (32, 16, "subm", 9000, "16 result channels"),
-                                                      (20, 5, "subm", 9000, "input channels not a multiple of 16"), (32, 6, "subm", 9000, "27 x 6 = 162 columns")])
+                                                      (20, 5, "subm", 9000, "input channels not a multiple of 16"), (32, 7, "subm", 9000, "27 x 7 = 189 columns"),
+                                                      (8, 16, "subm", 9000, "27 x 8 = 216 columns"), (6, 24, "subm", 9000, "result channels not a multiple of 16"),
+                                                      (6, 16, "subm", 1500, "fewer than 2048 output rows")])
 def test_everything_else_runs_what_it_ran_before(cin, cout, kind, n_vox, why):
     rng = np.random.default_rng(cin + cout + n_vox)
     rb, feat, dout = _case(rng, cin, cout, kind, n_vox)
