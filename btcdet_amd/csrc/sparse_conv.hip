@@ -222,7 +222,9 @@ __global__ __launch_bounds__(THREADS) void conv_apply(const float* __restrict__ 
 // Same summation order as conv_apply (offset ascending, channel ascending) -> same bits.
 // ------------------------------------------------------------------------------------------------------------
 constexpr int WS_WAVES = 16;
-constexpr int WS_KB = 4;
+constexpr int WS_KB = 8;    // offsets per group of gathers (round 6: 4 -> 8 with WS_Q below: a 27-offset tile is 4 dependent round trips, not 7;
+                            // 5 -> 32 at 210 K rows 80 -> 72 us, 4 -> 16 18.5 -> 16.4, same bits; 14 offsets per group measured 77)
+constexpr int WS_Q = 2;     // k-steps of a row: the kernel is launched for reductions of <= 8 channels only (it sized its fragment registers for 32)
 
 __host__ __device__ inline size_t ws_lds_bytes(int K, int Cred, int nt) {
   int crp = (Cred + 3) & ~3;
@@ -236,7 +238,7 @@ __global__ __launch_bounds__(WS_WAVES * 64) void conv_apply_ws(const float* __re
                                                               const BnFuse bn) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int LDW = NT * 16;
-  constexpr int QMAX = KC / 4;  // k-steps of a full 32-channel row
+  constexpr int QMAX = WS_Q;
   const int crp = (Cred + 3) & ~3;
   float* Ws = (float*)smem;                                     // [K][crp][LDW], column XOR-swizzled by (row & 1) << 4 when NT == 2
   int32_t* nb_all = (int32_t*)(Ws + (size_t)K * crp * LDW);     // [WS_WAVES][16][K]
@@ -1125,7 +1127,7 @@ int launch_apply(const float* feat, const float* W, const float* bias, const int
   // weight-stationary persistent kernel (one 16-wave workgroup per CU).  Measured on MI355X: its dword-granular register
   // gather wins 2.5x for Cred <= 8 (the dgrad of the 2/3-channel occupancy heads, the 4/6-channel input layers) and loses
   // 2x at Cred = 32 (load-issue bound), so wider layers stay on the LDS-staged float4 kernel below.
-  if (t_kernel != 1 && Cred <= 8 && Cres <= 32 && K <= 64 && n_rows >= 2048 && ws_lds_bytes(K, Cred, nt) <= 160 * 1024) {
+  if (t_kernel != 1 && Cred <= 4 * WS_Q && Cres <= 32 && K <= 64 && n_rows >= 2048 && ws_lds_bytes(K, Cred, nt) <= 160 * 1024) {
     const int n_tiles16 = btc_cdiv(n_rows, 16);
     int wgs = btc_cdiv(n_tiles16, WS_WAVES);
     if (wgs > 256) wgs = 256;

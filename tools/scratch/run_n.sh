@@ -1,4 +1,7 @@
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-timeout 1200 python -m pytest tests/test_hip_wgrad_n.py -q 2>&1 | tail -4
-timeout 300 python tools/wgrad_bench.py 2>&1 | grep -E " (4|6) +16 |totals| 32 +5 "
-AB_STEPS=80 bash tools/ab_env.sh 3 "narrow:BTC_X=0" "off:BTC_TUNE=22=1"
+for v in kb8 kb14; do
+  [ $v = kb14 ] && cp btcdet_amd/libbtcdet_hip_kb14.so btcdet_amd/libbtcdet_hip.so
+  echo == $v
+  CB_WARM=12 timeout 600 python tools/conv_bench.py split 2>&1 | grep -E " 27 +(4|5|6|16) +(4|6|16|32) | 27 +32 +5 |sum over"
+  timeout 900 python -m pytest tests/test_hip_core.py -q -x 2>&1 | tail -2
+done
