@@ -160,8 +160,6 @@ _SIGS = {
     "btc_spin": (ci, [ci, vp]),
     "btc_bn_relu_bwd": (ci, [vp, vp, vp, ci, ci, vp, vp, vp, ci, ci, vp, vp, vp, vp, sz, vp]),
     "btc_bn_relu_fwd_bf16": (ci, [vp, ci, ci, vp, vp, vp, vp, vp, ctypes.c_float, ctypes.c_float, ci, ci, vp, vp, vp, vp, sz, vp]),
-    "btc_conv_dgrad_bn_bwd": (ci, [ci, vp, ctypes.c_longlong, vp, vp, vp, ci, ci, ci, ci, vp, vp, vp, vp, vp, ci, vp, vp, vp, vp, vp]),
-    "btc_bn_relu_bwd_apply": (ci, [ci, vp, vp, vp, ci, ci, vp, vp, vp, ci, ci, vp, vp, vp, vp]),
     "btc_bn_relu_bwd_bf16": (ci, [vp, vp, vp, ci, ci, vp, vp, vp, ci, ci, vp, vp, vp, vp, sz, vp]),
     "btc_ball_query": (ci, [vp, vp, vp, vp, ci, ci, ctypes.c_float, ctypes.c_float, ci, vp, vp]),
     "btc_group_points": (ci, [vp, vp, vp, vp, ci, ci, ci, ci, vp, vp]),

@@ -264,43 +264,16 @@ std::tuple<Tensor, Tensor, Tensor> conv_bn_fwd(const Tensor& features, const Ten
   return std::make_tuple(x, std::get<0>(ys), std::get<1>(ys));
 }
 
-// ---- links between consecutive layers of a conv -> BatchNorm -> ReLU chain (conv_bn_relu_chain): layer i's output has layer i + 1 as
-// its ONLY consumer, so layer i + 1's data gradient is the whole dL/dy of layer i's BatchNorm and its epilogue can gather that
-// BatchNorm's backward statistics (btc_conv_dgrad_bn_bwd) -- layer i then runs the second launch of its BatchNorm backward only.
-// A link is a slot of a small ring, named by a serial number both nodes carry: layer i writes what the epilogue needs at forward time
-// (raw pointers into tensors ITS node saves for backward: alive whenever layer i + 1's backward runs, which always precedes layer
-// i's), layer i + 1's backward leaves dgamma | dbeta and the mark `filled`, layer i's backward takes them and clears the mark.  A graph
-// that is never walked backwards leaves a stale slot that the ring overwrites.
-struct BnLink {
-  int64_t id = -1;
-  const void *x = nullptr, *y = nullptr;
-  const float* stats = nullptr;   // mean | rstd
-  int64_t N = 0, C = 0;
-  bool relu = false, filled = false;
-  Tensor dparam;                  // (2, C): dgamma | dbeta, written by the consumer's data gradient
-};
-constexpr int BN_LINKS = 1024;
-BnLink g_links[BN_LINKS];
-std::mutex g_links_mu;
-std::atomic<int64_t> g_next_link{0};
-bool g_bn_bwd_fuse = true;
-std::atomic<long long> g_bn_bwd_fuse_hits{0};   // BatchNorm backward passes that ran their second launch only (tests, tools)
-void set_bn_bwd_fuse(bool on) { g_bn_bwd_fuse = on; }
-long long bn_bwd_fuse_hits() { return g_bn_bwd_fuse_hits.load(); }
-
-// dx, dparam (2, C) = dgamma | dbeta (have: the statistics came out of the consumer's data gradient -- second launch only)
+// dx, dparam (2, C) = dgamma | dbeta
 std::tuple<Tensor, Tensor> bn_bwd(const Tensor& x, const Tensor& y, const Tensor& dy, const OptTensor& gamma, const Tensor& stats, bool use_batch,
-                                  bool relu, const Tensor& ws, int64_t ws_bytes, int64_t stream, const Tensor* have = nullptr) {
+                                  bool relu, const Tensor& ws, int64_t ws_bytes, int64_t stream) {
   const int64_t N = x.size(0), C = x.size(1);
   need(dy.is_contiguous() && dy.scalar_type() == x.scalar_type(), "bn_bwd: dy must be contiguous and of the activation type");
   Tensor dx = at::empty_like(x);
-  Tensor dparam = have ? *have : at::empty({2, C}, x.options().dtype(at::kFloat));
+  Tensor dparam = at::empty({2, C}, x.options().dtype(at::kFloat));
   const float* mean = (const float*)stats.data_ptr();
   float* dgamma = (float*)dparam.data_ptr();
-  if (have)
-    chk(btc_bn_relu_bwd_apply((int)(x.scalar_type() == at::kBFloat16), x.data_ptr(), y.data_ptr(), dy.data_ptr(), (int)N, (int)C, fptr(gamma), mean, mean + C,
-                              (int)use_batch, (int)relu, dx.data_ptr(), dgamma, dgamma + C, st(stream)), "btc_bn_relu_bwd_apply");
-  else if (x.scalar_type() == at::kBFloat16)
+  if (x.scalar_type() == at::kBFloat16)
     chk(btc_bn_relu_bwd_bf16(x.data_ptr(), y.data_ptr(), dy.data_ptr(), (int)N, (int)C, fptr(gamma), mean, mean + C, (int)use_batch, (int)relu,
                              dx.data_ptr(), dgamma, dgamma + C, ws.data_ptr(), (size_t)ws_bytes, st(stream)), "btc_bn_relu_bwd_bf16");
   else
@@ -429,9 +402,9 @@ void set_side_stream(int64_t raw_stream, int64_t device_index) {
 // din (n_src, Cin), dw (shape of w); either may come back undefined (None) when not needed.  overlap: wgrad runs on a side
 // stream beside dgrad (fork / join with events, no host sync); every temporary is released after the join has been enqueued,
 // so the caching allocator's stream-ordered reuse stays valid without recordStream.
-std::tuple<OptTensor, OptTensor> conv_bwd_link(const Tensor& features, const Tensor& w, const Tensor& map_fwd, const Tensor& map_bwd,
-                                               const OptTensor& order_bwd, const Tensor& grad_out, bool need_din, bool need_dw, bool overlap,
-                                               bool allow_defer, int64_t stream, int64_t link_in) {
+std::tuple<OptTensor, OptTensor> conv_bwd(const Tensor& features, const Tensor& w, const Tensor& map_fwd, const Tensor& map_bwd,
+                                          const OptTensor& order_bwd, const Tensor& grad_out, bool need_din, bool need_dw, bool overlap,
+                                          bool allow_defer, int64_t stream) {
   const int64_t cin = w.size(-2), cout = w.size(-1), K = map_fwd.size(1), n_res = map_fwd.size(0), n_src = map_bwd.size(0);
   need(grad_out.is_contiguous() && grad_out.scalar_type() == features.scalar_type(), "conv_bwd: grad must be contiguous and of the activation type");
   const bool bf = features.scalar_type() == at::kBFloat16;
@@ -476,27 +449,6 @@ std::tuple<OptTensor, OptTensor> conv_bwd_link(const Tensor& features, const Ten
                                  order, (int)n_src, (int)K, (int)cin, (int)cout, d.data_ptr(), st(stream)), "btc_conv_apply_ordered (dgrad, bf16 operands)");
     } else if (split_operands(grad_out, K, cout, cin, n_src, stream)) {
       Tensor q = q_hold = weights_q(w, K, cin, cout, stream, 3);
-      // the layer in front is a link of a conv -> BatchNorm -> ReLU chain: its BatchNorm's backward statistics in this launch's epilogue
-      BnLink L;
-      if (link_in >= 0 && g_bn_bwd_fuse) {
-        std::lock_guard<std::mutex> lock(g_links_mu);
-        const BnLink& e = g_links[link_in % BN_LINKS];
-        if (e.id == link_in && e.y == features.data_ptr() && e.N == n_src && e.C == cin) L = e;
-      }
-      if (L.id >= 0) {
-        Tensor dparam = at::empty({2, cin}, grad_out.options().dtype(at::kFloat));
-        Tensor fw = fuse_ws_of(grad_out, stream);
-        int fused = 0;
-        chk(btc_conv_dgrad_bn_bwd(pass_dgrad, grad_out.data_ptr(), (long long)grad_out.size(0), q.data_ptr(), (const int32_t*)map_bwd.data_ptr(), order,
-                                  (int)n_src, (int)K, (int)cin, (int)cout, d.data_ptr(), L.x, L.y, L.stats, L.stats + cin, (int)L.relu,
-                                  (float*)dparam.data_ptr(), (float*)dparam.data_ptr() + cin, fw.data_ptr(), st(stream), &fused),
-            "btc_conv_dgrad_bn_bwd");
-        if (fused) {
-          std::lock_guard<std::mutex> lock(g_links_mu);
-          BnLink& e = g_links[link_in % BN_LINKS];
-          if (e.id == link_in) { e.dparam = dparam; e.filled = true; }
-        }
-      } else
       chk(btc_conv_apply_src(pass_dgrad, BTC_OPERANDS_F32_SPLIT, grad_out.data_ptr(), (long long)grad_out.size(0), q.data_ptr(), nullptr, (const int32_t*)map_bwd.data_ptr(),
                                  order, (int)n_src, (int)K, (int)cin, (int)cout, d.data_ptr(), st(stream)), "btc_conv_apply_src (dgrad, split operands)");
     } else
@@ -716,28 +668,14 @@ std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor> rulebook_conv_finish(const st
 // conv -> BatchNorm1d (-> ReLU) as a C++ autograd node: the same three launches as ops.SparseConvBNReLUFunction without the
 // Python Function.apply / ctx bookkeeping per layer (the forward pass is bound by the host's launch rate).  wgrad runs on the
 // backward stream right before dgrad (no side-stream overlap here; Python keeps that variant for the 20 K - 100 K-row layers).
-std::tuple<OptTensor, OptTensor> conv_bwd(const Tensor& features, const Tensor& w, const Tensor& map_fwd, const Tensor& map_bwd,
-                                          const OptTensor& order_bwd, const Tensor& grad_out, bool need_din, bool need_dw, bool overlap,
-                                          bool allow_defer, int64_t stream) {
-  return conv_bwd_link(features, w, map_fwd, map_bwd, order_bwd, grad_out, need_din, need_dw, overlap, allow_defer, stream, -1);
-}
-
 struct ConvBNReLUNode : public torch::autograd::Function<ConvBNReLUNode> {
   static Tensor forward(torch::autograd::AutogradContext* ctx, const Tensor& features, const Tensor& weight, const OptTensor& bias,
                         const Tensor& map_fwd, const Tensor& map_bwd, const OptTensor& order_fwd, const OptTensor& order_bwd,
                         const OptTensor& gamma, const OptTensor& beta, const OptTensor& rm, const OptTensor& rv, const OptTensor& nbt,
                         bool use_batch, double momentum, double eps, bool relu, const Tensor& ws, int64_t ws_bytes, bool overlap,
-                        bool allow_defer, int64_t link_in, int64_t link_out) {
+                        bool allow_defer) {
     const int64_t stream = current_stream();
     auto r = conv_bn_fwd(features, weight, bias, map_fwd, order_fwd, gamma, beta, rm, rv, nbt, use_batch, momentum, eps, relu, ws, ws_bytes, stream);
-    if (link_out >= 0) {   // (what the next layer's data gradient needs of THIS layer's BatchNorm: BnLink)
-      std::lock_guard<std::mutex> lock(g_links_mu);
-      BnLink& e = g_links[link_out % BN_LINKS];
-      e.id = link_out; e.x = std::get<0>(r).data_ptr(); e.y = std::get<1>(r).data_ptr(); e.stats = (const float*)std::get<2>(r).data_ptr();
-      e.N = std::get<0>(r).size(0); e.C = std::get<0>(r).size(1); e.relu = relu; e.filled = false; e.dparam = Tensor();
-    }
-    ctx->saved_data["link_in"] = link_in;
-    ctx->saved_data["link_out"] = link_out;
     const Tensor g = (gamma.has_value() && gamma->defined()) ? *gamma : Tensor();
     const Tensor ob = (order_bwd.has_value() && order_bwd->defined()) ? *order_bwd : Tensor();
     ctx->save_for_backward({features, weight, map_fwd, map_bwd, std::get<0>(r), std::get<1>(r), g, std::get<2>(r), ws, ob});
@@ -761,23 +699,13 @@ struct ConvBNReLUNode : public torch::autograd::Function<ConvBNReLUNode> {
     dy = dy.contiguous();
     OptTensor og;
     if (gamma.defined()) og = gamma;
-    // the consumer's data gradient (the next layer of the chain, which ran a moment ago) may have left this BatchNorm's statistics
-    Tensor have;
-    const int64_t link_out = ctx->saved_data["link_out"].toInt();
-    if (link_out >= 0) {
-      std::lock_guard<std::mutex> lock(g_links_mu);
-      BnLink& e = g_links[link_out % BN_LINKS];
-      if (e.id == link_out && e.filled && e.y == y.data_ptr() && e.dparam.defined() && e.dparam.size(1) == x.size(1)) have = e.dparam;
-      if (e.id == link_out) { e.filled = false; e.dparam = Tensor(); }
-    }
-    if (have.defined()) g_bn_bwd_fuse_hits.fetch_add(1);
-    auto b = bn_bwd(x, y, dy, og, stats, use_batch, relu, ws, ws_bytes, stream, have.defined() ? &have : nullptr);
+    auto b = bn_bwd(x, y, dy, og, stats, use_batch, relu, ws, ws_bytes, stream);
     const Tensor& dx = std::get<0>(b);
     const Tensor& dparam = std::get<1>(b);
     OptTensor order_bwd;
     if (saved[9].defined()) order_bwd = saved[9];
-    auto cb = conv_bwd_link(features, w, map_fwd, map_bwd, order_bwd, dx, ctx->needs_input_grad(0), ctx->needs_input_grad(1),
-                       ctx->saved_data["overlap"].toBool(), ctx->saved_data["allow_defer"].toBool(), stream, ctx->saved_data["link_in"].toInt());
+    auto cb = conv_bwd(features, w, map_fwd, map_bwd, order_bwd, dx, ctx->needs_input_grad(0), ctx->needs_input_grad(1),
+                       ctx->saved_data["overlap"].toBool(), ctx->saved_data["allow_defer"].toBool(), stream);
     Tensor din = std::get<0>(cb).has_value() ? *std::get<0>(cb) : Tensor();
     Tensor dw = std::get<1>(cb).has_value() ? *std::get<1>(cb) : Tensor();
     Tensor db;
@@ -796,7 +724,7 @@ struct ConvBNReLUNode : public torch::autograd::Function<ConvBNReLUNode> {
       dbeta = dparam[1];
     }
     return {din, dw, db, Tensor(), Tensor(), Tensor(), Tensor(), dgamma, dbeta, Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(),
-            Tensor(), Tensor(), Tensor(), Tensor()};
+            Tensor(), Tensor()};
   }
 };
 
@@ -804,7 +732,7 @@ Tensor conv_bn_relu(const Tensor& features, const Tensor& weight, const OptTenso
                     const OptTensor& order_fwd, const OptTensor& order_bwd, const OptTensor& gamma, const OptTensor& beta, const OptTensor& rm, const OptTensor& rv, const OptTensor& nbt, bool use_batch,
                     double momentum, double eps, bool relu, const Tensor& ws, int64_t ws_bytes, bool overlap, bool allow_defer) {
   return ConvBNReLUNode::apply(features, weight, bias, map_fwd, map_bwd, order_fwd, order_bwd, gamma, beta, rm, rv, nbt, use_batch, momentum, eps, relu, ws, ws_bytes,
-                               overlap, allow_defer, (int64_t)-1, (int64_t)-1);
+                               overlap, allow_defer);
 }
 
 // every rulebook of a chain of sparse layers from the input coordinates alone (BtcHotPath.prepare runs this in a worker thread
@@ -1084,15 +1012,9 @@ Tensor conv_bn_relu_chain(const Tensor& features, const std::vector<Tensor>& wei
            ws_bytes.size() == L && overlaps.size() == L && allow_defers.size() == L,
        "conv_bn_relu_chain: per-layer argument lists differ in length");
   Tensor x = features;
-  // links (BnLink): inside the chain layer i's output has layer i + 1 as its only consumer
-  const bool links = g_bn_bwd_fuse && at::GradMode::is_enabled() && features.scalar_type() == at::kFloat;
-  int64_t link_in = -1;
-  for (size_t i = 0; i < L; ++i) {
-    const int64_t link_out = (links && i + 1 < L && use_batch[i]) ? g_next_link.fetch_add(1) : (int64_t)-1;
+  for (size_t i = 0; i < L; ++i)
     x = ConvBNReLUNode::apply(x, weights[i], biases[i], map_fwd[i], map_bwd[i], order_fwd[i], order_bwd[i], gammas[i], betas[i], rms[i], rvs[i], nbts[i], use_batch[i],
-                              momenta[i], epss[i], relus[i], ws, ws_bytes[i], overlaps[i], allow_defers[i], link_in, link_out);
-    link_in = link_out;
-  }
+                              momenta[i], epss[i], relus[i], ws, ws_bytes[i], overlaps[i], allow_defers[i]);
   return x;
 }
 
@@ -1204,8 +1126,6 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("clear_grads_pl", &clear_grads_pl);
   m.def("join_wgrad", &join_wgrad, py::call_guard<py::gil_scoped_release>());
   m.def("set_defer_wgrad_join", &set_defer_wgrad_join);
-  m.def("set_bn_bwd_fuse", &set_bn_bwd_fuse);
-  m.def("bn_bwd_fuse_hits", &bn_bwd_fuse_hits);
   m.def("set_side_stream", &set_side_stream);
   m.def("rulebook_subm", &rulebook_subm, py::call_guard<py::gil_scoped_release>());
   m.def("rulebook_conv", &rulebook_conv, py::call_guard<py::gil_scoped_release>());

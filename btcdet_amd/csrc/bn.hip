@@ -494,16 +494,14 @@ static int bn_fwd_impl(const float* x, int N, int C, const float* gamma, const f
 template <bool BF>
 static int bn_bwd_impl(const float* x, const float* y, const float* dy, int N, int C, const float* gamma, const float* save_mean,
                                const float* save_rstd, int training, int relu, float* dx, float* dgamma, float* dbeta, void* ws,
-                               size_t ws_bytes, void* stream_, bool have_stats = false) {
-  // have_stats: dgamma / dbeta were produced by the epilogue of the data-gradient launch that made dy (bn_fuse.h, bwd): apply only
+                               size_t ws_bytes, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   BTC_CHECK_ARG(N >= 1 && C >= 1, "btc_bn_relu_bwd: empty input");
-  BTC_CHECK_ARG(have_stats || ws_bytes >= btc_bn_ws_bytes(C), "btc_bn_relu_bwd: workspace too small");
+  BTC_CHECK_ARG(ws_bytes >= btc_bn_ws_bytes(C), "btc_bn_relu_bwd: workspace too small");
   int32_t* counter = (int32_t*)ws;
   double* partial = (double*)((char*)ws + 256);
   BnShape S = bn_shape(N, C);
-  if (have_stats) {
-  } else if ((C & 3) == 0) {
+  if ((C & 3) == 0) {
     const BnShape SV = bn_shape(N, C >> 2);
     const int g = bn_grid_bytes((long long)N * C * (BF ? 6 : 12), BTC_TUNE_BN_BWD_KB, 128);
     bn_bwd_stats<BF, true><<<g, BN_T, 0, stream>>>(x, y, dy, save_mean, save_rstd, S, SV, relu, partial, counter, dgamma, dbeta);
@@ -596,7 +594,6 @@ extern "C" int btc_conv_bn_relu_fwd_src(int operands, const void* src, long long
     bn.mean_out = save_mean; bn.rstd_out = save_rstd;
     bn.running_mean = running_mean; bn.running_var = running_var; bn.num_batches = num_batches_tracked;
     bn.momentum = momentum; bn.eps = eps; bn.N = n_rows; bn.C = Cout; bn.nslots = btc_bn_fuse_nslots(n_rows);
-    bn.bwd = bn.relu = 0; bn.bx = bn.by = nullptr; bn.bmean = bn.brstd = nullptr; bn.dgamma = bn.dbeta = nullptr;
     int rc = btc_conv_fwd_stats(operands, src, src_rows, (const float*)W, bias, nbr, order, n_rows, K, Cin, Cout, x, bn, (hipStream_t)stream, &fused);
     if (rc) return rc;
   } else {
@@ -608,40 +605,4 @@ extern "C" int btc_conv_bn_relu_fwd_src(int operands, const void* src, long long
                              (float*)y, save_mean, save_rstd, ws, ws_bytes, stream, fused != 0);
   return bn_fwd_impl<false>((const float*)x, n_rows, Cout, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, 1, relu,
                             (float*)y, save_mean, save_rstd, ws, ws_bytes, stream, fused != 0);
-}
-
-// ---- data gradient of a sparse conv + the BACKWARD statistics of the BatchNorm (+ ReLU) in front of it, in the epilogue (bn_fuse.h) ------
-extern "C" int btc_conv_dgrad_bn_bwd(int pass, const void* dout, long long dout_rows, const void* Wq, const int32_t* nbr, const int32_t* order,
-                                     int n_rows, int K, int Cin, int Cout, void* din, const void* bn_x, const void* bn_y, const float* save_mean,
-                                     const float* save_rstd, int relu, float* dgamma, float* dbeta, void* fuse_ws, void* stream, int* fused) {
-  BTC_CHECK_ARG(pass == BTC_PASS_DGRAD || pass == BTC_PASS_DGRAD_MIRROR, "btc_conv_dgrad_bn_bwd: pass=%d", pass);
-  BTC_CHECK_ARG(fused != nullptr && bn_x && bn_y && save_mean && save_rstd && dgamma && dbeta, "btc_conv_dgrad_bn_bwd: NULL argument");
-  *fused = 0;
-  // the split-operand kernel and its slab reduction have the epilogue; 64-column float4 reads of x / y / mean / rstd in split_reduce and
-  // 16-column tiles in conv_apply_s both want Cin % 32 == 0, which btc_conv_split_supported asks anyway
-  if (fuse_ws && n_rows >= 1 && Cin <= BN_FUSE_CMAX && btc_tune_get(BTC_TUNE_BN_FUSE) != 1 && btc_tune_get(BTC_TUNE_BN_BWD_FUSE) != 1 &&
-      btc_conv_split_supported(K, Cout, Cin)) {
-    BTC_CHECK_ARG(dout_rows >= 0 && dout_rows * Cout * 4 < 0xFFFFFF00LL, "btc_conv_dgrad_bn_bwd: a source of %lld rows x %d channels is past the 32-bit "
-                  "gather offsets of the split-operand kernel", dout_rows, Cout);
-    BnFuse bn = btc_bn_fuse_none();
-    bn.counter = (int32_t*)fuse_ws;
-    bn.slots = (double*)((char*)fuse_ws + 256);
-    bn.N = n_rows; bn.C = Cin; bn.nslots = btc_bn_fuse_nslots(n_rows);
-    bn.bwd = 1; bn.relu = relu; bn.bx = bn_x; bn.by = bn_y; bn.bmean = save_mean; bn.brstd = save_rstd; bn.dgamma = dgamma; bn.dbeta = dbeta;
-    const int rc = btc_apply_split((const float*)dout, Wq, nullptr, nbr, order, n_rows, K, /*Cred=*/Cout, /*Cres=*/Cin, (float*)din, (hipStream_t)stream,
-                                   pass == BTC_PASS_DGRAD_MIRROR, &bn);
-    if (rc == BTC_OK) *fused = 1;
-    return rc;
-  }
-  return btc_conv_apply_src(pass, BTC_OPERANDS_F32_SPLIT, dout, dout_rows, Wq, nullptr, nbr, order, n_rows, K, Cin, Cout, din, stream);
-}
-
-extern "C" int btc_bn_relu_bwd_apply(int bf16_act, const void* x, const void* y, const void* dy, int N, int C, const float* gamma, const float* save_mean,
-                                     const float* save_rstd, int training, int relu, void* dx, const float* dgamma, const float* dbeta, void* stream) {
-  BTC_CHECK_ARG(dgamma && dbeta, "btc_bn_relu_bwd_apply: the statistics are the caller's to give");
-  if (bf16_act)
-    return bn_bwd_impl<true>((const float*)x, (const float*)y, (const float*)dy, N, C, gamma, save_mean, save_rstd, training, relu, (float*)dx,
-                             (float*)dgamma, (float*)dbeta, nullptr, 0, stream, true);
-  return bn_bwd_impl<false>((const float*)x, (const float*)y, (const float*)dy, N, C, gamma, save_mean, save_rstd, training, relu, (float*)dx,
-                            (float*)dgamma, (float*)dbeta, nullptr, 0, stream, true);
 }

@@ -30,20 +30,6 @@ struct BnFuse {
   float momentum, eps;
   int N, C;
   int nslots;           // power of two, 32 .. BN_FUSE_SLOTS_MAX
-  // Round 6, the BACKWARD statistics of the BatchNorm (+ ReLU) IN FRONT of a data-gradient launch (bwd != 0).  The launch's result is
-  // dL/dy of that BatchNorm, y being the launch's own result rows' forward values; the layer in front needs sum(g) and sum(g xhat) with
-  // g = dy (y > 0 under ReLU), xhat = (x - mean) rstd -- bn_bwd_stats' arithmetic, value for value -- before it can turn dy into dx.
-  // Gathered here, in the epilogue that has dy in registers (x and y tiles are read beside the store), the separate statistics launch of
-  // the layer in front (27 a step, each at its latency floor behind the producer's tail) disappears for every layer whose result has
-  // this launch as its only consumer.  Slots: [.][0] sum(g), [.][1] sum(g xhat); the last arriver publishes dbeta / dgamma.
-  int bwd;
-  int relu;
-  const void* bx;       // (N, C) conv result the BatchNorm normalised (fp32; bf16 under bf16 activations: see the callers)
-  const void* by;       // (N, C) its output
-  const float* bmean;   // [C] saved batch statistics
-  const float* brstd;
-  float* dgamma;        // [C] out
-  float* dbeta;         // [C] out
 };
 
 static inline size_t btc_bn_fuse_bytes() { return 256 + (size_t)BN_FUSE_SLOTS_MAX * 2 * BN_FUSE_CMAX * sizeof(double); }
@@ -58,7 +44,6 @@ static inline BnFuse btc_bn_fuse_none() {
   BnFuse b;
   b.slots = nullptr; b.counter = nullptr; b.mean_out = b.rstd_out = b.running_mean = b.running_var = nullptr; b.num_batches = nullptr;
   b.momentum = b.eps = 0.f; b.N = b.C = 0; b.nslots = 32;
-  b.bwd = b.relu = 0; b.bx = b.by = nullptr; b.bmean = b.brstd = nullptr; b.dgamma = b.dbeta = nullptr;
   return b;
 }
 
@@ -89,40 +74,6 @@ __device__ __forceinline__ void bn_fuse_wave(const BnFuse& bn, const float (&v)[
   }
 }
 
-// the same for the backward statistics (bn.bwd): v = the data gradient as stored, rows[r] the result row of register r (< 0: none);
-// fp32 activations
-template <int NT>
-__device__ __forceinline__ void bn_fuse_wave_bwd(const BnFuse& bn, const float (&v)[NT][4], const int (&rows)[4], int col0, int slot) {
-  const int lane = threadIdx.x & 63;
-  const float* __restrict__ X = (const float*)bn.bx;
-  const float* __restrict__ Y = (const float*)bn.by;
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    const int col = col0 + nt * 16 + (lane & 15);
-    const bool cok = col < bn.C;
-    const float m = cok ? bn.bmean[col] : 0.f, rs = cok ? bn.brstd[col] : 0.f;
-    double s1 = 0.0, s2 = 0.0;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      if (rows[r] >= 0 && cok) {
-        const size_t i = (size_t)rows[r] * bn.C + col;
-        const float g = (bn.relu && !(Y[i] > 0.f)) ? 0.f : v[nt][r];
-        s1 += (double)g;
-        s2 += (double)g * ((X[i] - m) * rs);
-      }
-    }
-    s1 += __shfl_xor(s1, 16, 64);
-    s2 += __shfl_xor(s2, 16, 64);
-    s1 += __shfl_xor(s1, 32, 64);
-    s2 += __shfl_xor(s2, 32, 64);
-    if (lane < 16 && cok) {
-      double* p = bn.slots + ((size_t)slot * 2) * BN_FUSE_CMAX + col;
-      unsafeAtomicAdd(p, s1);
-      unsafeAtomicAdd(p + BN_FUSE_CMAX, s2);
-    }
-  }
-}
-
 // end of the kernel, every thread of every workgroup: the last workgroup to arrive turns the slots into mean / rstd.
 // s_flag: one int of the workgroup's LDS that nobody needs any more (the kernels run at the 160 KB dynamic limit: no static LDS here);
 // s_part: blockDim.x * 2 doubles of dead LDS (or nullptr): with it the slot sums of a channel are shared by blockDim.x / C threads
@@ -145,11 +96,6 @@ __device__ __forceinline__ void bn_fuse_finish(const BnFuse& bn, int* s_flag, do
   if (tid == 0) btc_ticket_acquire();
   __syncthreads();
   auto publish = [&](int c, double a, double b) {
-    if (bn.bwd) {   // backward statistics: the sums themselves (bn_bwd_stats' last block)
-      bn.dbeta[c] = (float)a;
-      bn.dgamma[c] = (float)b;
-      return;
-    }
     const double mean = a / bn.N;
     double var = b / bn.N - mean * mean;  // biased, as F.batch_norm normalises with
     if (var < 0.0) var = 0.0;
@@ -200,7 +146,7 @@ __device__ __forceinline__ void bn_fuse_finish(const BnFuse& bn, int* s_flag, do
     }
   }
   if (tid == 0) {
-    if (bn.num_batches && !bn.bwd) *bn.num_batches += 1;
+    if (bn.num_batches) *bn.num_batches += 1;
     __hip_atomic_store(bn.counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }

@@ -222,7 +222,6 @@ __global__ __launch_bounds__(64 * (WR * WC + LW)) void conv_apply_s(const float*
   static_assert((S_STAGES - 2) * NPI <= 63, "vmcnt is a 6-bit counter");
   float vals[NTW][4];
   bool valid[4];
-  int rowid[4] = {-1, -1, -1, -1};
   if (LW > 0 && wave >= NW) {
     // ---- loader waves: wait for an item's pieces, meet the product waves at the item's barrier, issue the item S - 1 ahead
     // (two separate branches, so that the loaders' address registers and the product waves' accumulators share the register file)
@@ -345,7 +344,6 @@ __global__ __launch_bounds__(64 * (WR * WC + LW)) void conv_apply_s(const float*
       for (int r = 0; r < 4; ++r) {
         const int row = s_row[wr * 16 + kg * 4 + r];
         valid[r] = row >= 0;
-        rowid[r] = row;
         const float sum = acc[nt][r] + (accm[nt][r] + accs[nt][r]);
         const float v = bias ? (sum + bv0) : sum;
         if (row >= 0) out[(size_t)row * Cres + col] = v;
@@ -354,10 +352,7 @@ __global__ __launch_bounds__(64 * (WR * WC + LW)) void conv_apply_s(const float*
     }
   }
   if (bn.slots) {   // batch statistics for the BatchNorm behind this layer (bn_fuse.h)
-    if (computes) {
-      if (bn.bwd) bn_fuse_wave_bwd<NTW>(bn, vals, rowid, n0 + wc * NTW * 16, (int)((bx * WR + wr) & (bn.nslots - 1)));
-      else bn_fuse_wave<NTW>(bn, vals, valid, n0 + wc * NTW * 16, (int)((bx * WR + wr) & (bn.nslots - 1)));
-    }
+    if (computes) bn_fuse_wave<NTW>(bn, vals, valid, n0 + wc * NTW * 16, (int)((bx * WR + wr) & (bn.nslots - 1)));
     bn_fuse_finish(bn, (int*)smem, (double*)(smem + 16));
   }
 }
@@ -405,22 +400,10 @@ __global__ __launch_bounds__(256) void split_reduce(const float* __restrict__ sl
       for (int z = 1; z < Z; ++z) v += *(const f32x4*)(p + z * slab);
       if (bias) v += b;
       *(f32x4*)(out + (size_t)row * Cres + col) = v;
-      if (bn.slots && bn.bwd) {   // backward statistics of the BatchNorm in front of a z-split data gradient (bn_fuse.h)
-        const size_t i = (size_t)row * Cres + col;
-        const f32x4 xv = *(const f32x4*)((const float*)bn.bx + i), yv = *(const f32x4*)((const float*)bn.by + i);
-        const f32x4 mv = *(const f32x4*)(bn.bmean + col), rv = *(const f32x4*)(bn.brstd + col);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float g = (bn.relu && !(yv[e] > 0.f)) ? 0.f : v[e];
-          s1[e] += (double)g;
-          s2[e] += (double)g * ((xv[e] - mv[e]) * rv[e]);
-        }
-      } else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          s1[e] += (double)v[e];
-          s2[e] += (double)v[e] * (double)v[e];
-        }
+      for (int e = 0; e < 4; ++e) {
+        s1[e] += (double)v[e];
+        s2[e] += (double)v[e] * (double)v[e];
       }
     }
   }

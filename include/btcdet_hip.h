@@ -73,7 +73,6 @@ int btc_version(void);
 #define BTC_TUNE_RB_MARK_MULTI 19 /* chain rulebooks: 1 = mark every level by its own launch (rb_mark / rb_mark_b) instead of one launch for the leading run of strided conv layers (cross-check: same levels) */
 #define BTC_TUNE_SPLIT_PAIR 21 /* split-operand kernel and bf16-operand kernel, 32-channel reductions: 0 = built-in policy, 1 = one offset per item, 2 = two offsets per 64-channel item wherever a tile shape has the instance (same bits) */
 #define BTC_TUNE_WGRAD_NARROW 22 /* weight gradient of a layer with <= 8 result channels walked over its input rows (conv_wgrad_n.hip; needs the backward map or nbr_in == nbr_out): 0 = where supported, 1 = never */
-#define BTC_TUNE_BN_BWD_FUSE 23 /* btc_conv_dgrad_bn_bwd: 1 = never gather the BatchNorm's backward statistics in the data gradient's epilogue (the layer in front runs both launches of btc_bn_relu_bwd) */
 #define BTC_TUNE_APPLY_DEBUG 3 /* timing experiments only (WRONG results): 1 = no MFMA phase, 2 = no loads in the main loop */
 int btc_tune_set(int key, int value);
 int btc_tune_value(int key);   /* current value of a key (0 = built-in policy) */
@@ -522,20 +521,6 @@ int btc_conv_bn_relu_fwd_src(int operands, const void* src, long long src_rows, 
                          int n_rows, int K, int Cin, int Cout, void* x, const float* gamma, const float* beta, float* running_mean,
                          float* running_var, long long* num_batches_tracked, float momentum, float eps, int relu, void* y,
                          float* save_mean, float* save_rstd, void* ws, size_t ws_bytes, void* fuse_ws, void* stream);
-/* The other direction (round 6): the data gradient of a sparse conv (BTC_OPERANDS_F32_SPLIT: Wq = the planes of btc_weights_split3 for
- * dgrad; pass = BTC_PASS_DGRAD or BTC_PASS_DGRAD_MIRROR; dout has dout_rows rows) whose result din (n_rows, Cin) is dL/dy of a
- * BatchNorm1d (+ ReLU) -- the post_act_block IN FRONT of this conv in the reference's chain (spconv_backbone.py:33-43), y being this
- * conv's own input.  The epilogue gathers that BatchNorm's backward statistics, dbeta[c] = sum_r g, dgamma[c] = sum_r g xhat with
- * g = din (y > 0 under relu), xhat = (bn_x - save_mean) save_rstd -- value for value what btc_bn_relu_bwd's first launch computes -- so
- * the layer in front runs btc_bn_relu_bwd_apply only.  Valid only when din is the WHOLE gradient of y (this conv is y's only consumer).
- * *fused = 1: dgamma / dbeta are written; 0: the launch had no such epilogue (fuse_ws NULL, BTC_TUNE_BN_BWD_FUSE / BTC_TUNE_BN_FUSE = 1,
- * channel counts the split-operand kernel does not take) and din alone was computed.  fuse_ws as btc_conv_bn_relu_fwd's. */
-int btc_conv_dgrad_bn_bwd(int pass, const void* dout, long long dout_rows, const void* Wq, const int32_t* nbr, const int32_t* order,
-                          int n_rows, int K, int Cin, int Cout, void* din, const void* bn_x, const void* bn_y, const float* save_mean,
-                          const float* save_rstd, int relu, float* dgamma, float* dbeta, void* fuse_ws, void* stream, int* fused);
-/* btc_bn_relu_bwd[_bf16]'s second launch alone: dx from dy and GIVEN dgamma / dbeta (no workspace) */
-int btc_bn_relu_bwd_apply(int bf16_act, const void* x, const void* y, const void* dy, int N, int C, const float* gamma, const float* save_mean,
-                          const float* save_rstd, int training, int relu, void* dx, const float* dgamma, const float* dbeta, void* stream);
 int btc_col_sum(const float* x, int N, int C, float* out, void* ws, size_t ws_bytes, void* stream);
 int btc_col_sum_bf16(const void* x, int N, int C, float* out, void* ws, size_t ws_bytes, void* stream);
 
