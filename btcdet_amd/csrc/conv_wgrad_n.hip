@@ -173,7 +173,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_wgrad_n(const void* __restric
 // a layer with a narrow RESULT (Cout <= 8: walked over its input rows, Cin a multiple of 16) or a narrow INPUT (Cin <= 8: walked over its
 // output rows, Cout a multiple of 16): -> 1 / 2, or 0
 int btc_wgrad_n_kind(int K, int Cin, int Cout) {
-  if (K < 1 || Cin < 1 || Cout < 1) return 0;
+  if (K < 1 || K > 64 || Cin < 1 || Cout < 1) return 0;   // (K <= 64: a dead row's map offsets, N_RECORDS + 4 k', must stay below 2^32)
   if (Cout <= 8 && K * Cout <= 16 * NTL_MAX && Cin >= 16 && (Cin & 15) == 0) return 1;
   if (Cin <= 8 && K * Cin <= 16 * NTL_MAX && Cout >= 16 && (Cout & 15) == 0) return 2;
   return 0;

@@ -53,7 +53,7 @@ def _case(rng, cin, cout, kind, n_vox, k=(3, 3, 3)):
     shape, B = ((6, 30, 28) if kind == "transpose" else (12, 48, 44)), 2
     idx = rand_indices(rng, n_vox, B, shape)
     s = (1, 1, 1) if kind == "subm" else (2, 2, 2)
-    p = (1, 1, 1) if k == (3, 3, 3) else (0, 0, 0)
+    p = tuple(kk // 2 for kk in k) if kind == "subm" else ((1, 1, 1) if k == (3, 3, 3) else (0, 0, 0))
     (o_idx, o_out, o_in, o_sh), rb = _rb_both(idx, B, shape, k, s, p, (1, 1, 1), kind)
     feat = torch.from_numpy(rng.standard_normal((idx.shape[0], cin)).astype(np.float32)).to(dev())
     dout = torch.from_numpy(rng.standard_normal((o_idx.shape[0], cout)).astype(np.float32)).to(dev())
@@ -163,6 +163,17 @@ def test_everything_else_runs_what_it_ran_before(cin, cout, kind, n_vox, why):
     got = _wgrad(feat, dout, rb, cin, cout)
     off = _tuned([(N_KEY, 1)], lambda: _wgrad(feat, dout, rb, cin, cout))
     assert torch.equal(got, off), why
+
+
+def test_a_125_offset_kernel_stays_on_the_kernels_of_before():
+    """K <= 64 (a row past the end is addressed as N_RECORDS + 4 k': more offsets would wrap the 32-bit offset)"""
+    rng = np.random.default_rng(9)
+    rb, feat, dout = _case(rng, 16, 1, "subm", 6000, k=(5, 5, 5))
+    assert rb.nbr_out.shape[1] == 125
+    got = _wgrad(feat, dout, rb, 16, 1)
+    assert torch.equal(got, _tuned([(N_KEY, 1)], lambda: _wgrad(feat, dout, rb, 16, 1)))
+    ref = _ref64(feat, dout, rb.nbr_out, 125, 16, 1)
+    assert float((got.double() - ref).abs().max()) <= 1e-4 * float(ref.abs().max())
 
 
 def test_without_a_backward_map_the_output_rows_are_walked():
