@@ -12,7 +12,7 @@
 //     G[j][c] = dy[map[j][k']][co] that exists only in registers -- 135 columns for 27 x 5, nine 16-column tiles, nothing padded per
 //     offset -- so the whole dW is a (Cin x rows) . (rows x K Cout) product on `v_mfma_f32_16x16x4_f32` (exact fp32 products, fp32
 //     accumulation: the arithmetic of the fp32-pipe kernels, no split);
-//   * no LDS and no barrier in the walk: a wave owns every (8 S)-th group of 4 rows, keeps its 16 MT x 144 block of dW in accumulators,
+//   * no LDS and no barrier in the walk: a wave owns every (4 S)-th group of 4 rows, keeps its 16 MT x 16 NTL block of dW in accumulators,
 //     has the map values of the groups up to five steps ahead and the operand values of the next three groups in flight during a group's
 //     products (51 loads in flight per wave: one wave a SIMD measured faster than two).
 // A layer with a narrow INPUT (the 4- / 6-channel first layers: 52 us for 36 K rows on the fp32-pipe kernel) is the same walk with the roles
@@ -29,7 +29,6 @@ namespace {
 constexpr int NTL_MAX = 11;                 // 16-column tiles of the (k', narrow channel) dimension: 9 (K Cn <= 144) or 11 (<= 176) per instance
 constexpr int NW = 4;                       // waves per workgroup; one slab per workgroup (8 waves on 256 workgroups measured 57 against 48 us)
 #define N_RECORDS 0xFFFFFF00u
-#define N_ABSENT 0xFFFFFFF0u
 
 template <int MT, int NTL, bool BF>
 __global__ __launch_bounds__(NW * 64, 2) void conv_wgrad_n(const void* __restrict__ xsrc, const void* __restrict__ dysrc, const int32_t* __restrict__ map,
