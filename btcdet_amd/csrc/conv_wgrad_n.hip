@@ -73,8 +73,8 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_wgrad_n(const void* __restric
 
   // a group = 4 consecutive rows; lane group g4 holds row 4 g + g4 of both operands (the reduction index of the 16x16x4 product).
   // Every load is a raw buffer load and every "not there" an out-of-range offset (zeros come back, nothing is fetched, no branch):
-  //   a row past the end  -> its map row starts at N_RECORDS (K <= 64: every column of it is out of range), its x offsets are N_ABSENT,
-  //                          its dy offsets are or-ed with all ones;
+  //   a row past the end  -> its map row starts at N_RECORDS (K <= 64: every column of it is out of range), its x and dy offsets are
+  //                          or-ed with all ones;
   //   an absent neighbour -> map value -1: its sign, smeared over the word, is or-ed into the dy offset.
   // So the walk has no tail handling: a group past the end multiplies zeros.
   // Pipeline: the map values of group i are requested PM steps ahead of its products, its operand values PO steps ahead (from the map
